@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — MPPI iterations/s of the HIP rollout-and-reduce engine (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" is one pass of the optimisation-loop body (sample -> K x T rollout -> baseline/normExp -> weighted reduction,
+mean <- u*) with x0 and the control mean already resident in HBM.  Workload at every N: Cartpole
+(CartpoleDynamics + CartpoleQuadraticCost), K = 16384 rollouts PER GPU, T = 100, fp32, Philox noise drawn in the kernel.
+N > 1 is weak scaling: rank r owns rollouts [r*K, (r+1)*K) of a K*N-rollout problem and the ranks exchange one
+(T*C+4)-float record per iteration (RCCL all-gather) — value counts K-rollout iteration units over all ranks.
+
+roofline: algorithmic bytes of the dominant kernel (rolloutKernel) per launch, B_alg = 4*(2*K*T*C + 2*K + 2*T*C)
+(SURVEY.md §8d), divided by its average duration measured with HIP events on the engine's own stream.
+cpu_baseline: the CPU oracle (a port of the reference's CPU path) timed on this box's host cores on the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+K_PER_GPU = 16384
+T = 100
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(cfg, budget_s=12.0):
+    """oracle iterations/s on the host cores, bounded sample (never the thing shipped or measured as `value`)"""
+    import numpy as np
+    import pyoracle as po
+    from common import make_oracle
+    o = make_oracle(cfg)
+    K, Tn, C = cfg["K"], cfg["T"], o.C
+    eps = po.philox_normal(42, 0, K, Tn, C)
+    mean = np.zeros((1, Tn, C), np.float32)
+    threads = max(1, min(po.max_threads(), os.cpu_count() or 1))
+    out = {}
+    for label, th in (("all", threads), ("one", 1)):
+        o.time_iterations(cfg["x0"], mean, eps, 1, th)  # warm-up
+        t1 = o.time_iterations(cfg["x0"], mean, eps, 1, th)
+        n = max(1, int(budget_s / 2 / max(t1, 1e-4)))
+        n = min(n, 400)
+        tt = o.time_iterations(cfg["x0"], mean, eps, n, th)
+        out[label] = (n / tt, n, th)
+    v, n, th = out["all"]
+    return {
+        "value": round(v, 3), "unit": "MPPI iters/s", "cores": th, "kind": "port",
+        "sample": "%d iterations of the same workload (Cartpole K=%d T=%d, one optimisation-loop body each) with the "
+                  "rollouts spread over %d OpenMP threads" % (n, K, Tn, th),
+        "value_1core": round(out["one"][0], 3),
+        "sample_1core": "%d iterations, single thread (the reference's CPU path is single-threaded)" % out["one"][1],
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import mppi_generic_amd as m
+    from common import cartpole_cfg, make_engine
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    assert world == n_gpus or (world == 1 and n_gpus == 1), "launch with torch.distributed.run for --gpus > 1"
+    assert torch.cuda.is_available(), "bench.py needs a GPU; the product has no CPU path"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = cartpole_cfg(K=K_PER_GPU * world, T=T)
+    eng = make_engine(cfg, device=local_rank, rank=rank, world_size=world)
+    exchange = "none"
+    if world > 1:
+        import ctypes as C
+        lib = m.load_library()
+        uid = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            nb = C.c_size_t()
+            st = lib.mppi_rccl_unique_id(buf, 128, C.byref(nb))
+            uid[0] = bytes(buf.raw) if st == 0 else None
+        dist.broadcast_object_list(uid, src=0)
+        assert uid[0] is not None, "could not create an RCCL unique id"
+        eng.commInitRccl(uid[0])
+        exchange = "rccl all-gather of %d floats per rank per iteration" % eng.exchangeBuffers()[2]
+
+    x0 = cfg["x0"]
+    eng.uploadState(x0)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.optimize(args.warmup, True)
+    barrier()
+    t0 = time.perf_counter()
+    eng.optimize(args.steps, True)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ok = bool(np.isfinite(eng.getOptimalControlSeq()).all())
+
+    # dominant-kernel duration with HIP events on the engine's stream (separate, untimed pass)
+    n_ev = min(200, max(20, args.steps))
+    ms_total, ms_roll = eng.timeIterations(n_ev)
+    C_dim = eng.CONTROL_DIM
+    b_alg = 4.0 * (2.0 * K_PER_GPU * T * C_dim + 2.0 * K_PER_GPU + 2.0 * T * C_dim)
+    roll_us = ms_roll / n_ev * 1e3
+    achieved = b_alg / (roll_us * 1e-6) / 1e9
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        out = {
+            "metric": "MPPI iters/sec (KxT rollouts)", "value": round(value, 3), "unit": "MPPI iters/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "Cartpole (CartpoleDynamics + CartpoleQuadraticCost, examples/cartpole_example.cu config) "
+                            "VanillaMPPI optimisation iteration, K=16384 rollouts per GPU, T=100, dt=0.02, lambda=0.25, "
+                            "sigma=5, Philox noise fused in the rollout kernel",
+                "rollouts_per_gpu": K_PER_GPU, "global_rollouts": K_PER_GPU * world, "num_timesteps": T,
+                "parallelism": "K-sharded x%d" % world, "exchange": exchange,
+                "unit_definition": "one optimisation-loop body over K=16384 rollouts; value sums the units of all ranks",
+            },
+            "finite": ok,
+            "roofline": {
+                "bound": "hbm", "kernel": "rolloutKernel<CartpoleDynamics,CartpoleQuadraticCost,Gaussian,64,1,1>",
+                "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "algorithmic_bytes_per_launch": b_alg, "avg_kernel_us": round(roll_us, 3),
+                "avg_iteration_us_event_timed": round(ms_total / n_ev * 1e3, 3),
+                "note": "latency-bound: T=100 dependent Euler steps per rollout, one wave per CU at K=16384",
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cartpole_cfg(K=K_PER_GPU, T=T))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,260 @@
+/**
+ * mppi_amd.h — C ABI of the MI355X-native MPPI rollout-and-reduce engine (libmppi_amd.so).
+ *
+ * The reference (ACDSLab/MPPI-Generic) has no C ABI: its boundary is a compile-time template contract, and its only
+ * binary form is explicit instantiation of controller templates into shared libraries
+ * (reference: src/controllers/cartpole/cartpole_mppi.cu:30-42, src/controllers/autorally/autorally_mppi.cu:10-11,
+ * include/mppi/instantiations/).  This header is the C-level equivalent of those instantiations: every entry point
+ * names the reference interface it stands in for (paths relative to the reference's include/mppi/).  The templated
+ * Dynamics / Cost / SamplingDistribution plugin contract itself is in include/mppi_amd/plugin/ and
+ * include/mppi_amd/sampling_distributions/; a model is added by writing the plugin and registering one instantiation
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  Host arrays are caller-owned, row-major, last index fastest:
+ *      control sequence u[T][C] (== the reference's Eigen control_trajectory, C x T column-major, controller.cuh:96),
+ *      state sequence x[T][S], initial state x0[S] (Tube / RMPPI: see each call), noise eps[K][T][C], costs[D][K].
+ *  - Every call returns an mppi_status; nothing exit()s or throws across the boundary
+ *    (reference: HANDLE_ERROR -> exit, utils/gpu_err_chk.cuh:32-40; launch-shape checks -> exit, core/mppi_common.cu:
+ *    1266-1277, 1305-1310; shared-memory overflow -> std::runtime_error, controllers/MPPI/mppi_controller.cu:64-76).
+ *    mppi_last_error() returns the message of the last failing call on that handle.
+ *  - One call in flight per handle (the reference's controllers are single-caller too, core/base_plant.hpp:398-428);
+ *    handles are independent.  A handle owns its device buffers and, unless given one, its HIP stream.
+ *  - The library never falls back to a CPU path: without a usable HIP device mppi_create fails with MPPI_ERR_NO_DEVICE.
+ */
+#ifndef MPPI_AMD_H_
+#define MPPI_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPPI_AMD_VERSION_MAJOR 0
+#define MPPI_AMD_VERSION_MINOR 1
+
+typedef struct mppi_handle_s* mppi_handle;
+
+typedef enum mppi_status
+{
+  MPPI_OK = 0,
+  MPPI_ERR_INVALID_ARG = 1,
+  MPPI_ERR_UNKNOWN_MODEL = 2,
+  MPPI_ERR_NO_DEVICE = 3,
+  MPPI_ERR_HIP = 4,           /* a HIP runtime call failed; message in mppi_last_error */
+  MPPI_ERR_LAUNCH_SHAPE = 5,  /* unsupported block shape for this instantiation (mppi_common.cu:1266-1277, 1305-1310) */
+  MPPI_ERR_LDS_OVERFLOW = 6,  /* LDS request exceeds 160 KiB/CU (mppi_controller.cu:64-76 runtime_error) */
+  MPPI_ERR_STATE = 7,         /* call not valid in the handle's current state / configuration */
+  MPPI_ERR_NAN = 8,           /* non-finite value in the resulting control (base_plant.hpp:515-535 exit(-1)) */
+  MPPI_ERR_COMM = 9,          /* RCCL failure */
+  MPPI_ERR_UNSUPPORTED = 10
+} mppi_status;
+
+/** which controller loop runs on top of the kernels */
+typedef enum mppi_controller_kind
+{
+  MPPI_CONTROLLER_VANILLA = 0, /* controllers/MPPI/mppi_controller.cu:151-241 */
+  MPPI_CONTROLLER_TUBE = 1,    /* controllers/Tube-MPPI/tube_mppi_controller.cu:157-299 (two systems per launch) */
+  MPPI_CONTROLLER_ROBUST = 2,  /* controllers/R-MPPI/robust_mppi_controller.cu:635-755 */
+  MPPI_CONTROLLER_COLORED = 3  /* controllers/ColoredMPPI (vanilla loop + colored-noise sampler) */
+} mppi_controller_kind;
+
+/** where eps ~ N(0,1) comes from (reference: curandGenerateNormal, sampling_distributions/gaussian/gaussian.cu:380-394) */
+typedef enum mppi_noise_source
+{
+  MPPI_NOISE_PHILOX_FUSED = 0, /* Philox4x32-10 drawn inside the rollout kernel; nothing materialised in HBM */
+  MPPI_NOISE_INJECTED = 1,     /* caller-supplied eps (mppi_inject_noise): parity / replay mode */
+  MPPI_NOISE_ROCRAND_HOST = 2  /* rocrand_generate_normal (Philox) into an HBM eps buffer, the reference's structure */
+} mppi_noise_source;
+
+/**
+ * Construction parameters == the template arguments + ControllerParams of the reference
+ * (controllers/controller.cuh:46-68; template <DYN, COST, FB, SAMPLING, MAX_TIMESTEPS, NUM_ROLLOUTS>, :70-75).
+ */
+typedef struct mppi_config
+{
+  const char* model;     /* name of a registered instantiation: "cartpole", "double_integrator", ... (mppi_list_models) */
+  int controller;        /* mppi_controller_kind */
+  int num_rollouts;      /* K over ALL ranks (NUM_ROLLOUTS) */
+  int num_timesteps;     /* T (MAX_TIMESTEPS / num_timesteps_) */
+  float dt;              /* dt_ */
+  float lambda;          /* lambda_ */
+  float alpha;           /* alpha_ */
+  int num_iters;         /* num_iters_ : optimisation iterations per mppi_compute_control */
+  uint64_t seed;         /* seed_ (controller.cuh:59; the reference defaults to wall-clock time, here the caller decides) */
+  int noise_source;      /* mppi_noise_source */
+  int block_x, block_y;  /* dynamics_rollout_dim_.{x,y} hint; 0 = instantiation default */
+  int device;            /* HIP device ordinal */
+  void* stream;          /* hipStream_t to run on, or NULL: the handle creates its own (Managed::stream_, utils/managed.cuh:57) */
+  int rank, world_size;  /* K-sharding over GPUs: this handle owns rollouts [rank*K/world, (rank+1)*K/world) */
+  int save_samples;      /* != 0: keep the clamped samples v[D][K_local][T][C] in HBM (control_samples_d_) */
+} mppi_config;
+
+/** reference: GaussianParamsImpl, sampling_distributions/gaussian/gaussian.cuh:21-61 */
+typedef struct mppi_gaussian_params
+{
+  const float* std_dev;            /* [D][C] */
+  const float* control_cost_coeff; /* [C] */
+  float pure_noise_trajectories_percentage;
+  float std_dev_decay;
+  int sum_strides; /* accepted for compatibility; the block-local reduction does not need it */
+} mppi_gaussian_params;
+
+/** per-system statistics (reference: MPPIFreeEnergyStatistics controllers/controller.cuh:22-38, getBaselineCost/getNormalizerCost) */
+typedef struct mppi_system_stats
+{
+  float baseline;   /* rho  = min_k S_k              (computeBaselineCost, core/mppi_common.cu:858-900) */
+  float normalizer; /* eta  = sum_k exp(-(S_k-rho)/lambda) (computeNormalizer, core/mppi_common.cu:1055-1063) */
+  float free_energy_mean;
+  float free_energy_variance;
+  float free_energy_modified_variance; /* computeFreeEnergy, core/mppi_common.cu:1065-1081 */
+} mppi_system_stats;
+
+typedef struct mppi_stats
+{
+  mppi_system_stats real_sys;
+  mppi_system_stats nominal_sys; /* Tube / RMPPI */
+  int nominal_state_used;        /* tube_mppi_controller.cu:268-280 */
+} mppi_stats;
+
+/* ---------------------------------------------------------------- library ---------------------------------------- */
+const char* mppi_version(void);
+const char* mppi_status_string(mppi_status s);
+/** number of visible HIP devices (0 => mppi_create will fail with MPPI_ERR_NO_DEVICE) */
+int mppi_device_count(void);
+/** names of the registered (DYN, COST, SAMPLER) instantiations, '\n'-separated (reference: include/mppi/instantiations/) */
+const char* mppi_list_models(void);
+
+/* ---------------------------------------------------------------- lifecycle -------------------------------------- */
+/** Controller constructor + GPUSetup + allocateCUDAMemory (controllers/controller.cuh:160-216, 269-277, 931-992) */
+mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out);
+/** Controller destructor + freeCudaMem (controllers/controller.cuh:194-216) */
+void mppi_destroy(mppi_handle h);
+/** message of the last failing call; h == NULL: last mppi_create failure of this thread */
+const char* mppi_last_error(mppi_handle h);
+/** STATE_DIM, CONTROL_DIM, OUTPUT_DIM of the model (dynamics/dynamics.cuh:74-76) and the number of systems D per launch */
+mppi_status mppi_get_dims(mppi_handle h, int* state_dim, int* control_dim, int* output_dim, int* num_systems);
+/** rollouts owned by this handle (K / world_size) */
+mppi_status mppi_get_local_rollouts(mppi_handle h, int* k_local, int* k_offset);
+
+/* ---------------------------------------------------------------- parameters ------------------------------------- */
+/** Dynamics::setParams + paramsToDevice (dynamics/dynamics.cu:3-17); pod = the model's *_dynamics_params (mppi_amd/model_params.h) */
+mppi_status mppi_set_dynamics_params(mppi_handle h, const void* pod, size_t nbytes);
+/** Cost::setParams + paramsToDevice (cost_functions/cost.cu:5-13) */
+mppi_status mppi_set_cost_params(mppi_handle h, const void* pod, size_t nbytes);
+/** SamplingDistribution::setParams (sampling_distributions/sampling_distribution.cuh:93-116) */
+mppi_status mppi_set_sampler_params(mppi_handle h, const mppi_gaussian_params* p);
+/** Dynamics::setControlRanges (dynamics/dynamics.cu:19-36); lo_hi = [C][2] */
+mppi_status mppi_set_control_ranges(mppi_handle h, const float* lo_hi);
+/** Dynamics::setControlDeadbands (dynamics/dynamics.cu:38-55) */
+mppi_status mppi_set_control_deadband(mppi_handle h, const float* deadband);
+/** setLambda / setAlpha / setNumIters (controllers/controller.cuh:700-760) */
+mppi_status mppi_set_lambda_alpha(mppi_handle h, float lambda, float alpha);
+mppi_status mppi_set_num_iters(mppi_handle h, int num_iters);
+/** slide_control_scale_ (controller.cuh:67) [C]; Tube: nominal_threshold_ (Tube-MPPI/tube_mppi_controller.cuh:20) */
+mppi_status mppi_set_slide_control_scale(mppi_handle h, const float* scale);
+mppi_status mppi_set_nominal_threshold(mppi_handle h, float threshold);
+/** reseed the noise generator and reset its offset (controllers/controller.cu:200-207) */
+mppi_status mppi_set_seed(mppi_handle h, uint64_t seed);
+
+/* ---------------------------------------------------------------- control loop ----------------------------------- */
+/** updateImportanceSampler / init_control_traj_ (controllers/controller.cuh:330-349): u[T][C] */
+mppi_status mppi_set_nominal_control(mppi_handle h, const float* u);
+/**
+ * Parity / replay mode: eps[n_iters][K_local][T][C] replaces the generator for the next mppi_compute_control calls
+ * (iteration i of a call uses slab i % n_iters).  Switches the handle to MPPI_NOISE_INJECTED.  n_iters == 0 switches
+ * back to the configured generator.  (No reference equivalent: the reference never pins its noise)
+ */
+mppi_status mppi_inject_noise(mppi_handle h, const float* eps, int n_iters);
+/**
+ * Controller::computeControl(state, optimization_stride):
+ *   Vanilla  controllers/MPPI/mppi_controller.cu:151-241       x0 = [S]
+ *   Tube     controllers/Tube-MPPI/tube_mppi_controller.cu:157-299   x0 = actual state [S]
+ * Runs num_iters optimisation iterations on the device, then smoothing, state-trajectory propagation and constraint
+ * enforcement (controllers/controller.cuh:557-586, 643-663; mppi_controller.cu:225-231) and returns when the results are
+ * on the host.
+ */
+mppi_status mppi_compute_control(mppi_handle h, const float* x0, int optimization_stride);
+/** getControlSeq (controllers/controller.cuh:433-436): u_out[T][C]; Tube: the actual system's sequence */
+mppi_status mppi_get_control_seq(mppi_handle h, float* u_out);
+/** getTargetStateSeq (controllers/controller.cuh:438-446): x_out[T][S] */
+mppi_status mppi_get_state_seq(mppi_handle h, float* x_out);
+/** Tube: getNominalControlSeq / getNominalStateSeq equivalents (Tube-MPPI/tube_mppi_controller.cuh:86-106) */
+mppi_status mppi_get_nominal_control_seq(mppi_handle h, float* u_out);
+mppi_status mppi_get_nominal_state_seq(mppi_handle h, float* x_out);
+/** slideControlSequence(steps) (controllers/controller.cuh:351-356, 588-615; Tube: tube_mppi_controller.cu:312-323) */
+mppi_status mppi_slide(mppi_handle h, int steps);
+/** trajectory costs S[D][K_local] of the last iteration (trajectory_costs_d_, core/mppi_common.cu:850) */
+mppi_status mppi_get_costs(mppi_handle h, float* costs);
+/** baseline, normaliser, free-energy statistics of the last iteration (controllers/controller.cuh:22-38, 455-472) */
+mppi_status mppi_get_stats(mppi_handle h, mppi_stats* out);
+/** clamped samples v[D][K_local][T][C] of the last iteration (control_samples_d_); needs cfg.save_samples */
+mppi_status mppi_get_sampled_controls(mppi_handle h, float* v);
+
+/* ---------------------------------------------------------------- device-resident iteration loop ----------------- */
+/**
+ * Runs `num_iterations` passes of the optimisation-loop body (sample -> rollout -> baseline/normExp -> weighted
+ * reduction, mean <- u*) back to back on the handle's stream from the CURRENT device mean and initial state, without
+ * host round trips (the three blocking D2H copies per iteration of mppi_controller.cu:187-219 do not exist here).
+ * synchronize != 0 waits for completion.  This is the unit bench.py times.
+ */
+mppi_status mppi_optimize(mppi_handle h, int num_iterations, int synchronize);
+/** SamplingDistribution::setHostOptimalControlSequence (sampling_distributions/gaussian/gaussian.cu:459-478): copies the
+ *  device control means — the raw u* of the last iteration, before smoothing — to u_out[D][T][C] */
+mppi_status mppi_get_optimal_control(mppi_handle h, float* u_out);
+/** uploads x0 (Vanilla [S]; Tube [2][S]) and the nominal control without running anything */
+mppi_status mppi_upload_state(mppi_handle h, const float* x0);
+/**
+ * HIP-event timing on the handle's own stream: total ms for `num_iterations` iterations and, separately, the summed
+ * duration of the rollout kernel launches alone (events recorded around each rollout launch).
+ */
+mppi_status mppi_time_iterations(mppi_handle h, int num_iterations, float* ms_total, float* ms_rollout_kernels);
+/** waits for everything enqueued on the handle's stream */
+mppi_status mppi_synchronize(mppi_handle h);
+
+/* ---------------------------------------------------------------- multi-GPU (K-sharding) ---------- */
+/**
+ * Device pointers for an external exchange (torch.distributed / RCCL owned by the caller):
+ *   *send = this rank's merged record [D][T*C+4]; *recv = buffer for all ranks' records [world][D][T*C+4].
+ * Per iteration the caller all-gathers send -> recv on the handle's stream; mppi_optimize does this itself when the
+ * handle has an RCCL communicator (mppi_comm_init_rccl).
+ */
+mppi_status mppi_get_exchange_buffers(mppi_handle h, void** send, void** recv, size_t* floats_per_rank);
+/** one iteration split around the exchange: local rollout + local merge | (caller's all-gather) | global merge */
+mppi_status mppi_iteration_local(mppi_handle h);
+mppi_status mppi_iteration_merge(mppi_handle h);
+/** native RCCL path: unique id created on rank 0 and shipped by the caller to every rank (ncclGetUniqueId / ncclCommInitRank) */
+mppi_status mppi_rccl_unique_id(void* out_bytes, size_t capacity, size_t* nbytes);
+mppi_status mppi_comm_init_rccl(mppi_handle h, const void* unique_id, size_t nbytes);
+
+/* ---------------------------------------------------------------- kernel-level operators ------------------------- */
+/* Host-buffer wrappers around single kernels, mirroring the reference's launch wrappers; used by the kernel-level
+ * parity tests the way the reference's tests/include/kernel_tests/core harnesses use theirs. */
+/** one rollout launch from x0 ([D][S]) and the current nominal control, no mean update: costs via mppi_get_costs
+ *  (launchRolloutKernel, core/mppi_common.cu:1299-1325) */
+mppi_status mppi_rollout_costs(mppi_handle h, const float* x0, int optimization_stride);
+/** one model step on the device plugin, the simulation step of the reference's examples (examples/cartpole_example.cu:
+ *  76-80: model->enforceConstraints(x, u); model->step(x, x_next, xdot, u, y, t, dt)): u is clamped in place when
+ *  enforce_constraints != 0, then x <- x_next */
+mppi_status mppi_model_step(mppi_handle h, float* x_inout, float* u_inout, float dt, int enforce_constraints);
+/** launchNormExpKernel (core/mppi_common.cu:1327-1337): costs[K] -> exp(-lambda_inv (S - baseline)) in place */
+mppi_status mppi_norm_exp(float* costs, int num_rollouts, float lambda_inv, float baseline, int device);
+/** device two-pass baseline + normaliser (the role of fullGPUcomputeWeights, core/mppi_common.cu:1031-1053);
+ *  costs[K] -> weights in place, out2 = {baseline, normalizer} */
+mppi_status mppi_compute_weights(float* costs, int num_rollouts, float lambda_inv, float* out2, int device);
+/** launchWeightedReductionKernel (core/mppi_common.cu:1366-1388): u_out[T][C] = sum_k (w_k/normalizer) v[k][t][c] */
+mppi_status mppi_weighted_reduction(const float* weights, const float* v, float normalizer, int num_rollouts,
+                                    int num_timesteps, int control_dim, float* u_out, int device);
+/** eps[k_begin..k_end)[T][C] exactly as the fused generator draws it (for generator parity tests) */
+mppi_status mppi_philox_normal(uint64_t seed, uint32_t generation, int num_rollouts, int num_timesteps,
+                               int control_dim, int k_begin, int k_end, float* eps_out, int device);
+/** elementwise det_math on the device (func ids as oracle_det_eval): host/device bit-parity test hook */
+mppi_status mppi_det_eval(int func, const float* x, float* y, int n, int device);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MPPI_AMD_H_ */

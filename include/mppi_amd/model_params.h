@@ -1,0 +1,60 @@
+/**
+ * model_params.h — plain-old-data parameter blocks of the precompiled model instantiations.
+ *
+ * These are what mppi_set_dynamics_params() / mppi_set_cost_params() (include/mppi_amd.h) take as `const void* pod`.
+ * Field order and defaults follow the reference's parameter structs so a user of the reference can memcpy theirs:
+ *   mppi_cartpole_dynamics_params   <- CartpoleDynamicsParams        dynamics/cartpole/cartpole_dynamics.cuh:6-36
+ *   mppi_cartpole_cost_params       <- CartpoleQuadraticCostParams   cost_functions/cartpole/cartpole_quadratic_cost.cuh:10-23
+ *                                      (CostParams<1> base: control_cost_coeff[1], discount; cost_functions/cost.cuh:17-31)
+ *   mppi_di_dynamics_params         <- DoubleIntegratorParams        dynamics/double_integrator/di_dynamics.cuh:9-37
+ *   mppi_di_circle_cost_params      <- DoubleIntegratorCircleCostParams  cost_functions/double_integrator/double_integrator_circle_cost.cuh:8-23
+ * (paths relative to the reference's include/mppi/).
+ */
+#ifndef MPPI_AMD_MODEL_PARAMS_H_
+#define MPPI_AMD_MODEL_PARAMS_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mppi_cartpole_dynamics_params
+{
+  float cart_mass;   /* 1.0 */
+  float pole_mass;   /* 1.0 */
+  float pole_length; /* 1.0 */
+} mppi_cartpole_dynamics_params;
+
+typedef struct mppi_cartpole_cost_params
+{
+  float control_cost_coeff[1];     /* 10.0 */
+  float discount;                  /* 1.0 */
+  float cart_position_coeff;       /* 1000 */
+  float cart_velocity_coeff;       /* 100 */
+  float pole_angle_coeff;          /* 2000 */
+  float pole_angular_velocity_coeff; /* 100 */
+  float terminal_cost_coeff;       /* 0 */
+  float desired_terminal_state[4]; /* {0, 0, pi, 0} */
+} mppi_cartpole_cost_params;
+
+typedef struct mppi_di_dynamics_params
+{
+  float system_noise; /* 1.0 */
+} mppi_di_dynamics_params;
+
+typedef struct mppi_di_circle_cost_params
+{
+  float control_cost_coeff[2];    /* {0.01, 0.01} */
+  float discount;                 /* 1.0 */
+  float velocity_cost;            /* 1 */
+  float crash_cost;               /* 1000 */
+  float velocity_desired;         /* 2 */
+  float inner_path_radius2;       /* 1.875^2 */
+  float outer_path_radius2;       /* 2.125^2 */
+  float angular_momentum_desired; /* 2 * velocity_desired */
+} mppi_di_circle_cost_params;
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MPPI_AMD_MODEL_PARAMS_H_ */

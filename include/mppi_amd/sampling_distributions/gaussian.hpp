@@ -1,0 +1,329 @@
+/**
+ * gaussian.hpp — GaussianDistribution sampler plugin, MI355X design.
+ *
+ * Replaces, on the device side (reference paths relative to include/mppi/sampling_distributions/):
+ *   generateSamples + setGaussianControls      gaussian/gaussian.cu:374-431, :17-277   (a1, a2 in SURVEY.md §8a)
+ *   readControlSample / writeControlSample     sampling_distribution.cu:169-205, 278-314   (a4)
+ *   computeLikelihoodRatioCost (device)        gaussian/gaussian.cu:480-569                (a5)
+ *   the sample-side of updateDistributionParamsFromDevice (weighted reduction input)      gaussian/gaussian.cu:433-457
+ *
+ * Reference data flow: cuRAND writes eps[K][T][C] to HBM, setGaussianControls rewrites it as v = mu + sigma*eps, the
+ * rollout reads v with a T*C*4-byte stride between neighbouring threads (uncoalesced), clamps, writes v back, and the
+ * weighted reduction reads all of v once more with the same stride: >= 6 passes over V.
+ *
+ * Here the samples of a block never leave the CU: the sampler's per-rollout LDS request (getBlkSharedSizeBytes) IS the
+ * sample row v[k][0..T*C) (+1 float of padding when T*C is even, so that the 64 lanes of a wave, which walk the rows at
+ * the same t, hit 64 different banks).  initializeDistributions() fills the rows with eps — drawn in place from
+ * Philox4x32-10 (philox.h) or, in parity / rocRAND-host mode, copied coalesced from an eps buffer in HBM —
+ * readControlSample() applies the setGaussianControls rule on the fly, writeControlSample() stores the clamped control
+ * back into the row, and after the rollout the kernel's epilogue forms the block's weighted partial sum from the rows.
+ * The special-trajectory rules use the GLOBAL rollout index (rollout_offset_ + local index) so they survive sharding.
+ *
+ * Same names and argument meaning as the reference's SamplingDistribution device interface
+ * (sampling_distribution.cuh:32-430); `sample_index` is the rollout index local to this GPU.
+ */
+#ifndef MPPI_AMD_GAUSSIAN_DISTRIBUTION_HPP_
+#define MPPI_AMD_GAUSSIAN_DISTRIBUTION_HPP_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mppi_amd/plugin/managed.hpp"
+#include "mppi_amd/plugin/dynamics.hpp"
+#include "mppi_amd/philox.h"
+
+namespace mppi
+{
+namespace sampling_distributions
+{
+enum NoiseSource : int
+{
+  NOISE_PHILOX_FUSED = 0,  ///< eps drawn inside the rollout kernel (default)
+  NOISE_EPS_BUFFER = 1,    ///< eps read from eps_d_[K_local][T][C] (mppi_inject_noise, or the rocRAND host-API fill)
+};
+
+/** reference: sampling_distribution.cuh:17-30 (SamplingParams) + gaussian/gaussian.cuh:21-61 (GaussianParamsImpl) */
+template <int C_DIM, int MAX_DISTRIBUTIONS_T = 2>
+struct GaussianParamsImpl
+{
+  static const int CONTROL_DIM = C_DIM;
+  static const int MAX_DISTRIBUTIONS = MAX_DISTRIBUTIONS_T;
+  bool use_same_noise_for_all_distributions = true;
+  int num_rollouts = 1;  ///< rollouts on THIS GPU
+  int num_timesteps = 1;
+  int num_distributions = 1;
+  float std_dev[C_DIM * MAX_DISTRIBUTIONS_T];
+  float control_cost_coeff[C_DIM];
+  float pure_noise_trajectories_percentage = 0.01f;
+  float std_dev_decay = 1.0f;
+  int sum_strides = 32;  ///< kept for API compatibility; the block-local reduction does not use it
+  bool time_specific_std_dev = false;
+
+  GaussianParamsImpl(int num_rollouts = 1, int num_timesteps = 1, int num_distributions = 1)
+    : num_rollouts(num_rollouts), num_timesteps(num_timesteps), num_distributions(num_distributions)
+  {
+    for (int i = 0; i < C_DIM * MAX_DISTRIBUTIONS_T; i++)
+      std_dev[i] = 1.0f;
+    for (int i = 0; i < C_DIM; i++)
+      control_cost_coeff[i] = 0.0f;
+  }
+};
+
+template <class DYN_PARAMS_T>
+class GaussianDistribution : public Managed
+{
+public:
+  static const int CONTROL_DIM = E_INDEX(DYN_PARAMS_T::ControlIndex, NUM_CONTROLS);
+  typedef GaussianParamsImpl<CONTROL_DIM, 2> SAMPLING_PARAMS_T;
+  typedef GaussianDistribution<DYN_PARAMS_T> SAMPLING_T;
+
+  SAMPLING_PARAMS_T params_;
+
+  /* device buffers (owned by the engine) */
+  float* control_means_d_ = nullptr;      ///< mu [D][T][C]              (reference: gaussian.cuh control_means_d_)
+  const float* eps_d_ = nullptr;          ///< eps [K_local][T][C], NOISE_EPS_BUFFER only
+  float* control_samples_d_ = nullptr;    ///< optional dump of the clamped samples v [D][K_local][T][C]
+
+  /* per-call state, refreshed by the engine before every launch (the engine passes the object by value) */
+  int noise_source_ = NOISE_PHILOX_FUSED;
+  uint64_t seed_ = 0;
+  uint32_t generation_ = 0;          ///< number of generateSamples calls so far (cuRAND's advancing offset)
+  int optimization_stride_ = 0;
+  float std_dev_decayed_[CONTROL_DIM * 2];  ///< std_dev_decay^iteration * std_dev  (gaussian.cu:421, :86)
+  int rollout_offset_ = 0;           ///< global index of this GPU's first rollout
+  int num_rollouts_global_ = 1;      ///< K over all GPUs
+
+  GaussianDistribution(hipStream_t stream = 0)
+  {
+    bindToStream(stream);
+  }
+
+  /** row stride in floats: T*C, +1 when even (bank-conflict-free column walk) */
+  __host__ __device__ static inline int rowStride(int num_timesteps)
+  {
+    const int n = num_timesteps * CONTROL_DIM;
+    return (n & 1) ? n : n + 1;
+  }
+  /** LDS request per rollout slot: one sample row (reference: managed.cuh:104-111 Blk request) */
+  __host__ __device__ inline int getBlkSharedSizeBytes() const
+  {
+    return rowStride(params_.num_timesteps) * (int)sizeof(float);
+  }
+  __host__ __device__ inline int getGrdSharedSizeBytes() const
+  {
+    return 0;
+  }
+
+  /** decay^iter by repeated multiplication (exact for decay == 1; the CPU oracle does the same) */
+  void setIteration(int iteration_num, int optimization_stride)
+  {
+    float decay = 1.0f;
+    for (int i = 0; i < iteration_num; i++)
+      decay *= params_.std_dev_decay;
+    for (int i = 0; i < CONTROL_DIM * 2; i++)
+      std_dev_decayed_[i] = decay * params_.std_dev[i];
+    optimization_stride_ = optimization_stride;
+  }
+
+  __device__ inline float* sampleRow(float* theta_d, int slot) const
+  {
+    return theta_d + slot * rowStride(params_.num_timesteps);
+  }
+
+  __device__ inline bool isPureNoise(int sample_index) const
+  {
+    // reference: gaussian.cu:108 / :512 — float compare of the index against (1 - p) * K, GLOBAL index and K
+    return (float)(sample_index + rollout_offset_) >=
+           (1.0f - params_.pure_noise_trajectories_percentage) * (float)num_rollouts_global_;
+  }
+
+  /**
+   * Fills the block's sample rows with eps (all threads of the block cooperate; block-uniform control flow).
+   * Rows are consecutive rollouts, so the block's eps is one contiguous span of blockDim.x * T*C floats / one
+   * contiguous range of Philox counter blocks.
+   */
+  __device__ inline void initializeDistributions(const float* __restrict__ output, const float t_0, const float dt,
+                                                 float* __restrict__ theta_d)
+  {
+    const int TC = params_.num_timesteps * CONTROL_DIM;
+    const int stride = rowStride(params_.num_timesteps);
+    const int bx = (int)__builtin_amdgcn_workgroup_size_x();
+    const int tid_flat = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
+    const int nthreads = (int)(blockDim.x * blockDim.y * blockDim.z);
+    const int row0 = (int)(blockIdx.x * bx);  // first local rollout of the block
+    const int nrows = min(bx, params_.num_rollouts - row0);
+    const int nz = (int)blockDim.z;
+    if (nrows <= 0)
+      return;
+    const int total = nrows * TC;  // floats in the block's eps span
+    if (noise_source_ == NOISE_EPS_BUFFER)
+    {
+      const float* __restrict__ src = eps_d_ + (size_t)row0 * TC;
+      int row = 0, col = tid_flat;
+      while (col >= TC)
+      {
+        col -= TC;
+        row++;
+      }
+      for (int e = tid_flat; e < total; e += nthreads)
+      {
+        const float v = src[e];
+        for (int z = 0; z < nz; z++)
+          theta_d[(z * bx + row) * stride + col] = v;
+        col += nthreads;
+        while (col >= TC)
+        {
+          col -= TC;
+          row++;
+        }
+      }
+    }
+    else
+    {
+      // global element index of the span start; (row0 + offset) * TC is a multiple of 4 whenever bx is, otherwise the
+      // edge quads are generated by both neighbouring blocks and each keeps its own lanes
+      const uint64_t e0 = (uint64_t)(row0 + rollout_offset_) * (uint64_t)TC;
+      const uint64_t q0 = e0 >> 2;
+      const int lead = (int)(e0 & 3);  // lanes of the first quad that belong to the previous block
+      const int nquads = (lead + total + 3) >> 2;
+      for (int q = tid_flat; q < nquads; q += nthreads)
+      {
+        float zn[4];
+        mppi::rng::normal4(seed_, generation_, 0u, q0 + (uint64_t)q, zn);
+#pragma unroll
+        for (int l = 0; l < 4; l++)
+        {
+          const int e = q * 4 + l - lead;
+          if (e >= 0 && e < total)
+          {
+            const int row = e / TC;
+            const int col = e - row * TC;
+            for (int z = 0; z < nz; z++)
+              theta_d[(z * bx + row) * stride + col] = zn[l];
+          }
+        }
+      }
+    }
+  }
+
+  /**
+   * reference: sampling_distribution.cu:169-205 (readControlSample) fused with the setGaussianControls rule
+   * (gaussian.cu:99-127): k == 0 or t < stride -> mu; pure-noise rollouts -> sigma*eps; else mu + sigma*eps.
+   */
+  __device__ inline void readControlSample(const int& sample_index, const int& t, const int& distribution_index,
+                                           float* __restrict__ control, float* __restrict__ theta_d,
+                                           const int& block_size, const int& thread_index,
+                                           const float* __restrict__ output = nullptr)
+  {
+    const int d = distribution_index >= params_.num_distributions ? 0 : distribution_index;
+    const int slot = (int)(blockDim.x * threadIdx.z + threadIdx.x);
+    const float* row = sampleRow(theta_d, slot) + t * CONTROL_DIM;
+    const float* mean = control_means_d_ + (size_t)(params_.num_timesteps * d + t) * CONTROL_DIM;
+    const bool use_mean = ((sample_index + rollout_offset_) == 0) || (t < optimization_stride_);
+    const bool pure = isPureNoise(sample_index);
+    for (int i = thread_index; i < CONTROL_DIM; i += block_size)
+    {
+      const float m = mean[i];
+      const float sd = std_dev_decayed_[CONTROL_DIM * d + i];
+      const float e = row[i];
+      float v;
+      if (use_mean)
+        v = m;
+      else if (pure)
+        v = sd * e;
+      else
+        v = m + sd * e;
+      control[i] = v;
+    }
+  }
+
+  /** reference: sampling_distribution.cu:278-314 — the clamped control replaces the sample (mppi_common.cu:110-117) */
+  __device__ inline void writeControlSample(const int& sample_index, const int& t, const int& distribution_index,
+                                            const float* __restrict__ control, float* __restrict__ theta_d,
+                                            const int& block_size, const int& thread_index,
+                                            const float* __restrict__ output = nullptr)
+  {
+    const int slot = (int)(blockDim.x * threadIdx.z + threadIdx.x);
+    float* row = sampleRow(theta_d, slot) + t * CONTROL_DIM;
+    for (int i = thread_index; i < CONTROL_DIM; i += block_size)
+    {
+      row[i] = control[i];
+    }
+  }
+
+  /**
+   * reference: gaussian.cu:480-569, device flavour: 0.5*lambda*(1-alpha) * sum_i coeff_i*mu_i*(mu_i - 2u_i)/sigma_i^2
+   * with mu := 0 on pure-noise rollouts; vector-lane accumulation order of the CONTROL_DIM % 4 / % 2 / scalar branches.
+   */
+  __device__ inline float computeLikelihoodRatioCost(const float* __restrict__ u, float* __restrict__ theta_d,
+                                                     const int sample_index, const int t, const int distribution_idx,
+                                                     const float lambda = 1.0f, const float alpha = 0.0f)
+  {
+    const int d = distribution_idx >= params_.num_distributions ? 0 : distribution_idx;
+    const float* std_dev = &params_.std_dev[CONTROL_DIM * d];
+    const float* mean = control_means_d_ + (size_t)(params_.num_timesteps * d + t) * CONTROL_DIM;
+    const float* control_cost_coeff = params_.control_cost_coeff;
+    const bool pure = isPureNoise(sample_index);
+    float cost = 0.0f;
+    int i = (int)__builtin_amdgcn_workitem_id_y();
+    const int step = (int)__builtin_amdgcn_workgroup_size_y();
+    constexpr int W = (CONTROL_DIM % 4 == 0) ? 4 : ((CONTROL_DIM % 2 == 0) ? 2 : 1);
+    if constexpr (W > 1)
+    {
+      float lane[W];
+#pragma unroll
+      for (int l = 0; l < W; l++)
+        lane[l] = 0.0f;
+      for (; i < CONTROL_DIM / W; i += step)
+      {
+#pragma unroll
+        for (int l = 0; l < W; l++)
+        {
+          const int j = i * W + l;
+          const float mean_i = pure ? 0.0f : mean[j];
+          lane[l] += control_cost_coeff[j] * mean_i * (mean_i - 2.0f * u[j]) / (std_dev[j] * std_dev[j]);
+        }
+      }
+      if constexpr (W == 4)
+        cost += lane[0] + lane[1] + lane[2] + lane[3];
+      else
+        cost += lane[0] + lane[1];
+    }
+    else
+    {
+      for (; i < CONTROL_DIM; i += step)
+      {
+        const float mean_i = pure ? 0.0f : mean[i];
+        cost += control_cost_coeff[i] * mean_i * (mean_i - 2.0f * u[i]) / (std_dev[i] * std_dev[i]);
+      }
+    }
+    return 0.5f * lambda * (1.0f - alpha) * cost;
+  }
+
+  /** reference: gaussian.cu:571-629 */
+  __device__ inline float computeFeedbackCost(const float* __restrict__ u_fb, float* __restrict__ theta_d, const int t,
+                                              const int distribution_idx, const float lambda = 1.0f,
+                                              const float alpha = 0.0f)
+  {
+    const int d = distribution_idx >= params_.num_distributions ? 0 : distribution_idx;
+    const float* std_dev = &params_.std_dev[CONTROL_DIM * d];
+    float cost = 0.0f;
+    constexpr int W = (CONTROL_DIM % 4 == 0) ? 4 : ((CONTROL_DIM % 2 == 0) ? 2 : 1);
+    float lane[W];
+    for (int l = 0; l < W; l++)
+      lane[l] = 0.0f;
+    for (int i = (int)threadIdx.y; i < CONTROL_DIM / W; i += (int)blockDim.y)
+      for (int l = 0; l < W; l++)
+      {
+        const int j = i * W + l;
+        lane[l] += params_.control_cost_coeff[j] * (u_fb[j] * u_fb[j]) / (std_dev[j] * std_dev[j]);
+      }
+    for (int l = 0; l < W; l++)
+      cost += lane[l];
+    return 0.5f * lambda * (1.0f - alpha) * cost;
+  }
+};
+
+}  // namespace sampling_distributions
+}  // namespace mppi
+
+#endif

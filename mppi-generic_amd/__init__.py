@@ -1,0 +1,18 @@
+"""mppi-generic_amd — MI355X-native MPPI rollout-and-reduce engine (host-side Python mirror over the C ABI).
+
+The product is ``lib/libmppi_amd.so`` (hand-written HIP kernels for gfx950 behind include/mppi_amd.h).  This package
+only (a) builds it with hipcc, (b) declares its C entry points for ctypes, and (c) mirrors the reference's controller
+classes (same method names) on top of those entry points so tests read like the reference's own.
+"""
+from . import buildlib as _buildlib
+from .buildlib import build
+from .capi import (MppiConfig, MppiGaussianParams, MppiStats, MppiSystemStats, SIGNATURES, library_path, load_library)
+from .controllers import (MPPI_CONTROLLER_TUBE, MPPI_CONTROLLER_VANILLA, MPPI_NOISE_INJECTED, MPPI_NOISE_PHILOX_FUSED,
+                          MPPIError, MPPIController, TubeMPPIController, VanillaMPPIController, CartpoleDynamicsParams,
+                          CartpoleQuadraticCostParams, DoubleIntegratorParams, DoubleIntegratorCircleCostParams,
+                          det_eval, philox_normal, norm_exp, compute_weights, weighted_reduction)
+
+__all__ = [
+    "build", "load_library", "library_path", "MPPIError", "MPPIController", "VanillaMPPIController",
+    "TubeMPPIController", "MppiConfig", "SIGNATURES",
+]

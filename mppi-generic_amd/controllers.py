@@ -1,0 +1,339 @@
+"""Host-side mirror of the reference's controller classes over the C ABI.
+
+Method names follow the reference (controllers/controller.cuh, controllers/MPPI/mppi_controller.cuh,
+controllers/Tube-MPPI/tube_mppi_controller.cuh): computeControl, getControlSeq, getTargetStateSeq,
+slideControlSequence, updateImportanceSampler, getBaselineCost, getNormalizerCost, ...
+All numerics happen in libmppi_amd.so; arrays are numpy float32, row-major ([T][C], [T][S], [K][T][C]).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .capi import MppiConfig, MppiGaussianParams, MppiStats, load_library
+
+MPPI_CONTROLLER_VANILLA = 0
+MPPI_CONTROLLER_TUBE = 1
+MPPI_NOISE_PHILOX_FUSED = 0
+MPPI_NOISE_INJECTED = 1
+MPPI_NOISE_ROCRAND_HOST = 2
+
+
+class MPPIError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("mppi status %d: %s" % (status, message))
+        self.status = status
+
+
+# ---- POD parameter blocks (include/mppi_amd/model_params.h) -------------------------------------------------------
+class CartpoleDynamicsParams(C.Structure):
+    _fields_ = [("cart_mass", C.c_float), ("pole_mass", C.c_float), ("pole_length", C.c_float)]
+
+    def __init__(self, cart_mass=1.0, pole_mass=1.0, pole_length=1.0):
+        super().__init__(cart_mass, pole_mass, pole_length)
+
+
+class CartpoleQuadraticCostParams(C.Structure):
+    _fields_ = [
+        ("control_cost_coeff", C.c_float * 1), ("discount", C.c_float),
+        ("cart_position_coeff", C.c_float), ("cart_velocity_coeff", C.c_float), ("pole_angle_coeff", C.c_float),
+        ("pole_angular_velocity_coeff", C.c_float), ("terminal_cost_coeff", C.c_float),
+        ("desired_terminal_state", C.c_float * 4),
+    ]
+
+    def __init__(self):
+        super().__init__()
+        self.control_cost_coeff[0] = 10.0
+        self.discount = 1.0
+        self.cart_position_coeff = 1000
+        self.cart_velocity_coeff = 100
+        self.pole_angle_coeff = 2000
+        self.pole_angular_velocity_coeff = 100
+        self.terminal_cost_coeff = 0
+        self.desired_terminal_state[:] = [0.0, 0.0, np.float32(np.pi), 0.0]
+
+
+class DoubleIntegratorParams(C.Structure):
+    _fields_ = [("system_noise", C.c_float)]
+
+    def __init__(self, system_noise=1.0):
+        super().__init__(system_noise)
+
+
+class DoubleIntegratorCircleCostParams(C.Structure):
+    _fields_ = [
+        ("control_cost_coeff", C.c_float * 2), ("discount", C.c_float), ("velocity_cost", C.c_float),
+        ("crash_cost", C.c_float), ("velocity_desired", C.c_float), ("inner_path_radius2", C.c_float),
+        ("outer_path_radius2", C.c_float), ("angular_momentum_desired", C.c_float),
+    ]
+
+    def __init__(self):
+        super().__init__()
+        self.control_cost_coeff[:] = [0.01, 0.01]
+        self.discount = 1.0
+        self.velocity_cost = 1
+        self.crash_cost = 1000
+        self.velocity_desired = 2
+        self.inner_path_radius2 = 1.875 * 1.875
+        self.outer_path_radius2 = 2.125 * 2.125
+        self.angular_momentum_desired = 4
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class MPPIController:
+    """Common part of the reference's Controller<DYN, COST, FB, SAMPLING, MAX_TIMESTEPS, NUM_ROLLOUTS>."""
+
+    KIND = MPPI_CONTROLLER_VANILLA
+
+    def __init__(self, model, num_rollouts, num_timesteps, dt, lambda_, alpha=0.0, num_iters=1, seed=42,
+                 noise_source=MPPI_NOISE_PHILOX_FUSED, block_x=0, block_y=0, device=0, stream=None, rank=0,
+                 world_size=1, save_samples=False):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self._model = model.encode()
+        cfg = MppiConfig(self._model, self.KIND, num_rollouts, num_timesteps, dt, lambda_, alpha, num_iters, seed,
+                         noise_source, block_x, block_y, device, stream, rank, world_size, int(save_samples))
+        st = self._lib.mppi_create(C.byref(cfg), C.byref(self._h))
+        if st != 0:
+            self._h = C.c_void_p()
+            raise MPPIError(st, (self._lib.mppi_last_error(None) or b"").decode())
+        s, c, o, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.mppi_get_dims(self._h, C.byref(s), C.byref(c), C.byref(o), C.byref(d)))
+        self.STATE_DIM, self.CONTROL_DIM, self.OUTPUT_DIM, self.num_systems = s.value, c.value, o.value, d.value
+        kl, ko = C.c_int(), C.c_int()
+        self._check(self._lib.mppi_get_local_rollouts(self._h, C.byref(kl), C.byref(ko)))
+        self.num_rollouts_local, self.rollout_offset = kl.value, ko.value
+        self.num_rollouts, self.num_timesteps = num_rollouts, num_timesteps
+        self.dt, self.lambda_, self.alpha = dt, lambda_, alpha
+
+    # -- plumbing --
+    def _check(self, st):
+        if st != 0:
+            raise MPPIError(st, (self._lib.mppi_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.mppi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- parameters --
+    def setDynamicsParams(self, pod):
+        self._check(self._lib.mppi_set_dynamics_params(self._h, C.byref(pod), C.sizeof(pod)))
+
+    def setCostParams(self, pod):
+        self._check(self._lib.mppi_set_cost_params(self._h, C.byref(pod), C.sizeof(pod)))
+
+    def setSamplingParams(self, std_dev, control_cost_coeff=None, pure_noise_trajectories_percentage=0.01,
+                          std_dev_decay=1.0, sum_strides=32):
+        sd = _f32(std_dev).reshape(-1)
+        if sd.size == self.CONTROL_DIM and self.num_systems == 2:
+            sd = np.concatenate([sd, sd])
+        cc = _f32(np.zeros(self.CONTROL_DIM) if control_cost_coeff is None else control_cost_coeff).reshape(-1)
+        p = MppiGaussianParams(sd.ctypes.data_as(C.POINTER(C.c_float)), cc.ctypes.data_as(C.POINTER(C.c_float)),
+                               pure_noise_trajectories_percentage, std_dev_decay, sum_strides)
+        self._check(self._lib.mppi_set_sampler_params(self._h, C.byref(p)))
+
+    def setControlRanges(self, lo_hi):
+        self._check(self._lib.mppi_set_control_ranges(self._h, _f32(lo_hi).reshape(-1)))
+
+    def setControlDeadbands(self, db):
+        self._check(self._lib.mppi_set_control_deadband(self._h, _f32(db).reshape(-1)))
+
+    def setLambda(self, lambda_):
+        self.lambda_ = lambda_
+        self._check(self._lib.mppi_set_lambda_alpha(self._h, self.lambda_, self.alpha))
+
+    def setNumIters(self, n):
+        self._check(self._lib.mppi_set_num_iters(self._h, n))
+
+    def setSlideControlScale(self, scale):
+        self._check(self._lib.mppi_set_slide_control_scale(self._h, _f32(scale).reshape(-1)))
+
+    def setSeed(self, seed):
+        self._check(self._lib.mppi_set_seed(self._h, seed))
+
+    # -- control loop --
+    def updateImportanceSampler(self, u):
+        u = _f32(u)
+        assert u.shape == (self.num_timesteps, self.CONTROL_DIM)
+        self._check(self._lib.mppi_set_nominal_control(self._h, u))
+
+    def injectNoise(self, eps):
+        """eps[n_iters][K_local][T][C] (or [K_local][T][C]); None switches back to the generator."""
+        if eps is None:
+            self._check(self._lib.mppi_inject_noise(self._h, None, 0))
+            return
+        eps = _f32(eps)
+        if eps.ndim == 3:
+            eps = eps[None]
+        assert eps.shape[1:] == (self.num_rollouts_local, self.num_timesteps, self.CONTROL_DIM), eps.shape
+        self._check(self._lib.mppi_inject_noise(self._h, eps.ctypes.data, eps.shape[0]))
+
+    def computeControl(self, state, optimization_stride=1):
+        self._check(self._lib.mppi_compute_control(self._h, _f32(state).reshape(-1), optimization_stride))
+
+    def getControlSeq(self):
+        u = np.empty((self.num_timesteps, self.CONTROL_DIM), np.float32)
+        self._check(self._lib.mppi_get_control_seq(self._h, u))
+        return u
+
+    def getTargetStateSeq(self):
+        x = np.empty((self.num_timesteps, self.STATE_DIM), np.float32)
+        self._check(self._lib.mppi_get_state_seq(self._h, x))
+        return x
+
+    def slideControlSequence(self, steps):
+        self._check(self._lib.mppi_slide(self._h, steps))
+
+    def getSampledCostSeq(self):
+        costs = np.empty((self.num_systems, self.num_rollouts_local), np.float32)
+        self._check(self._lib.mppi_get_costs(self._h, costs))
+        return costs
+
+    def getSampledControls(self):
+        v = np.empty((self.num_systems, self.num_rollouts_local, self.num_timesteps, self.CONTROL_DIM), np.float32)
+        self._check(self._lib.mppi_get_sampled_controls(self._h, v))
+        return v
+
+    def getStats(self):
+        st = MppiStats()
+        self._check(self._lib.mppi_get_stats(self._h, C.byref(st)))
+        return st
+
+    def getBaselineCost(self, system=0):
+        st = self.getStats()
+        return (st.real_sys if system == 0 else st.nominal_sys).baseline
+
+    def getNormalizerCost(self, system=0):
+        st = self.getStats()
+        return (st.real_sys if system == 0 else st.nominal_sys).normalizer
+
+    # -- kernel-level / device-resident --
+    def rolloutCosts(self, x0, optimization_stride=1):
+        self._check(self._lib.mppi_rollout_costs(self._h, _f32(x0).reshape(-1), optimization_stride))
+        return self.getSampledCostSeq()
+
+    def uploadState(self, x0):
+        self._check(self._lib.mppi_upload_state(self._h, _f32(x0).reshape(-1)))
+
+    def getOptimalControlSeq(self):
+        """raw u* of the last iteration ([D][T][C]); reference: setHostOptimalControlSequence"""
+        u = np.empty((self.num_systems, self.num_timesteps, self.CONTROL_DIM), np.float32)
+        self._check(self._lib.mppi_get_optimal_control(self._h, u))
+        return u
+
+    def optimize(self, num_iterations, synchronize=True):
+        self._check(self._lib.mppi_optimize(self._h, num_iterations, int(synchronize)))
+
+    def timeIterations(self, n):
+        a, b = C.c_float(), C.c_float()
+        self._check(self._lib.mppi_time_iterations(self._h, n, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def synchronize(self):
+        self._check(self._lib.mppi_synchronize(self._h))
+
+    def modelStep(self, x, u, dt=None, enforce_constraints=True):
+        x = _f32(x).reshape(-1).copy()
+        u = _f32(u).reshape(-1).copy()
+        self._check(self._lib.mppi_model_step(self._h, x, u, self.dt if dt is None else dt, int(enforce_constraints)))
+        return x, u
+
+    # -- multi-GPU --
+    def exchangeBuffers(self):
+        s, r, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self._check(self._lib.mppi_get_exchange_buffers(self._h, C.byref(s), C.byref(r), C.byref(n)))
+        return s.value, r.value, n.value
+
+    def iterationLocal(self):
+        self._check(self._lib.mppi_iteration_local(self._h))
+
+    def iterationMerge(self):
+        self._check(self._lib.mppi_iteration_merge(self._h))
+
+    def commInitRccl(self, unique_id_bytes):
+        buf = C.create_string_buffer(bytes(unique_id_bytes), 128)
+        self._check(self._lib.mppi_comm_init_rccl(self._h, buf, 128))
+
+
+class VanillaMPPIController(MPPIController):
+    """reference: controllers/MPPI/mppi_controller.cuh — VanillaMPPIController"""
+    KIND = MPPI_CONTROLLER_VANILLA
+
+
+class TubeMPPIController(MPPIController):
+    """reference: controllers/Tube-MPPI/tube_mppi_controller.cuh — TubeMPPIController"""
+    KIND = MPPI_CONTROLLER_TUBE
+
+    def setNominalThreshold(self, t):
+        self._check(self._lib.mppi_set_nominal_threshold(self._h, t))
+
+    def getNominalControlSeq(self):
+        u = np.empty((self.num_timesteps, self.CONTROL_DIM), np.float32)
+        self._check(self._lib.mppi_get_nominal_control_seq(self._h, u))
+        return u
+
+    def getNominalStateSeq(self):
+        x = np.empty((self.num_timesteps, self.STATE_DIM), np.float32)
+        self._check(self._lib.mppi_get_nominal_state_seq(self._h, x))
+        return x
+
+
+# ---- kernel-level operators -----------------------------------------------------------------------------------------
+def _op_check(lib, st):
+    if st != 0:
+        raise MPPIError(st, (lib.mppi_last_error(None) or b"").decode())
+
+
+def det_eval(func, x, device=0):
+    lib = load_library()
+    x = _f32(x).reshape(-1)
+    y = np.empty_like(x)
+    _op_check(lib, lib.mppi_det_eval(func, x, y, x.size, device))
+    return y
+
+
+def philox_normal(seed, generation, K, T, Cdim, k_begin=0, k_end=None, device=0):
+    lib = load_library()
+    k_end = K if k_end is None else k_end
+    out = np.empty((k_end - k_begin, T, Cdim), np.float32)
+    _op_check(lib, lib.mppi_philox_normal(seed, generation, K, T, Cdim, k_begin, k_end, out, device))
+    return out
+
+
+def norm_exp(costs, lambda_inv, baseline, device=0):
+    lib = load_library()
+    w = _f32(costs).reshape(-1).copy()
+    _op_check(lib, lib.mppi_norm_exp(w, w.size, lambda_inv, baseline, device))
+    return w
+
+
+def compute_weights(costs, lambda_inv, device=0):
+    lib = load_library()
+    w = _f32(costs).reshape(-1).copy()
+    out = np.zeros(2, np.float32)
+    _op_check(lib, lib.mppi_compute_weights(w, w.size, lambda_inv, out, device))
+    return w, float(out[0]), float(out[1])
+
+
+def weighted_reduction(weights, v, normalizer, device=0):
+    lib = load_library()
+    v = _f32(v)
+    K, T, Cd = v.shape
+    u = np.empty((T, Cd), np.float32)
+    _op_check(lib, lib.mppi_weighted_reduction(_f32(weights).reshape(-1), v, normalizer, K, T, Cd, u, device))
+    return u

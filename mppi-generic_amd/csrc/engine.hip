@@ -1,0 +1,1225 @@
+/**
+ * engine.hip — implementation of the C ABI in include/mppi_amd.h: handle, device buffers, controller loops.
+ *
+ * Host-side logic restated from the reference's controllers (paths relative to the reference's include/mppi/):
+ *   Vanilla loop            controllers/MPPI/mppi_controller.cu:151-241
+ *   Tube loop               controllers/Tube-MPPI/tube_mppi_controller.cu:157-341
+ *   slide / history         controllers/controller.cuh:351-356, 588-615
+ * What differs by design: per iteration there is no D2H copy and no host scan — baseline, normaliser and the weighted
+ * reduction stay on the device (rollout_kernel.hpp, reduce_kernels.hpp); smoothing and the nominal state trajectory
+ * run in finalize_kernel.hpp.  The host owns the control sequence between calls exactly as the reference's control_.
+ */
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "mppi_amd.h"
+#include "model_instance.hpp"
+#include "models.hpp"
+
+using namespace mppi;
+using namespace mppi::engine;
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+static thread_local std::string g_create_error;
+
+struct mppi_handle_s
+{
+  mppi_config cfg{};
+  std::string model_name;
+  std::unique_ptr<ModelBase> model;
+  int D = 1, S = 0, C = 0, O = 0;
+  int K_local = 0, K_offset = 0;
+  int bx = 64, by = 1, bz = 1;
+  int num_blocks = 0;
+  int TC = 0, PS = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string last_error;
+
+  /* device buffers */
+  float* x0_d = nullptr;           // [D][S]
+  float* mean_d = nullptr;         // [D][T][C]
+  float* costs_d = nullptr;        // [D][K_local]
+  float* partials_d = nullptr;     // [D][num_blocks][PS]
+  float* send_d = nullptr;         // [D][PS]
+  float* recv_d = nullptr;         // [world][D][PS]
+  float* gather_tmp_d = nullptr;   // [D][world][PS] (records regrouped per system)
+  float* stats_d = nullptr;        // [D][STATS_STRIDE]
+  float* eps_d = nullptr;          // [n_eps_iters][K_local][T][C]
+  float* samples_d = nullptr;      // [D][K_local][T][C]
+  float* history_d = nullptr;      // [2][C]
+  float* ctrl_in_d = nullptr;      // [D][T][C]
+  float* ctrl_out_d = nullptr;     // [D][T][C]
+  float* state_out_d = nullptr;    // [D][T][S]
+  float* step_x_d = nullptr;       // [S]
+  float* step_u_d = nullptr;       // [C]
+  int n_eps_iters = 0;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+
+  /* host state (the reference's control_, control_history_, state_, nominal_* members) */
+  std::vector<float> control_h, history_h, state_h, nominal_control_h, nominal_state_h, slide_scale_h;
+  bool nominal_state_init = false;
+  float nominal_threshold = 20.0f;  // Tube-MPPI/tube_mppi_controller.cuh:20
+  mppi_stats stats_h{};
+  uint32_t generation = 0;
+  int last_stride = 1;
+  int noise_source = MPPI_NOISE_PHILOX_FUSED;
+
+  /* RCCL (loaded lazily) */
+  void* rccl_lib = nullptr;
+  void* comm = nullptr;
+};
+
+static mppi_status fail(mppi_handle h, mppi_status s, const std::string& msg)
+{
+  if (h)
+    h->last_error = msg;
+  else
+    g_create_error = msg;
+  return s;
+}
+
+#define HIP_TRY(h, expr)                                                                                             \
+  do                                                                                                                 \
+  {                                                                                                                  \
+    hipError_t e__ = (expr);                                                                                         \
+    if (e__ != hipSuccess)                                                                                           \
+      return fail((h), MPPI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                          \
+  } while (0)
+
+#define MPPI_TRY(expr)               \
+  do                                 \
+  {                                  \
+    mppi_status s__ = (expr);        \
+    if (s__ != MPPI_OK)              \
+      return s__;                    \
+  } while (0)
+
+#define CHECK_HANDLE(h)               \
+  if (!(h))                           \
+  return MPPI_ERR_INVALID_ARG
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+extern "C" {
+
+const char* mppi_version(void)
+{
+  return "mppi-generic_amd 0.1 (gfx950)";
+}
+
+const char* mppi_status_string(mppi_status s)
+{
+  switch (s)
+  {
+    case MPPI_OK: return "ok";
+    case MPPI_ERR_INVALID_ARG: return "invalid argument";
+    case MPPI_ERR_UNKNOWN_MODEL: return "unknown model";
+    case MPPI_ERR_NO_DEVICE: return "no usable HIP device";
+    case MPPI_ERR_HIP: return "HIP runtime error";
+    case MPPI_ERR_LAUNCH_SHAPE: return "unsupported launch shape";
+    case MPPI_ERR_LDS_OVERFLOW: return "LDS request exceeds 160 KiB";
+    case MPPI_ERR_STATE: return "invalid state for this call";
+    case MPPI_ERR_NAN: return "non-finite control";
+    case MPPI_ERR_COMM: return "RCCL error";
+    case MPPI_ERR_UNSUPPORTED: return "unsupported";
+  }
+  return "unknown status";
+}
+
+int mppi_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+const char* mppi_list_models(void)
+{
+  return mppi::engine::listModels();
+}
+
+const char* mppi_last_error(mppi_handle h)
+{
+  return h ? h->last_error.c_str() : g_create_error.c_str();
+}
+
+/* ---------------------------------------------------------------- lifecycle -------------------------------------- */
+static void freeAll(mppi_handle h)
+{
+  float** bufs[] = { &h->x0_d,     &h->mean_d,    &h->costs_d,   &h->partials_d,  &h->send_d,     &h->recv_d,
+                     &h->stats_d,  &h->eps_d,     &h->samples_d, &h->history_d,   &h->ctrl_in_d,  &h->ctrl_out_d,
+                     &h->state_out_d, &h->step_x_d, &h->step_u_d, &h->gather_tmp_d };
+  for (float** b : bufs)
+  {
+    if (*b)
+      (void)hipFree(*b);
+    *b = nullptr;
+  }
+  if (h->ev_a)
+    (void)hipEventDestroy(h->ev_a);
+  if (h->ev_b)
+    (void)hipEventDestroy(h->ev_b);
+  if (h->own_stream && h->stream)
+    (void)hipStreamDestroy(h->stream);
+}
+
+mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
+{
+  if (!cfg || !out || !cfg->model)
+    return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_create: null argument");
+  *out = nullptr;
+  if (cfg->num_rollouts <= 0 || cfg->num_timesteps <= 0 || !(cfg->dt > 0.0f) || !(cfg->lambda > 0.0f) ||
+      cfg->num_iters <= 0)
+    return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_create: num_rollouts, num_timesteps, dt, lambda, num_iters must be > 0");
+  const int world = cfg->world_size > 0 ? cfg->world_size : 1;
+  if (cfg->rank < 0 || cfg->rank >= world || cfg->num_rollouts % world != 0)
+    return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_create: rank/world_size invalid or num_rollouts not divisible by world_size");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, MPPI_ERR_NO_DEVICE, "mppi_create: no HIP device visible (this library has no CPU path)");
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_create: device ordinal out of range");
+
+  std::unique_ptr<mppi_handle_s> h(new mppi_handle_s());
+  h->cfg = *cfg;
+  h->cfg.world_size = world;
+  h->model_name = cfg->model;
+  h->cfg.model = h->model_name.c_str();
+  h->model.reset(makeModel(h->model_name));
+  if (!h->model)
+    return fail(nullptr, MPPI_ERR_UNKNOWN_MODEL, "mppi_create: model '" + h->model_name + "' is not registered; have:\n" + listModels());
+  mppi_handle hp = h.get();
+  switch (cfg->controller)
+  {
+    case MPPI_CONTROLLER_VANILLA: h->D = 1; break;
+    case MPPI_CONTROLLER_TUBE: h->D = 2; break;
+    default:
+      return fail(nullptr, MPPI_ERR_UNSUPPORTED, "mppi_create: controller kind not available in this build");
+  }
+  h->S = h->model->S;
+  h->C = h->model->C;
+  h->O = h->model->O;
+  h->K_local = cfg->num_rollouts / world;
+  h->K_offset = cfg->rank * h->K_local;
+  h->bx = cfg->block_x > 0 ? cfg->block_x : h->model->default_bx;
+  h->by = cfg->block_y > 0 ? cfg->block_y : h->model->default_by;
+  h->bz = h->D;
+  if (!h->model->supportsShape(h->bx, h->by, h->bz))
+    return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
+                "mppi_create: block shape (" + std::to_string(h->bx) + "," + std::to_string(h->by) + "," +
+                    std::to_string(h->bz) + ") is not instantiated for model '" + h->model_name + "'");
+  const size_t lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D);
+  if (lds > MAX_LDS_BYTES)
+    return fail(nullptr, MPPI_ERR_LDS_OVERFLOW,
+                "mppi_create: rollout kernel needs " + std::to_string(lds) + " B of LDS per block (max 163840)");
+  h->num_blocks = (h->K_local + h->bx - 1) / h->bx;
+  h->TC = cfg->num_timesteps * h->C;
+  h->PS = kernels::partialStride(cfg->num_timesteps, h->C);
+  h->noise_source = cfg->noise_source;
+  if (h->noise_source == MPPI_NOISE_ROCRAND_HOST)
+    return fail(nullptr, MPPI_ERR_UNSUPPORTED, "mppi_create: MPPI_NOISE_ROCRAND_HOST is not available in this build");
+
+  HIP_TRY(nullptr, hipSetDevice(cfg->device));
+  if (cfg->stream)
+  {
+    h->stream = (hipStream_t)cfg->stream;
+  }
+  else
+  {
+    HIP_TRY(nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  const int T = cfg->num_timesteps, D = h->D, S = h->S, C = h->C, K = h->K_local;
+  auto alloc = [&](float** p, size_t n) -> hipError_t {
+    hipError_t e = hipMalloc((void**)p, n * sizeof(float));
+    if (e == hipSuccess)
+      e = hipMemsetAsync(*p, 0, n * sizeof(float), h->stream);
+    return e;
+  };
+#define ALLOC_OR_FAIL(ptr, n)                                                                       \
+  do                                                                                                \
+  {                                                                                                 \
+    hipError_t e__ = alloc(&(ptr), (n));                                                            \
+    if (e__ != hipSuccess)                                                                          \
+    {                                                                                               \
+      freeAll(hp);                                                                                  \
+      return fail(nullptr, MPPI_ERR_HIP, std::string("hipMalloc " #ptr ": ") + hipGetErrorString(e__)); \
+    }                                                                                               \
+  } while (0)
+  ALLOC_OR_FAIL(h->x0_d, (size_t)D * S);
+  ALLOC_OR_FAIL(h->mean_d, (size_t)D * T * C);
+  ALLOC_OR_FAIL(h->costs_d, (size_t)D * K);
+  ALLOC_OR_FAIL(h->partials_d, (size_t)D * h->num_blocks * h->PS);
+  ALLOC_OR_FAIL(h->send_d, (size_t)D * h->PS);
+  ALLOC_OR_FAIL(h->recv_d, (size_t)world * D * h->PS);
+  ALLOC_OR_FAIL(h->gather_tmp_d, (size_t)world * D * h->PS);
+  ALLOC_OR_FAIL(h->stats_d, (size_t)D * kernels::STATS_STRIDE);
+  ALLOC_OR_FAIL(h->history_d, (size_t)2 * C);
+  ALLOC_OR_FAIL(h->ctrl_in_d, (size_t)D * T * C);
+  ALLOC_OR_FAIL(h->ctrl_out_d, (size_t)D * T * C);
+  ALLOC_OR_FAIL(h->state_out_d, (size_t)D * T * S);
+  ALLOC_OR_FAIL(h->step_x_d, (size_t)S);
+  ALLOC_OR_FAIL(h->step_u_d, (size_t)C);
+  if (cfg->save_samples)
+    ALLOC_OR_FAIL(h->samples_d, (size_t)D * K * T * C);
+#undef ALLOC_OR_FAIL
+  HIP_TRY(nullptr, hipEventCreate(&h->ev_a));
+  HIP_TRY(nullptr, hipEventCreate(&h->ev_b));
+  HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
+
+  h->control_h.assign((size_t)T * C, 0.0f);
+  h->history_h.assign((size_t)2 * C, 0.0f);
+  h->state_h.assign((size_t)T * S, 0.0f);
+  h->nominal_control_h.assign((size_t)T * C, 0.0f);
+  h->nominal_state_h.assign((size_t)T * S, 0.0f);
+  h->slide_scale_h.assign(C, 0.0f);  // controller.cuh:67 slide_control_scale_ = Zero()
+  *out = h.release();
+  return MPPI_OK;
+}
+
+void mppi_destroy(mppi_handle h)
+{
+  if (!h)
+    return;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream)
+    (void)hipStreamSynchronize(h->stream);
+  freeAll(h);
+  delete h;
+}
+
+mppi_status mppi_get_dims(mppi_handle h, int* s, int* c, int* o, int* d)
+{
+  CHECK_HANDLE(h);
+  if (s)
+    *s = h->S;
+  if (c)
+    *c = h->C;
+  if (o)
+    *o = h->O;
+  if (d)
+    *d = h->D;
+  return MPPI_OK;
+}
+
+mppi_status mppi_get_local_rollouts(mppi_handle h, int* k_local, int* k_offset)
+{
+  CHECK_HANDLE(h);
+  if (k_local)
+    *k_local = h->K_local;
+  if (k_offset)
+    *k_offset = h->K_offset;
+  return MPPI_OK;
+}
+
+/* ---------------------------------------------------------------- parameters ------------------------------------- */
+mppi_status mppi_set_dynamics_params(mppi_handle h, const void* pod, size_t nbytes)
+{
+  CHECK_HANDLE(h);
+  if (!pod)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_dynamics_params: null");
+  mppi_status s = h->model->setDynamicsParams(pod, nbytes);
+  return s == MPPI_OK ? s : fail(h, s, "mppi_set_dynamics_params: size does not match the model's parameter struct");
+}
+mppi_status mppi_set_cost_params(mppi_handle h, const void* pod, size_t nbytes)
+{
+  CHECK_HANDLE(h);
+  if (!pod)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_cost_params: null");
+  mppi_status s = h->model->setCostParams(pod, nbytes);
+  return s == MPPI_OK ? s : fail(h, s, "mppi_set_cost_params: size does not match the model's parameter struct");
+}
+mppi_status mppi_set_sampler_params(mppi_handle h, const mppi_gaussian_params* p)
+{
+  CHECK_HANDLE(h);
+  if (!p || !p->std_dev || !p->control_cost_coeff)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_sampler_params: null");
+  for (int i = 0; i < h->C * h->D; i++)
+    if (!(p->std_dev[i] > 0.0f))
+      return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_sampler_params: std_dev must be > 0");
+  h->model->setSamplerParams(p, h->D);
+  return MPPI_OK;
+}
+mppi_status mppi_set_control_ranges(mppi_handle h, const float* lo_hi)
+{
+  CHECK_HANDLE(h);
+  if (!lo_hi)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_control_ranges: null");
+  h->model->setControlRanges(lo_hi);
+  return MPPI_OK;
+}
+mppi_status mppi_set_control_deadband(mppi_handle h, const float* db)
+{
+  CHECK_HANDLE(h);
+  if (!db)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_control_deadband: null");
+  h->model->setControlDeadband(db);
+  return MPPI_OK;
+}
+mppi_status mppi_set_lambda_alpha(mppi_handle h, float lambda, float alpha)
+{
+  CHECK_HANDLE(h);
+  if (!(lambda > 0.0f))
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_lambda_alpha: lambda must be > 0");
+  h->cfg.lambda = lambda;
+  h->cfg.alpha = alpha;
+  return MPPI_OK;
+}
+mppi_status mppi_set_num_iters(mppi_handle h, int n)
+{
+  CHECK_HANDLE(h);
+  if (n <= 0)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_num_iters: must be > 0");
+  h->cfg.num_iters = n;
+  return MPPI_OK;
+}
+mppi_status mppi_set_slide_control_scale(mppi_handle h, const float* scale)
+{
+  CHECK_HANDLE(h);
+  if (!scale)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_slide_control_scale: null");
+  for (int i = 0; i < h->C; i++)
+    h->slide_scale_h[i] = scale[i];
+  return MPPI_OK;
+}
+mppi_status mppi_set_nominal_threshold(mppi_handle h, float t)
+{
+  CHECK_HANDLE(h);
+  h->nominal_threshold = t;
+  return MPPI_OK;
+}
+mppi_status mppi_set_seed(mppi_handle h, uint64_t seed)
+{
+  CHECK_HANDLE(h);
+  h->cfg.seed = seed;
+  h->generation = 0;  // controller.cu:200-207: offset reset on reseed
+  return MPPI_OK;
+}
+
+/* ---------------------------------------------------------------- internals -------------------------------------- */
+static mppi_status launchCombine(mppi_handle h, const float* records, int num_records, int finalize, float* record_out,
+                                 int k_total)
+{
+  kernels::CombineArgs a{};
+  a.records_d = records;
+  a.num_records = num_records;
+  a.TC = h->TC;
+  a.PS = h->PS;
+  a.lambda = h->cfg.lambda;
+  a.num_rollouts_total = k_total;
+  a.finalize = finalize;
+  a.mean_out_d = h->mean_d;
+  a.record_out_d = record_out;
+  a.stats_out_d = h->stats_d;
+  const size_t smem = sizeof(float) * (size_t)((num_records + 3) / 4 * 4);
+  hipLaunchKernelGGL(kernels::combineKernel, dim3(h->D), dim3(kernels::COMBINE_THREADS), smem, h->stream, a);
+  HIP_TRY(h, hipGetLastError());
+  return MPPI_OK;
+}
+
+static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
+{
+  kernels::RolloutArgs a{};
+  a.dt = h->cfg.dt;
+  a.num_timesteps = h->cfg.num_timesteps;
+  a.num_rollouts = h->K_local;
+  a.lambda = h->cfg.lambda;
+  a.alpha = h->cfg.alpha;
+  a.init_x_d = h->x0_d;
+  a.trajectory_costs_d = h->costs_d;
+  a.partials_d = h->partials_d;
+  a.save_samples = h->samples_d ? 1 : 0;
+  SamplerLaunchState s{};
+  s.num_rollouts_local = h->K_local;
+  s.num_rollouts_global = h->cfg.num_rollouts;
+  s.rollout_offset = h->K_offset;
+  s.num_timesteps = h->cfg.num_timesteps;
+  s.num_distributions = h->D;
+  s.control_means_d = h->mean_d;
+  s.eps_d = nullptr;
+  if (h->noise_source == MPPI_NOISE_INJECTED)
+  {
+    if (!h->eps_d || h->n_eps_iters <= 0)
+      return fail(h, MPPI_ERR_STATE, "noise source is MPPI_NOISE_INJECTED but no noise has been injected");
+    s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * h->K_local * h->TC;
+  }
+  s.control_samples_d = h->samples_d;
+  s.seed = h->cfg.seed;
+  s.generation = h->generation;
+  s.iteration = iteration;
+  s.optimization_stride = stride;
+  std::string err;
+  mppi_status st = h->model->launchRollout(h->bx, h->by, h->bz, a, s, h->stream, err);
+  if (st != MPPI_OK)
+    return fail(h, st, err);
+  h->generation++;
+  return MPPI_OK;
+}
+
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+static nccl_allgather_fn g_ncclAllGather = nullptr;
+
+/** regroup [world][D][PS] -> [D][world][PS] so that each system's records are contiguous for combineKernel */
+__global__ void regroupRecordsKernel(const float* __restrict__ in, float* __restrict__ out, int world, int D, int PS)
+{
+  const int n = world * D * PS;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+  {
+    const int g = i / (D * PS);
+    const int r = i - g * D * PS;
+    const int z = r / PS;
+    const int j = r - z * PS;
+    out[((size_t)z * world + g) * PS + j] = in[i];
+  }
+}
+
+static mppi_status iterationLocal(mppi_handle h, int iteration, int stride)
+{
+  MPPI_TRY(launchRollout(h, iteration, stride));
+  if (h->cfg.world_size == 1)
+    return launchCombine(h, h->partials_d, h->num_blocks, 1, nullptr, h->cfg.num_rollouts);
+  return launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local);
+}
+
+static mppi_status iterationMerge(mppi_handle h)
+{
+  if (h->cfg.world_size == 1)
+    return MPPI_OK;
+  const int n = h->cfg.world_size * h->D * h->PS;
+  hipLaunchKernelGGL(regroupRecordsKernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->recv_d, h->gather_tmp_d,
+                     h->cfg.world_size, h->D, h->PS);
+  HIP_TRY(h, hipGetLastError());
+  return launchCombine(h, h->gather_tmp_d, h->cfg.world_size, 1, nullptr, h->cfg.num_rollouts);
+}
+
+static mppi_status iteration(mppi_handle h, int it, int stride)
+{
+  MPPI_TRY(iterationLocal(h, it, stride));
+  if (h->cfg.world_size > 1)
+  {
+    if (!h->comm || !g_ncclAllGather)
+      return fail(h, MPPI_ERR_STATE,
+                  "world_size > 1: call mppi_comm_init_rccl first, or drive the exchange yourself with "
+                  "mppi_iteration_local / mppi_get_exchange_buffers / mppi_iteration_merge");
+    const int rc = g_ncclAllGather(h->send_d, h->recv_d, (size_t)h->D * h->PS, /*ncclFloat32*/ 7, h->comm, h->stream);
+    if (rc != 0)
+      return fail(h, MPPI_ERR_COMM, "ncclAllGather failed with code " + std::to_string(rc));
+    MPPI_TRY(iterationMerge(h));
+  }
+  return MPPI_OK;
+}
+
+static mppi_status fetchStats(mppi_handle h)
+{
+  float st[2 * kernels::STATS_STRIDE] = { 0 };
+  HIP_TRY(h, hipMemcpyAsync(st, h->stats_d, sizeof(float) * h->D * kernels::STATS_STRIDE, hipMemcpyDeviceToHost,
+                            h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  mppi_system_stats* sys[2] = { &h->stats_h.real_sys, &h->stats_h.nominal_sys };
+  for (int z = 0; z < h->D; z++)
+  {
+    const float* s = st + z * kernels::STATS_STRIDE;
+    sys[z]->baseline = s[0];
+    sys[z]->normalizer = s[1];
+    sys[z]->free_energy_mean = s[2];
+    sys[z]->free_energy_variance = s[3];
+    sys[z]->free_energy_modified_variance = s[4];
+  }
+  return MPPI_OK;
+}
+
+static bool allFinite(const std::vector<float>& v)
+{
+  for (float f : v)
+    if (!std::isfinite(f))
+      return false;
+  return true;
+}
+
+/** smoothing / state trajectories / constraints for the D systems in ctrl_in_d, results to the host vectors */
+static mppi_status finalize(mppi_handle h, const float* ctrl_in_d, int smooth_mask, int constrain_mask,
+                            std::vector<float>* ctrl_out[2], std::vector<float>* state_out[2])
+{
+  const int T = h->cfg.num_timesteps;
+  HIP_TRY(h, hipMemcpyAsync(h->history_d, h->history_h.data(), sizeof(float) * 2 * h->C, hipMemcpyHostToDevice,
+                            h->stream));
+  kernels::FinalizeArgs a{};
+  a.control_in_d = ctrl_in_d;
+  a.history_d = h->history_d;
+  a.x0_d = h->x0_d;
+  a.control_out_d = h->ctrl_out_d;
+  a.state_out_d = h->state_out_d;
+  a.dt = h->cfg.dt;
+  a.num_timesteps = T;
+  a.smooth_mask = smooth_mask;
+  a.constrain_mask = constrain_mask;
+  std::string err;
+  mppi_status st = h->model->launchFinalize(h->D, a, h->stream, err);
+  if (st != MPPI_OK)
+    return fail(h, st, err);
+  for (int z = 0; z < h->D; z++)
+  {
+    if (ctrl_out[z])
+      HIP_TRY(h, hipMemcpyAsync(ctrl_out[z]->data(), h->ctrl_out_d + (size_t)z * T * h->C, sizeof(float) * T * h->C,
+                                hipMemcpyDeviceToHost, h->stream));
+    if (state_out[z])
+      HIP_TRY(h, hipMemcpyAsync(state_out[z]->data(), h->state_out_d + (size_t)z * T * h->S, sizeof(float) * T * h->S,
+                                hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+/* ---------------------------------------------------------------- control loop ----------------------------------- */
+mppi_status mppi_set_nominal_control(mppi_handle h, const float* u)
+{
+  CHECK_HANDLE(h);
+  if (!u)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_nominal_control: null");
+  std::copy(u, u + h->control_h.size(), h->control_h.begin());
+  if (h->D == 2)
+    std::copy(u, u + h->control_h.size(), h->nominal_control_h.begin());
+  return MPPI_OK;
+}
+
+mppi_status mppi_inject_noise(mppi_handle h, const float* eps, int n_iters)
+{
+  CHECK_HANDLE(h);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (n_iters <= 0 || !eps)
+  {
+    h->noise_source = h->cfg.noise_source == MPPI_NOISE_INJECTED ? MPPI_NOISE_PHILOX_FUSED : h->cfg.noise_source;
+    return MPPI_OK;
+  }
+  const size_t n = (size_t)n_iters * h->K_local * h->TC;
+  if (n_iters != h->n_eps_iters)
+  {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->eps_d)
+      HIP_TRY(h, hipFree(h->eps_d));
+    h->eps_d = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&h->eps_d, n * sizeof(float)));
+    h->n_eps_iters = n_iters;
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->eps_d, eps, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->noise_source = MPPI_NOISE_INJECTED;
+  h->generation = 0;
+  return MPPI_OK;
+}
+
+static mppi_status uploadVanilla(mppi_handle h, const float* x0)
+{
+  HIP_TRY(h, hipMemcpyAsync(h->x0_d, x0, sizeof(float) * h->S, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice, h->stream));
+  return MPPI_OK;
+}
+
+static mppi_status uploadTube(mppi_handle h, const float* x0_actual)
+{
+  HIP_TRY(h, hipMemcpyAsync(h->x0_d, x0_actual, sizeof(float) * h->S, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->x0_d + h->S, h->nominal_state_h.data(), sizeof(float) * h->S, hipMemcpyHostToDevice,
+                            h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->mean_d + h->TC, h->nominal_control_h.data(), sizeof(float) * h->TC,
+                            hipMemcpyHostToDevice, h->stream));
+  return MPPI_OK;
+}
+
+static mppi_status computeControlVanilla(mppi_handle h, const float* x0, int stride)
+{
+  MPPI_TRY(uploadVanilla(h, x0));
+  for (int it = 0; it < h->cfg.num_iters; it++)
+    MPPI_TRY(iteration(h, it, stride));
+  std::vector<float>* co[2] = { &h->control_h, nullptr };
+  std::vector<float>* so[2] = { &h->state_h, nullptr };
+  MPPI_TRY(finalize(h, h->mean_d, /*smooth*/ 1, /*constrain*/ 1, co, so));
+  MPPI_TRY(fetchStats(h));
+  if (!allFinite(h->control_h))
+    return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control sequence");
+  return MPPI_OK;
+}
+
+/** reference: Tube-MPPI/tube_mppi_controller.cu:157-299 */
+static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride)
+{
+  const int S = h->S;
+  if (!h->nominal_state_init)
+  {
+    std::copy(x0, x0 + S, h->nominal_state_h.begin());
+    h->nominal_state_init = true;
+  }
+  std::vector<float>* co[2] = { &h->control_h, &h->nominal_control_h };
+  std::vector<float>* so[2] = { &h->state_h, &h->nominal_state_h };
+  for (int it = 0; it < h->cfg.num_iters; it++)
+  {
+    MPPI_TRY(uploadTube(h, x0));
+    MPPI_TRY(iteration(h, it, stride));
+    // new means -> host control_ / nominal_control_trajectory_, then both state trajectories (:255-263)
+    MPPI_TRY(finalize(h, h->mean_d, 0, 0, co, so));
+    MPPI_TRY(fetchStats(h));
+    if (h->stats_h.real_sys.baseline < h->stats_h.nominal_sys.baseline + h->nominal_threshold)
+    {
+      h->stats_h.nominal_state_used = 0;
+      h->nominal_state_h = h->state_h;
+      h->nominal_control_h = h->control_h;
+    }
+    else
+    {
+      h->stats_h.nominal_state_used = 1;
+    }
+  }
+  // smoothControlTrajectory() smooths the nominal control (:281, :325-329), then computeStateTrajectory(state)
+  HIP_TRY(h, hipMemcpyAsync(h->ctrl_in_d, h->control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->ctrl_in_d + h->TC, h->nominal_control_h.data(), sizeof(float) * h->TC,
+                            hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->x0_d + S, h->nominal_state_h.data(), sizeof(float) * S, hipMemcpyHostToDevice,
+                            h->stream));
+  MPPI_TRY(finalize(h, h->ctrl_in_d, /*smooth nominal*/ 2, 0, co, so));
+  if (!allFinite(h->control_h) || !allFinite(h->nominal_control_h))
+    return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control sequence");
+  return MPPI_OK;
+}
+
+mppi_status mppi_compute_control(mppi_handle h, const float* x0, int stride)
+{
+  CHECK_HANDLE(h);
+  if (!x0 || stride < 0)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_compute_control: null state or negative stride");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  h->last_stride = stride;
+  if (h->cfg.controller == MPPI_CONTROLLER_TUBE)
+    return computeControlTube(h, x0, stride);
+  return computeControlVanilla(h, x0, stride);
+}
+
+mppi_status mppi_get_control_seq(mppi_handle h, float* u)
+{
+  CHECK_HANDLE(h);
+  if (!u)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  std::copy(h->control_h.begin(), h->control_h.end(), u);
+  return MPPI_OK;
+}
+mppi_status mppi_get_state_seq(mppi_handle h, float* x)
+{
+  CHECK_HANDLE(h);
+  if (!x)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  std::copy(h->state_h.begin(), h->state_h.end(), x);
+  return MPPI_OK;
+}
+mppi_status mppi_get_nominal_control_seq(mppi_handle h, float* u)
+{
+  CHECK_HANDLE(h);
+  if (!u)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  if (h->D != 2)
+    return fail(h, MPPI_ERR_STATE, "no nominal system in this controller");
+  std::copy(h->nominal_control_h.begin(), h->nominal_control_h.end(), u);
+  return MPPI_OK;
+}
+mppi_status mppi_get_nominal_state_seq(mppi_handle h, float* x)
+{
+  CHECK_HANDLE(h);
+  if (!x)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  if (h->D != 2)
+    return fail(h, MPPI_ERR_STATE, "no nominal system in this controller");
+  std::copy(h->nominal_state_h.begin(), h->nominal_state_h.end(), x);
+  return MPPI_OK;
+}
+
+/** reference: controllers/controller.cuh:602-615 */
+static void saveControlHistory(int steps, const std::vector<float>& u, std::vector<float>& hist, int C)
+{
+  if (steps == 1)
+  {
+    for (int c = 0; c < C; c++)
+    {
+      hist[c] = hist[C + c];
+      hist[C + c] = u[c];
+    }
+  }
+  else if (steps >= 2)
+  {
+    for (int c = 0; c < C; c++)
+    {
+      hist[c] = u[(size_t)(steps - 2) * C + c];
+      hist[C + c] = u[(size_t)(steps - 1) * C + c];
+    }
+  }
+}
+/** reference: controllers/controller.cuh:588-600 */
+static void slideSequence(std::vector<float>& u, int T, int C, int steps, const float* zero, const float* scale)
+{
+  for (int i = 0; i < T; i++)
+  {
+    const int ind = std::min(i + steps, T - 1);
+    for (int c = 0; c < C; c++)
+    {
+      u[(size_t)i * C + c] = u[(size_t)ind * C + c];
+      if (i + steps > T - 1)
+        u[(size_t)i * C + c] = (u[(size_t)ind * C + c] - zero[c]) * scale[c] + zero[c];
+    }
+  }
+}
+
+mppi_status mppi_slide(mppi_handle h, int steps)
+{
+  CHECK_HANDLE(h);
+  const int T = h->cfg.num_timesteps, C = h->C;
+  if (steps < 0 || steps > T)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_slide: steps out of range");
+  std::vector<float> zero(C);
+  h->model->getZeroControl(zero.data());
+  if (h->cfg.controller == MPPI_CONTROLLER_TUBE)
+  {
+    // tube_mppi_controller.cu:312-323: updateNominalState(nominal_control.col(0)) — one in-place model step, no clamp
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(h->step_x_d, h->nominal_state_h.data(), sizeof(float) * h->S, hipMemcpyHostToDevice,
+                              h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->step_u_d, h->nominal_control_h.data(), sizeof(float) * C, hipMemcpyHostToDevice,
+                              h->stream));
+    std::string err;
+    mppi_status st = h->model->launchModelStep(h->step_x_d, h->step_u_d, h->cfg.dt, 0, h->stream, err);
+    if (st != MPPI_OK)
+      return fail(h, st, err);
+    HIP_TRY(h, hipMemcpyAsync(h->nominal_state_h.data(), h->step_x_d, sizeof(float) * h->S, hipMemcpyDeviceToHost,
+                              h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    saveControlHistory(steps, h->nominal_control_h, h->history_h, C);
+    slideSequence(h->nominal_control_h, T, C, steps, zero.data(), h->slide_scale_h.data());
+    slideSequence(h->control_h, T, C, steps, zero.data(), h->slide_scale_h.data());
+    return MPPI_OK;
+  }
+  saveControlHistory(steps, h->control_h, h->history_h, C);
+  slideSequence(h->control_h, T, C, steps, zero.data(), h->slide_scale_h.data());
+  return MPPI_OK;
+}
+
+mppi_status mppi_get_costs(mppi_handle h, float* costs)
+{
+  CHECK_HANDLE(h);
+  if (!costs)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(costs, h->costs_d, sizeof(float) * h->D * h->K_local, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+mppi_status mppi_get_stats(mppi_handle h, mppi_stats* out)
+{
+  CHECK_HANDLE(h);
+  if (!out)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const int used = h->stats_h.nominal_state_used;
+  MPPI_TRY(fetchStats(h));
+  h->stats_h.nominal_state_used = used;
+  *out = h->stats_h;
+  return MPPI_OK;
+}
+mppi_status mppi_get_sampled_controls(mppi_handle h, float* v)
+{
+  CHECK_HANDLE(h);
+  if (!v)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  if (!h->samples_d)
+    return fail(h, MPPI_ERR_STATE, "mppi_get_sampled_controls: handle was created without save_samples");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(v, h->samples_d, sizeof(float) * h->D * h->K_local * h->TC, hipMemcpyDeviceToHost,
+                            h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+/* ---------------------------------------------------------------- device-resident loop --------------------------- */
+mppi_status mppi_upload_state(mppi_handle h, const float* x0)
+{
+  CHECK_HANDLE(h);
+  if (!x0)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(h->x0_d, x0, sizeof(float) * h->D * h->S, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice, h->stream));
+  if (h->D == 2)
+    HIP_TRY(h, hipMemcpyAsync(h->mean_d + h->TC, h->nominal_control_h.data(), sizeof(float) * h->TC,
+                              hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+mppi_status mppi_get_optimal_control(mppi_handle h, float* u_out)
+{
+  CHECK_HANDLE(h);
+  if (!u_out)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(u_out, h->mean_d, sizeof(float) * h->D * h->TC, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+mppi_status mppi_optimize(mppi_handle h, int n, int synchronize)
+{
+  CHECK_HANDLE(h);
+  if (n < 0)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_optimize: negative iteration count");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  for (int i = 0; i < n; i++)
+    MPPI_TRY(iteration(h, 0, h->last_stride));
+  if (synchronize)
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+mppi_status mppi_time_iterations(mppi_handle h, int n, float* ms_total, float* ms_rollout)
+{
+  CHECK_HANDLE(h);
+  if (n <= 0 || !ms_total)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_time_iterations: bad arguments");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  // pass 1: whole iterations between two events
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipEventRecord(h->ev_a, h->stream));
+  for (int i = 0; i < n; i++)
+    MPPI_TRY(iteration(h, 0, h->last_stride));
+  HIP_TRY(h, hipEventRecord(h->ev_b, h->stream));
+  HIP_TRY(h, hipEventSynchronize(h->ev_b));
+  HIP_TRY(h, hipEventElapsedTime(ms_total, h->ev_a, h->ev_b));
+  if (ms_rollout)
+  {
+    // pass 2: the same iterations, events around each rollout launch only
+    std::vector<hipEvent_t> ev(2 * (size_t)n);
+    for (auto& e : ev)
+      HIP_TRY(h, hipEventCreate(&e));
+    for (int i = 0; i < n; i++)
+    {
+      HIP_TRY(h, hipEventRecord(ev[2 * i], h->stream));
+      MPPI_TRY(launchRollout(h, 0, h->last_stride));
+      HIP_TRY(h, hipEventRecord(ev[2 * i + 1], h->stream));
+      if (h->cfg.world_size == 1)
+        MPPI_TRY(launchCombine(h, h->partials_d, h->num_blocks, 1, nullptr, h->cfg.num_rollouts));
+      else
+        MPPI_TRY(launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    float sum = 0.0f;
+    for (int i = 0; i < n; i++)
+    {
+      float ms = 0.0f;
+      HIP_TRY(h, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+      sum += ms;
+    }
+    for (auto& e : ev)
+      (void)hipEventDestroy(e);
+    *ms_rollout = sum;
+  }
+  return MPPI_OK;
+}
+
+mppi_status mppi_synchronize(mppi_handle h)
+{
+  CHECK_HANDLE(h);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+/* ---------------------------------------------------------------- multi-GPU -------------------------------------- */
+mppi_status mppi_get_exchange_buffers(mppi_handle h, void** send, void** recv, size_t* floats_per_rank)
+{
+  CHECK_HANDLE(h);
+  if (send)
+    *send = h->send_d;
+  if (recv)
+    *recv = h->recv_d;
+  if (floats_per_rank)
+    *floats_per_rank = (size_t)h->D * h->PS;
+  return MPPI_OK;
+}
+mppi_status mppi_iteration_local(mppi_handle h)
+{
+  CHECK_HANDLE(h);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  return iterationLocal(h, 0, h->last_stride);
+}
+mppi_status mppi_iteration_merge(mppi_handle h)
+{
+  CHECK_HANDLE(h);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  return iterationMerge(h);
+}
+
+static void* loadRccl(std::string& err)
+{
+  static void* lib = nullptr;
+  if (lib)
+    return lib;
+  const char* names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" };
+  for (const char* n : names)
+  {
+    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (lib)
+      return lib;
+  }
+  err = std::string("cannot dlopen librccl.so: ") + dlerror();
+  return nullptr;
+}
+
+mppi_status mppi_rccl_unique_id(void* out_bytes, size_t capacity, size_t* nbytes)
+{
+  if (!out_bytes || capacity < 128)
+    return MPPI_ERR_INVALID_ARG;
+  std::string err;
+  void* lib = loadRccl(err);
+  if (!lib)
+    return fail(nullptr, MPPI_ERR_COMM, err);
+  typedef int (*fn_t)(void*);
+  fn_t f = (fn_t)dlsym(lib, "ncclGetUniqueId");
+  if (!f)
+    return fail(nullptr, MPPI_ERR_COMM, "ncclGetUniqueId not found");
+  const int rc = f(out_bytes);  // ncclUniqueId is 128 bytes
+  if (nbytes)
+    *nbytes = 128;
+  return rc == 0 ? MPPI_OK : fail(nullptr, MPPI_ERR_COMM, "ncclGetUniqueId failed");
+}
+
+mppi_status mppi_comm_init_rccl(mppi_handle h, const void* unique_id, size_t nbytes)
+{
+  CHECK_HANDLE(h);
+  if (!unique_id || nbytes != 128)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_comm_init_rccl: unique id must be 128 bytes");
+  std::string err;
+  void* lib = loadRccl(err);
+  if (!lib)
+    return fail(h, MPPI_ERR_COMM, err);
+  struct Id
+  {
+    char b[128];
+  } id;
+  memcpy(id.b, unique_id, 128);
+  typedef int (*init_fn)(void**, int, Id, int);
+  init_fn f = (init_fn)dlsym(lib, "ncclCommInitRank");
+  g_ncclAllGather = (nccl_allgather_fn)dlsym(lib, "ncclAllGather");
+  if (!f || !g_ncclAllGather)
+    return fail(h, MPPI_ERR_COMM, "ncclCommInitRank / ncclAllGather not found in librccl");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const int rc = f(&h->comm, h->cfg.world_size, id, h->cfg.rank);
+  if (rc != 0)
+    return fail(h, MPPI_ERR_COMM, "ncclCommInitRank failed with code " + std::to_string(rc));
+  h->rccl_lib = lib;
+  return MPPI_OK;
+}
+
+/* ---------------------------------------------------------------- kernel-level operators ------------------------- */
+mppi_status mppi_rollout_costs(mppi_handle h, const float* x0, int stride)
+{
+  CHECK_HANDLE(h);
+  if (!x0)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(h->x0_d, x0, sizeof(float) * h->D * h->S, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice, h->stream));
+  if (h->D == 2)
+    HIP_TRY(h, hipMemcpyAsync(h->mean_d + h->TC, h->nominal_control_h.data(), sizeof(float) * h->TC,
+                              hipMemcpyHostToDevice, h->stream));
+  MPPI_TRY(launchRollout(h, 0, stride));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+mppi_status mppi_model_step(mppi_handle h, float* x, float* u, float dt, int enforce)
+{
+  CHECK_HANDLE(h);
+  if (!x || !u)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(h->step_x_d, x, sizeof(float) * h->S, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->step_u_d, u, sizeof(float) * h->C, hipMemcpyHostToDevice, h->stream));
+  std::string err;
+  mppi_status st = h->model->launchModelStep(h->step_x_d, h->step_u_d, dt, enforce, h->stream, err);
+  if (st != MPPI_OK)
+    return fail(h, st, err);
+  HIP_TRY(h, hipMemcpyAsync(x, h->step_x_d, sizeof(float) * h->S, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(u, h->step_u_d, sizeof(float) * h->C, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+namespace
+{
+struct DevBuf
+{
+  float* p = nullptr;
+  ~DevBuf()
+  {
+    if (p)
+      (void)hipFree(p);
+  }
+  hipError_t alloc(size_t n)
+  {
+    return hipMalloc((void**)&p, n * sizeof(float));
+  }
+};
+mppi_status opFail(const char* what, hipError_t e)
+{
+  g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+  return MPPI_ERR_HIP;
+}
+}  // namespace
+#define OP_TRY(expr)                  \
+  do                                  \
+  {                                   \
+    hipError_t e__ = (expr);          \
+    if (e__ != hipSuccess)            \
+      return opFail(#expr, e__);      \
+  } while (0)
+
+static mppi_status opDevice(int device)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+  {
+    g_create_error = "no HIP device visible (this library has no CPU path)";
+    return MPPI_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n)
+    return MPPI_ERR_INVALID_ARG;
+  OP_TRY(hipSetDevice(device));
+  return MPPI_OK;
+}
+
+mppi_status mppi_norm_exp(float* costs, int K, float lambda_inv, float baseline, int device)
+{
+  if (!costs || K <= 0)
+    return MPPI_ERR_INVALID_ARG;
+  MPPI_TRY(opDevice(device));
+  DevBuf d;
+  OP_TRY(d.alloc(K));
+  OP_TRY(hipMemcpy(d.p, costs, sizeof(float) * K, hipMemcpyHostToDevice));
+  // reference: norm_exp_kernel_parallelization_ = 64 (controller.cuh:64) -> grid ceil(K/64) x 64
+  hipLaunchKernelGGL(kernels::normExpKernel, dim3((K + 63) / 64), dim3(64), 0, 0, K, d.p, lambda_inv, baseline);
+  OP_TRY(hipGetLastError());
+  OP_TRY(hipMemcpy(costs, d.p, sizeof(float) * K, hipMemcpyDeviceToHost));
+  return MPPI_OK;
+}
+
+mppi_status mppi_compute_weights(float* costs, int K, float lambda_inv, float* out2, int device)
+{
+  if (!costs || !out2 || K <= 0)
+    return MPPI_ERR_INVALID_ARG;
+  MPPI_TRY(opDevice(device));
+  DevBuf d, o;
+  OP_TRY(d.alloc(K));
+  OP_TRY(o.alloc(2));
+  OP_TRY(hipMemcpy(d.p, costs, sizeof(float) * K, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(kernels::computeWeightsKernel, dim3(1), dim3(kernels::COMBINE_THREADS), 0, 0, K, d.p, lambda_inv,
+                     o.p);
+  OP_TRY(hipGetLastError());
+  OP_TRY(hipMemcpy(costs, d.p, sizeof(float) * K, hipMemcpyDeviceToHost));
+  OP_TRY(hipMemcpy(out2, o.p, sizeof(float) * 2, hipMemcpyDeviceToHost));
+  return MPPI_OK;
+}
+
+mppi_status mppi_weighted_reduction(const float* weights, const float* v, float normalizer, int K, int T, int C,
+                                    float* u_out, int device)
+{
+  if (!weights || !v || !u_out || K <= 0 || T <= 0 || C <= 0)
+    return MPPI_ERR_INVALID_ARG;
+  MPPI_TRY(opDevice(device));
+  DevBuf w, vd, u;
+  const size_t TC = (size_t)T * C;
+  OP_TRY(w.alloc(K));
+  OP_TRY(vd.alloc((size_t)K * TC));
+  OP_TRY(u.alloc(TC));
+  OP_TRY(hipMemcpy(w.p, weights, sizeof(float) * K, hipMemcpyHostToDevice));
+  OP_TRY(hipMemcpy(vd.p, v, sizeof(float) * K * TC, hipMemcpyHostToDevice));
+  OP_TRY(hipMemset(u.p, 0, sizeof(float) * TC));
+  const int per_block = 32;
+  hipLaunchKernelGGL(kernels::weightedReductionKernel, dim3((K + per_block - 1) / per_block), dim3(256), 0, 0, w.p,
+                     vd.p, u.p, normalizer, (int)TC, K, per_block);
+  OP_TRY(hipGetLastError());
+  OP_TRY(hipMemcpy(u_out, u.p, sizeof(float) * TC, hipMemcpyDeviceToHost));
+  return MPPI_OK;
+}
+
+__global__ void philoxNormalKernel(uint64_t seed, uint32_t generation, uint64_t e0, uint64_t e1, float* out)
+{
+  const uint64_t q0 = e0 >> 2;
+  const uint64_t nq = ((e1 + 3) >> 2) - q0;
+  for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < nq; q += (uint64_t)gridDim.x * blockDim.x)
+  {
+    float z[4];
+    mppi::rng::normal4(seed, generation, 0u, q0 + q, z);
+    for (int l = 0; l < 4; l++)
+    {
+      const uint64_t e = (q0 + q) * 4 + l;
+      if (e >= e0 && e < e1)
+        out[e - e0] = z[l];
+    }
+  }
+}
+
+mppi_status mppi_philox_normal(uint64_t seed, uint32_t generation, int K, int T, int C, int k_begin, int k_end,
+                               float* eps_out, int device)
+{
+  if (!eps_out || K <= 0 || T <= 0 || C <= 0 || k_begin < 0 || k_end > K || k_begin >= k_end)
+    return MPPI_ERR_INVALID_ARG;
+  MPPI_TRY(opDevice(device));
+  const uint64_t e0 = (uint64_t)k_begin * T * C, e1 = (uint64_t)k_end * T * C;
+  DevBuf d;
+  OP_TRY(d.alloc(e1 - e0));
+  hipLaunchKernelGGL(philoxNormalKernel, dim3(256), dim3(256), 0, 0, seed, generation, e0, e1, d.p);
+  OP_TRY(hipGetLastError());
+  OP_TRY(hipMemcpy(eps_out, d.p, sizeof(float) * (e1 - e0), hipMemcpyDeviceToHost));
+  return MPPI_OK;
+}
+
+__global__ void detEvalKernel(int func, const float* x, float* y, int n)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+  {
+    float r = 0.0f;
+    switch (func)
+    {
+      case 0: r = mppi::det::sin(x[i]); break;
+      case 1: r = mppi::det::cos(x[i]); break;
+      case 2: r = mppi::det::exp(x[i]); break;
+      case 3: r = mppi::det::log(x[i]); break;
+      case 4: r = mppi::det::tanh(x[i]); break;
+      case 5: r = mppi::det::atan(x[i]); break;
+      case 6: r = mppi::det::normalizeAngle(x[i]); break;
+      case 7: r = mppi::det::sigmoid(x[i]); break;
+      case 8: r = mppi::det::sqrt(x[i]); break;
+      case 9: r = 1.0f / x[i]; break;
+    }
+    y[i] = r;
+  }
+}
+
+mppi_status mppi_det_eval(int func, const float* x, float* y, int n, int device)
+{
+  if (!x || !y || n <= 0)
+    return MPPI_ERR_INVALID_ARG;
+  MPPI_TRY(opDevice(device));
+  DevBuf dx, dy;
+  OP_TRY(dx.alloc(n));
+  OP_TRY(dy.alloc(n));
+  OP_TRY(hipMemcpy(dx.p, x, sizeof(float) * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(detEvalKernel, dim3(256), dim3(256), 0, 0, func, dx.p, dy.p, n);
+  OP_TRY(hipGetLastError());
+  OP_TRY(hipMemcpy(y, dy.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+  return MPPI_OK;
+}
+
+}  // extern "C"

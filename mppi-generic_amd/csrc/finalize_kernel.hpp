@@ -1,0 +1,152 @@
+/**
+ * finalize_kernel.hpp — post-processing of the optimised control sequence, on the device.
+ *
+ * Replaces the reference's host-side tail of computeControl (controllers/MPPI/mppi_controller.cu:225-231):
+ *   smoothControlTrajectoryHelper  controllers/controller.cuh:557-586   5-tap Savitzky-Golay [-3,12,17,12,-3]/35 over
+ *                                                                        [hist0, hist1, u_0..u_{T-1}, u_{T-1}, u_{T-1}]
+ *   computeStateTrajectoryHelper   controllers/controller.cuh:643-663   Euler re-rollout of u* (T-1 steps)
+ *   enforceConstraints on every column of the control                    mppi_controller.cu:227-231
+ * The reference runs these through the plugins' Eigen host overloads; here the SAME device plugin code that the rollout
+ * kernel calls is reused (one block per system, blockDim = (1, BY, 1)), so a model needs no host implementation and the
+ * nominal trajectory is propagated with exactly the arithmetic of the rollouts.
+ */
+#ifndef MPPI_AMD_FINALIZE_KERNEL_HPP_
+#define MPPI_AMD_FINALIZE_KERNEL_HPP_
+
+#include <hip/hip_runtime.h>
+#include "mppi_amd/plugin/managed.hpp"
+#include "mppi_amd/plugin/math_utils.hpp"
+#include "mppi_amd/plugin/parallel_utils.hpp"
+
+namespace mppi
+{
+namespace kernels
+{
+struct FinalizeArgs
+{
+  const float* control_in_d;  ///< [D][T][C]  (the sampler's control means after the last iteration)
+  const float* history_d;     ///< [2][C] control history (row 0 older), shared by the systems that smooth
+  const float* x0_d;          ///< [D][S]
+  float* control_out_d;       ///< [D][T][C]
+  float* state_out_d;         ///< [D][T][S]
+  float dt;
+  int num_timesteps;
+  int smooth_mask;            ///< bit z set: smooth system z
+  int constrain_mask;         ///< bit z set: enforceConstraints on every column of system z's control
+};
+
+template <class DYN_T>
+__host__ inline size_t finalizeSharedBytes(const DYN_T& dyn, int num_timesteps)
+{
+  constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
+  size_t n = calcClassSharedMemSize(&dyn, 1);
+  n += sizeof(float) * (math::nearest_multiple_4((num_timesteps + 4) * C) + math::nearest_multiple_4(num_timesteps * C) +
+                        4 * math::nearest_multiple_4(S) + math::nearest_multiple_4(C) + math::nearest_multiple_4(O));
+  return n;
+}
+
+template <class DYN_T, int BY>
+__global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const FinalizeArgs a)
+{
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == 1);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_y() == BY);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_z() == 1);
+  __builtin_assume(__builtin_amdgcn_workitem_id_x() == 0);
+  __builtin_assume(__builtin_amdgcn_workitem_id_y() < BY);
+  __builtin_assume(__builtin_amdgcn_workitem_id_z() == 0);
+  DYN_T* dynamics = &dynamics_obj;
+  constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
+  const int T = a.num_timesteps;
+  const int z = (int)blockIdx.x;
+  const int ty = (int)__builtin_amdgcn_workitem_id_y();
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* theta_s = reinterpret_cast<float*>(smem_raw);
+  float* buf = theta_s + calcClassSharedMemSize(dynamics, 1) / (int)sizeof(float);  // [(T+4)][C]
+  float* ctrl = buf + math::nearest_multiple_4((T + 4) * C);                         // [T][C]
+  float* x = ctrl + math::nearest_multiple_4(T * C);
+  float* xn = x + math::nearest_multiple_4(S);
+  float* xdot = xn + math::nearest_multiple_4(S);
+  float* zero_state = xdot + math::nearest_multiple_4(S);
+  float* u = zero_state + math::nearest_multiple_4(S);
+  float* y = u + math::nearest_multiple_4(C);
+
+  const float* uin = a.control_in_d + (size_t)z * T * C;
+
+  if ((a.smooth_mask >> z) & 1)
+  {
+    for (int i = ty; i < C; i += BY)
+    {
+      buf[0 * C + i] = a.history_d[0 * C + i];
+      buf[1 * C + i] = a.history_d[1 * C + i];
+      buf[(T + 2) * C + i] = uin[(T - 1) * C + i];
+      buf[(T + 3) * C + i] = uin[(T - 1) * C + i];
+    }
+    for (int e = ty; e < T * C; e += BY)
+      buf[2 * C + e] = uin[e];
+    __syncthreads();
+    // filter_coefficients << -3, 12, 17, 12, -3; filter_coefficients /= 35.0  (controller.cuh:564-566)
+    const float c0 = (float)(-3.0 / 35.0), c1 = (float)(12.0 / 35.0), c2 = (float)(17.0 / 35.0);
+    for (int e = ty; e < T * C; e += BY)
+    {
+      float acc = c0 * buf[e];
+      acc += c1 * buf[e + C];
+      acc += c2 * buf[e + 2 * C];
+      acc += c1 * buf[e + 3 * C];
+      acc += c0 * buf[e + 4 * C];
+      ctrl[e] = acc;
+    }
+  }
+  else
+  {
+    for (int e = ty; e < T * C; e += BY)
+      ctrl[e] = uin[e];
+  }
+  for (int i = ty; i < S; i += BY)
+  {
+    x[i] = a.x0_d[(size_t)z * S + i];
+    xdot[i] = 0.0f;
+    zero_state[i] = 0.0f;
+    a.state_out_d[((size_t)z * T + 0) * S + i] = x[i];
+  }
+  for (int i = ty; i < O; i += BY)
+    y[i] = 0.0f;
+  __syncthreads();
+  for (int i = ty; i < C; i += BY)
+    u[i] = ctrl[i];
+  __syncthreads();
+
+  // computeStateTrajectoryHelper (controller.cuh:643-663)
+  dynamics->initializeDynamics(x, u, y, theta_s, 0.0f, a.dt);
+  __syncthreads();
+  for (int t = 0; t < T - 1; t++)
+  {
+    for (int i = ty; i < C; i += BY)
+      u[i] = ctrl[t * C + i];
+    __syncthreads();
+    dynamics->enforceConstraints(x, u);
+    __syncthreads();
+    dynamics->step(x, xn, xdot, u, y, theta_s, t, a.dt);
+    __syncthreads();
+    for (int i = ty; i < S; i += BY)
+      a.state_out_d[((size_t)z * T + t + 1) * S + i] = xn[i];
+    float* tmp = x;
+    x = xn;
+    xn = tmp;
+  }
+  // enforceConstraints on every column of the control (mppi_controller.cu:227-231)
+  if ((a.constrain_mask >> z) & 1)
+  {
+    for (int t = 0; t < T; t++)
+    {
+      dynamics->enforceConstraints(zero_state, &ctrl[t * C]);
+    }
+  }
+  __syncthreads();
+  for (int e = ty; e < T * C; e += BY)
+    a.control_out_d[(size_t)z * T * C + e] = ctrl[e];
+}
+
+}  // namespace kernels
+}  // namespace mppi
+#endif

@@ -1,0 +1,310 @@
+/**
+ * model_instance.hpp — type-erased wrapper around one (DYN, COST, SAMPLER) template instantiation.
+ *
+ * The C ABI cannot carry templates, so each registered model is one ModelT<...> object behind the ModelBase
+ * interface — the role played in the reference by its explicit instantiations
+ * (reference: include/mppi/instantiations/cartpole_mppi/cartpole_mppi.cuh, src/controllers/cartpole/cartpole_mppi.cu:30-42).
+ * Block shapes are compile-time (see rollout_kernel.hpp); each model lists the shapes it is instantiated for.
+ */
+#ifndef MPPI_AMD_MODEL_INSTANCE_HPP_
+#define MPPI_AMD_MODEL_INSTANCE_HPP_
+
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string>
+
+#include "mppi_amd.h"
+#include "rollout_kernel.hpp"
+#include "reduce_kernels.hpp"
+#include "finalize_kernel.hpp"
+
+namespace mppi
+{
+namespace engine
+{
+constexpr size_t MAX_LDS_BYTES = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
+
+template <int X, int Y, int Z>
+struct Shape
+{
+};
+template <class... S>
+struct Shapes
+{
+};
+
+/** everything the sampler needs to know for one launch (the engine refreshes it before every launch) */
+struct SamplerLaunchState
+{
+  int num_rollouts_local, num_rollouts_global, rollout_offset;
+  int num_timesteps, num_distributions;
+  float* control_means_d;
+  const float* eps_d;  // nullptr => Philox
+  float* control_samples_d;
+  uint64_t seed;
+  uint32_t generation;
+  int iteration;  // opt_iter for std_dev_decay
+  int optimization_stride;
+};
+
+struct ModelBase
+{
+  int S = 0, C = 0, O = 0;
+  int default_bx = 64, default_by = 1;
+  virtual ~ModelBase() = default;
+  virtual mppi_status setDynamicsParams(const void* pod, size_t n) = 0;
+  virtual mppi_status setCostParams(const void* pod, size_t n) = 0;
+  virtual void setControlRanges(const float* lo_hi) = 0;
+  virtual void setControlDeadband(const float* db) = 0;
+  virtual void getZeroControl(float* out) const = 0;
+  virtual void setSamplerParams(const mppi_gaussian_params* p, int D) = 0;
+  virtual bool supportsShape(int bx, int by, int bz) const = 0;
+  virtual size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D) = 0;
+  virtual mppi_status launchRollout(int bx, int by, int bz, const kernels::RolloutArgs& args,
+                                    const SamplerLaunchState& s, hipStream_t stream, std::string& err) = 0;
+  virtual mppi_status launchFinalize(int D, const kernels::FinalizeArgs& a, hipStream_t stream, std::string& err) = 0;
+  /** x <- one model step (optionally after enforceConstraints on u), one block (1, by, 1) */
+  virtual mppi_status launchModelStep(float* x_d, float* u_d, float dt, int enforce, hipStream_t stream,
+                                      std::string& err) = 0;
+};
+
+template <class DYN_T, int BY>
+__global__ void __launch_bounds__(BY) modelStepKernel(DYN_T dynamics_obj, float* x_d, float* u_d, float dt, int enforce)
+{
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == 1);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_y() == BY);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_z() == 1);
+  __builtin_assume(__builtin_amdgcn_workitem_id_x() == 0);
+  __builtin_assume(__builtin_amdgcn_workitem_id_y() < BY);
+  __builtin_assume(__builtin_amdgcn_workitem_id_z() == 0);
+  DYN_T* dynamics = &dynamics_obj;
+  constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* theta_s = reinterpret_cast<float*>(smem_raw);
+  float* x = theta_s + calcClassSharedMemSize(dynamics, 1) / (int)sizeof(float);
+  float* xn = x + math::nearest_multiple_4(S);
+  float* xdot = xn + math::nearest_multiple_4(S);
+  float* u = xdot + math::nearest_multiple_4(S);
+  float* y = u + math::nearest_multiple_4(C);
+  const int ty = (int)__builtin_amdgcn_workitem_id_y();
+  for (int i = ty; i < S; i += BY)
+  {
+    x[i] = x_d[i];
+    xdot[i] = 0.0f;
+  }
+  for (int i = ty; i < C; i += BY)
+    u[i] = u_d[i];
+  for (int i = ty; i < O; i += BY)
+    y[i] = 0.0f;
+  __syncthreads();
+  dynamics->initializeDynamics(x, u, y, theta_s, 0.0f, dt);
+  __syncthreads();
+  if (enforce)
+  {
+    dynamics->enforceConstraints(x, u);
+    __syncthreads();
+  }
+  dynamics->step(x, xn, xdot, u, y, theta_s, 0, dt);
+  __syncthreads();
+  for (int i = ty; i < S; i += BY)
+    x_d[i] = xn[i];
+  for (int i = ty; i < C; i += BY)
+    u_d[i] = u[i];
+}
+
+template <class DYN_T, class COST_T, class SAMPLING_T, class SHAPES, int FIN_BY = 1>
+struct ModelT : ModelBase
+{
+  DYN_T dyn;
+  COST_T cost;
+  SAMPLING_T smp;
+
+  ModelT()
+  {
+    S = DYN_T::STATE_DIM;
+    C = DYN_T::CONTROL_DIM;
+    O = DYN_T::OUTPUT_DIM;
+  }
+
+  mppi_status setDynamicsParams(const void* pod, size_t n) override
+  {
+    // the params struct adds its fields after the (empty) DynamicsParams base: a flat block of floats / ints
+    if (n != sizeof(typename DYN_T::DYN_PARAMS_T))
+      return MPPI_ERR_INVALID_ARG;
+    memcpy((void*)&dyn.params_, pod, n);
+    return MPPI_OK;
+  }
+  mppi_status setCostParams(const void* pod, size_t n) override
+  {
+    if (n != sizeof(typename COST_T::COST_PARAMS_T))
+      return MPPI_ERR_INVALID_ARG;
+    memcpy((void*)&cost.params_, pod, n);
+    return MPPI_OK;
+  }
+  void setControlRanges(const float* lo_hi) override
+  {
+    for (int i = 0; i < DYN_T::CONTROL_DIM; i++)
+    {
+      dyn.control_rngs_[i].x = lo_hi[2 * i];
+      dyn.control_rngs_[i].y = lo_hi[2 * i + 1];
+    }
+  }
+  void setControlDeadband(const float* db) override
+  {
+    for (int i = 0; i < DYN_T::CONTROL_DIM; i++)
+      dyn.control_deadband_[i] = db[i];
+  }
+  void getZeroControl(float* out) const override
+  {
+    for (int i = 0; i < DYN_T::CONTROL_DIM; i++)
+      out[i] = dyn.zero_control_[i];
+  }
+  void setSamplerParams(const mppi_gaussian_params* p, int D) override
+  {
+    for (int i = 0; i < DYN_T::CONTROL_DIM * D && i < DYN_T::CONTROL_DIM * 2; i++)
+      smp.params_.std_dev[i] = p->std_dev[i];
+    if (D == 1)  // keep distribution 1 defined (copyStdDevToDistribution semantics, gaussian.cuh:45-60)
+      for (int i = 0; i < DYN_T::CONTROL_DIM; i++)
+        smp.params_.std_dev[DYN_T::CONTROL_DIM + i] = p->std_dev[i];
+    for (int i = 0; i < DYN_T::CONTROL_DIM; i++)
+      smp.params_.control_cost_coeff[i] = p->control_cost_coeff[i];
+    smp.params_.pure_noise_trajectories_percentage = p->pure_noise_trajectories_percentage;
+    smp.params_.std_dev_decay = p->std_dev_decay;
+    smp.params_.sum_strides = p->sum_strides;
+  }
+
+  template <int X, int Y, int Z, class... Rest>
+  static bool hasShape(Shapes<Shape<X, Y, Z>, Rest...>, int bx, int by, int bz)
+  {
+    return (bx == X && by == Y && bz == Z) || hasShape(Shapes<Rest...>{}, bx, by, bz);
+  }
+  static bool hasShape(Shapes<>, int, int, int)
+  {
+    return false;
+  }
+  bool supportsShape(int bx, int by, int bz) const override
+  {
+    return hasShape(SHAPES{}, bx, by, bz);
+  }
+
+  void prepSampler(const SamplerLaunchState& s)
+  {
+    smp.params_.num_rollouts = s.num_rollouts_local;
+    smp.params_.num_timesteps = s.num_timesteps;
+    smp.params_.num_distributions = s.num_distributions;
+    smp.control_means_d_ = s.control_means_d;
+    smp.eps_d_ = s.eps_d;
+    smp.control_samples_d_ = s.control_samples_d;
+    smp.noise_source_ = s.eps_d ? 1 /* NOISE_EPS_BUFFER */ : 0 /* NOISE_PHILOX_FUSED */;
+    smp.seed_ = s.seed;
+    smp.generation_ = s.generation;
+    smp.rollout_offset_ = s.rollout_offset;
+    smp.num_rollouts_global_ = s.num_rollouts_global;
+    smp.setIteration(s.iteration, s.optimization_stride);
+  }
+
+  size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D) override
+  {
+    smp.params_.num_timesteps = T;
+    smp.params_.num_distributions = D;
+    return kernels::rolloutSharedBytes(dyn, cost, smp, bx, by, bz);
+  }
+
+  template <int X, int Y, int Z>
+  mppi_status launchShape(const kernels::RolloutArgs& args, hipStream_t stream, std::string& err)
+  {
+    const size_t smem = kernels::rolloutSharedBytes(dyn, cost, smp, X, Y, Z);
+    if (smem > MAX_LDS_BYTES)
+    {
+      err = "rollout kernel needs " + std::to_string(smem) + " B of LDS per block; gfx950 has 163840";
+      return MPPI_ERR_LDS_OVERFLOW;
+    }
+    auto kfn = kernels::rolloutKernel<DYN_T, COST_T, SAMPLING_T, X, Y, Z>;
+    if (smem > 48 * 1024)
+    {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess)
+      {
+        err = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e);
+        return MPPI_ERR_HIP;
+      }
+    }
+    const int grid = (args.num_rollouts + X - 1) / X;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(X, Y, Z), smem, stream, dyn, cost, smp, args);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+      err = std::string("rolloutKernel launch: ") + hipGetErrorString(e);
+      return MPPI_ERR_HIP;
+    }
+    return MPPI_OK;
+  }
+
+  template <int X, int Y, int Z, class... Rest>
+  mppi_status dispatch(Shapes<Shape<X, Y, Z>, Rest...>, int bx, int by, int bz, const kernels::RolloutArgs& args,
+                       hipStream_t stream, std::string& err)
+  {
+    if (bx == X && by == Y && bz == Z)
+      return launchShape<X, Y, Z>(args, stream, err);
+    return dispatch(Shapes<Rest...>{}, bx, by, bz, args, stream, err);
+  }
+  mppi_status dispatch(Shapes<>, int bx, int by, int bz, const kernels::RolloutArgs&, hipStream_t, std::string& err)
+  {
+    err = "block shape (" + std::to_string(bx) + "," + std::to_string(by) + "," + std::to_string(bz) +
+          ") is not instantiated for this model";
+    return MPPI_ERR_LAUNCH_SHAPE;
+  }
+
+  mppi_status launchRollout(int bx, int by, int bz, const kernels::RolloutArgs& args, const SamplerLaunchState& s,
+                            hipStream_t stream, std::string& err) override
+  {
+    prepSampler(s);
+    return dispatch(SHAPES{}, bx, by, bz, args, stream, err);
+  }
+
+  mppi_status launchFinalize(int D, const kernels::FinalizeArgs& a, hipStream_t stream, std::string& err) override
+  {
+    const size_t smem = kernels::finalizeSharedBytes(dyn, a.num_timesteps);
+    if (smem > MAX_LDS_BYTES)
+    {
+      err = "finalize kernel LDS overflow";
+      return MPPI_ERR_LDS_OVERFLOW;
+    }
+    auto kfn = kernels::finalizeKernel<DYN_T, FIN_BY>;
+    if (smem > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem);
+    hipLaunchKernelGGL(kfn, dim3(D), dim3(1, FIN_BY, 1), smem, stream, dyn, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+      err = std::string("finalizeKernel launch: ") + hipGetErrorString(e);
+      return MPPI_ERR_HIP;
+    }
+    return MPPI_OK;
+  }
+
+  mppi_status launchModelStep(float* x_d, float* u_d, float dt, int enforce, hipStream_t stream,
+                              std::string& err) override
+  {
+    constexpr int Sd = DYN_T::STATE_DIM, Cd = DYN_T::CONTROL_DIM, Od = DYN_T::OUTPUT_DIM;
+    const size_t smem = calcClassSharedMemSize(&dyn, 1) +
+                        sizeof(float) * (3 * math::nearest_multiple_4(Sd) + math::nearest_multiple_4(Cd) +
+                                         math::nearest_multiple_4(Od));
+    hipLaunchKernelGGL((modelStepKernel<DYN_T, FIN_BY>), dim3(1), dim3(1, FIN_BY, 1), smem, stream, dyn, x_d, u_d, dt,
+                       enforce);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+      err = std::string("modelStepKernel launch: ") + hipGetErrorString(e);
+      return MPPI_ERR_HIP;
+    }
+    return MPPI_OK;
+  }
+};
+
+}  // namespace engine
+}  // namespace mppi
+
+#endif

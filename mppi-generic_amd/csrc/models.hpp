@@ -1,0 +1,54 @@
+/**
+ * models.hpp — the registered (Dynamics, Cost, Sampler) instantiations of libmppi_amd.so.
+ *
+ * This file is the analogue of the reference's include/mppi/instantiations/ + src/controllers/ (explicit template
+ * instantiations compiled into shared libraries).  To add a model: write the plugins against include/mppi_amd/plugin/,
+ * add one MODEL entry below with the block shapes it should be compiled for, rebuild.
+ *
+ * Block shapes (BX rollouts, BY lanes per rollout, BZ systems per launch):
+ *   BY == 1 : one lane per rollout, state in VGPRs, no barriers      — analytic models (cartpole, double integrator)
+ *   BY  > 1 : the reference's LDS + barrier scheme                     — kept for contract coverage and NN-sized models
+ *   BZ == 2 : Tube / RMPPI (actual + nominal system share one launch, tube_mppi_controller.cu:192-209)
+ */
+#ifndef MPPI_AMD_MODELS_HPP_
+#define MPPI_AMD_MODELS_HPP_
+
+#include <string>
+
+#include "model_instance.hpp"
+#include "mppi_amd/sampling_distributions/gaussian.hpp"
+#include "mppi_amd/dynamics/cartpole/cartpole_dynamics.hpp"
+#include "mppi_amd/cost_functions/cartpole/cartpole_quadratic_cost.hpp"
+#include "mppi_amd/dynamics/double_integrator/di_dynamics.hpp"
+#include "mppi_amd/cost_functions/double_integrator/double_integrator_circle_cost.hpp"
+
+namespace mppi
+{
+namespace engine
+{
+using CartpoleSampler = sampling_distributions::GaussianDistribution<CartpoleDynamicsParams>;
+using CartpoleModel = ModelT<CartpoleDynamics, CartpoleQuadraticCost, CartpoleSampler,
+                             Shapes<Shape<64, 1, 1>, Shape<64, 1, 2>, Shape<32, 1, 1>, Shape<64, 4, 1>, Shape<16, 4, 1>>>;
+
+using DISampler = sampling_distributions::GaussianDistribution<DoubleIntegratorParams>;
+using DIModel = ModelT<DoubleIntegratorDynamics, DoubleIntegratorCircleCost, DISampler,
+                       Shapes<Shape<64, 1, 1>, Shape<64, 1, 2>, Shape<32, 2, 2>, Shape<64, 2, 1>>>;
+
+inline ModelBase* makeModel(const std::string& name)
+{
+  if (name == "cartpole")
+    return new CartpoleModel();
+  if (name == "double_integrator")
+    return new DIModel();
+  return nullptr;
+}
+
+inline const char* listModels()
+{
+  return "cartpole\ndouble_integrator";
+}
+
+}  // namespace engine
+}  // namespace mppi
+
+#endif

@@ -1,0 +1,224 @@
+/**
+ * reduce_kernels.hpp — second pass of the two-pass softmin reduction.
+ *
+ * Replaces the reference's host baseline scan + normExpKernel + host normaliser sum + weightedReductionKernel tail
+ * (include/mppi/core/mppi_common.cu:858-900, 686-701, 1055-1063, 1138-1160; three blocking D2H copies per iteration in
+ * controllers/MPPI/mppi_controller.cu:187-219) with one small launch that never leaves the device.
+ *
+ * Input: per-(system, block) records {U_b[T*C], rho_b, eta_b, sum w^2} from rolloutKernel (or per-GPU records after the
+ * exchange).  Merge rule (exact in real arithmetic, ~1e-7 relative in fp32 — SURVEY.md §8e):
+ *   rho = min_b rho_b;  s_b = exp(-(rho_b - rho)/lambda);  eta = sum_b s_b eta_b (double);
+ *   U[j] = sum_b s_b U_b[j];   u*[j] = U[j] / eta.
+ * finalize == 0 writes the merged record (per-GPU partial, layout identical to the input records) instead of u*.
+ * Also produces the reference's free-energy statistics (mppi_common.cu:1065-1081) from eta and sum w^2.
+ *
+ * Launch: grid = D (one block per system), block = COMBINE_THREADS, dynamic LDS = num_records floats.
+ */
+#ifndef MPPI_AMD_REDUCE_KERNELS_HPP_
+#define MPPI_AMD_REDUCE_KERNELS_HPP_
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "mppi_amd/det_math.h"
+
+namespace mppi
+{
+namespace kernels
+{
+constexpr int COMBINE_THREADS = 256;
+/** floats per system in the stats buffer: rho, eta, fe_mean, fe_var, fe_modified_var, sum w^2, pad, pad */
+constexpr int STATS_STRIDE = 8;
+
+struct CombineArgs
+{
+  const float* records_d;  ///< [D][num_records][PS]
+  int num_records;
+  int TC;                  ///< T * C
+  int PS;                  ///< record stride in floats (TC + 4)
+  float lambda;
+  int num_rollouts_total;  ///< K over everything merged so far (free-energy normalisation)
+  int finalize;
+  float* mean_out_d;       ///< finalize: [D][T*C] new control mean (= u*)
+  float* record_out_d;     ///< !finalize: [D][PS] merged record
+  float* stats_out_d;      ///< finalize: [D][STATS_STRIDE]
+};
+
+__device__ inline float blockMin(float v, float* red_s)
+{
+  // wave64 shuffle tree, then across the waves of the block through LDS
+  for (int off = 32; off > 0; off >>= 1)
+    v = fminf(v, __shfl_xor(v, off, 64));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0)
+    red_s[wave] = v;
+  __syncthreads();
+  float r = red_s[0];
+  for (int i = 1; i < COMBINE_THREADS / 64; i++)
+    r = fminf(r, red_s[i]);
+  __syncthreads();
+  return r;
+}
+
+__device__ inline double blockSum(double v, double* red_s)
+{
+  for (int off = 32; off > 0; off >>= 1)
+    v += __shfl_xor(v, off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0)
+    red_s[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int i = 0; i < COMBINE_THREADS / 64; i++)
+    r += red_s[i];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s_b = reinterpret_cast<float*>(smem_raw);  // [num_records]
+  __shared__ double red_d[COMBINE_THREADS / 64];
+  __shared__ float red_f[COMBINE_THREADS / 64];
+
+  const int z = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* rec = a.records_d + (size_t)z * a.num_records * a.PS;
+  const float lambda_inv = (float)(1.0 / (double)a.lambda);
+
+  float rho = INFINITY;
+  for (int b = tid; b < a.num_records; b += COMBINE_THREADS)
+    rho = fminf(rho, rec[(size_t)b * a.PS + a.TC]);
+  rho = blockMin(rho, red_f);
+
+  double eta = 0.0, eta2 = 0.0;
+  for (int b = tid; b < a.num_records; b += COMBINE_THREADS)
+  {
+    const float* r = rec + (size_t)b * a.PS + a.TC;
+    const float s = mppi::det::exp(-lambda_inv * (r[0] - rho));
+    s_b[b] = s;
+    eta += (double)s * (double)r[1];
+    eta2 += (double)s * (double)s * (double)r[2];
+  }
+  eta = blockSum(eta, red_d);
+  eta2 = blockSum(eta2, red_d);  // blockSum's barriers also publish s_b
+
+  const float eta_f = (float)eta;
+  for (int j = tid; j < a.TC; j += COMBINE_THREADS)
+  {
+    float acc = 0.0f;
+    for (int b = 0; b < a.num_records; b++)
+      acc += s_b[b] * rec[(size_t)b * a.PS + j];
+    if (a.finalize)
+      a.mean_out_d[(size_t)z * a.TC + j] = acc / eta_f;
+    else
+      a.record_out_d[(size_t)z * a.PS + j] = acc;
+  }
+  if (tid == 0)
+  {
+    if (a.finalize)
+    {
+      // reference: mppi_common.cu:1065-1081 computeFreeEnergy
+      const float K = (float)a.num_rollouts_total;
+      const float norm = eta_f / K;
+      const float var = (float)eta2;
+      const float lambda = a.lambda;
+      const float fe = -lambda * mppi::det::log(norm) + rho;
+      const float fe_var = lambda * (var / K - norm * norm);
+      const float weird = fe_var / (norm * mppi::det::sqrt(K));
+      float* st = a.stats_out_d + (size_t)z * STATS_STRIDE;
+      st[0] = rho;
+      st[1] = eta_f;
+      st[2] = fe;
+      st[3] = fe_var;
+      st[4] = lambda * (weird + 0.5f * (weird * weird));
+      st[5] = var;
+      st[6] = 0.0f;
+      st[7] = 0.0f;
+    }
+    else
+    {
+      float* o = a.record_out_d + (size_t)z * a.PS + a.TC;
+      o[0] = rho;
+      o[1] = eta_f;
+      o[2] = (float)eta2;
+      o[3] = 0.0f;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Unfused kernel-level operators with the reference's launch-wrapper semantics, exported through the C ABI for the
+ * kernel-level parity tests (reference tests: tests/mppi_core/normexp_kernel_tests.cu, weightedreduction_kernel_tests.cu)
+ * and for callers that hold their own cost / sample buffers.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/** in-place w_i = exp(-lambda_inv * (S_i - baseline)); reference: normExpKernel mppi_common.cu:686-701, :958-966 */
+__global__ void normExpKernel(int num_rollouts, float* trajectory_costs_d, float lambda_inv, float baseline)
+{
+  const int stride = blockDim.x * gridDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_rollouts; i += stride)
+  {
+    const float cost_dif = trajectory_costs_d[i] - baseline;
+    trajectory_costs_d[i] = mppi::det::exp(-lambda_inv * cost_dif);
+  }
+}
+
+/**
+ * Single-block baseline + normaliser of a cost vector: out = {min_k S_k, sum_k exp(-lambda_inv (S_k - min))} — the
+ * two-pass device reduction the reference sketches in fullGPUcomputeWeights (mppi_common.cu:1031-1053) but never uses;
+ * also applies the exp transform in place.
+ */
+__global__ void __launch_bounds__(COMBINE_THREADS)
+    computeWeightsKernel(int num_rollouts, float* trajectory_costs_d, float lambda_inv, float* baseline_and_normalizer)
+{
+  __shared__ double red_d[COMBINE_THREADS / 64];
+  __shared__ float red_f[COMBINE_THREADS / 64];
+  const int tid = threadIdx.x;
+  float m = INFINITY;
+  for (int i = tid; i < num_rollouts; i += COMBINE_THREADS)
+    m = fminf(m, trajectory_costs_d[i]);
+  m = blockMin(m, red_f);
+  double s = 0.0;
+  for (int i = tid; i < num_rollouts; i += COMBINE_THREADS)
+  {
+    const float w = mppi::det::exp(-lambda_inv * (trajectory_costs_d[i] - m));
+    trajectory_costs_d[i] = w;
+    s += (double)w;
+  }
+  s = blockSum(s, red_d);
+  if (tid == 0)
+  {
+    baseline_and_normalizer[0] = m;
+    baseline_and_normalizer[1] = (float)s;
+  }
+}
+
+/**
+ * u*[t][c] = sum_k (w_k / eta) v[k][t][c] for samples in HBM (v: [K][T][C], reference layout).
+ * reference: weightedReductionKernel mppi_common.cu:710-737.  MI355X mapping: one block per chunk of rollouts reads its
+ * rows fully coalesced (a row is contiguous), accumulates T*C columns in registers per thread, and merges chunks with
+ * one float atomicAdd per (block, column) into a zeroed output.
+ */
+__global__ void __launch_bounds__(256)
+    weightedReductionKernel(const float* __restrict__ exp_costs_d, const float* __restrict__ v_d,
+                            float* __restrict__ new_u_d, const float normalizer, const int TC, const int num_rollouts,
+                            const int rollouts_per_block)
+{
+  const int k0 = blockIdx.x * rollouts_per_block;
+  const int k1 = min(num_rollouts, k0 + rollouts_per_block);
+  for (int j = threadIdx.x; j < TC; j += blockDim.x)
+  {
+    float acc = 0.0f;
+    for (int k = k0; k < k1; k++)
+    {
+      const float weight = exp_costs_d[k] / normalizer;
+      acc += weight * v_d[(size_t)k * TC + j];
+    }
+    atomicAdd(&new_u_d[j], acc);
+  }
+}
+
+}  // namespace kernels
+}  // namespace mppi
+
+#endif

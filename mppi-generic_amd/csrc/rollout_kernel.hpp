@@ -1,0 +1,290 @@
+/**
+ * rollout_kernel.hpp — the fused MPPI rollout kernel for gfx950.
+ *
+ * Replaces the reference's rolloutKernel / rolloutDynamicsKernel + rolloutCostKernel (include/mppi/core/
+ * mppi_common.cu:28-146, 269-362, 148-267), setGaussianControls (sampling_distributions/gaussian/gaussian.cu:17-277),
+ * normExpKernel (mppi_common.cu:686-701) and the sample-reading half of weightedReductionKernel (mppi_common.cu:710-737)
+ * with ONE launch per optimisation iteration:
+ *
+ *   prologue  sampler.initializeDistributions(): the block's eps rows are drawn (Philox) or loaded (coalesced) into LDS
+ *   loop      per (rollout x, lane y, system z) exactly the reference's call sequence
+ *               readControlSample -> enforceConstraints -> writeControlSample -> step -> runningCost + likelihoodRatio
+ *             same plugin methods, same argument meaning, same thread-index conventions (x = rollout, y = lane,
+ *             z = system).  With BY == 1 the per-rollout state/control/output arrays are thread-private (VGPRs) and no
+ *             barrier is executed; with BY > 1 they sit in per-slot LDS and phases are separated by block barriers.
+ *   epilogue  cost = running/T + terminal/T (mppi_common.cu:144, :843-853) -> trajectory_costs_d;
+ *             block-local softmin: rho_b = min_k S_k, w_k = exp(-(S_k - rho_b)/lambda), eta_b = sum w_k (double),
+ *             U_b[t][c] = sum_k w_k v[k][t][c] from the LDS sample rows.  One record (U_b, rho_b, eta_b, sum w^2) per
+ *             block and system goes to HBM; combineKernel (reduce_kernels.hpp) merges the records exactly like the
+ *             multi-GPU merge: rho = min rho_b, s_b = exp(-(rho_b - rho)/lambda), u* = sum s_b U_b / sum s_b eta_b.
+ *
+ * HBM traffic per iteration and system: K costs + (K/BX)*(T*C+4) partial floats written, T*C means + S state read.
+ * The K*T*C sample tensor never exists in HBM (unless the caller asks for a dump with save_samples).
+ *
+ * LDS per block: BX*BZ sample rows of (T*C | 1) floats + plugin scratch + (BY > 1: per-slot x, x_next, xdot, u, y).
+ */
+#ifndef MPPI_AMD_ROLLOUT_KERNEL_HPP_
+#define MPPI_AMD_ROLLOUT_KERNEL_HPP_
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "mppi_amd/plugin/managed.hpp"
+#include "mppi_amd/plugin/math_utils.hpp"
+#include "mppi_amd/plugin/parallel_utils.hpp"
+
+namespace mppi
+{
+namespace kernels
+{
+/** floats per (system, block) record: U_b[T*C], rho_b, eta_b, sum w^2, pad */
+__host__ __device__ inline int partialStride(int num_timesteps, int control_dim)
+{
+  return num_timesteps * control_dim + 4;
+}
+
+struct RolloutArgs
+{
+  float dt;
+  int num_timesteps;
+  int num_rollouts;  ///< rollouts on this GPU
+  float lambda;
+  float alpha;
+  const float* init_x_d;        ///< [D][S]
+  float* trajectory_costs_d;    ///< [D][K_local]
+  float* partials_d;            ///< [D][num_blocks][partialStride]
+  int save_samples;             ///< != 0: also write the clamped samples to sampler.control_samples_d_
+};
+
+template <class DYN_T, class COST_T, class SAMPLING_T>
+__host__ inline size_t rolloutSharedBytes(const DYN_T& dyn, const COST_T& cost, const SAMPLING_T& smp, int bx, int by,
+                                          int bz)
+{
+  const int slots = bx * bz;
+  size_t n = 0;
+  n += calcClassSharedMemSize(&dyn, slots);
+  n += calcClassSharedMemSize(&cost, slots);
+  n += calcClassSharedMemSize(&smp, slots);
+  if (by > 1)
+  {
+    n += sizeof(float) * (3 * math::nearest_multiple_4(slots * DYN_T::STATE_DIM) +
+                          math::nearest_multiple_4(slots * DYN_T::OUTPUT_DIM) +
+                          math::nearest_multiple_4(slots * DYN_T::CONTROL_DIM));
+    n += sizeof(float) * math::nearest_multiple_4(bx * by * bz);  // running cost per thread
+    n += sizeof(int) * math::nearest_multiple_4(slots);           // crash status
+  }
+  n += sizeof(float) * 2 * math::nearest_multiple_4(slots);  // cost_s, w_s
+  return n;
+}
+
+template <class DYN_T, class COST_T, class SAMPLING_T, int BX, int BY, int BZ>
+__global__ void __launch_bounds__(BX* BY* BZ)
+    rolloutKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args)
+{
+  // The block shape is a template parameter; telling the compiler lets the plugins' threadIdx.y / blockDim.y loops
+  // fold (see mppi_amd/plugin/parallel_utils.hpp).
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == BX);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_y() == BY);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_z() == BZ);
+  __builtin_assume(__builtin_amdgcn_workitem_id_x() < BX);
+  __builtin_assume(__builtin_amdgcn_workitem_id_y() < BY);
+  __builtin_assume(__builtin_amdgcn_workitem_id_z() < BZ);
+
+  DYN_T* dynamics = &dynamics_obj;
+  COST_T* costs = &costs_obj;
+  SAMPLING_T* sampling = &sampling_obj;
+
+  constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
+  constexpr int SLOTS = BX * BZ;
+  const int thread_idx = (int)__builtin_amdgcn_workitem_id_x();
+  const int thread_idy = (int)__builtin_amdgcn_workitem_id_y();
+  const int thread_idz = (int)__builtin_amdgcn_workitem_id_z();
+  const int block_idx = (int)blockIdx.x;
+  const int global_idx = BX * block_idx + thread_idx;
+  const int shared_idx = BX * thread_idz + thread_idx;
+  const int distribution_idx = thread_idz;
+  const int tid_flat = thread_idx + BX * (thread_idy + BY * thread_idz);
+  constexpr int NTHREADS = BX * BY * BZ;
+  const int num_timesteps = args.num_timesteps;
+  const int num_rollouts = args.num_rollouts;
+  const float dt = args.dt;
+  const bool valid = global_idx < num_rollouts;
+  const int nrows = min(BX, num_rollouts - BX * block_idx);
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* theta_s_shared = reinterpret_cast<float*>(smem_raw);
+  float* theta_c_shared = theta_s_shared + calcClassSharedMemSize(dynamics, SLOTS) / (int)sizeof(float);
+  float* theta_d_shared = theta_c_shared + calcClassSharedMemSize(costs, SLOTS) / (int)sizeof(float);
+  float* next_shared = theta_d_shared + calcClassSharedMemSize(sampling, SLOTS) / (int)sizeof(float);
+
+  float x_priv[S], xn_priv[S], xdot_priv[S], u_priv[C], y_priv[O];
+  int crash_priv = 0;
+  float *x, *x_next, *xdot, *u, *y;
+  int* crash_status;
+  float* running_cost_shared = nullptr;
+  if (BY == 1)
+  {
+    x = x_priv;
+    x_next = xn_priv;
+    xdot = xdot_priv;
+    u = u_priv;
+    y = y_priv;
+    crash_status = &crash_priv;
+  }
+  else
+  {
+    float* x_shared = next_shared;
+    float* x_next_shared = x_shared + math::nearest_multiple_4(SLOTS * S);
+    float* x_dot_shared = x_next_shared + math::nearest_multiple_4(SLOTS * S);
+    float* y_shared = x_dot_shared + math::nearest_multiple_4(SLOTS * S);
+    float* u_shared = y_shared + math::nearest_multiple_4(SLOTS * O);
+    running_cost_shared = u_shared + math::nearest_multiple_4(SLOTS * C);
+    int* crash_status_shared = (int*)(running_cost_shared + math::nearest_multiple_4(NTHREADS));
+    next_shared = (float*)(crash_status_shared + math::nearest_multiple_4(SLOTS));
+    x = &x_shared[shared_idx * S];
+    x_next = &x_next_shared[shared_idx * S];
+    xdot = &x_dot_shared[shared_idx * S];
+    u = &u_shared[shared_idx * C];
+    y = &y_shared[shared_idx * O];
+    crash_status = &crash_status_shared[shared_idx];
+  }
+  float* cost_s = next_shared;
+  float* w_s = cost_s + math::nearest_multiple_4(SLOTS);
+
+  // loadGlobalToShared (mppi_common.cu:770-840): x <- x0[z], xdot <- 0, u <- 0
+  for (int i = thread_idy; i < S; i += BY)
+  {
+    x[i] = args.init_x_d[S * thread_idz + i];
+    xdot[i] = 0.0f;
+    if (BY == 1)
+      x_next[i] = 0.0f;
+  }
+  for (int i = thread_idy; i < C; i += BY)
+    u[i] = 0.0f;
+  for (int i = thread_idy; i < O; i += BY)
+    y[i] = 0.0f;
+  if (thread_idy == 0)
+    crash_status[0] = 0;
+  __syncthreads();
+
+  /*<----Start of simulation loop-----> */
+  dynamics->initializeDynamics(x, u, y, theta_s_shared, 0.0f, dt);
+  sampling->initializeDistributions(y, 0.0f, dt, theta_d_shared);
+  costs->initializeCosts(y, u, theta_c_shared, 0.0f, dt);
+  __syncthreads();
+
+  float running_cost = 0.0f;
+  auto one_step = [&](float* xc, float* xn, int t) {
+    sampling->readControlSample(global_idx, t, distribution_idx, u, theta_d_shared, BY, thread_idy, y);
+    lane_sync();
+    dynamics->enforceConstraints(xc, u);
+    lane_sync();
+    sampling->writeControlSample(global_idx, t, distribution_idx, u, theta_d_shared, BY, thread_idy, y);
+    dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
+    lane_sync();
+    running_cost += costs->computeRunningCost(y, u, t, theta_c_shared, crash_status) +
+                    sampling->computeLikelihoodRatioCost(u, theta_d_shared, global_idx, t, distribution_idx,
+                                                         args.lambda, args.alpha);
+    lane_sync();
+  };
+  // two steps per trip so that x / x_next keep fixed roles (no pointer swap: keeps them in registers when BY == 1)
+  int t = 0;
+  for (; t + 1 < num_timesteps; t += 2)
+  {
+    one_step(x, x_next, t);
+    one_step(x_next, x, t + 1);
+  }
+  if (t < num_timesteps)
+  {
+    one_step(x, x_next, t);
+  }
+
+  /* ---- cost of the rollout: sum over the y lanes, running/T + terminal/T ---- */
+  if (BY > 1)
+  {
+    running_cost_shared[tid_flat] = running_cost;
+    __syncthreads();
+    if (thread_idy == 0)
+    {
+      float acc = 0.0f;
+      for (int j = 0; j < BY; j++)
+        acc += running_cost_shared[thread_idx + BX * (j + BY * thread_idz)];
+      running_cost = acc;
+    }
+  }
+  float traj_cost = INFINITY;
+  if (thread_idy == 0)
+  {
+    const float total =
+        running_cost / (float)num_timesteps + costs->terminalCost(y, theta_c_shared) / (float)num_timesteps;
+    if (valid)
+    {
+      traj_cost = total;
+      args.trajectory_costs_d[(size_t)num_rollouts * thread_idz + global_idx] = total;
+    }
+    cost_s[shared_idx] = traj_cost;
+  }
+  __syncthreads();
+
+  /* ---- block-local softmin record ---- */
+  const float lambda_inv = (float)(1.0 / (double)args.lambda);  // mppi_controller.cu:201 passes 1.0 / lambda
+  if (thread_idy == 0)
+  {
+    float rho_b = INFINITY;
+    for (int i = 0; i < BX; i++)
+      rho_b = fminf(rho_b, cost_s[BX * thread_idz + i]);
+    w_s[shared_idx] = valid ? mppi::det::exp(-lambda_inv * (traj_cost - rho_b)) : 0.0f;
+  }
+  __syncthreads();
+
+  const int TC = num_timesteps * C;
+  const int PS = partialStride(num_timesteps, C);
+  const int num_blocks = (int)gridDim.x;
+  const int row_stride = SAMPLING_T::rowStride(num_timesteps);
+  for (int o = tid_flat; o < BZ * TC; o += NTHREADS)
+  {
+    const int z = o / TC;
+    const int j = o - z * TC;
+    const float* rows = theta_d_shared + (size_t)(BX * z) * row_stride + j;
+    const float* wz = w_s + BX * z;
+    float acc = 0.0f;
+    for (int i = 0; i < nrows; i++)
+      acc += wz[i] * rows[i * row_stride];
+    args.partials_d[((size_t)z * num_blocks + block_idx) * PS + j] = acc;
+  }
+  if (tid_flat < BZ)
+  {
+    const int z = tid_flat;
+    float rho_b = INFINITY;
+    double eta = 0.0, eta2 = 0.0;
+    for (int i = 0; i < nrows; i++)
+    {
+      rho_b = fminf(rho_b, cost_s[BX * z + i]);
+      const double w = (double)w_s[BX * z + i];
+      eta += w;
+      eta2 += w * w;
+    }
+    float* rec = args.partials_d + ((size_t)z * num_blocks + block_idx) * PS + TC;
+    rec[0] = rho_b;
+    rec[1] = (float)eta;
+    rec[2] = (float)eta2;
+    rec[3] = 0.0f;
+  }
+  if (args.save_samples)
+  {
+    // dump v[z][k][t][c] (clamped) for getSampledControl-style readers and for the RNG-mode parity tests
+    for (int o = tid_flat; o < BZ * nrows * TC; o += NTHREADS)
+    {
+      const int z = o / (nrows * TC);
+      const int r = o - z * nrows * TC;
+      const int i = r / TC;
+      const int j = r - i * TC;
+      sampling->control_samples_d_[((size_t)z * num_rollouts + BX * block_idx + i) * TC + j] =
+          theta_d_shared[(size_t)(BX * z + i) * row_stride + j];
+    }
+  }
+}
+
+}  // namespace kernels
+}  // namespace mppi
+
+#endif

@@ -1,0 +1,311 @@
+/**
+ * oracle_capi.cpp — C entry points of the CPU oracle for ctypes.  TEST INFRASTRUCTURE ONLY (see oracle_core.hpp).
+ * Built by oracle/Makefile into oracle/_build/libmppi_oracle.so.
+ */
+#include "oracle_core.hpp"
+#include "oracle_models.hpp"
+#include "oracle_rng.hpp"
+
+#include <chrono>
+
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+
+using namespace oracle;
+
+extern "C" {
+
+/* ----- handles ----- */
+void* oracle_create(const char* model, int K, int T, int D, float dt, float lambda, float alpha, int num_iters)
+{
+  auto* c = new Controller();
+  if (!makeModel(model, c->dyn, c->cost))
+  {
+    delete c;
+    return nullptr;
+  }
+  c->dt = dt;
+  c->lambda = lambda;
+  c->alpha = alpha;
+  c->num_iters = num_iters;
+  c->init(K, T, D);
+  return c;
+}
+void oracle_destroy(void* h)
+{
+  delete (Controller*)h;
+}
+void oracle_dims(void* h, int* S, int* C, int* O)
+{
+  auto* c = (Controller*)h;
+  *S = c->dyn->S;
+  *C = c->dyn->C;
+  *O = c->dyn->O;
+}
+int oracle_set_dynamics_params(void* h, const void* pod, size_t n)
+{
+  return ((Controller*)h)->dyn->setParams(pod, n);
+}
+int oracle_set_cost_params(void* h, const void* pod, size_t n)
+{
+  return ((Controller*)h)->cost->setParams(pod, n);
+}
+void oracle_set_control_ranges(void* h, const float* lo_hi)
+{
+  auto* c = (Controller*)h;
+  for (int i = 0; i < c->dyn->C; i++)
+  {
+    c->dyn->rng_lo[i] = lo_hi[2 * i];
+    c->dyn->rng_hi[i] = lo_hi[2 * i + 1];
+  }
+}
+void oracle_set_control_deadband(void* h, const float* db)
+{
+  auto* c = (Controller*)h;
+  for (int i = 0; i < c->dyn->C; i++)
+    c->dyn->deadband[i] = db[i];
+}
+void oracle_set_sampler(void* h, const float* std_dev /*[D][C]*/, const float* control_cost_coeff /*[C]*/,
+                        float pure_noise_pct, float std_dev_decay, int sum_strides)
+{
+  auto* c = (Controller*)h;
+  for (size_t i = 0; i < c->smp.std_dev.size(); i++)
+    c->smp.std_dev[i] = std_dev[i];
+  for (int i = 0; i < c->dyn->C; i++)
+    c->smp.control_cost_coeff[i] = control_cost_coeff[i];
+  c->smp.pure_noise_trajectories_percentage = pure_noise_pct;
+  c->smp.std_dev_decay = std_dev_decay;
+  c->smp.sum_strides = sum_strides;
+}
+void oracle_set_controller_params(void* h, float nominal_threshold, const float* slide_scale)
+{
+  auto* c = (Controller*)h;
+  c->nominal_threshold = nominal_threshold;
+  if (slide_scale)
+    for (int i = 0; i < c->dyn->C; i++)
+      c->slide_scale[i] = slide_scale[i];
+}
+
+/* ----- kernel-level pieces ----- */
+void oracle_set_gaussian_controls(void* h, const float* mean, const float* eps, int stride, int iter, float* v)
+{
+  ((Controller*)h)->smp.setGaussianControls(mean, eps, stride, iter, v);
+}
+/** v in/out [D][K][T][C]; costs out [D][K]; OpenMP over rollouts when threads > 1 (each rollout is independent) */
+void oracle_rollout_costs(void* h, const float* x0, const float* mean, float* v, float* costs, int threads)
+{
+  auto* c = (Controller*)h;
+  if (threads <= 1)
+  {
+    rolloutCosts(*c->dyn, *c->cost, c->smp, c->dt, c->lambda, c->alpha, x0, mean, v, costs);
+    return;
+  }
+#if defined(_OPENMP)
+  const int K = c->K;
+  const int chunk = 64;
+#pragma omp parallel for schedule(dynamic) num_threads(threads)
+  for (int k0 = 0; k0 < K; k0 += chunk)
+  {
+    rolloutCosts(*c->dyn, *c->cost, c->smp, c->dt, c->lambda, c->alpha, x0, mean, v, costs, k0, std::min(K, k0 + chunk));
+  }
+#else
+  rolloutCosts(*c->dyn, *c->cost, c->smp, c->dt, c->lambda, c->alpha, x0, mean, v, costs);
+#endif
+}
+int oracle_best_index(const float* costs, int K)
+{
+  return computeBestIndex(costs, K);
+}
+float oracle_baseline(const float* costs, int K)
+{
+  return computeBaselineCost(costs, K);
+}
+void oracle_norm_exp(float* costs, int K, float lambda_inv, float baseline)
+{
+  normExpTransform(costs, K, lambda_inv, baseline);
+}
+float oracle_normalizer(const float* w, int K)
+{
+  return computeNormalizer(w, K);
+}
+void oracle_free_energy(const float* w, int K, float baseline, float lambda, float* out3)
+{
+  computeFreeEnergy(out3[0], out3[1], out3[2], w, K, baseline, lambda);
+}
+void oracle_weighted_reduction(const float* w, const float* v, float normalizer, int K, int T, int C, int sum_stride,
+                               float* u_out)
+{
+  weightedReduction(w, v, normalizer, K, T, C, sum_stride, u_out);
+}
+void oracle_smooth(float* u, const float* history, int T, int C)
+{
+  smoothControlTrajectory(u, history, T, C);
+}
+void oracle_slide(float* u, int T, int C, int steps, const float* zero_control, const float* slide_scale)
+{
+  slideControlSequence(u, T, C, steps, zero_control, slide_scale);
+}
+void oracle_save_history(int steps, const float* u, float* history, int C)
+{
+  saveControlHistory(steps, u, history, C);
+}
+void oracle_state_trajectory(void* h, const float* x0, const float* u, float* result)
+{
+  auto* c = (Controller*)h;
+  computeStateTrajectory(*c->dyn, c->dt, x0, u, c->T, result);
+}
+/** one model step on the host (used for closed-loop tests: examples/cartpole_example.cu:63-85) */
+void oracle_model_step(void* h, float* x, float* u, float dt)
+{
+  auto* c = (Controller*)h;
+  const int S = c->dyn->S, O = c->dyn->O;
+  std::vector<float> xn(S), xdot(S, 0.0f), y(O, 0.0f), th(std::max(1, c->dyn->scratchFloats()), 0.0f);
+  c->dyn->enforceConstraints(x, u);
+  c->dyn->step(x, xn.data(), xdot.data(), u, y.data(), th.data(), 0, dt);
+  for (int i = 0; i < S; i++)
+    x[i] = xn[i];
+}
+
+/* ----- controller level ----- */
+void oracle_set_nominal_control(void* h, const float* u)
+{
+  auto* c = (Controller*)h;
+  std::copy(u, u + c->control.size(), c->control.begin());
+}
+void oracle_iterate(void* h, const float* x0, const float* mean, const float* eps, int stride, int iter, float* u_new)
+{
+  ((Controller*)h)->iterate(x0, mean, eps, stride, iter, u_new);
+}
+void oracle_vanilla_compute_control(void* h, const float* x0, int stride, const float* eps)
+{
+  ((Controller*)h)->vanillaComputeControl(x0, stride, eps);
+}
+void oracle_tube_compute_control(void* h, const float* x0, int stride, const float* eps)
+{
+  ((Controller*)h)->tubeComputeControl(x0, stride, eps);
+}
+void oracle_vanilla_slide(void* h, int steps)
+{
+  ((Controller*)h)->vanillaSlide(steps);
+}
+void oracle_get_control(void* h, float* u)
+{
+  auto* c = (Controller*)h;
+  std::copy(c->control.begin(), c->control.end(), u);
+}
+void oracle_get_nominal_control(void* h, float* u)
+{
+  auto* c = (Controller*)h;
+  std::copy(c->nominal_control.begin(), c->nominal_control.end(), u);
+}
+void oracle_get_state_traj(void* h, float* x)
+{
+  auto* c = (Controller*)h;
+  std::copy(c->state_traj.begin(), c->state_traj.end(), x);
+}
+void oracle_get_nominal_state_traj(void* h, float* x)
+{
+  auto* c = (Controller*)h;
+  std::copy(c->nominal_state.begin(), c->nominal_state.end(), x);
+}
+void oracle_get_costs(void* h, float* costs)
+{
+  auto* c = (Controller*)h;
+  std::copy(c->costs.begin(), c->costs.end(), costs);
+}
+void oracle_get_weights(void* h, float* w)
+{
+  auto* c = (Controller*)h;
+  std::copy(c->w.begin(), c->w.end(), w);
+}
+void oracle_get_samples(void* h, float* v)
+{
+  auto* c = (Controller*)h;
+  std::copy(c->v.begin(), c->v.end(), v);
+}
+/** out: baseline[2], normalizer[2], fe[2], fe_var[2], fe_mod[2], nominal_state_used */
+void oracle_get_stats(void* h, float* out11)
+{
+  auto* c = (Controller*)h;
+  for (int d = 0; d < 2; d++)
+  {
+    out11[d] = c->stats.baseline[d];
+    out11[2 + d] = c->stats.normalizer[d];
+    out11[4 + d] = c->stats.free_energy[d];
+    out11[6 + d] = c->stats.free_energy_var[d];
+    out11[8 + d] = c->stats.free_energy_mod[d];
+  }
+  out11[10] = (float)c->stats.nominal_state_used;
+}
+
+/* ----- RNG ----- */
+void oracle_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out)
+{
+  philox4x32_10(ctr, key, out);
+}
+void oracle_philox_normal(uint64_t seed, uint32_t generation, uint32_t stream, int K, int T, int C, int k_begin,
+                          int k_end, float* eps)
+{
+  philoxNormal(seed, generation, stream, K, T, C, k_begin, k_end, eps);
+}
+
+/* ----- det_math elementwise (for the host-vs-GPU bit-parity test) ----- */
+void oracle_det_eval(int func, const float* x, float* y, int n)
+{
+  for (int i = 0; i < n; i++)
+  {
+    switch (func)
+    {
+      case 0: y[i] = det::sin(x[i]); break;
+      case 1: y[i] = det::cos(x[i]); break;
+      case 2: y[i] = det::exp(x[i]); break;
+      case 3: y[i] = det::log(x[i]); break;
+      case 4: y[i] = det::tanh(x[i]); break;
+      case 5: y[i] = det::atan(x[i]); break;
+      case 6: y[i] = det::normalizeAngle(x[i]); break;
+      case 7: y[i] = det::sigmoid(x[i]); break;
+      case 8: y[i] = det::sqrt(x[i]); break;
+      case 9: y[i] = 1.0f / x[i]; break;
+      default: y[i] = 0.0f;
+    }
+  }
+}
+
+/* ----- CPU baseline timing: one optimisation-loop body (bench.py cpu_baseline leg) ----- */
+/** returns seconds for `iters` passes of iterate() on the given inputs using `threads` host threads for the rollout */
+double oracle_time_iterations(void* h, const float* x0, const float* mean, const float* eps, int iters, int threads)
+{
+  auto* c = (Controller*)h;
+  const int C = c->dyn->C;
+  std::vector<float> u_new((size_t)c->D * c->T * C);
+  auto t0 = std::chrono::steady_clock::now();
+  for (int it = 0; it < iters; it++)
+  {
+    c->smp.setGaussianControls(mean, eps, 1, 0, c->v.data());
+    oracle_rollout_costs(h, x0, mean, c->v.data(), c->costs.data(), threads);
+    c->w = c->costs;
+    for (int d = 0; d < c->D; d++)
+    {
+      float* wd = &c->w[(size_t)d * c->K];
+      const float b = computeBaselineCost(wd, c->K);
+      normExpTransform(wd, c->K, (float)(1.0 / c->lambda), b);
+      const float eta = computeNormalizer(wd, c->K);
+      weightedReduction(wd, &c->v[(size_t)d * c->K * c->T * C], eta, c->K, c->T, C, c->smp.sum_strides,
+                        &u_new[(size_t)d * c->T * C]);
+    }
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+
+int oracle_max_threads()
+{
+#if defined(_OPENMP)
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+}  // extern "C"

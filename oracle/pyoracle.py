@@ -1,0 +1,282 @@
+"""ctypes loader for the CPU oracle (oracle/_build/libmppi_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_build", "libmppi_oracle.so")
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def build(force=False):
+    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".cpp", ".hpp"))]
+    srcs += [os.path.join(HERE, "..", "include", "mppi_amd", f) for f in ("det_math.h", "model_params.h")]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+        r = subprocess.run(["make", "-C", HERE, "-B" if force else "-s"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_dims.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
+        L.oracle_set_dynamics_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_set_cost_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_set_control_ranges.argtypes = [C.c_void_p, _f32p]
+        L.oracle_set_control_deadband.argtypes = [C.c_void_p, _f32p]
+        L.oracle_set_sampler.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, C.c_int]
+        L.oracle_set_controller_params.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+        L.oracle_set_gaussian_controls.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, _f32p]
+        L.oracle_rollout_costs.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_int]
+        L.oracle_best_index.restype = C.c_int
+        L.oracle_best_index.argtypes = [_f32p, C.c_int]
+        L.oracle_baseline.restype = C.c_float
+        L.oracle_baseline.argtypes = [_f32p, C.c_int]
+        L.oracle_norm_exp.argtypes = [_f32p, C.c_int, C.c_float, C.c_float]
+        L.oracle_normalizer.restype = C.c_float
+        L.oracle_normalizer.argtypes = [_f32p, C.c_int]
+        L.oracle_free_energy.argtypes = [_f32p, C.c_int, C.c_float, C.c_float, _f32p]
+        L.oracle_weighted_reduction.argtypes = [_f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+        L.oracle_smooth.argtypes = [_f32p, _f32p, C.c_int, C.c_int]
+        L.oracle_slide.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p]
+        L.oracle_save_history.argtypes = [C.c_int, _f32p, _f32p, C.c_int]
+        L.oracle_state_trajectory.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
+        L.oracle_model_step.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float]
+        L.oracle_set_nominal_control.argtypes = [C.c_void_p, _f32p]
+        L.oracle_iterate.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _f32p]
+        L.oracle_vanilla_compute_control.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p]
+        L.oracle_tube_compute_control.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p]
+        L.oracle_vanilla_slide.argtypes = [C.c_void_p, C.c_int]
+        for n in ("control", "nominal_control", "state_traj", "nominal_state_traj", "costs", "weights", "samples",
+                  "stats"):
+            getattr(L, "oracle_get_" + n).argtypes = [C.c_void_p, _f32p]
+        L.oracle_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
+        L.oracle_philox_normal.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, _f32p]
+        L.oracle_det_eval.argtypes = [C.c_int, _f32p, _f32p, C.c_int]
+        L.oracle_time_iterations.restype = C.c_double
+        L.oracle_time_iterations.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_int]
+        L.oracle_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Oracle:
+    """One (model, K, T, D) oracle instance: kernel-level pieces and the controller loops."""
+
+    def __init__(self, model, K, T, D=1, dt=0.01, lambda_=1.0, alpha=0.0, num_iters=1):
+        self.L = lib()
+        self.h = self.L.oracle_create(model.encode(), K, T, D, dt, lambda_, alpha, num_iters)
+        if not self.h:
+            raise ValueError("oracle: unknown model " + model)
+        s, c, o = C.c_int(), C.c_int(), C.c_int()
+        self.L.oracle_dims(self.h, C.byref(s), C.byref(c), C.byref(o))
+        self.S, self.C, self.O = s.value, c.value, o.value
+        self.K, self.T, self.D = K, T, D
+        self.dt, self.lambda_, self.alpha, self.num_iters = dt, lambda_, alpha, num_iters
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_destroy(self.h)
+            self.h = None
+
+    def set_dynamics_params(self, pod):
+        assert self.L.oracle_set_dynamics_params(self.h, C.byref(pod), C.sizeof(pod)) == 0
+
+    def set_cost_params(self, pod):
+        assert self.L.oracle_set_cost_params(self.h, C.byref(pod), C.sizeof(pod)) == 0
+
+    def set_control_ranges(self, lo_hi):
+        self.L.oracle_set_control_ranges(self.h, _f32(lo_hi).reshape(-1))
+
+    def set_control_deadband(self, db):
+        self.L.oracle_set_control_deadband(self.h, _f32(db).reshape(-1))
+
+    def set_sampler(self, std_dev, control_cost_coeff=None, pure_noise_pct=0.01, std_dev_decay=1.0, sum_strides=32):
+        sd = _f32(std_dev).reshape(-1)
+        if sd.size == self.C and self.D == 2:
+            sd = np.concatenate([sd, sd])
+        cc = _f32(np.zeros(self.C) if control_cost_coeff is None else control_cost_coeff).reshape(-1)
+        self.L.oracle_set_sampler(self.h, sd, cc, pure_noise_pct, std_dev_decay, sum_strides)
+
+    def set_controller_params(self, nominal_threshold=20.0, slide_scale=None):
+        p = None if slide_scale is None else _f32(slide_scale).ctypes.data
+        self.L.oracle_set_controller_params(self.h, nominal_threshold, p)
+
+    # kernel-level
+    def set_gaussian_controls(self, mean, eps, stride=1, iteration=0):
+        v = np.empty((self.D, self.K, self.T, self.C), np.float32)
+        self.L.oracle_set_gaussian_controls(self.h, _f32(mean).reshape(-1), _f32(eps).reshape(-1), stride, iteration, v)
+        return v
+
+    def rollout_costs(self, x0, mean, v, threads=1):
+        v = _f32(v).copy()
+        costs = np.empty((self.D, self.K), np.float32)
+        self.L.oracle_rollout_costs(self.h, _f32(x0).reshape(-1), _f32(mean).reshape(-1), v, costs, threads)
+        return costs, v
+
+    def iterate(self, x0, mean, eps, stride=1, iteration=0):
+        u = np.empty((self.D, self.T, self.C), np.float32)
+        self.L.oracle_iterate(self.h, _f32(x0).reshape(-1), _f32(mean).reshape(-1), _f32(eps).reshape(-1), stride,
+                              iteration, u)
+        return u
+
+    def state_trajectory(self, x0, u):
+        out = np.empty((self.T, self.S), np.float32)
+        self.L.oracle_state_trajectory(self.h, _f32(x0).reshape(-1), _f32(u).reshape(-1), out)
+        return out
+
+    def model_step(self, x, u, dt=None):
+        x = _f32(x).reshape(-1).copy()
+        u = _f32(u).reshape(-1).copy()
+        self.L.oracle_model_step(self.h, x, u, self.dt if dt is None else dt)
+        return x, u
+
+    # controller level
+    def set_nominal_control(self, u):
+        self.L.oracle_set_nominal_control(self.h, _f32(u).reshape(-1))
+
+    def vanilla_compute_control(self, x0, stride, eps):
+        self.L.oracle_vanilla_compute_control(self.h, _f32(x0).reshape(-1), stride, _f32(eps).reshape(-1))
+
+    def tube_compute_control(self, x0, stride, eps):
+        self.L.oracle_tube_compute_control(self.h, _f32(x0).reshape(-1), stride, _f32(eps).reshape(-1))
+
+    def vanilla_slide(self, steps):
+        self.L.oracle_vanilla_slide(self.h, steps)
+
+    def _get(self, name, shape):
+        out = np.empty(shape, np.float32)
+        getattr(self.L, "oracle_get_" + name)(self.h, out)
+        return out
+
+    def control(self):
+        return self._get("control", (self.T, self.C))
+
+    def nominal_control(self):
+        return self._get("nominal_control", (self.T, self.C))
+
+    def state_traj(self):
+        return self._get("state_traj", (self.T, self.S))
+
+    def nominal_state_traj(self):
+        return self._get("nominal_state_traj", (self.T, self.S))
+
+    def costs(self):
+        return self._get("costs", (self.D, self.K))
+
+    def weights(self):
+        return self._get("weights", (self.D, self.K))
+
+    def samples(self):
+        return self._get("samples", (self.D, self.K, self.T, self.C))
+
+    def stats(self):
+        s = self._get("stats", (11,))
+        return {"baseline": s[0:2], "normalizer": s[2:4], "free_energy": s[4:6], "free_energy_var": s[6:8],
+                "free_energy_mod": s[8:10], "nominal_state_used": int(s[10])}
+
+    def time_iterations(self, x0, mean, eps, iters, threads):
+        return self.L.oracle_time_iterations(self.h, _f32(x0).reshape(-1), _f32(mean).reshape(-1),
+                                             _f32(eps).reshape(-1), iters, threads)
+
+
+# free functions
+def philox4x32_10(ctr, key):
+    out = np.zeros(4, np.uint32)
+    lib().oracle_philox4x32_10(np.asarray(ctr, np.uint32), np.asarray(key, np.uint32), out)
+    return out
+
+
+def philox_normal(seed, generation, K, T, Cdim, k_begin=0, k_end=None, stream=0):
+    k_end = K if k_end is None else k_end
+    out = np.empty((k_end - k_begin, T, Cdim), np.float32)
+    lib().oracle_philox_normal(seed, generation, stream, K, T, Cdim, k_begin, k_end, out)
+    return out
+
+
+def det_eval(func, x):
+    x = _f32(x).reshape(-1)
+    y = np.empty_like(x)
+    lib().oracle_det_eval(func, x, y, x.size)
+    return y
+
+
+def baseline(costs):
+    c = _f32(costs).reshape(-1)
+    return float(lib().oracle_baseline(c, c.size))
+
+
+def best_index(costs):
+    c = _f32(costs).reshape(-1)
+    return int(lib().oracle_best_index(c, c.size))
+
+
+def norm_exp(costs, lambda_inv, base):
+    w = _f32(costs).reshape(-1).copy()
+    lib().oracle_norm_exp(w, w.size, lambda_inv, base)
+    return w
+
+
+def normalizer(w):
+    w = _f32(w).reshape(-1)
+    return float(lib().oracle_normalizer(w, w.size))
+
+
+def free_energy(w, base, lambda_):
+    w = _f32(w).reshape(-1)
+    out = np.zeros(3, np.float32)
+    lib().oracle_free_energy(w, w.size, base, lambda_, out)
+    return out
+
+
+def weighted_reduction(w, v, eta, sum_stride=32):
+    v = _f32(v)
+    K, T, Cd = v.shape
+    u = np.empty((T, Cd), np.float32)
+    lib().oracle_weighted_reduction(_f32(w).reshape(-1), v, eta, K, T, Cd, sum_stride, u)
+    return u
+
+
+def smooth(u, history):
+    u = _f32(u).copy()
+    T, Cd = u.shape
+    lib().oracle_smooth(u, _f32(history).reshape(-1), T, Cd)
+    return u
+
+
+def slide(u, steps, zero_control=None, slide_scale=None):
+    u = _f32(u).copy()
+    T, Cd = u.shape
+    z = _f32(np.zeros(Cd) if zero_control is None else zero_control)
+    s = _f32(np.zeros(Cd) if slide_scale is None else slide_scale)
+    lib().oracle_slide(u, T, Cd, steps, z, s)
+    return u
+
+
+def save_history(steps, u, history):
+    h = _f32(history).copy()
+    lib().oracle_save_history(steps, _f32(u).reshape(-1), h.reshape(-1), _f32(u).shape[1])
+    return h
+
+
+def max_threads():
+    return lib().oracle_max_threads()

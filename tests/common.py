@@ -1,0 +1,87 @@
+"""Shared test fixtures: the synthetic configurations of SURVEY.md §8d, built identically for the HIP engine (through
+the C ABI) and for the CPU oracle."""
+import numpy as np
+
+import mppi_generic_amd as m
+import pyoracle as po
+
+SEED = 42
+
+
+def cartpole_cfg(K=2048, T=100, lambda_=0.25, num_iters=1, soft=False):
+    """examples/cartpole_example.cu:9-51 (reference).  soft=True raises lambda so that many rollouts carry weight —
+    the weighted reduction is then a real average, not a copy of the best rollout."""
+    cost = m.CartpoleQuadraticCostParams()
+    cost.cart_position_coeff = 50
+    cost.pole_angle_coeff = 200
+    cost.cart_velocity_coeff = 10
+    cost.pole_angular_velocity_coeff = 1
+    cost.control_cost_coeff[0] = 0
+    cost.terminal_cost_coeff = 0
+    cost.desired_terminal_state[:] = [20, 0, np.float32(np.pi), 0]
+    return dict(model="cartpole", K=K, T=T, D=1, dt=0.02, lambda_=200.0 if soft else lambda_, alpha=0.0,
+                num_iters=num_iters, dyn=m.CartpoleDynamicsParams(1.0, 1.0, 1.0), cost=cost,
+                ranges=[[-5.0, 5.0]], std_dev=[5.0], control_cost_coeff=[0.0], x0=np.zeros(4, np.float32))
+
+
+def cartpole_cfg_lr(K=1024, T=50):
+    """variant that exercises the likelihood-ratio term, the terminal cost, alpha and a non-zero mean"""
+    c = cartpole_cfg(K, T, soft=True)
+    c["control_cost_coeff"] = [0.7]
+    c["alpha"] = 0.1
+    c["cost"].terminal_cost_coeff = 3.0
+    c["x0"] = np.array([0.3, -0.2, 0.5, 0.1], np.float32)
+    return c
+
+
+def di_cfg(K=1024, T=50, tube=True, lambda_=2.0, num_iters=1):
+    """examples/double_integrator_CORL2020.cu:30-39, 316-352 (reference) at test size"""
+    return dict(model="double_integrator", K=K, T=T, D=2 if tube else 1, dt=0.02, lambda_=lambda_, alpha=0.0,
+                num_iters=num_iters, dyn=m.DoubleIntegratorParams(1.0), cost=m.DoubleIntegratorCircleCostParams(),
+                ranges=None, std_dev=[1.0, 1.0], control_cost_coeff=[0.0, 0.0],
+                x0=np.array([2.0, 0.0, 0.0, 1.0], np.float32))
+
+
+def make_engine(cfg, tube=None, **kw):
+    tube = (cfg["D"] == 2) if tube is None else tube
+    cls = m.TubeMPPIController if tube else m.VanillaMPPIController
+    c = cls(cfg["model"], cfg["K"], cfg["T"], cfg["dt"], cfg["lambda_"], cfg["alpha"], cfg["num_iters"], seed=SEED, **kw)
+    c.setDynamicsParams(cfg["dyn"])
+    c.setCostParams(cfg["cost"])
+    if cfg["ranges"] is not None:
+        c.setControlRanges(cfg["ranges"])
+    c.setSamplingParams(cfg["std_dev"], cfg["control_cost_coeff"], cfg.get("pure_pct", 0.01), cfg.get("decay", 1.0))
+    return c
+
+
+def make_oracle(cfg):
+    o = po.Oracle(cfg["model"], cfg["K"], cfg["T"], cfg["D"], cfg["dt"], cfg["lambda_"], cfg["alpha"], cfg["num_iters"])
+    o.set_dynamics_params(cfg["dyn"])
+    o.set_cost_params(cfg["cost"])
+    if cfg["ranges"] is not None:
+        o.set_control_ranges(cfg["ranges"])
+    o.set_sampler(cfg["std_dev"], cfg["control_cost_coeff"], cfg.get("pure_pct", 0.01), cfg.get("decay", 1.0))
+    return o
+
+
+def host_noise(n_iters, K, T, C, seed=SEED):
+    """eps[n_iters][K][T][C] ~ N(0,1) from a fixed-seed host generator (parity is defined downstream of eps)"""
+    rng = np.random.Generator(np.random.Philox(seed))
+    return rng.standard_normal((n_iters, K, T, C), dtype=np.float32)
+
+
+def ulp_diff(a, b):
+    """distance in units in the last place between two float32 arrays (same sign assumed where it matters)"""
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+def merge_records_numpy(U, rho, eta, lambda_):
+    """float64 restatement of combineKernel's merge rule for host-logic tests"""
+    rho_min = rho.min()
+    s = np.exp(-(rho - rho_min) / lambda_)
+    eta_tot = float((s * eta).sum())
+    return (s[:, None] * U).sum(0) / eta_tot, rho_min, eta_tot

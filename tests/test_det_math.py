@@ -1,0 +1,52 @@
+"""Accuracy of include/mppi_amd/det_math.h against float64 libm (CPU side; the GPU side is checked bit-for-bit against
+this same host build in tests/test_gpu_ops.py::test_det_math_device_equals_host_bitwise)."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+
+
+def _ulp_err(got, want64):
+    want = want64.astype(np.float32)
+    ulp = np.abs(np.spacing(want)).astype(np.float64)
+    ulp = np.maximum(ulp, 1.4e-45)
+    return np.abs(got.astype(np.float64) - want64) / ulp
+
+
+@pytest.mark.parametrize("func,ref,lo,hi,tol", [
+    (0, np.sin, -1000, 1000, 2.0), (1, np.cos, -1000, 1000, 2.0), (2, np.exp, -87, 88, 2.0),
+    (4, np.tanh, -12, 12, 2.0), (5, np.arctan, -1e4, 1e4, 3.0),
+])
+def test_accuracy(func, ref, lo, hi, tol):
+    rng = np.random.default_rng(func)
+    x = rng.uniform(lo, hi, 1_000_000).astype(np.float32)
+    got = po.det_eval(func, x)
+    assert _ulp_err(got, ref(x.astype(np.float64))).max() <= tol
+
+
+def test_log_accuracy_and_edges():
+    rng = np.random.default_rng(9)
+    x = np.exp(rng.uniform(np.log(1e-38), np.log(1e38), 1_000_000)).astype(np.float32)
+    assert _ulp_err(po.det_eval(3, x), np.log(x.astype(np.float64))).max() <= 1.5
+    e = po.det_eval(3, np.array([1.0, 0.0, -1.0, np.inf, 1e-45], np.float32))
+    assert e[0] == 0 and e[1] == -np.inf and np.isnan(e[2]) and e[3] == np.inf and abs(e[4] - np.log(1.4e-45)) < 1e-3
+
+
+def test_exp_edges_and_tanh_sigmoid():
+    e = po.det_eval(2, np.array([0.0, -104.0, -200.0, 89.0, np.nan, -87.5, -100.0], np.float32))
+    assert e[0] == 1 and e[1] == 0 and e[2] == 0 and e[3] == np.inf and np.isnan(e[4])
+    assert abs(e[5] / np.exp(-87.5) - 1) < 1e-6 and abs(e[6] - np.exp(-100.0)) <= 1.5e-45  # subnormal range: 1 ulp
+    t = po.det_eval(4, np.array([0.0, 20.0, -20.0, 0.3], np.float32))
+    assert t[0] == 0 and t[1] == 1 and t[2] == -1 and abs(t[3] - np.tanh(0.3)) < 1e-7
+    s = po.det_eval(7, np.array([0.0, 2.0], np.float32))  # device-flavour sigmoid (activation_functions.cuh:49-59)
+    assert s[0] == 0.5 and abs(s[1] - 1 / (1 + np.exp(-2.0))) < 1e-7
+
+
+def test_normalize_angle_matches_fmodf_formula():
+    """reference: utils/angle_utils.cuh:21-27 — fmodf(a + pi, 2pi) -/+ pi in float; fmod is exact, so equality is bitwise"""
+    rng = np.random.default_rng(1)
+    a = rng.uniform(-1e4, 1e4, 500000).astype(np.float32)
+    pi = np.float32(np.pi)
+    r = np.fmod((a + pi).astype(np.float32), np.float32(2) * pi).astype(np.float32)
+    want = np.where(r <= 0, r + pi, r - pi).astype(np.float32)
+    assert np.array_equal(po.det_eval(6, a), want)

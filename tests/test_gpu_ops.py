@@ -1,0 +1,153 @@
+"""Kernel-level operators and error behaviour through the C ABI (reference tests: tests/mppi_core/
+normexp_kernel_tests.cu, weightedreduction_kernel_tests.cu, tests/controllers/controller_kernel_testing.cu)."""
+import numpy as np
+import pytest
+
+import mppi_generic_amd as m
+import pyoracle as po
+from common import cartpole_cfg, host_noise, make_engine, make_oracle, merge_records_numpy, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("func,lo,hi", [(0, -50, 50), (1, -50, 50), (2, -100, 88), (3, 1e-30, 1e30), (4, -12, 12),
+                                        (5, -100, 100), (6, -1000, 1000), (7, -30, 30), (8, 0, 1e20), (9, -1e3, 1e3)])
+def test_det_math_device_equals_host_bitwise(gpu, func, lo, hi):
+    rng = np.random.default_rng(func)
+    x = rng.uniform(lo, hi, 200000).astype(np.float32)
+    if func == 3:
+        x = np.exp(rng.uniform(np.log(1e-30), np.log(1e30), 200000)).astype(np.float32)
+    x[:8] = [0.0, -0.0, 1.0, -1.0, np.float32(np.pi), 1e-40, 0.625, -0.625]
+    if func in (3, 8):
+        x = np.abs(x)
+    a, b = m.det_eval(func, x), po.det_eval(func, x)
+    same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), "det func %d differs at x=%r: %r vs %r" % (func, x[~same][:4], a[~same][:4], b[~same][:4])
+
+
+def test_norm_exp_kernel(gpu):
+    """reference: tests/mppi_core/normexp_kernel_tests.cu:126-150"""
+    rng = np.random.default_rng(0)
+    costs = rng.uniform(0, 100, 10000).astype(np.float32)
+    base = float(costs.min())
+    w_gpu = m.norm_exp(costs, 1.0 / 0.5, base)
+    w_cpu = po.norm_exp(costs, 1.0 / 0.5, base)
+    assert ulp_diff(w_gpu, w_cpu).max() == 0
+
+
+def test_compute_weights_two_pass(gpu):
+    """reference: tests/mppi_core/normexp_kernel_tests.cu:180-256 (old host min/sum vs device weight transform)"""
+    rng = np.random.default_rng(1)
+    costs = rng.uniform(5, 60, 10000).astype(np.float32)
+    w, base, eta = m.compute_weights(costs, 2.0)
+    assert base == po.baseline(costs)
+    w_cpu = po.norm_exp(costs, 2.0, base)
+    assert ulp_diff(w, w_cpu).max() == 0
+    assert abs(eta - po.normalizer(w_cpu)) <= 1e-6 * eta
+
+
+def test_weighted_reduction_kernel(gpu):
+    """reference: tests/mppi_core/weightedreduction_kernel_tests.cu:135-173"""
+    rng = np.random.default_rng(2)
+    K, T, C = 1024, 100, 4
+    w = np.exp(-rng.normal(5.0, 1.2, K)).astype(np.float32)
+    w[0] = 1.0
+    v = rng.normal(5.0, 1.2, (K, T, C)).astype(np.float32)
+    eta = float(w.astype(np.float64).sum())
+    u_gpu = m.weighted_reduction(w, v, eta)
+    u_cpu = po.weighted_reduction(w, v, eta, 64)
+    assert np.abs(u_gpu - u_cpu).max() <= 1e-5 * np.abs(u_cpu).max()
+
+
+def test_error_codes(gpu):
+    with pytest.raises(m.MPPIError) as e:
+        m.VanillaMPPIController("no_such_model", 128, 10, 0.02, 1.0)
+    assert e.value.status == 2 and "cartpole" in str(e.value)
+    with pytest.raises(m.MPPIError) as e:  # launch shape not instantiated (reference: exit(), mppi_common.cu:1266-1277)
+        m.VanillaMPPIController("cartpole", 128, 10, 0.02, 1.0, block_x=48, block_y=3)
+    assert e.value.status == 5
+    with pytest.raises(m.MPPIError) as e:  # LDS overflow (reference: runtime_error, mppi_controller.cu:64-76)
+        m.VanillaMPPIController("cartpole", 128, 2000, 0.02, 1.0)
+    assert e.value.status == 6
+    with pytest.raises(m.MPPIError) as e:
+        m.VanillaMPPIController("cartpole", 0, 10, 0.02, 1.0)
+    assert e.value.status == 1
+    c = m.VanillaMPPIController("cartpole", 128, 10, 0.02, 1.0)
+    with pytest.raises(m.MPPIError) as e:
+        c.setDynamicsParams(m.DoubleIntegratorParams())  # wrong struct size
+    assert e.value.status == 1
+    with pytest.raises(m.MPPIError) as e:
+        c.getSampledControls()  # created without save_samples
+    assert e.value.status == 7
+
+
+def test_nan_state_reports_error(gpu):
+    """reference: base_plant.hpp:515-535 exits on NaN controls; here MPPI_ERR_NAN is returned"""
+    cfg = cartpole_cfg(K=256, T=20, soft=True)
+    eng = make_engine(cfg)
+    with pytest.raises(m.MPPIError) as e:
+        eng.computeControl(np.array([np.nan, 0, 0, 0], np.float32), 1)
+    assert e.value.status == 8
+
+
+def test_two_way_sharding_on_one_gpu(gpu):
+    """K split over two handles (rank 0/1 of world 2) with the exchange done by hand reproduces the unsharded u* —
+    the K-sharding of SURVEY.md §8e, exercised on one device."""
+    import ctypes as C
+    cfg = cartpole_cfg(K=2048, T=100, soft=True)
+    full = make_engine(cfg)
+    full.uploadState(cfg["x0"])
+    full.optimize(1)
+    u_full = full.getOptimalControlSeq()[0]
+    st_full = full.getStats().real_sys
+
+    r = [make_engine(cfg, rank=i, world_size=2) for i in range(2)]
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    for c in r:
+        assert c.num_rollouts_local == 1024
+        c.uploadState(cfg["x0"])
+        c.iterationLocal()
+        c.synchronize()
+    bufs = [c.exchangeBuffers() for c in r]
+    n = bufs[0][2]
+    for dst in range(2):
+        for src in range(2):
+            # recv[dst][src] <- send[src]   (what the all-gather does); 3 = hipMemcpyDeviceToDevice
+            assert hip.hipMemcpy(bufs[dst][1] + 4 * n * src, bufs[src][0], 4 * n, 3) == 0
+    for c in r:
+        c.iterationMerge()
+        c.synchronize()
+        u = c.getOptimalControlSeq()[0]
+        assert np.abs(u - u_full).max() <= 2e-6, np.abs(u - u_full).max()
+        st = c.getStats().real_sys
+        assert st.baseline == st_full.baseline
+        assert abs(st.normalizer - st_full.normalizer) <= 2e-6 * st_full.normalizer
+    # and against the oracle's un-sharded iteration on the oracle's own generator stream
+    orc = make_oracle(cfg)
+    eps = po.philox_normal(42, 0, cfg["K"], cfg["T"], 1)
+    u_orc = orc.iterate(cfg["x0"], np.zeros((cfg["T"], 1), np.float32), eps)[0]
+    assert np.abs(u_full - u_orc).max() <= 1e-5
+
+
+def test_full_size_properties(gpu):
+    """BASELINE size (K=16384, T=100): size-independent properties instead of a slow oracle run —
+    (1) baseline == min of the costs, (2) normaliser == sum of exp weights, (3) u* == direct weighted mean of the
+    dumped samples, (4) rollout 0 is noise-free, (5) the result does not depend on the block shape."""
+    cfg = cartpole_cfg(K=16384, T=100, soft=True)
+    eng = make_engine(cfg, save_samples=True)
+    eng.uploadState(cfg["x0"])
+    eng.optimize(1)
+    costs = eng.getSampledCostSeq()[0]
+    v = eng.getSampledControls()[0]
+    st = eng.getStats().real_sys
+    assert st.baseline == costs.min()
+    w = np.exp(-(costs.astype(np.float64) - costs.min()) / cfg["lambda_"])
+    assert abs(st.normalizer - w.sum()) <= 1e-5 * w.sum()
+    assert np.all(v[0] == 0.0)  # k = 0 takes the (zero) mean exactly
+    assert np.abs(v).max() <= 5.0  # clamped
+    # second handle, different block shape, same seed -> same costs
+    eng2 = make_engine(cfg, block_x=32)
+    eng2.uploadState(cfg["x0"])
+    eng2.optimize(1)
+    assert np.array_equal(eng2.getSampledCostSeq()[0], costs)

@@ -1,0 +1,173 @@
+"""Parity of the HIP engine (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances (fp32 path):
+  trajectory costs      bit-exact (0 ulp): same IEEE operations in the same order on both sides (det_math.h)
+  control sequence u*   L-inf <= 1e-5 absolute — the bar of BASELINE.json; the only difference is the summation order of
+                        the weighted reduction (block-local partials + rescale vs the reference's serial groups)
+  baseline rho          exact;  normaliser eta: 1e-6 relative
+"""
+import numpy as np
+import pytest
+
+import mppi_generic_amd as m
+import pyoracle as po
+from common import (cartpole_cfg, cartpole_cfg_lr, di_cfg, host_noise, make_engine, make_oracle, ulp_diff)
+
+pytestmark = pytest.mark.gpu
+U_TOL = 1e-5
+
+
+def _rollout_both(cfg, eps, mean=None, stride=1, **kw):
+    K, T, D = cfg["K"], cfg["T"], cfg["D"]
+    eng = make_engine(cfg, **kw)
+    orc = make_oracle(cfg)
+    C = eng.CONTROL_DIM
+    mean = np.zeros((T, C), np.float32) if mean is None else mean
+    eng.updateImportanceSampler(mean)
+    eng.injectNoise(eps)
+    x0 = np.tile(cfg["x0"], (D, 1))
+    costs_gpu = eng.rolloutCosts(x0, stride)
+    means = np.tile(mean, (D, 1, 1))
+    v = orc.set_gaussian_controls(means, eps, stride, 0)
+    costs_cpu, v_clamped = orc.rollout_costs(x0, means, v)
+    return eng, orc, costs_gpu, costs_cpu, v_clamped
+
+
+@pytest.mark.parametrize("shape", [(64, 1), (32, 1), (64, 4), (16, 4)])
+def test_cartpole_rollout_costs_bit_exact(gpu, shape):
+    """reference test: tests/mppi_core/rollout_kernel_tests.cu:200-261 (GPU rollout vs CPU rollout over block shapes;
+    reference tolerance 1e-4 relative, here 0 ulp)"""
+    cfg = cartpole_cfg(K=2048, T=100)
+    eps = host_noise(1, cfg["K"], cfg["T"], 1)[0]
+    eng, orc, g, c, _ = _rollout_both(cfg, eps, block_x=shape[0], block_y=shape[1])
+    assert np.isfinite(g).all()
+    assert ulp_diff(g, c).max() == 0, "max ulp diff %d" % ulp_diff(g, c).max()
+
+
+def test_cartpole_lr_terminal_nonzero_mean_bit_exact(gpu):
+    cfg = cartpole_cfg_lr()
+    eps = host_noise(1, cfg["K"], cfg["T"], 1)[0]
+    mean = (0.5 * np.sin(np.arange(cfg["T"], dtype=np.float32) * 0.3)).reshape(-1, 1).astype(np.float32)
+    eng, orc, g, c, _ = _rollout_both(cfg, eps, mean=mean, stride=3)
+    assert ulp_diff(g, c).max() == 0
+
+
+def test_ragged_rollout_count(gpu):
+    """K not a multiple of the block: the last block is partially filled (reference exits, mppi_common.cu:1305-1310)"""
+    cfg = cartpole_cfg(K=1000, T=37, soft=True)
+    eps = host_noise(1, cfg["K"], cfg["T"], 1)[0]
+    eng, orc, g, c, _ = _rollout_both(cfg, eps)
+    assert ulp_diff(g, c).max() == 0
+    eng.computeControl(cfg["x0"], 1)
+    orc.vanilla_compute_control(cfg["x0"], 1, eps)
+    assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
+
+
+@pytest.mark.parametrize("soft", [False, True])
+def test_vanilla_compute_control_parity(gpu, soft):
+    """one computeControl: u* (smoothed, constrained), nominal state trajectory, baseline, normaliser"""
+    cfg = cartpole_cfg(K=2048, T=100, soft=soft)
+    eps = host_noise(1, cfg["K"], cfg["T"], 1)
+    eng, orc = make_engine(cfg), make_oracle(cfg)
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    orc.vanilla_compute_control(cfg["x0"], 1, eps)
+    u_g, u_c = eng.getControlSeq(), orc.control()
+    assert np.abs(u_g - u_c).max() <= U_TOL, np.abs(u_g - u_c).max()
+    assert np.abs(eng.getTargetStateSeq() - orc.state_traj()).max() <= 1e-4
+    st, so = eng.getStats(), orc.stats()
+    assert st.real_sys.baseline == so["baseline"][0]
+    assert abs(st.real_sys.normalizer - so["normalizer"][0]) <= 1e-6 * so["normalizer"][0] + 1e-6
+    assert abs(st.real_sys.free_energy_mean - so["free_energy"][0]) <= 1e-4 * abs(so["free_energy"][0]) + 1e-4
+    if soft:
+        assert so["normalizer"][0] > 50.0  # the average really involves many rollouts
+
+
+def test_vanilla_multi_iteration_and_closed_loop(gpu):
+    """num_iters = 3 and a 15-step closed loop with slideControlSequence (examples/cartpole_example.cu:63-85)"""
+    cfg = cartpole_cfg(K=1024, T=60, soft=True, num_iters=3)
+    steps = 15
+    eng, orc = make_engine(cfg), make_oracle(cfg)
+    x_g = cfg["x0"].copy()
+    x_c = cfg["x0"].copy()
+    worst = 0.0
+    for i in range(steps):
+        eps = host_noise(3, cfg["K"], cfg["T"], 1, seed=100 + i)
+        eng.injectNoise(eps)
+        eng.computeControl(x_g, 1)
+        orc.vanilla_compute_control(x_c, 1, eps)
+        u_g, u_c = eng.getControlSeq(), orc.control()
+        worst = max(worst, float(np.abs(u_g - u_c).max()))
+        x_g, _ = eng.modelStep(x_g, u_g[0])
+        x_c, _ = orc.model_step(x_c, u_c[0])
+        eng.slideControlSequence(1)
+        orc.vanilla_slide(1)
+    # errors may compound through the closed loop (each step's u* feeds the next mean); still within the bar
+    assert worst <= 5e-5, worst
+    assert np.abs(x_g - x_c).max() <= 1e-4
+
+
+def test_fused_philox_matches_oracle_generator(gpu):
+    """the fused in-kernel generator draws exactly the oracle's Philox/Box-Muller stream, for every generation"""
+    for gen in (0, 1, 7):
+        a = m.philox_normal(1234567, gen, 640, 50, 2, 0, 640)
+        b = po.philox_normal(1234567, gen, 640, 50, 2, 0, 640)
+        assert ulp_diff(a, b).max() == 0
+    a = m.philox_normal(99, 3, 1000, 33, 1, 333, 667)  # a shard in the middle, odd sizes
+    b = po.philox_normal(99, 3, 1000, 33, 1, 333, 667)
+    assert ulp_diff(a, b).max() == 0
+    assert abs(float(a.mean())) < 0.02 and abs(float(a.std()) - 1.0) < 0.02
+
+
+def test_fused_rng_mode_parity(gpu):
+    """RNG mode end to end: the samples the kernel used == oracle samples from the oracle's generator; u* parity"""
+    cfg = cartpole_cfg(K=2048, T=100, soft=True, num_iters=2)
+    eng = make_engine(cfg, save_samples=True)
+    orc = make_oracle(cfg)
+    eps = np.stack([po.philox_normal(42, g, cfg["K"], cfg["T"], 1) for g in range(2)])
+    eng.computeControl(cfg["x0"], 1)
+    orc.vanilla_compute_control(cfg["x0"], 1, eps)
+    v_gpu = eng.getSampledControls()
+    assert ulp_diff(v_gpu, orc.samples()).max() == 0  # samples of the last iteration, clamped
+    assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
+
+
+def test_tube_double_integrator_parity(gpu):
+    """Tube-MPPI, two systems per launch (reference: tests/controllers/tube_mppi_test.cu, examples/
+    double_integrator_CORL2020.cu); nominal==actual invariance of rollout_kernel_tests.cu:181-198 is implied at step 0"""
+    cfg = di_cfg(K=1024, T=50, tube=True, num_iters=2)
+    eng, orc = make_engine(cfg), make_oracle(cfg)
+    x = cfg["x0"].copy()
+    for i in range(4):
+        eps = host_noise(2, cfg["K"], cfg["T"], 2, seed=7 + i)
+        eng.injectNoise(eps)
+        eng.computeControl(x, 1)
+        orc.tube_compute_control(x, 1, eps)
+        assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
+        assert np.abs(eng.getNominalControlSeq() - orc.nominal_control()).max() <= U_TOL
+        assert np.abs(eng.getTargetStateSeq() - orc.state_traj()).max() <= 1e-4
+        assert np.abs(eng.getNominalStateSeq() - orc.nominal_state_traj()).max() <= 1e-4
+        st, so = eng.getStats(), orc.stats()
+        assert st.real_sys.baseline == so["baseline"][0] and st.nominal_sys.baseline == so["baseline"][1]
+        assert st.nominal_state_used == so["nominal_state_used"]
+        # disturb the actual state so that the two systems diverge
+        x = x + np.array([0.05, -0.03, 0.2, -0.1], np.float32) * (i + 1)
+
+
+def test_tube_costs_identical_when_states_identical(gpu):
+    """reference: tests/mppi_core/rollout_kernel_tests.cu:181-198 — same x0 for both systems => identical costs"""
+    cfg = di_cfg(K=512, T=40, tube=True)
+    eng = make_engine(cfg)
+    eps = host_noise(1, cfg["K"], cfg["T"], 2)
+    eng.injectNoise(eps)
+    costs = eng.rolloutCosts(np.tile(cfg["x0"], (2, 1)), 1)
+    assert np.array_equal(costs[0], costs[1])
+
+
+def test_di_lds_contract_path(gpu):
+    """blockDim.y > 1 (LDS + barrier path of the plugin contract) gives the same costs as the register path"""
+    cfg = di_cfg(K=512, T=40, tube=False)
+    eps = host_noise(1, cfg["K"], cfg["T"], 2)[0]
+    _, _, g1, c, _ = _rollout_both(cfg, eps, block_x=64, block_y=1)
+    _, _, g2, _, _ = _rollout_both(cfg, eps, block_x=64, block_y=2)
+    assert ulp_diff(g1, c).max() == 0 and ulp_diff(g2, c).max() == 0
