@@ -87,34 +87,34 @@ MPPI_HD static inline float copysign(float mag, float sgn)
 }
 
 /**
- * Exact fmodf(a, b) for b > 0 (C99 semantics: result has the sign of a, |result| < b).
- * Fast path: q = trunc(a/b) may be off by one; fma(-q, b, a) is then exact because the true remainder is
- * representable, and one conditional +-b fixes the off-by-one.  Falls back to the (also exact) library fmodf when
- * the quotient does not fit the fast path.  Used by normalizeAngle (reference: utils/angle_utils.cuh:21-27).
+ * Exact fmodf(a, b) for b > 0 (C99 semantics: result has the sign of a, |result| < b), given rb = (float)(1/b).
+ * q = trunc(a * rb) is within one of the true quotient; fma(-q, b, a) is then exact because the true remainder is
+ * representable, and one conditional +-b fixes the off-by-one in either direction.  No division on the fast path.
+ * Falls back to the (also exact) library fmodf when the quotient is too large for that argument.
+ * Used by normalizeAngle (reference: utils/angle_utils.cuh:21-27).
  */
-MPPI_HD static inline float fmod(float a, float b)
+MPPI_HD static inline float fmod_rb(float a, float b, float rb)
 {
-  const float q = trunc(a / b);
-  if (!(fabs(q) < 4194304.0f))
+  const float q = trunc(a * rb);
+  if (!(fabs(q) < 2097152.0f))
   {
     return ::fmodf(a, b);
   }
   float r = fma(-q, b, a);
+  const float rp = r + b, rm = r - b;
   if (a >= 0.0f)
   {
-    if (r < 0.0f)
-      r += b;
-    else if (r >= b)
-      r -= b;
+    r = (r < 0.0f) ? rp : ((r >= b) ? rm : r);
   }
   else
   {
-    if (r > 0.0f)
-      r -= b;
-    else if (r <= -b)
-      r += b;
+    r = (r > 0.0f) ? rm : ((r <= -b) ? rp : r);
   }
   return r;
+}
+MPPI_HD static inline float fmod(float a, float b)
+{
+  return fmod_rb(a, b, 1.0f / b);
 }
 
 #define MPPI_DET_PI 3.14159274101257324219f     /* (float)pi, same value as glibc's M_PIf32 used by the reference */
@@ -123,7 +123,7 @@ MPPI_HD static inline float fmod(float a, float b)
 /** Reference: include/mppi/utils/angle_utils.cuh:21-27 (float overload), same branch structure. */
 MPPI_HD static inline float normalizeAngle(float angle)
 {
-  const float result = fmod(angle + MPPI_DET_PI, MPPI_DET_TWO_PI);
+  const float result = fmod_rb(angle + MPPI_DET_PI, MPPI_DET_TWO_PI, 0.15915494309189534561f);
   if (result <= 0.0f)
     return result + MPPI_DET_PI;
   return result - MPPI_DET_PI;

@@ -10,8 +10,11 @@
  *
  * The stream depends only on (seed, generation, GLOBAL element index), so any sharding of the K rollouts over GPUs
  * draws exactly the same noise — the property SURVEY.md §8e asks for.
- *   element e = (k*T + t)*C + c;  block = e / 4;  counter = {lo32(block), hi32(block), generation, stream}
- *   key = {lo32(seed), hi32(seed)};  (x0,x1) -> Box-Muller -> lanes 0,1;  (x2,x3) -> lanes 2,3
+ *   element j = t*C + c of rollout k's row;  quad q = j / 4, lane = j % 4
+ *   counter = {q, k_global, generation, stream};  key = {lo32(seed), hi32(seed)}
+ *   (x0,x1) -> Box-Muller -> lanes 0,1;  (x2,x3) -> lanes 2,3
+ * Quads never straddle rollouts, so the 64 lanes of a wave (64 consecutive rollouts at the same t) need a new quad at
+ * the same step: the draw is a wave-uniform branch inside the rollout loop.
  * Box-Muller uses det_math so host and device produce identical bits (tests/test_rng.py).
  */
 #ifndef MPPI_AMD_PHILOX_H_
@@ -74,12 +77,13 @@ MPPI_HD static inline void box_muller(uint32_t xa, uint32_t xb, float* z0, float
   *z1 = r * s;
 }
 
-/** four N(0,1) draws for counter block `blk` */
-MPPI_HD static inline void normal4(uint64_t seed, uint32_t generation, uint32_t stream, uint64_t blk, float z[4])
+/** four N(0,1) draws: quad `quad` of global rollout `rollout` */
+MPPI_HD static inline void normal4(uint64_t seed, uint32_t generation, uint32_t stream, uint32_t rollout, uint32_t quad,
+                                   float z[4])
 {
   uint4_t c;
-  c.x = (uint32_t)blk;
-  c.y = (uint32_t)(blk >> 32);
+  c.x = quad;
+  c.y = rollout;
   c.z = generation;
   c.w = stream;
   const uint4_t r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));

@@ -13,10 +13,14 @@
  *
  * Here the samples of a block never leave the CU: the sampler's per-rollout LDS request (getBlkSharedSizeBytes) IS the
  * sample row v[k][0..T*C) (+1 float of padding when T*C is even, so that the 64 lanes of a wave, which walk the rows at
- * the same t, hit 64 different banks).  initializeDistributions() fills the rows with eps — drawn in place from
- * Philox4x32-10 (philox.h) or, in parity / rocRAND-host mode, copied coalesced from an eps buffer in HBM —
- * readControlSample() applies the setGaussianControls rule on the fly, writeControlSample() stores the clamped control
- * back into the row, and after the rollout the kernel's epilogue forms the block's weighted partial sum from the rows.
+ * the same t, hit 64 different banks).  Where eps comes from:
+ *   - single-lane rollouts (blockDim.y == 1), Philox: drawn INSIDE the step loop, one Philox4x32-10 quad per 4 row
+ *     elements into registers (readControlSampleFused).  The draw does not depend on the state, so its instructions
+ *     fill the issue slots the dependent dynamics chain leaves empty;
+ *   - otherwise initializeDistributions() fills the rows first: Philox by all threads of the block, or — parity /
+ *     rocRAND-host mode — a coalesced copy from the eps buffer in HBM.
+ * readControlSample*() applies the setGaussianControls rule on the fly, writeControlSample() stores the clamped control
+ * into the row, and after the rollout the kernel's epilogue forms the block's weighted partial sum from the rows.
  * The special-trajectory rules use the GLOBAL rollout index (rollout_offset_ + local index) so they survive sharding.
  *
  * Same names and argument meaning as the reference's SamplingDistribution device interface
@@ -136,14 +140,22 @@ public:
            (1.0f - params_.pure_noise_trajectories_percentage) * (float)num_rollouts_global_;
   }
 
+  /** true when the kernel draws eps inside the step loop instead of pre-filling the rows */
+  __device__ inline bool drawsInLoop() const
+  {
+    return noise_source_ == NOISE_PHILOX_FUSED && __builtin_amdgcn_workgroup_size_y() == 1;
+  }
+
   /**
-   * Fills the block's sample rows with eps (all threads of the block cooperate; block-uniform control flow).
-   * Rows are consecutive rollouts, so the block's eps is one contiguous span of blockDim.x * T*C floats / one
-   * contiguous range of Philox counter blocks.
+   * Fills the block's sample rows with eps (all threads of the block cooperate; block-uniform control flow), unless
+   * the kernel draws in the loop.  Rows are consecutive rollouts, so in buffer mode the block's eps is one contiguous
+   * span of blockDim.x * T*C floats.
    */
   __device__ inline void initializeDistributions(const float* __restrict__ output, const float t_0, const float dt,
                                                  float* __restrict__ theta_d)
   {
+    if (drawsInLoop())
+      return;
     const int TC = params_.num_timesteps * CONTROL_DIM;
     const int stride = rowStride(params_.num_timesteps);
     const int bx = (int)__builtin_amdgcn_workgroup_size_x();
@@ -154,9 +166,9 @@ public:
     const int nz = (int)blockDim.z;
     if (nrows <= 0)
       return;
-    const int total = nrows * TC;  // floats in the block's eps span
     if (noise_source_ == NOISE_EPS_BUFFER)
     {
+      const int total = nrows * TC;  // floats in the block's eps span
       const float* __restrict__ src = eps_d_ + (size_t)row0 * TC;
       int row = 0, col = tid_flat;
       while (col >= TC)
@@ -179,29 +191,79 @@ public:
     }
     else
     {
-      // global element index of the span start; (row0 + offset) * TC is a multiple of 4 whenever bx is, otherwise the
-      // edge quads are generated by both neighbouring blocks and each keeps its own lanes
-      const uint64_t e0 = (uint64_t)(row0 + rollout_offset_) * (uint64_t)TC;
-      const uint64_t q0 = e0 >> 2;
-      const int lead = (int)(e0 & 3);  // lanes of the first quad that belong to the previous block
-      const int nquads = (lead + total + 3) >> 2;
-      for (int q = tid_flat; q < nquads; q += nthreads)
+      const int qpr = (TC + 3) >> 2;  // quads per row
+      const int nquads = nrows * qpr;
+      for (int i = tid_flat; i < nquads; i += nthreads)
       {
+        const int row = i / qpr;
+        const int q = i - row * qpr;
         float zn[4];
-        mppi::rng::normal4(seed_, generation_, 0u, q0 + (uint64_t)q, zn);
+        mppi::rng::normal4(seed_, generation_, 0u, (uint32_t)(row0 + row + rollout_offset_), (uint32_t)q, zn);
 #pragma unroll
         for (int l = 0; l < 4; l++)
         {
-          const int e = q * 4 + l - lead;
-          if (e >= 0 && e < total)
-          {
-            const int row = e / TC;
-            const int col = e - row * TC;
+          const int col = q * 4 + l;
+          if (col < TC)
             for (int z = 0; z < nz; z++)
               theta_d[(z * bx + row) * stride + col] = zn[l];
-          }
         }
       }
+    }
+  }
+
+  /** per-thread generator state of the in-loop draw: the current Philox quad */
+  struct ThreadNoise
+  {
+    float z0, z1, z2, z3;
+  };
+
+  /** the setGaussianControls rule (gaussian.cu:99-127), branch-free */
+  __device__ inline float shapeSample(float m, float sd, float e, bool use_mean, bool pure) const
+  {
+    const float se = sd * e;
+    const float full = m + se;
+    return use_mean ? m : (pure ? se : full);
+  }
+
+  /**
+   * readControlSample for a rollout that owns one lane: eps comes from registers (in-loop Philox) or from the
+   * pre-filled row.  Block-uniform in t, so the quad refresh is a uniform branch.
+   */
+  __device__ inline void readControlSampleFused(ThreadNoise& tn, const int sample_index, const int t,
+                                                const int distribution_index, float* __restrict__ control,
+                                                float* __restrict__ theta_d)
+  {
+    const int d = distribution_index >= params_.num_distributions ? 0 : distribution_index;
+    const int slot = (int)(blockDim.x * threadIdx.z + threadIdx.x);
+    const float* row = sampleRow(theta_d, slot) + t * CONTROL_DIM;
+    const float* mean = control_means_d_ + (size_t)(params_.num_timesteps * d + t) * CONTROL_DIM;
+    const bool use_mean = ((sample_index + rollout_offset_) == 0) || (t < optimization_stride_);
+    const bool pure = isPureNoise(sample_index);
+    const bool in_loop = noise_source_ == NOISE_PHILOX_FUSED;
+#pragma unroll
+    for (int i = 0; i < CONTROL_DIM; i++)
+    {
+      float e;
+      if (in_loop)
+      {
+        const int j = t * CONTROL_DIM + i;
+        if ((j & 3) == 0)
+        {
+          float zn[4];
+          mppi::rng::normal4(seed_, generation_, 0u, (uint32_t)(sample_index + rollout_offset_), (uint32_t)(j >> 2), zn);
+          tn.z0 = zn[0];
+          tn.z1 = zn[1];
+          tn.z2 = zn[2];
+          tn.z3 = zn[3];
+        }
+        const int l = j & 3;
+        e = (l == 0) ? tn.z0 : ((l == 1) ? tn.z1 : ((l == 2) ? tn.z2 : tn.z3));
+      }
+      else
+      {
+        e = row[i];
+      }
+      control[i] = shapeSample(mean[i], std_dev_decayed_[CONTROL_DIM * d + i], e, use_mean, pure);
     }
   }
 
@@ -222,17 +284,7 @@ public:
     const bool pure = isPureNoise(sample_index);
     for (int i = thread_index; i < CONTROL_DIM; i += block_size)
     {
-      const float m = mean[i];
-      const float sd = std_dev_decayed_[CONTROL_DIM * d + i];
-      const float e = row[i];
-      float v;
-      if (use_mean)
-        v = m;
-      else if (pure)
-        v = sd * e;
-      else
-        v = m + sd * e;
-      control[i] = v;
+      control[i] = shapeSample(mean[i], std_dev_decayed_[CONTROL_DIM * d + i], row[i], use_mean, pure);
     }
   }
 
@@ -263,6 +315,14 @@ public:
     const float* mean = control_means_d_ + (size_t)(params_.num_timesteps * d + t) * CONTROL_DIM;
     const float* control_cost_coeff = params_.control_cost_coeff;
     const bool pure = isPureNoise(sample_index);
+    // coeff == 0 for every control (the reference's default, gaussian.cuh:26): each term is exactly +-0 and the sum does
+    // not change the running cost, so the divisions are skipped (uniform branch)
+    bool any_coeff = false;
+#pragma unroll
+    for (int j = 0; j < CONTROL_DIM; j++)
+      any_coeff |= (control_cost_coeff[j] != 0.0f);
+    if (!any_coeff)
+      return 0.0f;
     float cost = 0.0f;
     int i = (int)__builtin_amdgcn_workitem_id_y();
     const int step = (int)__builtin_amdgcn_workgroup_size_y();

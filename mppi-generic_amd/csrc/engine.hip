@@ -420,7 +420,8 @@ static mppi_status launchCombine(mppi_handle h, const float* records, int num_re
   a.record_out_d = record_out;
   a.stats_out_d = h->stats_d;
   const size_t smem = sizeof(float) * (size_t)((num_records + 3) / 4 * 4);
-  hipLaunchKernelGGL(kernels::combineKernel, dim3(h->D), dim3(kernels::COMBINE_THREADS), smem, h->stream, a);
+  hipLaunchKernelGGL(kernels::combineKernel, dim3(h->D, (h->TC + kernels::COMBINE_COLS - 1) / kernels::COMBINE_COLS),
+                     dim3(kernels::COMBINE_THREADS), smem, h->stream, a);
   HIP_TRY(h, hipGetLastError());
   return MPPI_OK;
 }
@@ -643,8 +644,9 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0, int str
   std::vector<float>* so[2] = { &h->state_h, nullptr };
   MPPI_TRY(finalize(h, h->mean_d, /*smooth*/ 1, /*constrain*/ 1, co, so));
   MPPI_TRY(fetchStats(h));
-  if (!allFinite(h->control_h))
-    return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control sequence");
+  // base_plant.hpp:515-528 checks both the control and the state trajectory
+  if (!allFinite(h->control_h) || !allFinite(h->state_h))
+    return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control or state sequence");
   return MPPI_OK;
 }
 
@@ -684,8 +686,9 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
   HIP_TRY(h, hipMemcpyAsync(h->x0_d + S, h->nominal_state_h.data(), sizeof(float) * S, hipMemcpyHostToDevice,
                             h->stream));
   MPPI_TRY(finalize(h, h->ctrl_in_d, /*smooth nominal*/ 2, 0, co, so));
-  if (!allFinite(h->control_h) || !allFinite(h->nominal_control_h))
-    return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control sequence");
+  if (!allFinite(h->control_h) || !allFinite(h->nominal_control_h) || !allFinite(h->state_h) ||
+      !allFinite(h->nominal_state_h))
+    return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control or state sequence");
   return MPPI_OK;
 }
 
@@ -1153,20 +1156,17 @@ mppi_status mppi_weighted_reduction(const float* weights, const float* v, float 
   return MPPI_OK;
 }
 
-__global__ void philoxNormalKernel(uint64_t seed, uint32_t generation, uint64_t e0, uint64_t e1, float* out)
+__global__ void philoxNormalKernel(uint64_t seed, uint32_t generation, int TC, int k_begin, int k_end, float* out)
 {
-  const uint64_t q0 = e0 >> 2;
-  const uint64_t nq = ((e1 + 3) >> 2) - q0;
-  for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < nq; q += (uint64_t)gridDim.x * blockDim.x)
+  const int qpr = (TC + 3) / 4;  // quads per rollout row
+  const int nq = (k_end - k_begin) * qpr;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x)
   {
+    const int r = i / qpr, q = i - r * qpr;
     float z[4];
-    mppi::rng::normal4(seed, generation, 0u, q0 + q, z);
-    for (int l = 0; l < 4; l++)
-    {
-      const uint64_t e = (q0 + q) * 4 + l;
-      if (e >= e0 && e < e1)
-        out[e - e0] = z[l];
-    }
+    mppi::rng::normal4(seed, generation, 0u, (uint32_t)(k_begin + r), (uint32_t)q, z);
+    for (int l = 0; l < 4 && q * 4 + l < TC; l++)
+      out[(size_t)r * TC + q * 4 + l] = z[l];
   }
 }
 
@@ -1176,12 +1176,12 @@ mppi_status mppi_philox_normal(uint64_t seed, uint32_t generation, int K, int T,
   if (!eps_out || K <= 0 || T <= 0 || C <= 0 || k_begin < 0 || k_end > K || k_begin >= k_end)
     return MPPI_ERR_INVALID_ARG;
   MPPI_TRY(opDevice(device));
-  const uint64_t e0 = (uint64_t)k_begin * T * C, e1 = (uint64_t)k_end * T * C;
+  const size_t n = (size_t)(k_end - k_begin) * T * C;
   DevBuf d;
-  OP_TRY(d.alloc(e1 - e0));
-  hipLaunchKernelGGL(philoxNormalKernel, dim3(256), dim3(256), 0, 0, seed, generation, e0, e1, d.p);
+  OP_TRY(d.alloc(n));
+  hipLaunchKernelGGL(philoxNormalKernel, dim3(256), dim3(256), 0, 0, seed, generation, T * C, k_begin, k_end, d.p);
   OP_TRY(hipGetLastError());
-  OP_TRY(hipMemcpy(eps_out, d.p, sizeof(float) * (e1 - e0), hipMemcpyDeviceToHost));
+  OP_TRY(hipMemcpy(eps_out, d.p, sizeof(float) * n, hipMemcpyDeviceToHost));
   return MPPI_OK;
 }
 

@@ -12,7 +12,10 @@
  * finalize == 0 writes the merged record (per-GPU partial, layout identical to the input records) instead of u*.
  * Also produces the reference's free-energy statistics (mppi_common.cu:1065-1081) from eta and sum w^2.
  *
- * Launch: grid = D (one block per system), block = COMBINE_THREADS, dynamic LDS = num_records floats.
+ * Launch: grid = (D systems, ceil(T*C / 64) column blocks), block = COMBINE_THREADS (4 waves), dynamic LDS =
+ * num_records floats.  Every block recomputes rho / s_b / eta from the record tails (a few hundred floats), then wave w
+ * sums records w, w+4, ... for the block's 64 columns with 8 loads in flight per lane, and the four wave partials are
+ * added in a fixed order — the record matrix is read once, coalesced, by D*ceil(TC/64)*4 waves instead of one.
  */
 #ifndef MPPI_AMD_REDUCE_KERNELS_HPP_
 #define MPPI_AMD_REDUCE_KERNELS_HPP_
@@ -74,15 +77,21 @@ __device__ inline double blockSum(double v, double* red_s)
   return r;
 }
 
+constexpr int COMBINE_COLS = 64;
+
 __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* s_b = reinterpret_cast<float*>(smem_raw);  // [num_records]
   __shared__ double red_d[COMBINE_THREADS / 64];
   __shared__ float red_f[COMBINE_THREADS / 64];
+  __shared__ float part_s[COMBINE_THREADS / 64][COMBINE_COLS];
 
   const int z = blockIdx.x;
+  const int col0 = blockIdx.y * COMBINE_COLS;
   const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  constexpr int NW = COMBINE_THREADS / 64;
   const float* rec = a.records_d + (size_t)z * a.num_records * a.PS;
   const float lambda_inv = (float)(1.0 / (double)a.lambda);
 
@@ -102,19 +111,41 @@ __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineAr
   }
   eta = blockSum(eta, red_d);
   eta2 = blockSum(eta2, red_d);  // blockSum's barriers also publish s_b
-
   const float eta_f = (float)eta;
-  for (int j = tid; j < a.TC; j += COMBINE_THREADS)
+
+  const int j = col0 + lane;
+  float acc = 0.0f;
+  if (j < a.TC)
   {
-    float acc = 0.0f;
-    for (int b = 0; b < a.num_records; b++)
-      acc += s_b[b] * rec[(size_t)b * a.PS + j];
-    if (a.finalize)
-      a.mean_out_d[(size_t)z * a.TC + j] = acc / eta_f;
-    else
-      a.record_out_d[(size_t)z * a.PS + j] = acc;
+    const float* col = rec + j;
+    int b = wave;
+    for (; b + 7 * NW < a.num_records; b += 8 * NW)
+    {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        v[i] = col[(size_t)(b + i * NW) * a.PS];
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        acc += s_b[b + i * NW] * v[i];
+    }
+    for (; b < a.num_records; b += NW)
+      acc += s_b[b] * col[(size_t)b * a.PS];
   }
-  if (tid == 0)
+  part_s[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && j < a.TC)
+  {
+    float tot = part_s[0][lane];
+#pragma unroll
+    for (int w = 1; w < NW; w++)
+      tot += part_s[w][lane];
+    if (a.finalize)
+      a.mean_out_d[(size_t)z * a.TC + j] = tot / eta_f;
+    else
+      a.record_out_d[(size_t)z * a.PS + j] = tot;
+  }
+  if (tid == 0 && blockIdx.y == 0)
   {
     if (a.finalize)
     {

@@ -173,8 +173,12 @@ __global__ void __launch_bounds__(BX* BY* BZ)
   __syncthreads();
 
   float running_cost = 0.0f;
+  typename SAMPLING_T::ThreadNoise noise_state = {};
   auto one_step = [&](float* xc, float* xn, int t) {
-    sampling->readControlSample(global_idx, t, distribution_idx, u, theta_d_shared, BY, thread_idy, y);
+    if (BY == 1)
+      sampling->readControlSampleFused(noise_state, global_idx, t, distribution_idx, u, theta_d_shared);
+    else
+      sampling->readControlSample(global_idx, t, distribution_idx, u, theta_d_shared, BY, thread_idy, y);
     lane_sync();
     dynamics->enforceConstraints(xc, u);
     lane_sync();

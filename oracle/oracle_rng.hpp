@@ -10,9 +10,9 @@
  * rocRAND/cuRAND's PHILOX4_32_10 type), restated from the paper and checked against the Random123 known-answer
  * vectors in tests/test_oracle_kat.py, followed by a Box-Muller transform written with det_math.
  *
- * Counter layout (shard-count invariant: depends only on the GLOBAL element index):
- *   element e = (k*T + t)*C + c of eps[K][T][C];   block = e / 4, lane = e % 4
- *   counter = { lo32(block), hi32(block), generation, stream }   key = { lo32(seed), hi32(seed) }
+ * Counter layout (shard-count invariant: depends only on the GLOBAL rollout index):
+ *   element j = t*C + c of rollout k's row of eps[K][T][C];   quad = j / 4, lane = j % 4
+ *   counter = { quad, k, generation, stream }   key = { lo32(seed), hi32(seed) }
  *   generation = number of generateSamples calls so far (cuRAND's advancing offset), stream = 0 for eps.
  *   (x0,x1) -> Box-Muller -> lanes 0,1;  (x2,x3) -> lanes 2,3.
  */
@@ -72,20 +72,19 @@ inline void philoxNormal(uint64_t seed, uint32_t generation, uint32_t stream, in
                          int k_end, float* eps_out)
 {
   const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
-  const uint64_t e0 = (uint64_t)k_begin * T * C, e1 = (uint64_t)k_end * T * C;
-  for (uint64_t blk = e0 / 4; blk * 4 < e1; blk++)
+  const int TC = T * C;
+  for (int k = k_begin; k < k_end; k++)
   {
-    const uint32_t ctr[4] = { (uint32_t)blk, (uint32_t)(blk >> 32), generation, stream };
-    uint32_t x[4];
-    philox4x32_10(ctr, key, x);
-    float z[4];
-    boxMuller(x[0], x[1], &z[0], &z[1]);
-    boxMuller(x[2], x[3], &z[2], &z[3]);
-    for (int l = 0; l < 4; l++)
+    for (int q = 0; q * 4 < TC; q++)
     {
-      const uint64_t e = blk * 4 + l;
-      if (e >= e0 && e < e1)
-        eps_out[e - e0] = z[l];
+      const uint32_t ctr[4] = { (uint32_t)q, (uint32_t)k, generation, stream };
+      uint32_t x[4];
+      philox4x32_10(ctr, key, x);
+      float z[4];
+      boxMuller(x[0], x[1], &z[0], &z[1]);
+      boxMuller(x[2], x[3], &z[2], &z[3]);
+      for (int l = 0; l < 4 && q * 4 + l < TC; l++)
+        eps_out[(size_t)(k - k_begin) * TC + q * 4 + l] = z[l];
     }
   }
 }

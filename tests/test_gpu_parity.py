@@ -148,7 +148,10 @@ def test_tube_double_integrator_parity(gpu):
         assert np.abs(eng.getTargetStateSeq() - orc.state_traj()).max() <= 1e-4
         assert np.abs(eng.getNominalStateSeq() - orc.nominal_state_traj()).max() <= 1e-4
         st, so = eng.getStats(), orc.stats()
-        assert st.real_sys.baseline == so["baseline"][0] and st.nominal_sys.baseline == so["baseline"][1]
+        # u* differs from the oracle at the 1e-7 level (summation order), so from the second iteration on the costs
+        # are no longer bit-identical; the baselines agree to fp32 accuracy
+        assert abs(st.real_sys.baseline - so["baseline"][0]) <= 1e-5 * abs(so["baseline"][0])
+        assert abs(st.nominal_sys.baseline - so["baseline"][1]) <= 1e-5 * abs(so["baseline"][1])
         assert st.nominal_state_used == so["nominal_state_used"]
         # disturb the actual state so that the two systems diverge
         x = x + np.array([0.05, -0.03, 0.2, -0.1], np.float32) * (i + 1)
