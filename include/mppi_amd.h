@@ -156,6 +156,17 @@ mppi_status mppi_set_num_iters(mppi_handle h, int num_iters);
 /** slide_control_scale_ (controller.cuh:67) [C]; Tube: nominal_threshold_ (Tube-MPPI/tube_mppi_controller.cuh:20) */
 mppi_status mppi_set_slide_control_scale(mppi_handle h, const float* scale);
 mppi_status mppi_set_nominal_threshold(mppi_handle h, float threshold);
+/**
+ * Bulk model data, the role of the reference's .npz loaders (NeuralNetModel::loadParams -> FNNHelper::loadParams,
+ * utils/nn_helpers/fnn_helper.cu:96-174; ARStandardCost::loadTrackData, cost_functions/autorally/ar_standard_cost.cu:84-142).
+ * The caller parses the file (numpy / cnpy) and hands over plain arrays:
+ *   "dynamics_weights"  FNN parameters in the reference's blob order [W1 (out x in row-major) | b1 | W2 | b2 | ...]
+ *                       (fnn_helper.cu:176-183); dims = {count}
+ *   "costmap"           channel 0 of the track costmap, row-major [height][width]; dims = {height, width}.  The
+ *                       world -> texture transform goes in the cost parameter block (r_c1, r_c2, trs).
+ */
+mppi_status mppi_set_model_blob(mppi_handle h, const char* name, const float* data, size_t count, const int* dims,
+                                int ndims);
 /** reseed the noise generator and reset its offset (controllers/controller.cu:200-207) */
 mppi_status mppi_set_seed(mppi_handle h, uint64_t seed);
 

@@ -1,0 +1,111 @@
+/**
+ * NeuralNetModel<S_DIM, C_DIM, K_DIM> — AutoRally dynamics: analytic kinematics + an MLP for the dynamic states.
+ * reference: include/mppi/dynamics/autorally/ar_nn_model.cuh:22-160, ar_nn_model.cu:122-178
+ *   state  [x, y, yaw, roll, vx_body, vy_body, yaw_rate], control [steering, throttle], output = state + 1 filler
+ *   xdot[0..2] = kinematics(yaw, vx, vy, yaw_rate)                         (ar_nn_model.cu:122-128, cosf/sinf -> det)
+ *   xdot[3..6] = FNN([roll, vx, vy, yaw_rate, steering, throttle])         (ar_nn_model.cu:130-160)
+ */
+#ifndef MPPI_AMD_AR_NN_MODEL_HPP_
+#define MPPI_AMD_AR_NN_MODEL_HPP_
+
+#include "mppi_amd/plugin/dynamics.hpp"
+#include "mppi_amd/utils/nn_helpers/fnn_helper.hpp"
+
+struct NNDynamicsParams : public DynamicsParams
+{
+  enum class StateIndex : int
+  {
+    POS_X = 0,
+    POS_Y,
+    YAW,
+    ROLL,
+    BODY_VEL_X,
+    BODY_VEL_Y,
+    YAW_RATE,
+    NUM_STATES
+  };
+  enum class ControlIndex : int
+  {
+    STEERING = 0,
+    THROTTLE,
+    NUM_CONTROLS
+  };
+  enum class OutputIndex : int
+  {
+    POS_X = 0,
+    POS_Y,
+    YAW,
+    ROLL,
+    BODY_VEL_X,
+    BODY_VEL_Y,
+    YAW_RATE,
+    FILLER_1,
+    NUM_OUTPUTS
+  };
+};
+
+using namespace MPPI_internal;
+
+template <int S_DIM, int C_DIM, int K_DIM>
+class NeuralNetModel : public Dynamics<NeuralNetModel<S_DIM, C_DIM, K_DIM>, NNDynamicsParams>
+{
+public:
+  using PARENT_CLASS = Dynamics<NeuralNetModel<S_DIM, C_DIM, K_DIM>, NNDynamicsParams>;
+  static const int DYNAMICS_DIM = S_DIM - K_DIM;  ///< number of inputs from state
+
+  NeuralNetModel(hipStream_t stream = 0) : PARENT_CLASS(stream)
+  {
+    const int layers[4] = { 6, 32, 32, 4 };  // ar_nn_model.cu:7, :17
+    helper_.setStructure(layers, 4);
+  }
+  static const char* getDynamicsModelName()
+  {
+    return "FCN Autorally Model";
+  }
+
+  /** LDS requests are the network's (ar_nn_model.cu:8-10) */
+  __host__ __device__ int getGrdSharedSizeBytes() const
+  {
+    return helper_.getGrdSharedSizeBytes();
+  }
+  __host__ __device__ int getBlkSharedSizeBytes() const
+  {
+    return helper_.getBlkSharedSizeBytes();
+  }
+
+  __device__ inline void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
+                                            float dt)
+  {
+    PARENT_CLASS::initializeDynamics(state, control, output, theta_s, t_0, dt);
+    helper_.initialize(theta_s);
+  }
+
+  __device__ inline void computeKinematics(float* state, float* state_der)
+  {
+    float s, c;
+    mppi::det::sincos(state[2], &s, &c);
+    state_der[0] = c * state[4] - s * state[5];
+    state_der[1] = s * state[4] + c * state[5];
+    state_der[2] = -state[6];  // Pose estimate actually gives the negative yaw derivative
+  }
+
+  __device__ inline void computeDynamics(float* state, float* control, float* state_der, float* theta_s = nullptr)
+  {
+    const int tdy = (int)__builtin_amdgcn_workitem_id_y();
+    const int bdy = (int)__builtin_amdgcn_workgroup_size_y();
+    float* curr_act = helper_.getInputLocation(theta_s);
+    for (int i = tdy; i < DYNAMICS_DIM; i += bdy)
+      curr_act[i] = state[i + (S_DIM - DYNAMICS_DIM)];
+    for (int i = tdy; i < C_DIM; i += bdy)
+      curr_act[DYNAMICS_DIM + i] = control[i];
+    mppi::lane_sync();
+    curr_act = helper_.forward(nullptr, theta_s);
+    for (int i = tdy; i < DYNAMICS_DIM; i += bdy)
+      state_der[i + (S_DIM - DYNAMICS_DIM)] = curr_act[i];
+    mppi::lane_sync();
+  }
+
+  mppi::FNNHelper helper_;
+};
+
+#endif

@@ -53,6 +53,27 @@ typedef struct mppi_di_circle_cost_params
   float angular_momentum_desired; /* 2 * velocity_desired */
 } mppi_di_circle_cost_params;
 
+/** <- ARStandardCostParams  cost_functions/autorally/ar_standard_cost.cuh:14-41 (float3 r_c1, r_c2, trs as 3 floats each).
+ *  The AutoRally NeuralNetModel has no dynamics parameter block (NNDynamicsParams is empty); its weights are the
+ *  "dynamics_weights" blob and the costmap is the "costmap" blob of mppi_set_model_blob(). */
+typedef struct mppi_ar_standard_cost_params
+{
+  float control_cost_coeff[2]; /* {0, 0} */
+  float discount;              /* 1.0 */
+  float desired_speed;         /* 6.0 */
+  float speed_coeff;           /* 4.25 */
+  float track_coeff;           /* 200 */
+  float max_slip_ang;          /* 1.25 */
+  float slip_coeff;            /* 10 */
+  float track_slop;            /* 0 */
+  float crash_coeff;           /* 10000 */
+  float boundary_threshold;    /* 0.65 */
+  int grid_res;                /* 10 */
+  float r_c1[3];               /* world -> texture transform, column 1 */
+  float r_c2[3];               /* column 2 */
+  float trs[3];                /* translation */
+} mppi_ar_standard_cost_params;
+
 #ifdef __cplusplus
 }
 #endif

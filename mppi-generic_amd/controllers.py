@@ -78,6 +78,50 @@ class DoubleIntegratorCircleCostParams(C.Structure):
         self.angular_momentum_desired = 4
 
 
+class ARStandardCostParams(C.Structure):
+    _fields_ = [
+        ("control_cost_coeff", C.c_float * 2), ("discount", C.c_float), ("desired_speed", C.c_float),
+        ("speed_coeff", C.c_float), ("track_coeff", C.c_float), ("max_slip_ang", C.c_float),
+        ("slip_coeff", C.c_float), ("track_slop", C.c_float), ("crash_coeff", C.c_float),
+        ("boundary_threshold", C.c_float), ("grid_res", C.c_int), ("r_c1", C.c_float * 3), ("r_c2", C.c_float * 3),
+        ("trs", C.c_float * 3),
+    ]
+
+    def __init__(self):
+        super().__init__()
+        self.control_cost_coeff[:] = [0.0, 0.0]
+        self.discount = 1.0
+        self.desired_speed = 6.0
+        self.speed_coeff = 4.25
+        self.track_coeff = 200.0
+        self.max_slip_ang = 1.25
+        self.slip_coeff = 10.0
+        self.track_slop = 0
+        self.crash_coeff = 10000
+        self.boundary_threshold = 0.65
+        self.grid_res = 10
+        self.r_c1[:] = [1, 0, 0]
+        self.r_c2[:] = [0, 1, 0]
+        self.trs[:] = [0, 0, 1]
+
+    def setTransformFromBounds(self, x_min, x_max, y_min, y_max):
+        """the transform ARStandardCost::loadTrackData builds (ar_standard_cost.cu:132-137)"""
+        self.r_c1[:] = [1.0 / (x_max - x_min), 0, 0]
+        self.r_c2[:] = [0, 1.0 / (y_max - y_min), 0]
+        self.trs[:] = [-x_min / (x_max - x_min), -y_min / (y_max - y_min), 1]
+
+
+def fnn_blob_from_npz_dict(d, prefix="dynamics_"):
+    """flat FNN parameter blob [W1|b1|W2|b2|...] from the reference's .npz key layout (dynamics_W{i}, dynamics_b{i},
+    float64; FNNHelper::loadParams, utils/nn_helpers/fnn_helper.cu:96-174)"""
+    parts, i = [], 1
+    while prefix + "W%d" % i in d:
+        parts.append(np.asarray(d[prefix + "W%d" % i], np.float64).reshape(-1))
+        parts.append(np.asarray(d[prefix + "b%d" % i], np.float64).reshape(-1))
+        i += 1
+    return np.concatenate(parts).astype(np.float32)
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -146,6 +190,12 @@ class MPPIController:
         p = MppiGaussianParams(sd.ctypes.data_as(C.POINTER(C.c_float)), cc.ctypes.data_as(C.POINTER(C.c_float)),
                                pure_noise_trajectories_percentage, std_dev_decay, sum_strides)
         self._check(self._lib.mppi_set_sampler_params(self._h, C.byref(p)))
+
+    def setModelBlob(self, name, array):
+        """bulk model data (NN weights, costmap) — see mppi_set_model_blob"""
+        a = _f32(array)
+        dims = (C.c_int * a.ndim)(*a.shape)
+        self._check(self._lib.mppi_set_model_blob(self._h, name.encode(), a.reshape(-1), a.size, dims, a.ndim))
 
     def setControlRanges(self, lo_hi):
         self._check(self._lib.mppi_set_control_ranges(self._h, _f32(lo_hi).reshape(-1)))

@@ -396,6 +396,25 @@ mppi_status mppi_set_nominal_threshold(mppi_handle h, float t)
   h->nominal_threshold = t;
   return MPPI_OK;
 }
+mppi_status mppi_set_model_blob(mppi_handle h, const char* name, const float* data, size_t count, const int* dims,
+                                int ndims)
+{
+  CHECK_HANDLE(h);
+  if (!name || !data || count == 0)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_model_blob: null or empty");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::string err;
+  mppi_status st = h->model->setBlob(name, data, count, dims, ndims, h->stream, err);
+  if (st != MPPI_OK)
+    return fail(h, st, err);
+  // the LDS request may depend on the blob (network size): re-check it
+  const size_t lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, h->cfg.num_timesteps, h->D);
+  if (lds > MAX_LDS_BYTES)
+    return fail(h, MPPI_ERR_LDS_OVERFLOW, "rollout kernel LDS request exceeds 160 KiB after loading '" + std::string(name) + "'");
+  return MPPI_OK;
+}
+
 mppi_status mppi_set_seed(mppi_handle h, uint64_t seed)
 {
   CHECK_HANDLE(h);

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string>
+#include <type_traits>
+#include <utility>
 
 #include "mppi_amd.h"
 #include "rollout_kernel.hpp"
@@ -58,6 +60,13 @@ struct ModelBase
   virtual void setControlDeadband(const float* db) = 0;
   virtual void getZeroControl(float* out) const = 0;
   virtual void setSamplerParams(const mppi_gaussian_params* p, int D) = 0;
+  /** bulk data (NN weights, costmap); default: the model has none */
+  virtual mppi_status setBlob(const std::string& name, const float* data, size_t count, const int* dims, int ndims,
+                              hipStream_t stream, std::string& err)
+  {
+    err = "model has no blob named '" + name + "'";
+    return MPPI_ERR_INVALID_ARG;
+  }
   virtual bool supportsShape(int bx, int by, int bz) const = 0;
   virtual size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D) = 0;
   virtual mppi_status launchRollout(int bx, int by, int bz, const kernels::RolloutArgs& args,
@@ -112,12 +121,113 @@ __global__ void __launch_bounds__(BY) modelStepKernel(DYN_T dynamics_obj, float*
     u_d[i] = u[i];
 }
 
+/* detection of optional plugin members */
+template <class T, class = void>
+struct has_fnn_helper : std::false_type
+{
+};
+template <class T>
+struct has_fnn_helper<T, std::void_t<decltype(std::declval<T&>().helper_.theta_d_)>> : std::true_type
+{
+};
+template <class T, class = void>
+struct has_costmap : std::false_type
+{
+};
+template <class T>
+struct has_costmap<T, std::void_t<decltype(std::declval<T&>().costmap_d_)>> : std::true_type
+{
+};
+
 template <class DYN_T, class COST_T, class SAMPLING_T, class SHAPES, int FIN_BY = 1>
 struct ModelT : ModelBase
 {
   DYN_T dyn;
   COST_T cost;
   SAMPLING_T smp;
+  float* weights_d = nullptr;
+  float* costmap_d = nullptr;
+
+  ~ModelT() override
+  {
+    if (weights_d)
+      (void)hipFree(weights_d);
+    if (costmap_d)
+      (void)hipFree(costmap_d);
+  }
+
+  static mppi_status upload(float** dst, const float* src, size_t count, hipStream_t stream, std::string& err)
+  {
+    if (*dst)
+      (void)hipFree(*dst);
+    *dst = nullptr;
+    hipError_t e = hipMalloc((void**)dst, count * sizeof(float));
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(*dst, src, count * sizeof(float), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(stream);
+    if (e != hipSuccess)
+    {
+      err = std::string("blob upload: ") + hipGetErrorString(e);
+      return MPPI_ERR_HIP;
+    }
+    return MPPI_OK;
+  }
+
+  mppi_status setBlob(const std::string& name, const float* data, size_t count, const int* dims, int ndims,
+                      hipStream_t stream, std::string& err) override
+  {
+    if constexpr (has_fnn_helper<DYN_T>::value)
+    {
+      if (name == "dynamics_weights")
+      {
+        if ((int)count != dyn.helper_.NUM_PARAMS)
+        {
+          err = "dynamics_weights: expected " + std::to_string(dyn.helper_.NUM_PARAMS) + " floats, got " +
+                std::to_string(count);
+          return MPPI_ERR_INVALID_ARG;
+        }
+        mppi_status st = upload(&weights_d, data, count, stream, err);
+        dyn.helper_.theta_d_ = weights_d;
+        return st;
+      }
+    }
+    if constexpr (has_costmap<COST_T>::value)
+    {
+      if (name == "costmap")
+      {
+        if (ndims != 2 || dims[0] <= 0 || dims[1] <= 0 || (size_t)dims[0] * dims[1] != count)
+        {
+          err = "costmap: dims must be {height, width} with height*width == count";
+          return MPPI_ERR_INVALID_ARG;
+        }
+        mppi_status st = upload(&costmap_d, data, count, stream, err);
+        cost.costmap_d_ = costmap_d;
+        cost.height_ = dims[0];
+        cost.width_ = dims[1];
+        return st;
+      }
+    }
+    return ModelBase::setBlob(name, data, count, dims, ndims, stream, err);
+  }
+
+  /** models with bulk data must have it before the first launch */
+  bool blobsReady(std::string& err) const
+  {
+    if constexpr (has_fnn_helper<DYN_T>::value)
+      if (!dyn.helper_.theta_d_)
+      {
+        err = "model needs the 'dynamics_weights' blob (mppi_set_model_blob) before it can run";
+        return false;
+      }
+    if constexpr (has_costmap<COST_T>::value)
+      if (!cost.costmap_d_)
+      {
+        err = "model needs the 'costmap' blob (mppi_set_model_blob) before it can run";
+        return false;
+      }
+    return true;
+  }
 
   ModelT()
   {
@@ -129,6 +239,8 @@ struct ModelT : ModelBase
   mppi_status setDynamicsParams(const void* pod, size_t n) override
   {
     // the params struct adds its fields after the (empty) DynamicsParams base: a flat block of floats / ints
+    if (std::is_empty<typename DYN_T::DYN_PARAMS_T>::value)
+      return n == 0 ? MPPI_OK : MPPI_ERR_INVALID_ARG;
     if (n != sizeof(typename DYN_T::DYN_PARAMS_T))
       return MPPI_ERR_INVALID_ARG;
     memcpy((void*)&dyn.params_, pod, n);
@@ -262,12 +374,16 @@ struct ModelT : ModelBase
   mppi_status launchRollout(int bx, int by, int bz, const kernels::RolloutArgs& args, const SamplerLaunchState& s,
                             hipStream_t stream, std::string& err) override
   {
+    if (!blobsReady(err))
+      return MPPI_ERR_STATE;
     prepSampler(s);
     return dispatch(SHAPES{}, bx, by, bz, args, stream, err);
   }
 
   mppi_status launchFinalize(int D, const kernels::FinalizeArgs& a, hipStream_t stream, std::string& err) override
   {
+    if (!blobsReady(err))
+      return MPPI_ERR_STATE;
     const size_t smem = kernels::finalizeSharedBytes(dyn, a.num_timesteps);
     if (smem > MAX_LDS_BYTES)
     {
@@ -291,6 +407,8 @@ struct ModelT : ModelBase
   mppi_status launchModelStep(float* x_d, float* u_d, float dt, int enforce, hipStream_t stream,
                               std::string& err) override
   {
+    if (!blobsReady(err))
+      return MPPI_ERR_STATE;
     constexpr int Sd = DYN_T::STATE_DIM, Cd = DYN_T::CONTROL_DIM, Od = DYN_T::OUTPUT_DIM;
     const size_t smem = calcClassSharedMemSize(&dyn, 1) +
                         sizeof(float) * (3 * math::nearest_multiple_4(Sd) + math::nearest_multiple_4(Cd) +

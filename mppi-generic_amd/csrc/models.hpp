@@ -21,6 +21,8 @@
 #include "mppi_amd/cost_functions/cartpole/cartpole_quadratic_cost.hpp"
 #include "mppi_amd/dynamics/double_integrator/di_dynamics.hpp"
 #include "mppi_amd/cost_functions/double_integrator/double_integrator_circle_cost.hpp"
+#include "mppi_amd/dynamics/autorally/ar_nn_model.hpp"
+#include "mppi_amd/cost_functions/autorally/ar_standard_cost.hpp"
 
 namespace mppi
 {
@@ -34,8 +36,24 @@ using DISampler = sampling_distributions::GaussianDistribution<DoubleIntegratorP
 using DIModel = ModelT<DoubleIntegratorDynamics, DoubleIntegratorCircleCost, DISampler,
                        Shapes<Shape<64, 1, 1>, Shape<64, 1, 2>, Shape<32, 2, 2>, Shape<64, 2, 1>>>;
 
+/* AutoRally: MLP dynamics + costmap cost (reference: instantiations/autorally_mppi/autorally_mppi.cuh:10-13 uses
+ * dynamics_rollout_dim (8, 16, 1)).  BY lanes of a rollout share the neurons of a layer. */
+using ARModelDyn = NeuralNetModel<7, 2, 3>;
+using ARSampler = sampling_distributions::GaussianDistribution<NNDynamicsParams>;
+using ARModel = ModelT<ARModelDyn, ARStandardCost, ARSampler,
+                       Shapes<Shape<8, 16, 1>, Shape<16, 8, 1>, Shape<16, 4, 1>, Shape<64, 1, 1>, Shape<32, 8, 1>,
+                              Shape<64, 4, 1>, Shape<8, 16, 2>>,
+                       /*FIN_BY=*/8>;
+
 inline ModelBase* makeModel(const std::string& name)
 {
+  if (name == "autorally_nn")
+  {
+    ModelBase* m = new ARModel();
+    m->default_bx = 16;
+    m->default_by = 8;
+    return m;
+  }
   if (name == "cartpole")
     return new CartpoleModel();
   if (name == "double_integrator")
@@ -45,7 +63,7 @@ inline ModelBase* makeModel(const std::string& name)
 
 inline const char* listModels()
 {
-  return "cartpole\ndouble_integrator";
+  return "cartpole\ndouble_integrator\nautorally_nn";
 }
 
 }  // namespace engine

@@ -51,6 +51,45 @@ int oracle_set_cost_params(void* h, const void* pod, size_t n)
 {
   return ((Controller*)h)->cost->setParams(pod, n);
 }
+int oracle_set_blob(void* h, const char* name, const float* data, size_t count, const int* dims, int ndims)
+{
+  auto* c = (Controller*)h;
+  const std::string n(name);
+  if (n == "dynamics_weights")
+  {
+    auto* m = dynamic_cast<ARNeuralNetModel*>(c->dyn.get());
+    return m ? m->setWeights(data, count) : -1;
+  }
+  if (n == "costmap")
+  {
+    auto* m = dynamic_cast<ARStandardCost*>(c->cost.get());
+    return (m && ndims == 2) ? m->setCostmap(data, dims[0], dims[1]) : -1;
+  }
+  return -1;
+}
+/** one FNN forward on the host: layers[nl], theta blob, in -> out (known-answer tests) */
+void oracle_fnn_forward(const int* layers, int nl, const float* theta, const float* in, float* out)
+{
+  FNN net;
+  net.setStructure(std::vector<int>(layers, layers + nl));
+  std::copy(theta, theta + net.numParams(), net.theta.begin());
+  net.forward(in, out);
+}
+/** xdot = f(x, u) of the handle's model (kinematics + dynamics), for plugin-level known-answer tests */
+void oracle_state_deriv(void* h, const float* x, const float* u, float* xdot)
+{
+  auto* c = (Controller*)h;
+  std::vector<float> th(std::max(1, c->dyn->scratchFloats()), 0.0f);
+  for (int i = 0; i < c->dyn->S; i++)
+    xdot[i] = 0.0f;
+  c->dyn->computeKinematics(x, xdot);
+  c->dyn->computeDynamics(x, u, xdot, th.data());
+}
+/** running state cost of one output vector */
+float oracle_state_cost(void* h, const float* y, int t, int* crash)
+{
+  return ((Controller*)h)->cost->computeStateCost(y, t, crash);
+}
 void oracle_set_control_ranges(void* h, const float* lo_hi)
 {
   auto* c = (Controller*)h;

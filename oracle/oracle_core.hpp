@@ -66,8 +66,11 @@ struct Dynamics
   {
     return 0;
   }
+  /** reference: dynamics/dynamics.cuh:429-435 — the default copies the state into the output */
   virtual void initializeDynamics(const float* x, const float* u, float* y, float* theta_s, float t0, float dt)
   {
+    for (int i = 0; i < O && i < S; i++)
+      y[i] = x[i];
   }
   virtual void computeKinematics(const float* x, float* xdot)
   {

@@ -147,8 +147,196 @@ struct DoubleIntegratorCircleCost : Cost
   }
 };
 
+/* ------------------------------------------------------------------ AutoRally NN ---------------------------------- */
+/**
+ * Fully connected network, device flavour of FNNHelper::forward (utils/nn_helpers/fnn_helper.cu:420-484):
+ * neuron j: acc = 0; for k ascending acc = fma(W[j][k], act[k], acc); acc += b[j]; hidden: tanh.
+ * The reference's `tmp += W*act` is contracted to an FMA by nvcc; the k-ordered fma chain is also exactly what the
+ * engine's MFMA formulation computes.  Blob layout [W1 (out x in) | b1 | W2 | b2 | ...] (fnn_helper.cu:176-183).
+ */
+struct FNN
+{
+  std::vector<int> layers;
+  std::vector<float> theta;
+  void setStructure(const std::vector<int>& l)
+  {
+    layers = l;
+    size_t n = 0;
+    for (size_t i = 0; i + 1 < l.size(); i++)
+      n += (size_t)l[i] * l[i + 1] + l[i + 1];
+    theta.assign(n, 0.0f);
+  }
+  size_t numParams() const
+  {
+    return theta.size();
+  }
+  void forward(const float* in, float* out) const
+  {
+    std::vector<float> cur(in, in + layers[0]), nxt;
+    size_t off = 0;
+    for (size_t i = 0; i + 1 < layers.size(); i++)
+    {
+      const int n_in = layers[i], n_out = layers[i + 1];
+      const float* W = &theta[off];
+      const float* b = &theta[off + (size_t)n_in * n_out];
+      nxt.assign(n_out, 0.0f);
+      for (int j = 0; j < n_out; j++)
+      {
+        float tmp = 0.0f;
+        for (int k = 0; k < n_in; k++)
+          tmp = det::fma(W[(size_t)j * n_in + k], cur[k], tmp);
+        tmp += b[j];
+        if (i + 2 < layers.size())
+          tmp = det::tanh(tmp);
+        nxt[j] = tmp;
+      }
+      cur = nxt;
+      off += (size_t)n_in * n_out + n_out;
+    }
+    for (int j = 0; j < layers.back(); j++)
+      out[j] = cur[j];
+  }
+};
+
+/** reference: dynamics/autorally/ar_nn_model.cu:122-160 (device computeKinematics / computeDynamics), S=7, C=2, K=3 */
+struct ARNeuralNetModel : Dynamics
+{
+  FNN net;
+  ARNeuralNetModel() : Dynamics(7, 2, 8)
+  {
+    net.setStructure({ 6, 32, 32, 4 });
+  }
+  int setParams(const void* pod, size_t n) override
+  {
+    return n == 0 ? 0 : -1;
+  }
+  int setWeights(const float* w, size_t n)
+  {
+    if (n != net.numParams())
+      return -1;
+    std::copy(w, w + n, net.theta.begin());
+    return 0;
+  }
+  void computeKinematics(const float* state, float* state_der) override
+  {
+    float s, c;
+    det::sincos(state[2], &s, &c);
+    state_der[0] = c * state[4] - s * state[5];
+    state_der[1] = s * state[4] + c * state[5];
+    state_der[2] = -state[6];
+  }
+  void computeDynamics(const float* state, const float* control, float* state_der, float* theta_s) override
+  {
+    float in[6], out[4];
+    for (int i = 0; i < 4; i++)
+      in[i] = state[i + 3];
+    in[4] = control[0];
+    in[5] = control[1];
+    net.forward(in, out);
+    for (int i = 0; i < 4; i++)
+      state_der[i + 3] = out[i];
+  }
+};
+
+/** reference: cost_functions/autorally/ar_standard_cost.cu:224-243, 283-413 (device flavour) */
+struct ARStandardCost : Cost
+{
+  mppi_ar_standard_cost_params params_{ { 0.0f, 0.0f }, 1.0f, 6.0f, 4.25f, 200.0f, 1.25f, 10.0f, 0.0f, 10000.0f, 0.65f, 10,
+                                        { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+  std::vector<float> costmap; /* channel 0, [height][width] */
+  int width_ = -1, height_ = -1;
+  const float FRONT_D = 0.5, BACK_D = -0.5;
+  ARStandardCost() : Cost(2, 8)
+  {
+  }
+  int setParams(const void* pod, size_t n) override
+  {
+    if (n != sizeof(params_))
+      return -1;
+    memcpy(&params_, pod, n);
+    return 0;
+  }
+  int setCostmap(const float* data, int height, int width)
+  {
+    costmap.assign(data, data + (size_t)height * width);
+    height_ = height;
+    width_ = width;
+    return 0;
+  }
+  /** CUDA point sampling with clamp addressing and normalised coordinates: texel = clamp(floor(u * size)) */
+  float queryTextureTransformed(float x, float y) const
+  {
+    const float u = params_.r_c1[0] * x + params_.r_c2[0] * y + params_.trs[0];
+    const float v = params_.r_c1[1] * x + params_.r_c2[1] * y + params_.trs[1];
+    const float w = params_.r_c1[2] * x + params_.r_c2[2] * y + params_.trs[2];
+    const float fx = floorf(u / w * (float)width_);
+    const float fy = floorf(v / w * (float)height_);
+    const int ix = (fx >= 0.0f) ? ((fx < (float)width_) ? (int)fx : width_ - 1) : 0;
+    const int iy = (fy >= 0.0f) ? ((fy < (float)height_) ? (int)fy : height_ - 1) : 0;
+    return costmap[(size_t)iy * width_ + ix];
+  }
+  float getTrackCost(const float* s, int* crash) const
+  {
+    float sy, cy;
+    det::sincos(s[2], &sy, &cy);
+    const float x_front = s[0] + FRONT_D * cy, y_front = s[1] + FRONT_D * sy;
+    const float x_back = s[0] + BACK_D * cy, y_back = s[1] + BACK_D * sy;
+    const float tf = queryTextureTransformed(x_front, y_front);
+    const float tb = queryTextureTransformed(x_back, y_back);
+    float track_cost = (fabsf(tf) + fabsf(tb)) / 2.0f;
+    if (fabsf(track_cost) < params_.track_slop)
+      track_cost = 0;
+    else
+      track_cost = params_.track_coeff * track_cost;
+    if (tf >= params_.boundary_threshold || tb >= params_.boundary_threshold)
+      crash[0] = 1;
+    return track_cost;
+  }
+  float getSpeedCost(const float* s) const
+  {
+    const float error = s[4] - params_.desired_speed;
+    return params_.speed_coeff * (error * error);
+  }
+  float getStabilizingCost(const float* s, int* crash) const
+  {
+    float stabilizing_cost = 0;
+    if ((double)fabsf(s[4]) > 0.001)
+    {
+      const float slip = -det::atan(s[5] / fabsf(s[4]));
+      stabilizing_cost = params_.slip_coeff * (slip * slip);
+      if (fabsf(slip) > params_.max_slip_ang)
+        stabilizing_cost += params_.crash_coeff;
+    }
+    if ((double)fabsf(s[3]) > 1.57079632679489661923)
+      crash[0] = 1;
+    return stabilizing_cost;
+  }
+  float computeStateCost(const float* s, int timestep, int* crash) override
+  {
+    const float track_cost = getTrackCost(s, crash);
+    const float speed_cost = getSpeedCost(s);
+    const float stabilizing_cost = getStabilizingCost(s, crash);
+    const float disc = params_.discount == 1.0f ? 1.0f : det::pow_pos(params_.discount, (float)timestep);
+    const float crash_cost = disc * (crash[0] > 0 ? params_.crash_coeff : 0.0f);
+    float cost = speed_cost + crash_cost + track_cost + stabilizing_cost;
+    if (cost > 1e16f || cost != cost)
+      cost = 1e16f;
+    return cost;
+  }
+  float terminalCost(const float* s) override
+  {
+    return 0.0f;
+  }
+};
+
 inline bool makeModel(const std::string& name, std::unique_ptr<Dynamics>& dyn, std::unique_ptr<Cost>& cost)
 {
+  if (name == "autorally_nn")
+  {
+    dyn.reset(new ARNeuralNetModel());
+    cost.reset(new ARStandardCost());
+    return true;
+  }
   if (name == "cartpole")
   {
     dyn.reset(new CartpoleDynamics());

@@ -18,6 +18,7 @@ _lib = None
 def build(force=False):
     srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".cpp", ".hpp"))]
     srcs += [os.path.join(HERE, "..", "include", "mppi_amd", f) for f in ("det_math.h", "model_params.h")]
+    srcs.append(os.path.join(HERE, "Makefile"))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
         r = subprocess.run(["make", "-C", HERE, "-B" if force else "-s"], capture_output=True, text=True)
         if r.returncode != 0:
@@ -36,6 +37,11 @@ def lib():
         L.oracle_dims.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
         L.oracle_set_dynamics_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_set_cost_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_set_blob.argtypes = [C.c_void_p, C.c_char_p, _f32p, C.c_size_t, C.POINTER(C.c_int), C.c_int]
+        L.oracle_fnn_forward.argtypes = [C.POINTER(C.c_int), C.c_int, _f32p, _f32p, _f32p]
+        L.oracle_state_deriv.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
+        L.oracle_state_cost.restype = C.c_float
+        L.oracle_state_cost.argtypes = [C.c_void_p, _f32p, C.c_int, C.POINTER(C.c_int)]
         L.oracle_set_control_ranges.argtypes = [C.c_void_p, _f32p]
         L.oracle_set_control_deadband.argtypes = [C.c_void_p, _f32p]
         L.oracle_set_sampler.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, C.c_int]
@@ -103,6 +109,21 @@ class Oracle:
 
     def set_cost_params(self, pod):
         assert self.L.oracle_set_cost_params(self.h, C.byref(pod), C.sizeof(pod)) == 0
+
+    def set_blob(self, name, array):
+        a = _f32(array)
+        dims = (C.c_int * a.ndim)(*a.shape)
+        assert self.L.oracle_set_blob(self.h, name.encode(), a.reshape(-1), a.size, dims, a.ndim) == 0, name
+
+    def state_deriv(self, x, u):
+        out = np.zeros(self.S, np.float32)
+        self.L.oracle_state_deriv(self.h, _f32(x).reshape(-1), _f32(u).reshape(-1), out)
+        return out
+
+    def state_cost(self, y, t=0, crash=0):
+        cr = C.c_int(crash)
+        v = self.L.oracle_state_cost(self.h, _f32(y).reshape(-1), t, C.byref(cr))
+        return float(v), cr.value
 
     def set_control_ranges(self, lo_hi):
         self.L.oracle_set_control_ranges(self.h, _f32(lo_hi).reshape(-1))
@@ -210,6 +231,14 @@ def philox_normal(seed, generation, K, T, Cdim, k_begin=0, k_end=None, stream=0)
     k_end = K if k_end is None else k_end
     out = np.empty((k_end - k_begin, T, Cdim), np.float32)
     lib().oracle_philox_normal(seed, generation, stream, K, T, Cdim, k_begin, k_end, out)
+    return out
+
+
+def fnn_forward(layers, theta, x):
+    layers = list(layers)
+    arr = (C.c_int * len(layers))(*layers)
+    out = np.zeros(layers[-1], np.float32)
+    lib().oracle_fnn_forward(arr, len(layers), _f32(theta).reshape(-1), _f32(x).reshape(-1), out)
     return out
 
 

@@ -42,12 +42,43 @@ def di_cfg(K=1024, T=50, tube=True, lambda_=2.0, num_iters=1):
                 x0=np.array([2.0, 0.0, 0.0, 1.0], np.float32))
 
 
+def standard_track_map():
+    """channel 0 of the reference's `track_map_standard.npz` (scripts/autorally/test/generateTestMaps.py:47-76):
+    30 m x 30 m at 20 px/m, value = |15 - y| + x/30 in map coordinates; world bounds x in [-13, 17], y in [-10, 20]"""
+    n = 600
+    i = np.arange(n, dtype=np.float64)[:, None] / 20.0
+    j = np.arange(n, dtype=np.float64)[None, :] / 20.0
+    return (np.abs(15.0 - i) + j / 30.0).astype(np.float32), (-13.0, 17.0, -10.0, 20.0)
+
+
+def autorally_cfg(K=1024, T=50, lambda_=20.0, num_iters=1):
+    """SURVEY.md §8d config 4 at test size: NeuralNetModel<7,2,3> (FNN 6-32-32-4, synthetic weights U(-0.3, 0.3) in the
+    reference's dynamics_W/b key layout — the real autorally_nnet_09_12_2018.npz is a git-LFS stub) + ARStandardCost on
+    the reference's generated standard track map."""
+    rng = np.random.default_rng(SEED)
+    npz = {}
+    layers = [6, 32, 32, 4]
+    for i in range(1, 4):
+        npz["dynamics_W%d" % i] = rng.uniform(-0.3, 0.3, (layers[i], layers[i - 1])).astype(np.float64)
+        npz["dynamics_b%d" % i] = rng.uniform(-0.3, 0.3, layers[i]).astype(np.float64)
+    cmap, (x0b, x1b, y0b, y1b) = standard_track_map()
+    cost = m.ARStandardCostParams()
+    cost.setTransformFromBounds(x0b, x1b, y0b, y1b)
+    return dict(model="autorally_nn", K=K, T=T, D=1, dt=0.02, lambda_=lambda_, alpha=0.0, num_iters=num_iters,
+                dyn=None, cost=cost, ranges=[[-0.99, 0.99], [-0.99, 0.65]], std_dev=[0.3, 0.3],
+                control_cost_coeff=[0.0, 0.0], x0=np.array([-12.0, 5.0, 0.0, 0.0, 4.0, 0.0, 0.0], np.float32),
+                blobs={"dynamics_weights": m.fnn_blob_from_npz_dict(npz), "costmap": cmap})
+
+
 def make_engine(cfg, tube=None, **kw):
     tube = (cfg["D"] == 2) if tube is None else tube
     cls = m.TubeMPPIController if tube else m.VanillaMPPIController
     c = cls(cfg["model"], cfg["K"], cfg["T"], cfg["dt"], cfg["lambda_"], cfg["alpha"], cfg["num_iters"], seed=SEED, **kw)
-    c.setDynamicsParams(cfg["dyn"])
+    if cfg["dyn"] is not None:
+        c.setDynamicsParams(cfg["dyn"])
     c.setCostParams(cfg["cost"])
+    for name, arr in cfg.get("blobs", {}).items():
+        c.setModelBlob(name, arr)
     if cfg["ranges"] is not None:
         c.setControlRanges(cfg["ranges"])
     c.setSamplingParams(cfg["std_dev"], cfg["control_cost_coeff"], cfg.get("pure_pct", 0.01), cfg.get("decay", 1.0))
@@ -56,8 +87,11 @@ def make_engine(cfg, tube=None, **kw):
 
 def make_oracle(cfg):
     o = po.Oracle(cfg["model"], cfg["K"], cfg["T"], cfg["D"], cfg["dt"], cfg["lambda_"], cfg["alpha"], cfg["num_iters"])
-    o.set_dynamics_params(cfg["dyn"])
+    if cfg["dyn"] is not None:
+        o.set_dynamics_params(cfg["dyn"])
     o.set_cost_params(cfg["cost"])
+    for name, arr in cfg.get("blobs", {}).items():
+        o.set_blob(name, arr)
     if cfg["ranges"] is not None:
         o.set_control_ranges(cfg["ranges"])
     o.set_sampler(cfg["std_dev"], cfg["control_cost_coeff"], cfg.get("pure_pct", 0.01), cfg.get("decay", 1.0))
