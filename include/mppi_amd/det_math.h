@@ -18,8 +18,8 @@
  * explicit det::fma() calls (hipcc: v_fma_f32; gcc -mfma: vfmadd, or glibc's correctly rounded fmaf()).
  * Result: identical bits on the MI355X and on the host, which tests/test_det_math.py checks on the GPU.
  *
- * Accuracy (checked against float64 libm in tests/test_det_math.py): sin/cos/exp/log/tanh/atan <= 2 ulp on the
- * ranges the models use.  That is tighter than the reference's own device intrinsics, and well inside the
+ * Accuracy (checked against float64 libm in tests/test_det_math.py): sin/cos/exp/log <= 2 ulp, atan <= 3 ulp, tanh
+ * <= 7 ulp (4e-7 absolute; branch-free rational form) on the ranges the models use.  That is tighter than the reference's own device intrinsics, and well inside the
  * reference's GPU-vs-CPU test tolerances (tests/mppi_core/rollout_kernel_tests.cu:258: 1e-4 relative).
  *
  * Polynomial coefficients are the classic single-precision Cephes minimax sets (S. Moshier, netlib cephes/single).
@@ -253,24 +253,29 @@ MPPI_HD static inline float log(float x)
   return r;
 }
 
-/** tanh(x), Cephes tanhf structure.  |x| < 0.625: odd minimax polynomial; else 1 - 2/(exp(2|x|)+1). */
+/**
+ * tanh(x), branch-free: clamp to +-7.9053 (tanh rounds to +-1 in fp32 beyond), then the odd rational minimax
+ * x * P6(x^2) / Q3(x^2) with the coefficient set of Eigen's generic_fast_tanh_float (MathFunctionsImpl.h, MPL2), one
+ * correctly rounded division.  ~25 instructions and no divergent control flow — the NN dynamics evaluate 64 of these per
+ * rollout and step, and a two-branch exp-based form costs both branches on a SIMD machine.
+ * Accuracy: <= 7 ulp (4e-7 absolute) against float64 tanh; exactly 0 at 0 and exactly +-1 for |x| >= 7.9053.
+ */
 MPPI_HD static inline float tanh(float x)
 {
-  const float ax = fabs(x);
-  if (ax >= 9.1f)
-    return (x != x) ? x : copysign(1.0f, x);
-  if (ax >= 0.625f)
-  {
-    const float e = exp(ax + ax);
-    const float t = 1.0f - 2.0f / (e + 1.0f);
-    return copysign(t, x);
-  }
-  const float z = x * x;
-  float p = fma(-5.70498872745e-3f, z, 2.06390887954e-2f);
-  p = fma(p, z, -5.37397155531e-2f);
-  p = fma(p, z, 1.33314422036e-1f);
-  p = fma(p, z, -3.33332819422e-1f);
-  return fma(p * z, x, x);
+  const float xc = fminf(fmaxf(x, -7.90531110763549805f), 7.90531110763549805f);
+  const float x2 = xc * xc;
+  float p = fma(x2, -2.76076847742355e-16f, 2.00018790482477e-13f);
+  p = fma(x2, p, -8.60467152213735e-11f);
+  p = fma(x2, p, 5.12229709037114e-08f);
+  p = fma(x2, p, 1.48572235717979e-05f);
+  p = fma(x2, p, 6.37261928875436e-04f);
+  p = fma(x2, p, 4.89352455891786e-03f);
+  p = xc * p;
+  float q = fma(x2, 1.19825839466702e-06f, 1.18534705686654e-04f);
+  q = fma(x2, q, 2.26843463243900e-03f);
+  q = fma(x2, q, 4.89352518554385e-03f);
+  const float r = p / q;
+  return (x != x) ? x : r;
 }
 
 /** Device flavour of the reference's sigmoid (utils/activation_functions.cuh:49-59): (1 + tanh(x/2))/2. */

@@ -95,6 +95,24 @@ public:
   float std_dev_decayed_[CONTROL_DIM * 2];  ///< std_dev_decay^iteration * std_dev  (gaussian.cu:421, :86)
   int rollout_offset_ = 0;           ///< global index of this GPU's first rollout
   int num_rollouts_global_ = 1;      ///< K over all GPUs
+  /* thread mapping, set per thread by kernels whose blockDim.x is not "one thread per rollout" (replicated lanes):
+   * the kernel's copy of the object is private to the thread, so these are ordinary registers */
+  int thread_slot_ = -1;             ///< rollout slot of this thread, -1: blockDim.x * threadIdx.z + threadIdx.x
+  int block_rollouts_ = 0;           ///< rollouts per block, 0: blockDim.x
+
+  __device__ inline void setThreadMapping(int slot, int block_rollouts)
+  {
+    thread_slot_ = slot;
+    block_rollouts_ = block_rollouts;
+  }
+  __device__ inline int slotOfThread() const
+  {
+    return thread_slot_ >= 0 ? thread_slot_ : (int)(blockDim.x * threadIdx.z + threadIdx.x);
+  }
+  __device__ inline int rolloutsPerBlock() const
+  {
+    return block_rollouts_ > 0 ? block_rollouts_ : (int)__builtin_amdgcn_workgroup_size_x();
+  }
 
   GaussianDistribution(hipStream_t stream = 0)
   {
@@ -158,7 +176,7 @@ public:
       return;
     const int TC = params_.num_timesteps * CONTROL_DIM;
     const int stride = rowStride(params_.num_timesteps);
-    const int bx = (int)__builtin_amdgcn_workgroup_size_x();
+    const int bx = rolloutsPerBlock();
     const int tid_flat = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
     const int nthreads = (int)(blockDim.x * blockDim.y * blockDim.z);
     const int row0 = (int)(blockIdx.x * bx);  // first local rollout of the block
@@ -251,7 +269,7 @@ public:
                                            const float* __restrict__ output = nullptr)
   {
     const int d = distribution_index >= params_.num_distributions ? 0 : distribution_index;
-    const int slot = (int)(blockDim.x * threadIdx.z + threadIdx.x);
+    const int slot = slotOfThread();
     const float* row = sampleRow(theta_d, slot) + t * CONTROL_DIM;
     const float* mean = control_means_d_ + (size_t)(params_.num_timesteps * d + t) * CONTROL_DIM;
     const bool use_mean = ((sample_index + rollout_offset_) == 0) || (t < optimization_stride_);
@@ -268,7 +286,7 @@ public:
                                             const int& block_size, const int& thread_index,
                                             const float* __restrict__ output = nullptr)
   {
-    const int slot = (int)(blockDim.x * threadIdx.z + threadIdx.x);
+    const int slot = slotOfThread();
     float* row = sampleRow(theta_d, slot) + t * CONTROL_DIM;
     for (int i = thread_index; i < CONTROL_DIM; i += block_size)
     {

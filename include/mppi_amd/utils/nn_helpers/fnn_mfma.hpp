@@ -1,0 +1,167 @@
+/**
+ * fnn_mfma.hpp — the MLP forward pass of the NN dynamics on the CDNA4 matrix cores (fp32-input MFMA).
+ *
+ * One wave evaluates the network for 16 rollouts at a time with `v_mfma_f32_16x16x4_f32`
+ * (D[16x16] += A[16x4] * B[4x16], exact fp32, 32 cycles):
+ *     rows  m = output neurons of the layer (16 per row block),
+ *     cols  n = the 16 rollouts of the wave,
+ *     k       = input neurons, 4 per instruction.
+ * Lane l of the wave is (n = l & 15, g = l >> 4): it belongs to rollout n and is its k-group g — exactly the role the
+ * reference gives the threadIdx.y lanes of a rollout (block shape (16, 4): "x = rollout, y = intra-rollout lane"), only
+ * that the lanes now cooperate through the matrix core instead of LDS + block barriers
+ * (reference: FNNHelper::forward, include/mppi/utils/nn_helpers/fnn_helper.cu:420-484).
+ *
+ * Fragment layouts (cdna_hip_programming.md §3): A: lane holds A[m = l & 15][k = l >> 4]; B: lane holds
+ * B[k = l >> 4][n = l & 15]; D: lane holds rows 4*(l >> 4) + i, i = 0..3, of column l & 15.
+ *  - The weights are A fragments and stay in VGPRs for the whole kernel (28 registers for 6-32-32-4).
+ *  - A layer's output (D layout) is biased, squashed by det::tanh in place — 8 values per lane, i.e. the 512 tanh of a
+ *    32-neuron layer x 16 rollouts are spread evenly over the 64 lanes — and re-laid out as the next layer's B
+ *    fragments through a wave-private 2 KB LDS tile (8 ds_write + 8 ds_read per lane, no barrier: one wave, in-order LDS).
+ *  - The last layer's rows are replicated (row m computes output m & 3), so every lane of a rollout ends up holding all
+ *    OUT outputs and no broadcast is needed.
+ *
+ * Numerics: a chain of MFMAs over the k-steps is bit-for-bit the k-ordered fp32 fma chain
+ *     acc = fma(W[j][k], act[k], acc), k ascending, acc0 = 0;  then acc += b[j]
+ * that FNNHelper::forward (fnn_helper.hpp) and the CPU oracle evaluate; zero padding of k adds fma(0, 0, acc) = acc.
+ *
+ * Restrictions: layers {IN, H, H, OUT} with IN <= 8, H a multiple of 16, OUT <= 4 (the AutoRally 6-32-32-4 network).
+ */
+#ifndef MPPI_AMD_FNN_MFMA_HPP_
+#define MPPI_AMD_FNN_MFMA_HPP_
+
+#include <hip/hip_runtime.h>
+#include "mppi_amd/det_math.h"
+
+namespace mppi
+{
+typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int IN, int H, int OUT>
+struct FNNMfma
+{
+  static_assert(IN <= 8 && H % 16 == 0 && OUT <= 4, "unsupported network shape for the MFMA forward");
+  static constexpr int RB = H / 16;        ///< row blocks of a hidden layer
+  static constexpr int KS_IN = (IN + 3) / 4;
+  static constexpr int KS_H = H / 4;
+  static constexpr int LDS_FLOATS_PER_WAVE = H * 16;  ///< activation tile [H][16 rollouts]
+  static constexpr int NUM_PARAMS = IN * H + H + H * H + H + H * OUT + OUT;
+
+  /* per-lane constants: weight fragments (A operands) and the biases of the rows this lane owns in the D layout */
+  float a1[RB][KS_IN];
+  float a2[RB][KS_H];
+  float a3[KS_H];
+  float b1[RB][4];
+  float b2[RB][4];
+  float b3[4];
+
+  /** theta: parameter blob [W1 (H x IN) | b1 | W2 (H x H) | b2 | W3 (OUT x H) | b3] (fnn_helper.cu:176-183) */
+  __device__ inline void load(const float* __restrict__ theta, const int lane)
+  {
+    const int m = lane & 15, g = lane >> 4;
+    const float* W1 = theta;
+    const float* B1 = W1 + IN * H;
+    const float* W2 = B1 + H;
+    const float* B2 = W2 + H * H;
+    const float* W3 = B2 + H;
+    const float* B3 = W3 + H * OUT;
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)
+    {
+#pragma unroll
+      for (int s = 0; s < KS_IN; s++)
+      {
+        const int k = 4 * s + g;
+        a1[rb][s] = (k < IN) ? W1[(16 * rb + m) * IN + k] : 0.0f;
+      }
+#pragma unroll
+      for (int s = 0; s < KS_H; s++)
+        a2[rb][s] = W2[(16 * rb + m) * H + 4 * s + g];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+      {
+        b1[rb][i] = B1[16 * rb + 4 * g + i];
+        b2[rb][i] = B2[16 * rb + 4 * g + i];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS_H; s++)
+      a3[s] = ((m & 3) < OUT) ? W3[(m & 3) * H + 4 * s + g] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      b3[i] = (i < OUT) ? B3[i] : 0.0f;
+  }
+
+  /** hidden layer epilogue: bias, tanh, store in [neuron][rollout] layout for the next layer's B fragments */
+  __device__ inline void storeHidden(const mfma_f32x4 (&acc)[RB], const float (&bias)[RB][4], float* __restrict__ tile,
+                                     const int lane) const
+  {
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+      {
+        float v = acc[rb][i] + bias[rb][i];
+        v = mppi::det::tanh(v);
+        tile[(16 * rb + 4 * g + i) * 16 + n] = v;
+      }
+  }
+
+  /**
+   * in[IN]: the network input of this lane's rollout (every lane of the rollout holds the same values);
+   * out[OUT]: the network output, identical in the 4 lanes of the rollout.  tile: wave-private LDS, H*16 floats.
+   */
+  __device__ inline void forward(const float (&in)[IN], float (&out)[OUT], float* __restrict__ tile,
+                                 const int lane) const
+  {
+    const int n = lane & 15, g = lane >> 4;
+    mfma_f32x4 acc[RB];
+    /* ---- layer 1: B fragment of k-step s = in[4s + g] ---- */
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)
+      acc[rb] = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int s = 0; s < KS_IN; s++)
+    {
+      float b = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (4 * s + q < IN)
+          b = (g == q) ? in[4 * s + q] : b;
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++)
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rb][s], b, acc[rb], 0, 0, 0);
+    }
+    storeHidden(acc, b1, tile, lane);
+    __builtin_amdgcn_wave_barrier();
+    /* ---- layer 2 ---- */
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)
+      acc[rb] = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int s = 0; s < KS_H; s++)
+    {
+      const float b = tile[(4 * s + g) * 16 + n];
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++)
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[rb][s], b, acc[rb], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    storeHidden(acc, b2, tile, lane);
+    __builtin_amdgcn_wave_barrier();
+    /* ---- layer 3 (linear): rows replicated, every lane of the rollout receives all outputs ---- */
+    mfma_f32x4 o = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int s = 0; s < KS_H; s++)
+    {
+      const float b = tile[(4 * s + g) * 16 + n];
+      o = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s], b, o, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < OUT; i++)
+      out[i] = o[i] + b3[i];
+  }
+};
+}  // namespace mppi
+#endif

@@ -139,7 +139,13 @@ struct has_costmap<T, std::void_t<decltype(std::declval<T&>().costmap_d_)>> : st
 {
 };
 
-template <class DYN_T, class COST_T, class SAMPLING_T, class SHAPES, int FIN_BY = 1>
+/**
+ * DYN_FAST_T / FAST_SHAPES: an optional second Dynamics type implementing the same model for particular block shapes
+ * (e.g. the MFMA forward of the NN model for shape (16, 4)); it is constructed from the primary object at launch, so
+ * parameters, control ranges and blobs are shared.
+ */
+template <class DYN_T, class COST_T, class SAMPLING_T, class SHAPES, int FIN_BY = 1, class DYN_FAST_T = void,
+          class FAST_SHAPES = Shapes<>>
 struct ModelT : ModelBase
 {
   DYN_T dyn;
@@ -296,7 +302,7 @@ struct ModelT : ModelBase
   }
   bool supportsShape(int bx, int by, int bz) const override
   {
-    return hasShape(SHAPES{}, bx, by, bz);
+    return hasShape(SHAPES{}, bx, by, bz) || hasShape(FAST_SHAPES{}, bx, by, bz);
   }
 
   void prepSampler(const SamplerLaunchState& s)
@@ -319,7 +325,61 @@ struct ModelT : ModelBase
   {
     smp.params_.num_timesteps = T;
     smp.params_.num_distributions = D;
+    if constexpr (!std::is_void<DYN_FAST_T>::value)
+    {
+      if (hasShape(FAST_SHAPES{}, bx, by, bz))
+      {
+        DYN_FAST_T fast(dyn);
+        return kernels::rolloutSharedBytes(fast, cost, smp, bx, 1, bz);
+      }
+    }
     return kernels::rolloutSharedBytes(dyn, cost, smp, bx, by, bz);
+  }
+
+  /** fast variant: shape (X, REP, Z) runs as X rollouts x REP replicated lanes with one contract lane (BY = 1) */
+  template <int X, int Y, int Z, class FAST = DYN_FAST_T>
+  mppi_status launchFastShape(const kernels::RolloutArgs& args, hipStream_t stream, std::string& err)
+  {
+    FAST fast(dyn);
+    constexpr int REP = kernels::replicated_lanes<FAST>::value;
+    static_assert(REP == Y, "fast shape: BY must equal the plugin's REPLICATED_LANES");
+    const size_t smem = kernels::rolloutSharedBytes(fast, cost, smp, X, 1, Z);
+    if (smem > MAX_LDS_BYTES)
+    {
+      err = "rollout kernel needs " + std::to_string(smem) + " B of LDS per block; gfx950 has 163840";
+      return MPPI_ERR_LDS_OVERFLOW;
+    }
+    const bool in_loop = smp.noise_source_ == 0;
+    auto kfn = in_loop ? kernels::rolloutKernel<FAST, COST_T, SAMPLING_T, X, 1, Z, true>
+                       : kernels::rolloutKernel<FAST, COST_T, SAMPLING_T, X, 1, Z, false>;
+    if (smem > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem);
+    const int grid = (args.num_rollouts + X - 1) / X;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(X * REP, 1, Z), smem, stream, fast, cost, smp, args);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+      err = std::string("rolloutKernel (fast variant) launch: ") + hipGetErrorString(e);
+      return MPPI_ERR_HIP;
+    }
+    return MPPI_OK;
+  }
+  template <int X, int Y, int Z, class... Rest>
+  mppi_status dispatchFast(Shapes<Shape<X, Y, Z>, Rest...>, int bx, int by, int bz, const kernels::RolloutArgs& args,
+                           hipStream_t stream, std::string& err, bool& handled)
+  {
+    if (bx == X && by == Y && bz == Z)
+    {
+      handled = true;
+      return launchFastShape<X, Y, Z>(args, stream, err);
+    }
+    return dispatchFast(Shapes<Rest...>{}, bx, by, bz, args, stream, err, handled);
+  }
+  mppi_status dispatchFast(Shapes<>, int, int, int, const kernels::RolloutArgs&, hipStream_t, std::string&, bool& handled)
+  {
+    handled = false;
+    return MPPI_OK;
   }
 
   template <int X, int Y, int Z>
@@ -377,6 +437,13 @@ struct ModelT : ModelBase
     if (!blobsReady(err))
       return MPPI_ERR_STATE;
     prepSampler(s);
+    if constexpr (!std::is_void<DYN_FAST_T>::value)
+    {
+      bool handled = false;
+      mppi_status st = dispatchFast(FAST_SHAPES{}, bx, by, bz, args, stream, err, handled);
+      if (handled)
+        return st;
+    }
     return dispatch(SHAPES{}, bx, by, bz, args, stream, err);
   }
 

@@ -41,17 +41,18 @@ using DIModel = ModelT<DoubleIntegratorDynamics, DoubleIntegratorCircleCost, DIS
 using ARModelDyn = NeuralNetModel<7, 2, 3>;
 using ARSampler = sampling_distributions::GaussianDistribution<NNDynamicsParams>;
 using ARModel = ModelT<ARModelDyn, ARStandardCost, ARSampler,
-                       Shapes<Shape<8, 16, 1>, Shape<16, 8, 1>, Shape<16, 4, 1>, Shape<64, 1, 1>, Shape<32, 8, 1>,
-                              Shape<64, 4, 1>, Shape<8, 16, 2>>,
-                       /*FIN_BY=*/8>;
+                       Shapes<Shape<8, 16, 1>, Shape<16, 8, 1>, Shape<16, 4, 1>, Shape<64, 1, 1>, Shape<8, 16, 2>>,
+                       /*FIN_BY=*/8,
+                       /* MFMA forward: BX rollouts x 4 k-group lanes per block (BX/16 waves) */
+                       NeuralNetModelMFMA<7, 2, 3>, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>, Shape<64, 4, 2>>>;
 
 inline ModelBase* makeModel(const std::string& name)
 {
   if (name == "autorally_nn")
   {
     ModelBase* m = new ARModel();
-    m->default_bx = 16;
-    m->default_by = 8;
+    m->default_bx = 64;  // MFMA variant: 64 rollouts x 4 lanes = 4 waves, one per SIMD of a CU
+    m->default_by = 4;
     return m;
   }
   if (name == "cartpole")

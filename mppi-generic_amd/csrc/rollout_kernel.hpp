@@ -29,6 +29,7 @@
 
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 #include "mppi_amd/plugin/managed.hpp"
 #include "mppi_amd/plugin/math_utils.hpp"
 #include "mppi_amd/plugin/parallel_utils.hpp"
@@ -42,6 +43,19 @@ __host__ __device__ inline int partialStride(int num_timesteps, int control_dim)
 {
   return num_timesteps * control_dim + 4;
 }
+
+/** REPLICATED_LANES of a Dynamics plugin (default 1): the number of wave lanes that carry private copies of one rollout
+ *  and cooperate only inside the plugin (e.g. as MFMA k-groups, utils/nn_helpers/fnn_mfma.hpp) */
+template <class T, class = void>
+struct replicated_lanes
+{
+  static constexpr int value = 1;
+};
+template <class T>
+struct replicated_lanes<T, std::void_t<decltype(T::REPLICATED_LANES)>>
+{
+  static constexpr int value = T::REPLICATED_LANES;
+};
 
 struct RolloutArgs
 {
@@ -78,15 +92,19 @@ __host__ inline size_t rolloutSharedBytes(const DYN_T& dyn, const COST_T& cost, 
 }
 
 template <class DYN_T, class COST_T, class SAMPLING_T, int BX, int BY, int BZ, bool DRAW_IN_LOOP>
-__global__ void __launch_bounds__(BX* BY* BZ)
+__global__ void __launch_bounds__(BX* BY* BZ* replicated_lanes<DYN_T>::value)
     rolloutKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args)
 {
+  // BX rollouts per block.  REP > 1 (only with one contract lane per rollout, BY == 1): REP wave lanes carry private
+  // register copies of each rollout; blockDim.x = BX * REP and a wave holds 64 / REP rollouts.
+  constexpr int REP = replicated_lanes<DYN_T>::value;
+  static_assert(REP == 1 || (BY == 1 && 64 % REP == 0 && (BX * REP) % 64 == 0), "replicated lanes need BY == 1 and whole waves");
   // The block shape is a template parameter; telling the compiler lets the plugins' threadIdx.y / blockDim.y loops
   // fold (see mppi_amd/plugin/parallel_utils.hpp).
-  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == BX);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == BX * REP);
   __builtin_assume(__builtin_amdgcn_workgroup_size_y() == BY);
   __builtin_assume(__builtin_amdgcn_workgroup_size_z() == BZ);
-  __builtin_assume(__builtin_amdgcn_workitem_id_x() < BX);
+  __builtin_assume(__builtin_amdgcn_workitem_id_x() < BX * REP);
   __builtin_assume(__builtin_amdgcn_workitem_id_y() < BY);
   __builtin_assume(__builtin_amdgcn_workitem_id_z() < BZ);
 
@@ -96,15 +114,25 @@ __global__ void __launch_bounds__(BX* BY* BZ)
 
   constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
   constexpr int SLOTS = BX * BZ;
-  const int thread_idx = (int)__builtin_amdgcn_workitem_id_x();
+  const int tid_x = (int)__builtin_amdgcn_workitem_id_x();
+  int thread_idx = tid_x;  // rollout within the block
+  int rep_lane = 0;        // which of the REP copies of the rollout this thread is
+  if (REP > 1)
+  {
+    constexpr int PER_WAVE = 64 / REP;
+    const int l = tid_x & 63;
+    thread_idx = (tid_x >> 6) * PER_WAVE + (l % PER_WAVE);
+    rep_lane = l / PER_WAVE;
+  }
   const int thread_idy = (int)__builtin_amdgcn_workitem_id_y();
   const int thread_idz = (int)__builtin_amdgcn_workitem_id_z();
   const int block_idx = (int)blockIdx.x;
   const int global_idx = BX * block_idx + thread_idx;
   const int shared_idx = BX * thread_idz + thread_idx;
   const int distribution_idx = thread_idz;
-  const int tid_flat = thread_idx + BX * (thread_idy + BY * thread_idz);
-  constexpr int NTHREADS = BX * BY * BZ;
+  const int tid_flat = tid_x + BX * REP * (thread_idy + BY * thread_idz);
+  constexpr int NTHREADS = BX * REP * BY * BZ;
+  const bool writer = (rep_lane == 0) && (thread_idy == 0);  // the one thread that publishes a rollout's results
   const int num_timesteps = args.num_timesteps;
   const int num_rollouts = args.num_rollouts;
   const float dt = args.dt;
@@ -167,6 +195,9 @@ __global__ void __launch_bounds__(BX* BY* BZ)
     crash_status[0] = 0;
   __syncthreads();
 
+  if (REP > 1)
+    sampling->setThreadMapping(shared_idx, BX);
+
   /*<----Start of simulation loop-----> */
   dynamics->initializeDynamics(x, u, y, theta_s_shared, 0.0f, dt);
   sampling->initializeDistributions(y, 0.0f, dt, theta_d_shared);
@@ -184,7 +215,8 @@ __global__ void __launch_bounds__(BX* BY* BZ)
     lane_sync();
     dynamics->enforceConstraints(xc, u);
     lane_sync();
-    sampling->writeControlSample(global_idx, t, distribution_idx, u, theta_d_shared, BY, thread_idy, y);
+    if (rep_lane == 0)
+      sampling->writeControlSample(global_idx, t, distribution_idx, u, theta_d_shared, BY, thread_idy, y);
     dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
     lane_sync();
     running_cost += costs->computeRunningCost(y, u, t, theta_c_shared, crash_status) +
@@ -192,49 +224,54 @@ __global__ void __launch_bounds__(BX* BY* BZ)
                                                          args.lambda, args.alpha);
     lane_sync();
   };
-  // Four steps per trip: x / x_next keep fixed roles (no pointer swap, so they stay in registers when BY == 1) and a
-  // trip consumes exactly C Philox quads whose lanes are indexed statically.
+  // STEPS steps per trip (even, so that x / x_next keep fixed roles and stay in registers when BY == 1) chosen such
+  // that a trip consumes whole Philox quads whose lanes are indexed statically: 4 steps for odd C, 2 for even C.
+  constexpr int STEPS = (C % 2 == 0) ? 2 : 4;
+  constexpr int QUADS = STEPS * C / 4;
+  static_assert(STEPS * C % 4 == 0, "a loop trip must consume whole quads");
   int t = 0;
-  for (; t + 3 < num_timesteps; t += 4)
+  for (; t + STEPS - 1 < num_timesteps; t += STEPS)
   {
-    float zq[4 * C];
+    float zq[4 * QUADS];
     if (DRAW_IN_LOOP)
     {
 #pragma unroll
-      for (int q = 0; q < C; q++)
-        sampling->drawQuad(global_idx, t / 4 * C + q, &zq[4 * q]);
+      for (int q = 0; q < QUADS; q++)
+        sampling->drawQuad(global_idx, t * C / 4 + q, &zq[4 * q]);
     }
-    one_step(x, x_next, t, &zq[0 * C]);
-    one_step(x_next, x, t + 1, &zq[1 * C]);
-    one_step(x, x_next, t + 2, &zq[2 * C]);
-    one_step(x_next, x, t + 3, &zq[3 * C]);
+#pragma unroll
+    for (int s2 = 0; s2 < STEPS; s2 += 2)
+    {
+      one_step(x, x_next, t + s2, &zq[s2 * C]);
+      one_step(x_next, x, t + s2 + 1, &zq[(s2 + 1) * C]);
+    }
   }
   if (t < num_timesteps)
   {
-    // tail of 1..3 steps: the same quads, the unused lanes are simply not consumed
-    float zq[4 * C];
+    // tail of 1..STEPS-1 steps: the same quads, the unused lanes are simply not consumed
+    float zq[4 * QUADS];
     if (DRAW_IN_LOOP)
     {
 #pragma unroll
-      for (int q = 0; q < C; q++)
-        sampling->drawQuad(global_idx, t / 4 * C + q, &zq[4 * q]);
+      for (int q = 0; q < QUADS; q++)
+        sampling->drawQuad(global_idx, t * C / 4 + q, &zq[4 * q]);
     }
     const int rem = num_timesteps - t;
     one_step(x, x_next, t, &zq[0 * C]);
-    if (rem > 1)
-      one_step(x_next, x, t + 1, &zq[1 * C]);
-    if (rem > 2)
-      one_step(x, x_next, t + 2, &zq[2 * C]);
-    if (rem == 1 || rem == 3)
+    if (STEPS > 2)
     {
-      // an odd number of steps leaves the newest state in x_next; the epilogue reads y (the output), not x
+      if (rem > 1)
+        one_step(x_next, x, t + 1, &zq[1 * C]);
+      if (rem > 2)
+        one_step(x, x_next, t + 2, &zq[(STEPS > 2 ? 2 : 0) * C]);
     }
+    // (an odd number of steps leaves the newest state in x_next; the epilogue reads y, the output, not x)
   }
 
   /* ---- cost of the rollout: sum over the y lanes, running/T + terminal/T ---- */
   if (BY > 1)
   {
-    running_cost_shared[tid_flat] = running_cost;
+    running_cost_shared[thread_idx + BX * (thread_idy + BY * thread_idz)] = running_cost;
     __syncthreads();
     if (thread_idy == 0)
     {
@@ -245,7 +282,7 @@ __global__ void __launch_bounds__(BX* BY* BZ)
     }
   }
   float traj_cost = INFINITY;
-  if (thread_idy == 0)
+  if (writer)
   {
     const float total =
         running_cost / (float)num_timesteps + costs->terminalCost(y, theta_c_shared) / (float)num_timesteps;
@@ -260,7 +297,7 @@ __global__ void __launch_bounds__(BX* BY* BZ)
 
   /* ---- block-local softmin record ---- */
   const float lambda_inv = (float)(1.0 / (double)args.lambda);  // mppi_controller.cu:201 passes 1.0 / lambda
-  if (thread_idy == 0)
+  if (writer)
   {
     float rho_b = INFINITY;
     for (int i = 0; i < BX; i++)

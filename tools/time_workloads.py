@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Times optimisation iterations of the registered workloads for several block shapes (HIP events on the engine's
+stream).  Usage: python tools/time_workloads.py [cartpole|autorally|di] ..."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+from common import autorally_cfg, cartpole_cfg, di_cfg, make_engine  # noqa: E402
+
+
+def run(name, cfg, shapes, n=100):
+    for bx, by in shapes:
+        try:
+            eng = make_engine(cfg, block_x=bx, block_y=by)
+        except Exception as e:  # noqa: BLE001
+            print(name, (bx, by), "skip:", e)
+            continue
+        x0 = np.tile(cfg["x0"], (cfg["D"], 1))
+        eng.uploadState(x0)
+        eng.optimize(20)
+        tot, roll = eng.timeIterations(n)
+        print("%-10s K=%d T=%d shape=(%d,%d,%d): iteration %.1f us, rollout kernel %.1f us" %
+              (name, cfg["K"], cfg["T"], bx, by, cfg["D"], tot / n * 1e3, roll / n * 1e3), flush=True)
+        eng.close()
+
+
+which = sys.argv[1:] or ["cartpole", "autorally", "di"]
+if "cartpole" in which:
+    run("cartpole", cartpole_cfg(K=16384, T=100), [(64, 1), (32, 1)])
+    run("cartpole", cartpole_cfg(K=2048, T=100), [(64, 1)])
+if "autorally" in which:
+    run("autorally", autorally_cfg(K=16384, T=150, lambda_=1.0), [(64, 4), (32, 4), (8, 16)], n=30)
+if "di" in which:
+    run("di-tube", di_cfg(K=8192, T=150, tube=True), [(64, 1)])
