@@ -55,18 +55,48 @@ def cpu_baseline(cfg, budget_s=12.0):
     }
 
 
+def autorally_leg(device):
+    """AutoRally NeuralNetModel (FNN 6-32-32-4, synthetic weights) + ARStandardCost, K=16384, T=150, one GPU:
+    iterations/s and the MFMA roofline of the NN forward (F_alg = 2 * sum(MAC) * K * T)."""
+    from common import autorally_cfg, make_engine
+    K, Tn = 16384, 150
+    cfg = autorally_cfg(K=K, T=Tn, lambda_=1.0)
+    eng = make_engine(cfg, device=device)
+    eng.uploadState(cfg["x0"])
+    eng.optimize(20, True)
+    n = 100
+    t0 = time.perf_counter()
+    eng.optimize(n, True)
+    wall = time.perf_counter() - t0
+    ms_total, ms_roll = eng.timeIterations(50)
+    roll_us = ms_roll / 50 * 1e3
+    f_alg = 2.0 * (6 * 32 + 32 * 32 + 32 * 4) * K * Tn
+    achieved = f_alg / (roll_us * 1e-6) / 1e12
+    return {
+        "workload": "AutoRally NeuralNetModel<7,2,3> (FNN 6-32-32-4, synthetic weights) + ARStandardCost (600x600 "
+                    "generated track map), VanillaMPPI iteration, K=16384, T=150, block (64 rollouts x 4 MFMA lanes)",
+        "value": round(n / wall, 3), "unit": "MPPI iters/s", "ms_per_step": round(wall / n * 1e3, 6),
+        "roofline": {"bound": "mfma", "kernel": "rolloutKernel<NeuralNetModelMFMA<7,2,3>,ARStandardCost,Gaussian,64,1,1>",
+                     "achieved": round(achieved, 4), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 5),
+                     "traffic": None, "algorithmic_flops_per_launch": f_alg, "avg_kernel_us": round(roll_us, 3),
+                     "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak = the fp32 vector peak; the kernel also "
+                             "carries 64 tanh per rollout-step, kinematics, costmap gathers and the Philox draw"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--primary-only", action="store_true", help="skip the secondary AutoRally-NN leg")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import mppi_generic_amd as m
-    from common import cartpole_cfg, make_engine
+    from common import autorally_cfg, cartpole_cfg, make_engine
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -144,14 +174,20 @@ def main():
             },
             "finite": ok,
             "roofline": {
-                "bound": "hbm", "kernel": "rolloutKernel<CartpoleDynamics,CartpoleQuadraticCost,Gaussian,64,1,1>",
+                "bound": "hbm", "kernel": "rolloutPipelineKernel<CartpoleDynamics,CartpoleQuadraticCost,Gaussian,1,true>",
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "algorithmic_bytes_per_launch": b_alg, "avg_kernel_us": round(roll_us, 3),
                 "avg_iteration_us_event_timed": round(ms_total / n_ev * 1e3, 3),
-                "note": "latency-bound: T=100 dependent Euler steps per rollout, one wave per CU at K=16384",
+                "note": "latency-bound: T=100 dependent Euler steps per rollout; K=16384 is 256 blocks of 3 role-waves on 256 CUs",
             },
         }
+        # secondary workload of the north star (not the headline `value`): AutoRally-NN, K=16384, T=150, MFMA forward
+        if not args.primary_only:
+            try:
+                out["autorally_nn"] = autorally_leg(local_rank)
+            except Exception as e:  # noqa: BLE001
+                out["autorally_nn"] = {"error": str(e)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cartpole_cfg(K=K_PER_GPU, T=T))
         print(json.dumps(out), flush=True)

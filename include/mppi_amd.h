@@ -70,6 +70,18 @@ typedef enum mppi_noise_source
 } mppi_noise_source;
 
 /**
+ * Structure of the rollout kernel.  The reference chooses between its "single" and "split" kernels by timing both at
+ * construction (chooseAppropriateKernel, controllers/MPPI/mppi_controller.cu:44-143); here the choice is explicit, with an
+ * automatic default.  All variants produce bit-identical trajectory costs.
+ */
+typedef enum mppi_kernel_variant
+{
+  MPPI_KERNEL_AUTO = 0,     /* pipeline where the model is registered for it and the block shape is (64, 1), else fused */
+  MPPI_KERNEL_FUSED = 1,    /* one wave carries sampling, dynamics and cost of its rollouts (csrc/rollout_kernel.hpp) */
+  MPPI_KERNEL_PIPELINE = 2  /* sampler / dynamics / cost waves decoupled through LDS (csrc/rollout_pipeline_kernel.hpp) */
+} mppi_kernel_variant;
+
+/**
  * Construction parameters == the template arguments + ControllerParams of the reference
  * (controllers/controller.cuh:46-68; template <DYN, COST, FB, SAMPLING, MAX_TIMESTEPS, NUM_ROLLOUTS>, :70-75).
  */
@@ -90,6 +102,7 @@ typedef struct mppi_config
   void* stream;          /* hipStream_t to run on, or NULL: the handle creates its own (Managed::stream_, utils/managed.cuh:57) */
   int rank, world_size;  /* K-sharding over GPUs: this handle owns rollouts [rank*K/world, (rank+1)*K/world) */
   int save_samples;      /* != 0: keep the clamped samples v[D][K_local][T][C] in HBM (control_samples_d_) */
+  int kernel_variant;    /* mppi_kernel_variant: which rollout kernel structure to use */
 } mppi_config;
 
 /** reference: GaussianParamsImpl, sampling_distributions/gaussian/gaussian.cuh:21-61 */

@@ -95,22 +95,17 @@ MPPI_HD static inline float copysign(float mag, float sgn)
  */
 MPPI_HD static inline float fmod_rb(float a, float b, float rb)
 {
-  const float q = trunc(a * rb);
-  if (!(fabs(q) < 2097152.0f))
+  /* fmod(a, b) = copysign(fmod(|a|, b), a): work on |a| so that the off-by-one fix-up is two selects */
+  const float aa = fabs(a);
+  const float q = trunc(aa * rb);
+  if (!(q < 2097152.0f))
   {
     return ::fmodf(a, b);
   }
-  float r = fma(-q, b, a);
+  float r = fma(-q, b, aa);
   const float rp = r + b, rm = r - b;
-  if (a >= 0.0f)
-  {
-    r = (r < 0.0f) ? rp : ((r >= b) ? rm : r);
-  }
-  else
-  {
-    r = (r > 0.0f) ? rm : ((r <= -b) ? rp : r);
-  }
-  return r;
+  r = (r < 0.0f) ? rp : ((r >= b) ? rm : r);
+  return copysign(r, a);
 }
 MPPI_HD static inline float fmod(float a, float b)
 {

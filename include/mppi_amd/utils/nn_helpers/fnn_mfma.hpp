@@ -91,20 +91,18 @@ struct FNNMfma
       b3[i] = (i < OUT) ? B3[i] : 0.0f;
   }
 
-  /** hidden layer epilogue: bias, tanh, store in [neuron][rollout] layout for the next layer's B fragments */
-  __device__ inline void storeHidden(const mfma_f32x4 (&acc)[RB], const float (&bias)[RB][4], float* __restrict__ tile,
-                                     const int lane) const
+  /** hidden layer epilogue of one row block: bias, tanh, store in [neuron][rollout] layout (next layer's B operand) */
+  __device__ inline void storeHidden(const mfma_f32x4& acc, const float (&bias)[4], const int rb,
+                                     float* __restrict__ tile, const int lane) const
   {
     const int n = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int rb = 0; rb < RB; rb++)
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-      {
-        float v = acc[rb][i] + bias[rb][i];
-        v = mppi::det::tanh(v);
-        tile[(16 * rb + 4 * g + i) * 16 + n] = v;
-      }
+    for (int i = 0; i < 4; i++)
+    {
+      float v = acc[i] + bias[i];
+      v = mppi::det::tanh(v);
+      tile[(16 * rb + 4 * g + i) * 16 + n] = v;
+    }
   }
 
   /**
@@ -115,11 +113,10 @@ struct FNNMfma
                                  const int lane) const
   {
     const int n = lane & 15, g = lane >> 4;
-    mfma_f32x4 acc[RB];
+    /* Row blocks are processed one after the other: while the matrix core works on row block rb + 1, the VALU
+     * squashes row block rb (the tanh of one block is ~200 VALU instructions, a block's MFMA chain 8 x 32 cycles). */
     /* ---- layer 1: B fragment of k-step s = in[4s + g] ---- */
-#pragma unroll
-    for (int rb = 0; rb < RB; rb++)
-      acc[rb] = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    float bin[KS_IN];
 #pragma unroll
     for (int s = 0; s < KS_IN; s++)
     {
@@ -128,26 +125,38 @@ struct FNNMfma
       for (int q = 0; q < 4; q++)
         if (4 * s + q < IN)
           b = (g == q) ? in[4 * s + q] : b;
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++)
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rb][s], b, acc[rb], 0, 0, 0);
+      bin[s] = b;
     }
-    storeHidden(acc, b1, tile, lane);
-    __builtin_amdgcn_wave_barrier();
-    /* ---- layer 2 ---- */
+    mfma_f32x4 acc[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; rb++)
+    {
       acc[rb] = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
-    for (int s = 0; s < KS_H; s++)
-    {
-      const float b = tile[(4 * s + g) * 16 + n];
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++)
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[rb][s], b, acc[rb], 0, 0, 0);
+      for (int s = 0; s < KS_IN; s++)
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rb][s], bin[s], acc[rb], 0, 0, 0);
     }
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)
+      storeHidden(acc[rb], b1[rb], rb, tile, lane);
     __builtin_amdgcn_wave_barrier();
-    storeHidden(acc, b2, tile, lane);
+    /* ---- layer 2 ---- */
+    float bh[KS_H];
+#pragma unroll
+    for (int s = 0; s < KS_H; s++)
+      bh[s] = tile[(4 * s + g) * 16 + n];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)
+    {
+      acc[rb] = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+      for (int s = 0; s < KS_H; s++)
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[rb][s], bh[s], acc[rb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)
+      storeHidden(acc[rb], b2[rb], rb, tile, lane);
     __builtin_amdgcn_wave_barrier();
     /* ---- layer 3 (linear): rows replicated, every lane of the rollout receives all outputs ---- */
     mfma_f32x4 o = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };

@@ -33,6 +33,7 @@ class MppiConfig(C.Structure):
         ("rank", C.c_int),
         ("world_size", C.c_int),
         ("save_samples", C.c_int),
+        ("kernel_variant", C.c_int),
     ]
 
 

@@ -16,6 +16,7 @@ MPPI_CONTROLLER_TUBE = 1
 MPPI_NOISE_PHILOX_FUSED = 0
 MPPI_NOISE_INJECTED = 1
 MPPI_NOISE_ROCRAND_HOST = 2
+MPPI_KERNEL_AUTO, MPPI_KERNEL_FUSED, MPPI_KERNEL_PIPELINE = 0, 1, 2
 
 
 class MPPIError(RuntimeError):
@@ -133,12 +134,12 @@ class MPPIController:
 
     def __init__(self, model, num_rollouts, num_timesteps, dt, lambda_, alpha=0.0, num_iters=1, seed=42,
                  noise_source=MPPI_NOISE_PHILOX_FUSED, block_x=0, block_y=0, device=0, stream=None, rank=0,
-                 world_size=1, save_samples=False):
+                 world_size=1, save_samples=False, kernel_variant=0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self._model = model.encode()
         cfg = MppiConfig(self._model, self.KIND, num_rollouts, num_timesteps, dt, lambda_, alpha, num_iters, seed,
-                         noise_source, block_x, block_y, device, stream, rank, world_size, int(save_samples))
+                         noise_source, block_x, block_y, device, stream, rank, world_size, int(save_samples), kernel_variant)
         st = self._lib.mppi_create(C.byref(cfg), C.byref(self._h))
         if st != 0:
             self._h = C.c_void_p()

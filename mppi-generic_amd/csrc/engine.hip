@@ -37,6 +37,7 @@ struct mppi_handle_s
   int D = 1, S = 0, C = 0, O = 0;
   int K_local = 0, K_offset = 0;
   int bx = 64, by = 1, bz = 1;
+  bool pipeline = false;
   int num_blocks = 0;
   int TC = 0, PS = 0;
   hipStream_t stream = nullptr;
@@ -216,7 +217,19 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
                 "mppi_create: block shape (" + std::to_string(h->bx) + "," + std::to_string(h->by) + "," +
                     std::to_string(h->bz) + ") is not instantiated for model '" + h->model_name + "'");
-  const size_t lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D);
+  const bool pipe_ok = h->model->supportsPipeline() && h->bx == 64 && h->by == 1;
+  if (cfg->kernel_variant == MPPI_KERNEL_PIPELINE && !pipe_ok)
+    return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
+                "mppi_create: the pipeline variant needs a model registered for it and block shape (64, 1)");
+  if (cfg->kernel_variant < 0 || cfg->kernel_variant > MPPI_KERNEL_PIPELINE)
+    return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_create: unknown kernel_variant");
+  h->pipeline = pipe_ok && cfg->kernel_variant != MPPI_KERNEL_FUSED;
+  size_t lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, h->pipeline);
+  if (lds > MAX_LDS_BYTES && h->pipeline && cfg->kernel_variant == MPPI_KERNEL_AUTO)
+  {  // the output ring does not fit next to the sample rows: fall back to the fused variant
+    h->pipeline = false;
+    lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, false);
+  }
   if (lds > MAX_LDS_BYTES)
     return fail(nullptr, MPPI_ERR_LDS_OVERFLOW,
                 "mppi_create: rollout kernel needs " + std::to_string(lds) + " B of LDS per block (max 163840)");
@@ -409,7 +422,7 @@ mppi_status mppi_set_model_blob(mppi_handle h, const char* name, const float* da
   if (st != MPPI_OK)
     return fail(h, st, err);
   // the LDS request may depend on the blob (network size): re-check it
-  const size_t lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, h->cfg.num_timesteps, h->D);
+  const size_t lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, h->cfg.num_timesteps, h->D, h->pipeline);
   if (lds > MAX_LDS_BYTES)
     return fail(h, MPPI_ERR_LDS_OVERFLOW, "rollout kernel LDS request exceeds 160 KiB after loading '" + std::string(name) + "'");
   return MPPI_OK;
@@ -477,7 +490,7 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   s.iteration = iteration;
   s.optimization_stride = stride;
   std::string err;
-  mppi_status st = h->model->launchRollout(h->bx, h->by, h->bz, a, s, h->stream, err);
+  mppi_status st = h->model->launchRollout(h->bx, h->by, h->bz, h->pipeline, a, s, h->stream, err);
   if (st != MPPI_OK)
     return fail(h, st, err);
   h->generation++;

@@ -19,6 +19,7 @@
 #include "rollout_kernel.hpp"
 #include "reduce_kernels.hpp"
 #include "finalize_kernel.hpp"
+#include "rollout_pipeline_kernel.hpp"
 
 namespace mppi
 {
@@ -68,8 +69,13 @@ struct ModelBase
     return MPPI_ERR_INVALID_ARG;
   }
   virtual bool supportsShape(int bx, int by, int bz) const = 0;
-  virtual size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D) = 0;
-  virtual mppi_status launchRollout(int bx, int by, int bz, const kernels::RolloutArgs& args,
+  /** role-pipelined variant (rollout_pipeline_kernel.hpp) available for this model? */
+  virtual bool supportsPipeline() const
+  {
+    return false;
+  }
+  virtual size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D, bool pipeline) = 0;
+  virtual mppi_status launchRollout(int bx, int by, int bz, bool pipeline, const kernels::RolloutArgs& args,
                                     const SamplerLaunchState& s, hipStream_t stream, std::string& err) = 0;
   virtual mppi_status launchFinalize(int D, const kernels::FinalizeArgs& a, hipStream_t stream, std::string& err) = 0;
   /** x <- one model step (optionally after enforceConstraints on u), one block (1, by, 1) */
@@ -145,9 +151,45 @@ struct has_costmap<T, std::void_t<decltype(std::declval<T&>().costmap_d_)>> : st
  * parameters, control ranges and blobs are shared.
  */
 template <class DYN_T, class COST_T, class SAMPLING_T, class SHAPES, int FIN_BY = 1, class DYN_FAST_T = void,
-          class FAST_SHAPES = Shapes<>>
+          class FAST_SHAPES = Shapes<>, bool PIPELINE = false>
 struct ModelT : ModelBase
 {
+  bool supportsPipeline() const override
+  {
+    return PIPELINE;
+  }
+
+  template <int Z>
+  mppi_status launchPipeline(const kernels::RolloutArgs& args, hipStream_t stream, std::string& err)
+  {
+    if constexpr (PIPELINE)
+    {
+      const size_t smem = kernels::pipelineSharedBytes(dyn, cost, smp, Z);
+      if (smem > MAX_LDS_BYTES)
+      {
+        err = "pipeline rollout kernel needs " + std::to_string(smem) + " B of LDS per block; gfx950 has 163840";
+        return MPPI_ERR_LDS_OVERFLOW;
+      }
+      const bool in_loop = smp.noise_source_ == 0;
+      auto kfn = in_loop ? kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, true>
+                         : kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, false>;
+      if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+      const int grid = (args.num_rollouts + 63) / 64;
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * kernels::PIPE_ROLES, 1, Z), smem, stream, dyn, cost, smp, args);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess)
+      {
+        err = std::string("rolloutPipelineKernel launch: ") + hipGetErrorString(e);
+        return MPPI_ERR_HIP;
+      }
+      return MPPI_OK;
+    }
+    err = "model is not registered for the pipeline variant";
+    return MPPI_ERR_LAUNCH_SHAPE;
+  }
+
   DYN_T dyn;
   COST_T cost;
   SAMPLING_T smp;
@@ -321,10 +363,12 @@ struct ModelT : ModelBase
     smp.setIteration(s.iteration, s.optimization_stride);
   }
 
-  size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D) override
+  size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D, bool pipeline) override
   {
     smp.params_.num_timesteps = T;
     smp.params_.num_distributions = D;
+    if (pipeline)
+      return kernels::pipelineSharedBytes(dyn, cost, smp, bz);
     if constexpr (!std::is_void<DYN_FAST_T>::value)
     {
       if (hasShape(FAST_SHAPES{}, bx, by, bz))
@@ -431,12 +475,14 @@ struct ModelT : ModelBase
     return MPPI_ERR_LAUNCH_SHAPE;
   }
 
-  mppi_status launchRollout(int bx, int by, int bz, const kernels::RolloutArgs& args, const SamplerLaunchState& s,
-                            hipStream_t stream, std::string& err) override
+  mppi_status launchRollout(int bx, int by, int bz, bool pipeline, const kernels::RolloutArgs& args,
+                            const SamplerLaunchState& s, hipStream_t stream, std::string& err) override
   {
     if (!blobsReady(err))
       return MPPI_ERR_STATE;
     prepSampler(s);
+    if (pipeline)
+      return bz == 1 ? launchPipeline<1>(args, stream, err) : launchPipeline<2>(args, stream, err);
     if constexpr (!std::is_void<DYN_FAST_T>::value)
     {
       bool handled = false;

@@ -91,6 +91,93 @@ __host__ inline size_t rolloutSharedBytes(const DYN_T& dyn, const COST_T& cost, 
   return n;
 }
 
+/**
+ * Epilogue shared by the rollout kernels: trajectory cost = running/T + terminal/T (mppi_common.cu:144, :843-853),
+ * block-local softmin record {U_b, rho_b, eta_b, sum w^2} from the LDS sample rows, optional sample dump.
+ * Block-uniform; contains barriers.  `writer` marks the one thread that publishes a rollout's result.
+ */
+template <class SAMPLING_T, int C, int BX, int BZ, int NTHREADS>
+__device__ inline void blockSoftminEpilogue(SAMPLING_T* sampling, const RolloutArgs& args, const float terminal_cost,
+                                            const float running_cost, const bool writer, const bool valid,
+                                            const int global_idx, const int shared_idx, const int thread_idz,
+                                            const int tid_flat, const int block_idx, const int nrows,
+                                            float* theta_d_shared, float* cost_s, float* w_s)
+{
+  const int num_timesteps = args.num_timesteps;
+  const int num_rollouts = args.num_rollouts;
+  float traj_cost = INFINITY;
+  if (writer)
+  {
+    const float total =
+        running_cost / (float)num_timesteps + terminal_cost / (float)num_timesteps;
+    if (valid)
+    {
+      traj_cost = total;
+      args.trajectory_costs_d[(size_t)num_rollouts * thread_idz + global_idx] = total;
+    }
+    cost_s[shared_idx] = traj_cost;
+  }
+  __syncthreads();
+
+  /* ---- block-local softmin record ---- */
+  const float lambda_inv = (float)(1.0 / (double)args.lambda);  // mppi_controller.cu:201 passes 1.0 / lambda
+  if (writer)
+  {
+    float rho_b = INFINITY;
+    for (int i = 0; i < BX; i++)
+      rho_b = fminf(rho_b, cost_s[BX * thread_idz + i]);
+    w_s[shared_idx] = valid ? mppi::det::exp(-lambda_inv * (traj_cost - rho_b)) : 0.0f;
+  }
+  __syncthreads();
+
+  const int TC = num_timesteps * C;
+  const int PS = partialStride(num_timesteps, C);
+  const int num_blocks = (int)gridDim.x;
+  const int row_stride = SAMPLING_T::rowStride(num_timesteps);
+  for (int o = tid_flat; o < BZ * TC; o += NTHREADS)
+  {
+    const int z = o / TC;
+    const int j = o - z * TC;
+    const float* rows = theta_d_shared + (size_t)(BX * z) * row_stride + j;
+    const float* wz = w_s + BX * z;
+    float acc = 0.0f;
+    for (int i = 0; i < nrows; i++)
+      acc += wz[i] * rows[i * row_stride];
+    args.partials_d[((size_t)z * num_blocks + block_idx) * PS + j] = acc;
+  }
+  if (tid_flat < BZ)
+  {
+    const int z = tid_flat;
+    float rho_b = INFINITY;
+    double eta = 0.0, eta2 = 0.0;
+    for (int i = 0; i < nrows; i++)
+    {
+      rho_b = fminf(rho_b, cost_s[BX * z + i]);
+      const double w = (double)w_s[BX * z + i];
+      eta += w;
+      eta2 += w * w;
+    }
+    float* rec = args.partials_d + ((size_t)z * num_blocks + block_idx) * PS + TC;
+    rec[0] = rho_b;
+    rec[1] = (float)eta;
+    rec[2] = (float)eta2;
+    rec[3] = 0.0f;
+  }
+  if (args.save_samples)
+  {
+    // dump v[z][k][t][c] (clamped) for getSampledControl-style readers and for the RNG-mode parity tests
+    for (int o = tid_flat; o < BZ * nrows * TC; o += NTHREADS)
+    {
+      const int z = o / (nrows * TC);
+      const int r = o - z * nrows * TC;
+      const int i = r / TC;
+      const int j = r - i * TC;
+      sampling->control_samples_d_[((size_t)z * num_rollouts + BX * block_idx + i) * TC + j] =
+          theta_d_shared[(size_t)(BX * z + i) * row_stride + j];
+    }
+  }
+}
+
 template <class DYN_T, class COST_T, class SAMPLING_T, int BX, int BY, int BZ, bool DRAW_IN_LOOP>
 __global__ void __launch_bounds__(BX* BY* BZ* replicated_lanes<DYN_T>::value)
     rolloutKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args)
@@ -281,77 +368,9 @@ __global__ void __launch_bounds__(BX* BY* BZ* replicated_lanes<DYN_T>::value)
       running_cost = acc;
     }
   }
-  float traj_cost = INFINITY;
-  if (writer)
-  {
-    const float total =
-        running_cost / (float)num_timesteps + costs->terminalCost(y, theta_c_shared) / (float)num_timesteps;
-    if (valid)
-    {
-      traj_cost = total;
-      args.trajectory_costs_d[(size_t)num_rollouts * thread_idz + global_idx] = total;
-    }
-    cost_s[shared_idx] = traj_cost;
-  }
-  __syncthreads();
-
-  /* ---- block-local softmin record ---- */
-  const float lambda_inv = (float)(1.0 / (double)args.lambda);  // mppi_controller.cu:201 passes 1.0 / lambda
-  if (writer)
-  {
-    float rho_b = INFINITY;
-    for (int i = 0; i < BX; i++)
-      rho_b = fminf(rho_b, cost_s[BX * thread_idz + i]);
-    w_s[shared_idx] = valid ? mppi::det::exp(-lambda_inv * (traj_cost - rho_b)) : 0.0f;
-  }
-  __syncthreads();
-
-  const int TC = num_timesteps * C;
-  const int PS = partialStride(num_timesteps, C);
-  const int num_blocks = (int)gridDim.x;
-  const int row_stride = SAMPLING_T::rowStride(num_timesteps);
-  for (int o = tid_flat; o < BZ * TC; o += NTHREADS)
-  {
-    const int z = o / TC;
-    const int j = o - z * TC;
-    const float* rows = theta_d_shared + (size_t)(BX * z) * row_stride + j;
-    const float* wz = w_s + BX * z;
-    float acc = 0.0f;
-    for (int i = 0; i < nrows; i++)
-      acc += wz[i] * rows[i * row_stride];
-    args.partials_d[((size_t)z * num_blocks + block_idx) * PS + j] = acc;
-  }
-  if (tid_flat < BZ)
-  {
-    const int z = tid_flat;
-    float rho_b = INFINITY;
-    double eta = 0.0, eta2 = 0.0;
-    for (int i = 0; i < nrows; i++)
-    {
-      rho_b = fminf(rho_b, cost_s[BX * z + i]);
-      const double w = (double)w_s[BX * z + i];
-      eta += w;
-      eta2 += w * w;
-    }
-    float* rec = args.partials_d + ((size_t)z * num_blocks + block_idx) * PS + TC;
-    rec[0] = rho_b;
-    rec[1] = (float)eta;
-    rec[2] = (float)eta2;
-    rec[3] = 0.0f;
-  }
-  if (args.save_samples)
-  {
-    // dump v[z][k][t][c] (clamped) for getSampledControl-style readers and for the RNG-mode parity tests
-    for (int o = tid_flat; o < BZ * nrows * TC; o += NTHREADS)
-    {
-      const int z = o / (nrows * TC);
-      const int r = o - z * nrows * TC;
-      const int i = r / TC;
-      const int j = r - i * TC;
-      sampling->control_samples_d_[((size_t)z * num_rollouts + BX * block_idx + i) * TC + j] =
-          theta_d_shared[(size_t)(BX * z + i) * row_stride + j];
-    }
-  }
+  blockSoftminEpilogue<SAMPLING_T, C, BX, BZ, NTHREADS>(sampling, args, costs->terminalCost(y, theta_c_shared), running_cost,
+                                                        writer, valid, global_idx, shared_idx, thread_idz, tid_flat,
+                                                        block_idx, nrows, theta_d_shared, cost_s, w_s);
 }
 
 }  // namespace kernels

@@ -1,0 +1,269 @@
+/**
+ * rollout_pipeline_kernel.hpp — the rollout as a three-stage pipeline of role-specialised waves (MI355X design).
+ *
+ * Why: at the benchmark sizes (K = 16384 rollouts = 256 waves on 1024 SIMDs) the fused rollout is bound by the LENGTH
+ * of one wave's serial instruction stream (T steps x ~300 instructions x ~3.7 cycles), not by throughput: three of the
+ * four SIMDs of every CU idle.  The reference's plugin split happens to cut a step into three parts with a one-way data
+ * flow — SamplingDistribution -> Dynamics -> Cost (reference call order: core/mppi_common.cu:98-137) — and only the
+ * Dynamics part carries the step-to-step dependence.  So a block of 64 rollouts runs as three waves on three SIMDs:
+ *
+ *   wave S (sampler)   for every t: draw eps (Philox quad / pre-filled row), apply the setGaussianControls rule,
+ *                      store the sample in the rollout's LDS row                      -> sampling->drawQuad / shape...
+ *   wave D (dynamics)  for every t: fetch the sample, enforceConstraints, write the clamped control back to the row
+ *                      (mppi_common.cu:110-117), step, push the output y_t into an LDS ring  -> dynamics->...
+ *   wave C (cost)      for every t: pop y_t, read u_t, running += computeRunningCost + likelihoodRatioCost
+ *                                                                              -> costs->..., sampling->...
+ *
+ * The stages are decoupled by monotonic progress counters in LDS (one writer each, polled with s_sleep by the consumer,
+ * release/acquire at workgroup scope); S may run arbitrarily far ahead (the rows hold the whole horizon), C lags D by at
+ * most RING steps (back-pressure).  The critical path per step is wave D's ~130 instructions instead of ~300.
+ * Every rollout is still evaluated with exactly the arithmetic of rolloutKernel (same plugin methods, same order of the
+ * cost additions), so the results are bit-identical; the epilogue is shared (blockSoftminEpilogue).
+ *
+ * Requirements on the plugins: one lane per rollout (no threadIdx.y cooperation) and no block-wide barrier inside the
+ * per-step methods (mppi::lane_sync() is fine — it is a no-op for blockDim.y == 1).  Models are registered for this
+ * variant explicitly (csrc/models.hpp).
+ *
+ * Launch: grid = ceil(K / 64), block = (192, 1, BZ); thread x: role = x / 64, lane = x % 64.
+ */
+#ifndef MPPI_AMD_ROLLOUT_PIPELINE_KERNEL_HPP_
+#define MPPI_AMD_ROLLOUT_PIPELINE_KERNEL_HPP_
+
+#include "rollout_kernel.hpp"
+
+namespace mppi
+{
+namespace kernels
+{
+constexpr int PIPE_ROLES = 3;
+constexpr int PIPE_RING = 32;  ///< outputs buffered between the dynamics and the cost wave (steps)
+
+template <class DYN_T, class COST_T, class SAMPLING_T>
+__host__ inline size_t pipelineSharedBytes(const DYN_T& dyn, const COST_T& cost, const SAMPLING_T& smp, int bz)
+{
+  const int slots = 64 * bz;
+  size_t n = 0;
+  n += calcClassSharedMemSize(&dyn, slots);
+  n += calcClassSharedMemSize(&cost, slots);
+  n += calcClassSharedMemSize(&smp, slots);
+  n += sizeof(float) * 2 * math::nearest_multiple_4(slots);                     // cost_s, w_s
+  n += sizeof(float) * (size_t)bz * PIPE_RING * DYN_T::OUTPUT_DIM * 64;          // output ring [z][slot][i][lane]
+  n += sizeof(int) * 4 * 4 * bz;                                                 // progress counters (padded)
+  return n;
+}
+
+/** progress counters live in LDS: address-space-3 pointers keep the polls on ds_read instead of flat loads */
+typedef volatile __attribute__((address_space(3))) int* lds_counter_t;
+
+/**
+ * Blocks until *ctr >= need.  `cached` is the consumer's last observed value: the producer usually runs ahead, so most
+ * calls return without touching LDS.
+ */
+__device__ inline void pipeWait(lds_counter_t ctr, const int need, int& cached)
+{
+  if (cached >= need)
+    return;
+  int v = __builtin_amdgcn_readfirstlane(*ctr);
+  while (v < need)
+  {
+    __builtin_amdgcn_s_sleep(1);
+    v = __builtin_amdgcn_readfirstlane(*ctr);
+  }
+  cached = v;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ inline void pipePublish(lds_counter_t ctr, const int value, const int lane)
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0)
+    *ctr = value;
+}
+
+template <class DYN_T, class COST_T, class SAMPLING_T, int BZ, bool DRAW_IN_LOOP>
+__global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
+    rolloutPipelineKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args)
+{
+  constexpr int BX = 64;
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == BX * PIPE_ROLES);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_y() == 1);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_z() == BZ);
+  __builtin_assume(__builtin_amdgcn_workitem_id_x() < BX * PIPE_ROLES);
+  __builtin_assume(__builtin_amdgcn_workitem_id_y() == 0);
+  __builtin_assume(__builtin_amdgcn_workitem_id_z() < BZ);
+
+  DYN_T* dynamics = &dynamics_obj;
+  COST_T* costs = &costs_obj;
+  SAMPLING_T* sampling = &sampling_obj;
+  constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
+  constexpr int SLOTS = BX * BZ;
+  constexpr int NTHREADS = BX * PIPE_ROLES * BZ;
+
+  const int tid_x = (int)__builtin_amdgcn_workitem_id_x();
+  const int role = __builtin_amdgcn_readfirstlane(tid_x >> 6);  // wave-uniform
+  const int lane = tid_x & 63;
+  const int thread_idx = lane;
+  const int thread_idz = (int)__builtin_amdgcn_workitem_id_z();
+  const int block_idx = (int)blockIdx.x;
+  const int global_idx = BX * block_idx + thread_idx;
+  const int shared_idx = BX * thread_idz + thread_idx;
+  const int distribution_idx = thread_idz;
+  const int tid_flat = tid_x + BX * PIPE_ROLES * thread_idz;
+  const int num_timesteps = args.num_timesteps;
+  const int num_rollouts = args.num_rollouts;
+  const float dt = args.dt;
+  const bool valid = global_idx < num_rollouts;
+  const int nrows = min(BX, num_rollouts - BX * block_idx);
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* theta_s_shared = reinterpret_cast<float*>(smem_raw);
+  float* theta_c_shared = theta_s_shared + calcClassSharedMemSize(dynamics, SLOTS) / (int)sizeof(float);
+  float* theta_d_shared = theta_c_shared + calcClassSharedMemSize(costs, SLOTS) / (int)sizeof(float);
+  float* cost_s = theta_d_shared + calcClassSharedMemSize(sampling, SLOTS) / (int)sizeof(float);
+  float* w_s = cost_s + math::nearest_multiple_4(SLOTS);
+  float* ring_all = w_s + math::nearest_multiple_4(SLOTS);
+  float* ring = ring_all + (size_t)thread_idz * PIPE_RING * O * 64;  // [slot][i][lane]
+  lds_counter_t counters =
+      (lds_counter_t)(reinterpret_cast<int*>(ring_all + (size_t)BZ * PIPE_RING * O * 64) + 16 * thread_idz);
+  lds_counter_t smp_prog = counters + 0;   // steps whose shaped sample is in the row
+  lds_counter_t dyn_prog = counters + 4;   // steps whose output is in the ring
+  lds_counter_t cost_prog = counters + 8;  // steps the cost wave has consumed
+
+  sampling->setThreadMapping(shared_idx, BX);
+
+  float x[S], x_next[S], xdot[S], u[C], y[O];
+  int crash_status = 0;
+#pragma unroll
+  for (int i = 0; i < S; i++)
+  {
+    x[i] = args.init_x_d[S * thread_idz + i];
+    xdot[i] = 0.0f;
+    x_next[i] = 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    u[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < O; i++)
+    y[i] = 0.0f;
+  if (lane == 0 && role == 0)
+  {
+    *smp_prog = 0;
+    *dyn_prog = 0;
+    *cost_prog = 0;
+  }
+  __syncthreads();
+
+  // every wave runs the (cheap, possibly barrier-containing) initialisers: block-uniform control flow
+  dynamics->initializeDynamics(x, u, y, theta_s_shared, 0.0f, dt);
+  sampling->initializeDistributions(y, 0.0f, dt, theta_d_shared);
+  costs->initializeCosts(y, u, theta_c_shared, 0.0f, dt);
+  __syncthreads();
+
+  float running_cost = 0.0f;
+  float* row = sampling->sampleRow(theta_d_shared, shared_idx);
+
+  if (role == 0)
+  {
+    /* ------------------------------------------------ sampler wave ------------------------------------------------ */
+    constexpr int STEPS = (C % 2 == 0) ? 2 : 4;
+    constexpr int QUADS = STEPS * C / 4;
+    for (int t = 0; t < num_timesteps; t += STEPS)
+    {
+      float zq[4 * QUADS];
+      if (DRAW_IN_LOOP)
+      {
+#pragma unroll
+        for (int q = 0; q < QUADS; q++)
+          sampling->drawQuad(global_idx, t * C / 4 + q, &zq[4 * q]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < STEPS; s2++)
+      {
+        if (t + s2 < num_timesteps)
+        {
+          if (DRAW_IN_LOOP)
+            sampling->shapeControlSample(global_idx, t + s2, distribution_idx, &zq[s2 * C], u);
+          else
+            sampling->readControlSample(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
+          sampling->writeControlSample(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
+        }
+      }
+      pipePublish(smp_prog, min(t + STEPS, num_timesteps), lane);
+    }
+  }
+  else if (role == 1)
+  {
+    /* ------------------------------------------------ dynamics wave ----------------------------------------------- */
+    // the four samples of a trip are fetched up front (their LDS latency overlaps the first step's arithmetic)
+    auto dyn_step = [&](float* xc, float* xn, int t, const float* u_in) {
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        u[i] = u_in[i];
+      dynamics->enforceConstraints(xc, u);
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        row[t * C + i] = u[i];
+      dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
+      float* slot = ring + (size_t)(t % PIPE_RING) * O * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < O; i++)
+        slot[i * 64] = y[i];
+    };
+    int seen_smp = 0, seen_cost = 0;
+    for (int t = 0; t < num_timesteps; t += 4)
+    {
+      const int hi = min(t + 4, num_timesteps);
+      pipeWait(smp_prog, hi, seen_smp);               // samples for steps t .. hi-1 are in the rows
+      pipeWait(cost_prog, hi - PIPE_RING, seen_cost); // their ring slots have been consumed
+      float ubuf[4 * C];
+#pragma unroll
+      for (int j = 0; j < 4 * C; j++)
+        ubuf[j] = (t * C + j < num_timesteps * C) ? row[t * C + j] : 0.0f;
+      dyn_step(x, x_next, t, &ubuf[0]);
+      if (t + 1 < num_timesteps)
+        dyn_step(x_next, x, t + 1, &ubuf[C]);
+      if (t + 2 < num_timesteps)
+        dyn_step(x, x_next, t + 2, &ubuf[2 * C]);
+      if (t + 3 < num_timesteps)
+        dyn_step(x_next, x, t + 3, &ubuf[3 * C]);
+      pipePublish(dyn_prog, hi, lane);
+    }
+  }
+  else
+  {
+    /* ------------------------------------------------ cost wave --------------------------------------------------- */
+    int seen_dyn = 0;
+    for (int t = 0; t < num_timesteps; t += 4)
+    {
+      const int hi = min(t + 4, num_timesteps);
+      pipeWait(dyn_prog, hi, seen_dyn);
+      for (int tt = t; tt < hi; tt++)
+      {
+        const float* slot = ring + (size_t)(tt % PIPE_RING) * O * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < O; i++)
+          y[i] = slot[i * 64];
+#pragma unroll
+        for (int i = 0; i < C; i++)
+          u[i] = row[tt * C + i];
+        running_cost += costs->computeRunningCost(y, u, tt, theta_c_shared, &crash_status) +
+                        sampling->computeLikelihoodRatioCost(u, theta_d_shared, global_idx, tt, distribution_idx,
+                                                             args.lambda, args.alpha);
+      }
+      pipePublish(cost_prog, hi, lane);
+    }
+  }
+  __syncthreads();
+
+  // the cost wave holds the running cost and the last output: it publishes the rollout's result
+  const bool writer = (role == 2);
+  const float terminal = costs->terminalCost(y, theta_c_shared);
+  blockSoftminEpilogue<SAMPLING_T, C, BX, BZ, NTHREADS>(sampling, args, terminal, running_cost, writer, valid, global_idx,
+                                                        shared_idx, thread_idz, tid_flat, block_idx, nrows,
+                                                        theta_d_shared, cost_s, w_s);
+}
+
+}  // namespace kernels
+}  // namespace mppi
+
+#endif

@@ -44,6 +44,42 @@ def test_cartpole_rollout_costs_bit_exact(gpu, shape):
     assert ulp_diff(g, c).max() == 0, "max ulp diff %d" % ulp_diff(g, c).max()
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("mode", ["injected", "philox"])
+def test_kernel_variants_agree(gpu, variant, mode):
+    """fused (one wave per 64 rollouts) and pipeline (sampler / dynamics / cost waves) variants: identical costs, both
+    noise sources, Cartpole and the two-system Double Integrator"""
+    for cfg in (cartpole_cfg_lr(K=1000, T=50), cartpole_cfg(K=2048, T=99, soft=True), di_cfg(K=512, T=33, tube=True)):
+        C = len(cfg["std_dev"])
+        eng = make_engine(cfg, kernel_variant=variant, save_samples=True)
+        orc = make_oracle(cfg)
+        mean = (0.3 * np.sin(np.arange(cfg["T"] * C, dtype=np.float32) * 0.2)).reshape(cfg["T"], C)
+        eng.updateImportanceSampler(mean)
+        if mode == "injected":
+            eps = host_noise(1, cfg["K"], cfg["T"], C)[0]
+            eng.injectNoise(eps)
+        else:
+            eps = po.philox_normal(42, 0, cfg["K"], cfg["T"], C)
+        x0 = np.tile(cfg["x0"], (cfg["D"], 1))
+        g = eng.rolloutCosts(x0, 2)
+        means = np.tile(mean, (cfg["D"], 1, 1))
+        v = orc.set_gaussian_controls(means, eps, 2, 0)
+        c, vc = orc.rollout_costs(x0, means, v)
+        assert ulp_diff(g, c).max() == 0
+        assert ulp_diff(eng.getSampledControls(), vc).max() == 0
+        # and the merged result of one full iteration
+        eng.uploadState(x0)
+        eng.updateImportanceSampler(mean)
+        if mode == "injected":
+            eng.injectNoise(eps)
+        else:
+            eng.setSeed(42)
+        eng.uploadState(x0)
+        eng.optimize(1)
+        u_orc = orc.iterate(x0, means, eps, 1, 0)  # mppi_optimize runs with optimization_stride 1 here
+        assert np.abs(eng.getOptimalControlSeq() - u_orc).max() <= U_TOL
+
+
 def test_cartpole_lr_terminal_nonzero_mean_bit_exact(gpu):
     cfg = cartpole_cfg_lr()
     eps = host_noise(1, cfg["K"], cfg["T"], 1)[0]

@@ -12,9 +12,11 @@ from common import autorally_cfg, cartpole_cfg, di_cfg, make_engine  # noqa: E40
 
 
 def run(name, cfg, shapes, n=100):
-    for bx, by in shapes:
+    for sh in shapes:
+        bx, by = sh[0], sh[1]
+        variant = sh[2] if len(sh) > 2 else 0
         try:
-            eng = make_engine(cfg, block_x=bx, block_y=by)
+            eng = make_engine(cfg, block_x=bx, block_y=by, kernel_variant=variant)
         except Exception as e:  # noqa: BLE001
             print(name, (bx, by), "skip:", e)
             continue
@@ -22,16 +24,16 @@ def run(name, cfg, shapes, n=100):
         eng.uploadState(x0)
         eng.optimize(20)
         tot, roll = eng.timeIterations(n)
-        print("%-10s K=%d T=%d shape=(%d,%d,%d): iteration %.1f us, rollout kernel %.1f us" %
-              (name, cfg["K"], cfg["T"], bx, by, cfg["D"], tot / n * 1e3, roll / n * 1e3), flush=True)
+        print("%-10s K=%d T=%d shape=(%d,%d,%d) variant=%d: iteration %.1f us, rollout kernel %.1f us" %
+              (name, cfg["K"], cfg["T"], bx, by, cfg["D"], variant, tot / n * 1e3, roll / n * 1e3), flush=True)
         eng.close()
 
 
 which = sys.argv[1:] or ["cartpole", "autorally", "di"]
 if "cartpole" in which:
-    run("cartpole", cartpole_cfg(K=16384, T=100), [(64, 1), (32, 1)])
+    run("cartpole", cartpole_cfg(K=16384, T=100), [(64, 1, 1), (64, 1, 2), (32, 1)])
     run("cartpole", cartpole_cfg(K=2048, T=100), [(64, 1)])
 if "autorally" in which:
     run("autorally", autorally_cfg(K=16384, T=150, lambda_=1.0), [(64, 4), (32, 4), (8, 16)], n=30)
 if "di" in which:
-    run("di-tube", di_cfg(K=8192, T=150, tube=True), [(64, 1)])
+    run("di-tube", di_cfg(K=8192, T=150, tube=True), [(64, 1, 1), (64, 1, 2)])
