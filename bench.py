@@ -27,6 +27,27 @@ T = 100
 HBM_PEAK_GBS = 8000.0
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
+def pmc_traffic():
+    """HBM bytes per rollout launch from the committed PMC passes (profiles/), or None"""
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "r01_c_pmc_hbm_traffic.json")))
+        return d["rollout_traffic_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(cfg, budget_s=12.0):
     """oracle iterations/s on the host cores, bounded sample (never the thing shipped or measured as `value`)"""
     import numpy as np
@@ -36,7 +57,7 @@ def cpu_baseline(cfg, budget_s=12.0):
     K, Tn, C = cfg["K"], cfg["T"], o.C
     eps = po.philox_normal(42, 0, K, Tn, C)
     mean = np.zeros((1, Tn, C), np.float32)
-    threads = max(1, min(po.max_threads(), os.cpu_count() or 1))
+    threads = max(1, min(po.max_threads(), usable_cores()))
     out = {}
     for label, th in (("all", threads), ("one", 1)):
         o.time_iterations(cfg["x0"], mean, eps, 1, th)  # warm-up
@@ -176,7 +197,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "rolloutPipelineKernel<CartpoleDynamics,CartpoleQuadraticCost,Gaussian,1,true>",
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(),
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, profiles/r01_c_pmc_hbm_traffic.json "
+                                  "(2*FETCH_SIZE + WRITE_SIZE): the sample tensor never reaches HBM, so traffic << algorithmic bytes",
                 "algorithmic_bytes_per_launch": b_alg, "avg_kernel_us": round(roll_us, 3),
                 "avg_iteration_us_event_timed": round(ms_total / n_ev * 1e3, 3),
                 "note": "latency-bound: T=100 dependent Euler steps per rollout; K=16384 is 256 blocks of 3 role-waves on 256 CUs",
