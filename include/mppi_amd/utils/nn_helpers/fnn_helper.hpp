@@ -105,7 +105,13 @@ public:
   /** reference: fnn_helper.cu:420-484; returns the buffer holding the output layer */
   __device__ inline float* forward(float* input, float* theta_s) const
   {
-    float* curr_act = getInputLocation(theta_s);
+    return forward(input, theta_s, getInputLocation(theta_s));
+  }
+
+  /** the overload with an explicit activation buffer (reference: fnn_helper.cu:425-429, used by LSTMHelper::forward,
+   *  lstm_helper.cu:462): curr_act holds the input layer, the second buffer follows it */
+  __device__ inline float* forward(float* input, float* theta_s, float* curr_act) const
+  {
     float* next_act = curr_act + getBlkSharedSizeBytes() / (2 * (int)sizeof(float));
     const int tdy = (int)__builtin_amdgcn_workitem_id_y();
     const int bdy = (int)__builtin_amdgcn_workgroup_size_y();

@@ -10,7 +10,7 @@ from .capi import (MppiConfig, MppiGaussianParams, MppiStats, MppiSystemStats, S
 from .controllers import (MPPI_CONTROLLER_TUBE, MPPI_CONTROLLER_VANILLA, MPPI_NOISE_INJECTED, MPPI_NOISE_PHILOX_FUSED,
                           MPPIError, MPPIController, TubeMPPIController, VanillaMPPIController, CartpoleDynamicsParams,
                           CartpoleQuadraticCostParams, DoubleIntegratorParams, DoubleIntegratorCircleCostParams,
-                          ARStandardCostParams, fnn_blob_from_npz_dict,
+                          ARStandardCostParams, fnn_blob_from_npz_dict, lstm_blob_from_npz_dict,
                           det_eval, philox_normal, norm_exp, compute_weights, weighted_reduction)
 
 __all__ = [

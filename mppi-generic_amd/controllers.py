@@ -123,6 +123,29 @@ def fnn_blob_from_npz_dict(d, prefix="dynamics_"):
     return np.concatenate(parts).astype(np.float32)
 
 
+def lstm_blob_from_npz_dict(d, prefix=""):
+    """LSTM parameter blob [W_im W_fm W_om W_cm | W_ii W_fi W_oi W_ci | b_i b_f b_o b_c | h0 | c0] from the reference's
+    .npz key layout ({prefix}lstm/weight_hh_l0, weight_ih_l0, bias_hh_l0, bias_ih_l0, float64, PyTorch gate order
+    i, f, g, o; LSTMHelper::loadParams, utils/nn_helpers/lstm_helper.cu:514-578: gates re-ordered to i, f, o, c and the
+    two bias vectors summed).  Optional keys {prefix}lstm/h0, c0 give the initial state (default zeros).
+    Returns (lstm_blob, output_fnn_blob); the output network uses the keys {prefix}output/dynamics_W{i}, _b{i}."""
+    if prefix and not prefix.endswith("/"):
+        prefix += "/"
+    if "model/" + prefix + "lstm/weight_hh_l0" in d:
+        prefix = "model/" + prefix
+    whh = np.asarray(d[prefix + "lstm/weight_hh_l0"], np.float64)
+    wih = np.asarray(d[prefix + "lstm/weight_ih_l0"], np.float64)
+    b = np.asarray(d[prefix + "lstm/bias_hh_l0"], np.float64) + np.asarray(d[prefix + "lstm/bias_ih_l0"], np.float64)
+    H = b.size // 4
+    order = [0, 1, 3, 2]  # blob gate g <- torch gate order[g]  (i, f, o, c  <-  i, f, g(c), o)
+    parts = [whh[g * H:(g + 1) * H].reshape(-1) for g in order]
+    parts += [wih[g * H:(g + 1) * H].reshape(-1) for g in order]
+    parts += [b[g * H:(g + 1) * H] for g in order]
+    parts.append(np.asarray(d.get(prefix + "lstm/h0", np.zeros(H)), np.float64).reshape(-1))
+    parts.append(np.asarray(d.get(prefix + "lstm/c0", np.zeros(H)), np.float64).reshape(-1))
+    return np.concatenate(parts).astype(np.float32), fnn_blob_from_npz_dict(d, prefix + "output/dynamics_")
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

@@ -137,6 +137,14 @@ struct has_fnn_helper<T, std::void_t<decltype(std::declval<T&>().helper_.theta_d
 {
 };
 template <class T, class = void>
+struct has_lstm_helper : std::false_type
+{
+};
+template <class T>
+struct has_lstm_helper<T, std::void_t<decltype(std::declval<T&>().lstm_.weights_d_)>> : std::true_type
+{
+};
+template <class T, class = void>
 struct has_costmap : std::false_type
 {
 };
@@ -194,12 +202,15 @@ struct ModelT : ModelBase
   COST_T cost;
   SAMPLING_T smp;
   float* weights_d = nullptr;
+  float* weights2_d = nullptr;
   float* costmap_d = nullptr;
 
   ~ModelT() override
   {
     if (weights_d)
       (void)hipFree(weights_d);
+    if (weights2_d)
+      (void)hipFree(weights2_d);
     if (costmap_d)
       (void)hipFree(costmap_d);
   }
@@ -240,6 +251,33 @@ struct ModelT : ModelBase
         return st;
       }
     }
+    if constexpr (has_lstm_helper<DYN_T>::value)
+    {
+      if (name == "lstm_weights")
+      {
+        if ((int)count != dyn.lstm_.getNumParams())
+        {
+          err = "lstm_weights: expected " + std::to_string(dyn.lstm_.getNumParams()) + " floats, got " +
+                std::to_string(count);
+          return MPPI_ERR_INVALID_ARG;
+        }
+        mppi_status st = upload(&weights_d, data, count, stream, err);
+        dyn.lstm_.weights_d_ = weights_d;
+        return st;
+      }
+      if (name == "lstm_output_weights")
+      {
+        if ((int)count != dyn.lstm_.output_nn_.NUM_PARAMS)
+        {
+          err = "lstm_output_weights: expected " + std::to_string(dyn.lstm_.output_nn_.NUM_PARAMS) + " floats, got " +
+                std::to_string(count);
+          return MPPI_ERR_INVALID_ARG;
+        }
+        mppi_status st = upload(&weights2_d, data, count, stream, err);
+        dyn.lstm_.output_nn_.theta_d_ = weights2_d;
+        return st;
+      }
+    }
     if constexpr (has_costmap<COST_T>::value)
     {
       if (name == "costmap")
@@ -266,6 +304,12 @@ struct ModelT : ModelBase
       if (!dyn.helper_.theta_d_)
       {
         err = "model needs the 'dynamics_weights' blob (mppi_set_model_blob) before it can run";
+        return false;
+      }
+    if constexpr (has_lstm_helper<DYN_T>::value)
+      if (!dyn.lstm_.weights_d_ || !dyn.lstm_.output_nn_.theta_d_)
+      {
+        err = "model needs the 'lstm_weights' and 'lstm_output_weights' blobs (mppi_set_model_blob) before it can run";
         return false;
       }
     if constexpr (has_costmap<COST_T>::value)

@@ -23,6 +23,7 @@
 #include "mppi_amd/cost_functions/double_integrator/double_integrator_circle_cost.hpp"
 #include "mppi_amd/dynamics/autorally/ar_nn_model.hpp"
 #include "mppi_amd/cost_functions/autorally/ar_standard_cost.hpp"
+#include "mppi_amd/dynamics/bicycle_slip/bicycle_slip_lstm.hpp"
 
 namespace mppi
 {
@@ -48,8 +49,22 @@ using ARModel = ModelT<ARModelDyn, ARStandardCost, ARSampler,
                        /* MFMA forward: BX rollouts x 4 k-group lanes per block (BX/16 waves) */
                        NeuralNetModelMFMA<7, 2, 3>, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>, Shape<64, 4, 2>>>;
 
+/* LSTM bicycle-slip dynamics (BASELINE config 5): LSTM(6, 16) + MLP {22, 32, 4}, AutoRally state layout and cost.
+ * (BX, 4) = MFMA forward with the recurrent state in registers; the other shapes run LSTMHelper's LDS scheme. */
+using BSLSampler = sampling_distributions::GaussianDistribution<BicycleSlipLSTMParams>;
+using BSLModel = ModelT<BicycleSlipLSTM, ARStandardCost, BSLSampler,
+                        Shapes<Shape<16, 8, 1>, Shape<16, 4, 1>, Shape<64, 1, 1>, Shape<8, 16, 1>, Shape<16, 8, 2>>,
+                        /*FIN_BY=*/8, BicycleSlipLSTMMFMA, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>, Shape<64, 4, 2>>>;
+
 inline ModelBase* makeModel(const std::string& name)
 {
+  if (name == "bicycle_slip_lstm")
+  {
+    ModelBase* m = new BSLModel();
+    m->default_bx = 64;
+    m->default_by = 4;
+    return m;
+  }
   if (name == "autorally_nn")
   {
     ModelBase* m = new ARModel();
@@ -66,7 +81,7 @@ inline ModelBase* makeModel(const std::string& name)
 
 inline const char* listModels()
 {
-  return "cartpole\ndouble_integrator\nautorally_nn";
+  return "cartpole\ndouble_integrator\nautorally_nn\nbicycle_slip_lstm";
 }
 
 }  // namespace engine

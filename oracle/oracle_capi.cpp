@@ -60,6 +60,17 @@ int oracle_set_blob(void* h, const char* name, const float* data, size_t count, 
     auto* m = dynamic_cast<ARNeuralNetModel*>(c->dyn.get());
     return m ? m->setWeights(data, count) : -1;
   }
+  if (n == "lstm_weights" || n == "lstm_output_weights")
+  {
+    auto* m = dynamic_cast<BicycleSlipLSTM*>(c->dyn.get());
+    if (!m)
+      return -1;
+    std::vector<float>& dst = (n == "lstm_weights") ? m->net.w : m->net.out_net.theta;
+    if (count != dst.size())
+      return -1;
+    std::copy(data, data + count, dst.begin());
+    return 0;
+  }
   if (n == "costmap")
   {
     auto* m = dynamic_cast<ARStandardCost*>(c->cost.get());
@@ -75,6 +86,20 @@ void oracle_fnn_forward(const int* layers, int nl, const float* theta, const flo
   std::copy(theta, theta + net.numParams(), net.theta.begin());
   net.forward(in, out);
 }
+/** `steps` LSTM forwards on the host from (h0, c0) of the blob with a constant input (known-answer tests):
+ *  out [steps][output dim] */
+void oracle_lstm_forward(int input_dim, int hidden_dim, const int* out_layers, int nl, const float* lstm_blob,
+                         const float* fnn_blob, const float* in, int steps, float* out)
+{
+  LSTM net;
+  net.setStructure(input_dim, hidden_dim, std::vector<int>(out_layers, out_layers + nl));
+  std::copy(lstm_blob, lstm_blob + net.numParams(), net.w.begin());
+  std::copy(fnn_blob, fnn_blob + net.out_net.numParams(), net.out_net.theta.begin());
+  std::vector<float> h(net.h0(), net.h0() + hidden_dim), c(net.c0(), net.c0() + hidden_dim);
+  const int od = out_layers[nl - 1];
+  for (int t = 0; t < steps; t++)
+    net.forward(in + (size_t)t * input_dim, h.data(), c.data(), out + (size_t)t * od);
+}
 /** xdot = f(x, u) of the handle's model (kinematics + dynamics), for plugin-level known-answer tests */
 void oracle_state_deriv(void* h, const float* x, const float* u, float* xdot)
 {
@@ -82,6 +107,8 @@ void oracle_state_deriv(void* h, const float* x, const float* u, float* xdot)
   std::vector<float> th(std::max(1, c->dyn->scratchFloats()), 0.0f);
   for (int i = 0; i < c->dyn->S; i++)
     xdot[i] = 0.0f;
+  std::vector<float> y0(c->dyn->O, 0.0f);
+  c->dyn->initializeDynamics(x, u, y0.data(), th.data(), 0.0f, 0.0f);
   c->dyn->computeKinematics(x, xdot);
   c->dyn->computeDynamics(x, u, xdot, th.data());
 }
@@ -200,6 +227,7 @@ void oracle_model_step(void* h, float* x, float* u, float dt)
   auto* c = (Controller*)h;
   const int S = c->dyn->S, O = c->dyn->O;
   std::vector<float> xn(S), xdot(S, 0.0f), y(O, 0.0f), th(std::max(1, c->dyn->scratchFloats()), 0.0f);
+  c->dyn->initializeDynamics(x, u, y.data(), th.data(), 0.0f, dt);
   c->dyn->enforceConstraints(x, u);
   c->dyn->step(x, xn.data(), xdot.data(), u, y.data(), th.data(), 0, dt);
   for (int i = 0; i < S; i++)

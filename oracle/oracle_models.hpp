@@ -238,6 +238,147 @@ struct ARNeuralNetModel : Dynamics
   }
 };
 
+/* ------------------------------------------------------------------ LSTM bicycle-slip ----------------------------- */
+/**
+ * One-layer LSTM + output network, device flavour of LSTMHelper::forward (utils/nn_helpers/lstm_helper.cu:342-463).
+ * Blob [W_im W_fm W_om W_cm (H x H) | W_ii W_fi W_oi W_ci (H x I) | b_i b_f b_o b_c | h0 | c0] (lstm_helper.cu:71-88).
+ * Per unit i: g = 0; x part (j ascending), then h part (j ascending) as fma chains (nvcc contracts the reference's
+ * `temp += W * x`), g += b;  sigmoid = device flavour (activation_functions.cuh:49-59);
+ * c[i] = g_i * tanh(g_c) + g_f * c[i] (two roundings for the products, one for the sum), then h[i] = tanh(c[i]) * g_o[i]
+ * with the NEW cell state (lstm_helper.cu:450); output = FNN([h ; x]) (lstm_helper.cu:455-462).
+ */
+struct LSTM
+{
+  int I = 0, H = 0;
+  FNN out_net;
+  std::vector<float> w; /* 4HH + 4HI + 4H + 2H */
+  void setStructure(int input_dim, int hidden_dim, const std::vector<int>& output_layers)
+  {
+    I = input_dim;
+    H = hidden_dim;
+    out_net.setStructure(output_layers);
+    w.assign((size_t)4 * H * H + 4 * H * I + 6 * H, 0.0f);
+  }
+  size_t numParams() const
+  {
+    return w.size();
+  }
+  const float* h0() const
+  {
+    return &w[(size_t)4 * H * H + 4 * H * I + 4 * H];
+  }
+  const float* c0() const
+  {
+    return h0() + H;
+  }
+  /** h, c: in/out [H];  out: [output dim] */
+  void forward(const float* x, float* h, float* c, float* out) const
+  {
+    const float* W_im = w.data();
+    const float* W_fm = W_im + H * H;
+    const float* W_om = W_fm + H * H;
+    const float* W_cm = W_om + H * H;
+    const float* W_ii = W_cm + H * H;
+    const float* W_fi = W_ii + H * I;
+    const float* W_oi = W_fi + H * I;
+    const float* W_ci = W_oi + H * I;
+    const float* b_i = W_ci + H * I;
+    const float* b_f = b_i + H;
+    const float* b_o = b_f + H;
+    const float* b_c = b_o + H;
+    std::vector<float> g_o(H), c_new(H);
+    for (int i = 0; i < H; i++)
+    {
+      float gi = 0.0f, gf = 0.0f, go = 0.0f, gc = 0.0f;
+      for (int j = 0; j < I; j++)
+      {
+        gi = det::fma(W_ii[i * I + j], x[j], gi);
+        gf = det::fma(W_fi[i * I + j], x[j], gf);
+        go = det::fma(W_oi[i * I + j], x[j], go);
+        gc = det::fma(W_ci[i * I + j], x[j], gc);
+      }
+      for (int j = 0; j < H; j++)
+      {
+        gi = det::fma(W_im[i * H + j], h[j], gi);
+        gf = det::fma(W_fm[i * H + j], h[j], gf);
+        go = det::fma(W_om[i * H + j], h[j], go);
+        gc = det::fma(W_cm[i * H + j], h[j], gc);
+      }
+      gi += b_i[i];
+      gf += b_f[i];
+      go += b_o[i];
+      gc += b_c[i];
+      gi = det::sigmoid(gi);
+      gf = det::sigmoid(gf);
+      gc = det::tanh(gc);
+      g_o[i] = det::sigmoid(go);
+      const float in_part = gi * gc;
+      const float keep_part = gf * c[i];
+      c_new[i] = in_part + keep_part;
+    }
+    std::vector<float> act((size_t)H + I);
+    for (int i = 0; i < H; i++)
+    {
+      c[i] = c_new[i];
+      h[i] = det::tanh(c[i]) * g_o[i];
+      act[i] = h[i];
+    }
+    for (int j = 0; j < I; j++)
+      act[(size_t)H + j] = x[j];
+    out_net.forward(act.data(), out);
+  }
+};
+
+/**
+ * LSTM bicycle-slip dynamics (BASELINE config 5; see include/mppi_amd/dynamics/bicycle_slip/bicycle_slip_lstm.hpp for
+ * why this model is assembled from ar_nn_model.cu:122-178 and racer_dubins_elevation_lstm_steering.cu:117-167).
+ * theta_s slot = [h (16) | c (16)], seeded from the blob's (h0, c0) by initializeDynamics.
+ */
+struct BicycleSlipLSTM : Dynamics
+{
+  LSTM net;
+  BicycleSlipLSTM() : Dynamics(7, 2, 8)
+  {
+    net.setStructure(6, 16, { 22, 32, 4 });
+  }
+  int setParams(const void* pod, size_t n) override
+  {
+    return n == 0 ? 0 : -1;
+  }
+  int scratchFloats() const override
+  {
+    return 2 * net.H;
+  }
+  void initializeDynamics(const float* x, const float* u, float* y, float* theta_s, float t0, float dt) override
+  {
+    Dynamics::initializeDynamics(x, u, y, theta_s, t0, dt);
+    for (int i = 0; i < net.H; i++)
+    {
+      theta_s[i] = net.h0()[i];
+      theta_s[net.H + i] = net.c0()[i];
+    }
+  }
+  void computeKinematics(const float* state, float* state_der) override
+  {
+    float s, c;
+    det::sincos(state[2], &s, &c);
+    state_der[0] = c * state[4] - s * state[5];
+    state_der[1] = s * state[4] + c * state[5];
+    state_der[2] = -state[6];
+  }
+  void computeDynamics(const float* state, const float* control, float* state_der, float* theta_s) override
+  {
+    float in[6], out[4];
+    for (int i = 0; i < 4; i++)
+      in[i] = state[i + 3];
+    in[4] = control[0];
+    in[5] = control[1];
+    net.forward(in, theta_s, theta_s + net.H, out);
+    for (int i = 0; i < 4; i++)
+      state_der[i + 3] = out[i];
+  }
+};
+
 /** reference: cost_functions/autorally/ar_standard_cost.cu:224-243, 283-413 (device flavour) */
 struct ARStandardCost : Cost
 {
@@ -331,6 +472,12 @@ struct ARStandardCost : Cost
 
 inline bool makeModel(const std::string& name, std::unique_ptr<Dynamics>& dyn, std::unique_ptr<Cost>& cost)
 {
+  if (name == "bicycle_slip_lstm")
+  {
+    dyn.reset(new BicycleSlipLSTM());
+    cost.reset(new ARStandardCost());
+    return true;
+  }
   if (name == "autorally_nn")
   {
     dyn.reset(new ARNeuralNetModel());

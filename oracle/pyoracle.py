@@ -39,6 +39,8 @@ def lib():
         L.oracle_set_cost_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_set_blob.argtypes = [C.c_void_p, C.c_char_p, _f32p, C.c_size_t, C.POINTER(C.c_int), C.c_int]
         L.oracle_fnn_forward.argtypes = [C.POINTER(C.c_int), C.c_int, _f32p, _f32p, _f32p]
+        L.oracle_lstm_forward.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _f32p, _f32p, _f32p, C.c_int,
+                                          _f32p]
         L.oracle_state_deriv.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
         L.oracle_state_cost.restype = C.c_float
         L.oracle_state_cost.argtypes = [C.c_void_p, _f32p, C.c_int, C.POINTER(C.c_int)]
@@ -239,6 +241,17 @@ def fnn_forward(layers, theta, x):
     arr = (C.c_int * len(layers))(*layers)
     out = np.zeros(layers[-1], np.float32)
     lib().oracle_fnn_forward(arr, len(layers), _f32(theta).reshape(-1), _f32(x).reshape(-1), out)
+    return out
+
+
+def lstm_forward(input_dim, hidden_dim, out_layers, lstm_blob, fnn_blob, inputs):
+    """inputs [steps][input_dim] -> outputs [steps][out_layers[-1]], state carried from the blob's (h0, c0)"""
+    out_layers = list(out_layers)
+    arr = (C.c_int * len(out_layers))(*out_layers)
+    x = _f32(inputs).reshape(-1, input_dim)
+    out = np.zeros((x.shape[0], out_layers[-1]), np.float32)
+    lib().oracle_lstm_forward(input_dim, hidden_dim, arr, len(out_layers), _f32(lstm_blob).reshape(-1),
+                              _f32(fnn_blob).reshape(-1), x, x.shape[0], out)
     return out
 
 

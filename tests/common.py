@@ -70,6 +70,37 @@ def autorally_cfg(K=1024, T=50, lambda_=20.0, num_iters=1):
                 blobs={"dynamics_weights": m.fnn_blob_from_npz_dict(npz), "costmap": cmap})
 
 
+def lstm_npz(seed=SEED, scale=0.3, I=6, H=16, M=32, OUT=4):
+    """synthetic network in the reference's LSTM .npz key layout (float64, PyTorch gate order; lstm_helper.cu:514-585)"""
+    rng = np.random.default_rng(seed)
+    d = {
+        "lstm/weight_hh_l0": rng.uniform(-scale, scale, (4 * H, H)),
+        "lstm/weight_ih_l0": rng.uniform(-scale, scale, (4 * H, I)),
+        "lstm/bias_hh_l0": rng.uniform(-scale, scale, 4 * H),
+        "lstm/bias_ih_l0": rng.uniform(-scale, scale, 4 * H),
+        "lstm/h0": rng.uniform(-0.5, 0.5, H),
+        "lstm/c0": rng.uniform(-0.5, 0.5, H),
+        "output/dynamics_W1": rng.uniform(-scale, scale, (M, H + I)),
+        "output/dynamics_b1": rng.uniform(-scale, scale, M),
+        "output/dynamics_W2": rng.uniform(-scale, scale, (OUT, M)),
+        "output/dynamics_b2": rng.uniform(-scale, scale, OUT),
+    }
+    return d
+
+
+def bicycle_lstm_cfg(K=1024, T=50, lambda_=20.0, num_iters=1):
+    """SURVEY.md §8d config 5 at test size: LSTM bicycle-slip dynamics (LSTM(6,16) + MLP {22,32,4}, synthetic weights in
+    the reference's LSTM key layout) + ARStandardCost on the generated standard track map."""
+    lstm_blob, fnn_blob = m.lstm_blob_from_npz_dict(lstm_npz())
+    cmap, (x0b, x1b, y0b, y1b) = standard_track_map()
+    cost = m.ARStandardCostParams()
+    cost.setTransformFromBounds(x0b, x1b, y0b, y1b)
+    return dict(model="bicycle_slip_lstm", K=K, T=T, D=1, dt=0.02, lambda_=lambda_, alpha=0.0, num_iters=num_iters,
+                dyn=None, cost=cost, ranges=[[-0.99, 0.99], [-0.99, 0.65]], std_dev=[0.3, 0.3],
+                control_cost_coeff=[0.0, 0.0], x0=np.array([-12.0, 5.0, 0.0, 0.0, 4.0, 0.0, 0.0], np.float32),
+                blobs={"lstm_weights": lstm_blob, "lstm_output_weights": fnn_blob, "costmap": cmap})
+
+
 def make_engine(cfg, tube=None, **kw):
     tube = (cfg["D"] == 2) if tube is None else tube
     cls = m.TubeMPPIController if tube else m.VanillaMPPIController
