@@ -58,7 +58,8 @@ typedef enum mppi_controller_kind
   MPPI_CONTROLLER_VANILLA = 0, /* controllers/MPPI/mppi_controller.cu:151-241 */
   MPPI_CONTROLLER_TUBE = 1,    /* controllers/Tube-MPPI/tube_mppi_controller.cu:157-299 (two systems per launch) */
   MPPI_CONTROLLER_ROBUST = 2,  /* controllers/R-MPPI/robust_mppi_controller.cu:635-755 */
-  MPPI_CONTROLLER_COLORED = 3  /* controllers/ColoredMPPI (vanilla loop + colored-noise sampler) */
+  MPPI_CONTROLLER_COLORED = 3  /* controllers/ColoredMPPI/colored_mppi_controller.cu:134-240: the vanilla loop with the
+                                  colored-noise sampler; after smoothing only control channel 1 is clamped (:232-237) */
 } mppi_controller_kind;
 
 /** where eps ~ N(0,1) comes from (reference: curandGenerateNormal, sampling_distributions/gaussian/gaussian.cu:380-394) */
@@ -159,6 +160,10 @@ mppi_status mppi_set_dynamics_params(mppi_handle h, const void* pod, size_t nbyt
 mppi_status mppi_set_cost_params(mppi_handle h, const void* pod, size_t nbytes);
 /** SamplingDistribution::setParams (sampling_distributions/sampling_distribution.cuh:93-116) */
 mppi_status mppi_set_sampler_params(mppi_handle h, const mppi_gaussian_params* p);
+/** ColoredNoiseParamsImpl (sampling_distributions/colored_noise/colored_noise.cuh:45-73): exponents[C] (0 = white),
+ *  offset_decay_rate, fmin.  Only for handles created with MPPI_CONTROLLER_COLORED; std_dev etc. come from
+ *  mppi_set_sampler_params as for the Gaussian sampler (ColoredNoiseParams extends GaussianParams). */
+mppi_status mppi_set_colored_noise_params(mppi_handle h, const float* exponents, float offset_decay_rate, float fmin);
 /** Dynamics::setControlRanges (dynamics/dynamics.cu:19-36); lo_hi = [C][2] */
 mppi_status mppi_set_control_ranges(mppi_handle h, const float* lo_hi);
 /** Dynamics::setControlDeadbands (dynamics/dynamics.cu:38-55) */
@@ -187,8 +192,18 @@ mppi_status mppi_set_seed(mppi_handle h, uint64_t seed);
 /** updateImportanceSampler / init_control_traj_ (controllers/controller.cuh:330-349): u[T][C] */
 mppi_status mppi_set_nominal_control(mppi_handle h, const float* u);
 /**
+ * The raw noise eps[K_local][T][C] (before the mean / std-dev rule of setGaussianControls) that the next iteration
+ * would use with this optimization_stride — for colored noise the output of powerlaw_psd_gaussian's pipeline
+ * (colored_noise.cu:58-191: spectrum shaping, inverse real DFT, offset removal, normalisation).  Generator tests only;
+ * the rollout never materialises this tensor.  Not available for the in-loop Philox draw of the Gaussian sampler
+ * (use mppi_philox_normal for that stream).
+ */
+mppi_status mppi_sample_noise(mppi_handle h, int optimization_stride, float* eps_out);
+/**
  * Parity / replay mode: eps[n_iters][K_local][T][C] replaces the generator for the next mppi_compute_control calls
- * (iteration i of a call uses slab i % n_iters).  Switches the handle to MPPI_NOISE_INJECTED.  n_iters == 0 switches
+ * (iteration i of a call uses slab i % n_iters).  MPPI_CONTROLLER_COLORED handles take the Gaussian SPECTRUM instead, in
+ * the layout of the reference's samples_in_freq_complex_d_: z[n_iters][K_local][C][T+1][2] (colored_noise.cu:343).
+ * Switches the handle to MPPI_NOISE_INJECTED.  n_iters == 0 switches
  * back to the configured generator.  (No reference equivalent: the reference never pins its noise)
  */
 mppi_status mppi_inject_noise(mppi_handle h, const float* eps, int n_iters);

@@ -79,6 +79,8 @@ public:
   static const int CONTROL_DIM = E_INDEX(DYN_PARAMS_T::ControlIndex, NUM_CONTROLS);
   typedef GaussianParamsImpl<CONTROL_DIM, 2> SAMPLING_PARAMS_T;
   typedef GaussianDistribution<DYN_PARAMS_T> SAMPLING_T;
+  static constexpr bool IN_LOOP_DRAW = true;  ///< single-lane rollouts may draw eps inside the step loop
+  static constexpr bool COLORED = false;
 
   SAMPLING_PARAMS_T params_;
 

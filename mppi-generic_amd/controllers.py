@@ -13,6 +13,8 @@ from .capi import MppiConfig, MppiGaussianParams, MppiStats, load_library
 
 MPPI_CONTROLLER_VANILLA = 0
 MPPI_CONTROLLER_TUBE = 1
+MPPI_CONTROLLER_ROBUST = 2
+MPPI_CONTROLLER_COLORED = 3
 MPPI_NOISE_PHILOX_FUSED = 0
 MPPI_NOISE_INJECTED = 1
 MPPI_NOISE_ROCRAND_HOST = 2
@@ -252,10 +254,19 @@ class MPPIController:
             self._check(self._lib.mppi_inject_noise(self._h, None, 0))
             return
         eps = _f32(eps)
-        if eps.ndim == 3:
+        if eps.ndim == len(self._noise_shape()):
             eps = eps[None]
-        assert eps.shape[1:] == (self.num_rollouts_local, self.num_timesteps, self.CONTROL_DIM), eps.shape
+        assert eps.shape[1:] == self._noise_shape(), (eps.shape, self._noise_shape())
         self._check(self._lib.mppi_inject_noise(self._h, eps.ctypes.data, eps.shape[0]))
+
+    def _noise_shape(self):
+        return (self.num_rollouts_local, self.num_timesteps, self.CONTROL_DIM)
+
+    def sampleNoise(self, optimization_stride=1):
+        """raw eps[K_local][T][C] of the next iteration (generator tests; see mppi_sample_noise)"""
+        eps = np.empty((self.num_rollouts_local, self.num_timesteps, self.CONTROL_DIM), np.float32)
+        self._check(self._lib.mppi_sample_noise(self._h, optimization_stride, eps))
+        return eps
 
     def computeControl(self, state, optimization_stride=1):
         self._check(self._lib.mppi_compute_control(self._h, _f32(state).reshape(-1), optimization_stride))
@@ -347,6 +358,19 @@ class MPPIController:
 class VanillaMPPIController(MPPIController):
     """reference: controllers/MPPI/mppi_controller.cuh — VanillaMPPIController"""
     KIND = MPPI_CONTROLLER_VANILLA
+
+
+class ColoredMPPIController(MPPIController):
+    """reference: controllers/ColoredMPPI/colored_mppi_controller.cuh — ColoredMPPIController with
+    ColoredNoiseDistribution (sampling_distributions/colored_noise/colored_noise.cuh)"""
+    KIND = MPPI_CONTROLLER_COLORED
+
+    def setColoredNoiseParams(self, exponents, offset_decay_rate=0.97, fmin=0.0):
+        self._check(self._lib.mppi_set_colored_noise_params(self._h, _f32(exponents).reshape(-1), offset_decay_rate, fmin))
+
+    def _noise_shape(self):
+        """spectrum noise, the reference's samples_in_freq_complex_d_ layout: [K][C][T+1][2]"""
+        return (self.num_rollouts_local, self.CONTROL_DIM, self.num_timesteps + 1, 2)
 
 
 class TubeMPPIController(MPPIController):

@@ -62,6 +62,7 @@ struct mppi_handle_s
   float* step_x_d = nullptr;       // [S]
   float* step_u_d = nullptr;       // [C]
   int n_eps_iters = 0;
+  size_t noise_floats = 0;         // injected-noise floats per rollout (T*C, or C*(2T+2) spectrum entries when colored)
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
 
   /* host state (the reference's control_, control_history_, state_, nominal_* members) */
@@ -194,13 +195,17 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   h->cfg.world_size = world;
   h->model_name = cfg->model;
   h->cfg.model = h->model_name.c_str();
-  h->model.reset(makeModel(h->model_name));
+  const bool colored = cfg->controller == MPPI_CONTROLLER_COLORED;
+  h->model.reset(makeModel(h->model_name, colored));
+  if (!h->model && colored && makeModel(h->model_name, false))
+    return fail(nullptr, MPPI_ERR_UNSUPPORTED, "mppi_create: model '" + h->model_name + "' has no colored-noise instantiation");
   if (!h->model)
     return fail(nullptr, MPPI_ERR_UNKNOWN_MODEL, "mppi_create: model '" + h->model_name + "' is not registered; have:\n" + listModels());
   mppi_handle hp = h.get();
   switch (cfg->controller)
   {
     case MPPI_CONTROLLER_VANILLA: h->D = 1; break;
+    case MPPI_CONTROLLER_COLORED: h->D = 1; break;
     case MPPI_CONTROLLER_TUBE: h->D = 2; break;
     default:
       return fail(nullptr, MPPI_ERR_UNSUPPORTED, "mppi_create: controller kind not available in this build");
@@ -237,6 +242,7 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   h->TC = cfg->num_timesteps * h->C;
   h->PS = kernels::partialStride(cfg->num_timesteps, h->C);
   h->noise_source = cfg->noise_source;
+  h->noise_floats = h->model->noiseFloatsPerRollout(cfg->num_timesteps);
   if (h->noise_source == MPPI_NOISE_ROCRAND_HOST)
     return fail(nullptr, MPPI_ERR_UNSUPPORTED, "mppi_create: MPPI_NOISE_ROCRAND_HOST is not available in this build");
 
@@ -361,6 +367,19 @@ mppi_status mppi_set_sampler_params(mppi_handle h, const mppi_gaussian_params* p
   h->model->setSamplerParams(p, h->D);
   return MPPI_OK;
 }
+mppi_status mppi_set_colored_noise_params(mppi_handle h, const float* exponents, float offset_decay_rate, float fmin)
+{
+  CHECK_HANDLE(h);
+  if (!exponents)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_colored_noise_params: null");
+  for (int i = 0; i < h->C; i++)
+    if (!(exponents[i] >= 0.0f))
+      return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_colored_noise_params: exponents must be >= 0");
+  if (!(fmin >= 0.0f) || !(offset_decay_rate >= 0.0f))
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_colored_noise_params: fmin and offset_decay_rate must be >= 0");
+  mppi_status s = h->model->setColoredNoiseParams(exponents, offset_decay_rate, fmin);
+  return s == MPPI_OK ? s : fail(h, s, "mppi_set_colored_noise_params: the handle's sampler is Gaussian (create it with MPPI_CONTROLLER_COLORED)");
+}
 mppi_status mppi_set_control_ranges(mppi_handle h, const float* lo_hi)
 {
   CHECK_HANDLE(h);
@@ -482,7 +501,7 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   {
     if (!h->eps_d || h->n_eps_iters <= 0)
       return fail(h, MPPI_ERR_STATE, "noise source is MPPI_NOISE_INJECTED but no noise has been injected");
-    s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * h->K_local * h->TC;
+    s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * h->K_local * h->noise_floats;
   }
   s.control_samples_d = h->samples_d;
   s.seed = h->cfg.seed;
@@ -594,6 +613,8 @@ static mppi_status finalize(mppi_handle h, const float* ctrl_in_d, int smooth_ma
   a.num_timesteps = T;
   a.smooth_mask = smooth_mask;
   a.constrain_mask = constrain_mask;
+  // ColoredMPPI clamps only control channel 1 after smoothing (colored_mppi_controller.cu:232-237)
+  a.constrain_mode = h->cfg.controller == MPPI_CONTROLLER_COLORED ? 1 : 0;
   std::string err;
   mppi_status st = h->model->launchFinalize(h->D, a, h->stream, err);
   if (st != MPPI_OK)
@@ -632,7 +653,7 @@ mppi_status mppi_inject_noise(mppi_handle h, const float* eps, int n_iters)
     h->noise_source = h->cfg.noise_source == MPPI_NOISE_INJECTED ? MPPI_NOISE_PHILOX_FUSED : h->cfg.noise_source;
     return MPPI_OK;
   }
-  const size_t n = (size_t)n_iters * h->K_local * h->TC;
+  const size_t n = (size_t)n_iters * h->K_local * h->noise_floats;
   if (n_iters != h->n_eps_iters)
   {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -874,6 +895,51 @@ mppi_status mppi_get_sampled_controls(mppi_handle h, float* v)
   HIP_TRY(h, hipMemcpyAsync(v, h->samples_d, sizeof(float) * h->D * h->K_local * h->TC, hipMemcpyDeviceToHost,
                             h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+mppi_status mppi_sample_noise(mppi_handle h, int optimization_stride, float* eps_out)
+{
+  CHECK_HANDLE(h);
+  if (!eps_out || optimization_stride < 0)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_sample_noise: bad arguments");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  SamplerLaunchState s{};
+  s.num_rollouts_local = h->K_local;
+  s.num_rollouts_global = h->cfg.num_rollouts;
+  s.rollout_offset = h->K_offset;
+  s.num_timesteps = h->cfg.num_timesteps;
+  s.num_distributions = 1;
+  s.control_means_d = h->mean_d;
+  s.eps_d = nullptr;
+  if (h->noise_source == MPPI_NOISE_INJECTED)
+  {
+    if (!h->eps_d || h->n_eps_iters <= 0)
+      return fail(h, MPPI_ERR_STATE, "noise source is MPPI_NOISE_INJECTED but no noise has been injected");
+    s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * h->K_local * h->noise_floats;
+  }
+  s.control_samples_d = nullptr;
+  s.seed = h->cfg.seed;
+  s.generation = h->generation;
+  s.iteration = 0;
+  s.optimization_stride = optimization_stride;
+  const size_t n = (size_t)h->K_local * h->TC;
+  float* out_d = nullptr;
+  HIP_TRY(h, hipMalloc((void**)&out_d, n * sizeof(float)));
+  std::string err;
+  mppi_status st = h->model->launchNoiseDump(s, out_d, h->stream, err);
+  hipError_t e = hipSuccess;
+  if (st == MPPI_OK)
+  {
+    e = hipMemcpyAsync(eps_out, out_d, n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(h->stream);
+  }
+  (void)hipFree(out_d);
+  if (st != MPPI_OK)
+    return fail(h, st, err);
+  if (e != hipSuccess)
+    return fail(h, MPPI_ERR_HIP, std::string("mppi_sample_noise: ") + hipGetErrorString(e));
   return MPPI_OK;
 }
 

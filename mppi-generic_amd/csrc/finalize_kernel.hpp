@@ -33,6 +33,9 @@ struct FinalizeArgs
   int num_timesteps;
   int smooth_mask;            ///< bit z set: smooth system z
   int constrain_mask;         ///< bit z set: enforceConstraints on every column of system z's control
+  int constrain_mode;         ///< 0: Dynamics::enforceConstraints (mppi_controller.cu:227-231);
+                              ///< 1: ColoredMPPI — only control channel 1 is clamped to its range, no deadband
+                              ///<    (controllers/ColoredMPPI/colored_mppi_controller.cu:232-237)
 };
 
 template <class DYN_T>
@@ -137,9 +140,18 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
   // enforceConstraints on every column of the control (mppi_controller.cu:227-231)
   if ((a.constrain_mask >> z) & 1)
   {
-    for (int t = 0; t < T; t++)
+    if (a.constrain_mode == 1)
     {
-      dynamics->enforceConstraints(zero_state, &ctrl[t * C]);
+      if constexpr (C > 1)
+        for (int t = ty; t < T; t += BY)
+          ctrl[t * C + 1] = fminf(fmaxf(ctrl[t * C + 1], dynamics->control_rngs_[1].x), dynamics->control_rngs_[1].y);
+    }
+    else
+    {
+      for (int t = 0; t < T; t++)
+      {
+        dynamics->enforceConstraints(zero_state, &ctrl[t * C]);
+      }
     }
   }
   __syncthreads();

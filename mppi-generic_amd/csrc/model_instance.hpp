@@ -14,12 +14,14 @@
 #include <string>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 #include "mppi_amd.h"
 #include "rollout_kernel.hpp"
 #include "reduce_kernels.hpp"
 #include "finalize_kernel.hpp"
 #include "rollout_pipeline_kernel.hpp"
+#include "mppi_amd/sampling_distributions/colored_noise.hpp"
 
 namespace mppi
 {
@@ -68,6 +70,15 @@ struct ModelBase
     err = "model has no blob named '" + name + "'";
     return MPPI_ERR_INVALID_ARG;
   }
+  /** colored-noise sampler parameters (ColoredNoiseParamsImpl, colored_noise.cuh:45-73); default: Gaussian sampler */
+  virtual mppi_status setColoredNoiseParams(const float* exponents, float offset_decay_rate, float fmin)
+  {
+    return MPPI_ERR_STATE;
+  }
+  /** floats of injected noise per rollout: T*C time-domain eps, or C*(2T+2) spectrum entries for colored noise */
+  virtual size_t noiseFloatsPerRollout(int T) const = 0;
+  /** the sampled noise eps[K_local][T][C] the next launch would use, written to out_d (generator parity tests) */
+  virtual mppi_status launchNoiseDump(const SamplerLaunchState& s, float* out_d, hipStream_t stream, std::string& err) = 0;
   virtual bool supportsShape(int bx, int by, int bz) const = 0;
   /** role-pipelined variant (rollout_pipeline_kernel.hpp) available for this model? */
   virtual bool supportsPipeline() const
@@ -127,6 +138,33 @@ __global__ void __launch_bounds__(BY) modelStepKernel(DYN_T dynamics_obj, float*
     u_d[i] = u[i];
 }
 
+}  // namespace engine
+namespace kernels
+{
+/** the block's sample rows exactly as the rollout kernels see them after initializeDistributions(): raw eps[k][t][c]
+ *  (pre-filled modes only), block = 64 rollouts x one lane */
+template <class SAMPLING_T>
+__global__ void __launch_bounds__(64) noiseDumpKernel(SAMPLING_T sampling_obj, float* out_d)
+{
+  SAMPLING_T* sampling = &sampling_obj;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* theta_d = reinterpret_cast<float*>(smem_raw);
+  sampling->initializeDistributions(nullptr, 0.0f, 0.0f, theta_d);
+  __syncthreads();
+  const int T = sampling->params_.num_timesteps;
+  const int TC = T * SAMPLING_T::CONTROL_DIM;
+  const int stride = SAMPLING_T::rowStride(T);
+  const int row0 = (int)blockIdx.x * 64;
+  const int nrows = min(64, sampling->params_.num_rollouts - row0);
+  for (int e = (int)threadIdx.x; e < nrows * TC; e += 64)
+  {
+    const int r = e / TC, j = e - r * TC;
+    out_d[(size_t)(row0 + r) * TC + j] = theta_d[r * stride + j];
+  }
+}
+}  // namespace kernels
+namespace engine
+{
 /* detection of optional plugin members */
 template <class T, class = void>
 struct has_fnn_helper : std::false_type
@@ -178,8 +216,8 @@ struct ModelT : ModelBase
         err = "pipeline rollout kernel needs " + std::to_string(smem) + " B of LDS per block; gfx950 has 163840";
         return MPPI_ERR_LDS_OVERFLOW;
       }
-      const bool in_loop = smp.noise_source_ == 0;
-      auto kfn = in_loop ? kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, true>
+      const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
+      auto kfn = in_loop ? kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, SAMPLING_T::IN_LOOP_DRAW>
                          : kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, false>;
       if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -201,12 +239,18 @@ struct ModelT : ModelBase
   DYN_T dyn;
   COST_T cost;
   SAMPLING_T smp;
+  /* colored noise: basis table cache */
+  float* basis_d = nullptr;
+  int basis_T = -1, basis_stride = -1;
+  bool basis_dirty = true;
   float* weights_d = nullptr;
   float* weights2_d = nullptr;
   float* costmap_d = nullptr;
 
   ~ModelT() override
   {
+    if (basis_d)
+      (void)hipFree(basis_d);
     if (weights_d)
       (void)hipFree(weights_d);
     if (weights2_d)
@@ -377,6 +421,92 @@ struct ModelT : ModelBase
     smp.params_.sum_strides = p->sum_strides;
   }
 
+  mppi_status setColoredNoiseParams(const float* exponents, float offset_decay_rate, float fmin) override
+  {
+    if constexpr (SAMPLING_T::COLORED)
+    {
+      for (int i = 0; i < DYN_T::CONTROL_DIM; i++)
+        smp.exponents_[i] = exponents[i];
+      smp.offset_decay_rate_ = offset_decay_rate;
+      smp.fmin_ = fmin;
+      basis_dirty = true;
+      return MPPI_OK;
+    }
+    return MPPI_ERR_STATE;
+  }
+  size_t noiseFloatsPerRollout(int T) const override
+  {
+    if constexpr (SAMPLING_T::COLORED)
+      return (size_t)DYN_T::CONTROL_DIM * sampling_distributions::coloredSpectrumFloats(T);
+    return (size_t)DYN_T::CONTROL_DIM * T;
+  }
+  /** colored noise: (re)build the basis table for this (T, optimization_stride, parameters) and upload it */
+  mppi_status prepBasis(const SamplerLaunchState& s, hipStream_t stream, std::string& err)
+  {
+    if constexpr (SAMPLING_T::COLORED)
+    {
+      if (basis_dirty || basis_T != s.num_timesteps || basis_stride != s.optimization_stride)
+      {
+        std::vector<float> frag;
+        sampling_distributions::buildColoredNoiseBasis(s.num_timesteps, DYN_T::CONTROL_DIM, smp.exponents_,
+                                                       smp.offset_decay_rate_, smp.fmin_, s.optimization_stride, frag);
+        hipError_t e = hipStreamSynchronize(stream);  // earlier launches may still read the old table
+        if (e == hipSuccess && basis_d && basis_T != s.num_timesteps)
+        {
+          e = hipFree(basis_d);
+          basis_d = nullptr;
+        }
+        if (e == hipSuccess && !basis_d)
+          e = hipMalloc((void**)&basis_d, frag.size() * sizeof(float));
+        if (e == hipSuccess)
+          e = hipMemcpyAsync(basis_d, frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess)
+          e = hipStreamSynchronize(stream);  // frag is a local
+        if (e != hipSuccess)
+        {
+          err = std::string("colored-noise basis upload: ") + hipGetErrorString(e);
+          return MPPI_ERR_HIP;
+        }
+        basis_T = s.num_timesteps;
+        basis_stride = s.optimization_stride;
+        basis_dirty = false;
+      }
+      smp.basis_d_ = basis_d;
+    }
+    return MPPI_OK;
+  }
+
+  mppi_status launchNoiseDump(const SamplerLaunchState& s, float* out_d, hipStream_t stream, std::string& err) override
+  {
+    if (SAMPLING_T::IN_LOOP_DRAW && !s.eps_d)
+    {
+      err = "noise dump: this sampler draws inside the step loop; use mppi_philox_normal for its stream";
+      return MPPI_ERR_UNSUPPORTED;
+    }
+    prepSampler(s);
+    mppi_status st = prepBasis(s, stream, err);
+    if (st != MPPI_OK)
+      return st;
+    smp.params_.num_distributions = 1;
+    const size_t smem = calcClassSharedMemSize(&smp, 64);
+    if (smem > MAX_LDS_BYTES)
+    {
+      err = "noise dump kernel LDS overflow";
+      return MPPI_ERR_LDS_OVERFLOW;
+    }
+    auto kfn = kernels::noiseDumpKernel<SAMPLING_T>;
+    if (smem > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(kfn, dim3((s.num_rollouts_local + 63) / 64), dim3(64, 1, 1), smem, stream, smp, out_d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+      err = std::string("noiseDumpKernel launch: ") + hipGetErrorString(e);
+      return MPPI_ERR_HIP;
+    }
+    return MPPI_OK;
+  }
+
   template <int X, int Y, int Z, class... Rest>
   static bool hasShape(Shapes<Shape<X, Y, Z>, Rest...>, int bx, int by, int bz)
   {
@@ -437,8 +567,8 @@ struct ModelT : ModelBase
       err = "rollout kernel needs " + std::to_string(smem) + " B of LDS per block; gfx950 has 163840";
       return MPPI_ERR_LDS_OVERFLOW;
     }
-    const bool in_loop = smp.noise_source_ == 0;
-    auto kfn = in_loop ? kernels::rolloutKernel<FAST, COST_T, SAMPLING_T, X, 1, Z, true>
+    const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
+    auto kfn = in_loop ? kernels::rolloutKernel<FAST, COST_T, SAMPLING_T, X, 1, Z, SAMPLING_T::IN_LOOP_DRAW>
                        : kernels::rolloutKernel<FAST, COST_T, SAMPLING_T, X, 1, Z, false>;
     if (smem > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -480,8 +610,8 @@ struct ModelT : ModelBase
       return MPPI_ERR_LDS_OVERFLOW;
     }
     // in-loop Philox draw needs one lane per rollout; otherwise the rows are pre-filled by initializeDistributions
-    const bool in_loop = (Y == 1) && smp.noise_source_ == 0;
-    auto kfn = in_loop ? kernels::rolloutKernel<DYN_T, COST_T, SAMPLING_T, X, Y, Z, (Y == 1)>
+    const bool in_loop = (Y == 1) && SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
+    auto kfn = in_loop ? kernels::rolloutKernel<DYN_T, COST_T, SAMPLING_T, X, Y, Z, (Y == 1) && SAMPLING_T::IN_LOOP_DRAW>
                        : kernels::rolloutKernel<DYN_T, COST_T, SAMPLING_T, X, Y, Z, false>;
     if (smem > 48 * 1024)
     {
@@ -525,6 +655,11 @@ struct ModelT : ModelBase
     if (!blobsReady(err))
       return MPPI_ERR_STATE;
     prepSampler(s);
+    {
+      mppi_status st = prepBasis(s, stream, err);
+      if (st != MPPI_OK)
+        return st;
+    }
     if (pipeline)
       return bz == 1 ? launchPipeline<1>(args, stream, err) : launchPipeline<2>(args, stream, err);
     if constexpr (!std::is_void<DYN_FAST_T>::value)

@@ -17,6 +17,7 @@
 
 #include "model_instance.hpp"
 #include "mppi_amd/sampling_distributions/gaussian.hpp"
+#include "mppi_amd/sampling_distributions/colored_noise.hpp"
 #include "mppi_amd/dynamics/cartpole/cartpole_dynamics.hpp"
 #include "mppi_amd/cost_functions/cartpole/cartpole_quadratic_cost.hpp"
 #include "mppi_amd/dynamics/double_integrator/di_dynamics.hpp"
@@ -56,8 +57,42 @@ using BSLModel = ModelT<BicycleSlipLSTM, ARStandardCost, BSLSampler,
                         Shapes<Shape<16, 8, 1>, Shape<16, 4, 1>, Shape<64, 1, 1>, Shape<8, 16, 1>, Shape<16, 8, 2>>,
                         /*FIN_BY=*/8, BicycleSlipLSTMMFMA, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>, Shape<64, 4, 2>>>;
 
-inline ModelBase* makeModel(const std::string& name)
+/* ColoredMPPI instantiations (reference: controllers/ColoredMPPI/colored_mppi_controller.cuh with
+ * ColoredNoiseDistribution as SAMPLING_T): the same plugins with the colored-noise sampler. */
+using CartpoleColoredModel =
+    ModelT<CartpoleDynamics, CartpoleQuadraticCost, sampling_distributions::ColoredNoiseDistribution<CartpoleDynamicsParams>,
+           Shapes<Shape<64, 1, 1>, Shape<64, 4, 1>>, /*FIN_BY=*/1, void, Shapes<>, /*PIPELINE=*/true>;
+using DIColoredModel =
+    ModelT<DoubleIntegratorDynamics, DoubleIntegratorCircleCost,
+           sampling_distributions::ColoredNoiseDistribution<DoubleIntegratorParams>, Shapes<Shape<64, 1, 1>>, /*FIN_BY=*/1,
+           void, Shapes<>, /*PIPELINE=*/true>;
+using ARColoredModel = ModelT<ARModelDyn, ARStandardCost, sampling_distributions::ColoredNoiseDistribution<NNDynamicsParams>,
+                              Shapes<Shape<16, 8, 1>>, /*FIN_BY=*/8, NeuralNetModelMFMA<7, 2, 3>,
+                              Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>>>;
+using BSLColoredModel =
+    ModelT<BicycleSlipLSTM, ARStandardCost, sampling_distributions::ColoredNoiseDistribution<BicycleSlipLSTMParams>,
+           Shapes<Shape<16, 8, 1>>, /*FIN_BY=*/8, BicycleSlipLSTMMFMA, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>>>;
+
+inline ModelBase* makeModel(const std::string& name, bool colored = false)
 {
+  if (colored)
+  {
+    ModelBase* m = nullptr;
+    if (name == "cartpole")
+      m = new CartpoleColoredModel();
+    else if (name == "double_integrator")
+      m = new DIColoredModel();
+    else if (name == "autorally_nn")
+      m = new ARColoredModel();
+    else if (name == "bicycle_slip_lstm")
+      m = new BSLColoredModel();
+    if (m && (name == "autorally_nn" || name == "bicycle_slip_lstm"))
+    {
+      m->default_bx = 64;
+      m->default_by = 4;
+    }
+    return m;
+  }
   if (name == "bicycle_slip_lstm")
   {
     ModelBase* m = new BSLModel();

@@ -5,6 +5,7 @@
 #include "oracle_core.hpp"
 #include "oracle_models.hpp"
 #include "oracle_rng.hpp"
+#include "oracle_colored.hpp"
 
 #include <chrono>
 
@@ -304,6 +305,49 @@ void oracle_get_stats(void* h, float* out11)
     out11[8 + d] = c->stats.free_energy_mod[d];
   }
   out11[10] = (float)c->stats.nominal_state_used;
+}
+
+/* ----- colored noise ----- */
+static ColoredNoiseParams coloredParams(int C, const float* exponents, float decay, float fmin)
+{
+  ColoredNoiseParams p;
+  p.exponents.assign(exponents, exponents + C);
+  p.offset_decay_rate = decay;
+  p.fmin = fmin;
+  return p;
+}
+/** flavour 0: definition (double inverse DFT), 1: folded table + fp32 fma chains (the engine's arithmetic) */
+void oracle_colored_noise(int flavour, int K, int T, int C, const float* exponents, float decay, float fmin, int offset_t,
+                          const float* z, float* eps)
+{
+  const ColoredNoiseParams p = coloredParams(C, exponents, decay, fmin);
+  if (flavour == 0)
+    coloredNoiseDefinition(K, T, C, p, offset_t, z, eps);
+  else
+    coloredNoiseGemm(K, T, C, p, offset_t, z, eps);
+}
+void oracle_colored_weights(int T, int C, const float* exponents, float fmin, float* w /*[C][T+1]*/, float* sigma /*[C]*/)
+{
+  std::vector<float> ww, ss;
+  coloredWeights(T, C, coloredParams(C, exponents, 0.0f, fmin), ww, ss);
+  std::copy(ww.begin(), ww.end(), w);
+  std::copy(ss.begin(), ss.end(), sigma);
+}
+void oracle_philox_spectrum(uint64_t seed, uint32_t generation, int T, int C, int k_begin, int k_end, float* z)
+{
+  philoxSpectrum(seed, generation, T, C, k_begin, k_end, z);
+}
+/** ColoredMPPI computeControl; z: [num_iters][K][C][T+1][2] Gaussian spectrum */
+void oracle_colored_compute_control(void* h, const float* x0, int stride, const float* z, const float* exponents,
+                                    float decay, float fmin)
+{
+  auto* c = (Controller*)h;
+  const int C = c->dyn->C, K = c->K, T = c->T;
+  const ColoredNoiseParams p = coloredParams(C, exponents, decay, fmin);
+  std::vector<float> eps((size_t)c->num_iters * K * T * C);
+  for (int it = 0; it < c->num_iters; it++)
+    coloredNoiseGemm(K, T, C, p, stride, z + (size_t)it * K * C * 2 * (T + 1), &eps[(size_t)it * K * T * C]);
+  c->coloredComputeControl(x0, stride, eps.data());
 }
 
 /* ----- RNG ----- */

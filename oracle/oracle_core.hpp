@@ -18,6 +18,8 @@
  *   - smoothing / slide / history / state re-rollout           controllers/controller.cuh:557-615, 643-663
  *   - VanillaMPPIController::computeControl                    controllers/MPPI/mppi_controller.cu:151-241
  *   - TubeMPPIController::computeControl                       controllers/Tube-MPPI/tube_mppi_controller.cu:157-341
+ *   - ColoredMPPIController::computeControl                    controllers/ColoredMPPI/colored_mppi_controller.cu:134-240
+ *   - ColoredNoiseDistribution::generateSamples                oracle_colored.hpp
  *
  * Arithmetic: IEEE fp32 in the reference's expression order, compiled with -ffp-contract=off; transcendentals go
  * through include/mppi_amd/det_math.h (bit-reproducible on host and gfx950, see that header for why).  A rollout is
@@ -574,6 +576,27 @@ struct Controller
     std::vector<float> zero_state(S, 0.0f);
     for (int t = 0; t < T; t++)
       dyn->enforceConstraints(zero_state.data(), &control[(size_t)t * C]);
+  }
+
+  /**
+   * reference: controllers/ColoredMPPI/colored_mppi_controller.cu:134-240 — the vanilla loop (the sampler is the colored
+   * one: eps here is its time-domain output, [num_iters][K][T][C]), then smoothing, state trajectory, and ONLY control
+   * channel 1 clamped to its range (:232-237; the enforceConstraints call is commented out there).
+   */
+  void coloredComputeControl(const float* x0, int stride, const float* eps)
+  {
+    const int C = dyn->C;
+    std::vector<float> u_new((size_t)T * C);
+    for (int it = 0; it < num_iters; it++)
+    {
+      iterate(x0, control.data(), eps + (size_t)it * K * T * C, stride, it, u_new.data());
+      control = u_new;
+    }
+    smoothControlTrajectory(control.data(), control_history.data(), T, C);
+    computeStateTrajectory(*dyn, dt, x0, control.data(), T, state_traj.data());
+    if (C > 1)
+      for (int t = 0; t < T; t++)
+        control[(size_t)t * C + 1] = fminf(fmaxf(control[(size_t)t * C + 1], dyn->rng_lo[1]), dyn->rng_hi[1]);
   }
 
   /** reference: controllers/Tube-MPPI/tube_mppi_controller.cu:157-299.  eps: [num_iters][K][T][C] */

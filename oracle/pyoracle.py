@@ -72,6 +72,11 @@ def lib():
         for n in ("control", "nominal_control", "state_traj", "nominal_state_traj", "costs", "weights", "samples",
                   "stats"):
             getattr(L, "oracle_get_" + n).argtypes = [C.c_void_p, _f32p]
+        L.oracle_colored_noise.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_float, C.c_float, C.c_int,
+                                           _f32p, _f32p]
+        L.oracle_colored_weights.argtypes = [C.c_int, C.c_int, _f32p, C.c_float, _f32p, _f32p]
+        L.oracle_philox_spectrum.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+        L.oracle_colored_compute_control.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, _f32p, C.c_float, C.c_float]
         L.oracle_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
         L.oracle_philox_normal.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, _f32p]
@@ -180,6 +185,11 @@ class Oracle:
     def vanilla_compute_control(self, x0, stride, eps):
         self.L.oracle_vanilla_compute_control(self.h, _f32(x0).reshape(-1), stride, _f32(eps).reshape(-1))
 
+    def colored_compute_control(self, x0, stride, z, exponents, offset_decay_rate=0.97, fmin=0.0):
+        """ColoredMPPI loop; z [num_iters][K][C][T+1][2] Gaussian spectrum"""
+        self.L.oracle_colored_compute_control(self.h, _f32(x0).reshape(-1), stride, _f32(z).reshape(-1),
+                                              _f32(exponents).reshape(-1), offset_decay_rate, fmin)
+
     def tube_compute_control(self, x0, stride, eps):
         self.L.oracle_tube_compute_control(self.h, _f32(x0).reshape(-1), stride, _f32(eps).reshape(-1))
 
@@ -253,6 +263,33 @@ def lstm_forward(input_dim, hidden_dim, out_layers, lstm_blob, fnn_blob, inputs)
     lib().oracle_lstm_forward(input_dim, hidden_dim, arr, len(out_layers), _f32(lstm_blob).reshape(-1),
                               _f32(fnn_blob).reshape(-1), x, x.shape[0], out)
     return out
+
+
+def colored_noise(z, exponents, offset_decay_rate=0.97, fmin=0.0, offset_t=1, flavour="gemm"):
+    """z [K][C][T+1][2] Gaussian spectrum -> eps [K][T][C]; flavour "definition" (double inverse DFT, the reference's
+    pipeline step by step) or "gemm" (folded table + fp32 fma chains: the engine's arithmetic)"""
+    z = _f32(z)
+    K, Cd, F, _ = z.shape
+    T = F - 1
+    eps = np.zeros((K, T, Cd), np.float32)
+    lib().oracle_colored_noise(0 if flavour == "definition" else 1, K, T, Cd, _f32(exponents).reshape(-1),
+                               offset_decay_rate, fmin, offset_t, z.reshape(-1), eps)
+    return eps
+
+
+def colored_weights(T, exponents, fmin=0.0):
+    e = _f32(exponents).reshape(-1)
+    w = np.zeros((e.size, T + 1), np.float32)
+    sigma = np.zeros(e.size, np.float32)
+    lib().oracle_colored_weights(T, e.size, e, fmin, w, sigma)
+    return w, sigma
+
+
+def philox_spectrum(seed, generation, K, T, Cd, k_begin=0, k_end=None):
+    k_end = K if k_end is None else k_end
+    z = np.zeros((k_end - k_begin, Cd, T + 1, 2), np.float32)
+    lib().oracle_philox_spectrum(seed, generation, T, Cd, k_begin, k_end, z)
+    return z
 
 
 def det_eval(func, x):

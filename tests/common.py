@@ -104,6 +104,8 @@ def bicycle_lstm_cfg(K=1024, T=50, lambda_=20.0, num_iters=1):
 def make_engine(cfg, tube=None, **kw):
     tube = (cfg["D"] == 2) if tube is None else tube
     cls = m.TubeMPPIController if tube else m.VanillaMPPIController
+    if cfg.get("colored") is not None:
+        cls = m.ColoredMPPIController
     c = cls(cfg["model"], cfg["K"], cfg["T"], cfg["dt"], cfg["lambda_"], cfg["alpha"], cfg["num_iters"], seed=SEED, **kw)
     if cfg["dyn"] is not None:
         c.setDynamicsParams(cfg["dyn"])
@@ -113,7 +115,15 @@ def make_engine(cfg, tube=None, **kw):
     if cfg["ranges"] is not None:
         c.setControlRanges(cfg["ranges"])
     c.setSamplingParams(cfg["std_dev"], cfg["control_cost_coeff"], cfg.get("pure_pct", 0.01), cfg.get("decay", 1.0))
+    if cfg.get("colored") is not None:
+        c.setColoredNoiseParams(*cfg["colored"])
     return c
+
+
+def host_spectrum(n_iters, K, T, C, seed=SEED):
+    """z[n_iters][K][C][T+1][2] ~ N(0,1): the Gaussian spectrum the colored-noise sampler shapes (reference layout)"""
+    rng = np.random.Generator(np.random.Philox(seed))
+    return rng.standard_normal((n_iters, K, C, T + 1, 2), dtype=np.float32)
 
 
 def make_oracle(cfg):
