@@ -249,11 +249,36 @@ MPPI_HD static inline float log(float x)
 }
 
 /**
+ * p / q for the rational kernels below, where q is known to sit in a benign range (here q in [0.0049, 0.91]) so that no
+ * operand scaling is ever needed.  On the host this is the IEEE division.  On gfx950 the compiler's own expansion of an
+ * fp32 division is v_div_scale x2, v_rcp, 4 fma + 1 mul, v_div_fmas, v_div_fixup; the scale / fixup steps only act on
+ * extreme exponents, so in this range the SAME Newton-Raphson core written out by hand —
+ *     r = rcp(q); e = fma(-q, r, 1); r = fma(e, r, r); y = p r; y = fma(fma(-q, y, p), r, y); y = fma(fma(-q, y, p), r, y)
+ * — returns the same correctly rounded quotient with three instructions fewer, and every step but the seed is an fma
+ * that has a packed two-wide form (v_pk_fma_f32), which tanh2() below uses.
+ * tests/test_gpu_ops.py::test_det_math_device_equals_host_bitwise checks device == host bit for bit.
+ */
+MPPI_HD static inline float div_benign(float p, float q)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r = __builtin_amdgcn_rcpf(q);
+  const float e = fma(-q, r, 1.0f);
+  r = fma(e, r, r);
+  float y = p * r;
+  y = fma(fma(-q, y, p), r, y);
+  y = fma(fma(-q, y, p), r, y);
+  return y;
+#else
+  return p / q;
+#endif
+}
+
+/**
  * tanh(x), branch-free: clamp to +-7.9053 (tanh rounds to +-1 in fp32 beyond), then the odd rational minimax
  * x * P6(x^2) / Q3(x^2) with the coefficient set of Eigen's generic_fast_tanh_float (MathFunctionsImpl.h, MPL2), one
- * correctly rounded division.  ~25 instructions and no divergent control flow — the NN dynamics evaluate 64 of these per
- * rollout and step, and a two-branch exp-based form costs both branches on a SIMD machine.
- * Accuracy: <= 7 ulp (4e-7 absolute) against float64 tanh; exactly 0 at 0 and exactly +-1 for |x| >= 7.9053.
+ * correctly rounded division.  No divergent control flow — the NN dynamics evaluate 64 of these per rollout and step,
+ * and a two-branch exp-based form costs both branches on a SIMD machine.
+ * Accuracy: <= 7 ulp (4e-7 absolute) against float64 tanh; tanh(x) = x exactly for |x| < 2^-13; +-1 for |x| >= 7.9053.
  */
 MPPI_HD static inline float tanh(float x)
 {
@@ -269,14 +294,82 @@ MPPI_HD static inline float tanh(float x)
   float q = fma(x2, 1.19825839466702e-06f, 1.18534705686654e-04f);
   q = fma(x2, q, 2.26843463243900e-03f);
   q = fma(x2, q, 4.89352518554385e-03f);
-  const float r = p / q;
-  return (x != x) ? x : r;
+  const float r = div_benign(p, q);
+  /* |x| < 2^-13: tanh(x) = x to the last bit (x^3/3 is below half an ulp) — also keeps -0, subnormals and NaN intact
+   * (the comparison is false for NaN) and keeps div_benign's numerator away from the subnormal range */
+  return (fabs(x) >= 1.220703125e-4f) ? r : x;
+}
+
+/**
+ * Two tanh at once: the same operations as tanh() on each argument (so the results are bit-identical to two scalar
+ * calls), arranged as two-wide vectors so that gfx950 issues them as packed fp32 instructions (v_pk_mul_f32 /
+ * v_pk_fma_f32: two lanes' worth of work per issue slot).  The NN dynamics spend most of their VALU time here.
+ */
+MPPI_HD static inline void tanh2(const float xa, const float xb, float* ra, float* rb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 x = { xa, xb };
+  f32x2 xc;
+  xc.x = fminf(fmaxf(xa, -7.90531110763549805f), 7.90531110763549805f);
+  xc.y = fminf(fmaxf(xb, -7.90531110763549805f), 7.90531110763549805f);
+  const f32x2 x2 = xc * xc;
+#define MPPI_DET_PKFMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
+#define MPPI_DET_SPLAT(v) (f32x2{ (v), (v) })
+  f32x2 p = MPPI_DET_PKFMA(x2, MPPI_DET_SPLAT(-2.76076847742355e-16f), MPPI_DET_SPLAT(2.00018790482477e-13f));
+  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(-8.60467152213735e-11f));
+  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(5.12229709037114e-08f));
+  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(1.48572235717979e-05f));
+  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(6.37261928875436e-04f));
+  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(4.89352455891786e-03f));
+  p = xc * p;
+  f32x2 q = MPPI_DET_PKFMA(x2, MPPI_DET_SPLAT(1.19825839466702e-06f), MPPI_DET_SPLAT(1.18534705686654e-04f));
+  q = MPPI_DET_PKFMA(x2, q, MPPI_DET_SPLAT(2.26843463243900e-03f));
+  q = MPPI_DET_PKFMA(x2, q, MPPI_DET_SPLAT(4.89352518554385e-03f));
+  f32x2 r = { __builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y) };
+  const f32x2 e = MPPI_DET_PKFMA(-q, r, MPPI_DET_SPLAT(1.0f));
+  r = MPPI_DET_PKFMA(e, r, r);
+  f32x2 y = p * r;
+  y = MPPI_DET_PKFMA(MPPI_DET_PKFMA(-q, y, p), r, y);
+  y = MPPI_DET_PKFMA(MPPI_DET_PKFMA(-q, y, p), r, y);
+#undef MPPI_DET_PKFMA
+#undef MPPI_DET_SPLAT
+  *ra = (fabs(x.x) >= 1.220703125e-4f) ? y.x : x.x;
+  *rb = (fabs(x.y) >= 1.220703125e-4f) ? y.y : x.y;
+#else
+  *ra = tanh(xa);
+  *rb = tanh(xb);
+#endif
+}
+
+/** tanh of N values in place, pairwise through tanh2() */
+template <int N>
+MPPI_HD static inline void tanh_n(float (&v)[N])
+{
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2)
+    tanh2(v[i], v[i + 1], &v[i], &v[i + 1]);
+  if (N & 1)
+    v[N - 1] = tanh(v[N - 1]);
 }
 
 /** Device flavour of the reference's sigmoid (utils/activation_functions.cuh:49-59): (1 + tanh(x/2))/2. */
 MPPI_HD static inline float sigmoid(float x)
 {
   return (1.0f + tanh(x / 2.0f)) / 2.0f;
+}
+
+/** sigmoid of N values in place: the operations of sigmoid() with the tanh evaluated pairwise */
+template <int N>
+MPPI_HD static inline void sigmoid_n(float (&v)[N])
+{
+#pragma unroll
+  for (int i = 0; i < N; i++)
+    v[i] = v[i] / 2.0f;
+  tanh_n<N>(v);
+#pragma unroll
+  for (int i = 0; i < N; i++)
+    v[i] = (1.0f + v[i]) / 2.0f;
 }
 
 /** atan(x), Cephes atanf structure. */

@@ -137,14 +137,14 @@ public:
     theta_d_ = other.helper_.theta_d_;
   }
 
-  /** one activation tile [32][16 rollouts] per wave = 32 floats per rollout slot */
+  /** weights and activations live in registers: no LDS at all */
   __host__ __device__ int getGrdSharedSizeBytes() const
   {
     return 0;
   }
   __host__ __device__ int getBlkSharedSizeBytes() const
   {
-    return NET::LDS_FLOATS_PER_WAVE / 16 * (int)sizeof(float);
+    return 0;
   }
 
   __device__ inline void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
@@ -172,8 +172,7 @@ public:
 #pragma unroll
     for (int i = 0; i < C_DIM; i++)
       in[DYNAMICS_DIM + i] = control[i];
-    const int wave = (int)((threadIdx.x >> 6) + (blockDim.x >> 6) * threadIdx.z);
-    net_.forward(in, out, theta_s + wave * NET::LDS_FLOATS_PER_WAVE, (int)(threadIdx.x & 63));
+    net_.forward(in, out, (int)(threadIdx.x & 63));
 #pragma unroll
     for (int i = 0; i < DYNAMICS_DIM; i++)
       state_der[i + (S_DIM - DYNAMICS_DIM)] = out[i];

@@ -49,7 +49,8 @@ __host__ __device__ inline int coloredSpectrumFloats(int num_timesteps)
 /** k-steps (4 spectrum entries each) and 16-row time blocks of the basis table */
 __host__ __device__ inline int coloredNumKSteps(int num_timesteps)
 {
-  return (coloredSpectrumFloats(num_timesteps) + 3) / 4;
+  // rounded up to whole groups of 4 k-steps (= one Philox quad per lane); the padding rows of the table are zero
+  return (((coloredSpectrumFloats(num_timesteps) + 3) / 4) + 3) & ~3;
 }
 __host__ __device__ inline int coloredNumTBlocks(int num_timesteps)
 {
@@ -161,8 +162,8 @@ public:
 
   /** Philox spectrum draw: entry kk of (rollout, control c) is element (kk >> 2) & 3 of quad ((kk >> 4) << 2) + (kk & 3) of
    *  stream 1 + c — each lane's quad feeds four consecutive k-steps of its own k-group, so no draw is wasted */
-  __device__ inline void initializeDistributions(const float* __restrict__ output, const float t_0, const float dt,
-                                                 float* __restrict__ theta_d)
+  __device__ __forceinline__ void initializeDistributions(const float* __restrict__ output, const float t_0,
+                                                          const float dt, float* __restrict__ theta_d)
   {
     const int T = this->params_.num_timesteps;
     const int stride = PARENT::rowStride(T);
@@ -194,8 +195,24 @@ public:
 #pragma unroll
         for (int tb = 0; tb < MAX_TB; tb++)
           acc[tb] = colored_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        /* A fragments of one group (4 k-steps x up to MAX_TB time blocks) are fetched one group AHEAD of their use:
+         * the L2 round trip of group j + 1 overlaps the Philox draw and the 4 * NTB MFMAs of group j */
+        float a_cur[4][MAX_TB], a_nxt[4][MAX_TB];
+        auto fetch = [&](float (&a)[4][MAX_TB], const int ks4) {
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+          {
+            const float* __restrict__ a_row = basis + (size_t)(ks4 + e) * NTB * 64;
+#pragma unroll
+            for (int tb = 0; tb < MAX_TB; tb++)
+              a[e][tb] = (tb0 + tb < NTB) ? a_row[(tb0 + tb) * 64] : 0.0f;
+          }
+        };
+        fetch(a_cur, 0);
         for (int ks4 = 0; ks4 < KS; ks4 += 4)
         {
+          if (ks4 + 4 < KS)
+            fetch(a_nxt, ks4 + 4);
           float zq[4];
           if (from_buffer)
           {
@@ -212,17 +229,15 @@ public:
           }
 #pragma unroll
           for (int e = 0; e < 4; e++)
-          {
-            const int ks = ks4 + e;
-            if (ks < KS)
-            {
-              const float* __restrict__ a_row = basis + (size_t)ks * NTB * 64;
 #pragma unroll
-              for (int tb = 0; tb < MAX_TB; tb++)
-                if (tb0 + tb < NTB)
-                  acc[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_row[(tb0 + tb) * 64], zq[e], acc[tb], 0, 0, 0);
-            }
-          }
+            for (int tb = 0; tb < MAX_TB; tb++)
+              if (tb0 + tb < NTB)
+                acc[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[e][tb], zq[e], acc[tb], 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int tb = 0; tb < MAX_TB; tb++)
+              a_cur[e][tb] = a_nxt[e][tb];
         }
         if (valid)
         {

@@ -14,9 +14,10 @@
  * Fragment layouts (cdna_hip_programming.md §3): A: lane holds A[m = l & 15][k = l >> 4]; B: lane holds
  * B[k = l >> 4][n = l & 15]; D: lane holds rows 4*(l >> 4) + i, i = 0..3, of column l & 15.
  *  - The weights are A fragments and stay in VGPRs for the whole kernel (28 registers for 6-32-32-4).
- *  - A layer's output (D layout) is biased, squashed by det::tanh in place — 8 values per lane, i.e. the 512 tanh of a
- *    32-neuron layer x 16 rollouts are spread evenly over the 64 lanes — and re-laid out as the next layer's B
- *    fragments through a wave-private 2 KB LDS tile (8 ds_write + 8 ds_read per lane, no barrier: one wave, in-order LDS).
+ *  - A layer's output (D layout) is biased and squashed in place — 8 values per lane, i.e. the 512 tanh of a 32-neuron
+ *    layer x 16 rollouts are spread evenly over the 64 lanes, evaluated pairwise as packed fp32 (det::tanh2) — and
+ *    re-laid out as the next layer's B fragments with the cross-lane 4x4 transpose of wave_ops.hpp (v_permlane32_swap +
+ *    v_permlane16_swap): no LDS traffic and no barrier anywhere in the forward pass.
  *  - The last layer's rows are replicated (row m computes output m & 3), so every lane of a rollout ends up holding all
  *    OUT outputs and no broadcast is needed.
  *
@@ -31,6 +32,7 @@
 
 #include <hip/hip_runtime.h>
 #include "mppi_amd/det_math.h"
+#include "mppi_amd/utils/wave_ops.hpp"
 
 namespace mppi
 {
@@ -43,7 +45,6 @@ struct FNNMfma
   static constexpr int RB = H / 16;        ///< row blocks of a hidden layer
   static constexpr int KS_IN = (IN + 3) / 4;
   static constexpr int KS_H = H / 4;
-  static constexpr int LDS_FLOATS_PER_WAVE = H * 16;  ///< activation tile [H][16 rollouts]
   static constexpr int NUM_PARAMS = IN * H + H + H * H + H + H * OUT + OUT;
 
   /* per-lane constants: weight fragments (A operands) and the biases of the rows this lane owns in the D layout */
@@ -91,30 +92,36 @@ struct FNNMfma
       b3[i] = (i < OUT) ? B3[i] : 0.0f;
   }
 
-  /** hidden layer epilogue of one row block: bias, tanh, store in [neuron][rollout] layout (next layer's B operand) */
-  __device__ inline void storeHidden(const mfma_f32x4& acc, const float (&bias)[4], const int rb,
-                                     float* __restrict__ tile, const int lane) const
+  /** hidden layer epilogue: bias + tanh (pairwise packed, det::tanh_n) of the RB x 4 values this lane owns, then the
+   *  4x4 cross-lane transpose that turns each row block's D layout (units 16 rb + 4 g + i) into the next layer's B
+   *  fragments (unit 16 rb + 4 s + g in k-step 4 rb + s) */
+  __device__ inline void squash(const mfma_f32x4 (&acc)[RB], const float (&bias)[RB][4], float (&b_next)[KS_H]) const
   {
-    const int n = lane & 15, g = lane >> 4;
+    float v[RB * 4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        v[4 * rb + i] = acc[rb][i] + bias[rb][i];
+    mppi::det::tanh_n<RB * 4>(v);
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)
     {
-      float v = acc[i] + bias[i];
-      v = mppi::det::tanh(v);
-      tile[(16 * rb + 4 * g + i) * 16 + n] = v;
+      float t[4] = { v[4 * rb], v[4 * rb + 1], v[4 * rb + 2], v[4 * rb + 3] };
+      mppi::wave::transpose4x4(t);
+#pragma unroll
+      for (int sidx = 0; sidx < 4; sidx++)
+        b_next[4 * rb + sidx] = t[sidx];
     }
   }
 
   /**
    * in[IN]: the network input of this lane's rollout (every lane of the rollout holds the same values);
-   * out[OUT]: the network output, identical in the 4 lanes of the rollout.  tile: wave-private LDS, H*16 floats.
+   * out[OUT]: the network output, identical in the 4 lanes of the rollout.  No LDS, no barrier.
    */
-  __device__ inline void forward(const float (&in)[IN], float (&out)[OUT], float* __restrict__ tile,
-                                 const int lane) const
+  __device__ inline void forward(const float (&in)[IN], float (&out)[OUT], const int lane) const
   {
-    const int n = lane & 15, g = lane >> 4;
-    /* Row blocks are processed one after the other: while the matrix core works on row block rb + 1, the VALU
-     * squashes row block rb (the tanh of one block is ~200 VALU instructions, a block's MFMA chain 8 x 32 cycles). */
+    const int g = lane >> 4;
     /* ---- layer 1: B fragment of k-step s = in[4s + g] ---- */
     float bin[KS_IN];
 #pragma unroll
@@ -130,43 +137,31 @@ struct FNNMfma
     mfma_f32x4 acc[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; rb++)
-    {
       acc[rb] = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    // the row blocks' chains are independent: interleave them so that consecutive MFMAs do not wait on each other
 #pragma unroll
-      for (int s = 0; s < KS_IN; s++)
+    for (int s = 0; s < KS_IN; s++)
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++)
         acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rb][s], bin[s], acc[rb], 0, 0, 0);
-    }
+    float bh[KS_H];
+    squash(acc, b1, bh);
+    /* ---- layer 2 ---- */
 #pragma unroll
     for (int rb = 0; rb < RB; rb++)
-      storeHidden(acc[rb], b1[rb], rb, tile, lane);
-    __builtin_amdgcn_wave_barrier();
-    /* ---- layer 2 ---- */
-    float bh[KS_H];
+      acc[rb] = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
     for (int s = 0; s < KS_H; s++)
-      bh[s] = tile[(4 * s + g) * 16 + n];
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int rb = 0; rb < RB; rb++)
-    {
-      acc[rb] = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-      for (int s = 0; s < KS_H; s++)
+      for (int rb = 0; rb < RB; rb++)
         acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[rb][s], bh[s], acc[rb], 0, 0, 0);
-    }
-#pragma unroll
-    for (int rb = 0; rb < RB; rb++)
-      storeHidden(acc[rb], b2[rb], rb, tile, lane);
-    __builtin_amdgcn_wave_barrier();
+    float bo[KS_H];
+    squash(acc, b2, bo);
     /* ---- layer 3 (linear): rows replicated, every lane of the rollout receives all outputs ---- */
     mfma_f32x4 o = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
     for (int s = 0; s < KS_H; s++)
-    {
-      const float b = tile[(4 * s + g) * 16 + n];
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s], b, o, 0, 0, 0);
-    }
-    __builtin_amdgcn_wave_barrier();
+      o = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s], bo[s], o, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < OUT; i++)
       out[i] = o[i] + b3[i];

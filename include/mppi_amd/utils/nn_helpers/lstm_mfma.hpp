@@ -142,40 +142,68 @@ struct LSTMMfma
 #pragma unroll
       for (int gate = 0; gate < 4; gate++)
         acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[gate][s], hb[s], acc[gate], 0, 0, 0);
-    /* ---- cell / hidden update of units 4g + i, per lane ---- */
+    /* ---- cell / hidden update of units 4g + i, per lane; the 12 sigmoids and 8 tanh go pairwise through the packed
+     *      det::tanh2 ---- */
+    float sg[12], gc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+      sg[i] = acc[0][i] + bg[0][i];
+      sg[4 + i] = acc[1][i] + bg[1][i];
+      sg[8 + i] = acc[2][i] + bg[2][i];
+      gc[i] = acc[3][i] + bg[3][i];
+    }
+    mppi::det::sigmoid_n<12>(sg);
+    mppi::det::tanh_n<4>(gc);
     float hn[4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
     {
-      const float gi = mppi::det::sigmoid(acc[0][i] + bg[0][i]);
-      const float gf = mppi::det::sigmoid(acc[1][i] + bg[1][i]);
-      const float go = mppi::det::sigmoid(acc[2][i] + bg[2][i]);
-      const float gc = mppi::det::tanh(acc[3][i] + bg[3][i]);
-      const float in_part = gi * gc;
-      const float keep_part = gf * c[i];
+      const float in_part = sg[i] * gc[i];
+      const float keep_part = sg[4 + i] * c[i];
       c[i] = in_part + keep_part;
-      hn[i] = mppi::det::tanh(c[i]) * go;
+      hn[i] = c[i];
     }
+    mppi::det::tanh_n<4>(hn);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      hn[i] = hn[i] * sg[8 + i];
     mppi::wave::transpose4x4(hn);
 #pragma unroll
     for (int s = 0; s < KS_H; s++)
       hb[s] = hn[s];
     /* ---- output MLP, layer 1: [h ; x] -> M, tanh ---- */
     float act[RB_M][4];
-#pragma unroll
-    for (int rb = 0; rb < RB_M; rb++)
     {
-      mfma_f32x4 a = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+      mfma_f32x4 a[RB_M];
+#pragma unroll
+      for (int rb = 0; rb < RB_M; rb++)
+        a[rb] = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
       for (int s = 0; s < KS_H; s++)
-        a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[rb][s], hb[s], a, 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < RB_M; rb++)
+          a[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[rb][s], hb[s], a[rb], 0, 0, 0);
 #pragma unroll
       for (int s = 0; s < KS_X; s++)
-        a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1x[rb][s], bx[s], a, 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; i++)
-        act[rb][i] = mppi::det::tanh(a[i] + b1[rb][i]);
-      mppi::wave::transpose4x4(act[rb]);  // units 16 rb + 4 s + g, s = 0..3
+        for (int rb = 0; rb < RB_M; rb++)
+          a[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1x[rb][s], bx[s], a[rb], 0, 0, 0);
+      float v[RB_M * 4];
+#pragma unroll
+      for (int rb = 0; rb < RB_M; rb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          v[4 * rb + i] = a[rb][i] + b1[rb][i];
+      mppi::det::tanh_n<RB_M * 4>(v);
+#pragma unroll
+      for (int rb = 0; rb < RB_M; rb++)
+      {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          act[rb][i] = v[4 * rb + i];
+        mppi::wave::transpose4x4(act[rb]);  // units 16 rb + 4 s + g, s = 0..3
+      }
     }
     /* ---- layer 2 (linear), rows replicated so that every lane of the rollout receives all outputs ---- */
     mfma_f32x4 o = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };

@@ -1300,6 +1300,21 @@ __global__ void detEvalKernel(int func, const float* x, float* y, int n)
       case 7: r = mppi::det::sigmoid(x[i]); break;
       case 8: r = mppi::det::sqrt(x[i]); break;
       case 9: r = 1.0f / x[i]; break;
+      case 10:  // packed pair path: element i is evaluated together with its neighbour i ^ 1
+      {
+        float ra, rb;
+        const int j = (i ^ 1) < n ? (i ^ 1) : i;
+        mppi::det::tanh2(x[i & ~1], x[(i & ~1) + 1 < n ? (i & ~1) + 1 : i], &ra, &rb);
+        r = (i & 1) && (j != i) ? rb : ra;
+        break;
+      }
+      case 11:
+      {
+        float v[4] = { x[i], x[i] * 0.5f, -x[i], x[i] + 1.0f };
+        mppi::det::sigmoid_n<4>(v);
+        r = v[0] + v[1] + v[2] + v[3];
+        break;
+      }
     }
     y[i] = r;
   }

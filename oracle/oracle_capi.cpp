@@ -378,6 +378,10 @@ void oracle_det_eval(int func, const float* x, float* y, int n)
       case 7: y[i] = det::sigmoid(x[i]); break;
       case 8: y[i] = det::sqrt(x[i]); break;
       case 9: y[i] = 1.0f / x[i]; break;
+      case 10: y[i] = det::tanh(x[i]); break; /* device side: the packed tanh2() path */
+      case 11:
+        y[i] = det::sigmoid(x[i]) + det::sigmoid(x[i] * 0.5f) + det::sigmoid(-x[i]) + det::sigmoid(x[i] + 1.0f);
+        break;
       default: y[i] = 0.0f;
     }
   }

@@ -11,10 +11,17 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("func,lo,hi", [(0, -50, 50), (1, -50, 50), (2, -100, 88), (3, 1e-30, 1e30), (4, -12, 12),
-                                        (5, -100, 100), (6, -1000, 1000), (7, -30, 30), (8, 0, 1e20), (9, -1e3, 1e3)])
+                                        (5, -100, 100), (6, -1000, 1000), (7, -30, 30), (8, 0, 1e20), (9, -1e3, 1e3),
+                                        (10, -12, 12), (11, -20, 20), (4, -1e-3, 1e-3), (10, -1e-3, 1e-3)])
 def test_det_math_device_equals_host_bitwise(gpu, func, lo, hi):
+    """func 4 / 7 / 10 / 11: tanh and sigmoid run a hand-written division core on the device (det::div_benign, packed in
+    tanh2) that must reproduce the host's IEEE division bit for bit — 2 M samples each, plus tiny and subnormal inputs"""
     rng = np.random.default_rng(func)
-    x = rng.uniform(lo, hi, 200000).astype(np.float32)
+    n = 2_000_000 if func in (4, 7, 10, 11) else 200000
+    x = rng.uniform(lo, hi, n).astype(np.float32)
+    if func in (4, 10):
+        tiny = np.exp(rng.uniform(np.log(1e-44), np.log(1e-3), 100000)).astype(np.float32)
+        x[1000:101000] = tiny * np.where(rng.uniform(size=100000) < 0.5, -1, 1).astype(np.float32)
     if func == 3:
         x = np.exp(rng.uniform(np.log(1e-30), np.log(1e30), 200000)).astype(np.float32)
     x[:8] = [0.0, -0.0, 1.0, -1.0, np.float32(np.pi), 1e-40, 0.625, -0.625]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times optimisation iterations of the registered workloads for several block shapes (HIP events on the engine's
-stream).  Usage: python tools/time_workloads.py [cartpole|autorally|di] ..."""
+stream).  Usage: python tools/time_workloads.py [cartpole|autorally|di|lstm] ..."""
 import os
 import sys
 
@@ -8,7 +8,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
     sys.path.insert(0, p)
 import numpy as np  # noqa: E402
-from common import autorally_cfg, cartpole_cfg, di_cfg, make_engine  # noqa: E402
+from common import autorally_cfg, bicycle_lstm_cfg, cartpole_cfg, di_cfg, make_engine  # noqa: E402
 
 
 def run(name, cfg, shapes, n=100):
@@ -29,7 +29,7 @@ def run(name, cfg, shapes, n=100):
         eng.close()
 
 
-which = sys.argv[1:] or ["cartpole", "autorally", "di"]
+which = sys.argv[1:] or ["cartpole", "autorally", "di", "lstm"]
 if "cartpole" in which:
     run("cartpole", cartpole_cfg(K=16384, T=100), [(64, 1, 1), (64, 1, 2), (32, 1)])
     run("cartpole", cartpole_cfg(K=2048, T=100), [(64, 1)])
@@ -37,3 +37,11 @@ if "autorally" in which:
     run("autorally", autorally_cfg(K=16384, T=150, lambda_=1.0), [(64, 4), (32, 4), (8, 16)], n=30)
 if "di" in which:
     run("di-tube", di_cfg(K=8192, T=150, tube=True), [(64, 1, 1), (64, 1, 2)])
+if "lstm" in which:
+    cfg = bicycle_lstm_cfg(K=65536, T=200, lambda_=1.0)
+    run("lstm", cfg, [(64, 4), (32, 4)], n=10)
+    cfg["colored"] = ([1.0, 1.0], 0.97, 0.0)
+    run("lstm+colored", cfg, [(64, 4), (32, 4)], n=10)
+    cfg = cartpole_cfg(K=16384, T=100)
+    cfg["colored"] = ([1.0], 0.97, 0.0)
+    run("cartpole+colored", cfg, [(64, 1, 1), (64, 1, 2)], n=50)
