@@ -57,7 +57,8 @@ typedef enum mppi_controller_kind
 {
   MPPI_CONTROLLER_VANILLA = 0, /* controllers/MPPI/mppi_controller.cu:151-241 */
   MPPI_CONTROLLER_TUBE = 1,    /* controllers/Tube-MPPI/tube_mppi_controller.cu:157-299 (two systems per launch) */
-  MPPI_CONTROLLER_ROBUST = 2,  /* controllers/R-MPPI/robust_mppi_controller.cu:635-755 */
+  MPPI_CONTROLLER_ROBUST = 2,  /* controllers/R-MPPI/robust_mppi_controller.cu:548-755 (nominal + real system, tracking
+                                  feedback, candidate nominal states) */
   MPPI_CONTROLLER_COLORED = 3  /* controllers/ColoredMPPI/colored_mppi_controller.cu:134-240: the vanilla loop with the
                                   colored-noise sampler; after smoothing only control channel 1 is clamped (:232-237) */
 } mppi_controller_kind;
@@ -231,6 +232,34 @@ mppi_status mppi_get_costs(mppi_handle h, float* costs);
 mppi_status mppi_get_stats(mppi_handle h, mppi_stats* out);
 /** clamped samples v[D][K_local][T][C] of the last iteration (control_samples_d_); needs cfg.save_samples */
 mppi_status mppi_get_sampled_controls(mppi_handle h, float* v);
+
+/* ---------------------------------------------------------------- Robust MPPI (MPPI_CONTROLLER_ROBUST) ----------- */
+/* Systems of a Robust-MPPI handle: 0 = nominal, 1 = real (robust_mppi_controller.cu:637-640); x0 of
+ * mppi_compute_control is the REAL state, mppi_get_control_seq the real system's control (getControlSeq),
+ * mppi_get_state_seq the NOMINAL state trajectory (getTargetStateSeq, robust_mppi_controller.cuh:131-134),
+ * mppi_get_nominal_control_seq the importance-sampler (nominal) control.  mppi_slide is a no-op there (:178). */
+/** value_function_threshold_, num_candidate_nominal_states_ (odd, >= 3), samples per candidate = eval_dyn_kernel_dim_.x
+ *  (controllers/R-MPPI/robust_mppi_controller.cuh:46-53; checks of updateNumCandidates, robust_mppi_controller.cu:414-448
+ *  become MPPI_ERR_INVALID_ARG) */
+mppi_status mppi_set_rmppi_params(mppi_handle h, float value_function_threshold, int num_candidates,
+                                  int samples_per_candidate);
+/**
+ * DDP tracking-controller gains, the reference's DDPFeedbackState::fb_gain_traj_ (feedback_controllers/DDP/ddp.cuh:18-60):
+ * gains[T][S][C], entry [t][i][j] = K_t(j, i).  The producer (host DDP / iLQR, include/mppi/ddp/) is the caller's.
+ * accumulate_all_states == 0 reproduces DeviceDDPImpl::k (ddp.cu:11-45) including its behaviour for an even
+ * CONTROL_DIM (only the last state's gain row takes effect); != 0 sums over all states.
+ */
+mppi_status mppi_set_feedback_gains(mppi_handle h, const float* gains, int accumulate_all_states);
+/**
+ * RobustMPPIController::updateImportanceSamplingControl(state, stride) (robust_mppi_controller.cu:548-568): candidate
+ * nominal states by line search, init-eval kernel (core/rmppi_kernels.cu:231-356), best candidate by free energy,
+ * control histories, slide of the nominal control, nominal state trajectory.  The DDP gain update that ends the
+ * reference's function is the caller's (mppi_set_feedback_gains).
+ */
+mppi_status mppi_update_importance_sampling_control(mppi_handle h, const float* state, int stride);
+/** getNominalState, getBestIndex, nominal stride, getCandidateFreeEnergy [num_candidates]; any pointer may be NULL */
+mppi_status mppi_get_rmppi_state(mppi_handle h, float* nominal_state, int* best_index, int* nominal_stride,
+                                 float* candidate_free_energy);
 
 /* ---------------------------------------------------------------- device-resident iteration loop ----------------- */
 /**

@@ -1,0 +1,66 @@
+/**
+ * ddp_feedback.hpp — device side of the DDP tracking controller used by Robust MPPI: u_fb = K_t (x - x*).
+ *
+ * reference: include/mppi/feedback_controllers/DDP/ddp.cuh:18-60 (DDPFeedbackState: fb_gain_traj_[T][S][C], i.e. the
+ * C x S Eigen gain matrix of every timestep, column-major) and ddp.cu:11-45 (DeviceDDPImpl::k).
+ * The gain PRODUCER (the host-side DDP / iLQR solver, include/mppi/ddp/) is outside the hot path (SURVEY.md §8f item
+ * 3): gains arrive through the C ABI (mppi_set_feedback_gains) and live in one device buffer owned by the engine.
+ *
+ * Reference quirk, kept by default: for an even CONTROL_DIM ddp.cu:27-37 ASSIGNS `control_output = gain_row * e` inside
+ * the loop over the states instead of accumulating, so only the LAST state's gain row survives
+ * (u_fb[j] = K[S-1][j] * (x[S-1] - x*[S-1])); for an odd CONTROL_DIM it accumulates over all states (:39-43).
+ * accumulate_all_states_ = true gives the mathematically intended sum over all states for every CONTROL_DIM.
+ */
+#ifndef MPPI_AMD_DDP_FEEDBACK_HPP_
+#define MPPI_AMD_DDP_FEEDBACK_HPP_
+
+#include <hip/hip_runtime.h>
+#include "mppi_amd/plugin/managed.hpp"
+
+namespace mppi
+{
+template <class DYN_T>
+class DeviceDDP : public Managed
+{
+public:
+  static const int STATE_DIM = DYN_T::STATE_DIM;
+  static const int CONTROL_DIM = DYN_T::CONTROL_DIM;
+
+  const float* fb_gain_traj_d_ = nullptr;  ///< [T][S][C] (device pointer owned by the engine)
+  int num_timesteps_ = 0;
+  bool accumulate_all_states_ = false;     ///< false: the reference's behaviour (see the header comment)
+
+  __host__ __device__ int getGrdSharedSizeBytes() const
+  {
+    return 0;
+  }
+  __host__ __device__ int getBlkSharedSizeBytes() const
+  {
+    return 0;
+  }
+  /** reference: feedback_controllers/feedback.cuh initializeFeedback — nothing to set up for DDP gains */
+  __device__ inline void initializeFeedback(const float* x, const float* u, float* theta_fb, const float t, const float dt)
+  {
+  }
+
+  /** reference: ddp.cu:11-45.  control_output must be zero-initialised by the caller (rmppi_kernels.cu:755-758). */
+  __device__ inline void k(const float* __restrict__ x_act, const float* __restrict__ x_goal, const int t,
+                           float* __restrict__ theta, float* __restrict__ control_output) const
+  {
+    const float* fb_gain_t = fb_gain_traj_d_ + (size_t)STATE_DIM * CONTROL_DIM * t;
+    const bool assign = (CONTROL_DIM % 2 == 0) && !accumulate_all_states_;
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+    {
+      const float e = x_act[i] - x_goal[i];
+#pragma unroll
+      for (int j = 0; j < CONTROL_DIM; j++)
+      {
+        const float term = fb_gain_t[i * CONTROL_DIM + j] * e;
+        control_output[j] = assign ? term : control_output[j] + term;
+      }
+    }
+  }
+};
+}  // namespace mppi
+#endif

@@ -262,6 +262,38 @@ public:
   }
 
   /**
+   * Random access to one shaped sample v[d][sample_index][t][:] without the block's LDS rows: eps comes from the eps
+   * buffer or from the Philox quad that holds the element.  Used by the Robust-MPPI init-eval kernel, whose rollouts
+   * read sample `candidate_sample_idx` at the time-shifted index min(t + stride, T - 1)
+   * (reference: core/rmppi_kernels.cu:309-312 readControlSample(candidate_sample_idx, candidate_t, ...)).
+   */
+  __device__ inline void sampleAt(const int sample_index, const int t, const int distribution_index,
+                                  float* __restrict__ control) const
+  {
+    const int d = distribution_index >= params_.num_distributions ? 0 : distribution_index;
+    const float* mean = control_means_d_ + (size_t)(params_.num_timesteps * d + t) * CONTROL_DIM;
+    const bool use_mean = ((sample_index + rollout_offset_) == 0) || (t < optimization_stride_);
+    const bool pure = isPureNoise(sample_index);
+#pragma unroll
+    for (int i = 0; i < CONTROL_DIM; i++)
+    {
+      const int e = t * CONTROL_DIM + i;
+      float eps;
+      if (noise_source_ == NOISE_EPS_BUFFER)
+      {
+        eps = eps_d_[(size_t)sample_index * params_.num_timesteps * CONTROL_DIM + e];
+      }
+      else
+      {
+        float z[4];
+        mppi::rng::normal4(seed_, generation_, 0u, (uint32_t)(sample_index + rollout_offset_), (uint32_t)(e >> 2), z);
+        eps = (e & 3) == 0 ? z[0] : ((e & 3) == 1 ? z[1] : ((e & 3) == 2 ? z[2] : z[3]));
+      }
+      control[i] = shapeSample(mean[i], std_dev_decayed_[CONTROL_DIM * d + i], eps, use_mean, pure);
+    }
+  }
+
+  /**
    * reference: sampling_distribution.cu:169-205 (readControlSample) fused with the setGaussianControls rule
    * (gaussian.cu:99-127): k == 0 or t < stride -> mu; pure-noise rollouts -> sigma*eps; else mu + sigma*eps.
    */

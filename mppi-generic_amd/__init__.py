@@ -8,7 +8,7 @@ from . import buildlib as _buildlib
 from .buildlib import build
 from .capi import (MppiConfig, MppiGaussianParams, MppiStats, MppiSystemStats, SIGNATURES, library_path, load_library)
 from .controllers import (MPPI_CONTROLLER_TUBE, MPPI_CONTROLLER_VANILLA, MPPI_NOISE_INJECTED, MPPI_NOISE_PHILOX_FUSED,
-                          MPPIError, MPPIController, TubeMPPIController, VanillaMPPIController, ColoredMPPIController,
+                          MPPIError, MPPIController, TubeMPPIController, VanillaMPPIController, ColoredMPPIController, RobustMPPIController,
                           MPPI_CONTROLLER_COLORED, CartpoleDynamicsParams,
                           CartpoleQuadraticCostParams, DoubleIntegratorParams, DoubleIntegratorCircleCostParams,
                           ARStandardCostParams, fnn_blob_from_npz_dict, lstm_blob_from_npz_dict,

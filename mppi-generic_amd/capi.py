@@ -78,6 +78,10 @@ SIGNATURES = {
     "mppi_set_sampler_params": (C.c_int, [H, C.POINTER(MppiGaussianParams)]),
     "mppi_set_colored_noise_params": (C.c_int, [H, _f32p, C.c_float, C.c_float]),
     "mppi_sample_noise": (C.c_int, [H, C.c_int, _f32p]),
+    "mppi_set_rmppi_params": (C.c_int, [H, C.c_float, C.c_int, C.c_int]),
+    "mppi_set_feedback_gains": (C.c_int, [H, _f32p, C.c_int]),
+    "mppi_update_importance_sampling_control": (C.c_int, [H, _f32p, C.c_int]),
+    "mppi_get_rmppi_state": (C.c_int, [H, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
     "mppi_set_control_ranges": (C.c_int, [H, _f32p]),
     "mppi_set_control_deadband": (C.c_int, [H, _f32p]),
     "mppi_set_lambda_alpha": (C.c_int, [H, C.c_float, C.c_float]),

@@ -373,6 +373,39 @@ class ColoredMPPIController(MPPIController):
         return (self.num_rollouts_local, self.CONTROL_DIM, self.num_timesteps + 1, 2)
 
 
+class RobustMPPIController(MPPIController):
+    """reference: controllers/R-MPPI/robust_mppi_controller.cuh — RobustMPPIController.
+    Systems: 0 = nominal, 1 = real.  The DDP gain producer is the caller's (setFeedbackGains)."""
+    KIND = MPPI_CONTROLLER_ROBUST
+
+    def setRMPPIParams(self, value_function_threshold=1000.0, num_candidates=9, samples_per_candidate=32):
+        self.num_candidates = num_candidates
+        self._check(self._lib.mppi_set_rmppi_params(self._h, value_function_threshold, num_candidates,
+                                                    samples_per_candidate))
+
+    def setFeedbackGains(self, gains, accumulate_all_states=False):
+        """gains[T][S][C] (DDPFeedbackState::fb_gain_traj_)"""
+        g = _f32(gains)
+        assert g.shape == (self.num_timesteps, self.STATE_DIM, self.CONTROL_DIM), g.shape
+        self._check(self._lib.mppi_set_feedback_gains(self._h, g.reshape(-1), int(accumulate_all_states)))
+
+    def updateImportanceSamplingControl(self, state, stride):
+        self._check(self._lib.mppi_update_importance_sampling_control(self._h, _f32(state).reshape(-1), stride))
+
+    def getRMPPIState(self):
+        """(nominal_state[S], best_index, nominal_stride, candidate_free_energy[num_candidates])"""
+        ns = np.zeros(self.STATE_DIM, np.float32)
+        fe = np.zeros(getattr(self, "num_candidates", 9), np.float32)
+        bi, st = C.c_int(), C.c_int()
+        self._check(self._lib.mppi_get_rmppi_state(self._h, ns.ctypes.data, C.byref(bi), C.byref(st), fe.ctypes.data))
+        return ns, bi.value, st.value, fe
+
+    def getNominalControlSeq(self):
+        u = np.empty((self.num_timesteps, self.CONTROL_DIM), np.float32)
+        self._check(self._lib.mppi_get_nominal_control_seq(self._h, u))
+        return u
+
+
 class TubeMPPIController(MPPIController):
     """reference: controllers/Tube-MPPI/tube_mppi_controller.cuh — TubeMPPIController"""
     KIND = MPPI_CONTROLLER_TUBE

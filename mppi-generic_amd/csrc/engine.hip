@@ -74,6 +74,22 @@ struct mppi_handle_s
   int last_stride = 1;
   int noise_source = MPPI_NOISE_PHILOX_FUSED;
 
+  /* Robust MPPI (controllers/R-MPPI/robust_mppi_controller.cuh:46-53, 270-310) */
+  float value_function_threshold = 1000.0f;
+  int num_candidates = 9;
+  int samples_per_candidate = 32;  // eval_dyn_kernel_dim_.x default (robust_mppi_controller.cu:326-330)
+  bool fb_accumulate_all = false;
+  bool gains_set = false;
+  bool rm_nominal_init = false;
+  int best_index = 0, nominal_stride = 0, real_stride = 0;
+  std::vector<float> rm_nominal_state, rm_line_weights, rm_cand_states, rm_cand_costs, rm_cand_free_energy,
+      nominal_history_h;
+  std::vector<int> rm_cand_strides;
+  float* cand_states_d = nullptr;
+  float* cand_costs_d = nullptr;
+  int* cand_strides_d = nullptr;
+  int cand_capacity = 0;
+
   /* RCCL (loaded lazily) */
   void* rccl_lib = nullptr;
   void* comm = nullptr;
@@ -165,6 +181,12 @@ static void freeAll(mppi_handle h)
       (void)hipFree(*b);
     *b = nullptr;
   }
+  if (h->cand_states_d)
+    (void)hipFree(h->cand_states_d);
+  if (h->cand_costs_d)
+    (void)hipFree(h->cand_costs_d);
+  if (h->cand_strides_d)
+    (void)hipFree(h->cand_strides_d);
   if (h->ev_a)
     (void)hipEventDestroy(h->ev_a);
   if (h->ev_b)
@@ -206,6 +228,11 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   {
     case MPPI_CONTROLLER_VANILLA: h->D = 1; break;
     case MPPI_CONTROLLER_COLORED: h->D = 1; break;
+    case MPPI_CONTROLLER_ROBUST:
+      h->D = 2;
+      if (!h->model->supportsRMPPI())
+        return fail(nullptr, MPPI_ERR_UNSUPPORTED, "mppi_create: model '" + h->model_name + "' is not instantiated for Robust MPPI");
+      break;
     case MPPI_CONTROLLER_TUBE: h->D = 2; break;
     default:
       return fail(nullptr, MPPI_ERR_UNSUPPORTED, "mppi_create: controller kind not available in this build");
@@ -218,18 +245,27 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   h->bx = cfg->block_x > 0 ? cfg->block_x : h->model->default_bx;
   h->by = cfg->block_y > 0 ? cfg->block_y : h->model->default_by;
   h->bz = h->D;
+  if (cfg->controller == MPPI_CONTROLLER_ROBUST)
+  {  // rolloutRMPPIKernel: (64 rollouts, 1 lane, 2 systems)
+    if ((cfg->block_x != 0 && cfg->block_x != 64) || (cfg->block_y != 0 && cfg->block_y != 1))
+      return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE, "mppi_create: Robust MPPI runs with block shape (64, 1, 2)");
+    h->bx = 64;
+    h->by = 1;
+  }
   if (!h->model->supportsShape(h->bx, h->by, h->bz))
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
                 "mppi_create: block shape (" + std::to_string(h->bx) + "," + std::to_string(h->by) + "," +
                     std::to_string(h->bz) + ") is not instantiated for model '" + h->model_name + "'");
-  const bool pipe_ok = h->model->supportsPipeline() && h->bx == 64 && h->by == 1;
+  const bool pipe_ok = h->model->supportsPipeline() && h->bx == 64 && h->by == 1 && cfg->controller != MPPI_CONTROLLER_ROBUST;
   if (cfg->kernel_variant == MPPI_KERNEL_PIPELINE && !pipe_ok)
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
                 "mppi_create: the pipeline variant needs a model registered for it and block shape (64, 1)");
   if (cfg->kernel_variant < 0 || cfg->kernel_variant > MPPI_KERNEL_PIPELINE)
     return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_create: unknown kernel_variant");
   h->pipeline = pipe_ok && cfg->kernel_variant != MPPI_KERNEL_FUSED;
-  size_t lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, h->pipeline);
+  size_t lds = cfg->controller == MPPI_CONTROLLER_ROBUST ?
+                   h->model->rmppiSharedBytes(h->bx, cfg->num_timesteps) :
+                   h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, h->pipeline);
   if (lds > MAX_LDS_BYTES && h->pipeline && cfg->kernel_variant == MPPI_KERNEL_AUTO)
   {  // the output ring does not fit next to the sample rows: fall back to the fused variant
     h->pipeline = false;
@@ -281,7 +317,7 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   ALLOC_OR_FAIL(h->recv_d, (size_t)world * D * h->PS);
   ALLOC_OR_FAIL(h->gather_tmp_d, (size_t)world * D * h->PS);
   ALLOC_OR_FAIL(h->stats_d, (size_t)D * kernels::STATS_STRIDE);
-  ALLOC_OR_FAIL(h->history_d, (size_t)2 * C);
+  ALLOC_OR_FAIL(h->history_d, (size_t)4 * C);  // [2 systems][2][C] (RMPPI smooths both with their own history)
   ALLOC_OR_FAIL(h->ctrl_in_d, (size_t)D * T * C);
   ALLOC_OR_FAIL(h->ctrl_out_d, (size_t)D * T * C);
   ALLOC_OR_FAIL(h->state_out_d, (size_t)D * T * S);
@@ -300,6 +336,8 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   h->nominal_control_h.assign((size_t)T * C, 0.0f);
   h->nominal_state_h.assign((size_t)T * S, 0.0f);
   h->slide_scale_h.assign(C, 0.0f);  // controller.cuh:67 slide_control_scale_ = Zero()
+  h->nominal_history_h.assign((size_t)2 * C, 0.0f);
+  h->rm_nominal_state.assign(S, 0.0f);
   *out = h.release();
   return MPPI_OK;
 }
@@ -509,7 +547,18 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   s.iteration = iteration;
   s.optimization_stride = stride;
   std::string err;
-  mppi_status st = h->model->launchRollout(h->bx, h->by, h->bz, h->pipeline, a, s, h->stream, err);
+  mppi_status st;
+  if (h->cfg.controller == MPPI_CONTROLLER_ROBUST)
+  {
+    kernels::RMPPIArgs ra{};
+    ra.base = a;
+    ra.value_function_threshold = h->value_function_threshold;
+    st = h->model->launchRMPPI(h->bx, ra, s, h->stream, err);
+  }
+  else
+  {
+    st = h->model->launchRollout(h->bx, h->by, h->bz, h->pipeline, a, s, h->stream, err);
+  }
   if (st != MPPI_OK)
     return fail(h, st, err);
   h->generation++;
@@ -576,6 +625,8 @@ static mppi_status fetchStats(mppi_handle h)
                             h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   mppi_system_stats* sys[2] = { &h->stats_h.real_sys, &h->stats_h.nominal_sys };
+  if (h->cfg.controller == MPPI_CONTROLLER_ROBUST)  // system 0 is the NOMINAL one there (robust_mppi_controller.cu:637-640)
+    std::swap(sys[0], sys[1]);
   for (int z = 0; z < h->D; z++)
   {
     const float* s = st + z * kernels::STATS_STRIDE;
@@ -598,12 +649,24 @@ static bool allFinite(const std::vector<float>& v)
 
 /** smoothing / state trajectories / constraints for the D systems in ctrl_in_d, results to the host vectors */
 static mppi_status finalize(mppi_handle h, const float* ctrl_in_d, int smooth_mask, int constrain_mask,
-                            std::vector<float>* ctrl_out[2], std::vector<float>* state_out[2])
+                            std::vector<float>* ctrl_out[2], std::vector<float>* state_out[2], int num_systems = 0)
 {
   const int T = h->cfg.num_timesteps;
-  HIP_TRY(h, hipMemcpyAsync(h->history_d, h->history_h.data(), sizeof(float) * 2 * h->C, hipMemcpyHostToDevice,
-                            h->stream));
   kernels::FinalizeArgs a{};
+  if (h->cfg.controller == MPPI_CONTROLLER_ROBUST)
+  {  // system 0 (nominal) smooths with nominal_control_history_, system 1 (real) with control_history_
+    HIP_TRY(h, hipMemcpyAsync(h->history_d, h->nominal_history_h.data(), sizeof(float) * 2 * h->C, hipMemcpyHostToDevice,
+                              h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->history_d + 2 * h->C, h->history_h.data(), sizeof(float) * 2 * h->C,
+                              hipMemcpyHostToDevice, h->stream));
+    a.history_stride = 2 * h->C;
+  }
+  else
+  {
+    HIP_TRY(h, hipMemcpyAsync(h->history_d, h->history_h.data(), sizeof(float) * 2 * h->C, hipMemcpyHostToDevice,
+                              h->stream));
+    a.history_stride = 0;
+  }
   a.control_in_d = ctrl_in_d;
   a.history_d = h->history_d;
   a.x0_d = h->x0_d;
@@ -616,10 +679,11 @@ static mppi_status finalize(mppi_handle h, const float* ctrl_in_d, int smooth_ma
   // ColoredMPPI clamps only control channel 1 after smoothing (colored_mppi_controller.cu:232-237)
   a.constrain_mode = h->cfg.controller == MPPI_CONTROLLER_COLORED ? 1 : 0;
   std::string err;
-  mppi_status st = h->model->launchFinalize(h->D, a, h->stream, err);
+  const int nsys = num_systems > 0 ? num_systems : h->D;
+  mppi_status st = h->model->launchFinalize(nsys, a, h->stream, err);
   if (st != MPPI_OK)
     return fail(h, st, err);
-  for (int z = 0; z < h->D; z++)
+  for (int z = 0; z < nsys; z++)
   {
     if (ctrl_out[z])
       HIP_TRY(h, hipMemcpyAsync(ctrl_out[z]->data(), h->ctrl_out_d + (size_t)z * T * h->C, sizeof(float) * T * h->C,
@@ -639,7 +703,7 @@ mppi_status mppi_set_nominal_control(mppi_handle h, const float* u)
   if (!u)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_nominal_control: null");
   std::copy(u, u + h->control_h.size(), h->control_h.begin());
-  if (h->D == 2)
+  if (h->D == 2)  // Tube: both trajectories; RMPPI: nominal_control_trajectory_ = init_control_traj (:33)
     std::copy(u, u + h->control_h.size(), h->nominal_control_h.begin());
   return MPPI_OK;
 }
@@ -745,6 +809,200 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
   return MPPI_OK;
 }
 
+
+/* ---------------------------------------------------------------- Robust MPPI host logic ------------------------- */
+/** reference: robust_mppi_controller.cu:480-500 (computeLineSearchWeights) — [3][NC] row-major */
+static void rmLineSearchWeights(int nc, std::vector<float>& w)
+{
+  w.assign((size_t)3 * nc, 0.0f);
+  const int half = nc / 2;
+  for (int i = 0; i < half + 1; i++)
+  {
+    w[0 * nc + i] = 1 - i / float(half);
+    w[1 * nc + i] = i / float(half);
+    w[2 * nc + i] = 0.0f;
+  }
+  for (int i = 1; i < half + 1; i++)
+  {
+    w[0 * nc + half + i] = 0.0f;
+    w[1 * nc + half + i] = 1 - i / float(half);
+    w[2 * nc + half + i] = i / float(half);
+  }
+}
+/** reference: robust_mppi_controller.cu:502-512 — round((0, stride, stride) . weights) */
+static void rmImportanceSamplerStrides(int stride, int nc, const std::vector<float>& w, std::vector<int>& out)
+{
+  out.resize(nc);
+  for (int i = 0; i < nc; i++)
+  {
+    float acc = 0.0f * w[0 * nc + i];
+    acc += (float)stride * w[1 * nc + i];
+    acc += (float)stride * w[2 * nc + i];
+    out[i] = (int)roundf(acc);
+  }
+}
+/** reference: robust_mppi_controller.cu:514-545 (computeCandidateBaseline, computeBestIndex); expf / logf -> det */
+static void rmBestIndex(mppi_handle h)
+{
+  const int nc = h->num_candidates, ns = h->samples_per_candidate;
+  const float lambda = h->cfg.lambda;
+  float baseline = h->rm_cand_costs[0];
+  for (int i = 1; i < nc * ns; i++)
+    if (h->rm_cand_costs[i] < baseline)
+      baseline = h->rm_cand_costs[i];
+  h->rm_cand_free_energy.assign(nc, 0.0f);
+  for (int i = 0; i < nc; i++)
+  {
+    float fe = 0.0f;
+    for (int j = 0; j < ns; j++)
+      fe += mppi::det::exp((float)(-1.0 / (double)lambda * (double)(h->rm_cand_costs[(size_t)i * ns + j] - baseline)));
+    fe = (float)((double)fe / (1.0 * ns));
+    fe = -lambda * mppi::det::log(fe) + baseline;
+    h->rm_cand_free_energy[i] = fe;
+    if (fe < h->value_function_threshold)
+      h->best_index = i;
+  }
+}
+
+static mppi_status rmEnsureCandidateBuffers(mppi_handle h)
+{
+  const int n = h->num_candidates * h->samples_per_candidate;
+  if (n <= h->cand_capacity)
+    return MPPI_OK;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->cand_states_d)
+    (void)hipFree(h->cand_states_d);
+  if (h->cand_costs_d)
+    (void)hipFree(h->cand_costs_d);
+  if (h->cand_strides_d)
+    (void)hipFree(h->cand_strides_d);
+  h->cand_states_d = h->cand_costs_d = nullptr;
+  h->cand_strides_d = nullptr;
+  HIP_TRY(h, hipMalloc((void**)&h->cand_states_d, sizeof(float) * h->num_candidates * h->S));
+  HIP_TRY(h, hipMalloc((void**)&h->cand_costs_d, sizeof(float) * n));
+  HIP_TRY(h, hipMalloc((void**)&h->cand_strides_d, sizeof(int) * h->num_candidates));
+  h->cand_capacity = n;
+  return MPPI_OK;
+}
+
+/** the nominal state trajectory from rm_nominal_state under nominal_control_h (computeStateTrajectoryHelper) */
+static mppi_status rmNominalStateTrajectory(mppi_handle h)
+{
+  HIP_TRY(h, hipMemcpyAsync(h->x0_d, h->rm_nominal_state.data(), sizeof(float) * h->S, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->ctrl_in_d, h->nominal_control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice,
+                            h->stream));
+  std::vector<float>* co[2] = { nullptr, nullptr };
+  std::vector<float>* so[2] = { &h->nominal_state_h, nullptr };
+  return finalize(h, h->ctrl_in_d, 0, 0, co, so, 1);
+}
+
+/** reference: robust_mppi_controller.cu:571-626 (computeNominalStateAndStride) */
+static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, int stride)
+{
+  const int S = h->S, nc = h->num_candidates, ns = h->samples_per_candidate;
+  if (!h->rm_nominal_init)
+  {
+    std::copy(state, state + S, h->rm_nominal_state.begin());
+    h->rm_nominal_init = true;
+    h->nominal_stride = 0;
+    return MPPI_OK;
+  }
+  if (h->cfg.world_size > 1 && h->noise_source == MPPI_NOISE_INJECTED)
+    return fail(h, MPPI_ERR_UNSUPPORTED, "Robust MPPI init-eval with injected noise needs world_size == 1");
+  if (ns > h->K_local && h->noise_source == MPPI_NOISE_INJECTED)
+    return fail(h, MPPI_ERR_INVALID_ARG, "samples_per_candidate exceeds the injected noise rows");
+  // candidates = [nominal_x_k, nominal_x_k+1, real_x_k+1] * line search weights (:350-362)
+  rmLineSearchWeights(nc, h->rm_line_weights);
+  h->rm_cand_states.assign((size_t)nc * S, 0.0f);
+  for (int c = 0; c < nc; c++)
+    for (int i = 0; i < S; i++)
+    {
+      float acc = h->nominal_state_h[0 * S + i] * h->rm_line_weights[0 * nc + c];
+      acc += h->nominal_state_h[1 * S + i] * h->rm_line_weights[1 * nc + c];
+      acc += state[i] * h->rm_line_weights[2 * nc + c];
+      h->rm_cand_states[(size_t)c * S + i] = acc;
+    }
+  rmImportanceSamplerStrides(stride, nc, h->rm_line_weights, h->rm_cand_strides);
+  MPPI_TRY(rmEnsureCandidateBuffers(h));
+  HIP_TRY(h, hipMemcpyAsync(h->cand_states_d, h->rm_cand_states.data(), sizeof(float) * nc * S, hipMemcpyHostToDevice,
+                            h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->cand_strides_d, h->rm_cand_strides.data(), sizeof(int) * nc, hipMemcpyHostToDevice,
+                            h->stream));
+  // copyNominalControlToDevice: distribution 0 <- nominal control (:409-412)
+  HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->nominal_control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice,
+                            h->stream));
+  kernels::InitEvalArgs a{};
+  a.dt = h->cfg.dt;
+  a.num_timesteps = h->cfg.num_timesteps;
+  a.num_eval_rollouts = nc * ns;
+  a.samples_per_candidate = ns;
+  a.lambda = h->cfg.lambda;
+  a.alpha = h->cfg.alpha;
+  a.strides_d = h->cand_strides_d;
+  a.states_d = h->cand_states_d;
+  a.trajectory_costs_d = h->cand_costs_d;
+  SamplerLaunchState s{};
+  s.num_rollouts_local = h->K_local;
+  s.num_rollouts_global = h->cfg.num_rollouts;
+  s.rollout_offset = 0;  // eval samples are the GLOBAL rollouts 0 .. samples_per_candidate-1 on every rank
+  s.num_timesteps = h->cfg.num_timesteps;
+  s.num_distributions = h->D;
+  s.control_means_d = h->mean_d;
+  s.eps_d = nullptr;
+  if (h->noise_source == MPPI_NOISE_INJECTED)
+  {
+    if (!h->eps_d || h->n_eps_iters <= 0)
+      return fail(h, MPPI_ERR_STATE, "noise source is MPPI_NOISE_INJECTED but no noise has been injected");
+    s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * h->K_local * h->noise_floats;
+  }
+  s.control_samples_d = nullptr;
+  s.seed = h->cfg.seed;
+  s.generation = h->generation;
+  s.iteration = 0;  // generateSamples(stride, 0, gen) (:596)
+  s.optimization_stride = stride;
+  std::string err;
+  mppi_status st = h->model->launchInitEval(a, s, h->stream, err);
+  if (st != MPPI_OK)
+    return fail(h, st, err);
+  h->generation++;
+  h->rm_cand_costs.resize((size_t)nc * ns);
+  HIP_TRY(h, hipMemcpyAsync(h->rm_cand_costs.data(), h->cand_costs_d, sizeof(float) * nc * ns, hipMemcpyDeviceToHost,
+                            h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  rmBestIndex(h);
+  h->stats_h.nominal_state_used = h->best_index;
+  h->nominal_stride = h->rm_cand_strides[h->best_index];
+  std::copy(h->rm_cand_states.begin() + (size_t)h->best_index * S, h->rm_cand_states.begin() + (size_t)(h->best_index + 1) * S,
+            h->rm_nominal_state.begin());
+  return MPPI_OK;
+}
+
+/** reference: robust_mppi_controller.cu:635-755 */
+static mppi_status computeControlRobust(mppi_handle h, const float* x0_real, int stride)
+{
+  const int S = h->S;
+  if (!h->gains_set)
+    return fail(h, MPPI_ERR_STATE, "Robust MPPI: set the DDP feedback gains first (mppi_set_feedback_gains)");
+  HIP_TRY(h, hipMemcpyAsync(h->x0_d, h->rm_nominal_state.data(), sizeof(float) * S, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->x0_d + S, x0_real, sizeof(float) * S, hipMemcpyHostToDevice, h->stream));
+  // both importance samplers start from the nominal control (:655-656); later iterations continue from the NEW nominal
+  HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->nominal_control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice,
+                            h->stream));
+  for (int it = 0; it < h->cfg.num_iters; it++)
+  {
+    HIP_TRY(h, hipMemcpyAsync(h->mean_d + h->TC, h->mean_d, sizeof(float) * h->TC, hipMemcpyDeviceToDevice, h->stream));
+    MPPI_TRY(iteration(h, it, stride));
+  }
+  // smooth both with their own history, then the nominal state trajectory from the smoothed nominal control (:732-737)
+  std::vector<float>* co[2] = { &h->nominal_control_h, &h->control_h };
+  std::vector<float>* so[2] = { &h->nominal_state_h, &h->state_h };
+  MPPI_TRY(finalize(h, h->mean_d, /*smooth both*/ 3, /*constrain*/ 0, co, so));
+  MPPI_TRY(fetchStats(h));
+  if (!allFinite(h->control_h) || !allFinite(h->nominal_control_h) || !allFinite(h->nominal_state_h))
+    return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control or state sequence");
+  return MPPI_OK;
+}
+
 mppi_status mppi_compute_control(mppi_handle h, const float* x0, int stride)
 {
   CHECK_HANDLE(h);
@@ -754,6 +1012,8 @@ mppi_status mppi_compute_control(mppi_handle h, const float* x0, int stride)
   h->last_stride = stride;
   if (h->cfg.controller == MPPI_CONTROLLER_TUBE)
     return computeControlTube(h, x0, stride);
+  if (h->cfg.controller == MPPI_CONTROLLER_ROBUST)
+    return computeControlRobust(h, x0, stride);
   return computeControlVanilla(h, x0, stride);
 }
 
@@ -770,7 +1030,9 @@ mppi_status mppi_get_state_seq(mppi_handle h, float* x)
   CHECK_HANDLE(h);
   if (!x)
     return fail(h, MPPI_ERR_INVALID_ARG, "null");
-  std::copy(h->state_h.begin(), h->state_h.end(), x);
+  // RobustMPPI::getTargetStateSeq returns the nominal state trajectory (robust_mppi_controller.cuh:131-134)
+  const std::vector<float>& src = h->cfg.controller == MPPI_CONTROLLER_ROBUST ? h->nominal_state_h : h->state_h;
+  std::copy(src.begin(), src.end(), x);
   return MPPI_OK;
 }
 mppi_status mppi_get_nominal_control_seq(mppi_handle h, float* u)
@@ -793,6 +1055,11 @@ mppi_status mppi_get_nominal_state_seq(mppi_handle h, float* x)
   std::copy(h->nominal_state_h.begin(), h->nominal_state_h.end(), x);
   return MPPI_OK;
 }
+
+static void saveControlHistory(int steps, const std::vector<float>& u, std::vector<float>& hist, int C);
+static void slideSequence(std::vector<float>& u, int T, int C, int steps, const float* zero, const float* scale);
+static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, int stride);
+static mppi_status rmNominalStateTrajectory(mppi_handle h);
 
 /** reference: controllers/controller.cuh:602-615 */
 static void saveControlHistory(int steps, const std::vector<float>& u, std::vector<float>& hist, int C)
@@ -835,6 +1102,9 @@ mppi_status mppi_slide(mppi_handle h, int steps)
   const int T = h->cfg.num_timesteps, C = h->C;
   if (steps < 0 || steps > T)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_slide: steps out of range");
+  if (h->cfg.controller == MPPI_CONTROLLER_ROBUST)
+    return MPPI_OK;  // slideControlSequence is empty there (robust_mppi_controller.cuh:178): the slide is part of
+                     // updateImportanceSamplingControl
   std::vector<float> zero(C);
   h->model->getZeroControl(zero.data());
   if (h->cfg.controller == MPPI_CONTROLLER_TUBE)
@@ -859,6 +1129,83 @@ mppi_status mppi_slide(mppi_handle h, int steps)
   }
   saveControlHistory(steps, h->control_h, h->history_h, C);
   slideSequence(h->control_h, T, C, steps, zero.data(), h->slide_scale_h.data());
+  return MPPI_OK;
+}
+
+
+/* ---------------------------------------------------------------- Robust MPPI API -------------------------------- */
+mppi_status mppi_set_rmppi_params(mppi_handle h, float value_function_threshold, int num_candidates,
+                                  int samples_per_candidate)
+{
+  CHECK_HANDLE(h);
+  if (h->cfg.controller != MPPI_CONTROLLER_ROBUST)
+    return fail(h, MPPI_ERR_STATE, "mppi_set_rmppi_params: the handle is not a Robust MPPI controller");
+  // updateNumCandidates (robust_mppi_controller.cu:414-448): odd, >= 3, candidates * samples <= NUM_ROLLOUTS
+  if (num_candidates < 3)
+    return fail(h, MPPI_ERR_INVALID_ARG, "ERROR: number of candidates must be greater or equal to 3");
+  if (num_candidates % 2 == 0)
+    return fail(h, MPPI_ERR_INVALID_ARG, "ERROR: number of candidates must be odd");
+  if (samples_per_candidate <= 0 || (long long)num_candidates * samples_per_candidate > h->cfg.num_rollouts)
+    return fail(h, MPPI_ERR_INVALID_ARG, "ERROR: (number of candidates) * (SAMPLES_PER_CANDIDATE) cannot exceed NUM_ROLLOUTS");
+  h->value_function_threshold = value_function_threshold;
+  h->num_candidates = num_candidates;
+  h->samples_per_candidate = samples_per_candidate;
+  return MPPI_OK;
+}
+
+mppi_status mppi_set_feedback_gains(mppi_handle h, const float* gains, int accumulate_all_states)
+{
+  CHECK_HANDLE(h);
+  if (!gains)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_feedback_gains: null");
+  if (h->cfg.controller != MPPI_CONTROLLER_ROBUST)
+    return fail(h, MPPI_ERR_STATE, "mppi_set_feedback_gains: the handle is not a Robust MPPI controller");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  std::string err;
+  mppi_status st = h->model->setFeedbackGains(gains, h->cfg.num_timesteps, accumulate_all_states != 0, h->stream, err);
+  if (st != MPPI_OK)
+    return fail(h, st, err);
+  h->gains_set = true;
+  h->fb_accumulate_all = accumulate_all_states != 0;
+  return MPPI_OK;
+}
+
+/** reference: robust_mppi_controller.cu:548-568 (updateImportanceSamplingControl); the DDP gain computation at its end
+ *  (computeNominalFeedbackGains) is the caller's: mppi_set_feedback_gains */
+mppi_status mppi_update_importance_sampling_control(mppi_handle h, const float* state, int stride)
+{
+  CHECK_HANDLE(h);
+  if (!state || stride < 0)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_update_importance_sampling_control: null state or negative stride");
+  if (h->cfg.controller != MPPI_CONTROLLER_ROBUST)
+    return fail(h, MPPI_ERR_STATE, "mppi_update_importance_sampling_control: the handle is not a Robust MPPI controller");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const int T = h->cfg.num_timesteps, C = h->C;
+  h->real_stride = stride;
+  MPPI_TRY(rmNominalStateAndStride(h, state, stride));
+  saveControlHistory(h->nominal_stride, h->nominal_control_h, h->nominal_history_h, C);
+  saveControlHistory(h->real_stride, h->control_h, h->history_h, C);
+  std::vector<float> zero(C);
+  h->model->getZeroControl(zero.data());
+  slideSequence(h->nominal_control_h, T, C, h->nominal_stride, zero.data(), h->slide_scale_h.data());
+  return rmNominalStateTrajectory(h);
+}
+
+mppi_status mppi_get_rmppi_state(mppi_handle h, float* nominal_state, int* best_index, int* nominal_stride,
+                                 float* candidate_free_energy)
+{
+  CHECK_HANDLE(h);
+  if (h->cfg.controller != MPPI_CONTROLLER_ROBUST)
+    return fail(h, MPPI_ERR_STATE, "mppi_get_rmppi_state: the handle is not a Robust MPPI controller");
+  if (nominal_state)
+    std::copy(h->rm_nominal_state.begin(), h->rm_nominal_state.end(), nominal_state);
+  if (best_index)
+    *best_index = h->best_index;
+  if (nominal_stride)
+    *nominal_stride = h->nominal_stride;
+  if (candidate_free_energy)
+    for (int i = 0; i < h->num_candidates; i++)
+      candidate_free_energy[i] = i < (int)h->rm_cand_free_energy.size() ? h->rm_cand_free_energy[i] : 0.0f;
   return MPPI_OK;
 }
 

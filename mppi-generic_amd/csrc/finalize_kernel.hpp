@@ -25,7 +25,8 @@ namespace kernels
 struct FinalizeArgs
 {
   const float* control_in_d;  ///< [D][T][C]  (the sampler's control means after the last iteration)
-  const float* history_d;     ///< [2][C] control history (row 0 older), shared by the systems that smooth
+  const float* history_d;     ///< [2][C] control history (row 0 older); system z uses history_d + z * history_stride
+  int history_stride;         ///< 0: one history shared by the systems that smooth (Vanilla / Tube); 2*C: one each (RMPPI)
   const float* x0_d;          ///< [D][S]
   float* control_out_d;       ///< [D][T][C]
   float* state_out_d;         ///< [D][T][S]
@@ -80,8 +81,8 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
   {
     for (int i = ty; i < C; i += BY)
     {
-      buf[0 * C + i] = a.history_d[0 * C + i];
-      buf[1 * C + i] = a.history_d[1 * C + i];
+      buf[0 * C + i] = a.history_d[z * a.history_stride + 0 * C + i];
+      buf[1 * C + i] = a.history_d[z * a.history_stride + 1 * C + i];
       buf[(T + 2) * C + i] = uin[(T - 1) * C + i];
       buf[(T + 3) * C + i] = uin[(T - 1) * C + i];
     }

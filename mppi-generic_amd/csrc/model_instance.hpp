@@ -21,6 +21,8 @@
 #include "reduce_kernels.hpp"
 #include "finalize_kernel.hpp"
 #include "rollout_pipeline_kernel.hpp"
+#include "rmppi_kernels.hpp"
+#include "mppi_amd/feedback_controllers/ddp_feedback.hpp"
 #include "mppi_amd/sampling_distributions/colored_noise.hpp"
 
 namespace mppi
@@ -79,6 +81,34 @@ struct ModelBase
   virtual size_t noiseFloatsPerRollout(int T) const = 0;
   /** the sampled noise eps[K_local][T][C] the next launch would use, written to out_d (generator parity tests) */
   virtual mppi_status launchNoiseDump(const SamplerLaunchState& s, float* out_d, hipStream_t stream, std::string& err) = 0;
+  /* ---- Robust MPPI (rmppi_kernels.hpp); default: the model is not instantiated for it ---- */
+  virtual bool supportsRMPPI() const
+  {
+    return false;
+  }
+  /** DDP feedback gains [T][S][C] (ddp.cuh:18-60) -> device; accumulate_all_states: see ddp_feedback.hpp */
+  virtual mppi_status setFeedbackGains(const float* gains, int T, bool accumulate_all_states, hipStream_t stream,
+                                       std::string& err)
+  {
+    err = "model is not instantiated for Robust MPPI";
+    return MPPI_ERR_UNSUPPORTED;
+  }
+  virtual mppi_status launchInitEval(const kernels::InitEvalArgs& a, const SamplerLaunchState& s, hipStream_t stream,
+                                     std::string& err)
+  {
+    err = "model is not instantiated for Robust MPPI";
+    return MPPI_ERR_UNSUPPORTED;
+  }
+  virtual mppi_status launchRMPPI(int bx, const kernels::RMPPIArgs& a, const SamplerLaunchState& s, hipStream_t stream,
+                                  std::string& err)
+  {
+    err = "model is not instantiated for Robust MPPI";
+    return MPPI_ERR_UNSUPPORTED;
+  }
+  virtual size_t rmppiSharedBytes(int bx, int T)
+  {
+    return 0;
+  }
   virtual bool supportsShape(int bx, int by, int bz) const = 0;
   /** role-pipelined variant (rollout_pipeline_kernel.hpp) available for this model? */
   virtual bool supportsPipeline() const
@@ -197,9 +227,126 @@ struct has_costmap<T, std::void_t<decltype(std::declval<T&>().costmap_d_)>> : st
  * parameters, control ranges and blobs are shared.
  */
 template <class DYN_T, class COST_T, class SAMPLING_T, class SHAPES, int FIN_BY = 1, class DYN_FAST_T = void,
-          class FAST_SHAPES = Shapes<>, bool PIPELINE = false>
+          class FAST_SHAPES = Shapes<>, bool PIPELINE = false, bool RMPPI = false>
 struct ModelT : ModelBase
 {
+  /* ---- Robust MPPI: block = (64 rollouts, 1, 2 systems), one lane per rollout and system ---- */
+  DeviceDDP<DYN_T> fb;
+  float* gains_d = nullptr;
+  int gains_T = 0;
+  bool supportsRMPPI() const override
+  {
+    return RMPPI;
+  }
+  mppi_status setFeedbackGains(const float* gains, int T, bool accumulate_all_states, hipStream_t stream,
+                               std::string& err) override
+  {
+    if constexpr (RMPPI)
+    {
+      const size_t n = (size_t)T * DYN_T::STATE_DIM * DYN_T::CONTROL_DIM;
+      hipError_t e = hipSuccess;
+      if (gains_T != T)
+      {
+        e = hipStreamSynchronize(stream);
+        if (e == hipSuccess && gains_d)
+          e = hipFree(gains_d);
+        gains_d = nullptr;
+        if (e == hipSuccess)
+          e = hipMalloc((void**)&gains_d, n * sizeof(float));
+        gains_T = T;
+      }
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(gains_d, gains, n * sizeof(float), hipMemcpyHostToDevice, stream);
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(stream);
+      if (e != hipSuccess)
+      {
+        err = std::string("feedback gain upload: ") + hipGetErrorString(e);
+        return MPPI_ERR_HIP;
+      }
+      fb.fb_gain_traj_d_ = gains_d;
+      fb.num_timesteps_ = T;
+      fb.accumulate_all_states_ = accumulate_all_states;
+      return MPPI_OK;
+    }
+    return ModelBase::setFeedbackGains(gains, T, accumulate_all_states, stream, err);
+  }
+  size_t rmppiSharedBytes(int bx, int T) override
+  {
+    if constexpr (RMPPI)
+    {
+      smp.params_.num_timesteps = T;
+      smp.params_.num_distributions = 2;
+      return kernels::rmppiSharedBytes(dyn, cost, fb, smp, bx);
+    }
+    return 0;
+  }
+  mppi_status launchInitEval(const kernels::InitEvalArgs& a, const SamplerLaunchState& s, hipStream_t stream,
+                             std::string& err) override
+  {
+    if constexpr (RMPPI)
+    {
+      if (!blobsReady(err))
+        return MPPI_ERR_STATE;
+      prepSampler(s);
+      constexpr int BX = 64;
+      const size_t smem = kernels::initEvalSharedBytes<DYN_T, COST_T, SAMPLING_T>(dyn, cost, BX);
+      auto kfn = kernels::initEvalKernel<DYN_T, COST_T, SAMPLING_T, BX>;
+      if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(kfn, dim3((a.num_eval_rollouts + BX - 1) / BX), dim3(BX, 1, 1), smem, stream, dyn, cost, smp, a);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess)
+      {
+        err = std::string("initEvalKernel launch: ") + hipGetErrorString(e);
+        return MPPI_ERR_HIP;
+      }
+      return MPPI_OK;
+    }
+    return ModelBase::launchInitEval(a, s, stream, err);
+  }
+  mppi_status launchRMPPI(int bx, const kernels::RMPPIArgs& a, const SamplerLaunchState& s, hipStream_t stream,
+                          std::string& err) override
+  {
+    if constexpr (RMPPI)
+    {
+      if (!blobsReady(err))
+        return MPPI_ERR_STATE;
+      if (!fb.fb_gain_traj_d_ || fb.num_timesteps_ != s.num_timesteps)
+      {
+        err = "Robust MPPI needs the DDP feedback gains [T][S][C] (mppi_set_feedback_gains) before it can run";
+        return MPPI_ERR_STATE;
+      }
+      if (bx != 64)
+      {
+        err = "Robust MPPI rollout kernel is instantiated for 64 rollouts per block";
+        return MPPI_ERR_LAUNCH_SHAPE;
+      }
+      prepSampler(s);
+      constexpr int BX = 64;
+      const size_t smem = kernels::rmppiSharedBytes(dyn, cost, fb, smp, BX);
+      if (smem > MAX_LDS_BYTES)
+      {
+        err = "RMPPI rollout kernel needs " + std::to_string(smem) + " B of LDS per block; gfx950 has 163840";
+        return MPPI_ERR_LDS_OVERFLOW;
+      }
+      const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
+      auto kfn = in_loop ? kernels::rolloutRMPPIKernel<DYN_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, BX, SAMPLING_T::IN_LOOP_DRAW>
+                         : kernels::rolloutRMPPIKernel<DYN_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, BX, false>;
+      if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(kfn, dim3((a.base.num_rollouts + BX - 1) / BX), dim3(BX, 1, 2), smem, stream, dyn, cost, fb, smp, a);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess)
+      {
+        err = std::string("rolloutRMPPIKernel launch: ") + hipGetErrorString(e);
+        return MPPI_ERR_HIP;
+      }
+      return MPPI_OK;
+    }
+    return ModelBase::launchRMPPI(bx, a, s, stream, err);
+  }
+
   bool supportsPipeline() const override
   {
     return PIPELINE;
@@ -249,6 +396,8 @@ struct ModelT : ModelBase
 
   ~ModelT() override
   {
+    if (gains_d)
+      (void)hipFree(gains_d);
     if (basis_d)
       (void)hipFree(basis_d);
     if (weights_d)

@@ -33,12 +33,12 @@ namespace engine
 using CartpoleSampler = sampling_distributions::GaussianDistribution<CartpoleDynamicsParams>;
 using CartpoleModel = ModelT<CartpoleDynamics, CartpoleQuadraticCost, CartpoleSampler,
                              Shapes<Shape<64, 1, 1>, Shape<64, 1, 2>, Shape<32, 1, 1>, Shape<64, 4, 1>, Shape<16, 4, 1>>,
-                             /*FIN_BY=*/1, void, Shapes<>, /*PIPELINE=*/true>;
+                             /*FIN_BY=*/1, void, Shapes<>, /*PIPELINE=*/true, /*RMPPI=*/true>;
 
 using DISampler = sampling_distributions::GaussianDistribution<DoubleIntegratorParams>;
 using DIModel = ModelT<DoubleIntegratorDynamics, DoubleIntegratorCircleCost, DISampler,
                        Shapes<Shape<64, 1, 1>, Shape<64, 1, 2>, Shape<32, 2, 2>, Shape<64, 2, 1>>, /*FIN_BY=*/1, void,
-                       Shapes<>, /*PIPELINE=*/true>;
+                       Shapes<>, /*PIPELINE=*/true, /*RMPPI=*/true>;
 
 /* AutoRally: MLP dynamics + costmap cost (reference: instantiations/autorally_mppi/autorally_mppi.cuh:10-13 uses
  * dynamics_rollout_dim (8, 16, 1)).  BY lanes of a rollout share the neurons of a layer. */

@@ -92,24 +92,22 @@ __host__ inline size_t rolloutSharedBytes(const DYN_T& dyn, const COST_T& cost, 
 }
 
 /**
- * Epilogue shared by the rollout kernels: trajectory cost = running/T + terminal/T (mppi_common.cu:144, :843-853),
+ * Epilogue shared by the rollout kernels: given the trajectory cost `total` of the thread's rollout,
  * block-local softmin record {U_b, rho_b, eta_b, sum w^2} from the LDS sample rows, optional sample dump.
  * Block-uniform; contains barriers.  `writer` marks the one thread that publishes a rollout's result.
  */
 template <class SAMPLING_T, int C, int BX, int BZ, int NTHREADS>
-__device__ inline void blockSoftminEpilogue(SAMPLING_T* sampling, const RolloutArgs& args, const float terminal_cost,
-                                            const float running_cost, const bool writer, const bool valid,
-                                            const int global_idx, const int shared_idx, const int thread_idz,
-                                            const int tid_flat, const int block_idx, const int nrows,
-                                            float* theta_d_shared, float* cost_s, float* w_s)
+__device__ inline void blockSoftminEpilogueCost(SAMPLING_T* sampling, const RolloutArgs& args, const float total,
+                                                const bool writer, const bool valid, const int global_idx,
+                                                const int shared_idx, const int thread_idz, const int tid_flat,
+                                                const int block_idx, const int nrows, float* theta_d_shared,
+                                                float* cost_s, float* w_s)
 {
   const int num_timesteps = args.num_timesteps;
   const int num_rollouts = args.num_rollouts;
   float traj_cost = INFINITY;
   if (writer)
   {
-    const float total =
-        running_cost / (float)num_timesteps + terminal_cost / (float)num_timesteps;
     if (valid)
     {
       traj_cost = total;
@@ -176,6 +174,21 @@ __device__ inline void blockSoftminEpilogue(SAMPLING_T* sampling, const RolloutA
           theta_d_shared[(size_t)(BX * z + i) * row_stride + j];
     }
   }
+}
+
+/** trajectory cost = running/T + terminal/T (mppi_common.cu:144, :843-853), then the shared block-softmin epilogue */
+template <class SAMPLING_T, int C, int BX, int BZ, int NTHREADS>
+__device__ inline void blockSoftminEpilogue(SAMPLING_T* sampling, const RolloutArgs& args, const float terminal_cost,
+                                            const float running_cost, const bool writer, const bool valid,
+                                            const int global_idx, const int shared_idx, const int thread_idz,
+                                            const int tid_flat, const int block_idx, const int nrows,
+                                            float* theta_d_shared, float* cost_s, float* w_s)
+{
+  const float total =
+      running_cost / (float)args.num_timesteps + terminal_cost / (float)args.num_timesteps;
+  blockSoftminEpilogueCost<SAMPLING_T, C, BX, BZ, NTHREADS>(sampling, args, total, writer, valid, global_idx, shared_idx,
+                                                             thread_idz, tid_flat, block_idx, nrows, theta_d_shared,
+                                                             cost_s, w_s);
 }
 
 template <class DYN_T, class COST_T, class SAMPLING_T, int BX, int BY, int BZ, bool DRAW_IN_LOOP>

@@ -6,6 +6,7 @@
 #include "oracle_models.hpp"
 #include "oracle_rng.hpp"
 #include "oracle_colored.hpp"
+#include "oracle_rmppi.hpp"
 
 #include <chrono>
 
@@ -240,6 +241,8 @@ void oracle_set_nominal_control(void* h, const float* u)
 {
   auto* c = (Controller*)h;
   std::copy(u, u + c->control.size(), c->control.begin());
+  if (c->D == 2) /* Tube: nominal_control_trajectory_ too; RMPPI: nominal_control_trajectory_ = init_control_traj */
+    std::copy(u, u + c->control.size(), c->nominal_control.begin());
 }
 void oracle_iterate(void* h, const float* x0, const float* mean, const float* eps, int stride, int iter, float* u_new)
 {
@@ -348,6 +351,89 @@ void oracle_colored_compute_control(void* h, const float* x0, int stride, const 
   for (int it = 0; it < c->num_iters; it++)
     coloredNoiseGemm(K, T, C, p, stride, z + (size_t)it * K * C * 2 * (T + 1), &eps[(size_t)it * K * T * C]);
   c->coloredComputeControl(x0, stride, eps.data());
+}
+
+/* ----- Robust MPPI ----- */
+void* oracle_rmppi_create(void* h)
+{
+  auto* r = new RobustController();
+  r->init((Controller*)h);
+  return r;
+}
+void oracle_rmppi_destroy(void* r)
+{
+  delete (RobustController*)r;
+}
+void oracle_rmppi_set_params(void* r, float value_function_threshold, int num_candidates, int samples_per_candidate)
+{
+  auto* rc = (RobustController*)r;
+  rc->value_function_threshold = value_function_threshold;
+  rc->num_candidates = num_candidates;
+  rc->samples_per_candidate = samples_per_candidate;
+}
+void oracle_rmppi_set_gains(void* r, const float* gains, int accumulate_all_states)
+{
+  auto* rc = (RobustController*)r;
+  std::copy(gains, gains + rc->fb.fb_gain_traj.size(), rc->fb.fb_gain_traj.begin());
+  rc->fb.accumulate_all_states = accumulate_all_states != 0;
+}
+void oracle_rmppi_feedback(void* r, const float* x_act, const float* x_goal, int t, float* out)
+{
+  auto* rc = (RobustController*)r;
+  for (int j = 0; j < rc->fb.C; j++)
+    out[j] = 0.0f;
+  rc->fb.k(x_act, x_goal, t, out);
+}
+void oracle_rmppi_line_search(void* r, int stride, float* weights /*[3][nc]*/, int* strides /*[nc]*/)
+{
+  auto* rc = (RobustController*)r;
+  rc->computeLineSearchWeights();
+  rc->computeImportanceSamplerStride(stride);
+  std::copy(rc->line_search_weights.begin(), rc->line_search_weights.end(), weights);
+  std::copy(rc->strides.begin(), rc->strides.end(), strides);
+}
+void oracle_rmppi_candidates(void* r, const float* x_k, const float* x_kp1, const float* real_kp1, float* out /*[nc][S]*/)
+{
+  auto* rc = (RobustController*)r;
+  rc->computeLineSearchWeights();
+  rc->getInitNominalStateCandidates(x_k, x_kp1, real_kp1);
+  std::copy(rc->candidate_states.begin(), rc->candidate_states.end(), out);
+}
+int oracle_rmppi_best_index(void* r, const float* candidate_costs, float* free_energy /*[nc]*/)
+{
+  auto* rc = (RobustController*)r;
+  rc->candidate_costs.assign(candidate_costs, candidate_costs + (size_t)rc->num_candidates * rc->samples_per_candidate);
+  rc->computeBestIndex();
+  std::copy(rc->candidate_free_energy.begin(), rc->candidate_free_energy.end(), free_energy);
+  return rc->best_index;
+}
+/** x0 [2][S], mean [2][T][C], v [2][K][T][C] in/out, costs [2][K] */
+void oracle_rmppi_rollout_costs(void* r, const float* x0, const float* mean, float* v, float* costs)
+{
+  auto* rc = (RobustController*)r;
+  Controller* c = rc->c;
+  rmppiRolloutCosts(*c->dyn, *c->cost, c->smp, rc->fb, c->dt, c->lambda, c->alpha, rc->value_function_threshold, x0, mean,
+                    v, costs);
+}
+void oracle_rmppi_update_importance_sampling(void* r, const float* state, int stride, const float* eps)
+{
+  ((RobustController*)r)->updateImportanceSamplingControl(state, stride, eps);
+}
+void oracle_rmppi_compute_control(void* r, const float* state, int stride, const float* eps)
+{
+  ((RobustController*)r)->computeControl(state, stride, eps);
+}
+/** out: nominal_state [S], then best_index, nominal_stride; fe: candidate free energy [nc]; costs: [nc * ns] (may be null) */
+void oracle_rmppi_get_state(void* r, float* nominal_state, int* best_and_stride, float* fe, float* cand_costs)
+{
+  auto* rc = (RobustController*)r;
+  std::copy(rc->nominal_state.begin(), rc->nominal_state.end(), nominal_state);
+  best_and_stride[0] = rc->best_index;
+  best_and_stride[1] = rc->nominal_stride;
+  for (size_t i = 0; i < rc->candidate_free_energy.size(); i++)
+    fe[i] = rc->candidate_free_energy[i];
+  if (cand_costs)
+    std::copy(rc->candidate_costs.begin(), rc->candidate_costs.end(), cand_costs);
 }
 
 /* ----- RNG ----- */

@@ -77,6 +77,21 @@ def lib():
         L.oracle_colored_weights.argtypes = [C.c_int, C.c_int, _f32p, C.c_float, _f32p, _f32p]
         L.oracle_philox_spectrum.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
         L.oracle_colored_compute_control.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, _f32p, C.c_float, C.c_float]
+        _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+        L.oracle_rmppi_create.restype = C.c_void_p
+        L.oracle_rmppi_create.argtypes = [C.c_void_p]
+        L.oracle_rmppi_destroy.argtypes = [C.c_void_p]
+        L.oracle_rmppi_set_params.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
+        L.oracle_rmppi_set_gains.argtypes = [C.c_void_p, _f32p, C.c_int]
+        L.oracle_rmppi_feedback.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int, _f32p]
+        L.oracle_rmppi_line_search.argtypes = [C.c_void_p, C.c_int, _f32p, _i32p]
+        L.oracle_rmppi_candidates.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p]
+        L.oracle_rmppi_best_index.restype = C.c_int
+        L.oracle_rmppi_best_index.argtypes = [C.c_void_p, _f32p, _f32p]
+        L.oracle_rmppi_rollout_costs.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p]
+        L.oracle_rmppi_update_importance_sampling.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p]
+        L.oracle_rmppi_compute_control.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p]
+        L.oracle_rmppi_get_state.argtypes = [C.c_void_p, _f32p, _i32p, _f32p, C.c_void_p]
         L.oracle_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
         L.oracle_philox_normal.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, _f32p]
@@ -263,6 +278,71 @@ def lstm_forward(input_dim, hidden_dim, out_layers, lstm_blob, fnn_blob, inputs)
     lib().oracle_lstm_forward(input_dim, hidden_dim, arr, len(out_layers), _f32(lstm_blob).reshape(-1),
                               _f32(fnn_blob).reshape(-1), x, x.shape[0], out)
     return out
+
+
+class RobustOracle:
+    """RobustMPPIController logic on top of an Oracle created with D = 2 (system 0 nominal, 1 real)"""
+
+    def __init__(self, oracle, value_function_threshold=1000.0, num_candidates=9, samples_per_candidate=32):
+        assert oracle.D == 2
+        self.o, self.L = oracle, oracle.L
+        self.r = self.L.oracle_rmppi_create(oracle.h)
+        self.nc, self.ns = num_candidates, samples_per_candidate
+        self.L.oracle_rmppi_set_params(self.r, value_function_threshold, num_candidates, samples_per_candidate)
+
+    def __del__(self):
+        if getattr(self, "r", None):
+            self.L.oracle_rmppi_destroy(self.r)
+            self.r = None
+
+    def set_gains(self, gains, accumulate_all_states=False):
+        g = _f32(gains)
+        assert g.shape == (self.o.T, self.o.S, self.o.C)
+        self.L.oracle_rmppi_set_gains(self.r, g.reshape(-1), int(accumulate_all_states))
+
+    def feedback(self, x_act, x_goal, t):
+        out = np.zeros(self.o.C, np.float32)
+        self.L.oracle_rmppi_feedback(self.r, _f32(x_act).reshape(-1), _f32(x_goal).reshape(-1), t, out)
+        return out
+
+    def line_search(self, stride):
+        w = np.zeros((3, self.nc), np.float32)
+        s = np.zeros(self.nc, np.int32)
+        self.L.oracle_rmppi_line_search(self.r, stride, w, s)
+        return w, s
+
+    def candidates(self, x_k, x_kp1, real_kp1):
+        out = np.zeros((self.nc, self.o.S), np.float32)
+        self.L.oracle_rmppi_candidates(self.r, _f32(x_k).reshape(-1), _f32(x_kp1).reshape(-1), _f32(real_kp1).reshape(-1), out)
+        return out
+
+    def best_index(self, candidate_costs):
+        fe = np.zeros(self.nc, np.float32)
+        c = _f32(candidate_costs).reshape(-1)
+        assert c.size == self.nc * self.ns
+        return self.L.oracle_rmppi_best_index(self.r, c, fe), fe
+
+    def rollout_costs(self, x0, mean, v):
+        o = self.o
+        v = _f32(v).reshape(2, o.K, o.T, o.C).copy()
+        costs = np.zeros((2, o.K), np.float32)
+        self.L.oracle_rmppi_rollout_costs(self.r, _f32(x0).reshape(-1), _f32(mean).reshape(-1), v, costs)
+        return costs, v
+
+    def update_importance_sampling(self, state, stride, eps=None):
+        o = self.o
+        e = np.zeros((o.K, o.T, o.C), np.float32) if eps is None else _f32(eps).reshape(o.K, o.T, o.C)
+        self.L.oracle_rmppi_update_importance_sampling(self.r, _f32(state).reshape(-1), stride, e)
+
+    def compute_control(self, state, stride, eps):
+        self.L.oracle_rmppi_compute_control(self.r, _f32(state).reshape(-1), stride, _f32(eps).reshape(-1))
+
+    def state(self, with_costs=False):
+        ns = np.zeros(self.o.S, np.float32)
+        bs = np.zeros(2, np.int32)
+        fe = np.zeros(self.nc, np.float32)
+        self.L.oracle_rmppi_get_state(self.r, ns, bs, fe, None)
+        return ns, int(bs[0]), int(bs[1]), fe
 
 
 def colored_noise(z, exponents, offset_decay_rate=0.97, fmin=0.0, offset_t=1, flavour="gemm"):

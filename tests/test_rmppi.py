@@ -1,0 +1,198 @@
+"""Robust MPPI: DDP feedback k(), init-eval kernel, rolloutRMPPIKernel, controller logic."""
+import numpy as np
+import pytest
+
+import mppi_generic_amd as m
+import pyoracle as po
+from common import cartpole_cfg_lr, di_cfg, host_noise, make_engine, make_oracle, ulp_diff
+
+U_TOL = 1e-5
+
+
+def _rm_cfg(model="di", K=1024, T=40, num_iters=1):
+    if model == "di":
+        cfg = di_cfg(K=K, T=T, tube=True, num_iters=num_iters)
+        cfg["control_cost_coeff"] = [0.3, 0.2]  # exercise the likelihood-ratio and feedback cost terms
+        cfg["ranges"] = [[-3.0, 3.0], [-3.0, 3.0]]
+    else:
+        cfg = cartpole_cfg_lr(K=K, T=T)
+        cfg["D"] = 2
+        cfg["num_iters"] = num_iters
+        cfg["std_dev"] = [5.0, 4.0]  # different exploration for the nominal and the real system
+    return cfg
+
+
+def _gains(T, S, C, seed=1, scale=0.4):
+    return np.random.default_rng(seed).uniform(-scale, scale, (T, S, C)).astype(np.float32)
+
+
+def _make_pair(cfg, thr=1000.0, nc=9, ns=32, **kw):
+    eng = m.RobustMPPIController(cfg["model"], cfg["K"], cfg["T"], cfg["dt"], cfg["lambda_"], cfg["alpha"], cfg["num_iters"],
+                                 seed=42, **kw)
+    if cfg["dyn"] is not None:
+        eng.setDynamicsParams(cfg["dyn"])
+    eng.setCostParams(cfg["cost"])
+    if cfg["ranges"] is not None:
+        eng.setControlRanges(cfg["ranges"])
+    eng.setSamplingParams(cfg["std_dev"], cfg["control_cost_coeff"])
+    eng.setRMPPIParams(thr, nc, ns)
+    orc = make_oracle(cfg)
+    rob = po.RobustOracle(orc, thr, nc, ns)
+    return eng, orc, rob
+
+
+# ------------------------------------------------------------------ CPU: oracle pinned on the reference's KATs --------
+def test_line_search_weights_strides_candidates_known_answers():
+    """reference: tests/controllers/rmppi_test.cu:226-292 (LineSearchWeights_9, ImportanceSampler_Stride_2 / _4,
+    InitEvalSelection_Weights)"""
+    rob = po.RobustOracle(make_oracle(_rm_cfg(K=576, T=10)), 1000.0, 9, 64)
+    w, s2 = rob.line_search(2)
+    known = np.array([[1, .75, .5, .25, 0, 0, 0, 0, 0], [0, .25, .5, .75, 1, .75, .5, .25, 0],
+                      [0, 0, 0, 0, 0, .25, .5, .75, 1]], np.float32)
+    assert np.array_equal(w, known)
+    assert list(s2) == [0, 1, 1, 2, 2, 2, 2, 2, 2]
+    _, s4 = rob.line_search(4)
+    assert list(s4) == [0, 1, 2, 3, 4, 4, 4, 4, 4]
+    cand = rob.candidates([-4, 0, 0, 0], [0, 4, 0, 0], [4, 4, 0, 0])
+    want = np.zeros((9, 4), np.float32)
+    want[:, 0] = [-4, -3, -2, -1, 0, 1, 2, 3, 4]
+    want[:, 1] = [0, 1, 2, 3, 4, 4, 4, 4, 4]
+    assert np.array_equal(cand, want)
+
+
+def test_best_candidate_selection():
+    """reference: tests/controllers/rmppi_test.cu:357-421 (GetCandidateBaseline, ComputeBestCandidate): the LAST
+    candidate whose free energy is below the threshold"""
+    cfg = _rm_cfg(K=576, T=10)
+    lam = cfg["lambda_"]
+    rng = np.random.default_rng(3)
+    for thr in (1000.0, 30.0, 12.0):
+        rob = po.RobustOracle(make_oracle(cfg), thr, 9, 64)
+        costs = (rng.uniform(5, 60, (9, 64)) + np.arange(9)[:, None] * 4).astype(np.float32)
+        best, fe = rob.best_index(costs)
+        base = costs.min()
+        want_fe = -lam * np.log(np.exp(-(costs.astype(np.float64) - base) / lam).mean(1)) + base
+        np.testing.assert_allclose(fe, want_fe, rtol=2e-6)
+        below = np.nonzero(want_fe < thr)[0]
+        assert best == (below[-1] if below.size else 0)
+
+
+def test_ddp_feedback_reference_behaviour_and_sum_mode():
+    """reference: feedback_controllers/DDP/ddp.cu:11-45 — even CONTROL_DIM: only the last state's gain row survives;
+    odd CONTROL_DIM and accumulate_all_states: the full K (x - x*)"""
+    for model, S, C in (("di", 4, 2), ("cartpole", 4, 1)):
+        cfg = _rm_cfg(model, K=64, T=8)
+        rob = po.RobustOracle(make_oracle(cfg))
+        g = _gains(8, S, C)
+        x, xs = np.array([1, -2, 0.5, 3], np.float32), np.array([0.5, 1, -1, 2], np.float32)
+        e = x - xs
+        full = (g[3] * e[:, None]).sum(0)
+        rob.set_gains(g, accumulate_all_states=True)
+        np.testing.assert_allclose(rob.feedback(x, xs, 3), full, rtol=1e-6, atol=1e-7)
+        rob.set_gains(g, accumulate_all_states=False)
+        want = g[3, S - 1] * e[S - 1] if C % 2 == 0 else full
+        np.testing.assert_allclose(rob.feedback(x, xs, 3), want, rtol=1e-6, atol=1e-7)
+
+
+def test_rmppi_rollout_zero_gains_identical_systems():
+    """with no feedback, identical initial states and identical exploration the real and nominal costs coincide
+    (the nominal cost formula collapses to A + LR) — reference invariant of tests/mppi_core/rmppi_kernel_tests.cu"""
+    cfg = _rm_cfg("di", K=256, T=30)
+    orc = make_oracle(cfg)
+    rob = po.RobustOracle(orc)
+    rob.set_gains(np.zeros((30, 4, 2), np.float32))
+    eps = host_noise(1, 256, 30, 2)[0]
+    mean = np.tile((0.1 * np.ones((30, 2), np.float32))[None], (2, 1, 1))
+    v = orc.set_gaussian_controls(mean, eps, 1, 0)
+    costs, _ = rob.rollout_costs(np.tile(cfg["x0"], (2, 1)), mean, v)
+    np.testing.assert_allclose(costs[0], costs[1], rtol=2e-6)
+
+
+# ------------------------------------------------------------------ GPU parity -----------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,acc_all,mode", [("di", False, "injected"), ("di", True, "injected"), ("di", False, "philox"),
+                                                ("cartpole", False, "injected"), ("cartpole", False, "philox")])
+def test_rmppi_rollout_costs_bit_exact(gpu, model, acc_all, mode):
+    cfg = _rm_cfg(model, K=1000, T=37)  # ragged last block, odd horizon
+    eng, orc, rob = _make_pair(cfg, thr=40.0, save_samples=True)
+    S, C, T, K = eng.STATE_DIM, eng.CONTROL_DIM, cfg["T"], cfg["K"]
+    g = _gains(T, S, C)
+    eng.setFeedbackGains(g, acc_all)
+    rob.set_gains(g, acc_all)
+    mean = (0.3 * np.sin(np.arange(T * C, dtype=np.float32) * 0.2)).reshape(T, C)
+    eng.updateImportanceSampler(mean)
+    if mode == "injected":
+        eps = host_noise(1, K, T, C)[0]
+        eng.injectNoise(eps)
+    else:
+        eps = po.philox_normal(42, 0, K, T, C)
+    x0 = np.stack([cfg["x0"], cfg["x0"] + np.array([0.3, -0.2, 0.1, 0.05], np.float32)])
+    got = eng.rolloutCosts(x0, 2)
+    means = np.tile(mean, (2, 1, 1))
+    v = orc.set_gaussian_controls(means, eps, 2, 0)
+    want, v_fb = rob.rollout_costs(x0, means, v)
+    assert np.isfinite(got).all()
+    assert ulp_diff(got, want).max() == 0
+    assert ulp_diff(eng.getSampledControls(), v_fb).max() == 0  # feedback-filled clamped controls written back
+    assert np.abs(want[0] - want[1]).max() > 1e-3  # the two systems really differ
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["di", "cartpole"])
+def test_rmppi_closed_loop_parity(gpu, model):
+    """updateImportanceSamplingControl (candidates, init-eval kernel, best index, slide) + computeControl over several
+    steps with a disturbed real state, against the oracle"""
+    cfg = _rm_cfg(model, K=1024, T=40, num_iters=2)
+    nc, ns = 9, 32
+    eng, orc, rob = _make_pair(cfg, thr=25.0 if model == "di" else 2000.0, nc=nc, ns=ns)
+    S, C, T, K = eng.STATE_DIM, eng.CONTROL_DIM, cfg["T"], cfg["K"]
+    x = cfg["x0"].copy()
+    used = set()
+    for i in range(5):
+        g = _gains(T, S, C, seed=10 + i, scale=0.3)
+        eps = host_noise(3, K, T, C, seed=50 + i)
+        first = i == 0
+        eng.injectNoise(eps[1:] if first else eps)  # the first call does not evaluate candidates (nominal not set yet)
+        eng.updateImportanceSamplingControl(x, 2)
+        rob.update_importance_sampling(x, 2, eps[0])
+        ns_g, best_g, stride_g, fe_g = eng.getRMPPIState()
+        ns_o, best_o, stride_o, fe_o = rob.state()
+        assert best_g == best_o and stride_g == stride_o
+        assert np.array_equal(ns_g, ns_o)
+        if not first:
+            np.testing.assert_allclose(fe_g, fe_o, rtol=1e-5)
+            used.add(best_g)
+        eng.setFeedbackGains(g)
+        rob.set_gains(g)
+        eng.computeControl(x, 1)
+        rob.compute_control(x, 1, eps[1:])
+        assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
+        assert np.abs(eng.getNominalControlSeq() - orc.nominal_control()).max() <= U_TOL
+        assert np.abs(eng.getTargetStateSeq() - orc.nominal_state_traj()).max() <= 1e-4
+        st, so = eng.getStats(), orc.stats()
+        assert abs(st.nominal_sys.baseline - so["baseline"][0]) <= 1e-5 * abs(so["baseline"][0]) + 1e-6
+        assert abs(st.real_sys.baseline - so["baseline"][1]) <= 1e-5 * abs(so["baseline"][1]) + 1e-6
+        # the real system drifts away from the nominal one
+        x, _ = orc.model_step(x, orc.control()[0])
+        x = x + np.array([0.05, -0.03, 0.1, -0.05], np.float32)
+    assert len(used) >= 1
+
+
+@pytest.mark.gpu
+def test_rmppi_error_paths(gpu):
+    cfg = _rm_cfg("di", K=512, T=20)
+    eng, _, _ = _make_pair(cfg)
+    with pytest.raises(m.MPPIError) as e:
+        eng.computeControl(cfg["x0"], 1)  # no gains yet
+    assert e.value.status == 7 and "gains" in str(e.value)
+    for bad, msg in ((1, "greater or equal to 3"), (4, "must be odd"), (99, "cannot exceed")):
+        with pytest.raises(m.MPPIError) as e:
+            eng.setRMPPIParams(1000.0, bad, 32)
+        assert e.value.status == 1 and msg in str(e.value)
+    with pytest.raises(m.MPPIError) as e:
+        m.RobustMPPIController("autorally_nn", 512, 20, 0.02, 1.0)
+    assert e.value.status == 10
+    v = m.VanillaMPPIController("cartpole", 128, 10, 0.02, 1.0)
+    with pytest.raises(m.MPPIError) as e:
+        v._check(v._lib.mppi_set_feedback_gains(v._h, np.zeros(40, np.float32), 0))
+    assert e.value.status == 7
