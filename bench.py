@@ -100,9 +100,68 @@ def autorally_leg(device):
         "roofline": {"bound": "mfma", "kernel": "rolloutKernel<NeuralNetModelMFMA<7,2,3>,ARStandardCost,Gaussian,64,1,1>",
                      "achieved": round(achieved, 4), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 5),
                      "traffic": None, "algorithmic_flops_per_launch": f_alg, "avg_kernel_us": round(roll_us, 3),
-                     "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak = the fp32 vector peak; the kernel also "
-                             "carries 64 tanh per rollout-step, kinematics, costmap gathers and the Philox draw"},
+                     "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak = the fp32 vector peak; the kernel is bound by VALU "
+                             "issue, not by the matrix cores: 64 tanh per rollout-step (packed fp32), kinematics, costmap "
+                             "gathers and the Philox draw share the wave with 28 MFMAs per step; K=16384 is exactly one "
+                             "wave per SIMD"},
     }
+
+
+def lstm_colored_leg(device):
+    """BASELINE config 5: LSTM bicycle-slip dynamics (LSTM(6,16) + MLP {22,32,4}, synthetic weights) + ARStandardCost +
+    ColoredNoise sampler (exponents 1, offset decay 0.97), ColoredMPPI iteration, K=65536, T=200, one GPU.
+    MFMA roofline: F_alg = 2*(4H(I+H) + (H+I)*M + M*OUT)*K*T for the network + 2*(2T+2)*T*C*K for the colored-noise GEMM."""
+    from common import bicycle_lstm_cfg, make_engine
+    K, Tn = 65536, 200
+    cfg = bicycle_lstm_cfg(K=K, T=Tn, lambda_=1.0)
+    cfg["colored"] = ([1.0, 1.0], 0.97, 0.0)
+    eng = make_engine(cfg, device=device)
+    eng.uploadState(cfg["x0"])
+    eng.optimize(5, True)
+    n = 30
+    t0 = time.perf_counter()
+    eng.optimize(n, True)
+    wall = time.perf_counter() - t0
+    ms_total, ms_roll = eng.timeIterations(20)
+    roll_us = ms_roll / 20 * 1e3
+    f_net = 2.0 * (4 * 16 * (6 + 16) + (16 + 6) * 32 + 32 * 4) * K * Tn
+    f_noise = 2.0 * (2 * Tn + 2) * Tn * 2 * K
+    achieved = (f_net + f_noise) / (roll_us * 1e-6) / 1e12
+    return {
+        "workload": "LSTM bicycle-slip dynamics (LSTM(6,16) + MLP {22,32,4}, synthetic weights) + ARStandardCost + ColoredNoise "
+                    "sampler (exponents [1,1], offset_decay_rate 0.97), ColoredMPPI iteration, K=65536, T=200, block (64 "
+                    "rollouts x 4 MFMA lanes)",
+        "value": round(n / wall, 3), "unit": "MPPI iters/s", "ms_per_step": round(wall / n * 1e3, 6),
+        "roofline": {"bound": "mfma", "kernel": "rolloutKernel<BicycleSlipLSTMMFMA,ARStandardCost,ColoredNoise,64,1,1>",
+                     "achieved": round(achieved, 4), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 5),
+                     "traffic": None, "algorithmic_flops_per_launch": f_net + f_noise,
+                     "algorithmic_flops_network": f_net, "algorithmic_flops_colored_noise_gemm": f_noise,
+                     "avg_kernel_us": round(roll_us, 3),
+                     "note": "reference data flow for this config moves ~1.8 GB per iteration through HBM (cuRAND spectrum, "
+                             "cuFFT, rearrange, setGaussianControls, rollout, weighted reduction); here the samples never "
+                             "leave the CU"},
+    }
+
+
+def di_tube_leg(device):
+    """BASELINE config 3: DoubleIntegrator Tube-MPPI (CORL2020 parameters), K=8192, T=150, two systems per launch"""
+    from common import di_cfg, make_engine
+    cfg = di_cfg(K=8192, T=150, tube=True)
+    eng = make_engine(cfg, device=device)
+    eng.uploadState(np_tile(cfg["x0"], 2))
+    eng.optimize(50, True)
+    n = 500
+    t0 = time.perf_counter()
+    eng.optimize(n, True)
+    wall = time.perf_counter() - t0
+    return {"workload": "DoubleIntegrator + DoubleIntegratorCircleCost, Tube-MPPI iteration (actual + nominal system in one "
+                        "launch), K=8192, T=150", "value": round(n / wall, 3), "unit": "MPPI iters/s",
+            "ms_per_step": round(wall / n * 1e3, 6)}
+
+
+def np_tile(x, d):
+    import numpy as np
+    return np.tile(x, (d, 1))
 
 
 def main():
@@ -111,7 +170,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--primary-only", action="store_true", help="skip the secondary AutoRally-NN leg")
+    ap.add_argument("--primary-only", action="store_true", help="skip the secondary legs (AutoRally-NN, LSTM+colored, DI-Tube)")
     args = ap.parse_args()
 
     import numpy as np
@@ -207,10 +266,11 @@ def main():
         }
         # secondary workload of the north star (not the headline `value`): AutoRally-NN, K=16384, T=150, MFMA forward
         if not args.primary_only:
-            try:
-                out["autorally_nn"] = autorally_leg(local_rank)
-            except Exception as e:  # noqa: BLE001
-                out["autorally_nn"] = {"error": str(e)}
+            for key, leg in (("autorally_nn", autorally_leg), ("lstm_colored", lstm_colored_leg), ("di_tube", di_tube_leg)):
+                try:
+                    out[key] = leg(local_rank)
+                except Exception as e:  # noqa: BLE001
+                    out[key] = {"error": str(e)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cartpole_cfg(K=K_PER_GPU, T=T))
         print(json.dumps(out), flush=True)

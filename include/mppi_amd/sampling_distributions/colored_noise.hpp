@@ -14,10 +14,10 @@
  *     eps[k][t][c] = sum_kk  G_c[t][kk] * z[k][c][kk],        kk = 2 f + (0: real, 1: imaginary part),  f = 0..T
  * with one table G_c[T][2T+2] that folds the f^(-beta/2) weights, the Hermitian inverse DFT of length N = 2T, the
  * offset subtraction and the 1/(sigma_c N) normalisation.  That is a dense [rollouts x 2T+2] x [2T+2 x T] contraction —
- * genuine matrix-core work — and it runs INSIDE the rollout kernel's prologue: each wave takes 16 rollouts x one control,
- * draws z with Philox in registers (B fragments), streams the pre-swizzled table from L2 (A fragments, one coalesced
- * 256-byte read per MFMA) and writes the result straight into the block's LDS sample rows.  Nothing but the table
- * (T*(2T+2)*C floats, 0.64 MB at config 5) is read from memory and nothing is written to HBM.
+ * genuine matrix-core work — and it runs INSIDE the rollout kernel's prologue: each wave takes 16 rollouts, draws z with
+ * Philox in registers (B fragments), takes the pre-swizzled table (A fragments) from an LDS tile that the whole block
+ * stages from L2 once, and writes the result straight into the block's LDS sample rows.  Nothing but the table
+ * (T*(2T+2)*C floats, 0.64 MB at config 5, L2-resident) is read from memory and nothing is written to HBM.
  * readControlSample() then applies the setGaussianControls rule exactly like the Gaussian sampler
  * (colored_noise.cu:378-386 ends with the same kernel).
  *
@@ -54,7 +54,8 @@ __host__ __device__ inline int coloredNumKSteps(int num_timesteps)
 }
 __host__ __device__ inline int coloredNumTBlocks(int num_timesteps)
 {
-  return (num_timesteps + 15) / 16;
+  // rounded up to even: tiles are processed with an even compile-time width (coloredTiles<NTBP>); the padding block is zero
+  return (((num_timesteps + 15) / 16) + 1) & ~1;
 }
 
 /**
@@ -160,97 +161,174 @@ public:
   {
   }
 
-  /** Philox spectrum draw: entry kk of (rollout, control c) is element (kk >> 2) & 3 of quad ((kk >> 4) << 2) + (kk & 3) of
-   *  stream 1 + c — each lane's quad feeds four consecutive k-steps of its own k-group, so no draw is wasted */
+  /** block-shared LDS: the double-buffered A-fragment staging tile (4 k-steps x min(MAX_TB, NTB) time blocks x 64 lanes).
+   *  Layout of this class's LDS region: [slots x sample row][staging tile] (reference contract: Grd + Blk * slots bytes,
+   *  utils/managed.cuh:104-111; the split is the class's own business) */
+  __host__ __device__ inline int getGrdSharedSizeBytes() const
+  {
+    const int ntb = coloredNumTBlocks(this->params_.num_timesteps);  // even
+    return 2 * 4 * (ntb < MAX_TB ? ntb : MAX_TB) * 64 * (int)sizeof(float);
+  }
+
+  /**
+   * One (control, row-group pass, time-block chunk) of the prologue GEMM with a COMPILE-TIME number of time blocks NTBP
+   * (even; the table's time-block count is padded to even with a zero block, which adds fma(0, z, acc) = acc):
+   * the 4 * NTBP MFMAs of a tile are straight-line code, so their LDS reads are issued ahead of the matrix pipe.
+   */
+  template <int NTBP>
+  __device__ __forceinline__ void coloredTiles(const float* __restrict__ basis, float* __restrict__ stage,
+                                               float* __restrict__ theta_d, const float* __restrict__ zbuf,
+                                               const int c, const int tb0, const int ntb, const int NTB, const int NG,
+                                               const int KK, const int T, const int stride, const int bx, const int nz,
+                                               const int row, const uint32_t rollout, const bool active,
+                                               const bool valid, const bool from_buffer, const int tid_flat,
+                                               const int nthreads, const int lane)
+  {
+    const int g = lane >> 4;
+    constexpr int TILE4 = NTBP * 16;  // float4 per k-step of the staged tile
+    colored_f32x4 acc[NTBP];
+#pragma unroll
+    for (int tb = 0; tb < NTBP; tb++)
+      acc[tb] = colored_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    // tile j = table rows ks = 4j .. 4j+3, time blocks tb0 .. tb0+NTBP-1  ->  stage[j & 1][e][tb][lane], copied with the
+    // gfx950 LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per wave instruction, no staging registers, no
+    // ds_write pass); a tile is exactly NTBP KiB, the chunks are dealt round-robin to the waves of the block
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid_flat >> 6);
+    const int nwaves = nthreads >> 6;
+    auto stage_tile = [&](const int j) {
+      float* dst_tile = stage + (size_t)(j & 1) * 4 * NTBP * 64;
+      for (int chunk = wave_u; chunk < NTBP; chunk += nwaves)
+      {
+        const int i = chunk * 64 + lane;  // float4 index inside the tile
+        const int e = i / TILE4, r = i - e * TILE4;
+        const float* src = basis + ((size_t)(4 * j + e) * NTB + tb0) * 64 + 4 * r;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst_tile + chunk * 256), 16, 0, 0);
+      }
+    };
+    // the spectrum entries of tile j: one Philox quad per lane (or four loads in replay mode)
+    auto draw = [&](const int j, float (&zq)[4]) {
+      if (from_buffer)
+      {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+          const int kk = 4 * (4 * j + e) + g;
+          zq[e] = (kk < KK) ? zbuf[kk] : 0.0f;
+        }
+      }
+      else
+      {
+        mppi::rng::normal4(this->seed_, this->generation_, (uint32_t)(1 + c), rollout, (uint32_t)(4 * j + g), zq);
+      }
+    };
+    __syncthreads();  // the staging buffers may still be read by a slower wave of the previous pass
+    stage_tile(0);
+    float zq[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    if (active)
+      draw(0, zq);
+    __syncthreads();
+    for (int j = 0; j < NG; j++)
+    {
+      if (j + 1 < NG)
+        stage_tile(j + 1);
+      if (active)
+      {
+        const float* __restrict__ a_tile = stage + (size_t)(j & 1) * 4 * NTBP * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+          for (int tb = 0; tb < NTBP; tb++)
+            acc[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_tile[(e * NTBP + tb) * 64], zq[e], acc[tb], 0, 0, 0);
+        // the next tile's draw (~300 VALU instructions) does not depend on these MFMAs, so the scheduler is free to
+        // interleave the two (measured: neutral with ROCm 7.2's hipcc, which keeps them apart)
+        float zn[4];
+        draw(min(j + 1, NG - 1), zn);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          zq[e] = zn[e];
+      }
+      __syncthreads();
+    }
+    if (valid)
+    {
+#pragma unroll
+      for (int tb = 0; tb < NTBP; tb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+          const int t = 16 * (tb0 + tb) + 4 * g + i;
+          if (t < T)
+            for (int z = 0; z < nz; z++)
+              theta_d[(z * bx + row) * stride + t * CONTROL_DIM + c] = acc[tb][i];
+        }
+    }
+  }
+
+  /**
+   * Fills the block's sample rows with colored noise.  All waves of the block walk the table in lockstep — control by
+   * control, 4 k-steps (one Philox quad per lane) at a time — so that every A fragment is fetched from L2 ONCE per
+   * block: the threads stage the next tile global -> LDS (float4, coalesced) while the matrix cores work on the
+   * current one, one barrier per tile.  Wave w owns the 16 rollouts of row group w (+ nwaves, ...) and keeps their
+   * accumulators in registers; waves without a row group (the sampler / cost waves of the pipelined kernels) only help
+   * with the staging.
+   * Philox spectrum draw: entry kk of (rollout, control c) is element (kk >> 2) & 3 of quad ((kk >> 4) << 2) + (kk & 3)
+   * of stream 1 + c — each lane's quad feeds four consecutive k-steps of its own k-group, so no draw is wasted.
+   */
   __device__ __forceinline__ void initializeDistributions(const float* __restrict__ output, const float t_0,
                                                           const float dt, float* __restrict__ theta_d)
   {
     const int T = this->params_.num_timesteps;
     const int stride = PARENT::rowStride(T);
     const int bx = this->rolloutsPerBlock();
+    const int nthreads = (int)(blockDim.x * blockDim.y * blockDim.z);
     const int tid_flat = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
-    const int nwaves = (int)(blockDim.x * blockDim.y * blockDim.z) >> 6;
+    const int nwaves = nthreads >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid_flat >> 6);
     const int lane = tid_flat & 63;
-    const int n = lane & 15, g = lane >> 4;
+    const int n = lane & 15;
     const int row0 = (int)(blockIdx.x * bx);
     const int nrows = min(bx, this->params_.num_rollouts - row0);
     const int nz = (int)blockDim.z;
     const int RG = (bx + 15) >> 4;
     const int KS = coloredNumKSteps(T), NTB = coloredNumTBlocks(T), KK = coloredSpectrumFloats(T);
+    const int NG = KS >> 2;  // tiles of 4 k-steps
     const bool from_buffer = this->noise_source_ == NOISE_EPS_BUFFER;
-    for (int unit = wave; unit < RG * CONTROL_DIM; unit += nwaves)
+    float* __restrict__ stage = theta_d + (((size_t)bx * nz * stride + 3) & ~(size_t)3);  // 16-byte aligned
+    for (int c = 0; c < CONTROL_DIM; c++)
     {
-      const int c = unit % CONTROL_DIM;
-      const int rg = unit / CONTROL_DIM;
-      const int row = 16 * rg + n;
-      const bool valid = row < nrows;
-      const uint32_t rollout = (uint32_t)(row0 + row + this->rollout_offset_);
-      const float* __restrict__ zbuf =
-          from_buffer ? this->eps_d_ + ((size_t)(row0 + (valid ? row : 0)) * CONTROL_DIM + c) * KK : nullptr;
-      const float* __restrict__ basis = basis_d_ + (size_t)c * KS * NTB * 64 + lane;
-      for (int tb0 = 0; tb0 < NTB; tb0 += MAX_TB)
+      const float* __restrict__ basis = basis_d_ + (size_t)c * KS * NTB * 64;
+      for (int rg0 = 0; rg0 < RG; rg0 += nwaves)
       {
-        colored_f32x4 acc[MAX_TB];
-#pragma unroll
-        for (int tb = 0; tb < MAX_TB; tb++)
-          acc[tb] = colored_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-        /* A fragments of one group (4 k-steps x up to MAX_TB time blocks) are fetched one group AHEAD of their use:
-         * the L2 round trip of group j + 1 overlaps the Philox draw and the 4 * NTB MFMAs of group j */
-        float a_cur[4][MAX_TB], a_nxt[4][MAX_TB];
-        auto fetch = [&](float (&a)[4][MAX_TB], const int ks4) {
-#pragma unroll
-          for (int e = 0; e < 4; e++)
-          {
-            const float* __restrict__ a_row = basis + (size_t)(ks4 + e) * NTB * 64;
-#pragma unroll
-            for (int tb = 0; tb < MAX_TB; tb++)
-              a[e][tb] = (tb0 + tb < NTB) ? a_row[(tb0 + tb) * 64] : 0.0f;
-          }
-        };
-        fetch(a_cur, 0);
-        for (int ks4 = 0; ks4 < KS; ks4 += 4)
+        const int rg = rg0 + wave;
+        const bool active = rg < RG;  // wave-uniform
+        const int row = 16 * rg + n;
+        const bool valid = active && row < nrows;
+        const uint32_t rollout = (uint32_t)(row0 + row + this->rollout_offset_);
+        const float* __restrict__ zbuf =
+            from_buffer ? this->eps_d_ + ((size_t)(row0 + (valid ? row : 0)) * CONTROL_DIM + c) * KK : nullptr;
+        for (int tb0 = 0; tb0 < NTB; tb0 += MAX_TB)
         {
-          if (ks4 + 4 < KS)
-            fetch(a_nxt, ks4 + 4);
-          float zq[4];
-          if (from_buffer)
+          const int ntb = min(MAX_TB, NTB - tb0);  // even: NTB and MAX_TB are
+#define MPPI_COLORED_CASE(P)                                                                                           \
+  case P / 2:                                                                                                          \
+    coloredTiles<P>(basis, stage, theta_d, zbuf, c, tb0, ntb, NTB, NG, KK, T, stride, bx, nz, row, rollout, active,    \
+                    valid, from_buffer, tid_flat, nthreads, lane);                                                     \
+    break;
+          switch ((ntb + 1) >> 1)  // block-uniform
           {
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-            {
-              const int kk = 4 * (ks4 + e) + g;
-              zq[e] = (kk < KK) ? zbuf[kk] : 0.0f;
-            }
+            MPPI_COLORED_CASE(2)
+            MPPI_COLORED_CASE(4)
+            MPPI_COLORED_CASE(6)
+            MPPI_COLORED_CASE(8)
+            MPPI_COLORED_CASE(10)
+            MPPI_COLORED_CASE(12)
+            MPPI_COLORED_CASE(14)
+            default:
+              coloredTiles<16>(basis, stage, theta_d, zbuf, c, tb0, ntb, NTB, NG, KK, T, stride, bx, nz, row, rollout,
+                               active, valid, from_buffer, tid_flat, nthreads, lane);
           }
-          else
-          {
-            mppi::rng::normal4(this->seed_, this->generation_, (uint32_t)(1 + c), rollout, (uint32_t)(ks4 + g), zq);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; e++)
-#pragma unroll
-            for (int tb = 0; tb < MAX_TB; tb++)
-              if (tb0 + tb < NTB)
-                acc[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[e][tb], zq[e], acc[tb], 0, 0, 0);
-#pragma unroll
-          for (int e = 0; e < 4; e++)
-#pragma unroll
-            for (int tb = 0; tb < MAX_TB; tb++)
-              a_cur[e][tb] = a_nxt[e][tb];
-        }
-        if (valid)
-        {
-#pragma unroll
-          for (int tb = 0; tb < MAX_TB; tb++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-            {
-              const int t = 16 * (tb0 + tb) + 4 * g + i;
-              if (t < T)
-                for (int z = 0; z < nz; z++)
-                  theta_d[(z * bx + row) * stride + t * CONTROL_DIM + c] = acc[tb][i];
-            }
+#undef MPPI_COLORED_CASE
         }
       }
     }

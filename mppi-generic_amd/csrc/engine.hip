@@ -256,10 +256,13 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
                 "mppi_create: block shape (" + std::to_string(h->bx) + "," + std::to_string(h->by) + "," +
                     std::to_string(h->bz) + ") is not instantiated for model '" + h->model_name + "'");
-  const bool pipe_ok = h->model->supportsPipeline() && h->bx == 64 && h->by == 1 && cfg->controller != MPPI_CONTROLLER_ROBUST;
+  const bool pipe_ok = cfg->controller != MPPI_CONTROLLER_ROBUST &&
+                       ((h->model->supportsPipeline() && h->bx == 64 && h->by == 1) ||
+                        h->model->supportsPipelineRep(h->bx, h->by, h->bz));
   if (cfg->kernel_variant == MPPI_KERNEL_PIPELINE && !pipe_ok)
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
-                "mppi_create: the pipeline variant needs a model registered for it and block shape (64, 1)");
+                "mppi_create: the pipeline variant needs a model registered for it and block shape (64, 1), or (64, REP, 1) "
+                "for replicated-lane (MFMA) dynamics");
   if (cfg->kernel_variant < 0 || cfg->kernel_variant > MPPI_KERNEL_PIPELINE)
     return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_create: unknown kernel_variant");
   h->pipeline = pipe_ok && cfg->kernel_variant != MPPI_KERNEL_FUSED;

@@ -115,6 +115,11 @@ struct ModelBase
   {
     return false;
   }
+  /** role-pipelined variant for replicated-lane (MFMA) dynamics, shape (64, REP, 1) */
+  virtual bool supportsPipelineRep(int bx, int by, int bz) const
+  {
+    return false;
+  }
   virtual size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D, bool pipeline) = 0;
   virtual mppi_status launchRollout(int bx, int by, int bz, bool pipeline, const kernels::RolloutArgs& args,
                                     const SamplerLaunchState& s, hipStream_t stream, std::string& err) = 0;
@@ -350,6 +355,45 @@ struct ModelT : ModelBase
   bool supportsPipeline() const override
   {
     return PIPELINE;
+  }
+  bool supportsPipelineRep(int bx, int by, int bz) const override
+  {
+    if constexpr (!std::is_void<DYN_FAST_T>::value)
+      return bx == 64 && bz == 1 && by == kernels::replicated_lanes<DYN_FAST_T>::value && hasShape(FAST_SHAPES{}, bx, by, bz);
+    return false;
+  }
+  template <class FAST = DYN_FAST_T>
+  mppi_status launchPipelineRep(const kernels::RolloutArgs& args, hipStream_t stream, std::string& err)
+  {
+    if constexpr (!std::is_void<FAST>::value)
+    {
+      FAST fast(dyn);
+      const int ring = kernels::pipelineRepRingSteps(fast, cost, smp, MAX_LDS_BYTES);
+      if (ring == 0)
+      {
+        err = "pipeline rollout kernel: the sample rows leave no room for the output ring in 160 KiB of LDS";
+        return MPPI_ERR_LDS_OVERFLOW;
+      }
+      const size_t smem = kernels::pipelineRepSharedBytes(fast, cost, smp, ring);
+      const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
+      auto kfn = in_loop ? kernels::rolloutPipelineRepKernel<FAST, COST_T, SAMPLING_T, SAMPLING_T::IN_LOOP_DRAW>
+                         : kernels::rolloutPipelineRepKernel<FAST, COST_T, SAMPLING_T, false>;
+      if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+      constexpr int REP = kernels::replicated_lanes<FAST>::value;
+      const int grid = (args.num_rollouts + 63) / 64;
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * (REP + 2), 1, 1), smem, stream, fast, cost, smp, args, ring);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess)
+      {
+        err = std::string("rolloutPipelineRepKernel launch: ") + hipGetErrorString(e);
+        return MPPI_ERR_HIP;
+      }
+      return MPPI_OK;
+    }
+    err = "model has no replicated-lane dynamics";
+    return MPPI_ERR_LAUNCH_SHAPE;
   }
 
   template <int Z>
@@ -690,6 +734,15 @@ struct ModelT : ModelBase
   {
     smp.params_.num_timesteps = T;
     smp.params_.num_distributions = D;
+    if constexpr (!std::is_void<DYN_FAST_T>::value)
+    {
+      if (pipeline && supportsPipelineRep(bx, by, bz))
+      {
+        DYN_FAST_T fast(dyn);
+        const int ring = kernels::pipelineRepRingSteps(fast, cost, smp, MAX_LDS_BYTES);
+        return ring > 0 ? kernels::pipelineRepSharedBytes(fast, cost, smp, ring) : MAX_LDS_BYTES + 1;
+      }
+    }
     if (pipeline)
       return kernels::pipelineSharedBytes(dyn, cost, smp, bz);
     if constexpr (!std::is_void<DYN_FAST_T>::value)
@@ -809,6 +862,8 @@ struct ModelT : ModelBase
       if (st != MPPI_OK)
         return st;
     }
+    if (pipeline && supportsPipelineRep(bx, by, bz))
+      return launchPipelineRep(args, stream, err);
     if (pipeline)
       return bz == 1 ? launchPipeline<1>(args, stream, err) : launchPipeline<2>(args, stream, err);
     if constexpr (!std::is_void<DYN_FAST_T>::value)

@@ -263,6 +263,247 @@ __global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
                                                         theta_d_shared, cost_s, w_s);
 }
 
+
+/* =====================================================================================================================
+ * The same pipeline for models whose Dynamics runs REPLICATED_LANES > 1 lanes per rollout (the MFMA network forwards).
+ *
+ * Why it pays even more there: a single wave issues roughly one instruction every 4 cycles, while a SIMD can issue one
+ * every 2 when it has two waves to pick from (MI355X_MICROARCH.md, per-instruction constants).  In the fused kernel the
+ * 4 lanes of a rollout ALL execute the sampler and the cost function redundantly (~600 of the ~1150 instructions of an
+ * AutoRally step) and every SIMD holds exactly one wave at K = 16384.  Here a block of 64 rollouts runs as
+ *     REP dynamics waves   16 rollouts x REP lanes each: enforceConstraints, network + kinematics, Euler step
+ *     1 sampler wave       64 rollouts x 1 lane: Philox draw / colored row, setGaussianControls rule
+ *     1 cost wave          64 rollouts x 1 lane: running cost + likelihood ratio, terminal cost, epilogue
+ * so the sampler and the cost are evaluated once per rollout instead of REP times, and they fill issue slots next to the
+ * dynamics waves instead of lengthening them.  Protocol, counters and arithmetic are those of rolloutPipelineKernel
+ * (bit-identical costs); one progress counter per dynamics wave.  RING (runtime, power of two) is sized by the host to
+ * what the sample rows leave of the 160 KiB.
+ * Launch: grid = ceil(K / 64), block = ((REP + 2) * 64, 1, 1); wave w < REP: dynamics, w == REP: sampler, w == REP + 1: cost.
+ * ===================================================================================================================== */
+/** the sampler's block-shared (Grd) bytes sit at the END of its LDS region ([slot rows][Grd], see colored_noise.hpp) and
+ *  are only used by initializeDistributions(): the output ring, only used by the step loop, overlays them */
+template <class SAMPLING_T>
+__host__ __device__ inline int samplerGrdBytes(const SAMPLING_T* smp)
+{
+  return ((smp->getGrdSharedSizeBytes() + 15) / 16) * 16;
+}
+
+template <class DYN_T, class COST_T, class SAMPLING_T>
+__host__ inline size_t pipelineRepSharedBytes(const DYN_T& dyn, const COST_T& cost, const SAMPLING_T& smp, int ring)
+{
+  const int slots = 64;
+  size_t n = 0;
+  n += calcClassSharedMemSize(&dyn, slots);
+  n += calcClassSharedMemSize(&cost, slots);
+  n += calcClassSharedMemSize(&smp, slots) - samplerGrdBytes(&smp);       // the sample rows
+  const size_t ring_bytes = sizeof(float) * (size_t)ring * DYN_T::OUTPUT_DIM * 64;  // output ring [slot][i][rollout]
+  n += ring_bytes > (size_t)samplerGrdBytes(&smp) ? ring_bytes : (size_t)samplerGrdBytes(&smp);
+  n += sizeof(float) * 2 * math::nearest_multiple_4(slots);              // cost_s, w_s
+  n += sizeof(int) * 4 * (replicated_lanes<DYN_T>::value + 2);           // progress counters (padded)
+  return n;
+}
+
+/** largest power-of-two ring (<= 32 steps) that fits next to the sample rows; 0 if not even 4 steps fit */
+template <class DYN_T, class COST_T, class SAMPLING_T>
+__host__ inline int pipelineRepRingSteps(const DYN_T& dyn, const COST_T& cost, const SAMPLING_T& smp, size_t max_lds)
+{
+  for (int ring = 32; ring >= 4; ring >>= 1)
+    if (pipelineRepSharedBytes(dyn, cost, smp, ring) <= max_lds)
+      return ring;
+  return 0;
+}
+
+template <class DYN_T, class COST_T, class SAMPLING_T, bool DRAW_IN_LOOP>
+__global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
+    rolloutPipelineRepKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args,
+                             const int ring_steps)
+{
+  constexpr int BX = 64;
+  constexpr int REP = replicated_lanes<DYN_T>::value;
+  static_assert(REP > 1 && 64 % REP == 0, "this variant is for replicated-lane dynamics");
+  constexpr int DW = BX * REP / 64;  // dynamics waves
+  constexpr int NWAVES = DW + 2;
+  constexpr int NTHREADS = 64 * NWAVES;
+  constexpr int PER_WAVE = 64 / REP;
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == NTHREADS);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_y() == 1);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_z() == 1);
+  __builtin_assume(__builtin_amdgcn_workitem_id_x() < NTHREADS);
+  __builtin_assume(__builtin_amdgcn_workitem_id_y() == 0);
+  __builtin_assume(__builtin_amdgcn_workitem_id_z() == 0);
+
+  DYN_T* dynamics = &dynamics_obj;
+  COST_T* costs = &costs_obj;
+  SAMPLING_T* sampling = &sampling_obj;
+  constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
+  constexpr int SLOTS = BX;
+
+  const int tid_x = (int)__builtin_amdgcn_workitem_id_x();
+  const int wave = __builtin_amdgcn_readfirstlane(tid_x >> 6);  // wave-uniform
+  const int lane = tid_x & 63;
+  const bool is_dyn = wave < DW;
+  const bool is_sampler = wave == DW;
+  // rollout slot of this thread: dynamics waves carry PER_WAVE rollouts x REP lanes, the other two one lane per rollout
+  const int thread_idx = is_dyn ? wave * PER_WAVE + (lane % PER_WAVE) : lane;
+  const int rep_lane = is_dyn ? lane / PER_WAVE : 0;
+  const int block_idx = (int)blockIdx.x;
+  const int global_idx = BX * block_idx + thread_idx;
+  const int shared_idx = thread_idx;
+  const int num_timesteps = args.num_timesteps;
+  const int num_rollouts = args.num_rollouts;
+  const float dt = args.dt;
+  const bool valid = global_idx < num_rollouts;
+  const int nrows = min(BX, num_rollouts - BX * block_idx);
+  const int ring_mask = ring_steps - 1;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* theta_s_shared = reinterpret_cast<float*>(smem_raw);
+  float* theta_c_shared = theta_s_shared + calcClassSharedMemSize(dynamics, SLOTS) / (int)sizeof(float);
+  float* theta_d_shared = theta_c_shared + calcClassSharedMemSize(costs, SLOTS) / (int)sizeof(float);
+  // [sample rows][sampler Grd (prologue only)  U  output ring (step loop only)][cost_s][w_s][counters]
+  float* ring = theta_d_shared + (calcClassSharedMemSize(sampling, SLOTS) - samplerGrdBytes(sampling)) / (int)sizeof(float);
+  const int overlay_floats = max(ring_steps * O * 64, samplerGrdBytes(sampling) / (int)sizeof(float));
+  float* cost_s = ring + overlay_floats;
+  float* w_s = cost_s + math::nearest_multiple_4(SLOTS);
+  lds_counter_t counters = (lds_counter_t)reinterpret_cast<int*>(w_s + math::nearest_multiple_4(SLOTS));
+  lds_counter_t smp_prog = counters + 4 * DW;        // steps whose shaped sample is in the row
+  lds_counter_t cost_prog = counters + 4 * (DW + 1);  // steps the cost wave has consumed
+  // counters + 4 * w, w < DW: steps whose output dynamics wave w has put into the ring
+
+  sampling->setThreadMapping(shared_idx, BX);
+
+  float x[S], x_next[S], xdot[S], u[C], y[O];
+  int crash_status = 0;
+#pragma unroll
+  for (int i = 0; i < S; i++)
+  {
+    x[i] = args.init_x_d[i];
+    xdot[i] = 0.0f;
+    x_next[i] = 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    u[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < O; i++)
+    y[i] = 0.0f;
+  if (tid_x < NWAVES)
+    counters[4 * tid_x] = 0;
+  __syncthreads();
+
+  dynamics->initializeDynamics(x, u, y, theta_s_shared, 0.0f, dt);
+  sampling->initializeDistributions(y, 0.0f, dt, theta_d_shared);
+  costs->initializeCosts(y, u, theta_c_shared, 0.0f, dt);
+  __syncthreads();
+
+  float running_cost = 0.0f;
+  float* row = sampling->sampleRow(theta_d_shared, shared_idx);
+
+  if (is_sampler)
+  {
+    /* ------------------------------------------------ sampler wave ------------------------------------------------ */
+    constexpr int STEPS = (C % 2 == 0) ? 2 : 4;
+    constexpr int QUADS = STEPS * C / 4;
+    for (int t = 0; t < num_timesteps; t += STEPS)
+    {
+      float zq[4 * QUADS];
+      if (DRAW_IN_LOOP)
+      {
+#pragma unroll
+        for (int q = 0; q < QUADS; q++)
+          sampling->drawQuad(global_idx, t * C / 4 + q, &zq[4 * q]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < STEPS; s2++)
+      {
+        if (t + s2 < num_timesteps)
+        {
+          if (DRAW_IN_LOOP)
+            sampling->shapeControlSample(global_idx, t + s2, 0, &zq[s2 * C], u);
+          else
+            sampling->readControlSample(global_idx, t + s2, 0, u, theta_d_shared, 1, 0, y);
+          sampling->writeControlSample(global_idx, t + s2, 0, u, theta_d_shared, 1, 0, y);
+        }
+      }
+      pipePublish(smp_prog, min(t + STEPS, num_timesteps), lane);
+    }
+  }
+  else if (is_dyn)
+  {
+    /* ------------------------------------------------ dynamics waves ---------------------------------------------- */
+    lds_counter_t my_prog = counters + 4 * wave;
+    auto dyn_step = [&](float* xc, float* xn, int t, const float* u_in) {
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        u[i] = u_in[i];
+      dynamics->enforceConstraints(xc, u);
+      if (rep_lane == 0)
+      {
+#pragma unroll
+        for (int i = 0; i < C; i++)
+          row[t * C + i] = u[i];
+      }
+      dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
+      if (rep_lane == 0)
+      {
+        float* slot = ring + (size_t)(t & ring_mask) * O * 64 + thread_idx;
+#pragma unroll
+        for (int i = 0; i < O; i++)
+          slot[i * 64] = y[i];
+      }
+    };
+    int seen_smp = 0, seen_cost = 0;
+    for (int t = 0; t < num_timesteps; t += 2)
+    {
+      const int hi = min(t + 2, num_timesteps);
+      pipeWait(smp_prog, hi, seen_smp);
+      pipeWait(cost_prog, hi - ring_steps, seen_cost);
+      float ubuf[2 * C];
+#pragma unroll
+      for (int j = 0; j < 2 * C; j++)
+        ubuf[j] = (t * C + j < num_timesteps * C) ? row[t * C + j] : 0.0f;
+      dyn_step(x, x_next, t, &ubuf[0]);
+      if (t + 1 < num_timesteps)
+        dyn_step(x_next, x, t + 1, &ubuf[C]);
+      pipePublish(my_prog, hi, lane);
+    }
+  }
+  else
+  {
+    /* ------------------------------------------------ cost wave --------------------------------------------------- */
+    int seen_dyn[DW];
+#pragma unroll
+    for (int w = 0; w < DW; w++)
+      seen_dyn[w] = 0;
+    for (int t = 0; t < num_timesteps; t += 2)
+    {
+      const int hi = min(t + 2, num_timesteps);
+#pragma unroll
+      for (int w = 0; w < DW; w++)
+        pipeWait(counters + 4 * w, hi, seen_dyn[w]);
+      for (int tt = t; tt < hi; tt++)
+      {
+        const float* slot = ring + (size_t)(tt & ring_mask) * O * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < O; i++)
+          y[i] = slot[i * 64];
+#pragma unroll
+        for (int i = 0; i < C; i++)
+          u[i] = row[tt * C + i];
+        running_cost += costs->computeRunningCost(y, u, tt, theta_c_shared, &crash_status) +
+                        sampling->computeLikelihoodRatioCost(u, theta_d_shared, global_idx, tt, 0, args.lambda, args.alpha);
+      }
+      pipePublish(cost_prog, hi, lane);
+    }
+  }
+  __syncthreads();
+
+  const bool writer = !is_dyn && !is_sampler;
+  const float terminal = costs->terminalCost(y, theta_c_shared);
+  blockSoftminEpilogue<SAMPLING_T, C, BX, 1, NTHREADS>(sampling, args, terminal, running_cost, writer, valid, global_idx,
+                                                       shared_idx, 0, tid_x, block_idx, nrows, theta_d_shared, cost_s, w_s);
+}
+
 }  // namespace kernels
 }  // namespace mppi
 

@@ -80,13 +80,16 @@ def test_ar_standard_cost_pieces():
 
 # ------------------------------------------------------------------ GPU parity -----------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(16, 8), (8, 16), (16, 4), (64, 1), (64, 4), (32, 4)])
+@pytest.mark.parametrize("shape", [(16, 8), (8, 16), (16, 4), (64, 1), (64, 4), (32, 4), (64, 4, 1), (64, 4, 2)])
 def test_autorally_rollout_costs_bit_exact(gpu, shape):
     """reference: tests/dynamics/ar_dynamics_nn_test.cu (GPU == CPU over y_dim 1..16) + rollout_kernel_tests.cu.
     Shapes (64, 4) and (32, 4) are the MFMA forward (4 lanes of a rollout = MFMA k-groups), the others the LDS path."""
     cfg = autorally_cfg(K=512, T=40)
     eps = host_noise(1, cfg["K"], cfg["T"], 2)[0]
-    eng, orc = make_engine(cfg, block_x=shape[0], block_y=shape[1]), make_oracle(cfg)
+    # a third entry selects the kernel structure for the MFMA shape: 1 = fused, 2 = role-pipelined (the default there)
+    variant = shape[2] if len(shape) > 2 else 0
+    eng = make_engine(cfg, block_x=shape[0], block_y=shape[1], kernel_variant=variant)
+    orc = make_oracle(cfg)
     mean = np.zeros((cfg["T"], 2), np.float32)
     mean[:, 1] = 0.3
     eng.updateImportanceSampler(mean)

@@ -121,6 +121,7 @@ def test_colored_noise_generator_bit_exact(gpu, mk, T, stride):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mk,kw", [(_colored_cartpole, {}), (_colored_cartpole, {"kernel_variant": 1}),
                                    (_colored_cartpole, {"block_x": 64, "block_y": 4}), (_colored_bicycle, {}),
+                                   (_colored_bicycle, {"kernel_variant": 1}),
                                    (_colored_bicycle, {"block_x": 16, "block_y": 8})])
 def test_colored_rollout_costs_bit_exact(gpu, mk, kw):
     cfg = mk()

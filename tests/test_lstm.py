@@ -69,13 +69,16 @@ def test_bicycle_lstm_oracle_kinematics_and_state():
 
 # ------------------------------------------------------------------ GPU parity -----------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(16, 8), (8, 16), (16, 4), (64, 1), (64, 4), (32, 4)])
+@pytest.mark.parametrize("shape", [(16, 8), (8, 16), (16, 4), (64, 1), (64, 4), (32, 4), (64, 4, 1), (64, 4, 2)])
 def test_bicycle_lstm_rollout_costs_bit_exact(gpu, shape):
     """reference: tests/nn_helpers/lstm_helper_test.cu forwardGPU (GPU == CPU over y_dim 1..16) + rollout_kernel_tests.cu.
     (64, 4), (32, 4): MFMA forward, recurrent state in registers; the other shapes: LSTMHelper's LDS scheme."""
     cfg = bicycle_lstm_cfg(K=512, T=40)
     eps = host_noise(1, cfg["K"], cfg["T"], 2)[0]
-    eng, orc = make_engine(cfg, block_x=shape[0], block_y=shape[1]), make_oracle(cfg)
+    # a third entry selects the kernel structure for the MFMA shape: 1 = fused, 2 = role-pipelined (the default there)
+    variant = shape[2] if len(shape) > 2 else 0
+    eng = make_engine(cfg, block_x=shape[0], block_y=shape[1], kernel_variant=variant)
+    orc = make_oracle(cfg)
     mean = np.zeros((cfg["T"], 2), np.float32)
     mean[:, 1] = 0.3
     eng.updateImportanceSampler(mean)
