@@ -39,13 +39,20 @@ def usable_cores():
     return n
 
 
-def pmc_traffic():
-    """HBM bytes per rollout launch from the committed PMC passes (profiles/), or None"""
+PMC_FILE = os.path.join("profiles", "r01_d_pmc_hbm_traffic.json")
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the kernel whose (shortened) name starts with kernel_prefix, from the committed PMC passes
+    (tools/profile_bench.sh + tools/pmc_summary.py -> profiles/), or None"""
     try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r01_c_pmc_hbm_traffic.json")))
-        return d["rollout_traffic_bytes_per_launch"]
+        d = json.load(open(os.path.join(REPO, PMC_FILE)))
+        for name, e in d["kernels"].items():
+            if name.startswith(kernel_prefix) and e.get("hbm_traffic_bytes_per_launch"):
+                return round(e["hbm_traffic_bytes_per_launch"], 1)
     except Exception:  # noqa: BLE001
-        return None
+        pass
+    return None
 
 
 def cpu_baseline(cfg, budget_s=12.0):
@@ -97,13 +104,14 @@ def autorally_leg(device):
         "workload": "AutoRally NeuralNetModel<7,2,3> (FNN 6-32-32-4, synthetic weights) + ARStandardCost (600x600 "
                     "generated track map), VanillaMPPI iteration, K=16384, T=150, block (64 rollouts x 4 MFMA lanes)",
         "value": round(n / wall, 3), "unit": "MPPI iters/s", "ms_per_step": round(wall / n * 1e3, 6),
-        "roofline": {"bound": "mfma", "kernel": "rolloutKernel<NeuralNetModelMFMA<7,2,3>,ARStandardCost,Gaussian,64,1,1>",
+        "roofline": {"bound": "mfma", "kernel": "rolloutPipelineRepKernel<NeuralNetModelMFMA<7,2,3>,ARStandardCost,Gaussian,true>",
                      "achieved": round(achieved, 4), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 5),
-                     "traffic": None, "algorithmic_flops_per_launch": f_alg, "avg_kernel_us": round(roll_us, 3),
+                     "traffic": pmc_traffic("rolloutPipelineRepKernel<NeuralNetModelMFMA"),
+                     "algorithmic_flops_per_launch": f_alg, "avg_kernel_us": round(roll_us, 3),
                      "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak = the fp32 vector peak; the kernel is bound by VALU "
-                             "issue, not by the matrix cores: 64 tanh per rollout-step (packed fp32), kinematics, costmap "
-                             "gathers and the Philox draw share the wave with 28 MFMAs per step; K=16384 is exactly one "
-                             "wave per SIMD"},
+                             "issue, not by the matrix cores: per 16 rollouts and step a dynamics wave issues 28 MFMAs and ~500 "
+                             "VALU instructions (64 packed-fp32 tanh per rollout, kinematics, Euler); sampler and cost run "
+                             "once per rollout in their own waves; K=16384 is exactly one dynamics wave per SIMD"},
     }
 
 
@@ -132,9 +140,10 @@ def lstm_colored_leg(device):
                     "sampler (exponents [1,1], offset_decay_rate 0.97), ColoredMPPI iteration, K=65536, T=200, block (64 "
                     "rollouts x 4 MFMA lanes)",
         "value": round(n / wall, 3), "unit": "MPPI iters/s", "ms_per_step": round(wall / n * 1e3, 6),
-        "roofline": {"bound": "mfma", "kernel": "rolloutKernel<BicycleSlipLSTMMFMA,ARStandardCost,ColoredNoise,64,1,1>",
+        "roofline": {"bound": "mfma", "kernel": "rolloutPipelineRepKernel<BicycleSlipLSTMMFMA,ARStandardCost,ColoredNoise,false>",
                      "achieved": round(achieved, 4), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 5),
-                     "traffic": None, "algorithmic_flops_per_launch": f_net + f_noise,
+                     "traffic": pmc_traffic("rolloutPipelineRepKernel<BicycleSlipLSTMMFMA"),
+                     "algorithmic_flops_per_launch": f_net + f_noise,
                      "algorithmic_flops_network": f_net, "algorithmic_flops_colored_noise_gemm": f_noise,
                      "avg_kernel_us": round(roll_us, 3),
                      "note": "reference data flow for this config moves ~1.8 GB per iteration through HBM (cuRAND spectrum, "
@@ -256,8 +265,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "rolloutPipelineKernel<CartpoleDynamics,CartpoleQuadraticCost,Gaussian,1,true>",
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(),
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, profiles/r01_c_pmc_hbm_traffic.json "
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": pmc_traffic("rolloutPipelineKernel<CartpoleDynamics"),
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, " + PMC_FILE + " "
                                   "(2*FETCH_SIZE + WRITE_SIZE): the sample tensor never reaches HBM, so traffic << algorithmic bytes",
                 "algorithmic_bytes_per_launch": b_alg, "avg_kernel_us": round(roll_us, 3),
                 "avg_iteration_us_event_timed": round(ms_total / n_ev * 1e3, 3),

@@ -511,7 +511,7 @@ static mppi_status launchCombine(mppi_handle h, const float* records, int num_re
   a.mean_out_d = h->mean_d;
   a.record_out_d = record_out;
   a.stats_out_d = h->stats_d;
-  const size_t smem = sizeof(float) * (size_t)((num_records + 3) / 4 * 4);
+  const size_t smem = sizeof(float) * 4 * (size_t)num_records;
   hipLaunchKernelGGL(kernels::combineKernel, dim3(h->D, (h->TC + kernels::COMBINE_COLS - 1) / kernels::COMBINE_COLS),
                      dim3(kernels::COMBINE_THREADS), smem, h->stream, a);
   HIP_TRY(h, hipGetLastError());

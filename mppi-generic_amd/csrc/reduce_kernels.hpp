@@ -12,10 +12,11 @@
  * finalize == 0 writes the merged record (per-GPU partial, layout identical to the input records) instead of u*.
  * Also produces the reference's free-energy statistics (mppi_common.cu:1065-1081) from eta and sum w^2.
  *
- * Launch: grid = (D systems, ceil(T*C / 64) column blocks), block = COMBINE_THREADS (4 waves), dynamic LDS =
- * num_records floats.  Every block recomputes rho / s_b / eta from the record tails (a few hundred floats), then wave w
- * sums records w, w+4, ... for the block's 64 columns with 8 loads in flight per lane, and the four wave partials are
- * added in a fixed order — the record matrix is read once, coalesced, by D*ceil(TC/64)*4 waves instead of one.
+ * Launch: grid = (D systems, ceil(T*C / 64) column blocks), block = COMBINE_THREADS (16 waves), dynamic LDS =
+ * 4 * num_records floats.  The kernel is a chain of memory round trips (the records were just written by other CUs), so
+ * it is organised to need only TWO of them: every block fetches the record tails once (rho / eta / sum w^2 -> LDS) and,
+ * before reducing them, already has its first 16 column loads per lane in flight; wave w then sums records w, w+16, ...
+ * for the block's 64 columns and the sixteen wave partials are added in a fixed order.
  */
 #ifndef MPPI_AMD_REDUCE_KERNELS_HPP_
 #define MPPI_AMD_REDUCE_KERNELS_HPP_
@@ -28,7 +29,7 @@ namespace mppi
 {
 namespace kernels
 {
-constexpr int COMBINE_THREADS = 256;
+constexpr int COMBINE_THREADS = 1024;  ///< 16 waves: the merge is a chain of memory round trips, so it wants loads in flight, not ALUs
 /** floats per system in the stats buffer: rho, eta, fe_mean, fe_var, fe_modified_var, sum w^2, pad, pad */
 constexpr int STATS_STRIDE = 8;
 
@@ -82,7 +83,10 @@ constexpr int COMBINE_COLS = 64;
 __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* s_b = reinterpret_cast<float*>(smem_raw);  // [num_records]
+  float* s_b = reinterpret_cast<float*>(smem_raw);  // [num_records] scale factors
+  float* rho_s = s_b + a.num_records;               // [num_records] record tails, fetched from memory ONCE
+  float* eta_s = rho_s + a.num_records;
+  float* eta2_s = eta_s + a.num_records;
   __shared__ double red_d[COMBINE_THREADS / 64];
   __shared__ float red_f[COMBINE_THREADS / 64];
   __shared__ float part_s[COMBINE_THREADS / 64][COMBINE_COLS];
@@ -95,38 +99,64 @@ __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineAr
   const float* rec = a.records_d + (size_t)z * a.num_records * a.PS;
   const float lambda_inv = (float)(1.0 / (double)a.lambda);
 
+  // the column loads do not depend on the scale factors: issue the first batch before the reductions so that its
+  // memory round trip overlaps theirs
+  const int j = col0 + lane;
+  const bool col_ok = j < a.TC;
+  const float* col = rec + (col_ok ? j : 0);
+  constexpr int BATCH = 16;
+  float v0[BATCH];
+#pragma unroll
+  for (int i = 0; i < BATCH; i++)
+  {
+    const int b = wave + i * NW;
+    v0[i] = (col_ok && b < a.num_records) ? col[(size_t)b * a.PS] : 0.0f;
+  }
+
   float rho = INFINITY;
   for (int b = tid; b < a.num_records; b += COMBINE_THREADS)
-    rho = fminf(rho, rec[(size_t)b * a.PS + a.TC]);
+  {
+    const float* r = rec + (size_t)b * a.PS + a.TC;
+    const float r0 = r[0], r1 = r[1], r2 = r[2];
+    rho_s[b] = r0;
+    eta_s[b] = r1;
+    eta2_s[b] = r2;
+    rho = fminf(rho, r0);
+  }
   rho = blockMin(rho, red_f);
 
   double eta = 0.0, eta2 = 0.0;
   for (int b = tid; b < a.num_records; b += COMBINE_THREADS)
   {
-    const float* r = rec + (size_t)b * a.PS + a.TC;
-    const float s = mppi::det::exp(-lambda_inv * (r[0] - rho));
+    const float s = mppi::det::exp(-lambda_inv * (rho_s[b] - rho));
     s_b[b] = s;
-    eta += (double)s * (double)r[1];
-    eta2 += (double)s * (double)s * (double)r[2];
+    eta += (double)s * (double)eta_s[b];
+    eta2 += (double)s * (double)s * (double)eta2_s[b];
   }
   eta = blockSum(eta, red_d);
   eta2 = blockSum(eta2, red_d);  // blockSum's barriers also publish s_b
   const float eta_f = (float)eta;
 
-  const int j = col0 + lane;
+  // wave w sums records w, w + NW, ... in ascending order (fixed order => run-to-run reproducible)
   float acc = 0.0f;
-  if (j < a.TC)
-  {
-    const float* col = rec + j;
-    int b = wave;
-    for (; b + 7 * NW < a.num_records; b += 8 * NW)
-    {
-      float v[8];
 #pragma unroll
-      for (int i = 0; i < 8; i++)
+  for (int i = 0; i < BATCH; i++)
+  {
+    const int b = wave + i * NW;
+    if (b < a.num_records)
+      acc += s_b[b] * v0[i];
+  }
+  if (col_ok)
+  {
+    int b = wave + BATCH * NW;
+    for (; b + (BATCH - 1) * NW < a.num_records; b += BATCH * NW)
+    {
+      float v[BATCH];
+#pragma unroll
+      for (int i = 0; i < BATCH; i++)
         v[i] = col[(size_t)(b + i * NW) * a.PS];
 #pragma unroll
-      for (int i = 0; i < 8; i++)
+      for (int i = 0; i < BATCH; i++)
         acc += s_b[b + i * NW] * v[i];
     }
     for (; b < a.num_records; b += NW)
