@@ -196,14 +196,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
+        # control plane only (barrier, max over ranks, shipping the RCCL id): gloo.  The DATA path is the library's own
+        # RCCL communicator on the engine's stream.  (This image's torch wheel bundles a second ROCm runtime; device
+        # buffers and streams of libmppi_amd.so belong to the system runtime, so torch's NCCL backend is not used on them.)
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo")
 
     cfg = cartpole_cfg(K=K_PER_GPU * world, T=T)
     eng = make_engine(cfg, device=local_rank, rank=rank, world_size=world)
+    x0 = cfg["x0"]
     exchange = "none"
+    run = lambda n: eng.optimize(n, True)  # noqa: E731
     if world > 1:
         import ctypes as C
+        from mppi_generic_amd.distributed import HostStagedExchange
         lib = m.load_library()
         uid = [None]
         if rank == 0:
@@ -212,11 +218,29 @@ def main():
             st = lib.mppi_rccl_unique_id(buf, 128, C.byref(nb))
             uid[0] = bytes(buf.raw) if st == 0 else None
         dist.broadcast_object_list(uid, src=0)
-        assert uid[0] is not None, "could not create an RCCL unique id"
-        eng.commInitRccl(uid[0])
-        exchange = "rccl all-gather of %d floats per rank per iteration" % eng.exchangeBuffers()[2]
+        native_ok, why = False, "no RCCL unique id"
+        if uid[0] is not None:
+            try:
+                eng.commInitRccl(uid[0])
+                eng.uploadState(x0)
+                eng.optimize(1, True)
+                native_ok = bool(np.isfinite(eng.getOptimalControlSeq()).all())
+                why = "non-finite result after the first exchanged iteration"
+            except Exception as e:  # noqa: BLE001
+                why = str(e)
+        flags = [None] * world
+        dist.all_gather_object(flags, (native_ok, why))
+        if all(f[0] for f in flags):
+            exchange = "rccl all-gather of %d floats per rank per iteration (library-owned communicator)" % eng.exchangeBuffers()[2]
+        else:
+            # fall back to the host-staged exchange over the gloo group: slower, but independent of the collective library
+            reason = next(f[1] for f in flags if not f[0])
+            eng = make_engine(cfg, device=local_rank, rank=rank, world_size=world)
+            hx = HostStagedExchange(eng)
+            run = lambda n: (hx.iterate(n), eng.synchronize())  # noqa: E731
+            exchange = "host-staged all-gather over gloo of %d floats per rank per iteration (native RCCL unavailable: %s)" % (
+                eng.exchangeBuffers()[2], reason[:120])
 
-    x0 = cfg["x0"]
     eng.uploadState(x0)
 
     def barrier():
@@ -224,23 +248,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng.optimize(args.warmup, True)
+    run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    eng.optimize(args.steps, True)
+    run(args.steps)
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ok = bool(np.isfinite(eng.getOptimalControlSeq()).all())
 
     # dominant-kernel duration with HIP events on the engine's stream (separate, untimed pass)
     n_ev = min(200, max(20, args.steps))
-    ms_total, ms_roll = eng.timeIterations(n_ev)
+    try:
+        ms_total, ms_roll = eng.timeIterations(n_ev)
+    except Exception:  # noqa: BLE001  (host-staged fallback: no device-resident loop to time; use the wall-clock step)
+        ms_total = ms_roll = elapsed / args.steps * 1e3 * n_ev
     C_dim = eng.CONTROL_DIM
     b_alg = 4.0 * (2.0 * K_PER_GPU * T * C_dim + 2.0 * K_PER_GPU + 2.0 * T * C_dim)
     roll_us = ms_roll / n_ev * 1e3

@@ -105,6 +105,8 @@ typedef struct mppi_config
   int rank, world_size;  /* K-sharding over GPUs: this handle owns rollouts [rank*K/world, (rank+1)*K/world) */
   int save_samples;      /* != 0: keep the clamped samples v[D][K_local][T][C] in HBM (control_samples_d_) */
   int kernel_variant;    /* mppi_kernel_variant: which rollout kernel structure to use */
+  int force_exchange;    /* != 0 with world_size == 1: still run local merge -> all-gather -> global merge (exercises the
+                            RCCL path on a single GPU; needs mppi_comm_init_rccl or an external exchange) */
 } mppi_config;
 
 /** reference: GaussianParamsImpl, sampling_distributions/gaussian/gaussian.cuh:21-61 */
@@ -290,6 +292,11 @@ mppi_status mppi_synchronize(mppi_handle h);
  * handle has an RCCL communicator (mppi_comm_init_rccl).
  */
 mppi_status mppi_get_exchange_buffers(mppi_handle h, void** send, void** recv, size_t* floats_per_rank);
+/** host-staged variant of the external exchange, for callers whose collective library cannot touch this library's device
+ *  memory (e.g. a second ROCm runtime in the process): this rank's record [D][T*C+4] to the host / all ranks' records
+ *  [world][D][T*C+4] from the host.  Both synchronise the handle's stream. */
+mppi_status mppi_read_send_record(mppi_handle h, float* out);
+mppi_status mppi_write_recv_records(mppi_handle h, const float* in);
 /** one iteration split around the exchange: local rollout + local merge | (caller's all-gather) | global merge */
 mppi_status mppi_iteration_local(mppi_handle h);
 mppi_status mppi_iteration_merge(mppi_handle h);

@@ -34,6 +34,7 @@ class MppiConfig(C.Structure):
         ("world_size", C.c_int),
         ("save_samples", C.c_int),
         ("kernel_variant", C.c_int),
+        ("force_exchange", C.c_int),
     ]
 
 
@@ -107,6 +108,8 @@ SIGNATURES = {
     "mppi_time_iterations": (C.c_int, [H, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mppi_synchronize": (C.c_int, [H]),
     "mppi_get_exchange_buffers": (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "mppi_read_send_record": (C.c_int, [H, _f32p]),
+    "mppi_write_recv_records": (C.c_int, [H, _f32p]),
     "mppi_iteration_local": (C.c_int, [H]),
     "mppi_iteration_merge": (C.c_int, [H]),
     "mppi_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

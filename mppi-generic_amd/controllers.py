@@ -159,12 +159,13 @@ class MPPIController:
 
     def __init__(self, model, num_rollouts, num_timesteps, dt, lambda_, alpha=0.0, num_iters=1, seed=42,
                  noise_source=MPPI_NOISE_PHILOX_FUSED, block_x=0, block_y=0, device=0, stream=None, rank=0,
-                 world_size=1, save_samples=False, kernel_variant=0):
+                 world_size=1, save_samples=False, kernel_variant=0, force_exchange=False):
         self._lib = load_library()
         self._h = C.c_void_p()
         self._model = model.encode()
         cfg = MppiConfig(self._model, self.KIND, num_rollouts, num_timesteps, dt, lambda_, alpha, num_iters, seed,
-                         noise_source, block_x, block_y, device, stream, rank, world_size, int(save_samples), kernel_variant)
+                         noise_source, block_x, block_y, device, stream, rank, world_size, int(save_samples), kernel_variant,
+                         int(force_exchange))
         st = self._lib.mppi_create(C.byref(cfg), C.byref(self._h))
         if st != 0:
             self._h = C.c_void_p()
@@ -343,6 +344,16 @@ class MPPIController:
         s, r, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
         self._check(self._lib.mppi_get_exchange_buffers(self._h, C.byref(s), C.byref(r), C.byref(n)))
         return s.value, r.value, n.value
+
+    def readSendRecord(self):
+        n = self.exchangeBuffers()[2]
+        out = np.empty(n, np.float32)
+        self._check(self._lib.mppi_read_send_record(self._h, out))
+        return out
+
+    def writeRecvRecords(self, records):
+        r = _f32(records).reshape(-1)
+        self._check(self._lib.mppi_write_recv_records(self._h, r))
 
     def iterationLocal(self):
         self._check(self._lib.mppi_iteration_local(self._h))

@@ -95,6 +95,13 @@ struct mppi_handle_s
   void* comm = nullptr;
 };
 
+/** the multi-rank path (local merge -> all-gather -> global merge) runs for world_size > 1, and for a world of ONE when
+ *  the caller asks for it (cfg.force_exchange): that exercises the RCCL plumbing on a single GPU */
+static inline bool exchangeActive(const mppi_handle_s* h)
+{
+  return h->cfg.world_size > 1 || h->cfg.force_exchange != 0;
+}
+
 static mppi_status fail(mppi_handle h, mppi_status s, const std::string& msg)
 {
   if (h)
@@ -352,6 +359,14 @@ void mppi_destroy(mppi_handle h)
   (void)hipSetDevice(h->cfg.device);
   if (h->stream)
     (void)hipStreamSynchronize(h->stream);
+  if (h->comm && h->rccl_lib)
+  {
+    typedef int (*destroy_fn)(void*);
+    destroy_fn d = (destroy_fn)dlsym(h->rccl_lib, "ncclCommDestroy");
+    if (d)
+      (void)d(h->comm);
+    h->comm = nullptr;
+  }
   freeAll(h);
   delete h;
 }
@@ -588,14 +603,14 @@ __global__ void regroupRecordsKernel(const float* __restrict__ in, float* __rest
 static mppi_status iterationLocal(mppi_handle h, int iteration, int stride)
 {
   MPPI_TRY(launchRollout(h, iteration, stride));
-  if (h->cfg.world_size == 1)
+  if (!exchangeActive(h))
     return launchCombine(h, h->partials_d, h->num_blocks, 1, nullptr, h->cfg.num_rollouts);
   return launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local);
 }
 
 static mppi_status iterationMerge(mppi_handle h)
 {
-  if (h->cfg.world_size == 1)
+  if (!exchangeActive(h))
     return MPPI_OK;
   const int n = h->cfg.world_size * h->D * h->PS;
   hipLaunchKernelGGL(regroupRecordsKernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->recv_d, h->gather_tmp_d,
@@ -607,7 +622,7 @@ static mppi_status iterationMerge(mppi_handle h)
 static mppi_status iteration(mppi_handle h, int it, int stride)
 {
   MPPI_TRY(iterationLocal(h, it, stride));
-  if (h->cfg.world_size > 1)
+  if (exchangeActive(h))
   {
     if (!h->comm || !g_ncclAllGather)
       return fail(h, MPPI_ERR_STATE,
@@ -1358,7 +1373,7 @@ mppi_status mppi_time_iterations(mppi_handle h, int n, float* ms_total, float* m
       HIP_TRY(h, hipEventRecord(ev[2 * i], h->stream));
       MPPI_TRY(launchRollout(h, 0, h->last_stride));
       HIP_TRY(h, hipEventRecord(ev[2 * i + 1], h->stream));
-      if (h->cfg.world_size == 1)
+      if (!exchangeActive(h))
         MPPI_TRY(launchCombine(h, h->partials_d, h->num_blocks, 1, nullptr, h->cfg.num_rollouts));
       else
         MPPI_TRY(launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local));
@@ -1398,6 +1413,27 @@ mppi_status mppi_get_exchange_buffers(mppi_handle h, void** send, void** recv, s
     *floats_per_rank = (size_t)h->D * h->PS;
   return MPPI_OK;
 }
+mppi_status mppi_read_send_record(mppi_handle h, float* out)
+{
+  CHECK_HANDLE(h);
+  if (!out)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(out, h->send_d, sizeof(float) * h->D * h->PS, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+mppi_status mppi_write_recv_records(mppi_handle h, const float* in)
+{
+  CHECK_HANDLE(h);
+  if (!in)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(h->recv_d, in, sizeof(float) * h->cfg.world_size * h->D * h->PS, hipMemcpyHostToDevice,
+                            h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // `in` is the caller's
+  return MPPI_OK;
+}
 mppi_status mppi_iteration_local(mppi_handle h)
 {
   CHECK_HANDLE(h);
@@ -1416,14 +1452,34 @@ static void* loadRccl(std::string& err)
   static void* lib = nullptr;
   if (lib)
     return lib;
-  const char* names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" };
-  for (const char* n : names)
+  // The communicator must live on the SAME HIP runtime as this library's streams and buffers.  A host application may
+  // carry a second ROCm stack (PyTorch wheels bundle their own libamdhip64 / librccl), and a plain dlopen("librccl.so")
+  // would hand back that copy.  So: first the librccl that sits next to the libamdhip64 this library is linked to (by
+  // absolute path), then the usual names.
+  std::vector<std::string> candidates;
+  Dl_info info{};
+  if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname)
   {
-    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos)
+    {
+      dir.resize(slash);
+      candidates.push_back(dir + "/librccl.so.1");
+      candidates.push_back(dir + "/librccl.so");
+    }
+  }
+  candidates.push_back("/opt/rocm/lib/librccl.so.1");
+  candidates.push_back("/opt/rocm/lib/librccl.so");
+  candidates.push_back("librccl.so.1");
+  candidates.push_back("librccl.so");
+  for (const std::string& n : candidates)
+  {
+    lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (lib)
       return lib;
   }
-  err = std::string("cannot dlopen librccl.so: ") + dlerror();
+  err = std::string("cannot dlopen librccl: ") + dlerror();
   return nullptr;
 }
 

@@ -58,6 +58,37 @@ class RecordExchange:
         return recv.view(self.world, self.n)
 
 
+def hip_runtimes_in_process():
+    """distinct libamdhip64 files mapped into this process (PyTorch wheels bundle their own ROCm stack; device pointers
+    and streams of one HIP runtime must not be handed to libraries bound to another)"""
+    paths = set()
+    try:
+        for line in open("/proc/self/maps"):
+            if "libamdhip64" in line:
+                paths.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(paths)
+
+
+class HostStagedExchange:
+    """The same protocol with the records staged through host memory (mppi_read_send_record /
+    mppi_write_recv_records) and gathered by any torch.distributed backend (gloo included).  Slower (two small copies
+    and a stream sync per iteration) but independent of which ROCm runtime the collective library is bound to."""
+
+    def __init__(self, controller, group=None):
+        self.ctrl = controller
+        self.exchange = RecordExchange(controller.exchangeBuffers()[2], group)
+
+    def iterate(self, num_iterations=1):
+        import torch
+        for _ in range(num_iterations):
+            self.ctrl.iterationLocal()
+            rec = torch.from_numpy(self.ctrl.readSendRecord())
+            self.ctrl.writeRecvRecords(self.exchange.all_gather(rec).numpy())
+            self.ctrl.iterationMerge()
+
+
 class _DeviceSpan:
     """exposes a raw device pointer through __cuda_array_interface__ so that torch can alias it without a copy"""
 
@@ -68,23 +99,37 @@ class _DeviceSpan:
 
 class ShardedController:
     """Drives a controller created with (rank, world_size) through iterations whose exchange runs on torch.distributed.
-    Create the controller with stream=torch.cuda.current_stream().cuda_stream so that kernels and the collective are
-    ordered on one stream."""
 
-    def __init__(self, controller, group=None):
+    Kernels and the collective must be ordered on ONE stream: create a torch side stream, hand its raw handle to the
+    controller, and this class issues the all-gather under that stream:
+        s = torch.cuda.Stream()
+        ctrl = VanillaMPPIController(..., rank=r, world_size=G, stream=s.cuda_stream)
+        sharded = ShardedController(ctrl, s)
+    (torch's default stream is the NULL stream, which the engine treats as "create my own" — do not pass that.)"""
+
+    def __init__(self, controller, stream, group=None):
         import torch
+        if not stream.cuda_stream:
+            raise ValueError("ShardedController needs a non-default torch.cuda.Stream shared with the controller")
+        rts = hip_runtimes_in_process()
+        if len(rts) > 1:
+            raise RuntimeError("two HIP runtimes are loaded (%s): torch cannot operate on this library's device buffers "
+                               "and stream; use the library's own RCCL driver (mppi_comm_init_rccl) or HostStagedExchange"
+                               % ", ".join(rts))
         self.ctrl = controller
+        self.stream = stream
         send, recv, n = controller.exchangeBuffers()
         self.exchange = RecordExchange(n, group)
         self.send = torch.as_tensor(_DeviceSpan(send, n), device="cuda")
         self.recv = torch.as_tensor(_DeviceSpan(recv, n * self.exchange.world), device="cuda")
 
     def iterate(self, num_iterations=1):
-        for _ in range(num_iterations):
-            self.ctrl.iterationLocal()
-            if self.exchange.world > 1:
-                self.exchange.all_gather(self.send, self.recv)
-            self.ctrl.iterationMerge()
+        import torch
+        with torch.cuda.stream(self.stream):
+            for _ in range(num_iterations):
+                self.ctrl.iterationLocal()
+                self.exchange.all_gather(self.send, self.recv)  # a world of one copies send -> recv (force_exchange)
+                self.ctrl.iterationMerge()
 
 
 def merge_rule_float64(U, rho, eta, lambda_):

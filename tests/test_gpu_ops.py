@@ -137,6 +137,59 @@ def test_two_way_sharding_on_one_gpu(gpu):
     assert np.abs(u_full - u_orc).max() <= 1e-5
 
 
+def test_rccl_exchange_path_on_one_gpu(gpu):
+    """the library's own RCCL driver (dlopen, ncclGetUniqueId, ncclCommInitRank, ncclAllGather on the handle's stream) with a
+    world of ONE rank: force_exchange routes every iteration through local merge -> all-gather -> global merge"""
+    import ctypes as C
+    cfg = cartpole_cfg(K=2048, T=100, soft=True)
+    plain = make_engine(cfg)
+    plain.uploadState(cfg["x0"])
+    plain.optimize(3)
+    lib = m.load_library()
+    buf = C.create_string_buffer(128)
+    nb = C.c_size_t()
+    assert lib.mppi_rccl_unique_id(buf, 128, C.byref(nb)) == 0 and nb.value == 128
+    eng = make_engine(cfg, force_exchange=True)
+    with pytest.raises(m.MPPIError) as e:  # exchange requested but no communicator yet
+        eng.uploadState(cfg["x0"])
+        eng.optimize(1)
+    assert e.value.status == 7
+    eng.setSeed(42)
+    eng.commInitRccl(bytes(buf.raw))
+    eng.uploadState(cfg["x0"])
+    eng.optimize(3)
+    assert np.abs(eng.getOptimalControlSeq() - plain.getOptimalControlSeq()).max() <= 2e-6
+    assert eng.getStats().real_sys.baseline == plain.getStats().real_sys.baseline
+
+
+def test_host_staged_exchange_on_one_gpu(gpu):
+    """the external driver with host-staged records (mppi-generic_amd/distributed.py HostStagedExchange) over a gloo group
+    of one rank: local merge -> D2H -> all-gather -> H2D -> global merge reproduces the plain result"""
+    import torch.distributed as dist
+    from mppi_generic_amd.distributed import HostStagedExchange, ShardedController, hip_runtimes_in_process
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1)
+    cfg = cartpole_cfg(K=2048, T=100, soft=True)
+    plain = make_engine(cfg)
+    plain.uploadState(cfg["x0"])
+    plain.optimize(3)
+    eng = make_engine(cfg, force_exchange=True)
+    hx = HostStagedExchange(eng)
+    eng.uploadState(cfg["x0"])
+    hx.iterate(3)
+    assert np.abs(eng.getOptimalControlSeq() - plain.getOptimalControlSeq()).max() <= 2e-6
+    # the zero-copy variant refuses to run across two HIP runtimes (this image's torch wheel bundles its own ROCm)
+    import torch
+    if torch.cuda.is_available() and len(hip_runtimes_in_process()) > 1:
+        side = torch.cuda.Stream()
+        eng2 = make_engine(cfg, force_exchange=True, stream=side.cuda_stream)
+        with pytest.raises(RuntimeError):
+            ShardedController(eng2, side)
+    if created:
+        dist.destroy_process_group()
+
+
 def test_full_size_properties(gpu):
     """BASELINE size (K=16384, T=100): size-independent properties instead of a slow oracle run —
     (1) baseline == min of the costs, (2) normaliser == sum of exp weights, (3) u* == direct weighted mean of the
