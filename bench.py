@@ -302,13 +302,13 @@ def main():
             },
         }
         # secondary workload of the north star (not the headline `value`): AutoRally-NN, K=16384, T=150, MFMA forward
-        if not args.primary_only:
+        if not args.primary_only and world == 1:
             for key, leg in (("autorally_nn", autorally_leg), ("lstm_colored", lstm_colored_leg), ("di_tube", di_tube_leg)):
                 try:
                     out[key] = leg(local_rank)
                 except Exception as e:  # noqa: BLE001
                     out[key] = {"error": str(e)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cartpole_cfg(K=K_PER_GPU, T=T))
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -115,6 +115,25 @@ MPPI_HD static inline float fmod(float a, float b)
 #define MPPI_DET_PI 3.14159274101257324219f     /* (float)pi, same value as glibc's M_PIf32 used by the reference */
 #define MPPI_DET_TWO_PI 6.28318548202514648438f /* 2*(float)pi, exact doubling */
 
+/**
+ * normalizeAngle for |angle| < 1e7 rad (q = trunc(|a| / 2 pi) < 2^21): the fast path of fmod_rb without the test for the
+ * library fallback — bit-identical to normalizeAngle() on that range, and six instructions shorter on the dependent
+ * chain of a rollout step.  For models whose angles are physically bounded (a pole does not spin 10^6 times per horizon).
+ */
+MPPI_HD static inline float normalizeAngleBounded(float angle)
+{
+  const float a = angle + MPPI_DET_PI;
+  const float aa = fabs(a);
+  const float q = trunc(aa * 0.15915494309189534561f);
+  float r = fma(-q, MPPI_DET_TWO_PI, aa);
+  const float rp = r + MPPI_DET_TWO_PI, rm = r - MPPI_DET_TWO_PI;
+  r = (r < 0.0f) ? rp : ((r >= MPPI_DET_TWO_PI) ? rm : r);
+  const float result = copysign(r, a);
+  if (result <= 0.0f)
+    return result + MPPI_DET_PI;
+  return result - MPPI_DET_PI;
+}
+
 /** Reference: include/mppi/utils/angle_utils.cuh:21-27 (float overload), same branch structure. */
 MPPI_HD static inline float normalizeAngle(float angle)
 {
@@ -271,6 +290,12 @@ MPPI_HD static inline float div_benign(float p, float q)
 #else
   return p / q;
 #endif
+}
+
+/** 1 / x for x in a benign range (|x| in [2^-60, 2^60]): the correctly rounded reciprocal, see div_benign */
+MPPI_HD static inline float rcp_benign(float x)
+{
+  return div_benign(1.0f, x);
 }
 
 /**

@@ -75,7 +75,9 @@ public:
 
   __device__ inline void computeDynamics(float* state, float* control, float* state_der, float* theta = nullptr)
   {
-    float theta_n = angle_utils::normalizeAngle(state[2]);
+    // reference: angle_utils::normalizeAngle(state[2]) (cartpole_dynamics.cu:91); the bounded variant returns the same
+    // value for |theta| < 1e7 rad and keeps the range test off the rollout's dependent chain
+    float theta_n = angle_utils::normalizeAngleBounded(state[2]);
     float sin_theta, cos_theta;
     mppi::det::sincos(theta_n, &sin_theta, &cos_theta);
     float theta_dot = state[3];
@@ -85,11 +87,13 @@ public:
     float l_p = this->params_.pole_length;
 
     state_der[0] = state[1];
-    state_der[1] =
-        1.0f / (m_c + m_p * SQ(sin_theta)) * (force + m_p * sin_theta * (l_p * SQ(theta_dot) + gravity_ * cos_theta));
+    // 1.0f / x with x = m_c + m_p sin^2 (and l_p x below): positive, ordinary magnitudes -> det::rcp_benign returns the
+    // correctly rounded IEEE reciprocal (what the reference's `1.0f / (...)` and the CPU oracle compute) in 7 instructions
+    state_der[1] = mppi::det::rcp_benign(m_c + m_p * SQ(sin_theta)) *
+                   (force + m_p * sin_theta * (l_p * SQ(theta_dot) + gravity_ * cos_theta));
     state_der[2] = theta_dot;
     state_der[3] =
-        1.0f / (l_p * (m_c + m_p * SQ(sin_theta))) *
+        mppi::det::rcp_benign(l_p * (m_c + m_p * SQ(sin_theta))) *
         (-force * cos_theta - m_p * l_p * SQ(theta_dot) * cos_theta * sin_theta - (m_c + m_p) * gravity_ * sin_theta);
   }
 

@@ -43,6 +43,11 @@ __host__ __device__ static inline float normalizeAngle(float angle)
 {
   return mppi::det::normalizeAngle(angle);
 }
+/** the same value for |angle| < 1e7 rad, without the out-of-range test on the dependent chain (det_math.h) */
+__host__ __device__ static inline float normalizeAngleBounded(float angle)
+{
+  return mppi::det::normalizeAngleBounded(angle);
+}
 __host__ __device__ static inline float shortestAngularDistance(float from, float to)
 {
   return normalizeAngle(to - from);

@@ -44,6 +44,9 @@ def build(force=False, verbose=False):
         "-I" + os.path.join(REPO, "include"), "-I" + CSRC,
         os.path.join(CSRC, "engine.hip"), "-o", LIB + ".tmp", "-ldl",
     ]
+    extra = os.environ.get("MPPI_HIPCC_EXTRA", "")
+    if extra:
+        cmd[1:1] = extra.split()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)

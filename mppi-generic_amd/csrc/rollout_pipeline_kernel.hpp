@@ -210,11 +210,31 @@ __global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
         slot[i * 64] = y[i];
     };
     int seen_smp = 0, seen_cost = 0;
-    for (int t = 0; t < num_timesteps; t += 4)
+    int t = 0;
+    // Full groups of 4 steps form ONE basic block (no tail test between the steps): the recurrence is skewed — the angle
+    // of step t + 1 depends only on the state at t, not on step t's derivative — so the scheduler can start the next
+    // step's argument reduction / sincos underneath the current step's division chain.  A single wave issues in order,
+    // and most instructions of a step wait ~8 cycles on their predecessor; overlapping the two chains is what shortens
+    // the critical path.
+    for (; t + 3 < num_timesteps; t += 4)
     {
-      const int hi = min(t + 4, num_timesteps);
-      pipeWait(smp_prog, hi, seen_smp);               // samples for steps t .. hi-1 are in the rows
-      pipeWait(cost_prog, hi - PIPE_RING, seen_cost); // their ring slots have been consumed
+      pipeWait(smp_prog, t + 4, seen_smp);               // samples for steps t .. t+3 are in the rows
+      pipeWait(cost_prog, t + 4 - PIPE_RING, seen_cost); // their ring slots have been consumed
+      float ubuf[4 * C];
+#pragma unroll
+      for (int j = 0; j < 4 * C; j++)
+        ubuf[j] = row[t * C + j];
+      dyn_step(x, x_next, t, &ubuf[0]);
+      dyn_step(x_next, x, t + 1, &ubuf[C]);
+      dyn_step(x, x_next, t + 2, &ubuf[2 * C]);
+      dyn_step(x_next, x, t + 3, &ubuf[3 * C]);
+      pipePublish(dyn_prog, t + 4, lane);
+    }
+    if (t < num_timesteps)
+    {  // tail of 1..3 steps
+      const int hi = num_timesteps;
+      pipeWait(smp_prog, hi, seen_smp);
+      pipeWait(cost_prog, hi - PIPE_RING, seen_cost);
       float ubuf[4 * C];
 #pragma unroll
       for (int j = 0; j < 4 * C; j++)
@@ -224,8 +244,6 @@ __global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
         dyn_step(x_next, x, t + 1, &ubuf[C]);
       if (t + 2 < num_timesteps)
         dyn_step(x, x_next, t + 2, &ubuf[2 * C]);
-      if (t + 3 < num_timesteps)
-        dyn_step(x_next, x, t + 3, &ubuf[3 * C]);
       pipePublish(dyn_prog, hi, lane);
     }
   }
@@ -453,19 +471,31 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
       }
     };
     int seen_smp = 0, seen_cost = 0;
-    for (int t = 0; t < num_timesteps; t += 2)
+    int t = 0;
+    // full pairs of steps as one basic block (see rolloutPipelineKernel): lets the scheduler overlap the second step's
+    // independent work with the first step's MFMA chains
+    for (; t + 1 < num_timesteps; t += 2)
     {
-      const int hi = min(t + 2, num_timesteps);
-      pipeWait(smp_prog, hi, seen_smp);
-      pipeWait(cost_prog, hi - ring_steps, seen_cost);
+      pipeWait(smp_prog, t + 2, seen_smp);
+      pipeWait(cost_prog, t + 2 - ring_steps, seen_cost);
       float ubuf[2 * C];
 #pragma unroll
       for (int j = 0; j < 2 * C; j++)
-        ubuf[j] = (t * C + j < num_timesteps * C) ? row[t * C + j] : 0.0f;
+        ubuf[j] = row[t * C + j];
       dyn_step(x, x_next, t, &ubuf[0]);
-      if (t + 1 < num_timesteps)
-        dyn_step(x_next, x, t + 1, &ubuf[C]);
-      pipePublish(my_prog, hi, lane);
+      dyn_step(x_next, x, t + 1, &ubuf[C]);
+      pipePublish(my_prog, t + 2, lane);
+    }
+    if (t < num_timesteps)
+    {
+      pipeWait(smp_prog, num_timesteps, seen_smp);
+      pipeWait(cost_prog, num_timesteps - ring_steps, seen_cost);
+      float ubuf[C];
+#pragma unroll
+      for (int j = 0; j < C; j++)
+        ubuf[j] = row[t * C + j];
+      dyn_step(x, x_next, t, &ubuf[0]);
+      pipePublish(my_prog, num_timesteps, lane);
     }
   }
   else
