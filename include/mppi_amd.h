@@ -188,6 +188,22 @@ mppi_status mppi_set_nominal_threshold(mppi_handle h, float threshold);
  */
 mppi_status mppi_set_model_blob(mppi_handle h, const char* name, const float* data, size_t count, const int* dims,
                                 int ndims);
+/**
+ * The same data straight from the reference's .npz files (read with cnpy there; a ZIP + NPY reader with zlib here):
+ *   kind "dynamics"  FNNHelper::loadParams (utils/nn_helpers/fnn_helper.cu:96-174): keys {prefix}dynamics_W{i},
+ *                    {prefix}dynamics_b{i}, i = 1.., float64
+ *   kind "lstm"      LSTMHelper::loadParams (utils/nn_helpers/lstm_helper.cu:514-585): [model/]{prefix}lstm/weight_hh_l0,
+ *                    weight_ih_l0, bias_hh_l0, bias_ih_l0 (PyTorch gate order, re-ordered and summed as there) and
+ *                    {prefix}output/dynamics_W{i}, _b{i}; optional {prefix}lstm/h0, c0 (default zeros)
+ *   kind "costmap"   ARStandardCost::loadTrackData (cost_functions/autorally/ar_standard_cost.cu:84-142): xBounds, yBounds,
+ *                    pixelsPerMeter, channel0; also sets the world -> texture transform of the cost
+ * prefix may be NULL.  A git-LFS pointer file in place of the archive is reported as such.
+ */
+mppi_status mppi_load_npz(mppi_handle h, const char* kind, const char* path, const char* prefix);
+/** handle-free access to one array of an .npz (as double, C order): count / dims[<= 8] / ndims are always filled, out only
+ *  when non-NULL (capacity in elements).  Host-only; message of a failure: mppi_last_error(NULL). */
+mppi_status mppi_npz_read_array(const char* path, const char* key, double* out, size_t capacity, size_t* count, int* dims,
+                                int* ndims);
 /** reseed the noise generator and reset its offset (controllers/controller.cu:200-207) */
 mppi_status mppi_set_seed(mppi_handle h, uint64_t seed);
 

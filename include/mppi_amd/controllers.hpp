@@ -109,6 +109,11 @@ public:
   {
     check(mppi_set_model_blob(h_, name.c_str(), data.data(), data.size(), dims.data(), (int)dims.size()));
   }
+  /** kind: "dynamics" | "lstm" | "costmap" (the reference's .npz layouts; mppi_load_npz) */
+  void loadNpz(const std::string& kind, const std::string& path, const std::string& prefix = "")
+  {
+    check(mppi_load_npz(h_, kind.c_str(), path.c_str(), prefix.empty() ? nullptr : prefix.c_str()));
+  }
   void setLambda(float lambda, float alpha = 0.0f)
   {
     check(mppi_set_lambda_alpha(h_, lambda, alpha));

@@ -12,7 +12,7 @@ from .controllers import (MPPI_CONTROLLER_TUBE, MPPI_CONTROLLER_VANILLA, MPPI_NO
                           MPPI_CONTROLLER_COLORED, CartpoleDynamicsParams,
                           CartpoleQuadraticCostParams, DoubleIntegratorParams, DoubleIntegratorCircleCostParams,
                           ARStandardCostParams, fnn_blob_from_npz_dict, lstm_blob_from_npz_dict,
-                          det_eval, philox_normal, norm_exp, compute_weights, weighted_reduction)
+                          det_eval, npz_read_array, philox_normal, norm_exp, compute_weights, weighted_reduction)
 
 __all__ = [
     "build", "load_library", "library_path", "MPPIError", "MPPIController", "VanillaMPPIController",

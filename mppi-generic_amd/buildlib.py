@@ -42,7 +42,7 @@ def build(force=False, verbose=False):
     cmd = [
         hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
         "-I" + os.path.join(REPO, "include"), "-I" + CSRC,
-        os.path.join(CSRC, "engine.hip"), "-o", LIB + ".tmp", "-ldl",
+        os.path.join(CSRC, "engine.hip"), "-o", LIB + ".tmp", "-ldl", "-lz",
     ]
     extra = os.environ.get("MPPI_HIPCC_EXTRA", "")
     if extra:

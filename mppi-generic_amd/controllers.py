@@ -224,6 +224,11 @@ class MPPIController:
         dims = (C.c_int * a.ndim)(*a.shape)
         self._check(self._lib.mppi_set_model_blob(self._h, name.encode(), a.reshape(-1), a.size, dims, a.ndim))
 
+    def loadNpz(self, kind, path, prefix=None):
+        """model data straight from the reference's .npz layout (kind: "dynamics" | "lstm" | "costmap"); mppi_load_npz"""
+        self._check(self._lib.mppi_load_npz(self._h, kind.encode(), str(path).encode(),
+                                            None if prefix is None else prefix.encode()))
+
     def setControlRanges(self, lo_hi):
         self._check(self._lib.mppi_set_control_ranges(self._h, _f32(lo_hi).reshape(-1)))
 
@@ -439,6 +444,18 @@ class TubeMPPIController(MPPIController):
 def _op_check(lib, st):
     if st != 0:
         raise MPPIError(st, (lib.mppi_last_error(None) or b"").decode())
+
+
+def npz_read_array(path, key):
+    """one array of an .npz through the library's own reader (host only; returns float64 in C order)"""
+    lib = load_library()
+    n, nd = C.c_size_t(), C.c_int()
+    dims = (C.c_int * 8)()
+    _op_check(lib, lib.mppi_npz_read_array(str(path).encode(), key.encode(), None, 0, C.byref(n), dims, C.byref(nd)))
+    out = np.empty(n.value, np.float64)
+    _op_check(lib, lib.mppi_npz_read_array(str(path).encode(), key.encode(), out.ctypes.data, n.value, C.byref(n), dims,
+                                           C.byref(nd)))
+    return out.reshape([dims[i] for i in range(nd.value)])
 
 
 def det_eval(func, x, device=0):

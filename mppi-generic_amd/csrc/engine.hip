@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "mppi_amd.h"
+#include "npz_reader.hpp"
 #include "model_instance.hpp"
 #include "models.hpp"
 
@@ -500,6 +501,150 @@ mppi_status mppi_set_model_blob(mppi_handle h, const char* name, const float* da
   const size_t lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, h->cfg.num_timesteps, h->D, h->pipeline);
   if (lds > MAX_LDS_BYTES)
     return fail(h, MPPI_ERR_LDS_OVERFLOW, "rollout kernel LDS request exceeds 160 KiB after loading '" + std::string(name) + "'");
+  return MPPI_OK;
+}
+
+
+/* ---------------------------------------------------------------- .npz model data ---------------------------------- */
+static mppi_status setBlobD(mppi_handle h, const char* name, const std::vector<double>& v, const std::vector<int>& dims)
+{
+  std::vector<float> f(v.begin(), v.end());
+  return mppi_set_model_blob(h, name, f.data(), f.size(), dims.data(), (int)dims.size());
+}
+
+/** FNN blob [W1 | b1 | W2 | b2 | ...] from keys {prefix}dynamics_W{i}, {prefix}dynamics_b{i} (fnn_helper.cu:96-174) */
+static bool fnnBlobFromNpz(const std::map<std::string, npz::Array>& d, const std::string& prefix, std::vector<double>& blob,
+                           std::string& err)
+{
+  blob.clear();
+  for (int i = 1;; i++)
+  {
+    auto w = d.find(prefix + "dynamics_W" + std::to_string(i));
+    auto b = d.find(prefix + "dynamics_b" + std::to_string(i));
+    if (w == d.end() || b == d.end())
+    {
+      if (i == 1)
+      {
+        err = "no key '" + prefix + "dynamics_W1' / '" + prefix + "dynamics_b1' in the archive";
+        return false;
+      }
+      return true;
+    }
+    blob.insert(blob.end(), w->second.data.begin(), w->second.data.end());
+    blob.insert(blob.end(), b->second.data.begin(), b->second.data.end());
+  }
+}
+
+mppi_status mppi_load_npz(mppi_handle h, const char* kind, const char* path, const char* prefix_c)
+{
+  CHECK_HANDLE(h);
+  if (!kind || !path)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_load_npz: null");
+  std::map<std::string, npz::Array> d;
+  std::string err;
+  if (!npz::load(path, d, err))
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_load_npz: " + err);
+  std::string prefix = prefix_c ? prefix_c : "";
+  const std::string k(kind);
+  if (k == "dynamics")
+  {
+    std::vector<double> blob;
+    if (!fnnBlobFromNpz(d, prefix, blob, err))
+      return fail(h, MPPI_ERR_INVALID_ARG, "mppi_load_npz: " + err);
+    return setBlobD(h, "dynamics_weights", blob, { (int)blob.size() });
+  }
+  if (k == "lstm")
+  {
+    // LSTMHelper::loadParams (lstm_helper.cu:514-585): optional trailing '/', optional "model/" in front, PyTorch gate
+    // order i, f, g, o re-ordered to i, f, o, c, the two bias vectors summed; output network under {prefix}output/
+    if (!prefix.empty() && prefix.back() != '/')
+      prefix += "/";
+    if (d.count("model/" + prefix + "lstm/weight_hh_l0"))
+      prefix = "model/" + prefix;
+    const char* keys[4] = { "lstm/weight_hh_l0", "lstm/weight_ih_l0", "lstm/bias_hh_l0", "lstm/bias_ih_l0" };
+    for (const char* key : keys)
+      if (!d.count(prefix + key))
+        return fail(h, MPPI_ERR_INVALID_ARG, std::string("mppi_load_npz: no key '") + prefix + key + "' in the archive");
+    const npz::Array &whh = d[prefix + keys[0]], &wih = d[prefix + keys[1]], &bhh = d[prefix + keys[2]],
+                     &bih = d[prefix + keys[3]];
+    const int H = (int)bhh.size() / 4;
+    if (H <= 0 || (int)whh.size() != 4 * H * H || wih.size() % (4 * H) != 0 || bih.size() != bhh.size())
+      return fail(h, MPPI_ERR_INVALID_ARG, "mppi_load_npz: inconsistent LSTM array shapes");
+    const int I = (int)wih.size() / (4 * H);
+    const int order[4] = { 0, 1, 3, 2 };  // blob gate g <- torch gate order[g]
+    std::vector<double> blob;
+    for (int g = 0; g < 4; g++)
+      blob.insert(blob.end(), whh.data.begin() + (size_t)order[g] * H * H, whh.data.begin() + (size_t)(order[g] + 1) * H * H);
+    for (int g = 0; g < 4; g++)
+      blob.insert(blob.end(), wih.data.begin() + (size_t)order[g] * H * I, wih.data.begin() + (size_t)(order[g] + 1) * H * I);
+    for (int g = 0; g < 4; g++)
+      for (int i = 0; i < H; i++)
+        blob.push_back(bhh.data[(size_t)order[g] * H + i] + bih.data[(size_t)order[g] * H + i]);
+    for (const char* init : { "lstm/h0", "lstm/c0" })
+    {
+      auto it = d.find(prefix + init);
+      for (int i = 0; i < H; i++)
+        blob.push_back(it != d.end() && (int)it->second.size() == H ? it->second.data[i] : 0.0);
+    }
+    MPPI_TRY(setBlobD(h, "lstm_weights", blob, { (int)blob.size() }));
+    std::vector<double> out_blob;
+    if (!fnnBlobFromNpz(d, prefix + "output/", out_blob, err))
+      return fail(h, MPPI_ERR_INVALID_ARG, "mppi_load_npz: " + err);
+    return setBlobD(h, "lstm_output_weights", out_blob, { (int)out_blob.size() });
+  }
+  if (k == "costmap")
+  {
+    // ARStandardCost::loadTrackData (ar_standard_cost.cu:84-142)
+    for (const char* key : { "xBounds", "yBounds", "pixelsPerMeter", "channel0" })
+      if (!d.count(key))
+        return fail(h, MPPI_ERR_INVALID_ARG, std::string("mppi_load_npz: no key '") + key + "' in the archive");
+    const float x_min = (float)d["xBounds"].data[0], x_max = (float)d["xBounds"].data[1];
+    const float y_min = (float)d["yBounds"].data[0], y_max = (float)d["yBounds"].data[1];
+    const float ppm = (float)d["pixelsPerMeter"].data[0];
+    const int width = int((x_max - x_min) * ppm), height = int((y_max - y_min) * ppm);
+    if (width <= 0 || height <= 0 || (size_t)width * height != d["channel0"].size())
+      return fail(h, MPPI_ERR_INVALID_ARG, "mppi_load_npz: load track has invalid sizes");
+    const float r_c1[3] = { 1.0f / (x_max - x_min), 0.0f, 0.0f };
+    const float r_c2[3] = { 0.0f, 1.0f / (y_max - y_min), 0.0f };
+    const float trs[3] = { -x_min / (x_max - x_min), -y_min / (y_max - y_min), 1.0f };
+    if (h->model->setCostmapTransform(r_c1, r_c2, trs) != MPPI_OK)
+      return fail(h, MPPI_ERR_INVALID_ARG, "mppi_load_npz: the model's cost has no costmap");
+    return setBlobD(h, "costmap", d["channel0"].data, { height, width });
+  }
+  return fail(h, MPPI_ERR_INVALID_ARG, "mppi_load_npz: kind must be \"dynamics\", \"lstm\" or \"costmap\"");
+}
+
+mppi_status mppi_npz_read_array(const char* path, const char* key, double* out, size_t capacity, size_t* count, int* dims,
+                                int* ndims)
+{
+  if (!path || !key)
+    return MPPI_ERR_INVALID_ARG;
+  std::map<std::string, npz::Array> d;
+  std::string err;
+  if (!npz::load(path, d, err))
+  {
+    g_create_error = "mppi_npz_read_array: " + err;
+    return MPPI_ERR_INVALID_ARG;
+  }
+  auto it = d.find(key);
+  if (it == d.end())
+  {
+    g_create_error = std::string("mppi_npz_read_array: no key '") + key + "'";
+    return MPPI_ERR_INVALID_ARG;
+  }
+  if (count)
+    *count = it->second.size();
+  if (ndims)
+    *ndims = (int)it->second.shape.size();
+  if (dims)
+    for (size_t i = 0; i < it->second.shape.size() && i < 8; i++)
+      dims[i] = it->second.shape[i];
+  if (out)
+  {
+    if (capacity < it->second.size())
+      return MPPI_ERR_INVALID_ARG;
+    std::copy(it->second.data.begin(), it->second.data.end(), out);
+  }
   return MPPI_OK;
 }
 

@@ -109,6 +109,11 @@ struct ModelBase
   {
     return 0;
   }
+  /** world -> texture transform of a costmap cost (ARStandardCost::updateTransform, ar_standard_cost.cu:132-137) */
+  virtual mppi_status setCostmapTransform(const float* r_c1, const float* r_c2, const float* trs)
+  {
+    return MPPI_ERR_INVALID_ARG;
+  }
   virtual bool supportsShape(int bx, int by, int bz) const = 0;
   /** role-pipelined variant (rollout_pipeline_kernel.hpp) available for this model? */
   virtual bool supportsPipeline() const
@@ -532,6 +537,21 @@ struct ModelT : ModelBase
       }
     }
     return ModelBase::setBlob(name, data, count, dims, ndims, stream, err);
+  }
+
+  mppi_status setCostmapTransform(const float* r_c1, const float* r_c2, const float* trs) override
+  {
+    if constexpr (has_costmap<COST_T>::value)
+    {
+      for (int i = 0; i < 3; i++)
+      {
+        cost.params_.r_c1[i] = r_c1[i];
+        cost.params_.r_c2[i] = r_c2[i];
+        cost.params_.trs[i] = trs[i];
+      }
+      return MPPI_OK;
+    }
+    return MPPI_ERR_INVALID_ARG;
   }
 
   /** models with bulk data must have it before the first launch */
