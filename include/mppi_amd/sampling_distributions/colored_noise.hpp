@@ -289,7 +289,7 @@ public:
     const int n = lane & 15;
     const int row0 = (int)(blockIdx.x * bx);
     const int nrows = min(bx, this->params_.num_rollouts - row0);
-    const int nz = (int)blockDim.z;
+    const int nz = this->systemsPerBlock();
     const int RG = (bx + 15) >> 4;
     const int KS = coloredNumKSteps(T), NTB = coloredNumTBlocks(T), KK = coloredSpectrumFloats(T);
     const int NG = KS >> 2;  // tiles of 4 k-steps

@@ -101,11 +101,17 @@ public:
    * the kernel's copy of the object is private to the thread, so these are ordinary registers */
   int thread_slot_ = -1;             ///< rollout slot of this thread, -1: blockDim.x * threadIdx.z + threadIdx.x
   int block_rollouts_ = 0;           ///< rollouts per block, 0: blockDim.x
+  int block_systems_ = 0;            ///< systems per block, 0: blockDim.z
 
-  __device__ inline void setThreadMapping(int slot, int block_rollouts)
+  __device__ inline void setThreadMapping(int slot, int block_rollouts, int block_systems = 0)
   {
     thread_slot_ = slot;
     block_rollouts_ = block_rollouts;
+    block_systems_ = block_systems;
+  }
+  __device__ inline int systemsPerBlock() const
+  {
+    return block_systems_ > 0 ? block_systems_ : (int)__builtin_amdgcn_workgroup_size_z();
   }
   __device__ inline int slotOfThread() const
   {
@@ -183,7 +189,7 @@ public:
     const int nthreads = (int)(blockDim.x * blockDim.y * blockDim.z);
     const int row0 = (int)(blockIdx.x * bx);  // first local rollout of the block
     const int nrows = min(bx, params_.num_rollouts - row0);
-    const int nz = (int)blockDim.z;
+    const int nz = systemsPerBlock();
     if (nrows <= 0)
       return;
     if (noise_source_ == NOISE_EPS_BUFFER)
@@ -231,6 +237,41 @@ public:
     }
   }
 
+  /**
+   * Per-distribution table entry / mean.  LANE_D: the distribution index differs between the lanes of a wave (the folded
+   * Tube kernel carries both systems of a rollout in one wave).  Both rows are then fetched with wave-uniform loads and
+   * the lane selects: indexing the kernel-argument struct with a per-lane value would push it into scratch memory, and
+   * per-lane mean pointers would turn scalar loads into flat loads inside the step loop.
+   */
+  template <bool LANE_D>
+  __device__ inline float distValue(const float* __restrict__ table, const int d, const int j) const
+  {
+    if constexpr (LANE_D)
+    {
+      const float a = table[j], b = table[CONTROL_DIM + j];
+      return d == 0 ? a : b;
+    }
+    else
+    {
+      return table[CONTROL_DIM * d + j];
+    }
+  }
+  template <bool LANE_D>
+  __device__ inline float meanValue(const int d, const int t, const int j) const
+  {
+    const float* m0 = control_means_d_ + (size_t)t * CONTROL_DIM;
+    if constexpr (LANE_D)
+    {
+      const float* m1 = m0 + (params_.num_distributions > 1 ? params_.num_timesteps * CONTROL_DIM : 0);
+      const float a = m0[j], b = m1[j];
+      return d == 0 ? a : b;
+    }
+    else
+    {
+      return m0[(size_t)params_.num_timesteps * d * CONTROL_DIM + j];
+    }
+  }
+
   /** the setGaussianControls rule (gaussian.cu:99-127), branch-free */
   __device__ inline float shapeSample(float m, float sd, float e, bool use_mean, bool pure) const
   {
@@ -249,16 +290,17 @@ public:
    * readControlSample for a rollout that owns one lane, with eps[CONTROL_DIM] already in registers (in-loop Philox
    * draw): applies the setGaussianControls rule.  Everything but eps is wave-uniform.
    */
+  template <bool LANE_D = false>
   __device__ inline void shapeControlSample(const int sample_index, const int t, const int distribution_index,
                                             const float* __restrict__ eps, float* __restrict__ control) const
   {
     const int d = distribution_index >= params_.num_distributions ? 0 : distribution_index;
-    const float* mean = control_means_d_ + (size_t)(params_.num_timesteps * d + t) * CONTROL_DIM;
     const bool use_mean = ((sample_index + rollout_offset_) == 0) || (t < optimization_stride_);
     const bool pure = isPureNoise(sample_index);
 #pragma unroll
     for (int i = 0; i < CONTROL_DIM; i++)
-      control[i] = shapeSample(mean[i], std_dev_decayed_[CONTROL_DIM * d + i], eps[i], use_mean, pure);
+      control[i] = shapeSample(meanValue<LANE_D>(d, t, i), distValue<LANE_D>(std_dev_decayed_, d, i), eps[i], use_mean,
+                               pure);
   }
 
   /**
@@ -297,6 +339,7 @@ public:
    * reference: sampling_distribution.cu:169-205 (readControlSample) fused with the setGaussianControls rule
    * (gaussian.cu:99-127): k == 0 or t < stride -> mu; pure-noise rollouts -> sigma*eps; else mu + sigma*eps.
    */
+  template <bool LANE_D = false>
   __device__ inline void readControlSample(const int& sample_index, const int& t, const int& distribution_index,
                                            float* __restrict__ control, float* __restrict__ theta_d,
                                            const int& block_size, const int& thread_index,
@@ -305,12 +348,12 @@ public:
     const int d = distribution_index >= params_.num_distributions ? 0 : distribution_index;
     const int slot = slotOfThread();
     const float* row = sampleRow(theta_d, slot) + t * CONTROL_DIM;
-    const float* mean = control_means_d_ + (size_t)(params_.num_timesteps * d + t) * CONTROL_DIM;
     const bool use_mean = ((sample_index + rollout_offset_) == 0) || (t < optimization_stride_);
     const bool pure = isPureNoise(sample_index);
     for (int i = thread_index; i < CONTROL_DIM; i += block_size)
     {
-      control[i] = shapeSample(mean[i], std_dev_decayed_[CONTROL_DIM * d + i], row[i], use_mean, pure);
+      control[i] = shapeSample(meanValue<LANE_D>(d, t, i), distValue<LANE_D>(std_dev_decayed_, d, i), row[i], use_mean,
+                               pure);
     }
   }
 
@@ -332,13 +375,12 @@ public:
    * reference: gaussian.cu:480-569, device flavour: 0.5*lambda*(1-alpha) * sum_i coeff_i*mu_i*(mu_i - 2u_i)/sigma_i^2
    * with mu := 0 on pure-noise rollouts; vector-lane accumulation order of the CONTROL_DIM % 4 / % 2 / scalar branches.
    */
+  template <bool LANE_D = false>
   __device__ inline float computeLikelihoodRatioCost(const float* __restrict__ u, float* __restrict__ theta_d,
                                                      const int sample_index, const int t, const int distribution_idx,
                                                      const float lambda = 1.0f, const float alpha = 0.0f)
   {
     const int d = distribution_idx >= params_.num_distributions ? 0 : distribution_idx;
-    const float* std_dev = &params_.std_dev[CONTROL_DIM * d];
-    const float* mean = control_means_d_ + (size_t)(params_.num_timesteps * d + t) * CONTROL_DIM;
     const float* control_cost_coeff = params_.control_cost_coeff;
     const bool pure = isPureNoise(sample_index);
     // coeff == 0 for every control (the reference's default, gaussian.cuh:26): each term is exactly +-0 and the sum does
@@ -365,8 +407,10 @@ public:
         for (int l = 0; l < W; l++)
         {
           const int j = i * W + l;
-          const float mean_i = pure ? 0.0f : mean[j];
-          lane[l] += control_cost_coeff[j] * mean_i * (mean_i - 2.0f * u[j]) / (std_dev[j] * std_dev[j]);
+          const float mu = meanValue<LANE_D>(d, t, j);  // unconditional: a wave-uniform (scalar) load
+          const float mean_i = pure ? 0.0f : mu;
+          const float sd = distValue<LANE_D>(params_.std_dev, d, j);
+          lane[l] += control_cost_coeff[j] * mean_i * (mean_i - 2.0f * u[j]) / (sd * sd);
         }
       }
       if constexpr (W == 4)
@@ -378,8 +422,10 @@ public:
     {
       for (; i < CONTROL_DIM; i += step)
       {
-        const float mean_i = pure ? 0.0f : mean[i];
-        cost += control_cost_coeff[i] * mean_i * (mean_i - 2.0f * u[i]) / (std_dev[i] * std_dev[i]);
+        const float mu = meanValue<LANE_D>(d, t, i);  // unconditional: a wave-uniform (scalar) load
+        const float mean_i = pure ? 0.0f : mu;
+        const float sd = distValue<LANE_D>(params_.std_dev, d, i);
+        cost += control_cost_coeff[i] * mean_i * (mean_i - 2.0f * u[i]) / (sd * sd);
       }
     }
     return 0.5f * lambda * (1.0f - alpha) * cost;

@@ -260,12 +260,21 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     h->bx = 64;
     h->by = 1;
   }
-  if (!h->model->supportsShape(h->bx, h->by, h->bz))
+  // Tube with a pipeline-capable model and no explicit shape: fold the two systems into the lanes of a wave (32, 1, 2)
+  if (h->D == 2 && cfg->controller == MPPI_CONTROLLER_TUBE && cfg->block_x == 0 && cfg->block_y == 0 &&
+      cfg->kernel_variant != MPPI_KERNEL_FUSED && h->model->supportsPipelineFold(32, 1, 2) &&
+      h->model->rolloutSharedBytes(32, 1, 2, cfg->num_timesteps, 2, true) <= MAX_LDS_BYTES)
+  {
+    h->bx = 32;
+    h->by = 1;
+  }
+  if (!h->model->supportsShape(h->bx, h->by, h->bz) && !h->model->supportsPipelineFold(h->bx, h->by, h->bz))
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
                 "mppi_create: block shape (" + std::to_string(h->bx) + "," + std::to_string(h->by) + "," +
                     std::to_string(h->bz) + ") is not instantiated for model '" + h->model_name + "'");
   const bool pipe_ok = cfg->controller != MPPI_CONTROLLER_ROBUST &&
                        ((h->model->supportsPipeline() && h->bx == 64 && h->by == 1) ||
+                        h->model->supportsPipelineFold(h->bx, h->by, h->bz) ||
                         h->model->supportsPipelineRep(h->bx, h->by, h->bz));
   if (cfg->kernel_variant == MPPI_KERNEL_PIPELINE && !pipe_ok)
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,

@@ -120,6 +120,11 @@ struct ModelBase
   {
     return false;
   }
+  /** role-pipelined variant with the two systems of Tube-MPPI folded into the lanes of a wave, shape (32, 1, 2) */
+  virtual bool supportsPipelineFold(int bx, int by, int bz) const
+  {
+    return false;
+  }
   /** role-pipelined variant for replicated-lane (MFMA) dynamics, shape (64, REP, 1) */
   virtual bool supportsPipelineRep(int bx, int by, int bz) const
   {
@@ -401,25 +406,31 @@ struct ModelT : ModelBase
     return MPPI_ERR_LAUNCH_SHAPE;
   }
 
-  template <int Z>
+  bool supportsPipelineFold(int bx, int by, int bz) const override
+  {
+    return PIPELINE && bx == 32 && by == 1 && bz == 2;
+  }
+  template <int Z, bool FOLD = false>
   mppi_status launchPipeline(const kernels::RolloutArgs& args, hipStream_t stream, std::string& err)
   {
     if constexpr (PIPELINE)
     {
-      const size_t smem = kernels::pipelineSharedBytes(dyn, cost, smp, Z);
+      const size_t smem = kernels::pipelineSharedBytes(dyn, cost, smp, Z, FOLD);
       if (smem > MAX_LDS_BYTES)
       {
         err = "pipeline rollout kernel needs " + std::to_string(smem) + " B of LDS per block; gfx950 has 163840";
         return MPPI_ERR_LDS_OVERFLOW;
       }
       const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
-      auto kfn = in_loop ? kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, SAMPLING_T::IN_LOOP_DRAW>
-                         : kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, false>;
+      auto kfn = in_loop ? kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, SAMPLING_T::IN_LOOP_DRAW, FOLD>
+                         : kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, false, FOLD>;
       if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem);
-      const int grid = (args.num_rollouts + 63) / 64;
-      hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * kernels::PIPE_ROLES, 1, Z), smem, stream, dyn, cost, smp, args);
+      constexpr int RPB = FOLD ? 64 / Z : 64;  // rollouts per block
+      const int grid = (args.num_rollouts + RPB - 1) / RPB;
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(FOLD ? 64 * (2 + kernels::PIPE_FOLD_SAMPLERS) : 64 * kernels::PIPE_ROLES, 1, FOLD ? 1 : Z),
+                         smem, stream, dyn, cost, smp, args);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess)
       {
@@ -764,7 +775,7 @@ struct ModelT : ModelBase
       }
     }
     if (pipeline)
-      return kernels::pipelineSharedBytes(dyn, cost, smp, bz);
+      return kernels::pipelineSharedBytes(dyn, cost, smp, bz, supportsPipelineFold(bx, by, bz));
     if constexpr (!std::is_void<DYN_FAST_T>::value)
     {
       if (hasShape(FAST_SHAPES{}, bx, by, bz))
@@ -884,6 +895,8 @@ struct ModelT : ModelBase
     }
     if (pipeline && supportsPipelineRep(bx, by, bz))
       return launchPipelineRep(args, stream, err);
+    if (pipeline && supportsPipelineFold(bx, by, bz))
+      return launchPipeline<2, true>(args, stream, err);
     if (pipeline)
       return bz == 1 ? launchPipeline<1>(args, stream, err) : launchPipeline<2>(args, stream, err);
     if constexpr (!std::is_void<DYN_FAST_T>::value)

@@ -38,17 +38,21 @@ namespace kernels
 constexpr int PIPE_ROLES = 3;
 constexpr int PIPE_RING = 32;  ///< outputs buffered between the dynamics and the cost wave (steps)
 
+/** fold_z: the systems of a rollout are folded into the LANE dimension (64 / bz rollouts x bz systems per wave) instead of
+ *  the workgroup's z dimension — one ring and one counter set per block, half the sample rows per block */
 template <class DYN_T, class COST_T, class SAMPLING_T>
-__host__ inline size_t pipelineSharedBytes(const DYN_T& dyn, const COST_T& cost, const SAMPLING_T& smp, int bz)
+__host__ inline size_t pipelineSharedBytes(const DYN_T& dyn, const COST_T& cost, const SAMPLING_T& smp, int bz,
+                                           bool fold_z = false)
 {
-  const int slots = 64 * bz;
+  const int slots = fold_z ? 64 : 64 * bz;
+  const int rings = fold_z ? 1 : bz;
   size_t n = 0;
   n += calcClassSharedMemSize(&dyn, slots);
   n += calcClassSharedMemSize(&cost, slots);
   n += calcClassSharedMemSize(&smp, slots);
   n += sizeof(float) * 2 * math::nearest_multiple_4(slots);                     // cost_s, w_s
-  n += sizeof(float) * (size_t)bz * PIPE_RING * DYN_T::OUTPUT_DIM * 64;          // output ring [z][slot][i][lane]
-  n += sizeof(int) * 4 * 4 * bz;                                                 // progress counters (padded)
+  n += sizeof(float) * (size_t)rings * PIPE_RING * DYN_T::OUTPUT_DIM * 64;       // output ring [z][slot][i][lane]
+  n += sizeof(int) * 4 * 4 * rings;                                              // progress counters (padded)
   return n;
 }
 
@@ -79,35 +83,55 @@ __device__ inline void pipePublish(lds_counter_t ctr, const int value, const int
     *ctr = value;
 }
 
-template <class DYN_T, class COST_T, class SAMPLING_T, int BZ, bool DRAW_IN_LOOP>
-__global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
+/** sampler waves of the folded variant: with C = 2 a Philox quad only lasts two steps and the draw (Philox rounds + two
+ *  Box-Muller pairs, ~350 dependent instructions) is the longest of the three roles; one block per CU leaves the fourth
+ *  SIMD idle, so a second sampler wave is free */
+constexpr int PIPE_FOLD_SAMPLERS = 2;
+
+template <class DYN_T, class COST_T, class SAMPLING_T, int BZ, bool DRAW_IN_LOOP, bool FOLD_Z = false>
+__global__ void __launch_bounds__(FOLD_Z ? 64 * (2 + PIPE_FOLD_SAMPLERS) : 64 * PIPE_ROLES * BZ)
     rolloutPipelineKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args)
 {
-  constexpr int BX = 64;
-  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == BX * PIPE_ROLES);
+  // FOLD_Z (Tube: BZ == 2): a wave carries 32 rollouts x 2 systems in its 64 lanes.  Half the sample rows per block
+  // (two systems with T*C floats per rollout each are what overflows the LDS at 64 rollouts), twice the blocks — at
+  // K = 8192 exactly one block per CU — and the two systems of a rollout advance in the same instruction stream.
+  static_assert(!FOLD_Z || 64 % BZ == 0, "systems must divide the wave");
+  constexpr int BX = FOLD_Z ? 64 / BZ : 64;
+  constexpr int WZ = FOLD_Z ? 1 : BZ;  // z extent of the workgroup
+  // The folded variant draws with PAIRS of lanes: the two systems of a rollout see the same noise, so lane z = 0 draws
+  // Philox quad q, lane z = 1 quad q + 1, and one v_permlane32_swap per value hands both quads to both lanes — a trip is
+  // 8 row elements (8 / C steps) for the price of one draw.  NS sampler waves take alternate trips.
+  constexpr bool PAIR_DRAW = FOLD_Z && DRAW_IN_LOOP && BZ == 2 && DYN_T::CONTROL_DIM == 2;
+  constexpr int NS = PAIR_DRAW ? PIPE_FOLD_SAMPLERS : 1;  // sampler waves
+  constexpr int WX = FOLD_Z ? 64 * (2 + PIPE_FOLD_SAMPLERS) : 64 * PIPE_ROLES;
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == WX);
   __builtin_assume(__builtin_amdgcn_workgroup_size_y() == 1);
-  __builtin_assume(__builtin_amdgcn_workgroup_size_z() == BZ);
-  __builtin_assume(__builtin_amdgcn_workitem_id_x() < BX * PIPE_ROLES);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_z() == WZ);
+  __builtin_assume(__builtin_amdgcn_workitem_id_x() < WX);
   __builtin_assume(__builtin_amdgcn_workitem_id_y() == 0);
-  __builtin_assume(__builtin_amdgcn_workitem_id_z() < BZ);
+  __builtin_assume(__builtin_amdgcn_workitem_id_z() < WZ);
 
   DYN_T* dynamics = &dynamics_obj;
   COST_T* costs = &costs_obj;
   SAMPLING_T* sampling = &sampling_obj;
   constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
   constexpr int SLOTS = BX * BZ;
-  constexpr int NTHREADS = BX * PIPE_ROLES * BZ;
+  constexpr int NTHREADS = WX * WZ;
 
   const int tid_x = (int)__builtin_amdgcn_workitem_id_x();
-  const int role = __builtin_amdgcn_readfirstlane(tid_x >> 6);  // wave-uniform
+  const int wave_x = __builtin_amdgcn_readfirstlane(tid_x >> 6);  // wave-uniform
+  // waves 0 / 1 / 2: sampler / dynamics / cost; waves 3.. (folded variant): further samplers (idle without PAIR_DRAW)
+  const int role = wave_x < PIPE_ROLES ? wave_x : (wave_x - PIPE_ROLES + 1 < NS ? 0 : 3);
+  const int smp_id = wave_x < PIPE_ROLES ? 0 : wave_x - PIPE_ROLES + 1;
   const int lane = tid_x & 63;
-  const int thread_idx = lane;
-  const int thread_idz = (int)__builtin_amdgcn_workitem_id_z();
+  const int thread_idx = FOLD_Z ? lane % BX : lane;
+  const int thread_idz = FOLD_Z ? lane / BX : (int)__builtin_amdgcn_workitem_id_z();
+  const int ring_z = FOLD_Z ? 0 : thread_idz;  // which ring / counter set this thread uses
   const int block_idx = (int)blockIdx.x;
   const int global_idx = BX * block_idx + thread_idx;
   const int shared_idx = BX * thread_idz + thread_idx;
   const int distribution_idx = thread_idz;
-  const int tid_flat = tid_x + BX * PIPE_ROLES * thread_idz;
+  const int tid_flat = tid_x + WX * ring_z;
   const int num_timesteps = args.num_timesteps;
   const int num_rollouts = args.num_rollouts;
   const float dt = args.dt;
@@ -121,14 +145,16 @@ __global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
   float* cost_s = theta_d_shared + calcClassSharedMemSize(sampling, SLOTS) / (int)sizeof(float);
   float* w_s = cost_s + math::nearest_multiple_4(SLOTS);
   float* ring_all = w_s + math::nearest_multiple_4(SLOTS);
-  float* ring = ring_all + (size_t)thread_idz * PIPE_RING * O * 64;  // [slot][i][lane]
+  float* ring = ring_all + (size_t)ring_z * PIPE_RING * O * 64;  // [slot][i][lane]
   lds_counter_t counters =
-      (lds_counter_t)(reinterpret_cast<int*>(ring_all + (size_t)BZ * PIPE_RING * O * 64) + 16 * thread_idz);
+      (lds_counter_t)(reinterpret_cast<int*>(ring_all + (size_t)WZ * PIPE_RING * O * 64) + 16 * ring_z);
   lds_counter_t smp_prog = counters + 0;   // steps whose shaped sample is in the row
   lds_counter_t dyn_prog = counters + 4;   // steps whose output is in the ring
   lds_counter_t cost_prog = counters + 8;  // steps the cost wave has consumed
+  lds_counter_t smp_prog1 = counters + 12; // second sampler wave (trips 1, 3, 5, ...)
+  static_assert(NS <= 2, "one spare counter");
 
-  sampling->setThreadMapping(shared_idx, BX);
+  sampling->setThreadMapping(shared_idx, BX, BZ);
 
   float x[S], x_next[S], xdot[S], u[C], y[O];
   int crash_status = 0;
@@ -145,11 +171,12 @@ __global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
 #pragma unroll
   for (int i = 0; i < O; i++)
     y[i] = 0.0f;
-  if (lane == 0 && role == 0)
+  if (lane == 0 && wave_x == 0)
   {
     *smp_prog = 0;
     *dyn_prog = 0;
     *cost_prog = 0;
+    *smp_prog1 = 0;
   }
   __syncthreads();
 
@@ -162,7 +189,36 @@ __global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
   float running_cost = 0.0f;
   float* row = sampling->sampleRow(theta_d_shared, shared_idx);
 
-  if (role == 0)
+  if (role == 0 && PAIR_DRAW)
+  {
+    /* ------------------------------------------------ sampler waves, pair draw ------------------------------------- */
+    constexpr int STEPS = 8 / C;  // == 4: a trip is one group of the dynamics wave
+    lds_counter_t my_prog = smp_id == 0 ? smp_prog : smp_prog1;
+    for (int t = STEPS * smp_id; t < num_timesteps; t += STEPS * NS)
+    {
+      float zq[4], e[8];
+      sampling->drawQuad(global_idx, t * C / 4 + thread_idz, zq);
+#pragma unroll
+      for (int l = 0; l < 4; l++)
+      {  // r[0]: the value held by the pair's z = 0 lane, r[1]: by its z = 1 lane
+        const unsigned v = __float_as_uint(zq[l]);
+        auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        e[l] = __uint_as_float(r[0]);
+        e[4 + l] = __uint_as_float(r[1]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < STEPS; s2++)
+      {
+        if (t + s2 < num_timesteps)
+        {
+          sampling->template shapeControlSample<FOLD_Z>(global_idx, t + s2, distribution_idx, &e[s2 * C], u);
+          sampling->writeControlSample(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
+        }
+      }
+      pipePublish(my_prog, min(t + STEPS, num_timesteps), lane);
+    }
+  }
+  else if (role == 0)
   {
     /* ------------------------------------------------ sampler wave ------------------------------------------------ */
     constexpr int STEPS = (C % 2 == 0) ? 2 : 4;
@@ -182,9 +238,9 @@ __global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
         if (t + s2 < num_timesteps)
         {
           if (DRAW_IN_LOOP)
-            sampling->shapeControlSample(global_idx, t + s2, distribution_idx, &zq[s2 * C], u);
+            sampling->template shapeControlSample<FOLD_Z>(global_idx, t + s2, distribution_idx, &zq[s2 * C], u);
           else
-            sampling->readControlSample(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
+            sampling->template readControlSample<FOLD_Z>(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
           sampling->writeControlSample(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
         }
       }
@@ -209,7 +265,7 @@ __global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
       for (int i = 0; i < O; i++)
         slot[i * 64] = y[i];
     };
-    int seen_smp = 0, seen_cost = 0;
+    int seen_smp = 0, seen_smp1 = 0, seen_cost = 0;
     int t = 0;
     // Full groups of 4 steps form ONE basic block (no tail test between the steps): the recurrence is skewed — the angle
     // of step t + 1 depends only on the state at t, not on step t's derivative — so the scheduler can start the next
@@ -218,7 +274,10 @@ __global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
     // the critical path.
     for (; t + 3 < num_timesteps; t += 4)
     {
-      pipeWait(smp_prog, t + 4, seen_smp);               // samples for steps t .. t+3 are in the rows
+      if (NS == 2 && (t & 4))                            // samples for steps t .. t+3 are in the rows
+        pipeWait(smp_prog1, t + 4, seen_smp1);
+      else
+        pipeWait(smp_prog, t + 4, seen_smp);
       pipeWait(cost_prog, t + 4 - PIPE_RING, seen_cost); // their ring slots have been consumed
       float ubuf[4 * C];
 #pragma unroll
@@ -233,7 +292,10 @@ __global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
     if (t < num_timesteps)
     {  // tail of 1..3 steps
       const int hi = num_timesteps;
-      pipeWait(smp_prog, hi, seen_smp);
+      if (NS == 2 && (t & 4))
+        pipeWait(smp_prog1, hi, seen_smp1);
+      else
+        pipeWait(smp_prog, hi, seen_smp);
       pipeWait(cost_prog, hi - PIPE_RING, seen_cost);
       float ubuf[4 * C];
 #pragma unroll
@@ -247,28 +309,39 @@ __global__ void __launch_bounds__(64 * PIPE_ROLES * BZ)
       pipePublish(dyn_prog, hi, lane);
     }
   }
-  else
+  else if (role == 2)
   {
     /* ------------------------------------------------ cost wave --------------------------------------------------- */
     int seen_dyn = 0;
-    for (int t = 0; t < num_timesteps; t += 4)
+    auto cost_step = [&](const int tt) {
+      const float* slot = ring + (size_t)(tt % PIPE_RING) * O * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < O; i++)
+        y[i] = slot[i * 64];
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        u[i] = row[tt * C + i];
+      running_cost += costs->computeRunningCost(y, u, tt, theta_c_shared, &crash_status) +
+                      sampling->template computeLikelihoodRatioCost<FOLD_Z>(u, theta_d_shared, global_idx, tt,
+                                                                            distribution_idx, args.lambda, args.alpha);
+    };
+    int t = 0;
+    // full groups as one basic block: the four steps' ring / row reads and mean loads issue ahead of the arithmetic
+    for (; t + 3 < num_timesteps; t += 4)
     {
-      const int hi = min(t + 4, num_timesteps);
-      pipeWait(dyn_prog, hi, seen_dyn);
-      for (int tt = t; tt < hi; tt++)
-      {
-        const float* slot = ring + (size_t)(tt % PIPE_RING) * O * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < O; i++)
-          y[i] = slot[i * 64];
-#pragma unroll
-        for (int i = 0; i < C; i++)
-          u[i] = row[tt * C + i];
-        running_cost += costs->computeRunningCost(y, u, tt, theta_c_shared, &crash_status) +
-                        sampling->computeLikelihoodRatioCost(u, theta_d_shared, global_idx, tt, distribution_idx,
-                                                             args.lambda, args.alpha);
-      }
-      pipePublish(cost_prog, hi, lane);
+      pipeWait(dyn_prog, t + 4, seen_dyn);
+      cost_step(t);
+      cost_step(t + 1);
+      cost_step(t + 2);
+      cost_step(t + 3);
+      pipePublish(cost_prog, t + 4, lane);
+    }
+    if (t < num_timesteps)
+    {
+      pipeWait(dyn_prog, num_timesteps, seen_dyn);
+      for (int tt = t; tt < num_timesteps; tt++)
+        cost_step(tt);
+      pipePublish(cost_prog, num_timesteps, lane);
     }
   }
   __syncthreads();
@@ -470,7 +543,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
           slot[i * 64] = y[i];
       }
     };
-    int seen_smp = 0, seen_cost = 0;
+    int seen_smp = 0, seen_smp1 = 0, seen_cost = 0;
     int t = 0;
     // full pairs of steps as one basic block (see rolloutPipelineKernel): lets the scheduler overlap the second step's
     // independent work with the first step's MFMA chains

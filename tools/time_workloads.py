@@ -36,7 +36,7 @@ if "cartpole" in which:
 if "autorally" in which:
     run("autorally", autorally_cfg(K=16384, T=150, lambda_=1.0), [(64, 4, 1), (64, 4, 2), (32, 4), (8, 16)], n=30)
 if "di" in which:
-    run("di-tube", di_cfg(K=8192, T=150, tube=True), [(64, 1, 1), (64, 1, 2)])
+    run("di-tube", di_cfg(K=8192, T=150, tube=True), [(64, 1, 1), (0, 0, 0), (32, 1, 2)])
 if "lstm" in which:
     cfg = bicycle_lstm_cfg(K=65536, T=200, lambda_=1.0)
     run("lstm", cfg, [(64, 4, 1), (64, 4, 2), (32, 4)], n=10)
