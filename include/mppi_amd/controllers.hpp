@@ -45,7 +45,7 @@ public:
   Controller(const std::string& model, int controller_kind, int num_rollouts, int num_timesteps, float dt, int max_iter,
              float lambda, float alpha, unsigned long long seed = 42, int device = 0, int rank = 0, int world_size = 1,
              void* stream = nullptr)
-    : num_rollouts_(num_rollouts), num_timesteps_(num_timesteps)
+    : num_rollouts_(num_rollouts), num_timesteps_(num_timesteps), dt_(dt)
   {
     mppi_config cfg{};
     cfg.model = model.c_str();
@@ -189,6 +189,75 @@ public:
     check(mppi_optimize(h_, num_iterations, synchronize ? 1 : 0));
   }
 
+  /* ---- what a plant needs between optimisations (controllers/controller.cuh:329-387) ---- */
+  /** linear interpolation between the knots around rel_time; traj is [T][dim] */
+  std::vector<float> interpolate(double rel_time, const std::vector<float>& traj, int dim) const
+  {
+    const int lower = (int)(rel_time / dt_);
+    const double alpha = (rel_time - lower * (double)dt_) / dt_;
+    std::vector<float> out(dim);
+    for (int i = 0; i < dim; i++)
+      out[i] = (float)((1.0 - alpha) * traj[(size_t)lower * dim + i] + alpha * traj[(size_t)(lower + 1) * dim + i]);
+    return out;
+  }
+  std::vector<float> interpolateControls(double rel_time, const std::vector<float>& c_traj) const
+  {
+    return interpolate(rel_time, c_traj, control_dim_);
+  }
+  std::vector<float> interpolateState(const std::vector<float>& s_traj, double rel_time) const
+  {
+    return interpolate(rel_time, s_traj, state_dim_);
+  }
+  /** feedback.cuh:216-228 with k = K[t]^T (x - x*); gains is [T][S][C] (empty: feedback disabled) */
+  std::vector<float> interpolateFeedback(const std::vector<float>& state, const std::vector<float>& goal_state,
+                                         double rel_time, const std::vector<float>& gains) const
+  {
+    const int lower = (int)(rel_time / dt_);
+    const double alpha = (rel_time - lower * (double)dt_) / dt_;
+    std::vector<float> out(control_dim_, 0.0f);
+    for (int j = 0; j < control_dim_; j++)
+    {
+      double lo = 0.0, hi = 0.0;
+      for (int i = 0; i < state_dim_; i++)
+      {
+        const double e = (double)state[i] - goal_state[i];
+        lo += e * gains[((size_t)lower * state_dim_ + i) * control_dim_ + j];
+        hi += e * gains[((size_t)(lower + 1) * state_dim_ + i) * control_dim_ + j];
+      }
+      out[j] = (float)((1.0 - alpha) * lo + alpha * hi);
+    }
+    return out;
+  }
+  /** controller.cuh:329-345: u_ff + u_fb, then Dynamics::enforceConstraints */
+  std::vector<float> getCurrentControl(const std::vector<float>& state, double rel_time,
+                                       const std::vector<float>& target_nominal_state, const std::vector<float>& c_traj,
+                                       const std::vector<float>& gains)
+  {
+    std::vector<float> u = interpolateControls(rel_time, c_traj);
+    if (!gains.empty())
+    {
+      const std::vector<float> u_fb = interpolateFeedback(state, target_nominal_state, rel_time, gains);
+      for (int j = 0; j < control_dim_; j++)
+        u[j] += u_fb[j];
+    }
+    std::vector<float> zero_state(state_dim_, 0.0f);
+    modelStep(zero_state, u, 0.0f, true);  // a zero-length step returns the constrained control
+    return u;
+  }
+  /** Robust MPPI overrides this; a no-op for the other controllers (controller.cuh:321-327) */
+  virtual void updateImportanceSamplingControl(const std::vector<float>& state, int stride)
+  {
+  }
+  /** controller.cuh resetControls(): zero nominal control */
+  void resetControls()
+  {
+    updateImportanceSampler(std::vector<float>((size_t)num_timesteps_ * control_dim_, 0.0f));
+  }
+  float getDt() const
+  {
+    return dt_;
+  }
+
   int getStateDim() const
   {
     return state_dim_;
@@ -214,6 +283,7 @@ protected:
   }
   mppi_handle h_ = nullptr;
   int num_rollouts_, num_timesteps_;
+  float dt_;
   int state_dim_ = 0, control_dim_ = 0, output_dim_ = 0, num_systems_ = 1;
 };
 
@@ -287,7 +357,7 @@ public:
   {
     check(mppi_set_feedback_gains(h_, gains.data(), accumulate_all_states ? 1 : 0));
   }
-  void updateImportanceSamplingControl(const std::vector<float>& state, int stride)
+  void updateImportanceSamplingControl(const std::vector<float>& state, int stride) override
   {
     check(mppi_update_importance_sampling_control(h_, state.data(), stride));
   }

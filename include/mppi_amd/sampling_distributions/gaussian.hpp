@@ -256,13 +256,17 @@ public:
       return table[CONTROL_DIM * d + j];
     }
   }
+  /** The means are written by other kernels only (finalize / setters), never during a rollout: reading them through
+   *  the constant address space tells the compiler so — wave-uniform addresses then become scalar loads that may be
+   *  hoisted above the pipeline's acquire fences instead of per-step vector loads with a full L2 round trip. */
+  typedef const __attribute__((address_space(4))) float* const_float_ptr;
   template <bool LANE_D>
   __device__ inline float meanValue(const int d, const int t, const int j) const
   {
-    const float* m0 = control_means_d_ + (size_t)t * CONTROL_DIM;
+    const_float_ptr m0 = (const_float_ptr)(control_means_d_ + (size_t)t * CONTROL_DIM);
     if constexpr (LANE_D)
     {
-      const float* m1 = m0 + (params_.num_distributions > 1 ? params_.num_timesteps * CONTROL_DIM : 0);
+      const_float_ptr m1 = m0 + (params_.num_distributions > 1 ? params_.num_timesteps * CONTROL_DIM : 0);
       const float a = m0[j], b = m1[j];
       return d == 0 ? a : b;
     }

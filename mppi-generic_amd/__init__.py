@@ -13,8 +13,9 @@ from .controllers import (MPPI_CONTROLLER_TUBE, MPPI_CONTROLLER_VANILLA, MPPI_NO
                           CartpoleQuadraticCostParams, DoubleIntegratorParams, DoubleIntegratorCircleCostParams,
                           ARStandardCostParams, fnn_blob_from_npz_dict, lstm_blob_from_npz_dict,
                           det_eval, npz_read_array, philox_normal, norm_exp, compute_weights, weighted_reduction)
+from .plant import BasePlant, SimulatedPlant, interpolateControls, interpolateFeedback, interpolateState
 
 __all__ = [
     "build", "load_library", "library_path", "MPPIError", "MPPIController", "VanillaMPPIController",
-    "TubeMPPIController", "MppiConfig", "SIGNATURES",
+    "TubeMPPIController", "MppiConfig", "SIGNATURES", "BasePlant", "SimulatedPlant",
 ]

@@ -11,20 +11,22 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(REPO, "examples", "_build", "cartpole_example")
 
 
-def _build():
+def _build(name="cartpole_example"):
     m.load_library()
+    exe = os.path.join(os.path.dirname(EXE), name)
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     lib_dir = os.path.dirname(m.library_path())
-    cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(REPO, "include"),
-           os.path.join(REPO, "examples", "cartpole_example.cpp"), "-L" + lib_dir, "-lmppi_amd",
-           "-Wl,-rpath," + lib_dir, "-o", EXE]
+    cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(REPO, "include"),
+           os.path.join(REPO, "examples", name + ".cpp"), "-L" + lib_dir, "-lmppi_amd",
+           "-Wl,-rpath," + lib_dir, "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    return EXE
+    return exe
 
 
 def test_cpp_host_example_builds_and_fails_loudly_without_device(lib):
     exe = _build()
+    _build("cartpole_plant_example")
     if lib.mppi_device_count() > 0:
         return
     r = subprocess.run([exe, "5"], capture_output=True, text=True, timeout=120)
@@ -39,3 +41,12 @@ def test_cpp_host_cartpole_example_reaches_goal(gpu):
     r = subprocess.run([exe, "600"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "AT GOAL" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_plant_example(gpu):
+    """include/mppi_amd/plant.hpp: SimulatedPlant single-threaded (strides 1 and 2) and runControlLoop on a thread"""
+    exe = _build("cartpole_plant_example")
+    r = subprocess.run([exe, "600"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "PLANT OK" in r.stdout and "stride 2: 301 iterations, last stride 2" in r.stdout

@@ -1,0 +1,193 @@
+"""BasePlant-style wrapper (mppi-generic_amd/plant.py; reference: include/mppi/core/base_plant.hpp, tested upstream by
+tests/plant/base_plant_test.cu with a mock controller).  The CPU tests use a mock controller too — the plant is host
+logic; the GPU test closes the loop on the real engine."""
+import threading
+import types
+
+import numpy as np
+import pytest
+
+import mppi_generic_amd as m
+from common import cartpole_cfg, make_engine
+
+
+class MockController:
+    """records what the plant asks for; same surface the plant uses on a real controller"""
+    STATE_DIM, CONTROL_DIM = 2, 1
+
+    def __init__(self, T=10, dt=0.1):
+        self.num_timesteps, self.dt = T, dt
+        self.calls = []
+        self.lam = None
+
+    def slideControlSequence(self, steps):
+        self.calls.append(("slide", steps))
+
+    def updateImportanceSamplingControl(self, state, stride):
+        self.calls.append(("is", stride))
+
+    def computeControl(self, state, stride):
+        self.calls.append(("compute", stride, np.array(state)))
+
+    def getStats(self):
+        return types.SimpleNamespace(real_sys=types.SimpleNamespace(free_energy_mean=1.5))
+
+    def getControlSeq(self):
+        return np.arange(self.num_timesteps, dtype=np.float32).reshape(-1, 1)  # u[t] = t
+
+    def getTargetStateSeq(self):
+        t = np.arange(self.num_timesteps, dtype=np.float32)
+        return np.stack([t, -2 * t], 1)
+
+    def modelStep(self, x, u, dt=None, enforce_constraints=True):
+        return np.asarray(x, np.float32), np.clip(np.asarray(u, np.float32), -5.0, 5.0)
+
+    def setLambda(self, lam):
+        self.lam = lam
+
+    def setNumIters(self, n):
+        self.iters = n
+
+    def updateImportanceSampler(self, u):
+        self.calls.append(("reset",))
+
+
+class RecordingPlant(m.BasePlant):
+    def __init__(self, ctl, hz=10, stride=1):
+        super().__init__(ctl, hz, stride)
+        self.pub, self.nominal, self.fe = [], [], []
+
+    def pubControl(self, u):
+        self.pub.append(np.array(u))
+
+    def pubNominalState(self, s):
+        self.nominal.append(np.array(s))
+
+    def pubFreeEnergyStatistics(self, stats):
+        self.fe.append(stats.real_sys.free_energy_mean)
+
+    def getCurrentTime(self):
+        return self.state_time_
+
+
+def alive():
+    e = threading.Event()
+    e.set()
+    return e
+
+
+def test_interpolation_helpers():
+    c = np.arange(10, dtype=np.float32).reshape(-1, 1)
+    assert np.allclose(m.interpolateControls(0.25, c, 0.1), [2.5])
+    s = np.stack([np.arange(10.0), -np.arange(10.0)], 1).astype(np.float32)
+    assert np.allclose(m.interpolateState(s, 0.31, 0.1), [3.1, -3.1], atol=1e-5)
+    gains = np.zeros((10, 2, 1), np.float32)
+    gains[:, 0, 0] = np.arange(10)
+    # k(t) = K[t]^T (x - x*) = t * 0.5, interpolated half-way between knots 2 and 3
+    assert np.allclose(m.interpolateFeedback([1.5, 0.0], [1.0, 0.0], 0.25, gains, 0.1), [1.25])
+
+
+def test_first_iteration_has_stride_zero_and_no_slide():
+    ctl = MockController()
+    p = RecordingPlant(ctl)
+    p.updateState(np.array([1.0, 2.0]), 0.0)
+    assert p.pub == []  # nothing optimised yet: nothing published (base_plant.hpp:299-303)
+    p.runControlIteration(alive())
+    assert [c[0] for c in ctl.calls] == ["compute"] and ctl.calls[0][1] == 0
+    assert p.getLastOptimizationStride() == 0 and p.num_iter_ == 1 and p.fe == [1.5]
+    assert p.last_used_state_update_time_ == 0.0
+
+
+def test_stride_follows_robot_time_and_slides():
+    ctl = MockController(T=10, dt=0.1)
+    p = RecordingPlant(ctl, stride=1)
+    p.updateState(np.zeros(2), 0.0)
+    p.runControlIteration(alive())
+    ctl.calls.clear()
+    p.updateState(np.zeros(2), 0.31)  # 3.1 dt of robot time later
+    p.runControlIteration(alive())
+    assert ctl.calls[0] == ("is", 3) and ctl.calls[1] == ("slide", 3) and ctl.calls[2][:2] == ("compute", 3)
+    # a stride >= T is not slid (base_plant.hpp:494)
+    ctl.calls.clear()
+    p.updateState(np.zeros(2), 5.0)
+    p.runControlIteration(alive())
+    assert [c[0] for c in ctl.calls] == ["compute"] and ctl.calls[0][1] == 47
+    # the target stride is a lower bound
+    p.setTargetOptimizationStride(4)
+    ctl.calls.clear()
+    p.updateState(np.zeros(2), 5.1)
+    p.runControlIteration(alive())
+    assert ctl.calls[1] == ("slide", 4)
+
+
+def test_update_state_publishes_interpolated_constrained_control():
+    ctl = MockController(T=10, dt=0.1)
+    p = RecordingPlant(ctl)
+    p.setDebugMode(True)
+    p.updateState(np.zeros(2), 1.0)
+    p.runControlIteration(alive())
+    p.updateState(np.zeros(2), 1.25)
+    assert np.allclose(p.pub[-1], [2.5]) and np.allclose(p.nominal[-1], [2.5, -5.0], atol=1e-5)
+    p.updateState(np.zeros(2), 1.0 + 0.72)
+    assert np.allclose(p.pub[-1], [5.0])  # 7.2 clamped by enforceConstraints
+    n = len(p.pub)
+    p.updateState(np.zeros(2), 1.0 + 1.0)  # outside the optimised horizon: nothing published
+    p.updateState(np.zeros(2), 0.5)        # older than the solution
+    assert len(p.pub) == n
+    # feedback term
+    gains = np.zeros((10, 2, 1), np.float32)
+    gains[:, 0, 0] = 1.0
+    p.setFeedbackGains(gains)
+    p.updateState(np.array([3.0, 0.0], np.float32), 1.2)  # nominal x0 at 0.2 is 2.0 -> u_fb = 1
+    assert np.allclose(p.pub[-1], [3.0])
+
+
+def test_nan_state_skips_iteration_and_parameter_queue():
+    ctl = MockController()
+    p = RecordingPlant(ctl)
+    p.updateState(np.array([np.nan, 0.0]), 0.0)
+    p.runControlIteration(alive())
+    assert ctl.calls == [] and p.num_iter_ == 0
+    p.setControllerParams(lambda_=0.7, num_iters=3)
+    assert p.hasNewControllerParams()
+    assert p.updateParameters() and ctl.lam == 0.7 and ctl.iters == 3 and not p.hasNewControllerParams()
+    assert not p.updateParameters()
+
+
+def test_control_loop_thread_paces_on_state_time():
+    ctl = MockController(T=10, dt=0.1)
+    p = RecordingPlant(ctl, hz=10, stride=1)
+    e = alive()
+    th = threading.Thread(target=p.runControlLoop, args=(e,))
+    th.start()
+    try:
+        import time
+        for i in range(4):
+            p.updateState(np.zeros(2), 0.1 * i)
+            deadline = time.monotonic() + 5.0
+            while p.num_iter_ < i + 1 and time.monotonic() < deadline:
+                time.sleep(1e-3)
+            assert p.num_iter_ == i + 1
+    finally:
+        e.clear()
+        th.join(5.0)
+    assert not th.is_alive()
+    strides = [c[1] for c in ctl.calls if c[0] == "compute"]
+    assert strides == [0, 1, 1, 1] and p.avg_loop_time_ms_ > 0
+
+
+@pytest.mark.gpu
+def test_simulated_plant_drives_cartpole_to_goal(gpu):
+    cfg = cartpole_cfg(K=2048, T=100)
+    eng = make_engine(cfg)
+    plant = m.SimulatedPlant(eng, hz=50, optimization_stride=1, init_state=cfg["x0"])
+    x = plant.runSimulation(600)
+    assert plant.num_iter_ == 601 and plant.getLastOptimizationStride() == 1
+    assert abs(x[0] - 20.0) < 3.0  # the cart reaches the goal position (examples/cartpole_example.cu goal [20,0,pi,0])
+    assert plant.avg_optimize_time_ms_ > 0 and len(plant.published_controls_) == 600
+    assert all(abs(u[0]) <= 5.0 + 1e-6 for _, u in plant.published_controls_)
+    # stride 2: optimise every second tick, slide by 2
+    eng2 = make_engine(cfg)
+    plant2 = m.SimulatedPlant(eng2, hz=50, optimization_stride=2, init_state=cfg["x0"])
+    plant2.runSimulation(100)
+    assert plant2.num_iter_ == 51 and plant2.getLastOptimizationStride() == 2
