@@ -164,15 +164,14 @@ MPPI_HD static inline void sincos(float x, float* s_out, float* c_out)
   pc = fma(pc, z, 4.166664568298827e-2f);
   const float cr = fma(pc * z, z, fma(-0.5f, z, 1.0f));
   /* quadrant: k mod 4 (k is integral; the int conversion is exact for |k| < 2^31, saturating beyond) */
-  const int q = (int)k & 3;
-  float s = (q & 1) ? cr : sr;
-  float c = (q & 1) ? sr : cr;
-  if (q & 2)
-    s = -s;
-  if ((q + 1) & 2)
-    c = -c;
-  *s_out = s;
-  *c_out = c;
+  const uint32_t q = (uint32_t)(int)k;
+  const float s = (q & 1u) ? cr : sr;
+  const float c = (q & 1u) ? sr : cr;
+  /* sign: s = -s when q & 2, c = -c when (q + 1) & 2 — as a flip of the sign bit (bit 1 of q, resp. of q + 1, moved to
+   * bit 31): a shift, a mask and an xor instead of compare + select, whose VCC round trip costs a single wave three
+   * issue slots on gfx950 (tools/ubench/op_latency.hip) */
+  *s_out = u2f(f2u(s) ^ ((q << 30) & 0x80000000u));
+  *c_out = u2f(f2u(c) ^ (((q << 30) + 0x40000000u) & 0x80000000u));
 }
 MPPI_HD static inline float sin(float x)
 {
@@ -296,6 +295,29 @@ MPPI_HD static inline float div_benign(float p, float q)
 MPPI_HD static inline float rcp_benign(float x)
 {
   return div_benign(1.0f, x);
+}
+
+/** Two rcp_benign at once (bit-identical to two scalar calls): the six fma steps issue as packed v_pk_fma_f32, which
+ *  take one issue slot for the pair — a lone wave issues one VALU instruction every ~2 ns whether or not it depends on
+ *  the previous one (tools/ubench/op_latency.hip), so instruction COUNT is what a rollout step costs. */
+MPPI_HD static inline void rcp_benign2(const float xa, const float xb, float* ra, float* rb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 q = { xa, xb };
+  const f32x2 one = { 1.0f, 1.0f };
+  f32x2 r = { __builtin_amdgcn_rcpf(xa), __builtin_amdgcn_rcpf(xb) };
+  const f32x2 e = __builtin_elementwise_fma(-q, r, one);
+  r = __builtin_elementwise_fma(e, r, r);
+  f32x2 y = r; /* 1.0f * r */
+  y = __builtin_elementwise_fma(__builtin_elementwise_fma(-q, y, one), r, y);
+  y = __builtin_elementwise_fma(__builtin_elementwise_fma(-q, y, one), r, y);
+  *ra = y.x;
+  *rb = y.y;
+#else
+  *ra = 1.0f / xa;
+  *rb = 1.0f / xb;
+#endif
 }
 
 /**

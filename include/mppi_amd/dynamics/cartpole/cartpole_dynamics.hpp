@@ -87,13 +87,16 @@ public:
     float l_p = this->params_.pole_length;
 
     state_der[0] = state[1];
-    // 1.0f / x with x = m_c + m_p sin^2 (and l_p x below): positive, ordinary magnitudes -> det::rcp_benign returns the
-    // correctly rounded IEEE reciprocal (what the reference's `1.0f / (...)` and the CPU oracle compute) in 7 instructions
-    state_der[1] = mppi::det::rcp_benign(m_c + m_p * SQ(sin_theta)) *
-                   (force + m_p * sin_theta * (l_p * SQ(theta_dot) + gravity_ * cos_theta));
+    // 1.0f / x with x = m_c + m_p sin^2 and x = l_p (m_c + m_p sin^2): positive, ordinary magnitudes -> det::rcp_benign2
+    // returns the correctly rounded IEEE reciprocals (what the reference's `1.0f / (...)` and the CPU oracle compute),
+    // both in 8 instructions
+    const float den = m_c + m_p * SQ(sin_theta);
+    float r_x, r_th;
+    mppi::det::rcp_benign2(den, l_p * den, &r_x, &r_th);
+    state_der[1] = r_x * (force + m_p * sin_theta * (l_p * SQ(theta_dot) + gravity_ * cos_theta));
     state_der[2] = theta_dot;
     state_der[3] =
-        mppi::det::rcp_benign(l_p * (m_c + m_p * SQ(sin_theta))) *
+        r_th *
         (-force * cos_theta - m_p * l_p * SQ(theta_dot) * cos_theta * sin_theta - (m_c + m_p) * gravity_ * sin_theta);
   }
 

@@ -151,6 +151,14 @@ public:
     static_cast<CLASS_T*>(this)->stateToOutput(state, output);
   }
 
+  /**
+   * true when a plugin's enforceConstraints() reads `state` (override it in the plugin together with the function).  The
+   * base rule — deadband, then clamp to control_rngs_ — does not, and the role-pipelined rollout kernels then apply it in
+   * the SAMPLER waves (same function, same input, same result) instead of on the dynamics wave, where every instruction
+   * lengthens the rollout's serial chain.
+   */
+  static constexpr bool CONSTRAINTS_DEPEND_ON_STATE = false;
+
   /** reference: dynamics.cu:97-116 — deadband then clamp, lanes strided over threadIdx.y */
   __device__ inline void enforceConstraints(float* state, float* control)
   {
@@ -191,6 +199,23 @@ public:
   {
     int i, p_index, step;
     mppi::p1::getParallel1DIndex<mppi::p1::Parallel1Dir::THREAD_Y>(p_index, step);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (STATE_DIM % 2 == 0 && step == 1)
+    {  // one lane per rollout: two states per packed v_pk_mul_f32 / v_pk_add_f32 (same roundings as the scalar form)
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (i = 0; i + 1 < STATE_DIM; i += 2)
+      {
+        const f32x2 x = { state[i], state[i + 1] };
+        const f32x2 d = { state_der[i], state_der[i + 1] };
+        const f32x2 inc = d * f32x2{ dt, dt };
+        const f32x2 n = x + inc;
+        next_state[i] = n.x;
+        next_state[i + 1] = n.y;
+      }
+      return;
+    }
+#endif
     for (i = p_index; i < STATE_DIM; i += step)
     {
       next_state[i] = state[i] + state_der[i] * dt;

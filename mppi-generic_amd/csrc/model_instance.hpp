@@ -429,8 +429,8 @@ struct ModelT : ModelBase
                                   (int)smem);
       constexpr int RPB = FOLD ? 64 / Z : 64;  // rollouts per block
       const int grid = (args.num_rollouts + RPB - 1) / RPB;
-      hipLaunchKernelGGL(kfn, dim3(grid), dim3(FOLD ? 64 * (2 + kernels::PIPE_FOLD_SAMPLERS) : 64 * kernels::PIPE_ROLES, 1, FOLD ? 1 : Z),
-                         smem, stream, dyn, cost, smp, args);
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(kernels::pipelineBlockX(Z, FOLD), 1, FOLD ? 1 : Z), smem, stream, dyn, cost,
+                         smp, args);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess)
       {

@@ -83,13 +83,18 @@ __device__ inline void pipePublish(lds_counter_t ctr, const int value, const int
     *ctr = value;
 }
 
-/** sampler waves of the folded variant: with C = 2 a Philox quad only lasts two steps and the draw (Philox rounds + two
- *  Box-Muller pairs, ~350 dependent instructions) is the longest of the three roles; one block per CU leaves the fourth
- *  SIMD idle, so a second sampler wave is free */
-constexpr int PIPE_FOLD_SAMPLERS = 2;
+/** sampler waves of blocks that hold ONE set of role waves (BZ == 1, or the folded Tube variant): the draw (Philox rounds
+ *  + two Box-Muller pairs per quad, ~320 dependent instructions) is as long as the dynamics of four cart-pole steps, and a
+ *  block of three waves leaves the CU's fourth SIMD idle — a second sampler wave taking alternate trips is free */
+constexpr int PIPE_SAMPLERS = 2;
+/** workgroup x extent of rolloutPipelineKernel */
+__host__ __device__ constexpr int pipelineBlockX(int bz, bool fold_z)
+{
+  return (bz == 1 || fold_z) ? 64 * (2 + PIPE_SAMPLERS) : 64 * PIPE_ROLES;
+}
 
 template <class DYN_T, class COST_T, class SAMPLING_T, int BZ, bool DRAW_IN_LOOP, bool FOLD_Z = false>
-__global__ void __launch_bounds__(FOLD_Z ? 64 * (2 + PIPE_FOLD_SAMPLERS) : 64 * PIPE_ROLES * BZ)
+__global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ))
     rolloutPipelineKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args)
 {
   // FOLD_Z (Tube: BZ == 2): a wave carries 32 rollouts x 2 systems in its 64 lanes.  Half the sample rows per block
@@ -100,10 +105,12 @@ __global__ void __launch_bounds__(FOLD_Z ? 64 * (2 + PIPE_FOLD_SAMPLERS) : 64 * 
   constexpr int WZ = FOLD_Z ? 1 : BZ;  // z extent of the workgroup
   // The folded variant draws with PAIRS of lanes: the two systems of a rollout see the same noise, so lane z = 0 draws
   // Philox quad q, lane z = 1 quad q + 1, and one v_permlane32_swap per value hands both quads to both lanes — a trip is
-  // 8 row elements (8 / C steps) for the price of one draw.  NS sampler waves take alternate trips.
+  // 8 row elements (8 / C steps) for the price of one draw.
+  // A sampler trip is always 4 steps (= C Philox quads = one group of the dynamics wave); NS sampler waves take
+  // alternate trips.
   constexpr bool PAIR_DRAW = FOLD_Z && DRAW_IN_LOOP && BZ == 2 && DYN_T::CONTROL_DIM == 2;
-  constexpr int NS = PAIR_DRAW ? PIPE_FOLD_SAMPLERS : 1;  // sampler waves
-  constexpr int WX = FOLD_Z ? 64 * (2 + PIPE_FOLD_SAMPLERS) : 64 * PIPE_ROLES;
+  constexpr int WX = pipelineBlockX(BZ, FOLD_Z);
+  constexpr int NS = WX / 64 - 2;  // sampler waves
   __builtin_assume(__builtin_amdgcn_workgroup_size_x() == WX);
   __builtin_assume(__builtin_amdgcn_workgroup_size_y() == 1);
   __builtin_assume(__builtin_amdgcn_workgroup_size_z() == WZ);
@@ -117,11 +124,13 @@ __global__ void __launch_bounds__(FOLD_Z ? 64 * (2 + PIPE_FOLD_SAMPLERS) : 64 * 
   constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
   constexpr int SLOTS = BX * BZ;
   constexpr int NTHREADS = WX * WZ;
+  // state-independent control constraints are applied by the sampler waves, which have issue slots to spare
+  constexpr bool SMP_CONSTRAINS = !DYN_T::CONSTRAINTS_DEPEND_ON_STATE;
 
   const int tid_x = (int)__builtin_amdgcn_workitem_id_x();
   const int wave_x = __builtin_amdgcn_readfirstlane(tid_x >> 6);  // wave-uniform
-  // waves 0 / 1 / 2: sampler / dynamics / cost; waves 3.. (folded variant): further samplers (idle without PAIR_DRAW)
-  const int role = wave_x < PIPE_ROLES ? wave_x : (wave_x - PIPE_ROLES + 1 < NS ? 0 : 3);
+  // waves 0 / 1 / 2: sampler / dynamics / cost; wave 3 (if present): second sampler
+  const int role = wave_x < PIPE_ROLES ? wave_x : 0;
   const int smp_id = wave_x < PIPE_ROLES ? 0 : wave_x - PIPE_ROLES + 1;
   const int lane = tid_x & 63;
   const int thread_idx = FOLD_Z ? lane % BX : lane;
@@ -192,7 +201,7 @@ __global__ void __launch_bounds__(FOLD_Z ? 64 * (2 + PIPE_FOLD_SAMPLERS) : 64 * 
   if (role == 0 && PAIR_DRAW)
   {
     /* ------------------------------------------------ sampler waves, pair draw ------------------------------------- */
-    constexpr int STEPS = 8 / C;  // == 4: a trip is one group of the dynamics wave
+    constexpr int STEPS = 8 / C;  // == 4
     lds_counter_t my_prog = smp_id == 0 ? smp_prog : smp_prog1;
     for (int t = STEPS * smp_id; t < num_timesteps; t += STEPS * NS)
     {
@@ -212,6 +221,8 @@ __global__ void __launch_bounds__(FOLD_Z ? 64 * (2 + PIPE_FOLD_SAMPLERS) : 64 * 
         if (t + s2 < num_timesteps)
         {
           sampling->template shapeControlSample<FOLD_Z>(global_idx, t + s2, distribution_idx, &e[s2 * C], u);
+          if (SMP_CONSTRAINS)
+            dynamics->enforceConstraints(x, u);
           sampling->writeControlSample(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
         }
       }
@@ -221,9 +232,10 @@ __global__ void __launch_bounds__(FOLD_Z ? 64 * (2 + PIPE_FOLD_SAMPLERS) : 64 * 
   else if (role == 0)
   {
     /* ------------------------------------------------ sampler wave ------------------------------------------------ */
-    constexpr int STEPS = (C % 2 == 0) ? 2 : 4;
-    constexpr int QUADS = STEPS * C / 4;
-    for (int t = 0; t < num_timesteps; t += STEPS)
+    constexpr int STEPS = 4;
+    constexpr int QUADS = C;  // STEPS * C / 4
+    lds_counter_t my_prog = smp_id == 0 ? smp_prog : smp_prog1;
+    for (int t = STEPS * smp_id; t < num_timesteps; t += STEPS * NS)
     {
       float zq[4 * QUADS];
       if (DRAW_IN_LOOP)
@@ -241,10 +253,12 @@ __global__ void __launch_bounds__(FOLD_Z ? 64 * (2 + PIPE_FOLD_SAMPLERS) : 64 * 
             sampling->template shapeControlSample<FOLD_Z>(global_idx, t + s2, distribution_idx, &zq[s2 * C], u);
           else
             sampling->template readControlSample<FOLD_Z>(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
+          if (SMP_CONSTRAINS)
+            dynamics->enforceConstraints(x, u);
           sampling->writeControlSample(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
         }
       }
-      pipePublish(smp_prog, min(t + STEPS, num_timesteps), lane);
+      pipePublish(my_prog, min(t + STEPS, num_timesteps), lane);
     }
   }
   else if (role == 1)
@@ -255,10 +269,13 @@ __global__ void __launch_bounds__(FOLD_Z ? 64 * (2 + PIPE_FOLD_SAMPLERS) : 64 * 
 #pragma unroll
       for (int i = 0; i < C; i++)
         u[i] = u_in[i];
-      dynamics->enforceConstraints(xc, u);
+      if (!SMP_CONSTRAINS)
+      {
+        dynamics->enforceConstraints(xc, u);
 #pragma unroll
-      for (int i = 0; i < C; i++)
-        row[t * C + i] = u[i];
+        for (int i = 0; i < C; i++)
+          row[t * C + i] = u[i];
+      }
       dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
       float* slot = ring + (size_t)(t % PIPE_RING) * O * 64 + lane;
 #pragma unroll
@@ -428,6 +445,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
   SAMPLING_T* sampling = &sampling_obj;
   constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
   constexpr int SLOTS = BX;
+  constexpr bool SMP_CONSTRAINS = !DYN_T::CONSTRAINTS_DEPEND_ON_STATE;  // see rolloutPipelineKernel
 
   const int tid_x = (int)__builtin_amdgcn_workitem_id_x();
   const int wave = __builtin_amdgcn_readfirstlane(tid_x >> 6);  // wave-uniform
@@ -513,6 +531,8 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
             sampling->shapeControlSample(global_idx, t + s2, 0, &zq[s2 * C], u);
           else
             sampling->readControlSample(global_idx, t + s2, 0, u, theta_d_shared, 1, 0, y);
+          if (SMP_CONSTRAINS)
+            dynamics->enforceConstraints(x, u);
           sampling->writeControlSample(global_idx, t + s2, 0, u, theta_d_shared, 1, 0, y);
         }
       }
@@ -527,12 +547,15 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
 #pragma unroll
       for (int i = 0; i < C; i++)
         u[i] = u_in[i];
-      dynamics->enforceConstraints(xc, u);
-      if (rep_lane == 0)
+      if (!SMP_CONSTRAINS)
       {
+        dynamics->enforceConstraints(xc, u);
+        if (rep_lane == 0)
+        {
 #pragma unroll
-        for (int i = 0; i < C; i++)
-          row[t * C + i] = u[i];
+          for (int i = 0; i < C; i++)
+            row[t * C + i] = u[i];
+        }
       }
       dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
       if (rep_lane == 0)
