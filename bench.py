@@ -39,7 +39,13 @@ def usable_cores():
     return n
 
 
-PMC_FILE = os.path.join("profiles", "r01_d_pmc_hbm_traffic.json")
+def _latest_pmc_file():
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic.json")))
+    return files[-1] if files else os.path.join("profiles", "none.json")
+
+
+PMC_FILE = _latest_pmc_file()
 
 
 def pmc_traffic(kernel_prefix):

@@ -2,21 +2,23 @@
  * rollout_pipeline_kernel.hpp — the rollout as a three-stage pipeline of role-specialised waves (MI355X design).
  *
  * Why: at the benchmark sizes (K = 16384 rollouts = 256 waves on 1024 SIMDs) the fused rollout is bound by the LENGTH
- * of one wave's serial instruction stream (T steps x ~300 instructions x ~3.7 cycles), not by throughput: three of the
- * four SIMDs of every CU idle.  The reference's plugin split happens to cut a step into three parts with a one-way data
+ * of one wave's serial instruction stream (T steps x ~300 instructions x ~2 ns, dependent or not —
+ * tools/ubench/op_latency.hip), not by throughput: three of the four SIMDs of every CU idle.  The reference's plugin split happens to cut a step into three parts with a one-way data
  * flow — SamplingDistribution -> Dynamics -> Cost (reference call order: core/mppi_common.cu:98-137) — and only the
  * Dynamics part carries the step-to-step dependence.  So a block of 64 rollouts runs as three waves on three SIMDs:
  *
  *   wave S (sampler)   for every t: draw eps (Philox quad / pre-filled row), apply the setGaussianControls rule,
  *                      store the sample in the rollout's LDS row                      -> sampling->drawQuad / shape...
- *   wave D (dynamics)  for every t: fetch the sample, enforceConstraints, write the clamped control back to the row
- *                      (mppi_common.cu:110-117), step, push the output y_t into an LDS ring  -> dynamics->...
+ *   wave D (dynamics)  for every t: fetch the sample, step, push the output y_t into an LDS ring  -> dynamics->...
+ *                      (enforceConstraints + write-back of the clamped control, mppi_common.cu:110-117, happen here only
+ *                      when the plugin's constraints depend on the state; otherwise in the sampler waves)
  *   wave C (cost)      for every t: pop y_t, read u_t, running += computeRunningCost + likelihoodRatioCost
  *                                                                              -> costs->..., sampling->...
  *
  * The stages are decoupled by monotonic progress counters in LDS (one writer each, polled with s_sleep by the consumer,
  * release/acquire at workgroup scope); S may run arbitrarily far ahead (the rows hold the whole horizon), C lags D by at
- * most RING steps (back-pressure).  The critical path per step is wave D's ~130 instructions instead of ~300.
+ * most RING steps (back-pressure).  The critical path per step is wave D's instructions (Cartpole: 83) instead of ~300.
+ * Blocks with one set of role waves run TWO sampler waves on alternate trips of four steps (the CU's fourth SIMD).
  * Every rollout is still evaluated with exactly the arithmetic of rolloutKernel (same plugin methods, same order of the
  * cost additions), so the results are bit-identical; the epilogue is shared (blockSoftminEpilogue).
  *
@@ -24,7 +26,8 @@
  * per-step methods (mppi::lane_sync() is fine — it is a no-op for blockDim.y == 1).  Models are registered for this
  * variant explicitly (csrc/models.hpp).
  *
- * Launch: grid = ceil(K / 64), block = (192, 1, BZ); thread x: role = x / 64, lane = x % 64.
+ * Launch: grid = ceil(K / 64), block = (pipelineBlockX(), 1, BZ): waves 0 / 1 / 2 = sampler / dynamics / cost, wave 3 (blocks
+ * with one z slice) = second sampler.  FOLD_Z: see the kernel.
  */
 #ifndef MPPI_AMD_ROLLOUT_PIPELINE_KERNEL_HPP_
 #define MPPI_AMD_ROLLOUT_PIPELINE_KERNEL_HPP_
@@ -375,8 +378,8 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
 /* =====================================================================================================================
  * The same pipeline for models whose Dynamics runs REPLICATED_LANES > 1 lanes per rollout (the MFMA network forwards).
  *
- * Why it pays even more there: a single wave issues roughly one instruction every 4 cycles, while a SIMD can issue one
- * every 2 when it has two waves to pick from (MI355X_MICROARCH.md, per-instruction constants).  In the fused kernel the
+ * Why it pays even more there: a lone wave issues one VALU instruction every ~2 ns whatever its dependences
+ * (tools/ubench/op_latency.hip), so a step costs its instruction count on the slowest wave.  In the fused kernel the
  * 4 lanes of a rollout ALL execute the sampler and the cost function redundantly (~600 of the ~1150 instructions of an
  * AutoRally step) and every SIMD holds exactly one wave at K = 16384.  Here a block of 64 rollouts runs as
  *     REP dynamics waves   16 rollouts x REP lanes each: enforceConstraints, network + kinematics, Euler step

@@ -23,7 +23,9 @@ def short(name):
 
 def collect(d, counter):
     acc = defaultdict(list)
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    # gpurun merges every call's output into the same directory: only the newest run counts
+    files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter:
                 acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
