@@ -226,14 +226,27 @@ def main():
         dist.broadcast_object_list(uid, src=0)
         native_ok, why = False, "no RCCL unique id"
         if uid[0] is not None:
-            try:
-                eng.commInitRccl(uid[0])
-                eng.uploadState(x0)
-                eng.optimize(1, True)
-                native_ok = bool(np.isfinite(eng.getOptimalControlSeq()).all())
-                why = "non-finite result after the first exchanged iteration"
-            except Exception as e:  # noqa: BLE001
-                why = str(e)
+            # the first collective runs under a watchdog: a communicator that never forms must not hang the bench
+            import threading
+            res = {"ok": False, "why": "RCCL communicator setup or first all-gather did not finish within 120 s"}
+
+            def attempt():
+                try:
+                    eng.commInitRccl(uid[0])
+                    eng.uploadState(x0)
+                    eng.optimize(1, True)
+                    res["ok"] = bool(np.isfinite(eng.getOptimalControlSeq()).all())
+                    res["why"] = "non-finite result after the first exchanged iteration"
+                except Exception as e:  # noqa: BLE001
+                    res["why"] = str(e)
+
+            th = threading.Thread(target=attempt, daemon=True)
+            th.start()
+            th.join(120.0)
+            stuck = th.is_alive()
+            native_ok, why = (res["ok"] and not stuck), res["why"]
+            if stuck:
+                globals()["_HARD_EXIT"] = True  # a thread is parked inside the collective library: leave with os._exit
         flags = [None] * world
         dist.all_gather_object(flags, (native_ok, why))
         if all(f[0] for f in flags):
@@ -324,3 +337,6 @@ def main():
 
 if __name__ == "__main__":
     main()
+    if globals().get("_HARD_EXIT"):
+        sys.stdout.flush()
+        os._exit(0)
