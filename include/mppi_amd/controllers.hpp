@@ -9,7 +9,7 @@
  *   RobustMPPIController    R-MPPI/robust_mppi_controller.cuh              RobustMPPIController
  *
  * The reference's classes are templates over <DYN_T, COST_T, FB_T, MAX_TIMESTEPS, NUM_ROLLOUTS, SAMPLING_T>; the precompiled
- * engine selects the (DYN_T, COST_T, SAMPLING_T) instantiation by NAME ("cartpole", "double_integrator", "autorally_nn",
+ * engine selects the (DYN_T, COST_T, SAMPLING_T) instantiation by NAME ("cartpole", "double_integrator", "autorally_nn", "racer_dubins",
  * "bicycle_slip_lstm"; mppi_list_models()) and takes the sizes at run time.  Trajectories are row-major [T][C] / [T][S]
  * std::vector<float> — byte-compatible with the reference's column-major Eigen C x T / S x T matrices
  * (controllers/controller.cuh:96), so `Eigen::Map<control_trajectory>(u.data())` gives the reference's view.

@@ -1,0 +1,62 @@
+/**
+ * QuadraticCost plugin — sum_i coeff_i (y_i - goal_i)^2 over the OUTPUT vector of any Dynamics
+ * (reference: include/mppi/cost_functions/quadratic_cost/quadratic_cost.cuh:11-128, quadratic_cost.cu:39-60 device
+ * computeStateCost / terminalCost).  One goal (the reference's SIM_TIME_HORIZON = 1 instantiation: getIndex() clamps
+ * every timestep to the single stored goal).  powf(x, 2) of the reference is x * x (what the CUDA compiler emits for a
+ * constant exponent 2).
+ */
+#ifndef MPPI_AMD_QUADRATIC_COST_HPP_
+#define MPPI_AMD_QUADRATIC_COST_HPP_
+
+#include "mppi_amd/plugin/cost.hpp"
+
+template <class DYN_T>
+struct QuadraticCostParams : public CostParams<DYN_T::CONTROL_DIM>
+{
+  float s_goal[DYN_T::OUTPUT_DIM] = { 0 };
+  float s_coeffs[DYN_T::OUTPUT_DIM] = { 0 };
+  int current_time = 0;
+
+  QuadraticCostParams()
+  {
+    for (int i = 0; i < DYN_T::CONTROL_DIM; i++)
+    {
+      this->control_cost_coeff[i] = 0;
+    }
+    for (int i = 0; i < DYN_T::OUTPUT_DIM; i++)
+    {
+      this->s_coeffs[i] = 1;
+    }
+  }
+};
+
+template <class DYN_T>
+class QuadraticCost : public Cost<QuadraticCost<DYN_T>, QuadraticCostParams<DYN_T>, typename DYN_T::DYN_PARAMS_T>
+{
+public:
+  static constexpr float MAX_COST_VALUE = 1e16;
+  QuadraticCost(hipStream_t stream = nullptr)
+  {
+    this->bindToStream(stream);
+  }
+
+  __device__ inline float computeStateCost(float* s, int timestep = 0, float* theta_c = nullptr,
+                                           int* crash_status = nullptr)
+  {
+    float cost = 0;
+    const float* desired_state = this->params_.s_goal;
+#pragma unroll
+    for (int i = 0; i < DYN_T::OUTPUT_DIM; i++)
+    {
+      cost += ((s[i] - desired_state[i]) * (s[i] - desired_state[i])) * this->params_.s_coeffs[i];
+    }
+    return cost;
+  }
+
+  __device__ inline float terminalCost(float* s, float* theta_c)
+  {
+    return 0.0f;
+  }
+};
+
+#endif

@@ -179,6 +179,13 @@ MPPI_HD static inline float sin(float x)
   sincos(x, &s, &c);
   return s;
 }
+/** tan(x) = sin / cos with one correctly rounded division: <= 4 ulp for |x| <= 1e4 away from the poles */
+MPPI_HD static inline float tan(float x)
+{
+  float s, c;
+  sincos(x, &s, &c);
+  return s / c;
+}
 MPPI_HD static inline float cos(float x)
 {
   float s, c;

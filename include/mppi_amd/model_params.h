@@ -8,6 +8,8 @@
  *                                      (CostParams<1> base: control_cost_coeff[1], discount; cost_functions/cost.cuh:17-31)
  *   mppi_di_dynamics_params         <- DoubleIntegratorParams        dynamics/double_integrator/di_dynamics.cuh:9-37
  *   mppi_di_circle_cost_params      <- DoubleIntegratorCircleCostParams  cost_functions/double_integrator/double_integrator_circle_cost.cuh:8-23
+ *   mppi_racer_dubins_params        <- RacerDubinsParams             dynamics/racer_dubins/racer_dubins.cuh:67-87
+ *   mppi_quadratic_cost_params_28   <- QuadraticCostTrajectoryParams<RacerDubins, 1>  cost_functions/quadratic_cost/quadratic_cost.cuh:11-63
  * (paths relative to the reference's include/mppi/).
  */
 #ifndef MPPI_AMD_MODEL_PARAMS_H_
@@ -52,6 +54,39 @@ typedef struct mppi_di_circle_cost_params
   float outer_path_radius2;       /* 2.125^2 */
   float angular_momentum_desired; /* 2 * velocity_desired */
 } mppi_di_circle_cost_params;
+
+typedef struct mppi_racer_dubins_params
+{
+  float c_t[3];                    /* {1.3, 2.6, 3.9} */
+  float c_b[3];                    /* {2.5, 3.5, 4.5} */
+  float c_v[3];                    /* {3.7, 4.7, 5.7} */
+  float c_0;                       /* 4.9 */
+  float steering_constant;         /* 0.6 */
+  float steer_command_angle_scale; /* 5 */
+  float steer_angle_scale;         /* -9.1 */
+  float max_steer_angle;           /* 0.5 */
+  float max_steer_rate;            /* 5 */
+  float steer_accel_constant;      /* 12.1 */
+  float steer_accel_drag_constant; /* 1.0 */
+  float brake_delay_constant;      /* 6.6 */
+  float brake_delay_constant_neg;  /* 8.2 */
+  float max_brake_rate_neg;        /* 0.9 */
+  float max_brake_rate_pos;        /* 0.33 */
+  float wheel_base;                /* 0.3 */
+  float low_min_throttle;          /* 0.13 */
+  float gravity;                   /* -9.81 */
+  int gear_sign;                   /* 1 */
+} mppi_racer_dubins_params;
+
+/** QuadraticCost over the 28 outputs of the RACER models, one goal (SIM_TIME_HORIZON = 1) */
+typedef struct mppi_quadratic_cost_params_28
+{
+  float control_cost_coeff[2]; /* {0, 0} */
+  float discount;              /* 1.0 */
+  float s_goal[28];            /* 0 */
+  float s_coeffs[28];          /* 1 */
+  int current_time;            /* 0 */
+} mppi_quadratic_cost_params_28;
 
 /** <- ARStandardCostParams  cost_functions/autorally/ar_standard_cost.cuh:14-41 (float3 r_c1, r_c2, trs as 3 floats each).
  *  The AutoRally NeuralNetModel has no dynamics parameter block (NNDynamicsParams is empty); its weights are the

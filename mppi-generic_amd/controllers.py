@@ -81,6 +81,50 @@ class DoubleIntegratorCircleCostParams(C.Structure):
         self.angular_momentum_desired = 4
 
 
+class RacerDubinsParams(C.Structure):
+    """mppi_racer_dubins_params (reference: dynamics/racer_dubins/racer_dubins.cuh:67-87)"""
+    _fields_ = [("c_t", C.c_float * 3), ("c_b", C.c_float * 3), ("c_v", C.c_float * 3), ("c_0", C.c_float),
+                ("steering_constant", C.c_float), ("steer_command_angle_scale", C.c_float), ("steer_angle_scale", C.c_float),
+                ("max_steer_angle", C.c_float), ("max_steer_rate", C.c_float), ("steer_accel_constant", C.c_float),
+                ("steer_accel_drag_constant", C.c_float), ("brake_delay_constant", C.c_float),
+                ("brake_delay_constant_neg", C.c_float), ("max_brake_rate_neg", C.c_float), ("max_brake_rate_pos", C.c_float),
+                ("wheel_base", C.c_float), ("low_min_throttle", C.c_float), ("gravity", C.c_float), ("gear_sign", C.c_int)]
+
+    def __init__(self):
+        super().__init__()
+        self.c_t[:] = [1.3, 2.6, 3.9]
+        self.c_b[:] = [2.5, 3.5, 4.5]
+        self.c_v[:] = [3.7, 4.7, 5.7]
+        self.c_0 = 4.9
+        self.steering_constant = 0.6
+        self.steer_command_angle_scale = 5
+        self.steer_angle_scale = -9.1
+        self.max_steer_angle = 0.5
+        self.max_steer_rate = 5
+        self.steer_accel_constant = 12.1
+        self.steer_accel_drag_constant = 1.0
+        self.brake_delay_constant = 6.6
+        self.brake_delay_constant_neg = 8.2
+        self.max_brake_rate_neg = 0.9
+        self.max_brake_rate_pos = 0.33
+        self.wheel_base = 0.3
+        self.low_min_throttle = 0.13
+        self.gravity = -9.81
+        self.gear_sign = 1
+
+
+class QuadraticCostParams28(C.Structure):
+    """mppi_quadratic_cost_params_28 (reference: QuadraticCostTrajectoryParams<RacerDubins, 1>,
+    cost_functions/quadratic_cost/quadratic_cost.cuh:11-63)"""
+    _fields_ = [("control_cost_coeff", C.c_float * 2), ("discount", C.c_float), ("s_goal", C.c_float * 28),
+                ("s_coeffs", C.c_float * 28), ("current_time", C.c_int)]
+
+    def __init__(self):
+        super().__init__()
+        self.discount = 1.0
+        self.s_coeffs[:] = [1.0] * 28
+
+
 class ARStandardCostParams(C.Structure):
     _fields_ = [
         ("control_cost_coeff", C.c_float * 2), ("discount", C.c_float), ("desired_speed", C.c_float),

@@ -1868,6 +1868,7 @@ __global__ void detEvalKernel(int func, const float* x, float* y, int n)
         r = v[0] + v[1] + v[2] + v[3];
         break;
       }
+      case 12: r = mppi::det::tan(x[i]); break;
     }
     y[i] = r;
   }

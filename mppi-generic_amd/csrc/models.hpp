@@ -25,6 +25,8 @@
 #include "mppi_amd/dynamics/autorally/ar_nn_model.hpp"
 #include "mppi_amd/cost_functions/autorally/ar_standard_cost.hpp"
 #include "mppi_amd/dynamics/bicycle_slip/bicycle_slip_lstm.hpp"
+#include "mppi_amd/dynamics/racer_dubins/racer_dubins.hpp"
+#include "mppi_amd/cost_functions/quadratic_cost/quadratic_cost.hpp"
 
 namespace mppi
 {
@@ -57,6 +59,16 @@ using BSLModel = ModelT<BicycleSlipLSTM, ARStandardCost, BSLSampler,
                         Shapes<Shape<16, 8, 1>, Shape<16, 4, 1>, Shape<64, 1, 1>, Shape<8, 16, 1>, Shape<16, 8, 2>>,
                         /*FIN_BY=*/8, BicycleSlipLSTMMFMA, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>, Shape<64, 4, 2>>>;
 
+/* RACER Dubins car + QuadraticCost over its 28 outputs (dynamics/racer_dubins/racer_dubins.cuh,
+ * cost_functions/quadratic_cost/quadratic_cost.cuh) */
+using RacerSampler = sampling_distributions::GaussianDistribution<RacerDubinsParams>;
+using RacerDubinsModel = ModelT<RacerDubins, QuadraticCost<RacerDubins>, RacerSampler,
+                                Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/1, void, Shapes<>,
+                                /*PIPELINE=*/true>;
+using RacerDubinsColoredModel =
+    ModelT<RacerDubins, QuadraticCost<RacerDubins>, sampling_distributions::ColoredNoiseDistribution<RacerDubinsParams>,
+           Shapes<Shape<64, 1, 1>>, /*FIN_BY=*/1, void, Shapes<>, /*PIPELINE=*/true>;
+
 /* ColoredMPPI instantiations (reference: controllers/ColoredMPPI/colored_mppi_controller.cuh with
  * ColoredNoiseDistribution as SAMPLING_T): the same plugins with the colored-noise sampler. */
 using CartpoleColoredModel =
@@ -86,6 +98,8 @@ inline ModelBase* makeModel(const std::string& name, bool colored = false)
       m = new ARColoredModel();
     else if (name == "bicycle_slip_lstm")
       m = new BSLColoredModel();
+    else if (name == "racer_dubins")
+      m = new RacerDubinsColoredModel();
     if (m && (name == "autorally_nn" || name == "bicycle_slip_lstm"))
     {
       m->default_bx = 64;
@@ -111,12 +125,14 @@ inline ModelBase* makeModel(const std::string& name, bool colored = false)
     return new CartpoleModel();
   if (name == "double_integrator")
     return new DIModel();
+  if (name == "racer_dubins")
+    return new RacerDubinsModel();
   return nullptr;
 }
 
 inline const char* listModels()
 {
-  return "cartpole\ndouble_integrator\nautorally_nn\nbicycle_slip_lstm";
+  return "cartpole\ndouble_integrator\nautorally_nn\nbicycle_slip_lstm\nracer_dubins";
 }
 
 }  // namespace engine

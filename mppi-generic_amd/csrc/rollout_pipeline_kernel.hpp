@@ -39,7 +39,12 @@ namespace mppi
 namespace kernels
 {
 constexpr int PIPE_ROLES = 3;
-constexpr int PIPE_RING = 32;  ///< outputs buffered between the dynamics and the cost wave (steps)
+/** outputs buffered between the dynamics and the cost wave (steps): 32 for the small analytic models; wide output
+ *  vectors (the RACER models carry 28 floats) get a shorter ring — 8 steps = two groups of the dynamics wave */
+__host__ __device__ constexpr int pipeRingSteps(int output_dim)
+{
+  return output_dim <= 8 ? 32 : (output_dim <= 16 ? 16 : 8);
+}
 
 /** fold_z: the systems of a rollout are folded into the LANE dimension (64 / bz rollouts x bz systems per wave) instead of
  *  the workgroup's z dimension — one ring and one counter set per block, half the sample rows per block */
@@ -54,7 +59,7 @@ __host__ inline size_t pipelineSharedBytes(const DYN_T& dyn, const COST_T& cost,
   n += calcClassSharedMemSize(&cost, slots);
   n += calcClassSharedMemSize(&smp, slots);
   n += sizeof(float) * 2 * math::nearest_multiple_4(slots);                     // cost_s, w_s
-  n += sizeof(float) * (size_t)rings * PIPE_RING * DYN_T::OUTPUT_DIM * 64;       // output ring [z][slot][i][lane]
+  n += sizeof(float) * (size_t)rings * pipeRingSteps(DYN_T::OUTPUT_DIM) * DYN_T::OUTPUT_DIM * 64;  // output ring [z][slot][i][lane]
   n += sizeof(int) * 4 * 4 * rings;                                              // progress counters (padded)
   return n;
 }
@@ -125,6 +130,7 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
   COST_T* costs = &costs_obj;
   SAMPLING_T* sampling = &sampling_obj;
   constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
+  constexpr int PIPE_RING = pipeRingSteps(O);
   constexpr int SLOTS = BX * BZ;
   constexpr int NTHREADS = WX * WZ;
   // state-independent control constraints are applied by the sampler waves, which have issue slots to spare

@@ -114,6 +114,14 @@ void oracle_state_deriv(void* h, const float* x, const float* u, float* xdot)
   c->dyn->computeKinematics(x, xdot);
   c->dyn->computeDynamics(x, u, xdot, th.data());
 }
+/** Dynamics::updateState with a given derivative (the reference's TestUpdateState known answers) */
+void oracle_update_state(void* h, const float* x, const float* xdot, float dt, float* x_next)
+{
+  auto* c = (Controller*)h;
+  for (int i = 0; i < c->dyn->S; i++)
+    x_next[i] = 0.0f;
+  c->dyn->updateState(x, x_next, xdot, dt);
+}
 /** running state cost of one output vector */
 float oracle_state_cost(void* h, const float* y, int t, int* crash)
 {
@@ -468,6 +476,7 @@ void oracle_det_eval(int func, const float* x, float* y, int n)
       case 11:
         y[i] = det::sigmoid(x[i]) + det::sigmoid(x[i] * 0.5f) + det::sigmoid(-x[i]) + det::sigmoid(x[i] + 1.0f);
         break;
+      case 12: y[i] = det::tan(x[i]); break;
       default: y[i] = 0.0f;
     }
   }

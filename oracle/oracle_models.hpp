@@ -470,6 +470,100 @@ struct ARStandardCost : Cost
   }
 };
 
+/* ------------------------------------------------------------------ RACER Dubins + QuadraticCost -------------------- */
+/** reference: dynamics/racer_dubins/racer_dubins.cu:138-165 (device computeDynamics), :73-98 (device updateState);
+ *  known answers: tests/dynamics/racer_dubins_model_test.cu:36-162 (ComputeDynamics), :321-380 (TestUpdateState) */
+struct RacerDubins : Dynamics
+{
+  mppi_racer_dubins_params p{ { 1.3f, 2.6f, 3.9f }, { 2.5f, 3.5f, 4.5f }, { 3.7f, 4.7f, 5.7f }, 4.9f, .6f, 5, -9.1f, 0.5f, 5,
+                              12.1f, 1.0f, 6.6f, 8.2f, 0.9f, 0.33f, 0.3f, 0.13f, -9.81f, 1 };
+  enum
+  {
+    VEL_X = 0,
+    YAW,
+    POS_X,
+    POS_Y,
+    STEER_ANGLE,
+    BRAKE_STATE,
+    STEER_ANGLE_RATE
+  };
+  RacerDubins() : Dynamics(7, 2, 28)
+  {
+  }
+  int setParams(const void* pod, size_t n) override
+  {
+    if (n != sizeof(p))
+      return -1;
+    memcpy(&p, pod, n);
+    return 0;
+  }
+  void computeDynamics(const float* state, const float* control, float* state_der, float* theta_s) override
+  {
+    bool enable_brake = control[0] < 0;
+    state_der[BRAKE_STATE] =
+        fminf(fmaxf((enable_brake * -control[0] - state[BRAKE_STATE]) * p.brake_delay_constant, -p.max_brake_rate_neg),
+              p.max_brake_rate_pos);
+    state_der[VEL_X] = (!enable_brake) * p.c_t[0] * control[0] * p.gear_sign +
+                       p.c_b[0] * state[BRAKE_STATE] * (state[VEL_X] >= 0 ? -1 : 1) - p.c_v[0] * state[VEL_X] + p.c_0;
+    state_der[YAW] = (state[VEL_X] / p.wheel_base) * det::tan(state[STEER_ANGLE] / p.steer_angle_scale);
+    float yaw, sin_yaw, cos_yaw;
+    yaw = det::normalizeAngle(state[YAW]);
+    det::sincos(yaw, &sin_yaw, &cos_yaw); /* reference: __sincosf */
+    state_der[POS_X] = state[VEL_X] * cos_yaw;
+    state_der[POS_Y] = state[VEL_X] * sin_yaw;
+    state_der[STEER_ANGLE] =
+        fmaxf(fminf((control[1] * p.steer_command_angle_scale - state[STEER_ANGLE]) * p.steering_constant, p.max_steer_rate),
+              -p.max_steer_rate);
+  }
+  void updateState(const float* state, float* next_state, const float* state_der, float dt) const override
+  {
+    for (int i = 0; i < 6; i++)
+    {
+      next_state[i] = state[i] + state_der[i] * dt;
+      if (i == YAW)
+        next_state[i] = det::normalizeAngle(next_state[i]);
+      if (i == STEER_ANGLE)
+      {
+        next_state[i] = fmaxf(fminf(next_state[i], p.max_steer_angle), -p.max_steer_angle);
+        next_state[STEER_ANGLE_RATE] = state_der[i];
+      }
+      if (i == BRAKE_STATE)
+        next_state[i] = fminf(fmaxf(next_state[i], 0.0f), 1.0f);
+    }
+  }
+};
+
+/** reference: cost_functions/quadratic_cost/quadratic_cost.cu:39-60 (device), SIM_TIME_HORIZON = 1 */
+struct QuadraticCost28 : Cost
+{
+  mppi_quadratic_cost_params_28 params_;
+  QuadraticCost28() : Cost(2, 28)
+  {
+    memset(&params_, 0, sizeof(params_));
+    params_.discount = 1.0f;
+    for (int i = 0; i < 28; i++)
+      params_.s_coeffs[i] = 1.0f;
+  }
+  int setParams(const void* pod, size_t n) override
+  {
+    if (n != sizeof(params_))
+      return -1;
+    memcpy(&params_, pod, n);
+    return 0;
+  }
+  float computeStateCost(const float* s, int timestep, int* crash) override
+  {
+    float cost = 0;
+    for (int i = 0; i < 28; i++)
+      cost += ((s[i] - params_.s_goal[i]) * (s[i] - params_.s_goal[i])) * params_.s_coeffs[i]; /* powf(x, 2) */
+    return cost;
+  }
+  float terminalCost(const float* s) override
+  {
+    return 0.0f;
+  }
+};
+
 inline bool makeModel(const std::string& name, std::unique_ptr<Dynamics>& dyn, std::unique_ptr<Cost>& cost)
 {
   if (name == "bicycle_slip_lstm")
@@ -494,6 +588,12 @@ inline bool makeModel(const std::string& name, std::unique_ptr<Dynamics>& dyn, s
   {
     dyn.reset(new DoubleIntegratorDynamics());
     cost.reset(new DoubleIntegratorCircleCost());
+    return true;
+  }
+  if (name == "racer_dubins")
+  {
+    dyn.reset(new RacerDubins());
+    cost.reset(new QuadraticCost28());
     return true;
   }
   return false;

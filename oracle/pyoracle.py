@@ -42,6 +42,7 @@ def lib():
         L.oracle_lstm_forward.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _f32p, _f32p, _f32p, C.c_int,
                                           _f32p]
         L.oracle_state_deriv.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
+        L.oracle_update_state.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, _f32p]
         L.oracle_state_cost.restype = C.c_float
         L.oracle_state_cost.argtypes = [C.c_void_p, _f32p, C.c_int, C.POINTER(C.c_int)]
         L.oracle_set_control_ranges.argtypes = [C.c_void_p, _f32p]
@@ -141,6 +142,12 @@ class Oracle:
         out = np.zeros(self.S, np.float32)
         self.L.oracle_state_deriv(self.h, _f32(x).reshape(-1), _f32(u).reshape(-1), out)
         return out
+
+    def update_state(self, x, xdot, dt):
+        """Dynamics::updateState with a given derivative"""
+        xn = np.zeros(self.S, np.float32)
+        self.L.oracle_update_state(self.h, _f32(x).reshape(-1), _f32(xdot).reshape(-1), dt, xn)
+        return xn
 
     def state_cost(self, y, t=0, crash=0):
         cr = C.c_int(crash)

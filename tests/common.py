@@ -42,6 +42,26 @@ def di_cfg(K=1024, T=50, tube=True, lambda_=2.0, num_iters=1):
                 x0=np.array([2.0, 0.0, 0.0, 1.0], np.float32))
 
 
+def racer_cfg(K=1024, T=60, lambda_=0.2, num_iters=1):
+    """RacerDubins (dynamics/racer_dubins/racer_dubins.cuh defaults) + QuadraticCost over its outputs: hold 1.6 m/s (the
+    default parameters give dv/dt = 1.3 u - 3.7 v + 4.9, i.e. 1.32 m/s at u = 0 and 1.68 m/s at full throttle) towards a
+    way-point; throttle/brake in [-1, 1], steering command in [-1, 1]"""
+    cost = m.QuadraticCostParams28()
+    coeffs = [0.0] * 28
+    goal = [0.0] * 28
+    # plain RacerDubins: outputs 0..6 are the states [VEL_X, YAW, POS_X, POS_Y, STEER_ANGLE, BRAKE_STATE, STEER_ANGLE_RATE]
+    coeffs[0], goal[0] = 40.0, 1.6
+    coeffs[2], goal[2] = 1.0, 5.0
+    coeffs[3], goal[3] = 1.0, 2.0
+    coeffs[4] = 0.5
+    coeffs[6] = 0.05
+    cost.s_coeffs[:] = coeffs
+    cost.s_goal[:] = goal
+    return dict(model="racer_dubins", K=K, T=T, D=1, dt=0.02, lambda_=lambda_, alpha=0.0, num_iters=num_iters,
+                dyn=m.RacerDubinsParams(), cost=cost, ranges=[-1.0, 1.0, -1.0, 1.0], std_dev=[0.4, 0.5],
+                control_cost_coeff=[0.0, 0.0], x0=np.array([0.5, 0.3, 0.0, 0.0, 0.05, 0.0, 0.0], np.float32))
+
+
 def standard_track_map():
     """channel 0 of the reference's `track_map_standard.npz` (scripts/autorally/test/generateTestMaps.py:47-76):
     30 m x 30 m at 20 px/m, value = |15 - y| + x/30 in map coordinates; world bounds x in [-13, 17], y in [-10, 20]"""
