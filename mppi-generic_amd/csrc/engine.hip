@@ -766,6 +766,8 @@ static mppi_status iterationMerge(mppi_handle h)
 {
   if (!exchangeActive(h))
     return MPPI_OK;
+  if (h->D == 1)  // [world][1][PS] is already [1][world][PS]: no regroup launch (one kernel boundary less per iteration)
+    return launchCombine(h, h->recv_d, h->cfg.world_size, 1, nullptr, h->cfg.num_rollouts);
   const int n = h->cfg.world_size * h->D * h->PS;
   hipLaunchKernelGGL(regroupRecordsKernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->recv_d, h->gather_tmp_d,
                      h->cfg.world_size, h->D, h->PS);
