@@ -153,23 +153,8 @@ struct LSTMMfma
       sg[8 + i] = acc[2][i] + bg[2][i];
       gc[i] = acc[3][i] + bg[3][i];
     }
-    {  // the 12 sigmoids ((1 + tanh(x / 2)) / 2, activation_functions.cuh:49-59) and the 4 tanh as ONE lockstep batch of
-       // 8 packed pairs (det::tanh_n): same operations per value, no back-to-back dependent packed instructions
-      float t16[16];
-#pragma unroll
-      for (int i = 0; i < 12; i++)
-        t16[i] = sg[i] / 2.0f;
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        t16[12 + i] = gc[i];
-      mppi::det::tanh_n<16>(t16);
-#pragma unroll
-      for (int i = 0; i < 12; i++)
-        sg[i] = (1.0f + t16[i]) / 2.0f;
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        gc[i] = t16[12 + i];
-    }
+    mppi::det::sigmoid_n<12>(sg);
+    mppi::det::tanh_n<4>(gc);
     float hn[4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
