@@ -430,6 +430,17 @@ __host__ inline int pipelineRepRingSteps(const DYN_T& dyn, const COST_T& cost, c
   return 0;
 }
 
+/** pins every 32-bit word of a (trivially copyable) object to a VGPR: see the cost wave of rolloutPipelineRepKernel */
+template <class T>
+__device__ inline void vgprResident(T& obj)
+{
+  static_assert(sizeof(T) % 4 == 0, "whole words");
+  uint32_t* w = reinterpret_cast<uint32_t*>(&obj);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 4); i++)
+    asm volatile("" : "+v"(w[i]));
+}
+
 template <class DYN_T, class COST_T, class SAMPLING_T, bool DRAW_IN_LOOP>
 __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
     rolloutPipelineRepKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args,
@@ -606,6 +617,13 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
   else
   {
     /* ------------------------------------------------ cost wave --------------------------------------------------- */
+    // The cost plugin's parameters arrive as kernel arguments, i.e. in SGPRs, and this kernel's three roles together want
+    // more than the ~100 a wave has: the step loop of this wave was reloading spilled SGPRs with ~45 v_readlane per step.
+    // A private copy whose words are pinned to VGPRs (which this wave has to spare) takes the parameters out of that
+    // competition; every lane holds the same values, the arithmetic is unchanged.
+    COST_T costs_v = *costs;
+    vgprResident(costs_v);
+    COST_T* costs_w = &costs_v;
     int seen_dyn[DW];
 #pragma unroll
     for (int w = 0; w < DW; w++)
@@ -625,7 +643,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
 #pragma unroll
         for (int i = 0; i < C; i++)
           u[i] = row[tt * C + i];
-        running_cost += costs->computeRunningCost(y, u, tt, theta_c_shared, &crash_status) +
+        running_cost += costs_w->computeRunningCost(y, u, tt, theta_c_shared, &crash_status) +
                         sampling->computeLikelihoodRatioCost(u, theta_d_shared, global_idx, tt, 0, args.lambda, args.alpha);
       }
       pipePublish(cost_prog, hi, lane);
