@@ -195,6 +195,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MPPI_BENCH_DEVICE"):  # test hook: several ranks on one GPU (exercises the multi-rank control flow)
+        local_rank = int(os.environ["MPPI_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     n_gpus = args.gpus
     assert world == n_gpus or (world == 1 and n_gpus == 1), "launch with torch.distributed.run for --gpus > 1"
@@ -285,7 +287,9 @@ def main():
     n_ev = min(200, max(20, args.steps))
     try:
         ms_total, ms_roll = eng.timeIterations(n_ev)
-    except Exception:  # noqa: BLE001  (host-staged fallback: no device-resident loop to time; use the wall-clock step)
+        if ms_total == 0.0:  # host-staged fallback: the exchange is driven from here, use the wall-clock step
+            ms_total = elapsed / args.steps * 1e3 * n_ev
+    except Exception:  # noqa: BLE001
         ms_total = ms_roll = elapsed / args.steps * 1e3 * n_ev
     C_dim = eng.CONTROL_DIM
     b_alg = 4.0 * (2.0 * K_PER_GPU * T * C_dim + 2.0 * K_PER_GPU + 2.0 * T * C_dim)

@@ -1510,14 +1510,19 @@ mppi_status mppi_time_iterations(mppi_handle h, int n, float* ms_total, float* m
   if (n <= 0 || !ms_total)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_time_iterations: bad arguments");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-  // pass 1: whole iterations between two events
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  HIP_TRY(h, hipEventRecord(h->ev_a, h->stream));
-  for (int i = 0; i < n; i++)
-    MPPI_TRY(iteration(h, 0, h->last_stride));
-  HIP_TRY(h, hipEventRecord(h->ev_b, h->stream));
-  HIP_TRY(h, hipEventSynchronize(h->ev_b));
-  HIP_TRY(h, hipEventElapsedTime(ms_total, h->ev_a, h->ev_b));
+  // pass 1: whole iterations between two events.  Sharded handle whose exchange is driven by the caller (no library
+  // communicator): the iteration is not the library's to time — *ms_total = 0 and only the kernel pass below runs.
+  *ms_total = 0.0f;
+  if (!exchangeActive(h) || (h->comm && g_ncclAllGather))
+  {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev_a, h->stream));
+    for (int i = 0; i < n; i++)
+      MPPI_TRY(iteration(h, 0, h->last_stride));
+    HIP_TRY(h, hipEventRecord(h->ev_b, h->stream));
+    HIP_TRY(h, hipEventSynchronize(h->ev_b));
+    HIP_TRY(h, hipEventElapsedTime(ms_total, h->ev_a, h->ev_b));
+  }
   if (ms_rollout)
   {
     // pass 2: the rollout kernel alone, n launches back to back between two events (events around every single launch

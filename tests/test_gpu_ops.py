@@ -1,5 +1,7 @@
 """Kernel-level operators and error behaviour through the C ABI (reference tests: tests/mppi_core/
 normexp_kernel_tests.cu, weightedreduction_kernel_tests.cu, tests/controllers/controller_kernel_testing.cu)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -162,32 +164,52 @@ def test_rccl_exchange_path_on_one_gpu(gpu):
     assert eng.getStats().real_sys.baseline == plain.getStats().real_sys.baseline
 
 
+HOST_STAGED_SCRIPT = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
+    sys.path.insert(0, p)
+from common import cartpole_cfg, make_engine
+from mppi_generic_amd.distributed import HostStagedExchange, ShardedController, hip_runtimes_in_process
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1)
+cfg = cartpole_cfg(K=2048, T=100, soft=True)
+plain = make_engine(cfg)
+plain.uploadState(cfg["x0"])
+plain.optimize(3)
+eng = make_engine(cfg, force_exchange=True)
+hx = HostStagedExchange(eng)
+eng.uploadState(cfg["x0"])
+hx.iterate(3)
+assert np.abs(eng.getOptimalControlSeq() - plain.getOptimalControlSeq()).max() <= 2e-6
+# the zero-copy variant refuses to run across two HIP runtimes (this image's torch wheel bundles its own ROCm)
+if torch.cuda.is_available() and len(hip_runtimes_in_process()) > 1:
+    side = torch.cuda.Stream()
+    eng2 = make_engine(cfg, force_exchange=True, stream=side.cuda_stream)
+    try:
+        ShardedController(eng2, side)
+        raise SystemExit("ShardedController accepted two HIP runtimes")
+    except RuntimeError:
+        pass
+dist.destroy_process_group()
+print("HOST_STAGED_OK")
+sys.stdout.flush()
+os._exit(0)
+"""
+
+
 def test_host_staged_exchange_on_one_gpu(gpu):
     """the external driver with host-staged records (mppi-generic_amd/distributed.py HostStagedExchange) over a gloo group
-    of one rank: local merge -> D2H -> all-gather -> H2D -> global merge reproduces the plain result"""
-    import torch.distributed as dist
-    from mppi_generic_amd.distributed import HostStagedExchange, ShardedController, hip_runtimes_in_process
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1)
-    cfg = cartpole_cfg(K=2048, T=100, soft=True)
-    plain = make_engine(cfg)
-    plain.uploadState(cfg["x0"])
-    plain.optimize(3)
-    eng = make_engine(cfg, force_exchange=True)
-    hx = HostStagedExchange(eng)
-    eng.uploadState(cfg["x0"])
-    hx.iterate(3)
-    assert np.abs(eng.getOptimalControlSeq() - plain.getOptimalControlSeq()).max() <= 2e-6
-    # the zero-copy variant refuses to run across two HIP runtimes (this image's torch wheel bundles its own ROCm)
-    import torch
-    if torch.cuda.is_available() and len(hip_runtimes_in_process()) > 1:
-        side = torch.cuda.Stream()
-        eng2 = make_engine(cfg, force_exchange=True, stream=side.cuda_stream)
-        with pytest.raises(RuntimeError):
-            ShardedController(eng2, side)
-    if created:
-        dist.destroy_process_group()
+    of one rank: local merge -> D2H -> all-gather -> H2D -> global merge reproduces the plain result.  Runs in its own
+    process: torch brings a second ROCm runtime into the process, and whether that coexists with an already loaded
+    system RCCL depends on the import order of everything that ran before."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "REPO = %r\n" % repo + HOST_STAGED_SCRIPT], capture_output=True, text=True,
+                       timeout=600)
+    assert "HOST_STAGED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_full_size_properties(gpu):
