@@ -31,30 +31,36 @@ public:
     bindToStream(stream);
   }
 
+  /**
+   * sum_i coeff_i (x_i - goal_i)^2 over [cart position, cart velocity, pole angle, pole angular velocity], each term
+   * evaluated as (d * d) * coeff and added left to right — the rounding sequence of the reference's expression
+   * (cartpole_quadratic_cost.cu:20-29)
+   */
+  __device__ inline float weightedSquaredError(const float* x) const
+  {
+    const float w[4] = { params_.cart_position_coeff, params_.cart_velocity_coeff, params_.pole_angle_coeff,
+                         params_.pole_angular_velocity_coeff };
+    float d = x[0] - params_.desired_terminal_state[0];
+    float total = d * d * w[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+    {
+      d = x[i] - params_.desired_terminal_state[i];
+      total = total + d * d * w[i];
+    }
+    return total;
+  }
+
   __device__ inline float computeStateCost(float* state, int timestep = 0, float* theta_c = nullptr,
                                            int* crash_status = nullptr)
   {
-    return (state[0] - params_.desired_terminal_state[0]) * (state[0] - params_.desired_terminal_state[0]) *
-               params_.cart_position_coeff +
-           (state[1] - params_.desired_terminal_state[1]) * (state[1] - params_.desired_terminal_state[1]) *
-               params_.cart_velocity_coeff +
-           (state[2] - params_.desired_terminal_state[2]) * (state[2] - params_.desired_terminal_state[2]) *
-               params_.pole_angle_coeff +
-           (state[3] - params_.desired_terminal_state[3]) * (state[3] - params_.desired_terminal_state[3]) *
-               params_.pole_angular_velocity_coeff;
+    return weightedSquaredError(state);
   }
 
+  /** cartpole_quadratic_cost.cu:31-43: the same quadratic, scaled by terminal_cost_coeff */
   __device__ inline float terminalCost(float* state, float* theta_c)
   {
-    return ((state[0] - params_.desired_terminal_state[0]) * (state[0] - params_.desired_terminal_state[0]) *
-                params_.cart_position_coeff +
-            (state[1] - params_.desired_terminal_state[1]) * (state[1] - params_.desired_terminal_state[1]) *
-                params_.cart_velocity_coeff +
-            (state[2] - params_.desired_terminal_state[2]) * (state[2] - params_.desired_terminal_state[2]) *
-                params_.pole_angle_coeff +
-            (state[3] - params_.desired_terminal_state[3]) * (state[3] - params_.desired_terminal_state[3]) *
-                params_.pole_angular_velocity_coeff) *
-           params_.terminal_cost_coeff;
+    return weightedSquaredError(state) * params_.terminal_cost_coeff;
   }
 };
 

@@ -35,23 +35,28 @@ public:
     bindToStream(stream);
   }
 
+  /**
+   * Stay on the annulus inner_path_radius2 <= |p|^2 <= outer_path_radius2 (else discount^t * crash_cost), hold the
+   * desired speed and the desired (counter-clockwise) angular momentum p x v — the three terms are added in the
+   * reference's order (double_integrator_circle_cost.cu:8-32).
+   */
   __device__ inline float computeStateCost(float* s, int timestep = 0, float* theta_c = nullptr,
                                            int* crash_status = nullptr)
   {
-    float radial_position = s[0] * s[0] + s[1] * s[1];
-    float current_velocity = mppi::det::sqrt(s[2] * s[2] + s[3] * s[3]);
-    float current_angular_momentum = s[0] * s[3] - s[1] * s[2];
+    const float px = s[0], py = s[1], vx = s[2], vy = s[3];
+    const float r2 = px * px + py * py;
+    const float speed = mppi::det::sqrt(vx * vx + vy * vy);
+    const float ang_mom = px * vy - py * vx;
+    const bool off_track = (r2 < params_.inner_path_radius2) || (r2 > params_.outer_path_radius2);
 
     float cost = 0;
-    if ((radial_position < params_.inner_path_radius2) || (radial_position > params_.outer_path_radius2))
+    if (off_track)
     {
-      const float disc =
-          this->params_.discount == 1.0f ? 1.0f : mppi::det::pow_pos(this->params_.discount, (float)timestep);
-      cost += disc * params_.crash_cost;
+      const float gamma_t = params_.discount == 1.0f ? 1.0f : mppi::det::pow_pos(params_.discount, (float)timestep);
+      cost += gamma_t * params_.crash_cost;
     }
-
-    cost += params_.velocity_cost * fabsf(current_velocity - params_.velocity_desired);
-    cost += params_.velocity_cost * fabsf(current_angular_momentum - params_.angular_momentum_desired);
+    cost += params_.velocity_cost * fabsf(speed - params_.velocity_desired);
+    cost += params_.velocity_cost * fabsf(ang_mom - params_.angular_momentum_desired);
     return cost;
   }
 

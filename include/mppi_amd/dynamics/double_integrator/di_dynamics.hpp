@@ -51,12 +51,16 @@ public:
     return "2D Double Integrator Model";
   }
 
+  /** d/dt [p_x, p_y, v_x, v_y] = [v_x, v_y, a_x, a_y] with the control as the acceleration (di_dynamics.cu:46-53) */
   __device__ inline void computeDynamics(float* state, float* control, float* state_der, float* theta = nullptr)
   {
-    state_der[0] = state[2];    // xdot;
-    state_der[1] = state[3];    // ydot;
-    state_der[2] = control[0];  // x_force;
-    state_der[3] = control[1];  // y_force
+    constexpr int HALF = 2;  // positions, then velocities
+#pragma unroll
+    for (int axis = 0; axis < HALF; axis++)
+    {
+      state_der[axis] = state[HALF + axis];
+      state_der[HALF + axis] = control[axis];
+    }
   }
 };
 

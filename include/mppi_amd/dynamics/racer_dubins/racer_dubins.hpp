@@ -101,57 +101,68 @@ public:
     return "RACER Dubins Model";
   }
 
-  /** racer_dubins.cu:138-165 */
+  /**
+   * Continuous-time model (reference: racer_dubins.cu:138-165, same arithmetic in the same order):
+   *   brake lag      d(brake)/dt = clamp((brake_cmd - brake) k_brake, -r_neg, +r_pos),  brake_cmd = max(-u0, 0)
+   *   longitudinal   dv/dt = [u0 >= 0] c_t u0 gear + c_b brake (-sgn v) - c_v v + c_0
+   *   yaw            dyaw/dt = v / L * tan(steer / steer_angle_scale)
+   *   position       d(x, y)/dt = v (cos yaw, sin yaw),  yaw wrapped to (-pi, pi] first
+   *   steering lag   d(steer)/dt = clamp((u1 k_cmd - steer) k_steer, +-max_steer_rate)
+   */
   __device__ inline void computeDynamics(float* state, float* control, float* state_der, float* theta = nullptr)
   {
-    const bool enable_brake = control[C_INDEX(THROTTLE_BRAKE)] < 0;
+    const RacerDubinsParams& p = this->params_;
+    const float v = state[S_INDEX(VEL_X)], brake = state[S_INDEX(BRAKE_STATE)], steer = state[S_INDEX(STEER_ANGLE)];
+    const float u_tb = control[C_INDEX(THROTTLE_BRAKE)], u_steer = control[C_INDEX(STEER_CMD)];
+    const bool braking = u_tb < 0;
 
-    state_der[S_INDEX(BRAKE_STATE)] =
-        fminf(fmaxf((enable_brake * -control[C_INDEX(THROTTLE_BRAKE)] - state[S_INDEX(BRAKE_STATE)]) *
-                        this->params_.brake_delay_constant,
-                    -this->params_.max_brake_rate_neg),
-              this->params_.max_brake_rate_pos);
-    // applying position throttle
-    state_der[S_INDEX(VEL_X)] =
-        (!enable_brake) * this->params_.c_t[0] * control[0] * this->params_.gear_sign +
-        this->params_.c_b[0] * state[S_INDEX(BRAKE_STATE)] * (state[S_INDEX(VEL_X)] >= 0 ? -1 : 1) -
-        this->params_.c_v[0] * state[S_INDEX(VEL_X)] + this->params_.c_0;
-    state_der[S_INDEX(YAW)] = (state[S_INDEX(VEL_X)] / this->params_.wheel_base) *
-                              mppi::det::tan(state[S_INDEX(STEER_ANGLE)] / this->params_.steer_angle_scale);
-    float sin_yaw, cos_yaw;
-    const float yaw = angle_utils::normalizeAngle(state[S_INDEX(YAW)]);
-    mppi::det::sincos(yaw, &sin_yaw, &cos_yaw);
-    state_der[S_INDEX(POS_X)] = state[S_INDEX(VEL_X)] * cos_yaw;
-    state_der[S_INDEX(POS_Y)] = state[S_INDEX(VEL_X)] * sin_yaw;
-    state_der[S_INDEX(STEER_ANGLE)] =
-        fmaxf(fminf((control[1] * this->params_.steer_command_angle_scale - state[S_INDEX(STEER_ANGLE)]) *
-                        this->params_.steering_constant,
-                    this->params_.max_steer_rate),
-              -this->params_.max_steer_rate);
+    const float brake_rate = (braking * -u_tb - brake) * p.brake_delay_constant;
+    state_der[S_INDEX(BRAKE_STATE)] = fminf(fmaxf(brake_rate, -p.max_brake_rate_neg), p.max_brake_rate_pos);
+
+    const float drive = (!braking) * p.c_t[0] * u_tb * p.gear_sign;
+    const float drag = p.c_b[0] * brake * (v >= 0 ? -1 : 1);
+    state_der[S_INDEX(VEL_X)] = drive + drag - p.c_v[0] * v + p.c_0;
+
+    state_der[S_INDEX(YAW)] = (v / p.wheel_base) * mppi::det::tan(steer / p.steer_angle_scale);
+
+    float s_yaw, c_yaw;
+    mppi::det::sincos(angle_utils::normalizeAngle(state[S_INDEX(YAW)]), &s_yaw, &c_yaw);
+    state_der[S_INDEX(POS_X)] = v * c_yaw;
+    state_der[S_INDEX(POS_Y)] = v * s_yaw;
+
+    const float steer_rate = (u_steer * p.steer_command_angle_scale - steer) * p.steering_constant;
+    state_der[S_INDEX(STEER_ANGLE)] = fmaxf(fminf(steer_rate, p.max_steer_rate), -p.max_steer_rate);
   }
 
-  /** racer_dubins.cu:73-98: Euler step of the first six states, yaw wrapped, steering angle and brake state clamped,
-   *  the steering rate state is the steering angle's derivative */
+  /**
+   * Euler step of the six integrated states (reference: racer_dubins.cu:73-98): the yaw is wrapped, the steering angle
+   * and the brake state are clamped to their physical ranges, and the seventh state simply records the steering rate
+   * that was applied.
+   */
   __device__ inline void updateState(float* state, float* next_state, float* state_der, const float dt)
   {
-    int i, p_index, step;
-    mppi::p1::getParallel1DIndex<mppi::p1::Parallel1Dir::THREAD_Y>(p_index, step);
-    for (i = p_index; i < 6; i += step)
+    int first, stride;
+    mppi::p1::getParallel1DIndex<mppi::p1::Parallel1Dir::THREAD_Y>(first, stride);
+    constexpr int INTEGRATED = 6;
+    for (int i = first; i < INTEGRATED; i += stride)
     {
-      next_state[i] = state[i] + state_der[i] * dt;
-      if (i == S_INDEX(YAW))
+      float xn = state[i] + state_der[i] * dt;
+      switch (i)
       {
-        next_state[i] = angle_utils::normalizeAngle(next_state[i]);
+        case S_INDEX(YAW):
+          xn = angle_utils::normalizeAngle(xn);
+          break;
+        case S_INDEX(STEER_ANGLE):
+          xn = fmaxf(fminf(xn, this->params_.max_steer_angle), -this->params_.max_steer_angle);
+          next_state[S_INDEX(STEER_ANGLE_RATE)] = state_der[i];
+          break;
+        case S_INDEX(BRAKE_STATE):
+          xn = fminf(fmaxf(xn, 0.0f), 1.0f);
+          break;
+        default:
+          break;
       }
-      if (i == S_INDEX(STEER_ANGLE))
-      {
-        next_state[i] = fmaxf(fminf(next_state[i], this->params_.max_steer_angle), -this->params_.max_steer_angle);
-        next_state[S_INDEX(STEER_ANGLE_RATE)] = state_der[i];
-      }
-      if (i == S_INDEX(BRAKE_STATE))
-      {
-        next_state[i] = fminf(fmaxf(next_state[i], 0.0f), 1.0f);
-      }
+      next_state[i] = xn;
     }
   }
 };
