@@ -64,7 +64,7 @@ using BSLModel = ModelT<BicycleSlipLSTM, ARStandardCost, BSLSampler,
 using RacerSampler = sampling_distributions::GaussianDistribution<RacerDubinsParams>;
 using RacerDubinsModel = ModelT<RacerDubins, QuadraticCost<RacerDubins>, RacerSampler,
                                 Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/1, void, Shapes<>,
-                                /*PIPELINE=*/true>;
+                                /*PIPELINE=*/true, /*RMPPI=*/true>;
 using RacerDubinsColoredModel =
     ModelT<RacerDubins, QuadraticCost<RacerDubins>, sampling_distributions::ColoredNoiseDistribution<RacerDubinsParams>,
            Shapes<Shape<64, 1, 1>>, /*FIN_BY=*/1, void, Shapes<>, /*PIPELINE=*/true>;

@@ -4,7 +4,7 @@ import pytest
 
 import mppi_generic_amd as m
 import pyoracle as po
-from common import cartpole_cfg_lr, di_cfg, host_noise, make_engine, make_oracle, ulp_diff
+from common import cartpole_cfg_lr, di_cfg, host_noise, make_engine, make_oracle, racer_cfg, ulp_diff
 
 U_TOL = 1e-5
 
@@ -14,6 +14,10 @@ def _rm_cfg(model="di", K=1024, T=40, num_iters=1):
         cfg = di_cfg(K=K, T=T, tube=True, num_iters=num_iters)
         cfg["control_cost_coeff"] = [0.3, 0.2]  # exercise the likelihood-ratio and feedback cost terms
         cfg["ranges"] = [[-3.0, 3.0], [-3.0, 3.0]]
+    elif model == "racer":
+        cfg = racer_cfg(K=K, T=T, num_iters=num_iters)
+        cfg["D"] = 2
+        cfg["control_cost_coeff"] = [0.2, 0.1]
     else:
         cfg = cartpole_cfg_lr(K=K, T=T)
         cfg["D"] = 2
@@ -111,6 +115,7 @@ def test_rmppi_rollout_zero_gains_identical_systems():
 # ------------------------------------------------------------------ GPU parity -----------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("model,acc_all,mode", [("di", False, "injected"), ("di", True, "injected"), ("di", False, "philox"),
+                                                ("racer", False, "injected"), ("racer", True, "philox"),
                                                 ("cartpole", False, "injected"), ("cartpole", False, "philox")])
 def test_rmppi_rollout_costs_bit_exact(gpu, model, acc_all, mode):
     cfg = _rm_cfg(model, K=1000, T=37)  # ragged last block, odd horizon
@@ -126,7 +131,7 @@ def test_rmppi_rollout_costs_bit_exact(gpu, model, acc_all, mode):
         eng.injectNoise(eps)
     else:
         eps = po.philox_normal(42, 0, K, T, C)
-    x0 = np.stack([cfg["x0"], cfg["x0"] + np.array([0.3, -0.2, 0.1, 0.05], np.float32)])
+    x0 = np.stack([cfg["x0"], cfg["x0"] + np.array([0.3, -0.2, 0.1, 0.05, 0.02, 0.01, 0.0], np.float32)[:S]])
     got = eng.rolloutCosts(x0, 2)
     means = np.tile(mean, (2, 1, 1))
     v = orc.set_gaussian_controls(means, eps, 2, 0)
