@@ -344,6 +344,23 @@ mppi_status mppi_philox_normal(uint64_t seed, uint32_t generation, int num_rollo
 /** elementwise det_math on the device (func ids as oracle_det_eval): host/device bit-parity test hook */
 mppi_status mppi_det_eval(int func, const float* x, float* y, int n, int device);
 
+/** geometry / sampling state of one 2-D map (reference: TextureParams, utils/texture_helpers/texture_helper.cuh:17-63) */
+typedef struct mppi_texture2d_params
+{
+  int address_mode[2];   /* 0 clamp (default), 1 border */
+  int filter_mode;       /* 0 linear (default), 1 point */
+  float border_color[4];
+  float origin[3];
+  float rotations[9];    /* row-major 3x3, world -> map */
+  float resolution[3];   /* metres per texel */
+} mppi_texture2d_params;
+/** TwoDTextureHelper lookups on the device (utils/texture_helpers/two_d_texture_helper.hpp; reference:
+ *  texture_helper.cu:270-289): data[height][width][channels] (channels 1 or 4), points[n][3], frame 0 = normalised texture
+ *  coordinate (queryTexture), 1 = map pose (queryTextureAtMapPose), 2 = world pose (queryTextureAtWorldPose);
+ *  out[n][channels] */
+mppi_status mppi_texture2d_query(const float* data, int width, int height, int channels, const mppi_texture2d_params* p,
+                                 const float* points, int n, int frame, float* out, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,162 @@
+/**
+ * two_d_texture_helper.hpp — generic 2-D map lookup for Dynamics / Cost plugins (elevation maps, cost maps): world pose ->
+ * map frame -> normalised texture coordinate -> bilinear (or nearest) sample with clamp or border addressing.
+ *
+ * Replaces the reference's TextureHelper / TwoDTextureHelper (include/mppi/utils/texture_helpers/texture_helper.cuh:17-204,
+ * texture_helper.cu:94-133, 270-289; two_d_texture_helper.cu:66-73 and 151-245).  The reference samples with the CUDA
+ * texture unit (tex2D, cudaFilterModeLinear: 9-bit fixed-point interpolation weights) on the device and with an fp32
+ * restatement (queryTextureCPU) on the host, and its own tests accept the difference.  gfx950 compute kernels have no
+ * reason to route a few KB of L2-resident map through the image path: this helper evaluates the reference's HOST
+ * formula in fp32 on the device too, so device, host and oracle agree bit for bit and the interpolation is exact at the
+ * cell centres.
+ *
+ * Layout: texel (row r, column c) of texture i at data[(r * width + c) * NC + ch], NC channels per texel (1 or 4 in the
+ * reference: float / float4).  Same method names and argument meaning as the reference; float3 arguments are plain
+ * float[3].  The object is a POD that travels as a kernel argument like every other plugin member.
+ */
+#ifndef MPPI_AMD_TWO_D_TEXTURE_HELPER_HPP_
+#define MPPI_AMD_TWO_D_TEXTURE_HELPER_HPP_
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MPPI_TEX_HD __host__ __device__
+#else
+#define MPPI_TEX_HD
+#endif
+
+namespace mppi
+{
+namespace texture
+{
+enum AddressMode : int
+{
+  ADDRESS_CLAMP = 0,   ///< cudaAddressModeClamp (the reference's default, texture_helper.cuh:41-43)
+  ADDRESS_BORDER = 1,  ///< cudaAddressModeBorder: border_color outside the map
+};
+enum FilterMode : int
+{
+  FILTER_LINEAR = 0,  ///< cudaFilterModeLinear (default, texture_helper.cuh:48)
+  FILTER_POINT = 1,
+};
+
+/** reference: TextureParams (texture_helper.cuh:17-63) without the CUDA array / texture object */
+struct TextureParams2D
+{
+  const float* data = nullptr;  ///< [height][width][NC], device (or host, for the host-side call) pointer
+  int width = 0, height = 0;
+  int use = 0;                  ///< checkTextureUse()
+  int address_mode[2] = { ADDRESS_CLAMP, ADDRESS_CLAMP };
+  int filter_mode = FILTER_LINEAR;
+  float border_color[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+  float origin[3] = { 0.0f, 0.0f, 0.0f };
+  float rotations[9] = { 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f };  ///< row-major 3x3
+  float resolution[3] = { 1.0f, 1.0f, 1.0f };                                     ///< metres per texel
+};
+
+template <int NUM_TEXTURES, int NC = 1>
+struct TwoDTextureHelper
+{
+  static constexpr int CHANNELS = NC;
+  TextureParams2D textures_[NUM_TEXTURES];
+
+  MPPI_TEX_HD inline bool checkTextureUse(const int index) const
+  {
+    return textures_[index].use != 0;
+  }
+
+  /** texture_helper.cu:94-104 */
+  MPPI_TEX_HD inline void worldPoseToMapPose(const int index, const float* input, float* output) const
+  {
+    const TextureParams2D& p = textures_[index];
+    const float dx = input[0] - p.origin[0], dy = input[1] - p.origin[1], dz = input[2] - p.origin[2];
+    const float* R = p.rotations;
+    output[0] = R[0] * dx + R[1] * dy + R[2] * dz;
+    output[1] = R[3] * dx + R[4] * dy + R[5] * dz;
+    output[2] = R[6] * dx + R[7] * dy + R[8] * dz;
+  }
+
+  /** texture_helper.cu:106-124: metres -> texels -> normalised coordinate (the 2-D helper has depth 0: z only scaled) */
+  MPPI_TEX_HD inline void mapPoseToTexCoord(const int index, const float* input, float* output) const
+  {
+    const TextureParams2D& p = textures_[index];
+    output[0] = (input[0] / p.resolution[0]) / (float)p.width;
+    output[1] = (input[1] / p.resolution[1]) / (float)p.height;
+    output[2] = input[2] / p.resolution[2];
+  }
+
+  /**
+   * two_d_texture_helper.cu:151-245 (queryTextureCPU): normalised coordinate -> texel units, minus half a cell (values sit
+   * at the cell centres), addressing, then bilinear interpolation between the four neighbours or the nearest texel.
+   */
+  MPPI_TEX_HD inline void queryTexture(const int index, const float* point, float* out) const
+  {
+    const TextureParams2D& p = textures_[index];
+    const int w = p.width, h = p.height;
+    float qx = point[0] * (float)w - 0.5f;
+    float qy = point[1] * (float)h - 0.5f;
+    bool border = false;
+    if (p.address_mode[0] == ADDRESS_CLAMP)
+      qx = (qx > (float)(w - 1)) ? (float)(w - 1) : ((qx <= 0.0f) ? 0.0f : qx);
+    else
+      border = border || (qx > (float)(w - 1)) || (qx <= 0.0f);
+    if (p.address_mode[1] == ADDRESS_CLAMP)
+      qy = (qy > (float)(h - 1)) ? (float)(h - 1) : ((qy <= 0.0f) ? 0.0f : qy);
+    else
+      border = border || (qy > (float)(h - 1)) || (qy <= 0.0f);
+    if (border)
+    {
+      for (int ch = 0; ch < NC; ch++)
+        out[ch] = p.border_color[ch];
+      return;
+    }
+    if (p.filter_mode == FILTER_POINT)
+    {
+      const int idx = (int)roundf(qy) * w + (int)roundf(qx);
+      for (int ch = 0; ch < NC; ch++)
+        out[ch] = p.data[(size_t)idx * NC + ch];
+      return;
+    }
+    const int x_min = min((int)floorf(qx), w - 2), x_max = x_min + 1;
+    const int y_min = min((int)floorf(qy), h - 2), y_max = y_min + 1;
+    // weights exactly as the reference writes them: (x_max - q) / (x_max - x_min) with the denominator 1
+    const float wx0 = ((float)x_max - qx) / (float)(x_max - x_min), wx1 = (qx - (float)x_min) / (float)(x_max - x_min);
+    const float wy0 = ((float)y_max - qy) / (float)(y_max - y_min), wy1 = (qy - (float)y_min) / (float)(y_max - y_min);
+    for (int ch = 0; ch < NC; ch++)
+    {
+      const float q11 = p.data[((size_t)y_min * w + x_min) * NC + ch], q12 = p.data[((size_t)y_min * w + x_max) * NC + ch];
+      const float q21 = p.data[((size_t)y_max * w + x_min) * NC + ch], q22 = p.data[((size_t)y_max * w + x_max) * NC + ch];
+      const float lo = q11 * wx0 + q12 * wx1;
+      const float hi = q21 * wx0 + q22 * wx1;
+      out[ch] = lo * wy0 + hi * wy1;
+    }
+  }
+
+  /** texture_helper.cu:274-280 */
+  MPPI_TEX_HD inline void queryTextureAtWorldPose(const int index, const float* input, float* out) const
+  {
+    float map[3], tex[3];
+    worldPoseToMapPose(index, input, map);
+    mapPoseToTexCoord(index, map, tex);
+    queryTexture(index, tex, out);
+  }
+
+  /** texture_helper.cu:283-289 */
+  MPPI_TEX_HD inline void queryTextureAtMapPose(const int index, const float* input, float* out) const
+  {
+    float tex[3];
+    mapPoseToTexCoord(index, input, tex);
+    queryTexture(index, tex, out);
+  }
+
+private:
+  MPPI_TEX_HD static inline int min(int a, int b)
+  {
+    return a < b ? a : b;
+  }
+};
+}  // namespace texture
+}  // namespace mppi
+
+#endif

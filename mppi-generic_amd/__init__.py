@@ -6,13 +6,13 @@ classes (same method names) on top of those entry points so tests read like the 
 """
 from . import buildlib as _buildlib
 from .buildlib import build
-from .capi import (MppiConfig, MppiGaussianParams, MppiStats, MppiSystemStats, SIGNATURES, library_path, load_library)
+from .capi import (MppiTexture2dParams, MppiConfig, MppiGaussianParams, MppiStats, MppiSystemStats, SIGNATURES, library_path, load_library)
 from .controllers import (MPPI_CONTROLLER_TUBE, MPPI_CONTROLLER_VANILLA, MPPI_NOISE_INJECTED, MPPI_NOISE_PHILOX_FUSED,
                           MPPIError, MPPIController, TubeMPPIController, VanillaMPPIController, ColoredMPPIController, RobustMPPIController,
                           MPPI_CONTROLLER_COLORED, CartpoleDynamicsParams,
                           CartpoleQuadraticCostParams, DoubleIntegratorParams, DoubleIntegratorCircleCostParams,
                           ARStandardCostParams, RacerDubinsParams, QuadraticCostParams28, fnn_blob_from_npz_dict, lstm_blob_from_npz_dict,
-                          det_eval, npz_read_array, philox_normal, norm_exp, compute_weights, weighted_reduction)
+                          det_eval, texture2d_query, npz_read_array, philox_normal, norm_exp, compute_weights, weighted_reduction)
 from .plant import BasePlant, SimulatedPlant, interpolateControls, interpolateFeedback, interpolateState
 
 __all__ = [

@@ -124,7 +124,24 @@ SIGNATURES = {
     "mppi_weighted_reduction": (C.c_int, [_f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
     "mppi_philox_normal": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
     "mppi_det_eval": (C.c_int, [C.c_int, _f32p, _f32p, C.c_int, C.c_int]),
+    "mppi_texture2d_query": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, _f32p, C.c_int, C.c_int, _f32p, C.c_int]),
 }
+
+class MppiTexture2dParams(C.Structure):
+    """mppi_texture2d_params"""
+    _fields_ = [("address_mode", C.c_int * 2), ("filter_mode", C.c_int), ("border_color", C.c_float * 4),
+                ("origin", C.c_float * 3), ("rotations", C.c_float * 9), ("resolution", C.c_float * 3)]
+
+    def __init__(self, origin=(0, 0, 0), rotations=(1, 0, 0, 0, 1, 0, 0, 0, 1), resolution=(1, 1, 1), address_mode=(0, 0),
+                 filter_mode=0, border_color=(0, 0, 0, 0)):
+        super().__init__()
+        self.origin[:] = origin
+        self.rotations[:] = rotations
+        self.resolution[:] = resolution
+        self.address_mode[:] = address_mode
+        self.filter_mode = filter_mode
+        self.border_color[:] = border_color
+
 
 _lib = None
 

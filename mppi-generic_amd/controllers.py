@@ -502,6 +502,23 @@ def npz_read_array(path, key):
     return out.reshape([dims[i] for i in range(nd.value)])
 
 
+def texture2d_query(data, points, frame, params=None, device=0):
+    """TwoDTextureHelper lookups on the device (mppi_texture2d_query): data[h][w] or [h][w][channels], points[n][3],
+    frame 0 texture coordinate / 1 map pose / 2 world pose"""
+    from .capi import MppiTexture2dParams
+    lib = load_library()
+    d = _f32(data)
+    if d.ndim == 2:
+        d = d[:, :, None]
+    h, w, ch = d.shape
+    pts = _f32(points).reshape(-1, 3)
+    out = np.zeros((pts.shape[0], ch), np.float32)
+    p = params if params is not None else MppiTexture2dParams()
+    _op_check(lib, lib.mppi_texture2d_query(d.reshape(-1), w, h, ch, C.byref(p), pts.reshape(-1), pts.shape[0], frame,
+                                            out.reshape(-1), device))
+    return out
+
+
 def det_eval(func, x, device=0):
     lib = load_library()
     x = _f32(x).reshape(-1)

@@ -23,6 +23,7 @@
 #include "npz_reader.hpp"
 #include "model_instance.hpp"
 #include "models.hpp"
+#include "mppi_amd/utils/texture_helpers/two_d_texture_helper.hpp"
 
 using namespace mppi;
 using namespace mppi::engine;
@@ -1879,6 +1880,68 @@ __global__ void detEvalKernel(int func, const float* x, float* y, int n)
     }
     y[i] = r;
   }
+}
+
+extern "C++" {
+template <int NC>
+__global__ void texture2dQueryKernel(mppi::texture::TwoDTextureHelper<1, NC> helper, const float* __restrict__ points, int n,
+                                     int frame, float* __restrict__ out)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+  {
+    const float pt[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
+    float r[NC];
+    if (frame == 0)
+      helper.queryTexture(0, pt, r);
+    else if (frame == 1)
+      helper.queryTextureAtMapPose(0, pt, r);
+    else
+      helper.queryTextureAtWorldPose(0, pt, r);
+    for (int ch = 0; ch < NC; ch++)
+      out[(size_t)i * NC + ch] = r[ch];
+  }
+}
+
+template <int NC>
+static mppi_status texture2dQuery(const float* data, int width, int height, const mppi_texture2d_params* p,
+                                  const float* points, int n, int frame, float* out)
+{
+  DevBuf dd, dp, dout;
+  const size_t texels = (size_t)width * height * NC;
+  OP_TRY(dd.alloc(texels));
+  OP_TRY(dp.alloc((size_t)3 * n));
+  OP_TRY(dout.alloc((size_t)n * NC));
+  OP_TRY(hipMemcpy(dd.p, data, sizeof(float) * texels, hipMemcpyHostToDevice));
+  OP_TRY(hipMemcpy(dp.p, points, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+  mppi::texture::TwoDTextureHelper<1, NC> helper;
+  mppi::texture::TextureParams2D& t = helper.textures_[0];
+  t.data = dd.p;
+  t.width = width;
+  t.height = height;
+  t.use = 1;
+  t.address_mode[0] = p->address_mode[0];
+  t.address_mode[1] = p->address_mode[1];
+  t.filter_mode = p->filter_mode;
+  memcpy(t.border_color, p->border_color, sizeof(t.border_color));
+  memcpy(t.origin, p->origin, sizeof(t.origin));
+  memcpy(t.rotations, p->rotations, sizeof(t.rotations));
+  memcpy(t.resolution, p->resolution, sizeof(t.resolution));
+  hipLaunchKernelGGL((texture2dQueryKernel<NC>), dim3((n + 255) / 256), dim3(256), 0, 0, helper, dp.p, n, frame, dout.p);
+  OP_TRY(hipGetLastError());
+  OP_TRY(hipMemcpy(out, dout.p, sizeof(float) * n * NC, hipMemcpyDeviceToHost));
+  return MPPI_OK;
+}
+}  // extern "C++"
+
+mppi_status mppi_texture2d_query(const float* data, int width, int height, int channels, const mppi_texture2d_params* p,
+                                 const float* points, int n, int frame, float* out, int device)
+{
+  if (!data || !p || !points || !out || n <= 0 || width < 2 || height < 2 || frame < 0 || frame > 2 ||
+      (channels != 1 && channels != 4))
+    return MPPI_ERR_INVALID_ARG;
+  MPPI_TRY(opDevice(device));
+  return channels == 1 ? texture2dQuery<1>(data, width, height, p, points, n, frame, out) :
+                         texture2dQuery<4>(data, width, height, p, points, n, frame, out);
 }
 
 mppi_status mppi_det_eval(int func, const float* x, float* y, int n, int device)

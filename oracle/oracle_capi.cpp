@@ -3,6 +3,7 @@
  * Built by oracle/Makefile into oracle/_build/libmppi_oracle.so.
  */
 #include "oracle_core.hpp"
+#include "oracle_texture.hpp"
 #include "oracle_models.hpp"
 #include "oracle_rng.hpp"
 #include "oracle_colored.hpp"
@@ -479,6 +480,46 @@ void oracle_det_eval(int func, const float* x, float* y, int n)
       case 12: y[i] = det::tan(x[i]); break;
       default: y[i] = 0.0f;
     }
+  }
+}
+
+/* ----- 2-D texture helper lookups (oracle_texture.hpp); params laid out as mppi_texture2d_params ----- */
+void oracle_texture2d_query(const float* data, int width, int height, int channels, const int* address_mode, int filter_mode,
+                            const float* border_color, const float* origin, const float* rotations, const float* resolution,
+                            const float* points, int n, int frame, float* out)
+{
+  oracle::Texture2D t;
+  t.values = data;
+  t.width = width;
+  t.height = height;
+  t.channels = channels;
+  t.address_mode[0] = address_mode[0];
+  t.address_mode[1] = address_mode[1];
+  t.filter_mode = filter_mode;
+  for (int i = 0; i < 4; i++)
+    t.border_color[i] = border_color[i];
+  for (int i = 0; i < 3; i++)
+  {
+    t.origin[i] = origin[i];
+    t.resolution[i] = resolution[i];
+    for (int j = 0; j < 3; j++)
+      t.rot[i][j] = rotations[3 * i + j];
+  }
+  for (int i = 0; i < n; i++)
+  {
+    float map[3], tex[3];
+    const float* pt = points + 3 * i;
+    if (frame == 2)
+    {
+      t.worldToMap(pt, map);
+      t.mapToTex(map, tex);
+    }
+    else if (frame == 1)
+      t.mapToTex(pt, tex);
+    else
+      for (int k = 0; k < 3; k++)
+        tex[k] = pt[k];
+    t.query(tex, out + (size_t)i * channels);
   }
 }
 

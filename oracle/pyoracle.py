@@ -42,6 +42,8 @@ def lib():
         L.oracle_lstm_forward.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _f32p, _f32p, _f32p, C.c_int,
                                           _f32p]
         L.oracle_state_deriv.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
+        L.oracle_texture2d_query.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _f32p, _f32p, _f32p,
+                                             _f32p, _f32p, C.c_int, C.c_int, _f32p]
         L.oracle_update_state.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, _f32p]
         L.oracle_state_cost.restype = C.c_float
         L.oracle_state_cost.argtypes = [C.c_void_p, _f32p, C.c_int, C.POINTER(C.c_int)]
@@ -377,6 +379,22 @@ def philox_spectrum(seed, generation, K, T, Cd, k_begin=0, k_end=None):
     z = np.zeros((k_end - k_begin, Cd, T + 1, 2), np.float32)
     lib().oracle_philox_spectrum(seed, generation, T, Cd, k_begin, k_end, z)
     return z
+
+
+def texture2d_query(data, points, frame, origin=(0, 0, 0), rotations=(1, 0, 0, 0, 1, 0, 0, 0, 1), resolution=(1, 1, 1),
+                    address_mode=(0, 0), filter_mode=0, border_color=(0, 0, 0, 0)):
+    """data[h][w] or [h][w][channels]; points[n][3]; frame 0 texture coordinate / 1 map pose / 2 world pose"""
+    d = _f32(data)
+    if d.ndim == 2:
+        d = d[:, :, None]
+    h, w, ch = d.shape
+    pts = _f32(points).reshape(-1, 3)
+    out = np.zeros((pts.shape[0], ch), np.float32)
+    am = (C.c_int * 2)(*address_mode)
+    lib().oracle_texture2d_query(d.reshape(-1), w, h, ch, am, filter_mode, _f32(border_color), _f32(origin),
+                                 _f32(rotations).reshape(-1), _f32(resolution), pts.reshape(-1), pts.shape[0], frame,
+                                 out.reshape(-1))
+    return out
 
 
 def det_eval(func, x):
