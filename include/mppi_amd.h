@@ -239,6 +239,9 @@ mppi_status mppi_compute_control(mppi_handle h, const float* x0, int optimizatio
 mppi_status mppi_get_control_seq(mppi_handle h, float* u_out);
 /** getTargetStateSeq (controllers/controller.cuh:438-446): x_out[T][S] */
 mppi_status mppi_get_state_seq(mppi_handle h, float* x_out);
+/** getTargetOutputSeq(): the outputs y[T][O] along the same trajectory (computeOutputTrajectoryHelper,
+ *  controllers/controller.cuh:643-662: output after initializeDynamics, then after every step) */
+mppi_status mppi_get_output_seq(mppi_handle h, float* y_out);
 /** Tube: getNominalControlSeq / getNominalStateSeq equivalents (Tube-MPPI/tube_mppi_controller.cuh:86-106) */
 mppi_status mppi_get_nominal_control_seq(mppi_handle h, float* u_out);
 mppi_status mppi_get_nominal_state_seq(mppi_handle h, float* x_out);

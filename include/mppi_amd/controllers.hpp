@@ -152,6 +152,12 @@ public:
     check(mppi_get_state_seq(h_, x.data()));
     return x;
   }
+  std::vector<float> getTargetOutputSeq() const
+  {
+    std::vector<float> y((size_t)num_timesteps_ * output_dim_);
+    check(mppi_get_output_seq(h_, y.data()));
+    return y;
+  }
   void slideControlSequence(int steps)
   {
     check(mppi_slide(h_, steps));

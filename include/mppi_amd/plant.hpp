@@ -168,13 +168,21 @@ public:
     return !todo.empty();
   }
 
-  virtual void setSolution(const s_traj& state_seq, const c_traj& control_seq, double timestamp)
+  virtual void setSolution(const s_traj& state_seq, const c_traj& control_seq, const std::vector<float>& output_seq,
+                           double timestamp)
   {
     last_used_state_update_time_ = timestamp;
     std::lock_guard<std::mutex> lck(access_guard_);
     state_traj_ = state_seq;
     control_traj_ = control_seq;
+    output_traj_ = output_seq;
     num_iter_++;
+  }
+  /** outputs y[T][O] along the latched solution (getTargetOutputSeq) */
+  std::vector<float> getOutputTraj()
+  {
+    std::lock_guard<std::mutex> lck(access_guard_);
+    return output_traj_;
   }
 
   virtual void updateState(const s_array& state, double time)
@@ -254,11 +262,12 @@ public:
     const mppi_stats fe_stats = controller_->getFreeEnergyStatistics();
     const c_traj control_traj = controller_->getControlSeq();
     const s_traj state_traj = controller_->getTargetStateSeq();
+    const std::vector<float> output_traj = controller_->getTargetOutputSeq();
     optimization_duration_ = ms_since(opt_start);
     const clock::time_point fb_start = clock::now();
     computeFeedback(state, state_traj, control_traj);
     feedback_duration_ = ms_since(fb_start);
-    setSolution(state_traj, control_traj, state_time);
+    setSolution(state_traj, control_traj, output_traj, state_time);
     status_ = status;
     pubFreeEnergyStatistics(fe_stats);
     const double prev = (num_iter_ - 1.0) / num_iter_;
@@ -304,6 +313,7 @@ protected:
   c_array init_u_, u_;
   s_traj state_traj_;
   c_traj control_traj_;
+  std::vector<float> output_traj_;
   std::vector<float> feedback_gains_;
   std::vector<std::function<void(CONTROLLER_T&)>> pending_updates_;
   double state_time_ = -1;

@@ -99,6 +99,7 @@ SIGNATURES = {
     "mppi_compute_control": (C.c_int, [H, _f32p, C.c_int]),
     "mppi_get_control_seq": (C.c_int, [H, _f32p]),
     "mppi_get_state_seq": (C.c_int, [H, _f32p]),
+    "mppi_get_output_seq": (C.c_int, [H, _f32p]),
     "mppi_get_nominal_control_seq": (C.c_int, [H, _f32p]),
     "mppi_get_nominal_state_seq": (C.c_int, [H, _f32p]),
     "mppi_slide": (C.c_int, [H, C.c_int]),

@@ -331,6 +331,11 @@ class MPPIController:
         self._check(self._lib.mppi_get_state_seq(self._h, x))
         return x
 
+    def getTargetOutputSeq(self):
+        y = np.empty((self.num_timesteps, self.OUTPUT_DIM), np.float32)
+        self._check(self._lib.mppi_get_output_seq(self._h, y))
+        return y
+
     def slideControlSequence(self, steps):
         self._check(self._lib.mppi_slide(self._h, steps))
 

@@ -61,6 +61,7 @@ struct mppi_handle_s
   float* ctrl_in_d = nullptr;      // [D][T][C]
   float* ctrl_out_d = nullptr;     // [D][T][C]
   float* state_out_d = nullptr;    // [D][T][S]
+  float* output_out_d = nullptr;   // [D][T][O]
   float* step_x_d = nullptr;       // [S]
   float* step_u_d = nullptr;       // [C]
   int n_eps_iters = 0;
@@ -183,7 +184,7 @@ static void freeAll(mppi_handle h)
 {
   float** bufs[] = { &h->x0_d,     &h->mean_d,    &h->costs_d,   &h->partials_d,  &h->send_d,     &h->recv_d,
                      &h->stats_d,  &h->eps_d,     &h->samples_d, &h->history_d,   &h->ctrl_in_d,  &h->ctrl_out_d,
-                     &h->state_out_d, &h->step_x_d, &h->step_u_d, &h->gather_tmp_d };
+                     &h->state_out_d, &h->step_x_d, &h->step_u_d, &h->gather_tmp_d, &h->output_out_d };
   for (float** b : bufs)
   {
     if (*b)
@@ -342,6 +343,7 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   ALLOC_OR_FAIL(h->ctrl_in_d, (size_t)D * T * C);
   ALLOC_OR_FAIL(h->ctrl_out_d, (size_t)D * T * C);
   ALLOC_OR_FAIL(h->state_out_d, (size_t)D * T * S);
+  ALLOC_OR_FAIL(h->output_out_d, (size_t)D * T * h->O);
   ALLOC_OR_FAIL(h->step_x_d, (size_t)S);
   ALLOC_OR_FAIL(h->step_u_d, (size_t)C);
   if (cfg->save_samples)
@@ -847,6 +849,7 @@ static mppi_status finalize(mppi_handle h, const float* ctrl_in_d, int smooth_ma
   a.x0_d = h->x0_d;
   a.control_out_d = h->ctrl_out_d;
   a.state_out_d = h->state_out_d;
+  a.output_out_d = h->output_out_d;
   a.dt = h->cfg.dt;
   a.num_timesteps = T;
   a.smooth_mask = smooth_mask;
@@ -1210,6 +1213,20 @@ mppi_status mppi_get_state_seq(mppi_handle h, float* x)
   std::copy(src.begin(), src.end(), x);
   return MPPI_OK;
 }
+mppi_status mppi_get_output_seq(mppi_handle h, float* y)
+{
+  CHECK_HANDLE(h);
+  if (!y)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_get_output_seq: null");
+  // system 0 of the last finalize pass is the trajectory mppi_get_state_seq reports (real system for Vanilla / Tube, the
+  // nominal one for Robust MPPI)
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(y, h->output_out_d, sizeof(float) * h->cfg.num_timesteps * h->O, hipMemcpyDeviceToHost,
+                            h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
 mppi_status mppi_get_nominal_control_seq(mppi_handle h, float* u)
 {
   CHECK_HANDLE(h);

@@ -30,6 +30,8 @@ struct FinalizeArgs
   const float* x0_d;          ///< [D][S]
   float* control_out_d;       ///< [D][T][C]
   float* state_out_d;         ///< [D][T][S]
+  float* output_out_d;        ///< [D][T][O] or nullptr: the outputs along the same trajectory
+                              ///< (computeOutputTrajectoryHelper, controllers/controller.cuh:643-662)
   float dt;
   int num_timesteps;
   int smooth_mask;            ///< bit z set: smooth system z
@@ -123,6 +125,9 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
   // computeStateTrajectoryHelper (controller.cuh:643-663)
   dynamics->initializeDynamics(x, u, y, theta_s, 0.0f, a.dt);
   __syncthreads();
+  if (a.output_out_d)
+    for (int i = ty; i < O; i += BY)
+      a.output_out_d[((size_t)z * T + 0) * O + i] = y[i];
   for (int t = 0; t < T - 1; t++)
   {
     for (int i = ty; i < C; i += BY)
@@ -134,6 +139,9 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
     __syncthreads();
     for (int i = ty; i < S; i += BY)
       a.state_out_d[((size_t)z * T + t + 1) * S + i] = xn[i];
+    if (a.output_out_d)
+      for (int i = ty; i < O; i += BY)
+        a.output_out_d[((size_t)z * T + t + 1) * O + i] = y[i];
     float* tmp = x;
     x = xn;
     xn = tmp;

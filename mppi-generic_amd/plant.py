@@ -66,6 +66,7 @@ class BasePlant:
         self.u_ = np.zeros(C, np.float32)
         self.state_time_ = -1.0
         self.last_used_state_update_time_ = -1.0
+        self.output_traj_ = None  # [T][O], latched with the solution when the controller offers getTargetOutputSeq()
         self.state_traj_ = np.zeros((controller.num_timesteps, S), np.float32)
         self.control_traj_ = np.zeros((controller.num_timesteps, C), np.float32)
         self.feedback_gains_ = None  # [T][S][C] or None (feedback disabled)
@@ -190,11 +191,12 @@ class BasePlant:
         return bool(pending)
 
     # ---- the solution latch and the control publisher ----
-    def setSolution(self, state_seq, control_seq, timestamp):
+    def setSolution(self, state_seq, control_seq, timestamp, output_seq=None):
         self.last_used_state_update_time_ = timestamp
         with self.access_guard_:
             self.state_traj_ = state_seq
             self.control_traj_ = control_seq
+            self.output_traj_ = output_seq
             self.num_iter_ += 1
 
     def getCurrentControl(self, state, rel_time, target_nominal_state):
@@ -268,7 +270,8 @@ class BasePlant:
         fb_start = _time.monotonic()
         self.computeFeedback(state, state_traj, control_traj)
         self.feedback_duration_ = (_time.monotonic() - fb_start) * 1e3
-        self.setSolution(state_traj, control_traj, state_time)
+        output_traj = ctl.getTargetOutputSeq() if hasattr(ctl, "getTargetOutputSeq") else None
+        self.setSolution(state_traj, control_traj, state_time, output_traj)
         self.status_ = status
         self.pubFreeEnergyStatistics(stats)
         n = float(self.num_iter_)

@@ -232,6 +232,11 @@ void oracle_state_trajectory(void* h, const float* x0, const float* u, float* re
   auto* c = (Controller*)h;
   computeStateTrajectory(*c->dyn, c->dt, x0, u, c->T, result);
 }
+void oracle_output_trajectory(void* h, const float* x0, const float* u, float* state_result, float* output_result)
+{
+  auto* c = (Controller*)h;
+  computeStateTrajectory(*c->dyn, c->dt, x0, u, c->T, state_result, output_result);
+}
 /** one model step on the host (used for closed-loop tests: examples/cartpole_example.cu:63-85) */
 void oracle_model_step(void* h, float* x, float* u, float dt)
 {

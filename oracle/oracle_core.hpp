@@ -461,8 +461,11 @@ inline void saveControlHistory(int steps, const float* u, float* history, int C)
   }
 }
 
-/** reference: controllers/controller.cuh:643-663.  result: [T][S]; u: [T][C] (not modified) */
-inline void computeStateTrajectory(Dynamics& dyn, float dt, const float* x0, const float* u, int T, float* result)
+/** reference: controllers/controller.cuh:643-663 (computeStateTrajectoryHelper) and :643-662 (computeOutputTrajectoryHelper:
+ *  the same loop, also keeping the output after initializeDynamics and after every step).  result: [T][S]; u: [T][C] (not
+ *  modified); output_result: [T][O] or nullptr */
+inline void computeStateTrajectory(Dynamics& dyn, float dt, const float* x0, const float* u, int T, float* result,
+                                   float* output_result = nullptr)
 {
   const int S = dyn.S, C = dyn.C, O = dyn.O;
   std::vector<float> x(S), xn(S), xdot(S, 0.0f), ui(C), y(O, 0.0f), theta(std::max(1, dyn.scratchFloats()), 0.0f);
@@ -471,6 +474,9 @@ inline void computeStateTrajectory(Dynamics& dyn, float dt, const float* x0, con
   for (int c = 0; c < C; c++)
     ui[c] = u[c];
   dyn.initializeDynamics(result, ui.data(), y.data(), theta.data(), 0.0f, dt);
+  if (output_result)
+    for (int i = 0; i < O; i++)
+      output_result[i] = y[i];
   for (int t = 0; t < T - 1; t++)
   {
     for (int i = 0; i < S; i++)
@@ -481,6 +487,9 @@ inline void computeStateTrajectory(Dynamics& dyn, float dt, const float* x0, con
     dyn.step(x.data(), xn.data(), xdot.data(), ui.data(), y.data(), theta.data(), t, dt);
     for (int i = 0; i < S; i++)
       result[(size_t)(t + 1) * S + i] = xn[i];
+    if (output_result)
+      for (int i = 0; i < O; i++)
+        output_result[(size_t)(t + 1) * O + i] = y[i];
   }
 }
 

@@ -66,6 +66,7 @@ def lib():
         L.oracle_slide.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p]
         L.oracle_save_history.argtypes = [C.c_int, _f32p, _f32p, C.c_int]
         L.oracle_state_trajectory.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
+        L.oracle_output_trajectory.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p]
         L.oracle_model_step.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float]
         L.oracle_set_nominal_control.argtypes = [C.c_void_p, _f32p]
         L.oracle_iterate.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _f32p]
@@ -195,6 +196,13 @@ class Oracle:
         out = np.empty((self.T, self.S), np.float32)
         self.L.oracle_state_trajectory(self.h, _f32(x0).reshape(-1), _f32(u).reshape(-1), out)
         return out
+
+    def output_trajectory(self, x0, u):
+        """computeOutputTrajectoryHelper: (state [T][S], output [T][O])"""
+        xs = np.empty((self.T, self.S), np.float32)
+        ys = np.empty((self.T, self.O), np.float32)
+        self.L.oracle_output_trajectory(self.h, _f32(x0).reshape(-1), _f32(u).reshape(-1), xs, ys)
+        return xs, ys
 
     def model_step(self, x, u, dt=None):
         x = _f32(x).reshape(-1).copy()

@@ -110,3 +110,22 @@ def test_racer_dubins_model_step_and_closed_loop(gpu):
         x, _ = eng.modelStep(x, u)
         eng.slideControlSequence(1)
     assert 1.45 < x[0] < 1.7 and np.isfinite(x).all()  # at the goal speed of the quadratic cost
+
+
+@pytest.mark.gpu
+def test_target_output_sequence_matches_oracle(gpu):
+    """getTargetOutputSeq (computeOutputTrajectoryHelper, controllers/controller.cuh:643-662): outputs after
+    initializeDynamics and after every step of the optimal trajectory; for the plain RacerDubins outputs 0..6 are the
+    states and 7..27 stay zero"""
+    cfg = racer_cfg(K=512, T=40)
+    eps = host_noise(1, cfg["K"], cfg["T"], 2, seed=9)
+    o = make_oracle(cfg)
+    o.vanilla_compute_control(cfg["x0"], 1, eps)
+    eng = make_engine(cfg)
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    y = eng.getTargetOutputSeq()
+    xs, ys = o.output_trajectory(cfg["x0"], o.control())
+    assert y.shape == (cfg["T"], 28)
+    assert np.abs(y - ys).max() <= 1e-4
+    assert np.abs(y[:, :7] - eng.getTargetStateSeq()).max() == 0 and np.abs(y[:, 7:]).max() == 0
