@@ -62,6 +62,14 @@ struct mppi_handle_s
   float* ctrl_out_d = nullptr;     // [D][T][C]
   float* state_out_d = nullptr;    // [D][T][S]
   float* output_out_d = nullptr;   // [D][T][O]
+  /* x0_d | mean_d | history_d are slices of ONE device block, ctrl_out_d | state_out_d | output_out_d | stats_d of
+   * another, each mirrored in pinned host memory: mppi_compute_control hands its inputs over with one copy and takes its
+   * results back with one copy and one synchronisation (single-system controllers; the others copy slice by slice) */
+  float* in_block_d = nullptr;
+  float* out_block_d = nullptr;
+  float* in_pin_h = nullptr;
+  float* out_pin_h = nullptr;
+  size_t in_floats = 0, out_floats = 0;
   float* step_x_d = nullptr;       // [S]
   float* step_u_d = nullptr;       // [C]
   int n_eps_iters = 0;
@@ -182,9 +190,15 @@ const char* mppi_last_error(mppi_handle h)
 /* ---------------------------------------------------------------- lifecycle -------------------------------------- */
 static void freeAll(mppi_handle h)
 {
-  float** bufs[] = { &h->x0_d,     &h->mean_d,    &h->costs_d,   &h->partials_d,  &h->send_d,     &h->recv_d,
-                     &h->stats_d,  &h->eps_d,     &h->samples_d, &h->history_d,   &h->ctrl_in_d,  &h->ctrl_out_d,
-                     &h->state_out_d, &h->step_x_d, &h->step_u_d, &h->gather_tmp_d, &h->output_out_d };
+  // x0_d, mean_d, history_d and ctrl_out_d, state_out_d, output_out_d, stats_d are slices of in_block_d / out_block_d
+  h->x0_d = h->mean_d = h->history_d = h->ctrl_out_d = h->state_out_d = h->output_out_d = h->stats_d = nullptr;
+  if (h->in_pin_h)
+    (void)hipHostFree(h->in_pin_h);
+  if (h->out_pin_h)
+    (void)hipHostFree(h->out_pin_h);
+  h->in_pin_h = h->out_pin_h = nullptr;
+  float** bufs[] = { &h->in_block_d, &h->out_block_d, &h->costs_d,   &h->partials_d,  &h->send_d,     &h->recv_d,
+                     &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->step_u_d, &h->gather_tmp_d };
   for (float** b : bufs)
   {
     if (*b)
@@ -331,19 +345,37 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
       return fail(nullptr, MPPI_ERR_HIP, std::string("hipMalloc " #ptr ": ") + hipGetErrorString(e__)); \
     }                                                                                               \
   } while (0)
-  ALLOC_OR_FAIL(h->x0_d, (size_t)D * S);
-  ALLOC_OR_FAIL(h->mean_d, (size_t)D * T * C);
+  {
+    auto pad4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
+    const size_t o_mean = pad4((size_t)D * S), o_hist = o_mean + pad4((size_t)D * T * C);
+    h->in_floats = o_hist + pad4((size_t)4 * C);  // history: [2 systems][2][C] (RMPPI smooths both with their own)
+    ALLOC_OR_FAIL(h->in_block_d, h->in_floats);
+    h->x0_d = h->in_block_d;
+    h->mean_d = h->in_block_d + o_mean;
+    h->history_d = h->in_block_d + o_hist;
+    const size_t o_state = pad4((size_t)D * T * C), o_out = o_state + pad4((size_t)D * T * S),
+                 o_stats = o_out + pad4((size_t)D * T * h->O);
+    h->out_floats = o_stats + pad4((size_t)D * kernels::STATS_STRIDE);
+    ALLOC_OR_FAIL(h->out_block_d, h->out_floats);
+    h->ctrl_out_d = h->out_block_d;
+    h->state_out_d = h->out_block_d + o_state;
+    h->output_out_d = h->out_block_d + o_out;
+    h->stats_d = h->out_block_d + o_stats;
+    if (hipHostMalloc((void**)&h->in_pin_h, h->in_floats * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->out_pin_h, h->out_floats * sizeof(float), hipHostMallocDefault) != hipSuccess)
+    {
+      freeAll(hp);
+      return fail(nullptr, MPPI_ERR_HIP, "hipHostMalloc of the pinned hand-over buffers failed");
+    }
+    memset(h->in_pin_h, 0, h->in_floats * sizeof(float));
+    memset(h->out_pin_h, 0, h->out_floats * sizeof(float));
+  }
   ALLOC_OR_FAIL(h->costs_d, (size_t)D * K);
   ALLOC_OR_FAIL(h->partials_d, (size_t)D * h->num_blocks * h->PS);
   ALLOC_OR_FAIL(h->send_d, (size_t)D * h->PS);
   ALLOC_OR_FAIL(h->recv_d, (size_t)world * D * h->PS);
   ALLOC_OR_FAIL(h->gather_tmp_d, (size_t)world * D * h->PS);
-  ALLOC_OR_FAIL(h->stats_d, (size_t)D * kernels::STATS_STRIDE);
-  ALLOC_OR_FAIL(h->history_d, (size_t)4 * C);  // [2 systems][2][C] (RMPPI smooths both with their own history)
   ALLOC_OR_FAIL(h->ctrl_in_d, (size_t)D * T * C);
-  ALLOC_OR_FAIL(h->ctrl_out_d, (size_t)D * T * C);
-  ALLOC_OR_FAIL(h->state_out_d, (size_t)D * T * S);
-  ALLOC_OR_FAIL(h->output_out_d, (size_t)D * T * h->O);
   ALLOC_OR_FAIL(h->step_x_d, (size_t)S);
   ALLOC_OR_FAIL(h->step_u_d, (size_t)C);
   if (cfg->save_samples)
@@ -795,24 +827,14 @@ static mppi_status iteration(mppi_handle h, int it, int stride)
   return MPPI_OK;
 }
 
+static void parseStats(mppi_handle h, const float* st);
 static mppi_status fetchStats(mppi_handle h)
 {
   float st[2 * kernels::STATS_STRIDE] = { 0 };
   HIP_TRY(h, hipMemcpyAsync(st, h->stats_d, sizeof(float) * h->D * kernels::STATS_STRIDE, hipMemcpyDeviceToHost,
                             h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  mppi_system_stats* sys[2] = { &h->stats_h.real_sys, &h->stats_h.nominal_sys };
-  if (h->cfg.controller == MPPI_CONTROLLER_ROBUST)  // system 0 is the NOMINAL one there (robust_mppi_controller.cu:637-640)
-    std::swap(sys[0], sys[1]);
-  for (int z = 0; z < h->D; z++)
-  {
-    const float* s = st + z * kernels::STATS_STRIDE;
-    sys[z]->baseline = s[0];
-    sys[z]->normalizer = s[1];
-    sys[z]->free_energy_mean = s[2];
-    sys[z]->free_energy_variance = s[3];
-    sys[z]->free_energy_modified_variance = s[4];
-  }
+  parseStats(h, st);
   return MPPI_OK;
 }
 
@@ -912,13 +934,6 @@ mppi_status mppi_inject_noise(mppi_handle h, const float* eps, int n_iters)
   return MPPI_OK;
 }
 
-static mppi_status uploadVanilla(mppi_handle h, const float* x0)
-{
-  HIP_TRY(h, hipMemcpyAsync(h->x0_d, x0, sizeof(float) * h->S, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice, h->stream));
-  return MPPI_OK;
-}
-
 static mppi_status uploadTube(mppi_handle h, const float* x0_actual)
 {
   HIP_TRY(h, hipMemcpyAsync(h->x0_d, x0_actual, sizeof(float) * h->S, hipMemcpyHostToDevice, h->stream));
@@ -930,15 +945,60 @@ static mppi_status uploadTube(mppi_handle h, const float* x0_actual)
   return MPPI_OK;
 }
 
+/** stats of system z from the floats the merge kernel wrote */
+static void parseStats(mppi_handle h, const float* st)
+{
+  mppi_system_stats* sys[2] = { &h->stats_h.real_sys, &h->stats_h.nominal_sys };
+  if (h->cfg.controller == MPPI_CONTROLLER_ROBUST)  // system 0 is the NOMINAL one there (robust_mppi_controller.cu:637-640)
+    std::swap(sys[0], sys[1]);
+  for (int z = 0; z < h->D; z++)
+  {
+    const float* s = st + z * kernels::STATS_STRIDE;
+    sys[z]->baseline = s[0];
+    sys[z]->normalizer = s[1];
+    sys[z]->free_energy_mean = s[2];
+    sys[z]->free_energy_variance = s[3];
+    sys[z]->free_energy_modified_variance = s[4];
+  }
+}
+
 static mppi_status computeControlVanilla(mppi_handle h, const float* x0, int stride)
 {
-  MPPI_TRY(uploadVanilla(h, x0));
+  // one hand-over in (x0, nominal control, control history), one back (control, state and output trajectories, stats):
+  // two copies through pinned memory and a single synchronisation per call
+  const int T = h->cfg.num_timesteps;
+  float* in = h->in_pin_h;
+  std::copy(x0, x0 + h->S, in + (h->x0_d - h->in_block_d));
+  std::copy(h->control_h.begin(), h->control_h.end(), in + (h->mean_d - h->in_block_d));
+  std::copy(h->history_h.begin(), h->history_h.end(), in + (h->history_d - h->in_block_d));
+  HIP_TRY(h, hipMemcpyAsync(h->in_block_d, in, sizeof(float) * h->in_floats, hipMemcpyHostToDevice, h->stream));
   for (int it = 0; it < h->cfg.num_iters; it++)
     MPPI_TRY(iteration(h, it, stride));
-  std::vector<float>* co[2] = { &h->control_h, nullptr };
-  std::vector<float>* so[2] = { &h->state_h, nullptr };
-  MPPI_TRY(finalize(h, h->mean_d, /*smooth*/ 1, /*constrain*/ 1, co, so));
-  MPPI_TRY(fetchStats(h));
+  kernels::FinalizeArgs a{};
+  a.control_in_d = h->mean_d;
+  a.history_d = h->history_d;
+  a.history_stride = 0;
+  a.x0_d = h->x0_d;
+  a.control_out_d = h->ctrl_out_d;
+  a.state_out_d = h->state_out_d;
+  a.output_out_d = h->output_out_d;
+  a.dt = h->cfg.dt;
+  a.num_timesteps = T;
+  a.smooth_mask = 1;
+  a.constrain_mask = 1;
+  // ColoredMPPI clamps only control channel 1 after smoothing (colored_mppi_controller.cu:232-237)
+  a.constrain_mode = h->cfg.controller == MPPI_CONTROLLER_COLORED ? 1 : 0;
+  std::string err;
+  const mppi_status st = h->model->launchFinalize(1, a, h->stream, err);
+  if (st != MPPI_OK)
+    return fail(h, st, err);
+  HIP_TRY(h, hipMemcpyAsync(h->out_pin_h, h->out_block_d, sizeof(float) * h->out_floats, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const float* out = h->out_pin_h;
+  std::copy(out, out + (size_t)T * h->C, h->control_h.begin());
+  std::copy(out + (h->state_out_d - h->out_block_d), out + (h->state_out_d - h->out_block_d) + (size_t)T * h->S,
+            h->state_h.begin());
+  parseStats(h, out + (h->stats_d - h->out_block_d));
   // base_plant.hpp:515-528 checks both the control and the state trajectory
   if (!allFinite(h->control_h) || !allFinite(h->state_h))
     return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control or state sequence");

@@ -108,6 +108,58 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
     for (int e = ty; e < T * C; e += BY)
       ctrl[e] = uin[e];
   }
+  if constexpr (BY == 1)
+  {
+    // One lane per rollout: the whole trajectory is one thread's serial chain, so the state lives in registers and there
+    // is nothing to synchronise with (the LDS-resident variant below spent ~0.55 us per step on LDS round trips and
+    // barriers; this one ~0.2 us — the kernel is most of what mppi_compute_control costs beyond the iteration itself).
+    float xr[S], xnr[S], xdr[S], ur[C], yr[O];
+#pragma unroll
+    for (int i = 0; i < S; i++)
+    {
+      xr[i] = a.x0_d[(size_t)z * S + i];
+      xdr[i] = 0.0f;
+      xnr[i] = 0.0f;
+      zero_state[i] = 0.0f;
+      a.state_out_d[((size_t)z * T + 0) * S + i] = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < O; i++)
+      yr[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < C; i++)
+      ur[i] = ctrl[i];
+    // computeStateTrajectoryHelper / computeOutputTrajectoryHelper (controller.cuh:643-663)
+    dynamics->initializeDynamics(xr, ur, yr, theta_s, 0.0f, a.dt);
+    if (a.output_out_d)
+    {
+#pragma unroll
+      for (int i = 0; i < O; i++)
+        a.output_out_d[((size_t)z * T + 0) * O + i] = yr[i];
+    }
+    for (int t = 0; t < T - 1; t++)
+    {
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        ur[i] = ctrl[t * C + i];
+      dynamics->enforceConstraints(xr, ur);
+      dynamics->step(xr, xnr, xdr, ur, yr, theta_s, t, a.dt);
+#pragma unroll
+      for (int i = 0; i < S; i++)
+      {
+        a.state_out_d[((size_t)z * T + t + 1) * S + i] = xnr[i];
+        xr[i] = xnr[i];
+      }
+      if (a.output_out_d)
+      {
+#pragma unroll
+        for (int i = 0; i < O; i++)
+          a.output_out_d[((size_t)z * T + t + 1) * O + i] = yr[i];
+      }
+    }
+  }
+  else
+  {
   for (int i = ty; i < S; i += BY)
   {
     x[i] = a.x0_d[(size_t)z * S + i];
@@ -145,6 +197,7 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
     float* tmp = x;
     x = xn;
     xn = tmp;
+  }
   }
   // enforceConstraints on every column of the control (mppi_controller.cu:227-231)
   if ((a.constrain_mask >> z) & 1)

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Wall-clock latency of one mppi_compute_control call (host hand-over, rollout + merge, finalize kernel, results back):
+the PCIe-inclusive figure a control loop sees, as opposed to the device-resident iteration bench.py reports."""
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+from common import cartpole_cfg, make_engine  # noqa: E402
+
+for K in (2048, 16384):
+    cfg = cartpole_cfg(K=K, T=100)
+    eng = make_engine(cfg)
+    x = cfg["x0"].copy()
+    for _ in range(50):
+        eng.computeControl(x, 1)
+    n = 1000
+    t0 = time.perf_counter()
+    for _ in range(n):
+        eng.computeControl(x, 1)
+    t1 = time.perf_counter()
+    for _ in range(n):
+        eng.computeControl(x, 1)
+        eng.getControlSeq()
+        eng.slideControlSequence(1)
+    t2 = time.perf_counter()
+    print("K=%d: computeControl %.1f us; + getControlSeq + slide %.1f us" % (K, (t1 - t0) / n * 1e6, (t2 - t1) / n * 1e6))
