@@ -70,6 +70,7 @@ struct mppi_handle_s
   float* in_pin_h = nullptr;
   float* out_pin_h = nullptr;
   size_t in_floats = 0, out_floats = 0;
+  bool out_pin_fresh = false;      // out_pin_h holds the results (incl. stats) of the last finalize pass; reset by launches
   float* step_x_d = nullptr;       // [S]
   float* step_u_d = nullptr;       // [C]
   int n_eps_iters = 0;
@@ -769,6 +770,7 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   if (st != MPPI_OK)
     return fail(h, st, err);
   h->generation++;
+  h->out_pin_fresh = false;
   return MPPI_OK;
 }
 
@@ -830,6 +832,11 @@ static mppi_status iteration(mppi_handle h, int it, int stride)
 static void parseStats(mppi_handle h, const float* st);
 static mppi_status fetchStats(mppi_handle h)
 {
+  if (h->out_pin_fresh)
+  {  // the last finalize pass brought the statistics along
+    parseStats(h, h->out_pin_h + (h->stats_d - h->out_block_d));
+    return MPPI_OK;
+  }
   float st[2 * kernels::STATS_STRIDE] = { 0 };
   HIP_TRY(h, hipMemcpyAsync(st, h->stats_d, sizeof(float) * h->D * kernels::STATS_STRIDE, hipMemcpyDeviceToHost,
                             h->stream));
@@ -852,20 +859,20 @@ static mppi_status finalize(mppi_handle h, const float* ctrl_in_d, int smooth_ma
 {
   const int T = h->cfg.num_timesteps;
   kernels::FinalizeArgs a{};
+  // the control history goes up through its slice of the pinned input block (one small asynchronous copy)
+  float* hist_pin = h->in_pin_h + (h->history_d - h->in_block_d);
   if (h->cfg.controller == MPPI_CONTROLLER_ROBUST)
   {  // system 0 (nominal) smooths with nominal_control_history_, system 1 (real) with control_history_
-    HIP_TRY(h, hipMemcpyAsync(h->history_d, h->nominal_history_h.data(), sizeof(float) * 2 * h->C, hipMemcpyHostToDevice,
-                              h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->history_d + 2 * h->C, h->history_h.data(), sizeof(float) * 2 * h->C,
-                              hipMemcpyHostToDevice, h->stream));
+    std::copy(h->nominal_history_h.begin(), h->nominal_history_h.end(), hist_pin);
+    std::copy(h->history_h.begin(), h->history_h.end(), hist_pin + 2 * h->C);
     a.history_stride = 2 * h->C;
   }
   else
   {
-    HIP_TRY(h, hipMemcpyAsync(h->history_d, h->history_h.data(), sizeof(float) * 2 * h->C, hipMemcpyHostToDevice,
-                              h->stream));
+    std::copy(h->history_h.begin(), h->history_h.end(), hist_pin);
     a.history_stride = 0;
   }
+  HIP_TRY(h, hipMemcpyAsync(h->history_d, hist_pin, sizeof(float) * 4 * h->C, hipMemcpyHostToDevice, h->stream));
   a.control_in_d = ctrl_in_d;
   a.history_d = h->history_d;
   a.x0_d = h->x0_d;
@@ -883,16 +890,19 @@ static mppi_status finalize(mppi_handle h, const float* ctrl_in_d, int smooth_ma
   mppi_status st = h->model->launchFinalize(nsys, a, h->stream, err);
   if (st != MPPI_OK)
     return fail(h, st, err);
+  // controls, states, outputs and the merge statistics come back with ONE copy into pinned memory and one synchronisation
+  HIP_TRY(h, hipMemcpyAsync(h->out_pin_h, h->out_block_d, sizeof(float) * h->out_floats, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   for (int z = 0; z < nsys; z++)
   {
+    const float* c = h->out_pin_h + (h->ctrl_out_d - h->out_block_d) + (size_t)z * T * h->C;
+    const float* x = h->out_pin_h + (h->state_out_d - h->out_block_d) + (size_t)z * T * h->S;
     if (ctrl_out[z])
-      HIP_TRY(h, hipMemcpyAsync(ctrl_out[z]->data(), h->ctrl_out_d + (size_t)z * T * h->C, sizeof(float) * T * h->C,
-                                hipMemcpyDeviceToHost, h->stream));
+      std::copy(c, c + (size_t)T * h->C, ctrl_out[z]->begin());
     if (state_out[z])
-      HIP_TRY(h, hipMemcpyAsync(state_out[z]->data(), h->state_out_d + (size_t)z * T * h->S, sizeof(float) * T * h->S,
-                                hipMemcpyDeviceToHost, h->stream));
+      std::copy(x, x + (size_t)T * h->S, state_out[z]->begin());
   }
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->out_pin_fresh = true;
   return MPPI_OK;
 }
 
@@ -936,12 +946,15 @@ mppi_status mppi_inject_noise(mppi_handle h, const float* eps, int n_iters)
 
 static mppi_status uploadTube(mppi_handle h, const float* x0_actual)
 {
-  HIP_TRY(h, hipMemcpyAsync(h->x0_d, x0_actual, sizeof(float) * h->S, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->x0_d + h->S, h->nominal_state_h.data(), sizeof(float) * h->S, hipMemcpyHostToDevice,
-                            h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->mean_d + h->TC, h->nominal_control_h.data(), sizeof(float) * h->TC,
-                            hipMemcpyHostToDevice, h->stream));
+  // both initial states and both nominal controls through the pinned input block: one copy
+  float* in = h->in_pin_h;
+  std::copy(x0_actual, x0_actual + h->S, in);
+  std::copy(h->nominal_state_h.begin(), h->nominal_state_h.begin() + h->S, in + h->S);
+  float* mean = in + (h->mean_d - h->in_block_d);
+  std::copy(h->control_h.begin(), h->control_h.end(), mean);
+  std::copy(h->nominal_control_h.begin(), h->nominal_control_h.end(), mean + h->TC);
+  const size_t n = (size_t)(h->mean_d - h->in_block_d) + 2 * (size_t)h->TC;
+  HIP_TRY(h, hipMemcpyAsync(h->in_block_d, in, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
   return MPPI_OK;
 }
 

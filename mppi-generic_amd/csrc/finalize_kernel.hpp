@@ -17,6 +17,7 @@
 #include "mppi_amd/plugin/managed.hpp"
 #include "mppi_amd/plugin/math_utils.hpp"
 #include "mppi_amd/plugin/parallel_utils.hpp"
+#include "rollout_kernel.hpp"
 
 namespace mppi
 {
@@ -41,13 +42,18 @@ struct FinalizeArgs
                               ///<    (controllers/ColoredMPPI/colored_mppi_controller.cu:232-237)
 };
 
+/** by > 1 (LDS + barrier contract): the state and output trajectories are collected in LDS and written out once at the end —
+ *  a block barrier waits for the wave's outstanding global stores, so storing every step put a memory round trip on
+ *  each of the ~5 barriers of a step */
 template <class DYN_T>
-__host__ inline size_t finalizeSharedBytes(const DYN_T& dyn, int num_timesteps)
+__host__ inline size_t finalizeSharedBytes(const DYN_T& dyn, int num_timesteps, int by = 1)
 {
   constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
   size_t n = calcClassSharedMemSize(&dyn, 1);
   n += sizeof(float) * (math::nearest_multiple_4((num_timesteps + 4) * C) + math::nearest_multiple_4(num_timesteps * C) +
                         4 * math::nearest_multiple_4(S) + math::nearest_multiple_4(C) + math::nearest_multiple_4(O));
+  if (by > 1)
+    n += sizeof(float) * (math::nearest_multiple_4(num_timesteps * S) + math::nearest_multiple_4(num_timesteps * O));
   return n;
 }
 
@@ -76,6 +82,8 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
   float* zero_state = xdot + math::nearest_multiple_4(S);
   float* u = zero_state + math::nearest_multiple_4(S);
   float* y = u + math::nearest_multiple_4(C);
+  float* x_traj = y + math::nearest_multiple_4(O);             // [T][S], BY > 1 only
+  float* y_traj = x_traj + math::nearest_multiple_4(T * S);    // [T][O], BY > 1 only
 
   const float* uin = a.control_in_d + (size_t)z * T * C;
 
@@ -165,7 +173,7 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
     x[i] = a.x0_d[(size_t)z * S + i];
     xdot[i] = 0.0f;
     zero_state[i] = 0.0f;
-    a.state_out_d[((size_t)z * T + 0) * S + i] = x[i];
+    x_traj[i] = x[i];
   }
   for (int i = ty; i < O; i += BY)
     y[i] = 0.0f;
@@ -177,9 +185,8 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
   // computeStateTrajectoryHelper (controller.cuh:643-663)
   dynamics->initializeDynamics(x, u, y, theta_s, 0.0f, a.dt);
   __syncthreads();
-  if (a.output_out_d)
-    for (int i = ty; i < O; i += BY)
-      a.output_out_d[((size_t)z * T + 0) * O + i] = y[i];
+  for (int i = ty; i < O; i += BY)
+    y_traj[i] = y[i];
   for (int t = 0; t < T - 1; t++)
   {
     for (int i = ty; i < C; i += BY)
@@ -190,14 +197,19 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
     dynamics->step(x, xn, xdot, u, y, theta_s, t, a.dt);
     __syncthreads();
     for (int i = ty; i < S; i += BY)
-      a.state_out_d[((size_t)z * T + t + 1) * S + i] = xn[i];
-    if (a.output_out_d)
-      for (int i = ty; i < O; i += BY)
-        a.output_out_d[((size_t)z * T + t + 1) * O + i] = y[i];
+      x_traj[(t + 1) * S + i] = xn[i];
+    for (int i = ty; i < O; i += BY)
+      y_traj[(t + 1) * O + i] = y[i];
     float* tmp = x;
     x = xn;
     xn = tmp;
   }
+  __syncthreads();
+  for (int e = ty; e < T * S; e += BY)
+    a.state_out_d[(size_t)z * T * S + e] = x_traj[e];
+  if (a.output_out_d)
+    for (int e = ty; e < T * O; e += BY)
+      a.output_out_d[(size_t)z * T * O + e] = y_traj[e];
   }
   // enforceConstraints on every column of the control (mppi_controller.cu:227-231)
   if ((a.constrain_mask >> z) & 1)
@@ -218,6 +230,158 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
   }
   __syncthreads();
   for (int e = ty; e < T * C; e += BY)
+    a.control_out_d[(size_t)z * T * C + e] = ctrl[e];
+}
+
+/**
+ * The same pass for models with replicated-lane (MFMA) dynamics: one wave, laid out as the rollout kernels lay out 16
+ * rollouts x REP lanes, all 16 columns carrying the SAME trajectory (an MFMA computes 16 columns whether they are needed
+ * or not).  State in registers, no barrier in the step loop — the LDS + barrier network forward of the contract variant
+ * made this kernel 700 us for AutoRally (T = 150), i.e. most of mppi_compute_control; the MFMA forward is the one the
+ * rollouts use, so the trajectory is bit-identical to what they integrated.  Launch: grid = D, block = (64, 1, 1).
+ */
+template <class DYN_T>
+__host__ inline size_t finalizeRepSharedBytes(const DYN_T& dyn, int num_timesteps)
+{
+  constexpr int C = DYN_T::CONTROL_DIM;
+  constexpr int ROLLOUTS = 64 / replicated_lanes<DYN_T>::value;
+  return calcClassSharedMemSize(&dyn, ROLLOUTS) +
+         sizeof(float) * (math::nearest_multiple_4((num_timesteps + 4) * C) + math::nearest_multiple_4(num_timesteps * C));
+}
+
+template <class DYN_T>
+__global__ void __launch_bounds__(64) finalizeRepKernel(DYN_T dynamics_obj, const FinalizeArgs a)
+{
+  constexpr int REP = replicated_lanes<DYN_T>::value;
+  static_assert(REP > 1 && 64 % REP == 0, "for replicated-lane dynamics");
+  constexpr int ROLLOUTS = 64 / REP;
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == 64);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_y() == 1);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_z() == 1);
+  __builtin_assume(__builtin_amdgcn_workitem_id_y() == 0);
+  __builtin_assume(__builtin_amdgcn_workitem_id_z() == 0);
+  DYN_T* dynamics = &dynamics_obj;
+  constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
+  const int T = a.num_timesteps;
+  const int z = (int)blockIdx.x;
+  const int lane = (int)__builtin_amdgcn_workitem_id_x();
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* theta_s = reinterpret_cast<float*>(smem_raw);
+  float* buf = theta_s + calcClassSharedMemSize(dynamics, ROLLOUTS) / (int)sizeof(float);  // [(T+4)][C]
+  float* ctrl = buf + math::nearest_multiple_4((T + 4) * C);                                // [T][C]
+  const float* uin = a.control_in_d + (size_t)z * T * C;
+
+  if ((a.smooth_mask >> z) & 1)
+  {
+    // smoothControlTrajectoryHelper (controller.cuh:557-586): [history(2) | u | last, last] * [-3, 12, 17, 12, -3] / 35
+    if (lane < C)
+    {
+      buf[0 * C + lane] = a.history_d[z * a.history_stride + 0 * C + lane];
+      buf[1 * C + lane] = a.history_d[z * a.history_stride + 1 * C + lane];
+      buf[(T + 2) * C + lane] = uin[(T - 1) * C + lane];
+      buf[(T + 3) * C + lane] = uin[(T - 1) * C + lane];
+    }
+    for (int e = lane; e < T * C; e += 64)
+      buf[2 * C + e] = uin[e];
+    __syncthreads();
+    const float c0 = (float)(-3.0 / 35.0), c1 = (float)(12.0 / 35.0), c2 = (float)(17.0 / 35.0);
+    for (int e = lane; e < T * C; e += 64)
+    {
+      float acc = c0 * buf[e];
+      acc += c1 * buf[e + C];
+      acc += c2 * buf[e + 2 * C];
+      acc += c1 * buf[e + 3 * C];
+      acc += c0 * buf[e + 4 * C];
+      ctrl[e] = acc;
+    }
+  }
+  else
+  {
+    for (int e = lane; e < T * C; e += 64)
+      ctrl[e] = uin[e];
+  }
+  __syncthreads();
+
+  float x[S], xn[S], xdot[S], u[C], y[O], zero_state[S];
+#pragma unroll
+  for (int i = 0; i < S; i++)
+  {
+    x[i] = a.x0_d[(size_t)z * S + i];
+    xn[i] = 0.0f;
+    xdot[i] = 0.0f;
+    zero_state[i] = 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < O; i++)
+    y[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    u[i] = ctrl[i];
+  const bool writer = lane == 0;
+  if (writer)
+  {
+#pragma unroll
+    for (int i = 0; i < S; i++)
+      a.state_out_d[((size_t)z * T + 0) * S + i] = x[i];
+  }
+  // computeStateTrajectoryHelper / computeOutputTrajectoryHelper (controller.cuh:643-663)
+  dynamics->initializeDynamics(x, u, y, theta_s, 0.0f, a.dt);
+  if (writer && a.output_out_d)
+  {
+#pragma unroll
+    for (int i = 0; i < O; i++)
+      a.output_out_d[((size_t)z * T + 0) * O + i] = y[i];
+  }
+  for (int t = 0; t < T - 1; t++)
+  {
+#pragma unroll
+    for (int i = 0; i < C; i++)
+      u[i] = ctrl[t * C + i];
+    dynamics->enforceConstraints(x, u);
+    dynamics->step(x, xn, xdot, u, y, theta_s, t, a.dt);
+    if (writer)
+    {
+#pragma unroll
+      for (int i = 0; i < S; i++)
+        a.state_out_d[((size_t)z * T + t + 1) * S + i] = xn[i];
+      if (a.output_out_d)
+      {
+#pragma unroll
+        for (int i = 0; i < O; i++)
+          a.output_out_d[((size_t)z * T + t + 1) * O + i] = y[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < S; i++)
+      x[i] = xn[i];
+  }
+  // enforceConstraints on every column of the control (mppi_controller.cu:227-231)
+  if ((a.constrain_mask >> z) & 1)
+  {
+    if (a.constrain_mode == 1)
+    {
+      if constexpr (C > 1)
+        for (int t = lane; t < T; t += 64)
+          ctrl[t * C + 1] = fminf(fmaxf(ctrl[t * C + 1], dynamics->control_rngs_[1].x), dynamics->control_rngs_[1].y);
+    }
+    else
+    {
+      for (int t = lane; t < T; t += 64)
+      {
+        float uc[C];
+#pragma unroll
+        for (int i = 0; i < C; i++)
+          uc[i] = ctrl[t * C + i];
+        dynamics->enforceConstraints(zero_state, uc);
+#pragma unroll
+        for (int i = 0; i < C; i++)
+          ctrl[t * C + i] = uc[i];
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = lane; e < T * C; e += 64)
     a.control_out_d[(size_t)z * T * C + e] = ctrl[e];
 }
 

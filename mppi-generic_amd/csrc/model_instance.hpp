@@ -913,7 +913,27 @@ struct ModelT : ModelBase
   {
     if (!blobsReady(err))
       return MPPI_ERR_STATE;
-    const size_t smem = kernels::finalizeSharedBytes(dyn, a.num_timesteps);
+    if constexpr (!std::is_void<DYN_FAST_T>::value)
+    {  // replicated-lane (MFMA) dynamics: the register-resident single-wave variant
+      DYN_FAST_T fast(dyn);
+      const size_t smem_rep = kernels::finalizeRepSharedBytes(fast, a.num_timesteps);
+      if (smem_rep <= MAX_LDS_BYTES)
+      {
+        auto krep = kernels::finalizeRepKernel<DYN_FAST_T>;
+        if (smem_rep > 48 * 1024)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(krep), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem_rep);
+        hipLaunchKernelGGL(krep, dim3(D), dim3(64, 1, 1), smem_rep, stream, fast, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+        {
+          err = std::string("finalizeRepKernel launch: ") + hipGetErrorString(e);
+          return MPPI_ERR_HIP;
+        }
+        return MPPI_OK;
+      }
+    }
+    const size_t smem = kernels::finalizeSharedBytes(dyn, a.num_timesteps, FIN_BY);
     if (smem > MAX_LDS_BYTES)
     {
       err = "finalize kernel LDS overflow";

@@ -48,7 +48,7 @@ using ARModelDyn = NeuralNetModel<7, 2, 3>;
 using ARSampler = sampling_distributions::GaussianDistribution<NNDynamicsParams>;
 using ARModel = ModelT<ARModelDyn, ARStandardCost, ARSampler,
                        Shapes<Shape<8, 16, 1>, Shape<16, 8, 1>, Shape<16, 4, 1>, Shape<64, 1, 1>, Shape<8, 16, 2>>,
-                       /*FIN_BY=*/8,
+                       /*FIN_BY=*/32,
                        /* MFMA forward: BX rollouts x 4 k-group lanes per block (BX/16 waves) */
                        NeuralNetModelMFMA<7, 2, 3>, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>, Shape<64, 4, 2>>>;
 
@@ -57,7 +57,7 @@ using ARModel = ModelT<ARModelDyn, ARStandardCost, ARSampler,
 using BSLSampler = sampling_distributions::GaussianDistribution<BicycleSlipLSTMParams>;
 using BSLModel = ModelT<BicycleSlipLSTM, ARStandardCost, BSLSampler,
                         Shapes<Shape<16, 8, 1>, Shape<16, 4, 1>, Shape<64, 1, 1>, Shape<8, 16, 1>, Shape<16, 8, 2>>,
-                        /*FIN_BY=*/8, BicycleSlipLSTMMFMA, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>, Shape<64, 4, 2>>>;
+                        /*FIN_BY=*/32, BicycleSlipLSTMMFMA, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>, Shape<64, 4, 2>>>;
 
 /* RACER Dubins car + QuadraticCost over its 28 outputs (dynamics/racer_dubins/racer_dubins.cuh,
  * cost_functions/quadratic_cost/quadratic_cost.cuh) */
@@ -79,11 +79,11 @@ using DIColoredModel =
            sampling_distributions::ColoredNoiseDistribution<DoubleIntegratorParams>, Shapes<Shape<64, 1, 1>>, /*FIN_BY=*/1,
            void, Shapes<>, /*PIPELINE=*/true>;
 using ARColoredModel = ModelT<ARModelDyn, ARStandardCost, sampling_distributions::ColoredNoiseDistribution<NNDynamicsParams>,
-                              Shapes<Shape<16, 8, 1>>, /*FIN_BY=*/8, NeuralNetModelMFMA<7, 2, 3>,
+                              Shapes<Shape<16, 8, 1>>, /*FIN_BY=*/32, NeuralNetModelMFMA<7, 2, 3>,
                               Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>>>;
 using BSLColoredModel =
     ModelT<BicycleSlipLSTM, ARStandardCost, sampling_distributions::ColoredNoiseDistribution<BicycleSlipLSTMParams>,
-           Shapes<Shape<16, 8, 1>>, /*FIN_BY=*/8, BicycleSlipLSTMMFMA, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>>>;
+           Shapes<Shape<16, 8, 1>>, /*FIN_BY=*/32, BicycleSlipLSTMMFMA, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>>>;
 
 inline ModelBase* makeModel(const std::string& name, bool colored = false)
 {
