@@ -321,7 +321,7 @@ def main():
                                   "(2*FETCH_SIZE + WRITE_SIZE): the sample tensor never reaches HBM, so traffic << algorithmic bytes",
                 "algorithmic_bytes_per_launch": b_alg, "avg_kernel_us": round(roll_us, 3),
                 "avg_iteration_us_event_timed": round(ms_total / n_ev * 1e3, 3),
-                "note": "latency-bound: T=100 dependent Euler steps per rollout; K=16384 is 256 blocks of 3 role-waves on 256 CUs",
+                "note": "issue-bound on the dynamics wave: T=100 dependent Euler steps per rollout at ~83 instructions each; K=16384 is 256 blocks of 4 role waves (2 samplers, dynamics, cost) on 256 CUs",
             },
         }
         # secondary workload of the north star (not the headline `value`): AutoRally-NN, K=16384, T=150, MFMA forward
@@ -331,6 +331,20 @@ def main():
                     out[key] = leg(local_rank)
                 except Exception as e:  # noqa: BLE001
                     out[key] = {"error": str(e)}
+        if world == 1:
+            # what a control loop sees: one mppi_compute_control call (inputs handed over from the host, one iteration,
+            # smoothing + re-rollout of u*, results back) — the PCIe-inclusive figure, never `value`
+            try:
+                lat_eng = make_engine(cartpole_cfg(K=K_PER_GPU, T=T), device=local_rank)
+                for _ in range(50):
+                    lat_eng.computeControl(x0, 1)
+                t_a = time.perf_counter()
+                for _ in range(300):
+                    lat_eng.computeControl(x0, 1)
+                out["compute_control_latency_us"] = round((time.perf_counter() - t_a) / 300 * 1e6, 2)
+                lat_eng.close()
+            except Exception as e:  # noqa: BLE001
+                out["compute_control_latency_us"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cartpole_cfg(K=K_PER_GPU, T=T))
         print(json.dumps(out), flush=True)
