@@ -69,6 +69,7 @@ struct mppi_handle_s
   float* out_block_d = nullptr;
   float* in_pin_h = nullptr;
   float* out_pin_h = nullptr;
+  float* step_pin_h = nullptr;     // [S + C] pinned mirror of step_x_d | step_u_d (one block too)
   size_t in_floats = 0, out_floats = 0;
   bool out_pin_fresh = false;      // out_pin_h holds the results (incl. stats) of the last finalize pass; reset by launches
   float* step_x_d = nullptr;       // [S]
@@ -197,9 +198,12 @@ static void freeAll(mppi_handle h)
     (void)hipHostFree(h->in_pin_h);
   if (h->out_pin_h)
     (void)hipHostFree(h->out_pin_h);
-  h->in_pin_h = h->out_pin_h = nullptr;
+  if (h->step_pin_h)
+    (void)hipHostFree(h->step_pin_h);
+  h->in_pin_h = h->out_pin_h = h->step_pin_h = nullptr;
+  h->step_u_d = nullptr;  // slice of the step_x_d block
   float** bufs[] = { &h->in_block_d, &h->out_block_d, &h->costs_d,   &h->partials_d,  &h->send_d,     &h->recv_d,
-                     &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->step_u_d, &h->gather_tmp_d };
+                     &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->gather_tmp_d };
   for (float** b : bufs)
   {
     if (*b)
@@ -377,8 +381,13 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   ALLOC_OR_FAIL(h->recv_d, (size_t)world * D * h->PS);
   ALLOC_OR_FAIL(h->gather_tmp_d, (size_t)world * D * h->PS);
   ALLOC_OR_FAIL(h->ctrl_in_d, (size_t)D * T * C);
-  ALLOC_OR_FAIL(h->step_x_d, (size_t)S);
-  ALLOC_OR_FAIL(h->step_u_d, (size_t)C);
+  ALLOC_OR_FAIL(h->step_x_d, (size_t)S + C);  // [x | u] of mppi_model_step
+  h->step_u_d = h->step_x_d + S;
+  if (hipHostMalloc((void**)&h->step_pin_h, ((size_t)S + C) * sizeof(float), hipHostMallocDefault) != hipSuccess)
+  {
+    freeAll(hp);
+    return fail(nullptr, MPPI_ERR_HIP, "hipHostMalloc of the pinned model-step buffer failed");
+  }
   if (cfg->save_samples)
     ALLOC_OR_FAIL(h->samples_d, (size_t)D * K * T * C);
 #undef ALLOC_OR_FAIL
@@ -1796,15 +1805,19 @@ mppi_status mppi_model_step(mppi_handle h, float* x, float* u, float dt, int enf
   if (!x || !u)
     return fail(h, MPPI_ERR_INVALID_ARG, "null");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-  HIP_TRY(h, hipMemcpyAsync(h->step_x_d, x, sizeof(float) * h->S, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->step_u_d, u, sizeof(float) * h->C, hipMemcpyHostToDevice, h->stream));
+  // [x | u] through pinned memory: one copy up, one copy back, one synchronisation
+  std::copy(x, x + h->S, h->step_pin_h);
+  std::copy(u, u + h->C, h->step_pin_h + h->S);
+  const size_t bytes = sizeof(float) * (size_t)(h->S + h->C);
+  HIP_TRY(h, hipMemcpyAsync(h->step_x_d, h->step_pin_h, bytes, hipMemcpyHostToDevice, h->stream));
   std::string err;
   mppi_status st = h->model->launchModelStep(h->step_x_d, h->step_u_d, dt, enforce, h->stream, err);
   if (st != MPPI_OK)
     return fail(h, st, err);
-  HIP_TRY(h, hipMemcpyAsync(x, h->step_x_d, sizeof(float) * h->S, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(u, h->step_u_d, sizeof(float) * h->C, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->step_pin_h, h->step_x_d, bytes, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::copy(h->step_pin_h, h->step_pin_h + h->S, x);
+  std::copy(h->step_pin_h + h->S, h->step_pin_h + h->S + h->C, u);
   return MPPI_OK;
 }
 
