@@ -117,7 +117,7 @@ def autorally_leg(device):
                      "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak = the fp32 vector peak; the kernel is bound by VALU "
                              "issue, not by the matrix cores: per 16 rollouts and step a dynamics wave issues 28 MFMAs and ~500 "
                              "VALU instructions (64 packed-fp32 tanh per rollout, kinematics, Euler); sampler and cost run "
-                             "once per rollout in their own waves; K=16384 is exactly one dynamics wave per SIMD"},
+                             "once per rollout in helper waves (two samplers, two relaying cost waves: one helper per SIMD); K=16384 is exactly one dynamics wave per SIMD"},
     }
 
 

@@ -10,6 +10,7 @@
 #define MPPI_AMD_MODEL_INSTANCE_HPP_
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -378,6 +379,9 @@ struct ModelT : ModelBase
     if constexpr (!std::is_void<FAST>::value)
     {
       FAST fast(dyn);
+      constexpr int REP = kernels::replicated_lanes<FAST>::value;
+      const int grid = (args.num_rollouts + 63) / 64;
+      const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
       const int ring = kernels::pipelineRepRingSteps(fast, cost, smp, MAX_LDS_BYTES);
       if (ring == 0)
       {
@@ -385,15 +389,13 @@ struct ModelT : ModelBase
         return MPPI_ERR_LDS_OVERFLOW;
       }
       const size_t smem = kernels::pipelineRepSharedBytes(fast, cost, smp, ring);
-      const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
       auto kfn = in_loop ? kernels::rolloutPipelineRepKernel<FAST, COST_T, SAMPLING_T, SAMPLING_T::IN_LOOP_DRAW>
                          : kernels::rolloutPipelineRepKernel<FAST, COST_T, SAMPLING_T, false>;
       if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem);
-      constexpr int REP = kernels::replicated_lanes<FAST>::value;
-      const int grid = (args.num_rollouts + 63) / 64;
-      hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * (REP + 2), 1, 1), smem, stream, fast, cost, smp, args, ring);
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * (REP + kernels::PIPE_REP_SAMPLERS + kernels::PIPE_REP_COSTS), 1, 1), smem, stream, fast, cost, smp,
+                         args, ring);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess)
       {

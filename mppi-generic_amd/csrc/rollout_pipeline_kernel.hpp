@@ -405,6 +405,12 @@ __host__ __device__ inline int samplerGrdBytes(const SAMPLING_T* smp)
   return ((smp->getGrdSharedSizeBytes() + 15) / 16) * 16;
 }
 
+/** helper waves of rolloutPipelineRepKernel: a block of REP dynamics waves puts one on each SIMD of the CU; two sampler
+ *  waves (alternate trips) and two cost waves (alternate step pairs, see the kernel) give every SIMD one helper of about
+ *  half a role instead of loading two SIMDs with a whole role each */
+constexpr int PIPE_REP_SAMPLERS = 2;
+constexpr int PIPE_REP_COSTS = 2;
+
 template <class DYN_T, class COST_T, class SAMPLING_T>
 __host__ inline size_t pipelineRepSharedBytes(const DYN_T& dyn, const COST_T& cost, const SAMPLING_T& smp, int ring)
 {
@@ -415,8 +421,8 @@ __host__ inline size_t pipelineRepSharedBytes(const DYN_T& dyn, const COST_T& co
   n += calcClassSharedMemSize(&smp, slots) - samplerGrdBytes(&smp);       // the sample rows
   const size_t ring_bytes = sizeof(float) * (size_t)ring * DYN_T::OUTPUT_DIM * 64;  // output ring [slot][i][rollout]
   n += ring_bytes > (size_t)samplerGrdBytes(&smp) ? ring_bytes : (size_t)samplerGrdBytes(&smp);
-  n += sizeof(float) * 2 * math::nearest_multiple_4(slots);              // cost_s, w_s
-  n += sizeof(int) * 4 * (replicated_lanes<DYN_T>::value + 2);           // progress counters (padded)
+  n += sizeof(float) * 4 * math::nearest_multiple_4(slots);              // cost_s, w_s, relay_cost, relay_status
+  n += sizeof(int) * 4 * (replicated_lanes<DYN_T>::value + PIPE_REP_SAMPLERS + 1);  // progress counters (padded)
   return n;
 }
 
@@ -442,7 +448,7 @@ __device__ inline void vgprResident(T& obj)
 }
 
 template <class DYN_T, class COST_T, class SAMPLING_T, bool DRAW_IN_LOOP>
-__global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
+__global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_REP_SAMPLERS + PIPE_REP_COSTS))
     rolloutPipelineRepKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args,
                              const int ring_steps)
 {
@@ -450,7 +456,11 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
   constexpr int REP = replicated_lanes<DYN_T>::value;
   static_assert(REP > 1 && 64 % REP == 0, "this variant is for replicated-lane dynamics");
   constexpr int DW = BX * REP / 64;  // dynamics waves
-  constexpr int NWAVES = DW + 2;
+  constexpr int NS = PIPE_REP_SAMPLERS, NC = PIPE_REP_COSTS;
+  // wave order: dynamics 0 .. DW-1, then sampler 0, cost 0, sampler 1, cost 1: with the waves of a workgroup dealt to
+  // the CU's four SIMDs in turn, every SIMD gets one dynamics wave and one helper
+  constexpr int NWAVES = DW + NS + NC;
+  static_assert(NS == 2 && NC == 2, "helper wave order below");
   constexpr int NTHREADS = 64 * NWAVES;
   constexpr int PER_WAVE = 64 / REP;
   __builtin_assume(__builtin_amdgcn_workgroup_size_x() == NTHREADS);
@@ -471,7 +481,8 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
   const int wave = __builtin_amdgcn_readfirstlane(tid_x >> 6);  // wave-uniform
   const int lane = tid_x & 63;
   const bool is_dyn = wave < DW;
-  const bool is_sampler = wave == DW;
+  const bool is_sampler = !is_dyn && ((wave - DW) & 1) == 0;
+  const int helper_id = is_dyn ? 0 : (wave - DW) >> 1;  // which of the two samplers / cost waves
   // rollout slot of this thread: dynamics waves carry PER_WAVE rollouts x REP lanes, the other two one lane per rollout
   const int thread_idx = is_dyn ? wave * PER_WAVE + (lane % PER_WAVE) : lane;
   const int rep_lane = is_dyn ? lane / PER_WAVE : 0;
@@ -494,10 +505,12 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
   const int overlay_floats = max(ring_steps * O * 64, samplerGrdBytes(sampling) / (int)sizeof(float));
   float* cost_s = ring + overlay_floats;
   float* w_s = cost_s + math::nearest_multiple_4(SLOTS);
-  lds_counter_t counters = (lds_counter_t)reinterpret_cast<int*>(w_s + math::nearest_multiple_4(SLOTS));
-  lds_counter_t smp_prog = counters + 4 * DW;        // steps whose shaped sample is in the row
-  lds_counter_t cost_prog = counters + 4 * (DW + 1);  // steps the cost wave has consumed
+  float* relay_cost = w_s + math::nearest_multiple_4(SLOTS);  // running cost / status handed from cost wave to cost wave
+  int* relay_status = reinterpret_cast<int*>(relay_cost + math::nearest_multiple_4(SLOTS));
+  lds_counter_t counters = (lds_counter_t)(relay_status + math::nearest_multiple_4(SLOTS));
   // counters + 4 * w, w < DW: steps whose output dynamics wave w has put into the ring
+  // counters + 4 * (DW + s): sampler s — steps (of ITS trips) whose shaped sample is in the row
+  lds_counter_t cost_prog = counters + 4 * (DW + NS);  // steps the cost waves have consumed
 
   sampling->setThreadMapping(shared_idx, BX);
 
@@ -516,7 +529,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
 #pragma unroll
   for (int i = 0; i < O; i++)
     y[i] = 0.0f;
-  if (tid_x < NWAVES)
+  if (tid_x < DW + NS + 1)
     counters[4 * tid_x] = 0;
   __syncthreads();
 
@@ -527,13 +540,15 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
 
   float running_cost = 0.0f;
   float* row = sampling->sampleRow(theta_d_shared, shared_idx);
+  constexpr int STEPS = (C % 2 == 0) ? 2 : 4;  // steps per sampler trip (whole Philox quads)
 
   if (is_sampler)
   {
-    /* ------------------------------------------------ sampler wave ------------------------------------------------ */
-    constexpr int STEPS = (C % 2 == 0) ? 2 : 4;
+    /* ------------------------------------------------ sampler waves ----------------------------------------------- */
+    // sampler s takes trips s, s + NS, ...
     constexpr int QUADS = STEPS * C / 4;
-    for (int t = 0; t < num_timesteps; t += STEPS)
+    lds_counter_t smp_prog = counters + 4 * (DW + helper_id);
+    for (int t = STEPS * helper_id; t < num_timesteps; t += STEPS * NS)
     {
       float zq[4 * QUADS];
       if (DRAW_IN_LOOP)
@@ -586,13 +601,24 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
           slot[i * 64] = y[i];
       }
     };
-    int seen_smp = 0, seen_smp1 = 0, seen_cost = 0;
+    int seen_smp[NS], seen_cost = 0;
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+      seen_smp[q] = 0;
+    // the pair (t, t + 1) lies inside one sampler trip (STEPS is even): wait for the sampler that owns the trip
+    auto wait_samples = [&](const int t, const int need) {
+      const int owner = (t / STEPS) % NS;
+      if (owner == 0)
+        pipeWait(counters + 4 * DW, need, seen_smp[0]);
+      else
+        pipeWait(counters + 4 * (DW + 1), need, seen_smp[1]);
+    };
     int t = 0;
     // full pairs of steps as one basic block (see rolloutPipelineKernel): lets the scheduler overlap the second step's
     // independent work with the first step's MFMA chains
     for (; t + 1 < num_timesteps; t += 2)
     {
-      pipeWait(smp_prog, t + 2, seen_smp);
+      wait_samples(t, t + 2);
       pipeWait(cost_prog, t + 2 - ring_steps, seen_cost);
       float ubuf[2 * C];
 #pragma unroll
@@ -604,7 +630,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
     }
     if (t < num_timesteps)
     {
-      pipeWait(smp_prog, num_timesteps, seen_smp);
+      wait_samples(t, num_timesteps);
       pipeWait(cost_prog, num_timesteps - ring_steps, seen_cost);
       float ubuf[C];
 #pragma unroll
@@ -616,42 +642,76 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + 2))
   }
   else
   {
-    /* ------------------------------------------------ cost wave --------------------------------------------------- */
+    /* ------------------------------------------------ cost waves -------------------------------------------------- */
     // The cost plugin's parameters arrive as kernel arguments, i.e. in SGPRs, and this kernel's three roles together want
     // more than the ~100 a wave has: the step loop of this wave was reloading spilled SGPRs with ~45 v_readlane per step.
     // A private copy whose words are pinned to VGPRs (which this wave has to spare) takes the parameters out of that
     // competition; every lane holds the same values, the arithmetic is unchanged.
+    //
+    // Two cost waves take alternate PAIRS of steps.  The running cost is a sum in step order and the plugin's status
+    // word (crash flags) threads through the steps, so a pair can only be evaluated after the one before it: the waves
+    // do not run concurrently, they RELAY — each finishes its pair, leaves the running cost and the status of its 64
+    // rollouts in LDS and publishes cost_prog; the other picks them up.  The point is where the instructions issue: each
+    // of the two SIMDs hosting a cost wave carries half the cost role next to its dynamics wave (the block finishes
+    // with its slowest dynamics wave), and the outputs of a wave's next pair are fetched while it waits for its turn.
     COST_T costs_v = *costs;
     vgprResident(costs_v);
     COST_T* costs_w = &costs_v;
-    int seen_dyn[DW];
+    int seen_dyn[DW], seen_cost = 0;
 #pragma unroll
     for (int w = 0; w < DW; w++)
       seen_dyn[w] = 0;
-    for (int t = 0; t < num_timesteps; t += 2)
+    for (int t = 2 * helper_id; t < num_timesteps; t += 2 * NC)
     {
       const int hi = min(t + 2, num_timesteps);
 #pragma unroll
       for (int w = 0; w < DW; w++)
         pipeWait(counters + 4 * w, hi, seen_dyn[w]);
-      for (int tt = t; tt < hi; tt++)
+      float yb[2][O], ub[2][C];
+#pragma unroll
+      for (int q = 0; q < 2; q++)
       {
+        const int tt = min(t + q, num_timesteps - 1);
         const float* slot = ring + (size_t)(tt & ring_mask) * O * 64 + lane;
 #pragma unroll
         for (int i = 0; i < O; i++)
-          y[i] = slot[i * 64];
+          yb[q][i] = slot[i * 64];
 #pragma unroll
         for (int i = 0; i < C; i++)
-          u[i] = row[tt * C + i];
-        running_cost += costs_w->computeRunningCost(y, u, tt, theta_c_shared, &crash_status) +
-                        sampling->computeLikelihoodRatioCost(u, theta_d_shared, global_idx, tt, 0, args.lambda, args.alpha);
+          ub[q][i] = row[tt * C + i];
       }
+      if (t > 0)
+      {
+        pipeWait(cost_prog, t, seen_cost);
+        running_cost = relay_cost[lane];
+        crash_status = relay_status[lane];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+      {
+        if (t + q < num_timesteps)
+          running_cost += costs_w->computeRunningCost(yb[q], ub[q], t + q, theta_c_shared, &crash_status) +
+                          sampling->computeLikelihoodRatioCost(ub[q], theta_d_shared, global_idx, t + q, 0, args.lambda,
+                                                               args.alpha);
+      }
+      relay_cost[lane] = running_cost;
+      relay_status[lane] = crash_status;
       pipePublish(cost_prog, hi, lane);
     }
   }
   __syncthreads();
 
-  const bool writer = !is_dyn && !is_sampler;
+  // cost wave 0 publishes the rollouts' results: the last pair's wave left the running cost in the relay slots and the
+  // last step's outputs are still in the ring (terminalCost reads them)
+  const bool writer = !is_dyn && !is_sampler && helper_id == 0;
+  if (writer)
+  {
+    running_cost = relay_cost[lane];
+    const float* slot = ring + (size_t)((num_timesteps - 1) & ring_mask) * O * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < O; i++)
+      y[i] = slot[i * 64];
+  }
   const float terminal = costs->terminalCost(y, theta_c_shared);
   blockSoftminEpilogue<SAMPLING_T, C, BX, 1, NTHREADS>(sampling, args, terminal, running_cost, writer, valid, global_idx,
                                                        shared_idx, 0, tid_x, block_idx, nrows, theta_d_shared, cost_s, w_s);
