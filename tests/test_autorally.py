@@ -103,6 +103,34 @@ def test_autorally_rollout_costs_bit_exact(gpu, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("K,T", [(200, 37), (64, 1), (130, 3), (72, 2), (512, 41)])
+@pytest.mark.parametrize("mode", ["injected", "philox"])
+def test_autorally_pipeline_ragged_and_short_horizons(gpu, K, T, mode):
+    """the MFMA pipeline kernel (dynamics waves + two samplers + two relaying cost waves): partially filled last block,
+    odd horizons (the last pair of steps is a single step), horizons shorter than one sampler trip / one relay round,
+    both noise sources, non-zero likelihood-ratio coefficients and a crash-prone start so that the status word travels
+    through the relay.  Reference edge cases: mppi_common.cu:1305-1310 (ragged K), rollout_kernel_tests.cu (T sweep)."""
+    cfg = autorally_cfg(K=K, T=T)
+    cfg["control_cost_coeff"] = [0.7, 0.3]
+    cfg["x0"] = np.array([-12.0, 5.0, 0.4, 0.0, 6.0, 0.5, 0.0], np.float32)
+    eng = make_engine(cfg, block_x=64, block_y=4, kernel_variant=2, save_samples=True)
+    orc = make_oracle(cfg)
+    mean = (0.3 * np.sin(np.arange(T * 2, dtype=np.float32) * 0.2)).reshape(T, 2)
+    eng.updateImportanceSampler(mean)
+    if mode == "injected":
+        eps = host_noise(1, K, T, 2)[0]
+        eng.injectNoise(eps)
+    else:
+        eps = po.philox_normal(42, 0, K, T, 2)
+    g = eng.rolloutCosts(cfg["x0"], 1)
+    v = orc.set_gaussian_controls(mean[None], eps, 1, 0)
+    c, vc = orc.rollout_costs(cfg["x0"], mean[None], v)
+    assert g.shape == c.shape and np.isfinite(g).all()
+    assert ulp_diff(g, c).max() == 0, ulp_diff(g, c).max()
+    assert ulp_diff(eng.getSampledControls(), vc).max() == 0
+
+
+@pytest.mark.gpu
 def test_autorally_compute_control_parity(gpu):
     cfg = autorally_cfg(K=1024, T=50, num_iters=2)
     eng, orc = make_engine(cfg), make_oracle(cfg)
