@@ -275,11 +275,13 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   h->by = cfg->block_y > 0 ? cfg->block_y : h->model->default_by;
   h->bz = h->D;
   if (cfg->controller == MPPI_CONTROLLER_ROBUST)
-  {  // rolloutRMPPIKernel: (64 rollouts, 1 lane, 2 systems)
-    if ((cfg->block_x != 0 && cfg->block_x != 64) || (cfg->block_y != 0 && cfg->block_y != 1))
-      return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE, "mppi_create: Robust MPPI runs with block shape (64, 1, 2)");
-    h->bx = 64;
+  {  // rolloutRMPPIKernel: (64 rollouts, 1 lane, 2 systems); (32, 1, 2) when the sample rows of 64 x 2 overflow the LDS
+    if ((cfg->block_x != 0 && cfg->block_x != 64 && cfg->block_x != 32) || (cfg->block_y != 0 && cfg->block_y != 1))
+      return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE, "mppi_create: Robust MPPI runs with block shape (64, 1, 2) or (32, 1, 2)");
+    h->bx = cfg->block_x != 0 ? cfg->block_x : 64;
     h->by = 1;
+    if (cfg->block_x == 0 && h->model->rmppiSharedBytes(64, cfg->num_timesteps) > MAX_LDS_BYTES)
+      h->bx = 32;
   }
   // Tube with a pipeline-capable model and no explicit shape: fold the two systems into the lanes of a wave (32, 1, 2)
   if (h->D == 2 && cfg->controller == MPPI_CONTROLLER_TUBE && cfg->block_x == 0 && cfg->block_y == 0 &&
@@ -289,7 +291,8 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     h->bx = 32;
     h->by = 1;
   }
-  if (!h->model->supportsShape(h->bx, h->by, h->bz) && !h->model->supportsPipelineFold(h->bx, h->by, h->bz))
+  // (Robust MPPI's two kernels are instantiated per model — checked above — not per block shape)
+  if (cfg->controller != MPPI_CONTROLLER_ROBUST && !h->model->supportsShape(h->bx, h->by, h->bz) && !h->model->supportsPipelineFold(h->bx, h->by, h->bz))
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
                 "mppi_create: block shape (" + std::to_string(h->bx) + "," + std::to_string(h->by) + "," +
                     std::to_string(h->bz) + ") is not instantiated for model '" + h->model_name + "'");
@@ -552,7 +555,9 @@ mppi_status mppi_set_model_blob(mppi_handle h, const char* name, const float* da
   if (st != MPPI_OK)
     return fail(h, st, err);
   // the LDS request may depend on the blob (network size): re-check it
-  const size_t lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, h->cfg.num_timesteps, h->D, h->pipeline);
+  const size_t lds = h->cfg.controller == MPPI_CONTROLLER_ROBUST ?
+                         h->model->rmppiSharedBytes(h->bx, h->cfg.num_timesteps) :
+                         h->model->rolloutSharedBytes(h->bx, h->by, h->bz, h->cfg.num_timesteps, h->D, h->pipeline);
   if (lds > MAX_LDS_BYTES)
     return fail(h, MPPI_ERR_LDS_OVERFLOW, "rollout kernel LDS request exceeds 160 KiB after loading '" + std::string(name) + "'");
   return MPPI_OK;

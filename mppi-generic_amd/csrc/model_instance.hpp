@@ -293,7 +293,13 @@ struct ModelT : ModelBase
     {
       smp.params_.num_timesteps = T;
       smp.params_.num_distributions = 2;
-      return kernels::rmppiSharedBytes(dyn, cost, fb, smp, bx);
+      if constexpr (!std::is_void<DYN_FAST_T>::value)
+      {
+        DYN_FAST_T fast(dyn);
+        return kernels::rmppiSharedBytes(fast, cost, fb, smp, bx);
+      }
+      else
+        return kernels::rmppiSharedBytes(dyn, cost, fb, smp, bx);
     }
     return 0;
   }
@@ -306,11 +312,16 @@ struct ModelT : ModelBase
         return MPPI_ERR_STATE;
       prepSampler(s);
       constexpr int BX = 64;
-      const size_t smem = kernels::initEvalSharedBytes<DYN_T, COST_T, SAMPLING_T>(dyn, cost, BX);
-      auto kfn = kernels::initEvalKernel<DYN_T, COST_T, SAMPLING_T, BX>;
+      // models with replicated-lane (MFMA) dynamics run both Robust MPPI kernels on them
+      using RM_DYN_T = std::conditional_t<std::is_void<DYN_FAST_T>::value, DYN_T, DYN_FAST_T>;
+      constexpr int REP = kernels::replicated_lanes<RM_DYN_T>::value;
+      RM_DYN_T rm_dyn(dyn);
+      const size_t smem = kernels::initEvalSharedBytes<RM_DYN_T, COST_T, SAMPLING_T>(rm_dyn, cost, BX);
+      auto kfn = kernels::initEvalKernel<RM_DYN_T, COST_T, SAMPLING_T, BX>;
       if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL(kfn, dim3((a.num_eval_rollouts + BX - 1) / BX), dim3(BX, 1, 1), smem, stream, dyn, cost, smp, a);
+      hipLaunchKernelGGL(kfn, dim3((a.num_eval_rollouts + BX - 1) / BX), dim3(BX * REP, 1, 1), smem, stream, rm_dyn, cost,
+                         smp, a);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess)
       {
@@ -320,6 +331,38 @@ struct ModelT : ModelBase
       return MPPI_OK;
     }
     return ModelBase::launchInitEval(a, s, stream, err);
+  }
+  template <int BX>
+  mppi_status launchRMPPIShape(const kernels::RMPPIArgs& a, hipStream_t stream, std::string& err)
+  {
+    if constexpr (RMPPI)
+    {
+      using RM_DYN_T = std::conditional_t<std::is_void<DYN_FAST_T>::value, DYN_T, DYN_FAST_T>;
+      constexpr int REP = kernels::replicated_lanes<RM_DYN_T>::value;
+      RM_DYN_T rm_dyn(dyn);
+      const size_t smem = kernels::rmppiSharedBytes(rm_dyn, cost, fb, smp, BX);
+      if (smem > MAX_LDS_BYTES)
+      {
+        err = "RMPPI rollout kernel needs " + std::to_string(smem) + " B of LDS per block; gfx950 has 163840";
+        return MPPI_ERR_LDS_OVERFLOW;
+      }
+      const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
+      auto kfn = in_loop ? kernels::rolloutRMPPIKernel<RM_DYN_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, BX, SAMPLING_T::IN_LOOP_DRAW>
+                         : kernels::rolloutRMPPIKernel<RM_DYN_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, BX, false>;
+      if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(kfn, dim3((a.base.num_rollouts + BX - 1) / BX), dim3(BX * REP, 1, 2), smem, stream, rm_dyn, cost, fb,
+                         smp, a);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess)
+      {
+        err = std::string("rolloutRMPPIKernel launch: ") + hipGetErrorString(e);
+        return MPPI_ERR_HIP;
+      }
+      return MPPI_OK;
+    }
+    err = "model is not registered for Robust MPPI";
+    return MPPI_ERR_UNSUPPORTED;
   }
   mppi_status launchRMPPI(int bx, const kernels::RMPPIArgs& a, const SamplerLaunchState& s, hipStream_t stream,
                           std::string& err) override
@@ -333,32 +376,13 @@ struct ModelT : ModelBase
         err = "Robust MPPI needs the DDP feedback gains [T][S][C] (mppi_set_feedback_gains) before it can run";
         return MPPI_ERR_STATE;
       }
-      if (bx != 64)
-      {
-        err = "Robust MPPI rollout kernel is instantiated for 64 rollouts per block";
-        return MPPI_ERR_LAUNCH_SHAPE;
-      }
       prepSampler(s);
-      constexpr int BX = 64;
-      const size_t smem = kernels::rmppiSharedBytes(dyn, cost, fb, smp, BX);
-      if (smem > MAX_LDS_BYTES)
-      {
-        err = "RMPPI rollout kernel needs " + std::to_string(smem) + " B of LDS per block; gfx950 has 163840";
-        return MPPI_ERR_LDS_OVERFLOW;
-      }
-      const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
-      auto kfn = in_loop ? kernels::rolloutRMPPIKernel<DYN_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, BX, SAMPLING_T::IN_LOOP_DRAW>
-                         : kernels::rolloutRMPPIKernel<DYN_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, BX, false>;
-      if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL(kfn, dim3((a.base.num_rollouts + BX - 1) / BX), dim3(BX, 1, 2), smem, stream, dyn, cost, fb, smp, a);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess)
-      {
-        err = std::string("rolloutRMPPIKernel launch: ") + hipGetErrorString(e);
-        return MPPI_ERR_HIP;
-      }
-      return MPPI_OK;
+      if (bx == 64)
+        return launchRMPPIShape<64>(a, stream, err);
+      if (bx == 32)  // horizons whose sample rows for 64 rollouts x 2 systems do not fit the LDS
+        return launchRMPPIShape<32>(a, stream, err);
+      err = "Robust MPPI rollout kernel is instantiated for 64 or 32 rollouts per block";
+      return MPPI_ERR_LAUNCH_SHAPE;
     }
     return ModelBase::launchRMPPI(bx, a, s, stream, err);
   }

@@ -57,22 +57,42 @@ __host__ inline size_t initEvalSharedBytes(const DYN_T& dyn, const COST_T& cost,
   return calcClassSharedMemSize(&dyn, bx) + calcClassSharedMemSize(&cost, bx);
 }
 
-/** reference: rmppi_kernels.cu:231-356.  block = (BX, 1, 1); global thread = candidate * samples_per_candidate + sample */
+/** lane -> (rollout of the block, replica) for dynamics with REPLICATED_LANES > 1 (MFMA forward: a wave carries 64 / REP
+ *  rollouts, each REP times), identity otherwise — the mapping of rolloutKernel */
+template <int REP>
+__device__ inline void replicaMapping(const int tid_x, int& thread_idx, int& rep_lane)
+{
+  thread_idx = tid_x;
+  rep_lane = 0;
+  if (REP > 1)
+  {
+    constexpr int PER_WAVE = 64 / REP;
+    const int l = tid_x & 63;
+    thread_idx = (tid_x >> 6) * PER_WAVE + (l % PER_WAVE);
+    rep_lane = l / PER_WAVE;
+  }
+}
+
+/** reference: rmppi_kernels.cu:231-356.  block = (BX * REP, 1, 1); rollout = candidate * samples_per_candidate + sample */
 template <class DYN_T, class COST_T, class SAMPLING_T, int BX>
-__global__ void __launch_bounds__(BX)
+__global__ void __launch_bounds__(BX* replicated_lanes<DYN_T>::value)
     initEvalKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const InitEvalArgs args)
 {
-  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == BX);
+  constexpr int REP = replicated_lanes<DYN_T>::value;
+  static_assert(REP == 1 || (64 % REP == 0 && (BX * REP) % 64 == 0), "replicated lanes need whole waves");
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == BX * REP);
   __builtin_assume(__builtin_amdgcn_workgroup_size_y() == 1);
   __builtin_assume(__builtin_amdgcn_workgroup_size_z() == 1);
-  __builtin_assume(__builtin_amdgcn_workitem_id_x() < BX);
+  __builtin_assume(__builtin_amdgcn_workitem_id_x() < BX * REP);
   __builtin_assume(__builtin_amdgcn_workitem_id_y() == 0);
   __builtin_assume(__builtin_amdgcn_workitem_id_z() == 0);
   DYN_T* dynamics = &dynamics_obj;
   COST_T* costs = &costs_obj;
   SAMPLING_T* sampling = &sampling_obj;
   constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
-  const int global_idx = BX * (int)blockIdx.x + (int)__builtin_amdgcn_workitem_id_x();
+  int thread_idx, rep_lane;
+  replicaMapping<REP>((int)__builtin_amdgcn_workitem_id_x(), thread_idx, rep_lane);
+  const int global_idx = BX * (int)blockIdx.x + thread_idx;
   const bool valid = global_idx < args.num_eval_rollouts;
   const int gi = valid ? global_idx : 0;
   const int candidate_idx = gi / args.samples_per_candidate;
@@ -121,7 +141,7 @@ __global__ void __launch_bounds__(BX)
     x_next = tmp;
   }
   // computeAndSaveCost (mppi_common.cu:843-853) with running / T passed in
-  if (valid)
+  if (valid && rep_lane == 0)
     args.trajectory_costs_d[global_idx] =
         running_cost / (float)num_timesteps + costs->terminalCost(y, theta_c_shared) / (float)num_timesteps;
 }
@@ -144,14 +164,18 @@ __host__ inline size_t rmppiSharedBytes(const DYN_T& dyn, const COST_T& cost, co
 }
 
 template <class DYN_T, class COST_T, class FB_T, class SAMPLING_T, int BX, bool DRAW_IN_LOOP>
-__global__ void __launch_bounds__(BX * 2)
+__global__ void __launch_bounds__(BX * 2 * replicated_lanes<DYN_T>::value)
     rolloutRMPPIKernel(DYN_T dynamics_obj, COST_T costs_obj, FB_T fb_obj, SAMPLING_T sampling_obj, const RMPPIArgs rargs)
 {
   constexpr int BZ = 2;
-  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == BX);
+  // REP > 1 (MFMA dynamics): REP wave lanes carry private copies of a rollout of one system and cooperate only inside
+  // the dynamics plugin; blockDim.x = BX * REP, everything else is evaluated redundantly on the replicas
+  constexpr int REP = replicated_lanes<DYN_T>::value;
+  static_assert(REP == 1 || (64 % REP == 0 && (BX * REP) % 64 == 0), "replicated lanes need whole waves");
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == BX * REP);
   __builtin_assume(__builtin_amdgcn_workgroup_size_y() == 1);
   __builtin_assume(__builtin_amdgcn_workgroup_size_z() == BZ);
-  __builtin_assume(__builtin_amdgcn_workitem_id_x() < BX);
+  __builtin_assume(__builtin_amdgcn_workitem_id_x() < BX * REP);
   __builtin_assume(__builtin_amdgcn_workitem_id_y() == 0);
   __builtin_assume(__builtin_amdgcn_workitem_id_z() < BZ);
   const RolloutArgs& args = rargs.base;
@@ -161,14 +185,16 @@ __global__ void __launch_bounds__(BX * 2)
   SAMPLING_T* sampling = &sampling_obj;
   constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
   constexpr int SLOTS = BX * BZ;
-  constexpr int NTHREADS = BX * BZ;
-  const int thread_idx = (int)__builtin_amdgcn_workitem_id_x();
+  constexpr int NTHREADS = BX * REP * BZ;
+  const int tid_x = (int)__builtin_amdgcn_workitem_id_x();
+  int thread_idx, rep_lane;  // rollout within the block, replica
+  replicaMapping<REP>(tid_x, thread_idx, rep_lane);
   const int thread_idz = (int)__builtin_amdgcn_workitem_id_z();
   const int block_idx = (int)blockIdx.x;
   const int global_idx = BX * block_idx + thread_idx;
   const int shared_idx = BX * thread_idz + thread_idx;
   const int distribution_idx = thread_idz;
-  const int tid_flat = thread_idx + BX * thread_idz;
+  const int tid_flat = tid_x + BX * REP * thread_idz;
   const bool is_nominal = thread_idz == RMPPI_NOMINAL_IDX;
   const int num_timesteps = args.num_timesteps;
   const int num_rollouts = args.num_rollouts;
@@ -204,6 +230,8 @@ __global__ void __launch_bounds__(BX * 2)
     y[i] = 0.0f;
   __syncthreads();
 
+  if (REP > 1)
+    sampling->setThreadMapping(shared_idx, BX);
   dynamics->initializeDynamics(xa, u, y, theta_s_shared, 0.0f, dt);
   sampling->initializeDistributions(y, 0.0f, dt, theta_d_shared);
   costs->initializeCosts(y, u, theta_c_shared, 0.0f, dt);
@@ -242,7 +270,8 @@ __global__ void __launch_bounds__(BX * 2)
       u[i] += fb_control[i];
     dynamics->enforceConstraints(xc, u);
     // the feedback-filled, clamped control replaces the sample (rmppi_kernels.cu:780-781)
-    sampling->writeControlSample(global_idx, t, distribution_idx, u, theta_d_shared, 1, 0, y);
+    if (rep_lane == 0)
+      sampling->writeControlSample(global_idx, t, distribution_idx, u, theta_d_shared, 1, 0, y);
     dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
     const float curr_cost = costs->computeRunningCost(y, u, t, theta_c_shared, &crash_status);
     const float lr =
@@ -315,7 +344,7 @@ __global__ void __launch_bounds__(BX * 2)
     traj_cost = 0.5f * acc_a + 0.5f * fmaxf(fminf(tracking, rargs.value_function_threshold), acc_a);
     traj_cost += acc_b;
   }
-  blockSoftminEpilogueCost<SAMPLING_T, C, BX, BZ, NTHREADS>(sampling, args, traj_cost, true, valid, global_idx, shared_idx,
+  blockSoftminEpilogueCost<SAMPLING_T, C, BX, BZ, NTHREADS>(sampling, args, traj_cost, rep_lane == 0, valid, global_idx, shared_idx,
                                                              thread_idz, tid_flat, block_idx, nrows, theta_d_shared, cost_s,
                                                              w_s);
 }

@@ -4,7 +4,8 @@ import pytest
 
 import mppi_generic_amd as m
 import pyoracle as po
-from common import cartpole_cfg_lr, di_cfg, host_noise, make_engine, make_oracle, racer_cfg, ulp_diff
+from common import (autorally_cfg, bicycle_lstm_cfg, cartpole_cfg_lr, di_cfg, host_noise, make_engine, make_oracle, racer_cfg,
+                    ulp_diff)
 
 U_TOL = 1e-5
 
@@ -16,6 +17,11 @@ def _rm_cfg(model="di", K=1024, T=40, num_iters=1):
         cfg["ranges"] = [[-3.0, 3.0], [-3.0, 3.0]]
     elif model == "racer":
         cfg = racer_cfg(K=K, T=T, num_iters=num_iters)
+        cfg["D"] = 2
+        cfg["control_cost_coeff"] = [0.2, 0.1]
+    elif model in ("autorally", "lstm"):
+        # the NN models: Robust MPPI runs them one lane per rollout and system (LDS forward)
+        cfg = autorally_cfg(K=K, T=T, num_iters=num_iters) if model == "autorally" else bicycle_lstm_cfg(K=K, T=T, num_iters=num_iters)
         cfg["D"] = 2
         cfg["control_cost_coeff"] = [0.2, 0.1]
     else:
@@ -36,6 +42,8 @@ def _make_pair(cfg, thr=1000.0, nc=9, ns=32, **kw):
     if cfg["dyn"] is not None:
         eng.setDynamicsParams(cfg["dyn"])
     eng.setCostParams(cfg["cost"])
+    for name, blob in cfg.get("blobs", {}).items():
+        eng.setModelBlob(name, blob)
     if cfg["ranges"] is not None:
         eng.setControlRanges(cfg["ranges"])
     eng.setSamplingParams(cfg["std_dev"], cfg["control_cost_coeff"])
@@ -116,7 +124,9 @@ def test_rmppi_rollout_zero_gains_identical_systems():
 @pytest.mark.gpu
 @pytest.mark.parametrize("model,acc_all,mode", [("di", False, "injected"), ("di", True, "injected"), ("di", False, "philox"),
                                                 ("racer", False, "injected"), ("racer", True, "philox"),
-                                                ("cartpole", False, "injected"), ("cartpole", False, "philox")])
+                                                ("cartpole", False, "injected"), ("cartpole", False, "philox"),
+                                                ("autorally", False, "injected"), ("autorally", True, "philox"),
+                                                ("lstm", False, "injected")])
 def test_rmppi_rollout_costs_bit_exact(gpu, model, acc_all, mode):
     cfg = _rm_cfg(model, K=1000, T=37)  # ragged last block, odd horizon
     eng, orc, rob = _make_pair(cfg, thr=40.0, save_samples=True)
@@ -143,13 +153,49 @@ def test_rmppi_rollout_costs_bit_exact(gpu, model, acc_all, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["di", "cartpole"])
+@pytest.mark.parametrize("model,T,block_x", [("autorally", 150, 0), ("di", 37, 32), ("di", 200, 0)])
+def test_rmppi_32_rollout_blocks(gpu, model, T, block_x):
+    """horizons whose sample rows for 64 rollouts x 2 systems overflow the 160 KiB of LDS run with (32, 1, 2) blocks
+    (chosen automatically, or requested): same costs, bit for bit"""
+    cfg = _rm_cfg(model, K=320, T=T)
+    eng, orc, rob = _make_pair(cfg, thr=40.0, save_samples=True, block_x=block_x)
+    S, C, K = eng.STATE_DIM, eng.CONTROL_DIM, cfg["K"]
+    g = _gains(T, S, C)
+    eng.setFeedbackGains(g)
+    rob.set_gains(g)
+    mean = (0.3 * np.sin(np.arange(T * C, dtype=np.float32) * 0.2)).reshape(T, C)
+    eng.updateImportanceSampler(mean)
+    eps = host_noise(1, K, T, C)[0]
+    eng.injectNoise(eps)
+    x0 = np.stack([cfg["x0"], cfg["x0"] + np.array([0.3, -0.2, 0.1, 0.05, 0.02, 0.01, 0.0], np.float32)[:S]])
+    got = eng.rolloutCosts(x0, 2)
+    means = np.tile(mean, (2, 1, 1))
+    v = orc.set_gaussian_controls(means, eps, 2, 0)
+    want, v_fb = rob.rollout_costs(x0, means, v)
+    assert ulp_diff(got, want).max() == 0
+    assert ulp_diff(eng.getSampledControls(), v_fb).max() == 0
+    # and a whole control computation through the merged records of the 32-rollout blocks
+    eng, orc, rob = _make_pair(cfg, thr=40.0, block_x=block_x)
+    eps2 = host_noise(2, K, T, C, seed=77)
+    eng.injectNoise(eps2[1:])
+    eng.updateImportanceSamplingControl(x0[1], 1)
+    rob.update_importance_sampling(x0[1], 1, eps2[0])
+    eng.setFeedbackGains(g)
+    rob.set_gains(g)
+    eng.computeControl(x0[1], 1)
+    rob.compute_control(x0[1], 1, eps2[1:])
+    assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
+    assert np.abs(eng.getNominalControlSeq() - orc.nominal_control()).max() <= U_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["di", "cartpole", "autorally"])
 def test_rmppi_closed_loop_parity(gpu, model):
     """updateImportanceSamplingControl (candidates, init-eval kernel, best index, slide) + computeControl over several
     steps with a disturbed real state, against the oracle"""
     cfg = _rm_cfg(model, K=1024, T=40, num_iters=2)
     nc, ns = 9, 32
-    eng, orc, rob = _make_pair(cfg, thr=25.0 if model == "di" else 2000.0, nc=nc, ns=ns)
+    eng, orc, rob = _make_pair(cfg, thr={"di": 25.0, "autorally": 500.0}.get(model, 2000.0), nc=nc, ns=ns)
     S, C, T, K = eng.STATE_DIM, eng.CONTROL_DIM, cfg["T"], cfg["K"]
     x = cfg["x0"].copy()
     used = set()
@@ -163,7 +209,8 @@ def test_rmppi_closed_loop_parity(gpu, model):
         ns_g, best_g, stride_g, fe_g = eng.getRMPPIState()
         ns_o, best_o, stride_o, fe_o = rob.state()
         assert best_g == best_o and stride_g == stride_o
-        assert np.array_equal(ns_g, ns_o)
+        # the candidates are blends of states that went through the optimised controls (equal to U_TOL, not bitwise)
+        np.testing.assert_allclose(ns_g, ns_o, rtol=1e-5, atol=1e-6)
         if not first:
             np.testing.assert_allclose(fe_g, fe_o, rtol=1e-5)
             used.add(best_g)
@@ -179,7 +226,7 @@ def test_rmppi_closed_loop_parity(gpu, model):
         assert abs(st.real_sys.baseline - so["baseline"][1]) <= 1e-5 * abs(so["baseline"][1]) + 1e-6
         # the real system drifts away from the nominal one
         x, _ = orc.model_step(x, orc.control()[0])
-        x = x + np.array([0.05, -0.03, 0.1, -0.05], np.float32)
+        x = x + np.array([0.05, -0.03, 0.1, -0.05, 0.02, 0.01, 0.0], np.float32)[:S]
     assert len(used) >= 1
 
 
@@ -194,9 +241,9 @@ def test_rmppi_error_paths(gpu):
         with pytest.raises(m.MPPIError) as e:
             eng.setRMPPIParams(1000.0, bad, 32)
         assert e.value.status == 1 and msg in str(e.value)
-    with pytest.raises(m.MPPIError) as e:
-        m.RobustMPPIController("autorally_nn", 512, 20, 0.02, 1.0)
-    assert e.value.status == 10
+    with pytest.raises(m.MPPIError) as e:  # the Robust kernels have one shape: (64 rollouts, 1 lane, 2 systems)
+        m.RobustMPPIController("autorally_nn", 512, 20, 0.02, 1.0, block_x=64, block_y=4)
+    assert e.value.status == 5
     v = m.VanillaMPPIController("cartpole", 128, 10, 0.02, 1.0)
     with pytest.raises(m.MPPIError) as e:
         v._check(v._lib.mppi_set_feedback_gains(v._h, np.zeros(40, np.float32), 0))
