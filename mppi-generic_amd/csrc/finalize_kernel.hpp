@@ -57,20 +57,32 @@ __host__ inline size_t finalizeSharedBytes(const DYN_T& dyn, int num_timesteps, 
   return n;
 }
 
-template <class DYN_T, int BY>
-__global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const FinalizeArgs a)
+/** x extent of finalizeKernel's block: with one contract lane (BY == 1) the block is a whole wave — lane 0 carries the
+ *  trajectory (a serial chain), all 64 lanes share the element-wise passes around it (history copy, 5-tap smoothing,
+ *  per-column constraints, write-out), which as one lane's serial loops were ~40 % of the kernel */
+__host__ __device__ constexpr int finalizeBlockX(int by)
 {
-  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == 1);
+  return by == 1 ? 64 : 1;
+}
+
+template <class DYN_T, int BY>
+__global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T dynamics_obj, const FinalizeArgs a)
+{
+  constexpr int LX = finalizeBlockX(BY);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == LX);
   __builtin_assume(__builtin_amdgcn_workgroup_size_y() == BY);
   __builtin_assume(__builtin_amdgcn_workgroup_size_z() == 1);
-  __builtin_assume(__builtin_amdgcn_workitem_id_x() == 0);
+  __builtin_assume(__builtin_amdgcn_workitem_id_x() < LX);
   __builtin_assume(__builtin_amdgcn_workitem_id_y() < BY);
   __builtin_assume(__builtin_amdgcn_workitem_id_z() == 0);
   DYN_T* dynamics = &dynamics_obj;
   constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
   const int T = a.num_timesteps;
   const int z = (int)blockIdx.x;
-  const int ty = (int)__builtin_amdgcn_workitem_id_y();
+  const int lx = (int)__builtin_amdgcn_workitem_id_x();
+  // index / stride of the element-wise loops: the y lanes of the contract variant, the 64 x lanes of the BY == 1 variant
+  const int ty = (BY == 1) ? lx : (int)__builtin_amdgcn_workitem_id_y();
+  constexpr int NL = BY * LX;
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* theta_s = reinterpret_cast<float*>(smem_raw);
@@ -89,19 +101,19 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
 
   if ((a.smooth_mask >> z) & 1)
   {
-    for (int i = ty; i < C; i += BY)
+    for (int i = ty; i < C; i += NL)
     {
       buf[0 * C + i] = a.history_d[z * a.history_stride + 0 * C + i];
       buf[1 * C + i] = a.history_d[z * a.history_stride + 1 * C + i];
       buf[(T + 2) * C + i] = uin[(T - 1) * C + i];
       buf[(T + 3) * C + i] = uin[(T - 1) * C + i];
     }
-    for (int e = ty; e < T * C; e += BY)
+    for (int e = ty; e < T * C; e += NL)
       buf[2 * C + e] = uin[e];
     __syncthreads();
     // filter_coefficients << -3, 12, 17, 12, -3; filter_coefficients /= 35.0  (controller.cuh:564-566)
     const float c0 = (float)(-3.0 / 35.0), c1 = (float)(12.0 / 35.0), c2 = (float)(17.0 / 35.0);
-    for (int e = ty; e < T * C; e += BY)
+    for (int e = ty; e < T * C; e += NL)
     {
       float acc = c0 * buf[e];
       acc += c1 * buf[e + C];
@@ -113,11 +125,14 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
   }
   else
   {
-    for (int e = ty; e < T * C; e += BY)
+    for (int e = ty; e < T * C; e += NL)
       ctrl[e] = uin[e];
   }
   if constexpr (BY == 1)
   {
+    __syncthreads();  // ctrl is complete
+    if (lx == 0)
+    {
     // One lane per rollout: the whole trajectory is one thread's serial chain, so the state lives in registers and there
     // is nothing to synchronise with (the LDS-resident variant below spent ~0.55 us per step on LDS round trips and
     // barriers; this one ~0.2 us — the kernel is most of what mppi_compute_control costs beyond the iteration itself).
@@ -165,6 +180,8 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
           a.output_out_d[((size_t)z * T + t + 1) * O + i] = yr[i];
       }
     }
+    }
+    __syncthreads();  // zero_state
   }
   else
   {
@@ -217,19 +234,20 @@ __global__ void __launch_bounds__(BY) finalizeKernel(DYN_T dynamics_obj, const F
     if (a.constrain_mode == 1)
     {
       if constexpr (C > 1)
-        for (int t = ty; t < T; t += BY)
+        for (int t = ty; t < T; t += NL)
           ctrl[t * C + 1] = fminf(fmaxf(ctrl[t * C + 1], dynamics->control_rngs_[1].x), dynamics->control_rngs_[1].y);
     }
     else
     {
-      for (int t = 0; t < T; t++)
+      // BY == 1: one column per lane; contract variant: every y lane takes its share of each column
+      for (int t = (BY == 1) ? lx : 0; t < T; t += LX)
       {
         dynamics->enforceConstraints(zero_state, &ctrl[t * C]);
       }
     }
   }
   __syncthreads();
-  for (int e = ty; e < T * C; e += BY)
+  for (int e = ty; e < T * C; e += NL)
     a.control_out_d[(size_t)z * T * C + e] = ctrl[e];
 }
 

@@ -969,7 +969,7 @@ struct ModelT : ModelBase
     if (smem > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem);
-    hipLaunchKernelGGL(kfn, dim3(D), dim3(1, FIN_BY, 1), smem, stream, dyn, a);
+    hipLaunchKernelGGL(kfn, dim3(D), dim3(kernels::finalizeBlockX(FIN_BY), FIN_BY, 1), smem, stream, dyn, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
     {
