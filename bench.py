@@ -61,6 +61,24 @@ def pmc_traffic(kernel_prefix):
     return None
 
 
+def pmc_pipe_util(kernel_prefix):
+    """{"mfma_util_percent", "valu_busy_percent"} of the kernel from the committed SQ counter pass
+    (tools/profile_bench.sh + tools/pmc_mfma_summary.py -> profiles/r*_pmc_mfma_valu.json), or None"""
+    import glob
+    try:
+        files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_mfma_valu.json")))
+        d = json.load(open(files[-1]))
+        for name, e in d["kernels"].items():
+            if name.startswith(kernel_prefix):
+                return {"mfma_util_percent": round(e.get("MfmaUtil_percent", 0.0), 2),
+                        "valu_busy_percent": round(e.get("VALUBusy_percent", 0.0), 2),
+                        "source": os.path.relpath(files[-1], REPO) + " (SQ_VALU_MFMA_BUSY_CYCLES, SQ_ACTIVE_INST_VALU, "
+                                  "GRBM_GUI_ACTIVE)"}
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
 def cpu_baseline(cfg, budget_s=12.0):
     """oracle iterations/s on the host cores, bounded sample (never the thing shipped or measured as `value`)"""
     import numpy as np
@@ -113,6 +131,7 @@ def autorally_leg(device):
         "roofline": {"bound": "mfma", "kernel": "rolloutPipelineRepKernel<NeuralNetModelMFMA<7,2,3>,ARStandardCost,Gaussian,true>",
                      "achieved": round(achieved, 4), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 5),
                      "traffic": pmc_traffic("rolloutPipelineRepKernel<NeuralNetModelMFMA"),
+                     "pipe_utilisation_pmc": pmc_pipe_util("rolloutPipelineRepKernel<NeuralNetModelMFMA"),
                      "algorithmic_flops_per_launch": f_alg, "avg_kernel_us": round(roll_us, 3),
                      "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak = the fp32 vector peak; the kernel is bound by VALU "
                              "issue, not by the matrix cores: per 16 rollouts and step a dynamics wave issues 28 MFMAs and ~500 "
@@ -149,6 +168,7 @@ def lstm_colored_leg(device):
         "roofline": {"bound": "mfma", "kernel": "rolloutPipelineRepKernel<BicycleSlipLSTMMFMA,ARStandardCost,ColoredNoise,false>",
                      "achieved": round(achieved, 4), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 5),
                      "traffic": pmc_traffic("rolloutPipelineRepKernel<BicycleSlipLSTMMFMA"),
+                     "pipe_utilisation_pmc": pmc_pipe_util("rolloutPipelineRepKernel<BicycleSlipLSTMMFMA"),
                      "algorithmic_flops_per_launch": f_net + f_noise,
                      "algorithmic_flops_network": f_net, "algorithmic_flops_colored_noise_gemm": f_noise,
                      "avg_kernel_us": round(roll_us, 3),
@@ -317,6 +337,7 @@ def main():
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": pmc_traffic("rolloutPipelineKernel<CartpoleDynamics"),
+                "pipe_utilisation_pmc": pmc_pipe_util("rolloutPipelineKernel<CartpoleDynamics"),
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, " + PMC_FILE + " "
                                   "(2*FETCH_SIZE + WRITE_SIZE): the sample tensor never reaches HBM, so traffic << algorithmic bytes",
                 "algorithmic_bytes_per_launch": b_alg, "avg_kernel_us": round(roll_us, 3),

@@ -9,3 +9,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/pmc_write -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/prof/pmc_write.log 2>&1
 find gpurun_out/prof -type f | head -50
 for f in $(find gpurun_out/prof -name "*.csv" | head -12); do echo "== $f"; head -3 $f | cut -c1-400; done
+# matrix / vector pipe utilisation of the rollout kernels (tools/pmc_mfma_summary.py)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/prof/pmc_mfma -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline > gpurun_out/prof/pmc_mfma.log 2>&1
