@@ -119,6 +119,25 @@ def test_vanilla_compute_control_parity(gpu, soft):
         assert so["normalizer"][0] > 10.0  # the average really involves many rollouts
 
 
+@pytest.mark.parametrize("T", [1, 2, 3, 5, 63, 64, 65, 129])
+def test_compute_control_short_and_odd_horizons(gpu, T):
+    """the post-processing pass (smoothing over [history | u | last, last], T - 1 re-rollout steps, per-column
+    constraints, write-out shared by the 64 lanes of a wave) at horizons around its loop strides, down to T = 1;
+    Cartpole and the two-system Double Integrator (Tube)"""
+    for cfg, tube in ((cartpole_cfg(K=256, T=T, soft=True), False), (di_cfg(K=256, T=T, tube=True), True)):
+        C = len(cfg["std_dev"])
+        eps = host_noise(1, cfg["K"], T, C, seed=5)
+        eng, orc = make_engine(cfg), make_oracle(cfg)
+        eng.injectNoise(eps)
+        eng.computeControl(cfg["x0"], 1)
+        if tube:
+            orc.tube_compute_control(cfg["x0"], 1, eps)
+        else:
+            orc.vanilla_compute_control(cfg["x0"], 1, eps)
+        assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
+        assert np.abs(eng.getTargetStateSeq() - orc.state_traj()).max() <= 1e-4
+
+
 def test_vanilla_multi_iteration_and_closed_loop(gpu):
     """num_iters = 3 and a 15-step closed loop with slideControlSequence (examples/cartpole_example.cu:63-85)"""
     cfg = cartpole_cfg(K=1024, T=60, soft=True, num_iters=3)
