@@ -315,9 +315,35 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     h->pipeline = false;
     lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, false);
   }
+  if (lds > MAX_LDS_BYTES && cfg->block_x == 0 && cfg->block_y == 0 && cfg->controller != MPPI_CONTROLLER_ROBUST &&
+      cfg->kernel_variant != MPPI_KERNEL_PIPELINE)
+  {
+    // Long horizons: the sample rows of the default block (T * C floats per rollout and system) do not fit the 160 KiB of
+    // LDS.  No shape was requested, so take the registered shape with the most rollouts per block that does fit (fused
+    // variant; the reference keeps its samples in global memory and has no such limit — here they never leave the CU).
+    std::vector<int> shapes;
+    h->model->listShapes(shapes);
+    int best = -1;
+    for (size_t i = 0; i + 2 < shapes.size(); i += 3)
+    {
+      if (shapes[i + 2] != h->bz)
+        continue;
+      const size_t need = h->model->rolloutSharedBytes(shapes[i], shapes[i + 1], shapes[i + 2], cfg->num_timesteps, h->D, false);
+      if (need <= MAX_LDS_BYTES && (best < 0 || shapes[i] > shapes[best]))
+        best = (int)i;
+    }
+    if (best >= 0)
+    {
+      h->bx = shapes[best];
+      h->by = shapes[best + 1];
+      h->pipeline = false;
+      lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, false);
+    }
+  }
   if (lds > MAX_LDS_BYTES)
     return fail(nullptr, MPPI_ERR_LDS_OVERFLOW,
-                "mppi_create: rollout kernel needs " + std::to_string(lds) + " B of LDS per block (max 163840)");
+                "mppi_create: rollout kernel needs " + std::to_string(lds) + " B of LDS per block (max 163840) — the sample "
+                "rows of a block live in LDS; shorten the horizon or register a block shape with fewer rollouts");
   h->num_blocks = (h->K_local + h->bx - 1) / h->bx;
   h->TC = cfg->num_timesteps * h->C;
   h->PS = kernels::partialStride(cfg->num_timesteps, h->C);

@@ -132,6 +132,8 @@ struct ModelBase
     return false;
   }
   virtual size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D, bool pipeline) = 0;
+  /** every registered block shape as (bx, by, bz) triples, flattened */
+  virtual void listShapes(std::vector<int>& out) const = 0;
   virtual mppi_status launchRollout(int bx, int by, int bz, bool pipeline, const kernels::RolloutArgs& args,
                                     const SamplerLaunchState& s, hipStream_t stream, std::string& err) = 0;
   virtual mppi_status launchFinalize(int D, const kernels::FinalizeArgs& a, hipStream_t stream, std::string& err) = 0;
@@ -769,6 +771,22 @@ struct ModelT : ModelBase
   bool supportsShape(int bx, int by, int bz) const override
   {
     return hasShape(SHAPES{}, bx, by, bz) || hasShape(FAST_SHAPES{}, bx, by, bz);
+  }
+  template <int X, int Y, int Z, class... Rest>
+  static void appendShapes(Shapes<Shape<X, Y, Z>, Rest...>, std::vector<int>& out)
+  {
+    out.push_back(X);
+    out.push_back(Y);
+    out.push_back(Z);
+    appendShapes(Shapes<Rest...>{}, out);
+  }
+  static void appendShapes(Shapes<>, std::vector<int>&)
+  {
+  }
+  void listShapes(std::vector<int>& out) const override
+  {
+    appendShapes(FAST_SHAPES{}, out);  // the MFMA shapes first: preferred at equal rollouts per block
+    appendShapes(SHAPES{}, out);
   }
 
   void prepSampler(const SamplerLaunchState& s)

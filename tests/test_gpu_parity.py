@@ -138,6 +138,26 @@ def test_compute_control_short_and_odd_horizons(gpu, T):
         assert np.abs(eng.getTargetStateSeq() - orc.state_traj()).max() <= 1e-4
 
 
+def test_long_horizon_picks_a_smaller_block(gpu):
+    """T * C floats per rollout live in LDS: when the default block's rows do not fit the 160 KiB, mppi_create takes the
+    registered shape with the most rollouts per block that does (the reference has no such limit: samples in HBM)"""
+    cfg = cartpole_cfg(K=300, T=700, soft=True)
+    eps = host_noise(1, cfg["K"], cfg["T"], 1, seed=3)
+    eng, orc = make_engine(cfg), make_oracle(cfg)
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    orc.vanilla_compute_control(cfg["x0"], 1, eps)
+    assert ulp_diff(eng.getSampledCostSeq(), orc.costs()).max() == 0
+    assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
+    import mppi_generic_amd as m
+    with pytest.raises(m.MPPIError) as e:  # an explicit shape is honoured, not replaced
+        make_engine(cfg, block_x=64, block_y=1)
+    assert e.value.status == 6
+    with pytest.raises(m.MPPIError) as e:  # nothing registered fits
+        make_engine(cartpole_cfg(K=300, T=20000))
+    assert e.value.status == 6 and "horizon" in str(e.value)
+
+
 def test_vanilla_multi_iteration_and_closed_loop(gpu):
     """num_iters = 3 and a 15-step closed loop with slideControlSequence (examples/cartpole_example.cu:63-85)"""
     cfg = cartpole_cfg(K=1024, T=60, soft=True, num_iters=3)
