@@ -50,7 +50,7 @@ using ARModel = ModelT<ARModelDyn, ARStandardCost, ARSampler,
                        Shapes<Shape<8, 16, 1>, Shape<16, 8, 1>, Shape<16, 4, 1>, Shape<64, 1, 1>, Shape<8, 16, 2>>,
                        /*FIN_BY=*/32,
                        /* MFMA forward: BX rollouts x 4 k-group lanes per block (BX/16 waves) */
-                       NeuralNetModelMFMA<7, 2, 3>, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>, Shape<64, 4, 2>>,
+                       NeuralNetModelMFMA<7, 2, 3>, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>, Shape<64, 4, 2>, Shape<32, 4, 2>>,
                        /*PIPELINE=*/false, /*RMPPI=*/true>;  // Robust MPPI runs on the MFMA forward too
 
 /* LSTM bicycle-slip dynamics (BASELINE config 5): LSTM(6, 16) + MLP {22, 32, 4}, AutoRally state layout and cost.
@@ -58,7 +58,7 @@ using ARModel = ModelT<ARModelDyn, ARStandardCost, ARSampler,
 using BSLSampler = sampling_distributions::GaussianDistribution<BicycleSlipLSTMParams>;
 using BSLModel = ModelT<BicycleSlipLSTM, ARStandardCost, BSLSampler,
                         Shapes<Shape<16, 8, 1>, Shape<16, 4, 1>, Shape<64, 1, 1>, Shape<8, 16, 1>, Shape<16, 8, 2>>,
-                        /*FIN_BY=*/32, BicycleSlipLSTMMFMA, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>, Shape<64, 4, 2>>,
+                        /*FIN_BY=*/32, BicycleSlipLSTMMFMA, Shapes<Shape<64, 4, 1>, Shape<32, 4, 1>, Shape<64, 4, 2>, Shape<32, 4, 2>>,
                         /*PIPELINE=*/false, /*RMPPI=*/true>;
 
 /* RACER Dubins car + QuadraticCost over its 28 outputs (dynamics/racer_dubins/racer_dubins.cuh,

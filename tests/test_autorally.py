@@ -148,6 +148,26 @@ def test_autorally_compute_control_parity(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("block_x", [64, 32])
+def test_autorally_tube_parity(gpu, block_x):
+    """Tube-MPPI on the NN model: actual + nominal system in one launch on the MFMA forward, blocks of 64 or 32 rollouts
+    (the latter is what long horizons fall back to); reference: controllers/Tube-MPPI/tube_mppi_controller.cu:157-299"""
+    cfg = autorally_cfg(K=512, T=40, num_iters=1)
+    cfg["D"] = 2
+    eng, orc = make_engine(cfg, block_x=block_x, block_y=4), make_oracle(cfg)
+    x = cfg["x0"].copy()
+    for i in range(3):
+        eps = host_noise(1, cfg["K"], cfg["T"], 2, seed=21 + i)
+        eng.injectNoise(eps)
+        eng.computeControl(x, 1)
+        orc.tube_compute_control(x, 1, eps)
+        assert np.abs(eng.getControlSeq() - orc.control()).max() <= 1e-5
+        assert np.abs(eng.getNominalControlSeq() - orc.nominal_control()).max() <= 1e-5
+        assert np.abs(eng.getTargetStateSeq() - orc.state_traj()).max() <= 1e-4
+        x = x + np.array([0.02, -0.01, 0.01, 0.0, 0.05, 0.0, 0.0], np.float32)  # the actual state drifts off the nominal
+
+
+@pytest.mark.gpu
 def test_autorally_requires_blobs(gpu):
     import mppi_generic_amd as m
     c = m.VanillaMPPIController("autorally_nn", 128, 10, 0.02, 1.0)
