@@ -34,12 +34,14 @@ namespace engine
 {
 using CartpoleSampler = sampling_distributions::GaussianDistribution<CartpoleDynamicsParams>;
 using CartpoleModel = ModelT<CartpoleDynamics, CartpoleQuadraticCost, CartpoleSampler,
-                             Shapes<Shape<64, 1, 1>, Shape<64, 1, 2>, Shape<32, 1, 1>, Shape<64, 4, 1>, Shape<16, 4, 1>>,
+                             Shapes<Shape<64, 1, 1>, Shape<64, 1, 2>, Shape<32, 1, 1>, Shape<64, 4, 1>, Shape<16, 4, 1>,
+                                    /* long horizons (the sample rows of a block live in LDS): */ Shape<16, 1, 1>, Shape<16, 1, 2>>,
                              /*FIN_BY=*/1, void, Shapes<>, /*PIPELINE=*/true, /*RMPPI=*/true>;
 
 using DISampler = sampling_distributions::GaussianDistribution<DoubleIntegratorParams>;
 using DIModel = ModelT<DoubleIntegratorDynamics, DoubleIntegratorCircleCost, DISampler,
-                       Shapes<Shape<64, 1, 1>, Shape<64, 1, 2>, Shape<32, 2, 2>, Shape<64, 2, 1>>, /*FIN_BY=*/1, void,
+                       Shapes<Shape<64, 1, 1>, Shape<64, 1, 2>, Shape<32, 2, 2>, Shape<64, 2, 1>, Shape<16, 1, 1>, Shape<16, 1, 2>>,
+                       /*FIN_BY=*/1, void,
                        Shapes<>, /*PIPELINE=*/true, /*RMPPI=*/true>;
 
 /* AutoRally: MLP dynamics + costmap cost (reference: instantiations/autorally_mppi/autorally_mppi.cuh:10-13 uses
@@ -65,7 +67,8 @@ using BSLModel = ModelT<BicycleSlipLSTM, ARStandardCost, BSLSampler,
  * cost_functions/quadratic_cost/quadratic_cost.cuh) */
 using RacerSampler = sampling_distributions::GaussianDistribution<RacerDubinsParams>;
 using RacerDubinsModel = ModelT<RacerDubins, QuadraticCost<RacerDubins>, RacerSampler,
-                                Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/1, void, Shapes<>,
+                                Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>, Shape<16, 1, 1>, Shape<16, 1, 2>>, /*FIN_BY=*/1,
+                                void, Shapes<>,
                                 /*PIPELINE=*/true, /*RMPPI=*/true>;
 using RacerDubinsColoredModel =
     ModelT<RacerDubins, QuadraticCost<RacerDubins>, sampling_distributions::ColoredNoiseDistribution<RacerDubinsParams>,
