@@ -420,8 +420,8 @@ struct ModelT : ModelBase
       if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem);
-      hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * (REP + kernels::PIPE_REP_SAMPLERS + kernels::PIPE_REP_COSTS), 1, 1), smem, stream, fast, cost, smp,
-                         args, ring);
+      constexpr int WAVES = REP + kernels::PIPE_REP_SAMPLERS + kernels::PIPE_REP_COSTS;  // dynamics + helper waves
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WAVES, 1, 1), smem, stream, fast, cost, smp, args, ring);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess)
       {
