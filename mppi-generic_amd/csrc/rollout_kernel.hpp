@@ -380,6 +380,164 @@ __global__ void __launch_bounds__(BX* BY* BZ* replicated_lanes<DYN_T>::value)
   constexpr int QUADS = STEPS * C / 4;
   static_assert(STEPS * C % 4 == 0, "a loop trip must consume whole quads");
   int t = 0;
+  if constexpr (REP > 1 && REP % 2 == 0)
+  {
+    /* Replicated-lane (MFMA) dynamics: a wave holds its 64 / REP rollouts REP times over, and only the dynamics need the
+     * replicas — one_step() would shape the sample and evaluate the cost REP times redundantly.  Instead the replicas
+     * share that work in TIME:
+     *   - sampler: lane (rollout j, replica r) shapes, clamps and stores the samples of steps t0 + STEPS * r .. of
+     *     rollout j — one pass per STEPS * REP steps with all 64 lanes busy;
+     *   - cost: after REP dynamics steps lane (j, r) evaluates the cost of step t + r from the outputs the wave kept.
+     *     The running cost is accumulated in step order from the replicas (REP cross-lane reads): the sum the
+     *     sequential code forms, bit for bit.
+     * The plugin contract threads an integer status (crash flags) through computeRunningCost: step t + r must see what
+     * steps t .. t + r - 1 left behind.  The slices run with the status at the start of the group; if one of the first
+     * REP - 1 slices CHANGES it, the wave redoes that group step by step on every lane — for the sticky flags of the
+     * reference's costs at most once per rollout.  (computeRunningCost has to be a pure function of output, control, t
+     * and status, which the reference's cost classes are.)  AutoRally-NN, K = 16384, T = 150: 355 -> 257 us. */
+    static_assert(BY == 1, "replicated lanes run with one contract lane");
+    constexpr int PER_WAVE = 64 / REP;
+    constexpr bool SMP_CONSTRAINS = !DYN_T::CONSTRAINTS_DEPEND_ON_STATE;
+    constexpr int SGROUP = STEPS * REP;  // steps one sampling pass of the wave covers
+    const int col = (tid_x & 63) % PER_WAVE;
+    float* row = sampling->sampleRow(theta_d_shared, shared_idx);
+    auto sample_pass = [&](const int t0) {
+      const int ts = t0 + STEPS * rep_lane;
+      float zq[4 * QUADS], us[C];
+      if (DRAW_IN_LOOP)
+      {
+#pragma unroll
+        for (int q = 0; q < QUADS; q++)
+          sampling->drawQuad(global_idx, ts * C / 4 + q, &zq[4 * q]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < STEPS; s2++)
+      {
+        if (ts + s2 < num_timesteps)
+        {
+          if (DRAW_IN_LOOP)
+            sampling->shapeControlSample(global_idx, ts + s2, distribution_idx, &zq[s2 * C], us);
+          else
+            sampling->readControlSample(global_idx, ts + s2, distribution_idx, us, theta_d_shared, 1, 0, y);
+          if (SMP_CONSTRAINS)
+            dynamics->enforceConstraints(x, us);
+          sampling->writeControlSample(global_idx, ts + s2, distribution_idx, us, theta_d_shared, 1, 0, y);
+        }
+      }
+      // the other replicas of the rollout read these rows: LDS operations of a wave execute in order, the fence keeps
+      // the compiler (which reasons per lane) from moving a lane's row reads above its own, differently addressed, stores
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    };
+    auto dyn_step = [&](float* xc, float* xn, int tt, const float* u_in) {
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        u[i] = u_in[i];
+      if (!SMP_CONSTRAINS)
+      {
+        dynamics->enforceConstraints(xc, u);
+        if (rep_lane == 0)
+        {
+#pragma unroll
+          for (int i = 0; i < C; i++)
+            row[tt * C + i] = u[i];
+        }
+      }
+      dynamics->step(xc, xn, xdot, u, y, theta_s_shared, tt, dt);
+    };
+    auto step_cost = [&](float* ys, int tt, int* status) {
+      float us[C];
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        us[i] = row[tt * C + i];
+      return costs->computeRunningCost(ys, us, tt, theta_c_shared, status) +
+             sampling->computeLikelihoodRatioCost(us, theta_d_shared, global_idx, tt, distribution_idx, args.lambda,
+                                                  args.alpha);
+    };
+    int sampled = 0;  // steps whose shaped samples are in the rows (a multiple of SGROUP, hence of REP)
+    for (; t + REP <= num_timesteps; t += REP)
+    {
+      if (t >= sampled)
+      {
+        sample_pass(sampled);
+        sampled += SGROUP;
+      }
+      float ubuf[REP * C];
+#pragma unroll
+      for (int j = 0; j < REP * C; j++)
+        ubuf[j] = row[t * C + j];
+      float ybuf[REP][O];
+#pragma unroll
+      for (int r = 0; r < REP; r += 2)
+      {
+        dyn_step(x, x_next, t + r, &ubuf[r * C]);
+#pragma unroll
+        for (int i = 0; i < O; i++)
+          ybuf[r][i] = y[i];
+        dyn_step(x_next, x, t + r + 1, &ubuf[(r + 1) * C]);
+#pragma unroll
+        for (int i = 0; i < O; i++)
+          ybuf[r + 1][i] = y[i];
+      }
+      if (!SMP_CONSTRAINS)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // replica 0 stored the clamped controls
+      float ys[O];
+#pragma unroll
+      for (int i = 0; i < O; i++)
+      {
+        ys[i] = ybuf[0][i];
+#pragma unroll
+        for (int r = 1; r < REP; r++)
+          ys[i] = (rep_lane == r) ? ybuf[r][i] : ys[i];
+      }
+      int status = crash_status[0];
+      const float val = step_cost(ys, t + rep_lane, &status);
+      const bool stale = (rep_lane < REP - 1) && (status != crash_status[0]);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(stale) != 0, 0))
+      {
+        // a slice changed the status under a later slice of the same group: this group again, in order, on every lane
+#pragma nounroll
+        for (int r = 0; r < REP; r++)
+        {
+#pragma unroll
+          for (int i = 0; i < O; i++)
+          {
+            ys[i] = ybuf[0][i];
+#pragma unroll
+            for (int q = 1; q < REP; q++)
+              ys[i] = (r == q) ? ybuf[q][i] : ys[i];
+          }
+          running_cost += step_cost(ys, t + r, crash_status);
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int r = 0; r < REP; r++)
+          running_cost += __shfl(val, r * PER_WAVE + col, 64);
+        crash_status[0] = __shfl(status, (REP - 1) * PER_WAVE + col, 64);
+      }
+    }
+    // the last num_timesteps % REP steps: step by step, cost on every lane
+    for (; t < num_timesteps; t++)
+    {
+      if (t >= sampled)
+      {
+        sample_pass(sampled);
+        sampled += SGROUP;
+      }
+      float ubuf[C];
+#pragma unroll
+      for (int j = 0; j < C; j++)
+        ubuf[j] = row[t * C + j];
+      dyn_step(x, x_next, t, ubuf);
+#pragma unroll
+      for (int i = 0; i < S; i++)
+        x[i] = x_next[i];
+      running_cost += step_cost(y, t, crash_status);
+    }
+  }
+  else
+  {
   for (; t + STEPS - 1 < num_timesteps; t += STEPS)
   {
     float zq[4 * QUADS];
@@ -416,6 +574,8 @@ __global__ void __launch_bounds__(BX* BY* BZ* replicated_lanes<DYN_T>::value)
         one_step(x, x_next, t + 2, &zq[(STEPS > 2 ? 2 : 0) * C]);
     }
     // (an odd number of steps leaves the newest state in x_next; the epilogue reads y, the output, not x)
+  }
+
   }
 
   /* ---- cost of the rollout: sum over the y lanes, running/T + terminal/T ---- */
