@@ -239,7 +239,8 @@ __global__ void __launch_bounds__(BX * 2 * replicated_lanes<DYN_T>::value)
   __syncthreads();
 
   float acc_a = 0.0f, acc_b = 0.0f;
-  auto one_step = [&](float* xc, float* xn, int t, const float* eps) {
+  // one step up to and including the dynamics; leaves the clamped control in u and the feedback term in fb_control
+  auto step_core = [&](float* xc, float* xn, int t, const float* eps) {
     if (DRAW_IN_LOOP)
       sampling->shapeControlSample(global_idx, t, distribution_idx, eps, u);
     else
@@ -273,24 +274,127 @@ __global__ void __launch_bounds__(BX * 2 * replicated_lanes<DYN_T>::value)
     if (rep_lane == 0)
       sampling->writeControlSample(global_idx, t, distribution_idx, u, theta_d_shared, 1, 0, y);
     dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
-    const float curr_cost = costs->computeRunningCost(y, u, t, theta_c_shared, &crash_status);
+  };
+  // what step tt adds to the two accumulators of this lane's system (rmppi_kernels.cu:797-812)
+  auto cost_terms = [&](float* ys, float* us, float* fbs, int tt, int* status, float& da, float& db) {
+    const float curr_cost = costs->computeRunningCost(ys, us, tt, theta_c_shared, status);
     const float lr =
-        sampling->computeLikelihoodRatioCost(u, theta_d_shared, global_idx, t, distribution_idx, args.lambda, args.alpha);
+        sampling->computeLikelihoodRatioCost(us, theta_d_shared, global_idx, tt, distribution_idx, args.lambda, args.alpha);
     if (is_nominal)
     {
-      acc_a += curr_cost;
-      acc_b += lr;
+      da = curr_cost;
+      db = lr;
     }
     else
     {
-      acc_a += curr_cost + lr;
-      acc_b += curr_cost +
-               sampling->computeFeedbackCost(fb_control, theta_d_shared, t, distribution_idx, args.lambda, args.alpha);
+      da = curr_cost + lr;
+      db = curr_cost + sampling->computeFeedbackCost(fbs, theta_d_shared, tt, distribution_idx, args.lambda, args.alpha);
     }
+  };
+  auto one_step = [&](float* xc, float* xn, int t, const float* eps) {
+    step_core(xc, xn, t, eps);
+    float da, db;
+    cost_terms(y, u, fb_control, t, &crash_status, da, db);
+    acc_a += da;
+    acc_b += db;
   };
   constexpr int STEPS = (C % 2 == 0) ? 2 : 4;
   constexpr int QUADS = STEPS * C / 4;
   int t = 0;
+  if constexpr (REP > 1 && REP % STEPS == 0)
+  {
+    // Replicated-lane (MFMA) dynamics: the REP replicas of a rollout would evaluate every step's cost terms REP times.
+    // Instead the wave keeps the outputs, clamped controls and feedback terms of REP steps and replica r evaluates step
+    // t + r; the accumulators then take the REP contributions in step order (cross-lane reads), bit for bit the sum the
+    // sequential code forms.  The status word is handled as in rolloutKernel: slices run with the status at the start of
+    // the group, and a group in which one of the first REP - 1 slices changes it is redone in order on every lane.
+    // (The sample shaping stays per step: the feedback term makes the control depend on the state.)
+    constexpr int PER_WAVE = 64 / REP;
+    const int col = (tid_x & 63) % PER_WAVE;
+    for (; t + REP <= num_timesteps; t += REP)
+    {
+      float ybuf[REP][O], ubuf[REP][C], fbuf[REP][C];
+      auto keep = [&](const int r) {
+#pragma unroll
+        for (int i = 0; i < O; i++)
+          ybuf[r][i] = y[i];
+#pragma unroll
+        for (int i = 0; i < C; i++)
+        {
+          ubuf[r][i] = u[i];
+          fbuf[r][i] = fb_control[i];
+        }
+      };
+#pragma unroll
+      for (int g = 0; g < REP; g += STEPS)
+      {
+        float zq[4 * QUADS];
+        if (DRAW_IN_LOOP)
+        {
+#pragma unroll
+          for (int q = 0; q < QUADS; q++)
+            sampling->drawQuad(global_idx, (t + g) * C / 4 + q, &zq[4 * q]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < STEPS; s2 += 2)
+        {
+          step_core(xa, xb, t + g + s2, &zq[s2 * C]);
+          keep(g + s2);
+          step_core(xb, xa, t + g + s2 + 1, &zq[(s2 + 1) * C]);
+          keep(g + s2 + 1);
+        }
+      }
+      float ys[O], us[C], fbs[C];
+      auto pick = [&](const int r) {  // this lane's copy of step t + r (r may be per-lane)
+#pragma unroll
+        for (int i = 0; i < O; i++)
+        {
+          ys[i] = ybuf[0][i];
+#pragma unroll
+          for (int q = 1; q < REP; q++)
+            ys[i] = (r == q) ? ybuf[q][i] : ys[i];
+        }
+#pragma unroll
+        for (int i = 0; i < C; i++)
+        {
+          us[i] = ubuf[0][i];
+          fbs[i] = fbuf[0][i];
+#pragma unroll
+          for (int q = 1; q < REP; q++)
+          {
+            us[i] = (r == q) ? ubuf[q][i] : us[i];
+            fbs[i] = (r == q) ? fbuf[q][i] : fbs[i];
+          }
+        }
+      };
+      pick(rep_lane);
+      int status = crash_status;
+      float da, db;
+      cost_terms(ys, us, fbs, t + rep_lane, &status, da, db);
+      const bool stale = (rep_lane < REP - 1) && (status != crash_status);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(stale) != 0, 0))
+      {
+#pragma nounroll
+        for (int r = 0; r < REP; r++)
+        {
+          pick(r);
+          cost_terms(ys, us, fbs, t + r, &crash_status, da, db);
+          acc_a += da;
+          acc_b += db;
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int r = 0; r < REP; r++)
+        {
+          acc_a += __shfl(da, r * PER_WAVE + col, 64);
+          acc_b += __shfl(db, r * PER_WAVE + col, 64);
+        }
+        crash_status = __shfl(status, (REP - 1) * PER_WAVE + col, 64);
+      }
+    }
+  }
   for (; t + STEPS - 1 < num_timesteps; t += STEPS)
   {
     float zq[4 * QUADS];
