@@ -79,8 +79,8 @@ typedef enum mppi_noise_source
 typedef enum mppi_kernel_variant
 {
   MPPI_KERNEL_AUTO = 0,     /* pipeline where the model is registered for it and the block shape is (64, 1), else fused */
-  MPPI_KERNEL_FUSED = 1,    /* one wave carries sampling, dynamics and cost of its rollouts (csrc/rollout_kernel.hpp) */
-  MPPI_KERNEL_PIPELINE = 2  /* sampler / dynamics / cost waves decoupled through LDS (csrc/rollout_pipeline_kernel.hpp) */
+  MPPI_KERNEL_FUSED = 1,    /* one wave carries sampling, dynamics and cost of its rollouts (engine/rollout_kernel.hpp) */
+  MPPI_KERNEL_PIPELINE = 2  /* sampler / dynamics / cost waves decoupled through LDS (engine/rollout_pipeline_kernel.hpp) */
 } mppi_kernel_variant;
 
 /**
@@ -143,6 +143,28 @@ const char* mppi_status_string(mppi_status s);
 int mppi_device_count(void);
 /** names of the registered (DYN, COST, SAMPLER) instantiations, '\n'-separated (reference: include/mppi/instantiations/) */
 const char* mppi_list_models(void);
+/** hex digest of the sources libmppi_amd.so was built from (buildlib.py; __graft_entry__.smoke() compares it with the tree) */
+const char* mppi_source_hash(void);
+
+/* ---------------------------------------------------------------- model registration ------------------------------ */
+/**
+ * The reference's user instantiates the controller templates with their own Dynamics / Cost classes in their own
+ * translation unit (src/controllers/cartpole/cartpole_mppi.cu:30-42).  Here such a translation unit registers a factory
+ * for its ModelT<...> under a model name (include/mppi_amd/engine/model_registry.hpp: MPPI_REGISTER_MODEL) — the in-tree
+ * models do it from static initialisers of libmppi_amd.so, an out-of-tree model from a library of its own that is linked
+ * next to libmppi_amd.so or loaded with mppi_load_plugin.
+ */
+typedef enum mppi_sampler_kind
+{
+  MPPI_SAMPLER_GAUSSIAN = 0, /* used by the Vanilla / Tube / Robust controllers */
+  MPPI_SAMPLER_COLORED = 1   /* used by MPPI_CONTROLLER_COLORED */
+} mppi_sampler_kind;
+/** returns a new mppi::engine::ModelBase* (owned by the handle that asked for it) */
+typedef void* (*mppi_model_factory)(void);
+/** model_base_size = sizeof(mppi::engine::ModelBase) in the caller's build: a mismatch (header / library skew) is refused */
+mppi_status mppi_register_model(const char* name, int sampler_kind, mppi_model_factory factory, int model_base_size);
+/** dlopen()s a library whose static initialisers call mppi_register_model; the library stays loaded */
+mppi_status mppi_load_plugin(const char* path);
 
 /* ---------------------------------------------------------------- lifecycle -------------------------------------- */
 /** Controller constructor + GPUSetup + allocateCUDAMemory (controllers/controller.cuh:160-216, 269-277, 931-992) */

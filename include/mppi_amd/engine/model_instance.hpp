@@ -19,7 +19,6 @@
 
 #include "mppi_amd.h"
 #include "rollout_kernel.hpp"
-#include "reduce_kernels.hpp"
 #include "finalize_kernel.hpp"
 #include "rollout_pipeline_kernel.hpp"
 #include "rmppi_kernels.hpp"

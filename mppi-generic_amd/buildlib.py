@@ -1,60 +1,164 @@
-"""Builds libmppi_amd.so (the HIP engine + C ABI) for gfx950 with hipcc, in-tree.
+"""Builds libmppi_amd.so (the HIP engine + C ABI + the in-tree model instantiations) for gfx950 with hipcc, in-tree.
 
 hipcc cross-compiles without a GPU.  Flags that matter:
   --offload-arch=gfx950   the only target (MI355X / CDNA4)
   -ffp-contract=off       the only fused multiply-adds are the explicit det::fma() calls, so device results match the
                           CPU oracle bit for bit (include/mppi_amd/det_math.h)
+
+One object per translation unit (csrc/engine.hip + csrc/models/*.hip), compiled in parallel and cached under
+csrc/build/ with the compiler's own dependency files (-MD), then linked.  The library carries the digest of the
+sources it was built from (mppi_source_hash()); build() rebuilds whenever the tree's digest differs from the
+library's, so "the shipped .so matches the sources" is checked, not assumed.
 """
+import hashlib
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
+BUILD_DIR = os.path.join(CSRC, "build")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB = os.path.join(LIB_DIR, "libmppi_amd.so")
+INCLUDE = os.path.join(REPO, "include")
+
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+
+
+def _hipcc():
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _flags():
+    extra = os.environ.get("MPPI_HIPCC_EXTRA", "")
+    return FLAGS + (extra.split() if extra else []) + ["-I" + INCLUDE, "-I" + CSRC]
+
+
+def translation_units():
+    tus = [os.path.join(CSRC, "engine.hip")]
+    mdir = os.path.join(CSRC, "models")
+    tus += sorted(os.path.join(mdir, f) for f in os.listdir(mdir) if f.endswith(".hip"))
+    return tus
 
 
 def _sources():
     out = []
-    for root in (CSRC, os.path.join(REPO, "include")):
-        for d, _, files in os.walk(root):
+    for root in (CSRC, INCLUDE):
+        for d, dirs, files in os.walk(root):
+            dirs[:] = [x for x in dirs if x != "build"]
             for f in files:
                 if f.endswith((".hip", ".hpp", ".h")):
                     out.append(os.path.join(d, f))
-    return out
+    return sorted(out)
+
+
+def source_hash():
+    """sha256 over (relative path, contents) of every source the library is built from + the compiler flags"""
+    h = hashlib.sha256()
+    h.update(" ".join(_flags()[:len(FLAGS)] + os.environ.get("MPPI_HIPCC_EXTRA", "").split()).encode())
+    for s in _sources():
+        h.update(os.path.relpath(s, REPO).encode())
+        with open(s, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:32]
+
+
+def library_hash():
+    """the digest embedded in the built library (read from the file, without loading it)"""
+    if not os.path.exists(LIB):
+        return None
+    with open(LIB, "rb") as f:
+        blob = f.read()
+    tag = b"MPPI_AMD_SOURCE_HASH="
+    i = blob.find(tag)
+    return blob[i + len(tag):i + len(tag) + 32].decode() if i >= 0 else None
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    return library_hash() != source_hash()
+
+
+def _obj_path(tu):
+    return os.path.join(BUILD_DIR, os.path.relpath(tu, CSRC).replace(os.sep, "_") + ".o")
+
+
+def _obj_stale(tu, obj, flag_sig):
+    dep = obj + ".d"
+    sig = obj + ".flags"
+    if not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(sig)):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(s) > t for s in _sources())
+    if open(sig).read() != flag_sig:
+        return True
+    t = os.path.getmtime(obj)
+    text = open(dep).read().replace("\\\n", " ")
+    deps = text.split(":", 1)[1].split() if ":" in text else []
+    for d in deps + [tu]:
+        if not os.path.exists(d) or os.path.getmtime(d) > t:
+            return True
+    return False
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/engine.hip -> lib/libmppi_amd.so.  Returns the library path."""
-    if not force and not needs_build():
-        return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [
-        hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-        "-I" + os.path.join(REPO, "include"), "-I" + CSRC,
-        os.path.join(CSRC, "engine.hip"), "-o", LIB + ".tmp", "-ldl", "-lz",
-    ]
-    extra = os.environ.get("MPPI_HIPCC_EXTRA", "")
-    if extra:
-        cmd[1:1] = extra.split()
+def _compile(tu, verbose):
+    obj = _obj_path(tu)
+    flag_sig = " ".join(_flags())
+    if not _obj_stale(tu, obj, flag_sig):
+        return obj, 0.0
+    import time
+    t0 = time.time()
+    cmd = [_hipcc()] + _flags() + ["-MD", "-MF", obj + ".d", "-c", tu, "-o", obj]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed on %s:\n%s%s" % (tu, r.stdout, r.stderr))
+    with open(obj + ".flags", "w") as f:
+        f.write(flag_sig)
+    return obj, time.time() - t0
+
+
+def build(force=False, verbose=False, jobs=None):
+    """Compile csrc/engine.hip + csrc/models/*.hip -> lib/libmppi_amd.so.  Returns the library path."""
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    if force:
+        for f in os.listdir(BUILD_DIR):
+            os.remove(os.path.join(BUILD_DIR, f))
+    digest = source_hash()
+    hash_cpp = os.path.join(BUILD_DIR, "source_hash.cpp")
+    with open(hash_cpp, "w") as f:
+        f.write('extern "C" const char* mppi_source_hash_impl(void)\n{\n'
+                '  static const char tag[] = "MPPI_AMD_SOURCE_HASH=%s";\n  return tag + 21;\n}\n' % digest)
+    tus = translation_units()
+    jobs = jobs or int(os.environ.get("MPPI_BUILD_JOBS", "0")) or min(len(tus), os.cpu_count() or 4)
+    # the slowest units first (the NN models with their MFMA / RMPPI / pipeline instantiations)
+    order = sorted(tus, key=lambda t: (0 if ("lstm" in t or "autorally" in t) else 1, t))
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        results = list(ex.map(lambda t: _compile(t, verbose), order))
+    if verbose:
+        for (obj, dt), tu in zip(results, order):
+            print("  %-40s %6.1f s" % (os.path.basename(tu), dt), file=sys.stderr)
+    objs = [o for o, _ in results]
+    hash_obj = os.path.join(BUILD_DIR, "source_hash.o")
+    r = subprocess.run(["g++", "-O1", "-fPIC", "-c", hash_cpp, "-o", hash_obj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed on source_hash.cpp:\n" + r.stdout + r.stderr)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", hash_obj] + objs + ["-o", LIB + ".tmp", "-ldl", "-lz"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
     os.replace(LIB + ".tmp", LIB)
+    assert library_hash() == digest, "embedded source hash not found in the linked library"
     return LIB
 
 
 if __name__ == "__main__":
+    import time
+    t0 = time.time()
     print(build(force="--force" in sys.argv, verbose=True))
+    print("build took %.1f s" % (time.time() - t0), file=sys.stderr)

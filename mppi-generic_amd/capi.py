@@ -69,6 +69,9 @@ SIGNATURES = {
     "mppi_status_string": (C.c_char_p, [C.c_int]),
     "mppi_device_count": (C.c_int, []),
     "mppi_list_models": (C.c_char_p, []),
+    "mppi_source_hash": (C.c_char_p, []),
+    "mppi_register_model": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int]),
+    "mppi_load_plugin": (C.c_int, [C.c_char_p]),
     "mppi_create": (C.c_int, [C.POINTER(MppiConfig), C.POINTER(H)]),
     "mppi_destroy": (None, [H]),
     "mppi_last_error": (C.c_char_p, [H]),
@@ -162,7 +165,7 @@ def load_library(build_if_missing=True):
     if not os.path.exists(path):
         raise RuntimeError(
             "libmppi_amd.so is missing (%s); run `python mppi-generic_amd/buildlib.py` — there is no fallback path" % path)
-    lib = C.CDLL(path)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)  # plugins (mppi_load_plugin) resolve mppi_register_model against it
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError => the library does not export a declared symbol
         fn.restype = res

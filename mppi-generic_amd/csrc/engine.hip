@@ -15,14 +15,16 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "mppi_amd.h"
 #include "npz_reader.hpp"
-#include "model_instance.hpp"
-#include "models.hpp"
+#include "mppi_amd/engine/model_instance.hpp"
+#include "reduce_kernels.hpp"
 #include "mppi_amd/utils/texture_helpers/two_d_texture_helper.hpp"
 
 using namespace mppi;
@@ -30,6 +32,32 @@ using namespace mppi::engine;
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 static thread_local std::string g_create_error;
+
+/* the model table (include/mppi_amd/engine/model_registry.hpp): filled by static initialisers of the model translation
+ * units (csrc/models/[*].hip) and of out-of-tree plugins, hence a function-local static */
+struct ModelRegistry
+{
+  std::mutex mu;
+  std::map<std::pair<std::string, int>, mppi_model_factory> factories;
+  std::string listing;
+};
+static ModelRegistry& registry()
+{
+  static ModelRegistry* r = new ModelRegistry();  // never destroyed: plugins may unregister nothing at exit
+  return *r;
+}
+static ModelBase* makeModel(const std::string& name, bool colored)
+{
+  ModelRegistry& r = registry();
+  mppi_model_factory f = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(r.mu);
+    auto it = r.factories.find({ name, colored ? MPPI_SAMPLER_COLORED : MPPI_SAMPLER_GAUSSIAN });
+    if (it != r.factories.end())
+      f = it->second;
+  }
+  return f ? static_cast<ModelBase*>(f()) : nullptr;
+}
 
 struct mppi_handle_s
 {
@@ -149,7 +177,13 @@ extern "C" {
 
 const char* mppi_version(void)
 {
-  return "mppi-generic_amd 0.1 (gfx950)";
+  return "mppi-generic_amd 0.2 (gfx950)";
+}
+
+extern "C" const char* mppi_source_hash_impl(void);  // generated by buildlib.py (build/source_hash.cpp)
+const char* mppi_source_hash(void)
+{
+  return mppi_source_hash_impl();
 }
 
 const char* mppi_status_string(mppi_status s)
@@ -181,7 +215,41 @@ int mppi_device_count(void)
 
 const char* mppi_list_models(void)
 {
-  return mppi::engine::listModels();
+  ModelRegistry& r = registry();
+  std::lock_guard<std::mutex> lock(r.mu);
+  r.listing.clear();
+  for (const auto& kv : r.factories)
+    if (kv.first.second == MPPI_SAMPLER_GAUSSIAN || !r.factories.count({ kv.first.first, MPPI_SAMPLER_GAUSSIAN }))
+      r.listing += (r.listing.empty() ? "" : "\n") + kv.first.first;
+  return r.listing.c_str();
+}
+
+mppi_status mppi_register_model(const char* name, int sampler_kind, mppi_model_factory factory, int model_base_size)
+{
+  if (!name || !*name || !factory || (sampler_kind != MPPI_SAMPLER_GAUSSIAN && sampler_kind != MPPI_SAMPLER_COLORED))
+    return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_register_model: null name / factory or unknown sampler kind");
+  if (model_base_size != (int)sizeof(ModelBase))
+    return fail(nullptr, MPPI_ERR_INVALID_ARG,
+                std::string("mppi_register_model('") + name + "'): built against a different mppi_amd/engine/model_instance.hpp "
+                "than this library (sizeof(ModelBase) " + std::to_string(model_base_size) + " vs " +
+                std::to_string(sizeof(ModelBase)) + ")");
+  ModelRegistry& r = registry();
+  std::lock_guard<std::mutex> lock(r.mu);
+  r.factories[{ name, sampler_kind }] = factory;  // a later registration of the same name replaces the earlier one
+  return MPPI_OK;
+}
+
+mppi_status mppi_load_plugin(const char* path)
+{
+  if (!path)
+    return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_load_plugin: null path");
+  void* lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+  if (!lib)
+  {
+    const char* e = dlerror();
+    return fail(nullptr, MPPI_ERR_INVALID_ARG, std::string("mppi_load_plugin: ") + (e ? e : "dlopen failed"));
+  }
+  return MPPI_OK;  // its static initialisers have registered the models; the library stays loaded
 }
 
 const char* mppi_last_error(mppi_handle h)
@@ -248,10 +316,10 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   h->cfg.model = h->model_name.c_str();
   const bool colored = cfg->controller == MPPI_CONTROLLER_COLORED;
   h->model.reset(makeModel(h->model_name, colored));
-  if (!h->model && colored && makeModel(h->model_name, false))
+  if (!h->model && colored && std::unique_ptr<ModelBase>(makeModel(h->model_name, false)))
     return fail(nullptr, MPPI_ERR_UNSUPPORTED, "mppi_create: model '" + h->model_name + "' has no colored-noise instantiation");
   if (!h->model)
-    return fail(nullptr, MPPI_ERR_UNKNOWN_MODEL, "mppi_create: model '" + h->model_name + "' is not registered; have:\n" + listModels());
+    return fail(nullptr, MPPI_ERR_UNKNOWN_MODEL, "mppi_create: model '" + h->model_name + "' is not registered; have:\n" + mppi_list_models());
   mppi_handle hp = h.get();
   switch (cfg->controller)
   {
