@@ -128,6 +128,30 @@ float oracle_state_cost(void* h, const float* y, int t, int* crash)
 {
   return ((Controller*)h)->cost->computeStateCost(y, t, crash);
 }
+/** the individual terms of ARStandardCost (pinned on tests/cost_functions/autorally_standard_cost_test.cu):
+ *  which = 0 speed, 1 stabilizing, 2 track, 3 crash; returns NaN if the handle's cost is not ARStandardCost */
+float oracle_ar_cost_term(void* h, int which, const float* s, int* crash)
+{
+  auto* c = dynamic_cast<ARStandardCost*>(((Controller*)h)->cost.get());
+  if (!c)
+    return NAN;
+  switch (which)
+  {
+    case 0: return c->getSpeedCost(s);
+    case 1: return c->getStabilizingCost(s, crash);
+    case 2: return c->getTrackCost(s, crash);
+    case 3: return c->getCrashCost(crash);
+  }
+  return NAN;
+}
+int oracle_ar_coor_transform(void* h, float x, float y, float* uvw)
+{
+  auto* c = dynamic_cast<ARStandardCost*>(((Controller*)h)->cost.get());
+  if (!c)
+    return -1;
+  c->coorTransform(x, y, uvw, uvw + 1, uvw + 2);
+  return 0;
+}
 void oracle_set_control_ranges(void* h, const float* lo_hi)
 {
   auto* c = (Controller*)h;

@@ -404,12 +404,23 @@ struct ARStandardCost : Cost
     width_ = width;
     return 0;
   }
+  /** reference: ar_standard_cost.cu:199-206 (known answer: tests/cost_functions/autorally_standard_cost_test.cu:184-210) */
+  void coorTransform(float x, float y, float* u, float* v, float* w) const
+  {
+    *u = params_.r_c1[0] * x + params_.r_c2[0] * y + params_.trs[0];
+    *v = params_.r_c1[1] * x + params_.r_c2[1] * y + params_.trs[1];
+    *w = params_.r_c1[2] * x + params_.r_c2[2] * y + params_.trs[2];
+  }
+  /** reference: ar_standard_cost.cu:315-324 (known answer: autorally_standard_cost_test.cu:803-828) */
+  float getCrashCost(const int* crash) const
+  {
+    return crash[0] > 0 ? params_.crash_coeff : 0.0f;
+  }
   /** CUDA point sampling with clamp addressing and normalised coordinates: texel = clamp(floor(u * size)) */
   float queryTextureTransformed(float x, float y) const
   {
-    const float u = params_.r_c1[0] * x + params_.r_c2[0] * y + params_.trs[0];
-    const float v = params_.r_c1[1] * x + params_.r_c2[1] * y + params_.trs[1];
-    const float w = params_.r_c1[2] * x + params_.r_c2[2] * y + params_.trs[2];
+    float u, v, w;
+    coorTransform(x, y, &u, &v, &w);
     const float fx = floorf(u / w * (float)width_);
     const float fy = floorf(v / w * (float)height_);
     const int ix = (fx >= 0.0f) ? ((fx < (float)width_) ? (int)fx : width_ - 1) : 0;
@@ -458,7 +469,7 @@ struct ARStandardCost : Cost
     const float speed_cost = getSpeedCost(s);
     const float stabilizing_cost = getStabilizingCost(s, crash);
     const float disc = params_.discount == 1.0f ? 1.0f : det::pow_pos(params_.discount, (float)timestep);
-    const float crash_cost = disc * (crash[0] > 0 ? params_.crash_coeff : 0.0f);
+    const float crash_cost = disc * getCrashCost(crash);
     float cost = speed_cost + crash_cost + track_cost + stabilizing_cost;
     if (cost > 1e16f || cost != cost)
       cost = 1e16f;

@@ -47,6 +47,9 @@ def lib():
         L.oracle_update_state.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, _f32p]
         L.oracle_state_cost.restype = C.c_float
         L.oracle_state_cost.argtypes = [C.c_void_p, _f32p, C.c_int, C.POINTER(C.c_int)]
+        L.oracle_ar_cost_term.restype = C.c_float
+        L.oracle_ar_cost_term.argtypes = [C.c_void_p, C.c_int, _f32p, C.POINTER(C.c_int)]
+        L.oracle_ar_coor_transform.argtypes = [C.c_void_p, C.c_float, C.c_float, _f32p]
         L.oracle_set_control_ranges.argtypes = [C.c_void_p, _f32p]
         L.oracle_set_control_deadband.argtypes = [C.c_void_p, _f32p]
         L.oracle_set_sampler.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, C.c_int]
@@ -156,6 +159,18 @@ class Oracle:
         cr = C.c_int(crash)
         v = self.L.oracle_state_cost(self.h, _f32(y).reshape(-1), t, C.byref(cr))
         return float(v), cr.value
+
+    def ar_cost_term(self, which, s, crash=0):
+        """one term of ARStandardCost: which in ("speed", "stabilizing", "track", "crash") -> (value, crash flag)"""
+        cr = C.c_int(crash)
+        v = self.L.oracle_ar_cost_term(self.h, ("speed", "stabilizing", "track", "crash").index(which),
+                                       _f32(s).reshape(-1), C.byref(cr))
+        return float(v), cr.value
+
+    def ar_coor_transform(self, x, y):
+        out = np.empty(3, np.float32)
+        assert self.L.oracle_ar_coor_transform(self.h, x, y, out) == 0
+        return out
 
     def set_control_ranges(self, lo_hi):
         self.L.oracle_set_control_ranges(self.h, _f32(lo_hi).reshape(-1))

@@ -78,6 +78,126 @@ def test_ar_standard_cost_pieces():
     assert np.isfinite(c8) and crash8 == 1
 
 
+def _ar_oracle(**params):
+    """oracle with ARStandardCost on the reference's generated standard track map, parameters as the reference test sets them"""
+    import mppi_generic_amd as m
+    cfg = autorally_cfg(K=64, T=4)
+    cost = m.ARStandardCostParams()
+    cost.setTransformFromBounds(-13.0, 17.0, -10.0, 20.0)
+    for k, v in params.items():
+        setattr(cost, k, v)
+    cfg["cost"] = cost
+    return make_oracle(cfg)
+
+
+def test_ar_cost_reference_known_answers_terms():
+    """the oracle's ARStandardCost terms against the values the REFERENCE's own tests hold
+    (tests/cost_functions/autorally_standard_cost_test.cu): coorTransformTest :184-210, getSpeedCostTest :721-748,
+    getStablizingCostTest :750-801, getCrashCostTest :803-828"""
+    import mppi_generic_amd as m
+    # coorTransformTest: r_c1 = (0,1,2), r_c2 = (3,4,5), trs = (6,7,8), (x, y) = (0, 10) -> (36, 47, 58)
+    o = _ar_oracle()
+    cost = m.ARStandardCostParams()
+    cost.r_c1[:] = [0, 1, 2]
+    cost.r_c2[:] = [3, 4, 5]
+    cost.trs[:] = [6, 7, 8]
+    o.set_cost_params(cost)
+    assert np.array_equal(o.ar_coor_transform(0.0, 10.0), np.array([36, 47, 58], np.float32))
+    # getSpeedCostTest
+    s = np.zeros(7, np.float32)
+    s[4] = 10
+    assert _ar_oracle(desired_speed=25, speed_coeff=10).ar_cost_term("speed", s)[0] == np.float32(15 * 15 * 10)
+    assert _ar_oracle(desired_speed=0, speed_coeff=100).ar_cost_term("speed", s)[0] == np.float32(10 * 10 * 100)
+    # getStablizingCostTest: EXPECT_FLOAT_EQ = 4 ulp
+    o = _ar_oracle(slip_coeff=25, crash_coeff=1000, max_slip_ang=0.5)
+    s = np.zeros(7, np.float32)
+    s[4] = 0.1
+    assert o.ar_cost_term("stabilizing", s) == (0.0, 0)
+    s[5] = 0.01
+    v, crash = o.ar_cost_term("stabilizing", s)
+    assert ulp_diff(np.float32(v), np.float32(0.2483460072)) <= 4 and crash == 0
+    s[5] = 0.2
+    v, crash = o.ar_cost_term("stabilizing", s)
+    assert ulp_diff(np.float32(v), np.float32(1030.6444)) <= 4 and crash == 0
+    s[3], s[5] = 1.6, 0.0
+    assert o.ar_cost_term("stabilizing", s) == (0.0, 1)
+    s[3] = -1.6
+    assert o.ar_cost_term("stabilizing", s) == (0.0, 1)
+    # getCrashCostTest
+    o = _ar_oracle(crash_coeff=10000)
+    s = np.zeros(7, np.float32)
+    s[4] = 10
+    assert o.ar_cost_term("crash", s, 0)[0] == 0.0
+    assert o.ar_cost_term("crash", s, 1)[0] == 10000.0
+
+
+def _reference_costmap_value(state, width=30, height=30, x_min=-13, x_max=17, y_min=-10, y_max=20, ppm=20):
+    """calculateStandardCostmapValue of the reference test (autorally_standard_cost_test.cu:830-848), float64"""
+    x, y, th = state
+    xf, yf = x + 0.5 * np.cos(th), y + 0.5 * np.sin(th)
+    xb, yb = x - 0.5 * np.cos(th), y - 0.5 * np.sin(th)
+    nx, ny = max(min(xf - x_min, x_max - x_min), 0.0), max(min(yf - y_min, y_max - y_min), 0.0)
+    front = abs(height / 2.0 - ny) + nx / width
+    nx = max(min(xb - x_min + 1.0 / (width * ppm), x_max - x_min), 0.0)
+    ny = max(min(yb - y_min + 1.0 / (height * ppm), y_max - y_min), 0.0)
+    back = abs(height / 2.0 - ny) + nx / width
+    return (front + back) / 2.0
+
+
+def test_ar_cost_reference_track_cost():
+    """getTrackCostTest (autorally_standard_cost_test.cu:850-895): track_coeff 1, slop 0, boundary_threshold 1 on
+    track_map_standard.npz; the reference compares its GPU result with calculateStandardCostmapValue within 0.001
+    (states 0, 1) and 0.1 (states 2, 3 — the car's ends sit exactly on texel boundaries there), crash = 1 everywhere"""
+    o = _ar_oracle(track_coeff=1, track_slop=0.0, boundary_threshold=1.0)
+    for (x, y, th), tol in [((-13.5, -10, 0.0), 0.001), ((0, -10.0, 0.0), 0.001), ((0.0, 0.0, np.pi / 2), 0.1),
+                            ((3.0, 0.0, np.pi / 2), 0.1)]:
+        v, crash = o.ar_cost_term("track", [x, y, th, 0, 0, 0, 0])
+        assert abs(v - _reference_costmap_value((x, y, th))) <= tol, (x, y, th, v)
+        assert crash == 1
+
+
+def test_ar_cost_reference_compute_cost_individual():
+    """computeCostIndividualTest (autorally_standard_cost_test.cu:897-981): state (3, 0, pi/2, 0, 2, 1, 0.1), timestep 1,
+    discount 0.9, one coefficient switched on at a time.  Speed, slip, crash and the discounted crash term are
+    EXPECT_FLOAT_EQ values; the track term (1116.3333 on the reference's GPU) has both ends of the car exactly ON a texel
+    boundary (y_map = 10.5 m and 9.5 m at 20 px/m, x_map = 16 m), where CUDA's texture unit — it truncates the normalised
+    coordinate to fixed point before scaling — lands one texel lower than floor(u * width) evaluated in fp32: 0.87 %,
+    the same effect the reference's own getTrackCostTest absorbs with its 0.1 tolerance.  Off texel boundaries the
+    two agree (states 0 and 1 of test_ar_cost_reference_track_cost)."""
+    y = [3.0, 0.0, np.pi / 2, 0.0, 2.0, 1.0, 0.1, 0.0]
+    zero = dict(track_coeff=0, speed_coeff=0, crash_coeff=0.0, slip_coeff=0.0, discount=0.9)
+
+    def cost(t=1, **kw):
+        p = dict(zero)
+        p.update(kw)
+        return np.float32(_ar_oracle(**p).state_cost(y, t, 0)[0])
+
+    assert cost() == 0.0
+    speed_cost = np.float32(4.0 ** 2 * 4.25)
+    assert cost(speed_coeff=4.25) == speed_cost
+    slip_cost = np.float32(np.float32(np.arctan(np.float32(0.5))) ** 2 * np.float32(10))
+    assert ulp_diff(cost(slip_coeff=10), slip_cost) <= 4
+    track_cost = cost(track_coeff=200.0)
+    assert abs(track_cost - 1116.3333) <= 0.01 * 1116.3333  # texel-boundary case, see the docstring
+    # one texel lower at both ends (what the reference's GPU sampled) reproduces the reference's number to fp32
+    cmap, _ = standard_track_map()
+    assert abs(200.0 * (cmap[209, 319] + cmap[189, 319]) / 2.0 - 1116.3333) < 1e-3
+    assert ulp_diff(cost(crash_coeff=10000), np.float32(9000)) <= 4
+    total = cost(speed_coeff=4.25, track_coeff=200, slip_coeff=10, crash_coeff=10000)
+    assert ulp_diff(total, np.float32(speed_cost + slip_cost + track_cost + np.float32(9000))) <= 4
+    total4 = cost(t=4, speed_coeff=4.25, track_coeff=200, slip_coeff=10, crash_coeff=10000)
+    want4 = np.float32(speed_cost + slip_cost + track_cost + np.float32(0.9) ** 4 * np.float32(10000))
+    assert ulp_diff(total4, want4) <= 4
+
+
+def test_ar_cost_reference_overflow():
+    """computeCostOverflowTest (autorally_standard_cost_test.cu:983-1032): cost > MAX_COST_VALUE or NaN -> MAX_COST_VALUE (1e16)"""
+    y = [3.0, 0.0, np.pi / 2, 0.0, 2.0, 1.0, 0.1, 0.0]
+    base = dict(track_coeff=0, speed_coeff=10, crash_coeff=0.0, slip_coeff=0.0)
+    assert _ar_oracle(desired_speed=1e16, **base).state_cost(y, 1, 0)[0] == np.float32(1e16)
+    assert _ar_oracle(desired_speed=float("nan"), **base).state_cost(y, 1, 0)[0] == np.float32(1e16)
+
+
 # ------------------------------------------------------------------ GPU parity -----------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(16, 8), (8, 16), (16, 4), (64, 1), (64, 4), (32, 4), (64, 4, 1), (64, 4, 2)])

@@ -1,10 +1,13 @@
 """ColoredNoiseDistribution + ColoredMPPI (BASELINE config 5 sampler)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 import mppi_generic_amd as m
 import pyoracle as po
-from common import (bicycle_lstm_cfg, cartpole_cfg, host_spectrum, make_engine, make_oracle, ulp_diff)
+from common import (bicycle_lstm_cfg, cartpole_cfg, di_cfg, host_spectrum, make_engine, make_oracle, ulp_diff)
 
 
 def _numpy_reference(z, exponents, decay, fmin, offset_t):
@@ -38,6 +41,40 @@ def test_oracle_definition_matches_numpy_irfft(T, exps, decay, fmin, stride):
     got = po.colored_noise(z, exps, decay, fmin, stride, flavour="definition")
     want = _numpy_reference(z, exps, decay, fmin, stride)
     assert np.abs(got - want).max() <= 3e-6 * max(1.0, np.abs(want).max())
+
+
+# ---- pinned on the REFERENCE's own implementation: golden vectors made by importing scripts/colored_noise.py -------------
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "colored_noise_reference.npz")
+GOLDEN_CASES = ["pink_T50", "white_brown_T33", "cutoff_T100", "config5_T200"]
+
+
+def _golden(name):
+    d = np.load(GOLDEN)
+    return d[name + "_z"], d[name + "_y"], list(d[name + "_exponents"]), float(d[name + "_fmin"][0])
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("flavour", ["definition", "gemm"])
+def test_oracle_matches_reference_script_golden(name, flavour):
+    """tests/golden/make_colored_noise_reference.py ran the reference's scripts/colored_noise.py:powerlaw_psd_gaussian with
+    recorded N(0,1) draws; the oracle, fed the same draws as its spectrum (offset removal off: decay 0), must reproduce the
+    script's first T samples.  3e-6: fp32 evaluation against the script's float64."""
+    z, y, exps, fmin = _golden(name)
+    got = po.colored_noise(z, exps, 0.0, fmin, 0, flavour=flavour)
+    assert got.shape == y.shape
+    assert np.abs(got - y).max() <= 3e-6 * max(1.0, np.abs(y).max()), np.abs(got - y).max()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/scripts/colored_noise.py"), reason="reference tree not present")
+def test_golden_is_what_the_reference_script_produces_now():
+    """in the build container: re-import the reference script and regenerate one case -> identical to the committed fixture"""
+    sys.path.insert(0, os.path.dirname(GOLDEN))
+    import make_colored_noise_reference as mk
+    mod = mk.load_reference_module()
+    for i, (name, K, T, exps, fmin) in enumerate(mk.CASES):
+        z, y = mk.run_case(mod, K, T, exps, fmin, seed=1000 + i)
+        zg, yg, _, _ = _golden(name)
+        assert np.array_equal(z, zg) and np.array_equal(y, yg)
 
 
 @pytest.mark.parametrize("T,exps,decay,fmin,stride", [(50, [1.0, 0.5], 0.97, 0.0, 1), (200, [1.0, 1.0], 0.97, 0.0, 1),
@@ -116,6 +153,21 @@ def test_colored_noise_generator_bit_exact(gpu, mk, T, stride):
     got = eng.sampleNoise(stride)
     zp = po.philox_spectrum(1234, 0, cfg["K"], T, C)
     assert ulp_diff(got, po.colored_noise(zp, exps, decay, fmin, stride, flavour="gemm")).max() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_engine_sampler_matches_reference_script_golden(gpu, name):
+    """the engine's in-kernel MFMA GEMM, fed the recorded draws of the reference's scripts/colored_noise.py, reproduces the
+    script's output (two controls: the double integrator instantiation; offset removal off)"""
+    z, y, exps, fmin = _golden(name)
+    K, T = y.shape[0], y.shape[1]
+    cfg = di_cfg(K=K, T=T, tube=False)
+    cfg["colored"] = (exps, 0.0, fmin)
+    eng = make_engine(cfg)
+    eng.injectNoise(z)
+    got = eng.sampleNoise(0)
+    assert np.abs(got - y).max() <= 3e-6 * max(1.0, np.abs(y).max()), np.abs(got - y).max()
 
 
 @pytest.mark.gpu

@@ -1,0 +1,200 @@
+"""HIP engine vs CPU oracle at the FULL sizes of BASELINE.json's configs (north_star: control-sequence L-inf <= 1e-5).
+
+Small-K tests do not exercise what these do: one block per CU (256 blocks at K = 16384), the 256- / 1024-record merge of
+combineKernel, LDS occupancy at T = 150 / 200, ragged tails.  Every test runs ONE computeControl through the C ABI and the
+same call on the oracle (OpenMP over rollouts), on the same injected noise or on the same Philox stream, and asserts
+  trajectory costs   0 ulp          (reference's own bar: 1e-4 relative, tests/mppi_core/rollout_kernel_tests.cu:200-261)
+  baseline rho       exact
+  normaliser eta     <= 1e-6 relative
+  u*                 <= 1e-5 L-inf  (fp32 tolerance of north_star)
+  state trajectory   <= 1e-4
+and, for the sharded variants, the same after an 8-way split of K over eight handles with the exchange done by hand.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mppi_generic_amd as m
+import pyoracle as po
+from common import (autorally_cfg, bicycle_lstm_cfg, cartpole_cfg, di_cfg, host_noise, host_spectrum, make_engine,
+                    make_oracle, ulp_diff)
+
+pytestmark = pytest.mark.gpu
+
+U_TOL = 1e-5      # north_star: control-sequence L-inf vs reference
+ETA_RTOL = 1e-6
+X_TOL = 1e-4
+
+
+def _check_system(eng_stats, orc_stats, z):
+    assert eng_stats.baseline == orc_stats["baseline"][z], (eng_stats.baseline, orc_stats["baseline"][z])
+    eta = float(orc_stats["normalizer"][z])
+    assert abs(eng_stats.normalizer - eta) <= ETA_RTOL * eta, (eng_stats.normalizer, eta)
+
+
+def _check_vanilla(eng, orc):
+    dc = int(ulp_diff(eng.getSampledCostSeq(), orc.costs()).max())
+    assert dc == 0, "trajectory costs differ by %d ulp" % dc
+    _check_system(eng.getStats().real_sys, orc.stats(), 0)
+    du = float(np.abs(eng.getControlSeq() - orc.control()).max())
+    assert du <= U_TOL, du
+    assert np.abs(eng.getTargetStateSeq() - orc.state_traj()).max() <= X_TOL
+    return du
+
+
+# ------------------------------------------------------------------ config 2: Cartpole K=16384 T=100 ------------------
+@pytest.mark.parametrize("variant", [0, 1], ids=["pipeline", "fused"])
+@pytest.mark.parametrize("noise", ["injected", "philox"])
+@pytest.mark.parametrize("soft", [False, True], ids=["lambda0.25", "lambda200"])
+def test_cartpole_16384x100_vs_oracle(gpu, variant, noise, soft):
+    """BASELINE headline config (examples/cartpole_example.cu parameters; lambda 0.25 as upstream, and lambda 200 where
+    thousands of rollouts carry weight), both kernel structures, injected eps and the in-kernel Philox stream"""
+    cfg = cartpole_cfg(K=16384, T=100, soft=soft, num_iters=2)
+    eng, orc = make_engine(cfg, kernel_variant=variant), make_oracle(cfg)
+    if noise == "injected":
+        eps = host_noise(2, cfg["K"], cfg["T"], 1)
+        eng.injectNoise(eps)
+    else:
+        eng.setSeed(42)  # generation 0 and 1 of the Philox stream: the two optimisation iterations
+        eps = np.stack([po.philox_normal(42, g, cfg["K"], cfg["T"], 1) for g in range(2)])
+    eng.computeControl(cfg["x0"], 1)
+    orc.vanilla_compute_control(cfg["x0"], 1, eps)
+    _check_vanilla(eng, orc)
+
+
+# ------------------------------------------------------------------ config 4: AutoRally-NN K=16384 T=150 --------------
+@pytest.mark.parametrize("variant", [0, 1], ids=["mfma-pipeline", "mfma-fused"])
+def test_autorally_16384x150_vs_oracle(gpu, variant):
+    """NeuralNetModel<7,2,3> on the MFMA forward + ARStandardCost, SURVEY.md §8d config 4"""
+    cfg = autorally_cfg(K=16384, T=150)
+    eng, orc = make_engine(cfg, kernel_variant=variant), make_oracle(cfg)
+    eps = host_noise(1, cfg["K"], cfg["T"], 2)
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    orc.vanilla_compute_control(cfg["x0"], 1, eps)
+    _check_vanilla(eng, orc)
+    assert (orc.costs() < 1e4).sum() > 1000, "config should keep a good share of rollouts on the track"
+
+
+def test_autorally_16384x150_philox_vs_oracle(gpu):
+    cfg = autorally_cfg(K=16384, T=150)
+    eng, orc = make_engine(cfg), make_oracle(cfg)
+    eng.setSeed(7)
+    eng.computeControl(cfg["x0"], 1)
+    orc.vanilla_compute_control(cfg["x0"], 1, po.philox_normal(7, 0, cfg["K"], cfg["T"], 2)[None])
+    _check_vanilla(eng, orc)
+
+
+# ------------------------------------------------------------------ config 3: DI Tube K=8192 T=150 --------------------
+@pytest.mark.parametrize("kw", [{}, {"kernel_variant": 1}, {"block_x": 64, "block_y": 1}],
+                         ids=["folded-pipeline", "fused", "pipeline-64x1x2"])
+def test_di_tube_8192x150_vs_oracle(gpu, kw):
+    """Tube-MPPI, CORL2020 parameters (examples/double_integrator_CORL2020.cu:30-39, 316-352) at BASELINE size: two
+    systems per launch; three calls with the actual state drifting so the nominal-state logic is exercised"""
+    cfg = di_cfg(K=8192, T=150)
+    eng, orc = make_engine(cfg, **kw), make_oracle(cfg)
+    x = cfg["x0"].copy()
+    for i in range(3):
+        eps = host_noise(1, cfg["K"], cfg["T"], 2, seed=70 + i)
+        eng.injectNoise(eps)
+        eng.computeControl(x, 1)
+        orc.tube_compute_control(x, 1, eps)
+        assert ulp_diff(eng.getSampledCostSeq(), orc.costs()).max() == 0
+        st, so = eng.getStats(), orc.stats()
+        _check_system(st.real_sys, so, 0)
+        _check_system(st.nominal_sys, so, 1)
+        assert st.nominal_state_used == so["nominal_state_used"]
+        assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
+        assert np.abs(eng.getNominalControlSeq() - orc.nominal_control()).max() <= U_TOL
+        assert np.abs(eng.getTargetStateSeq() - orc.state_traj()).max() <= X_TOL
+        x = x + np.array([0.05, -0.03, 0.02, 0.01], np.float32)
+        eng.slideControlSequence(1)
+        orc.vanilla_slide(1)
+
+
+# ------------------------------------------------------------------ config 5: LSTM + colored K=65536 T=200 ------------
+@pytest.mark.parametrize("noise", ["injected", "philox"])
+def test_lstm_colored_65536x200_vs_oracle(gpu, noise):
+    """LSTM bicycle-slip dynamics on MFMA + colored-noise sampler (in-kernel GEMM), one iteration at BASELINE size.
+    The oracle needs ~30 s on 8 cores for the 13 M LSTM steps + the O(T^2) inverse DFT of every sample row."""
+    cfg = bicycle_lstm_cfg(K=65536, T=200)
+    cfg["colored"] = ([1.0, 1.0], 0.97, 0.0)
+    eng, orc = make_engine(cfg), make_oracle(cfg)
+    if noise == "injected":
+        z = host_spectrum(1, cfg["K"], cfg["T"], 2, seed=5)
+        eng.injectNoise(z)
+    else:
+        eng.setSeed(99)
+        z = po.philox_spectrum(99, 0, cfg["K"], cfg["T"], 2)[None]
+    eng.computeControl(cfg["x0"], 1)
+    orc.colored_compute_control(cfg["x0"], 1, z, *cfg["colored"])
+    _check_vanilla(eng, orc)
+
+
+# ------------------------------------------------------------------ 8-way K split on one device -----------------------
+def _eight_way(cfg, eps, controls=2):
+    """rank r of world 8 owns rollouts [r K/8, (r+1) K/8); the all-gather is done by hand with device copies"""
+    W = 8
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    ranks = [make_engine(cfg, rank=r, world_size=W) for r in range(W)]
+    Kl = cfg["K"] // W
+    for r, c in enumerate(ranks):
+        assert c.num_rollouts_local == Kl
+        if eps is not None:
+            c.injectNoise(eps[:, r * Kl:(r + 1) * Kl])
+        c.uploadState(cfg["x0"])
+        c.iterationLocal()
+        c.synchronize()
+    bufs = [c.exchangeBuffers() for c in ranks]
+    n = bufs[0][2]
+    for dst in range(W):
+        for src in range(W):
+            assert hip.hipMemcpy(bufs[dst][1] + 4 * n * src, bufs[src][0], 4 * n, 3) == 0  # 3 = device to device
+    out = []
+    for c in ranks:
+        c.iterationMerge()
+        c.synchronize()
+        out.append((c.getOptimalControlSeq()[0], c.getStats().real_sys))
+    return out
+
+
+@pytest.mark.parametrize("mk,K,T,Cd", [(cartpole_cfg, 16384, 100, 1), (autorally_cfg, 16384, 150, 2)],
+                         ids=["cartpole", "autorally"])
+@pytest.mark.parametrize("noise", ["injected", "philox"])
+def test_eight_way_split_matches_unsharded_oracle(gpu, mk, K, T, Cd, noise):
+    """SURVEY.md §8e at BASELINE size: the K rollouts split over 8 handles (global rollout index decides the special
+    trajectories and the Philox counters) + one record exchange == the oracle's UN-sharded iteration"""
+    cfg = mk(K=K, T=T, soft=True) if mk is cartpole_cfg else mk(K=K, T=T)
+    orc = make_oracle(cfg)
+    if noise == "injected":
+        eps = host_noise(1, K, T, Cd, seed=17)
+        res = _eight_way(cfg, eps)
+    else:
+        eps = po.philox_normal(42, 0, K, T, Cd)[None]
+        res = _eight_way(cfg, None)
+    u_orc = orc.iterate(cfg["x0"], np.zeros((T, Cd), np.float32), eps[0])[0]
+    w = orc.weights()[0].astype(np.float64)
+    rho = float(orc.costs()[0].min())
+    for u, st in res:
+        assert np.abs(u - u_orc).max() <= U_TOL, np.abs(u - u_orc).max()
+        assert st.baseline == rho
+        assert abs(st.normalizer - w.sum()) <= 2e-6 * w.sum()
+    # every rank ends with the same bits
+    for u, _ in res[1:]:
+        assert np.array_equal(u, res[0][0])
+
+
+def test_full_size_weighted_mean_of_dumped_samples(gpu):
+    """u* of the engine == float64 weighted mean of the samples the engine itself dumped (independent of the oracle):
+    the block-local softmin + 256-record merge against a direct evaluation of sum_k w_k v_k / sum_k w_k"""
+    cfg = cartpole_cfg(K=16384, T=100, soft=True)
+    eng = make_engine(cfg, save_samples=True)
+    eng.uploadState(cfg["x0"])
+    eng.optimize(1)
+    costs = eng.getSampledCostSeq()[0].astype(np.float64)
+    v = eng.getSampledControls()[0].astype(np.float64)
+    w = np.exp(-(costs - costs.min()) / cfg["lambda_"])
+    u_direct = (w[:, None, None] * v).sum(0) / w.sum()
+    assert np.abs(eng.getOptimalControlSeq()[0] - u_direct).max() <= 2e-6
