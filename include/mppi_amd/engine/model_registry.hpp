@@ -4,7 +4,7 @@
  * The reference's user instantiates the controller templates in a translation unit of their own and links it
  * (reference: src/controllers/cartpole/cartpole_mppi.cu:30-42, include/mppi/instantiations/cartpole_mppi/cartpole_mppi.cuh).
  * Here that translation unit is a .hip file that names one ModelT<...> and registers a factory for it under a model
- * name; the in-tree models (mppi-generic_amd/csrc/models/*.hip) and a user's out-of-tree model (examples/my_model/)
+ * name; the in-tree models (mppi-generic_amd/csrc/models/[*].hip) and a user's out-of-tree model (examples/my_model/)
  * do exactly the same thing:
  *
  *     using MyModel = mppi::engine::ModelT<MyDynamics, MyCost, MySampler, Shapes<Shape<64, 1, 1>>, 1, void, Shapes<>, true>;
