@@ -38,6 +38,22 @@ namespace mppi
 {
 typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
 
+/* A/B experiment hooks (tools/, never defined in a product build): what the step loop costs without its MFMAs / tanh */
+#if defined(MPPI_KNOCKOUT_MFMA)
+__device__ inline mfma_f32x4 mfma16x16x4(float a, float b, mfma_f32x4 c)
+{
+  typedef float f32x2 __attribute__((ext_vector_type(2)));  // two packed fma instead of the MFMA: same data flow
+  const f32x2 lo = __builtin_elementwise_fma(f32x2{ a, b }, f32x2{ b, a }, f32x2{ c[0], c[1] });
+  const f32x2 hi = __builtin_elementwise_fma(f32x2{ b, a }, f32x2{ a, a }, f32x2{ c[2], c[3] });
+  return mfma_f32x4{ lo.x, lo.y, hi.x, hi.y };
+}
+#else
+__device__ inline mfma_f32x4 mfma16x16x4(float a, float b, mfma_f32x4 c)
+{
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+#endif
+
 template <int IN, int H, int OUT>
 struct FNNMfma
 {
@@ -103,7 +119,9 @@ struct FNNMfma
 #pragma unroll
       for (int i = 0; i < 4; i++)
         v[4 * rb + i] = acc[rb][i] + bias[rb][i];
+#if !defined(MPPI_KNOCKOUT_TANH)
     mppi::det::tanh_n<RB * 4>(v);
+#endif
 #pragma unroll
     for (int rb = 0; rb < RB; rb++)
     {
@@ -118,6 +136,13 @@ struct FNNMfma
   /**
    * in[IN]: the network input of this lane's rollout (every lane of the rollout holds the same values);
    * out[OUT]: the network output, identical in the 4 lanes of the rollout.  No LDS, no barrier.
+   *
+   * MFMAs and the VALU work between them are left in the compiler's order, MFMAs mostly back to back: a wave that is alone
+   * on its SIMD does NOT issue VALU instructions under its own MFMA (tools/ubench/mfma_overlap.hip: {MFMA + N independent
+   * v_fma} costs 19.6 + 1.85 N ns against 13.3 ns for the MFMA alone — the times add, plus ~6 ns per MFMA <-> VALU switch), so
+   * a hand-interleaved forward (row block 1's MFMAs between the tanh stages of row block 0) measured the same 227 us per
+   * AutoRally launch.  Only ANOTHER wave of the SIMD fills the matrix pipe's shadow — the helper waves of the pipelined
+   * kernel do.
    */
   __device__ inline void forward(const float (&in)[IN], float (&out)[OUT], const int lane) const
   {
@@ -143,7 +168,7 @@ struct FNNMfma
     for (int s = 0; s < KS_IN; s++)
 #pragma unroll
       for (int rb = 0; rb < RB; rb++)
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rb][s], bin[s], acc[rb], 0, 0, 0);
+        acc[rb] = mfma16x16x4(a1[rb][s], bin[s], acc[rb]);
     float bh[KS_H];
     squash(acc, b1, bh);
     /* ---- layer 2 ---- */
@@ -154,14 +179,14 @@ struct FNNMfma
     for (int s = 0; s < KS_H; s++)
 #pragma unroll
       for (int rb = 0; rb < RB; rb++)
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[rb][s], bh[s], acc[rb], 0, 0, 0);
+        acc[rb] = mfma16x16x4(a2[rb][s], bh[s], acc[rb]);
     float bo[KS_H];
     squash(acc, b2, bo);
     /* ---- layer 3 (linear): rows replicated, every lane of the rollout receives all outputs ---- */
     mfma_f32x4 o = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
     for (int s = 0; s < KS_H; s++)
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[s], bo[s], o, 0, 0, 0);
+      o = mfma16x16x4(a3[s], bo[s], o);
 #pragma unroll
     for (int i = 0; i < OUT; i++)
       out[i] = o[i] + b3[i];

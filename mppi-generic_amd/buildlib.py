@@ -118,6 +118,43 @@ def _compile(tu, verbose):
     return obj, time.time() - t0
 
 
+def build_variant(tag, extra_flags, only=None, verbose=False):
+    """An experimental build for A/B measurements (tools/): the translation units matching `only` (substring; all when
+    None) compiled with extra flags into csrc/build/variant_<tag>/, linked with the regular objects of the other units
+    into lib/libmppi_amd_<tag>.so.  Load it with MPPI_AMD_LIB=<path>."""
+    build()
+    vdir = os.path.join(BUILD_DIR, "variant_" + tag)
+    os.makedirs(vdir, exist_ok=True)
+    objs = []
+    todo = []
+    for tu in translation_units():
+        if only is None or only in os.path.basename(tu):
+            obj = os.path.join(vdir, os.path.basename(tu) + ".o")
+            todo.append((tu, obj))
+            objs.append(obj)
+        else:
+            objs.append(_obj_path(tu))
+
+    def one(job):
+        tu, obj = job
+        cmd = [_hipcc()] + _flags() + list(extra_flags) + ["-c", tu, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s%s" % (tu, r.stdout, r.stderr))
+
+    with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
+        list(ex.map(one, todo))
+    out = os.path.join(LIB_DIR, "libmppi_amd_%s.so" % tag)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", os.path.join(BUILD_DIR, "source_hash.o")] + objs + \
+          ["-o", out, "-ldl", "-lz"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
+    return out
+
+
 def build(force=False, verbose=False, jobs=None):
     """Compile csrc/engine.hip + csrc/models/*.hip -> lib/libmppi_amd.so.  Returns the library path."""
     if not force and not needs_build():
@@ -160,5 +197,10 @@ def build(force=False, verbose=False, jobs=None):
 if __name__ == "__main__":
     import time
     t0 = time.time()
+    if "--variant" in sys.argv:  # buildlib.py --variant <tag> <only-substring|all> <extra flags...>
+        i = sys.argv.index("--variant")
+        tag, only = sys.argv[i + 1], sys.argv[i + 2]
+        print(build_variant(tag, sys.argv[i + 3:], None if only == "all" else only, verbose=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print("build took %.1f s" % (time.time() - t0), file=sys.stderr)

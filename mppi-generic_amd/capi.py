@@ -159,8 +159,8 @@ def load_library(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
-    if build_if_missing and _build.needs_build():
+    path = os.environ.get("MPPI_AMD_LIB") or _build.LIB  # MPPI_AMD_LIB: an experimental build (tools/ A/B runs only)
+    if path == _build.LIB and build_if_missing and _build.needs_build():
         _build.build()
     if not os.path.exists(path):
         raise RuntimeError(
