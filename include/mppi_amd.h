@@ -351,6 +351,14 @@ mppi_status mppi_comm_init_rccl(mppi_handle h, const void* unique_id, size_t nby
 /** one rollout launch from x0 ([D][S]) and the current nominal control, no mean update: costs via mppi_get_costs
  *  (launchRolloutKernel, core/mppi_common.cu:1299-1325) */
 mppi_status mppi_rollout_costs(mppi_handle h, const float* x0, int optimization_stride);
+/**
+ * Dynamics::enforceConstraints on one control vector u[C] (state[S] may be NULL; only plugins with state-dependent
+ * constraints read it): what Controller::getCurrentControl applies before a control is published
+ * (controllers/controller.cuh:329-345).  For plugins that keep the base rule (deadband, clamp to the control ranges) this runs
+ * on the host and takes no handle lock, so it can be called from a second thread while mppi_compute_control is in flight;
+ * every other entry point of a handle is serialised by the handle's own mutex.
+ */
+mppi_status mppi_enforce_constraints(mppi_handle h, const float* state, float* u);
 /** one model step on the device plugin, the simulation step of the reference's examples (examples/cartpole_example.cu:
  *  76-80: model->enforceConstraints(x, u); model->step(x, x_next, xdot, u, y, t, dt)): u is clamped in place when
  *  enforce_constraints != 0, then x <- x_next */

@@ -189,6 +189,12 @@ public:
   {
     check(mppi_model_step(h_, x.data(), u.data(), dt, enforce_constraints ? 1 : 0));
   }
+  /** Dynamics::enforceConstraints on one control vector; on the host for plugins that keep the base rule, and without the
+   *  handle lock, so the state-callback thread may call it while computeControl runs (mppi_enforce_constraints) */
+  void enforceConstraints(const std::vector<float>& state, std::vector<float>& u)
+  {
+    check(mppi_enforce_constraints(h_, state.empty() ? nullptr : state.data(), u.data()));
+  }
   /** device-resident iterations without host round trips (the unit bench.py times) */
   void optimize(int num_iterations, bool synchronize = true)
   {
@@ -246,18 +252,17 @@ public:
       for (int j = 0; j < control_dim_; j++)
         u[j] += u_fb[j];
     }
-    std::vector<float> zero_state(state_dim_, 0.0f);
-    modelStep(zero_state, u, 0.0f, true);  // a zero-length step returns the constrained control
+    enforceConstraints(state, u);
     return u;
   }
   /** Robust MPPI overrides this; a no-op for the other controllers (controller.cuh:321-327) */
   virtual void updateImportanceSamplingControl(const std::vector<float>& state, int stride)
   {
   }
-  /** controller.cuh resetControls(): zero nominal control */
+  /** controller.cuh:617-620 resetControls(): an empty TODO in the reference — the nominal control sequence set through
+   *  updateImportanceSampler before the control loop starts survives it, so it does here */
   void resetControls()
   {
-    updateImportanceSampler(std::vector<float>((size_t)num_timesteps_ * control_dim_, 0.0f));
   }
   float getDt() const
   {

@@ -64,6 +64,8 @@ struct ModelBase
   virtual void setControlRanges(const float* lo_hi) = 0;
   virtual void setControlDeadband(const float* db) = 0;
   virtual void getZeroControl(float* out) const = 0;
+  /** the base enforceConstraints rule on the host (dynamics.cu:97-116); false: the plugin overrides it, run the device code */
+  virtual bool hostEnforceConstraints(float* u) const = 0;
   virtual void setSamplerParams(const mppi_gaussian_params* p, int D) = 0;
   /** bulk data (NN weights, costmap); default: the model has none */
   virtual mppi_status setBlob(const std::string& name, const float* data, size_t count, const int* dims, int ndims,
@@ -657,6 +659,20 @@ struct ModelT : ModelBase
   {
     for (int i = 0; i < DYN_T::CONTROL_DIM; i++)
       out[i] = dyn.zero_control_[i];
+  }
+  bool hostEnforceConstraints(float* u) const override
+  {
+    if (!DYN_T::BASE_CONSTRAINTS || DYN_T::CONSTRAINTS_DEPEND_ON_STATE)
+      return false;
+    for (int i = 0; i < DYN_T::CONTROL_DIM; i++)
+    {  // the operations of Dynamics::enforceConstraints (plugin/dynamics.hpp), correctly rounded on either side
+      if (fabsf(u[i]) < dyn.control_deadband_[i])
+        u[i] = dyn.zero_control_[i];
+      else
+        u[i] += dyn.control_deadband_[i] * -mppi::math::sign(u[i]);
+      u[i] = fminf(fmaxf(dyn.control_rngs_[i].x, u[i]), dyn.control_rngs_[i].y);
+    }
+    return true;
   }
   void setSamplerParams(const mppi_gaussian_params* p, int D) override
   {

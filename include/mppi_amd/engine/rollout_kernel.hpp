@@ -146,7 +146,10 @@ __device__ inline void blockSoftminEpilogueCost(SAMPLING_T* sampling, const Roll
       for (int i = 0; i < BX; i++)
         rho_b = fminf(rho_b, cost_s[BX * thread_idz + i]);
     }
-    w_s[shared_idx] = valid ? mppi::det::exp(-lambda_inv * (traj_cost - rho_b)) : 0.0f;
+    // S - rho_b is NaN when every valid rollout of the block has cost +inf (inf - inf), or when S itself is NaN: such a
+    // rollout gets weight 0 — what the reference's single global baseline gives it (exp(-inf)) — instead of poisoning U_b
+    const float dist = traj_cost - rho_b;
+    w_s[shared_idx] = (valid && dist == dist) ? mppi::det::exp(-lambda_inv * dist) : 0.0f;
   }
   __syncthreads();
 

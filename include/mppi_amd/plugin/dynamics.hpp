@@ -158,6 +158,14 @@ public:
    * lengthens the rollout's serial chain.
    */
   static constexpr bool CONSTRAINTS_DEPEND_ON_STATE = false;
+  /**
+   * true while the plugin keeps the base enforceConstraints() below (deadband, then clamp to control_rngs_).  The engine then
+   * evaluates the rule on the HOST where the reference does (Controller::getCurrentControl -> model_->enforceConstraints on
+   * the state-estimator thread, controllers/controller.cuh:329-345) — the same IEEE operations, no kernel launch behind
+   * the rollouts in flight.  A plugin that overrides enforceConstraints() sets this to false; the engine then runs the
+   * plugin's device code for it.
+   */
+  static constexpr bool BASE_CONSTRAINTS = true;
 
   /** reference: dynamics.cu:97-116 — deadband then clamp, lanes strided over threadIdx.y */
   __device__ inline void enforceConstraints(float* state, float* control)

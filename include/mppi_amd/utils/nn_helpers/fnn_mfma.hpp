@@ -133,6 +133,19 @@ struct FNNMfma
     }
   }
 
+  /** All eight B fragments of a layer pass through one empty asm statement: a data dependence the compiler cannot see
+   *  through, so no MFMA of the layer is issued before the whole squash in front of it is done and the layer's MFMAs end up
+   *  back to back.  Left alone, the scheduler spreads them between the tanh stages "to hide their latency" — but a wave alone
+   *  on its SIMD does not issue VALU work under its own MFMA, and every MFMA <-> VALU switch costs it ~6 ns
+   *  (tools/ubench/mfma_overlap.hip). */
+  __device__ static inline void gather8(float (&b)[KS_H])
+  {
+    static_assert(KS_H == 8, "gather8 is written for H = 32");
+#if !defined(MPPI_FNN_NO_CLUSTER)
+    asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+#endif
+  }
+
   /**
    * in[IN]: the network input of this lane's rollout (every lane of the rollout holds the same values);
    * out[OUT]: the network output, identical in the 4 lanes of the rollout.  No LDS, no barrier.
@@ -171,6 +184,7 @@ struct FNNMfma
         acc[rb] = mfma16x16x4(a1[rb][s], bin[s], acc[rb]);
     float bh[KS_H];
     squash(acc, b1, bh);
+    gather8(bh);
     /* ---- layer 2 ---- */
 #pragma unroll
     for (int rb = 0; rb < RB; rb++)
@@ -182,6 +196,7 @@ struct FNNMfma
         acc[rb] = mfma16x16x4(a2[rb][s], bh[s], acc[rb]);
     float bo[KS_H];
     squash(acc, b2, bo);
+    gather8(bo);
     /* ---- layer 3 (linear): rows replicated, every lane of the rollout receives all outputs ---- */
     mfma_f32x4 o = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll

@@ -96,6 +96,9 @@ struct TwoDTextureHelper
     const int w = p.width, h = p.height;
     float qx = point[0] * (float)w - 0.5f;
     float qy = point[1] * (float)h - 0.5f;
+    // a NaN coordinate (a diverged rollout) would reach (int)floorf(NaN); it samples texel 0 like ARStandardCost's lookup
+    qx = (qx == qx) ? qx : 0.0f;
+    qy = (qy == qy) ? qy : 0.0f;
     bool border = false;
     if (p.address_mode[0] == ADDRESS_CLAMP)
       qx = (qx > (float)(w - 1)) ? (float)(w - 1) : ((qx <= 0.0f) ? 0.0f : qx);
@@ -118,11 +121,14 @@ struct TwoDTextureHelper
         out[ch] = p.data[(size_t)idx * NC + ch];
       return;
     }
-    const int x_min = min((int)floorf(qx), w - 2), x_max = x_min + 1;
-    const int y_min = min((int)floorf(qy), h - 2), y_max = y_min + 1;
+    // a 1-texel axis has no second sample: both taps read texel 0 (weights still sum to one)
+    const int x_min = max(min((int)floorf(qx), w - 2), 0), x_max = min(x_min + 1, w - 1) > x_min ? x_min + 1 : x_min;
+    const int y_min = max(min((int)floorf(qy), h - 2), 0), y_max = min(y_min + 1, h - 1) > y_min ? y_min + 1 : y_min;
     // weights exactly as the reference writes them: (x_max - q) / (x_max - x_min) with the denominator 1
-    const float wx0 = ((float)x_max - qx) / (float)(x_max - x_min), wx1 = (qx - (float)x_min) / (float)(x_max - x_min);
-    const float wy0 = ((float)y_max - qy) / (float)(y_max - y_min), wy1 = (qy - (float)y_min) / (float)(y_max - y_min);
+    const float wx0 = (x_max > x_min) ? ((float)x_max - qx) / (float)(x_max - x_min) : 1.0f;
+    const float wx1 = (x_max > x_min) ? (qx - (float)x_min) / (float)(x_max - x_min) : 0.0f;
+    const float wy0 = (y_max > y_min) ? ((float)y_max - qy) / (float)(y_max - y_min) : 1.0f;
+    const float wy1 = (y_max > y_min) ? (qy - (float)y_min) / (float)(y_max - y_min) : 0.0f;
     for (int ch = 0; ch < NC; ch++)
     {
       const float q11 = p.data[((size_t)y_min * w + x_min) * NC + ch], q12 = p.data[((size_t)y_min * w + x_max) * NC + ch];

@@ -122,6 +122,7 @@ SIGNATURES = {
     "mppi_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mppi_comm_init_rccl": (C.c_int, [H, C.c_void_p, C.c_size_t]),
     "mppi_rollout_costs": (C.c_int, [H, _f32p, C.c_int]),
+    "mppi_enforce_constraints": (C.c_int, [H, C.c_void_p, _f32p]),
     "mppi_model_step": (C.c_int, [H, _f32p, _f32p, C.c_float, C.c_int]),
     "mppi_norm_exp": (C.c_int, [_f32p, C.c_int, C.c_float, C.c_float, C.c_int]),
     "mppi_compute_weights": (C.c_int, [_f32p, C.c_int, C.c_float, _f32p, C.c_int]),

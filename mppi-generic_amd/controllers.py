@@ -387,6 +387,13 @@ class MPPIController:
     def synchronize(self):
         self._check(self._lib.mppi_synchronize(self._h))
 
+    def enforceConstraints(self, state, u):
+        """Dynamics::enforceConstraints on one control vector (host-side and lock-free for the base rule)"""
+        u = _f32(u).reshape(-1).copy()
+        sp = None if state is None else _f32(state).reshape(-1).ctypes.data
+        self._check(self._lib.mppi_enforce_constraints(self._h, sp, u))
+        return u
+
     def modelStep(self, x, u, dt=None, enforce_constraints=True):
         x = _f32(x).reshape(-1).copy()
         u = _f32(u).reshape(-1).copy()

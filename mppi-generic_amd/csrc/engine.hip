@@ -61,6 +61,12 @@ static ModelBase* makeModel(const std::string& name, bool colored)
 
 struct mppi_handle_s
 {
+  /* Entry points of one handle are serialised: the reference's controllers are single-caller, but its BasePlant calls them
+   * from two threads (state callback + control loop, core/base_plant.hpp:398-428) behind its own mutex — here the handle
+   * carries it.  mppi_enforce_constraints' host path deliberately does NOT take it (a control publication must never wait
+   * for a computeControl in flight); it reads the control ranges under params_mu only. */
+  std::recursive_mutex mu;
+  std::mutex params_mu;
   mppi_config cfg{};
   std::string model_name;
   std::unique_ptr<ModelBase> model;
@@ -113,6 +119,7 @@ struct mppi_handle_s
   mppi_stats stats_h{};
   uint32_t generation = 0;
   int last_stride = 1;
+  int external_iteration = 0;  // opt_iter of a caller-driven loop (mppi_iteration_local), reset by mppi_upload_state
   int noise_source = MPPI_NOISE_PHILOX_FUSED;
 
   /* Robust MPPI (controllers/R-MPPI/robust_mppi_controller.cuh:46-53, 270-310) */
@@ -170,7 +177,8 @@ static mppi_status fail(mppi_handle h, mppi_status s, const std::string& msg)
 
 #define CHECK_HANDLE(h)               \
   if (!(h))                           \
-  return MPPI_ERR_INVALID_ARG
+    return MPPI_ERR_INVALID_ARG;      \
+  std::lock_guard<std::recursive_mutex> handle_lock__((h)->mu)
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 extern "C" {
@@ -300,6 +308,8 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   if (cfg->num_rollouts <= 0 || cfg->num_timesteps <= 0 || !(cfg->dt > 0.0f) || !(cfg->lambda > 0.0f) ||
       cfg->num_iters <= 0)
     return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_create: num_rollouts, num_timesteps, dt, lambda, num_iters must be > 0");
+  if (cfg->kernel_variant < 0 || cfg->kernel_variant > MPPI_KERNEL_PIPELINE)
+    return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_create: unknown kernel_variant");
   const int world = cfg->world_size > 0 ? cfg->world_size : 1;
   if (cfg->rank < 0 || cfg->rank >= world || cfg->num_rollouts % world != 0)
     return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_create: rank/world_size invalid or num_rollouts not divisible by world_size");
@@ -372,8 +382,6 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
                 "mppi_create: the pipeline variant needs a model registered for it and block shape (64, 1), or (64, REP, 1) "
                 "for replicated-lane (MFMA) dynamics");
-  if (cfg->kernel_variant < 0 || cfg->kernel_variant > MPPI_KERNEL_PIPELINE)
-    return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_create: unknown kernel_variant");
   h->pipeline = pipe_ok && cfg->kernel_variant != MPPI_KERNEL_FUSED;
   size_t lds = cfg->controller == MPPI_CONTROLLER_ROBUST ?
                    h->model->rmppiSharedBytes(h->bx, cfg->num_timesteps) :
@@ -488,9 +496,18 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   if (cfg->save_samples)
     ALLOC_OR_FAIL(h->samples_d, (size_t)D * K * T * C);
 #undef ALLOC_OR_FAIL
-  HIP_TRY(nullptr, hipEventCreate(&h->ev_a));
-  HIP_TRY(nullptr, hipEventCreate(&h->ev_b));
-  HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
+  {
+    hipError_t e = hipEventCreate(&h->ev_a);
+    if (e == hipSuccess)
+      e = hipEventCreate(&h->ev_b);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess)
+    {
+      freeAll(hp);
+      return fail(nullptr, MPPI_ERR_HIP, std::string("mppi_create: event / stream setup: ") + hipGetErrorString(e));
+    }
+  }
 
   h->control_h.assign((size_t)T * C, 0.0f);
   h->history_h.assign((size_t)2 * C, 0.0f);
@@ -591,6 +608,7 @@ mppi_status mppi_set_colored_noise_params(mppi_handle h, const float* exponents,
 mppi_status mppi_set_control_ranges(mppi_handle h, const float* lo_hi)
 {
   CHECK_HANDLE(h);
+  std::lock_guard<std::mutex> params_lock(h->params_mu);
   if (!lo_hi)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_control_ranges: null");
   h->model->setControlRanges(lo_hi);
@@ -599,6 +617,7 @@ mppi_status mppi_set_control_ranges(mppi_handle h, const float* lo_hi)
 mppi_status mppi_set_control_deadband(mppi_handle h, const float* db)
 {
   CHECK_HANDLE(h);
+  std::lock_guard<std::mutex> params_lock(h->params_mu);
   if (!db)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_control_deadband: null");
   h->model->setControlDeadband(db);
@@ -1676,6 +1695,7 @@ mppi_status mppi_upload_state(mppi_handle h, const float* x0)
     HIP_TRY(h, hipMemcpyAsync(h->mean_d + h->TC, h->nominal_control_h.data(), sizeof(float) * h->TC,
                               hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->external_iteration = 0;
   return MPPI_OK;
 }
 
@@ -1696,8 +1716,8 @@ mppi_status mppi_optimize(mppi_handle h, int n, int synchronize)
   if (n < 0)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_optimize: negative iteration count");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-  for (int i = 0; i < n; i++)
-    MPPI_TRY(iteration(h, 0, h->last_stride));
+  for (int i = 0; i < n; i++)  // opt_iter of mppi_controller.cu:160: std_dev_decay^i shapes iteration i of this call
+    MPPI_TRY(iteration(h, i, h->last_stride));
   if (synchronize)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPPI_OK;
@@ -1791,7 +1811,8 @@ mppi_status mppi_iteration_local(mppi_handle h)
 {
   CHECK_HANDLE(h);
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-  return iterationLocal(h, 0, h->last_stride);
+  // the caller drives the optimisation loop: its iteration index (std_dev_decay) restarts with mppi_upload_state
+  return iterationLocal(h, h->external_iteration++, h->last_stride);
 }
 mppi_status mppi_iteration_merge(mppi_handle h)
 {
@@ -1896,6 +1917,26 @@ mppi_status mppi_rollout_costs(mppi_handle h, const float* x0, int stride)
   MPPI_TRY(launchRollout(h, 0, stride));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPPI_OK;
+}
+
+mppi_status mppi_enforce_constraints(mppi_handle h, const float* state, float* u)
+{
+  if (!h)
+    return MPPI_ERR_INVALID_ARG;
+  if (!u)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_enforce_constraints: null control");
+  {
+    // host path: no handle lock, no stream — a control publication from the state-estimator thread never queues behind the
+    // rollouts of a computeControl in flight (the reference clamps on the host too, controller.cuh:329-345)
+    std::lock_guard<std::mutex> params_lock(h->params_mu);
+    if (h->model->hostEnforceConstraints(u))
+      return MPPI_OK;
+  }
+  // the plugin overrides enforceConstraints(): a zero-length model step on the device returns the constrained control
+  std::vector<float> x(h->S, 0.0f);
+  if (state)
+    std::copy(state, state + h->S, x.begin());
+  return mppi_model_step(h, x.data(), u, 0.0f, 1);
 }
 
 mppi_status mppi_model_step(mppi_handle h, float* x, float* u, float dt, int enforce)

@@ -88,10 +88,22 @@ inline bool parseNpy(const std::vector<unsigned char>& b, Array& out, std::strin
     while (c < h.size() && h[c] == ' ')
       c++;
     size_t e = c;
+    if (c >= h.size())
+      return "";
     if (h[c] == '(')
-      e = h.find(')', c) + 1;
+    {
+      e = h.find(')', c);
+      if (e == std::string::npos)
+        return "";
+      e++;
+    }
     else if (h[c] == '\'')
-      e = h.find('\'', c + 1) + 1;
+    {
+      e = h.find('\'', c + 1);
+      if (e == std::string::npos)
+        return "";
+      e++;
+    }
     else
       while (e < h.size() && h[e] != ',' && h[e] != '}')
         e++;
@@ -119,9 +131,21 @@ inline bool parseNpy(const std::vector<unsigned char>& b, Array& out, std::strin
   {
     if (shape[i] >= '0' && shape[i] <= '9')
     {
-      long v = 0;
+      unsigned long long v = 0;
       while (i < shape.size() && shape[i] >= '0' && shape[i] <= '9')
-        v = v * 10 + (shape[i++] - '0');
+      {
+        v = v * 10 + (unsigned long long)(shape[i++] - '0');
+        if (v > 0x7fffffffull)  // dimensions are ints downstream; also keeps the element count below from overflowing
+        {
+          err = "NPY shape dimension out of range";
+          return false;
+        }
+      }
+      if (v != 0 && n > (size_t)0x7fffffffffffull / (size_t)v)
+      {
+        err = "NPY element count out of range";
+        return false;
+      }
       out.shape.push_back((int)v);
       n *= (size_t)v;
     }
@@ -136,7 +160,7 @@ inline bool parseNpy(const std::vector<unsigned char>& b, Array& out, std::strin
     return false;
   }
   const unsigned char* p = &b[hoff + hlen];
-  if (hoff + hlen + n * (size_t)width > b.size())
+  if (width <= 0 || width > 8 || n > (b.size() - (hoff + hlen)) / (size_t)width)
   {
     err = "truncated NPY payload";
     return false;
@@ -240,6 +264,11 @@ inline bool load(const std::string& path, std::map<std::string, Array>& out, std
     const size_t csize = rd32(&buf[cd + 20]), usize = rd32(&buf[cd + 24]);
     const int nlen = rd16(&buf[cd + 28]), xlen = rd16(&buf[cd + 30]), clen = rd16(&buf[cd + 32]);
     const size_t lho = rd32(&buf[cd + 42]);
+    if (cd + 46 + (size_t)nlen + (size_t)xlen + (size_t)clen > buf.size())
+    {
+      err = path + ": corrupt ZIP central directory (entry runs past the end of the file)";
+      return false;
+    }
     std::string name((const char*)&buf[cd + 46], nlen);
     cd += 46 + nlen + xlen + clen;
     if (csize == 0xffffffffu || usize == 0xffffffffu)
@@ -253,7 +282,9 @@ inline bool load(const std::string& path, std::map<std::string, Array>& out, std
       return false;
     }
     const size_t data_off = lho + 30 + rd16(&buf[lho + 26]) + rd16(&buf[lho + 28]);
-    if (data_off + csize > buf.size())
+    // deflate expands at most ~1032x; an uncompressed size beyond that (or beyond 1 GiB) is a corrupt / hostile directory
+    if (data_off > buf.size() || csize > buf.size() - data_off || usize > ((size_t)1 << 30) ||
+        (method == 8 && usize > 1040 * csize + 64))
     {
       err = path + ": truncated ZIP member";
       return false;

@@ -128,7 +128,10 @@ __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineAr
   double eta = 0.0, eta2 = 0.0;
   for (int b = tid; b < a.num_records; b += COMBINE_THREADS)
   {
-    const float s = mppi::det::exp(-lambda_inv * (rho_s[b] - rho));
+    // a record whose rollouts all cost +inf has rho_b = inf and U_b = eta_b = 0: scale 0 (inf - inf would be NaN when
+    // the global minimum is inf as well — then nothing has weight, as with the reference's global baseline)
+    const float dist = rho_s[b] - rho;
+    const float s = (dist == dist) ? mppi::det::exp(-lambda_inv * dist) : 0.0f;
     s_b[b] = s;
     eta += (double)s * (double)eta_s[b];
     eta2 += (double)s * (double)s * (double)eta2_s[b];

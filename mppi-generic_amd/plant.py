@@ -205,10 +205,9 @@ class BasePlant:
         u = interpolateControls(rel_time, self.control_traj_, dt)
         if self.feedback_gains_ is not None:
             u = u + interpolateFeedback(state, target_nominal_state, rel_time, self.feedback_gains_, dt)
-        # enforceConstraints on a zero state: a zero-length model step returns the constrained control
-        _, u = self.controller_.modelStep(np.zeros(self.controller_.STATE_DIM, np.float32), u, dt=0.0,
-                                          enforce_constraints=True)
-        return u
+        # host-side for the base rule and lock-free: this runs on the state-callback thread while computeControl may be in
+        # flight on the control-loop thread (mppi_enforce_constraints)
+        return self.controller_.enforceConstraints(state, u)
 
     def updateState(self, state, time):
         """base_plant.hpp:288-320"""
@@ -289,8 +288,8 @@ class BasePlant:
         """base_plant.hpp:566-603"""
         self.state_ = self.init_state_.copy()
         self.u_ = self.init_u_.copy()
-        self.controller_.updateImportanceSampler(
-            np.zeros((self.controller_.num_timesteps, self.controller_.CONTROL_DIM), np.float32))  # resetControls()
+        # controller_->resetControls() is an empty TODO in the reference (controller.cuh:617-620): an initial control
+        # trajectory set through updateImportanceSampler before the loop starts is kept
         while is_alive.is_set():
             self.runControlIteration(is_alive)
             wait_until_state_time = self.last_used_state_update_time_ + (1.0 / self.hz_) * self.optimization_stride_

@@ -44,6 +44,9 @@ struct Texture2D
     float qx = point[0] * (float)width, qy = point[1] * (float)height;
     qx = qx - 0.5f;
     qy = qy - 0.5f;
+    // the reference has no NaN rule (a NaN reaches an int conversion); the product maps it to texel 0, and so does this
+    qx = (qx == qx) ? qx : 0.0f;
+    qy = (qy == qy) ? qy : 0.0f;
     bool outside = false;
     if (address_mode[0] == 0)
     {
@@ -76,13 +79,14 @@ struct Texture2D
         result[ch] = at((int)std::round(qy), (int)std::round(qx));
         continue;
       }
-      const int x_min = std::min((int)std::floor(qx), width - 2), x_max = x_min + 1;
-      const int y_min = std::min((int)std::floor(qy), height - 2), y_max = y_min + 1;
-      const float y_min_interp =
-          at(y_min, x_min) * ((x_max - qx) / (x_max - x_min)) + at(y_min, x_max) * ((qx - x_min) / (x_max - x_min));
-      const float y_max_interp =
-          at(y_max, x_min) * ((x_max - qx) / (x_max - x_min)) + at(y_max, x_max) * ((qx - x_min) / (x_max - x_min));
-      result[ch] = y_min_interp * ((y_max - qy) / (y_max - y_min)) + y_max_interp * ((qy - y_min) / (y_max - y_min));
+      // 1-texel axes (not covered by the reference, which would index texel -1): both taps read texel 0
+      const int x_min = std::max(std::min((int)std::floor(qx), width - 2), 0), x_max = std::min(x_min + 1, width - 1);
+      const int y_min = std::max(std::min((int)std::floor(qy), height - 2), 0), y_max = std::min(y_min + 1, height - 1);
+      const float wx0 = x_max > x_min ? (x_max - qx) / (x_max - x_min) : 1.0f, wx1 = x_max > x_min ? (qx - x_min) / (x_max - x_min) : 0.0f;
+      const float wy0 = y_max > y_min ? (y_max - qy) / (y_max - y_min) : 1.0f, wy1 = y_max > y_min ? (qy - y_min) / (y_max - y_min) : 0.0f;
+      const float y_min_interp = at(y_min, x_min) * wx0 + at(y_min, x_max) * wx1;
+      const float y_max_interp = at(y_max, x_min) * wx0 + at(y_max, x_max) * wx1;
+      result[ch] = y_min_interp * wy0 + y_max_interp * wy1;
     }
   }
 };

@@ -42,6 +42,9 @@ class MockController:
     def modelStep(self, x, u, dt=None, enforce_constraints=True):
         return np.asarray(x, np.float32), np.clip(np.asarray(u, np.float32), -5.0, 5.0)
 
+    def enforceConstraints(self, state, u):
+        return np.clip(np.asarray(u, np.float32), -5.0, 5.0)
+
     def setLambda(self, lam):
         self.lam = lam
 

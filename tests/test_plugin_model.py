@@ -1,0 +1,131 @@
+"""Out-of-tree model registration (mppi_register_model / mppi_load_plugin; include/mppi_amd/engine/model_registry.hpp).
+
+The reference's user instantiates the controller templates with their own Dynamics / Cost in their own translation unit
+(src/controllers/cartpole/cartpole_mppi.cu:30-42).  Here examples/my_model/pendulum_model.hip is compiled on its own with
+hipcc into a library of its own and loaded into the engine at run time; nothing of libmppi_amd.so is rebuilt."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import mppi_generic_amd as m
+from common import SEED, host_noise
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(REPO, "examples", "my_model", "pendulum_model.hip")
+OUT_DIR = os.path.join(REPO, "examples", "_build")
+PLUGIN = os.path.join(OUT_DIR, "libpendulum_model.so")
+
+
+class PendulumParams(C.Structure):
+    _fields_ = [("mass", C.c_float), ("length", C.c_float), ("damping", C.c_float), ("gravity", C.c_float)]
+
+
+class PendulumCostParams(C.Structure):
+    _fields_ = [("control_cost_coeff", C.c_float * 1), ("discount", C.c_float), ("angle_coeff", C.c_float),
+                ("velocity_coeff", C.c_float), ("terminal_coeff", C.c_float), ("goal_angle", C.c_float)]
+
+
+def build_plugin():
+    if os.path.exists(PLUGIN) and os.path.getmtime(PLUGIN) >= max(
+            os.path.getmtime(SRC), os.path.getmtime(os.path.join(REPO, "include", "mppi_amd", "engine", "model_instance.hpp"))):
+        return PLUGIN
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-I" + os.path.join(REPO, "include"), SRC, "-o", PLUGIN]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return PLUGIN
+
+
+@pytest.fixture(scope="module")
+def plugin():
+    lib = m.load_library()
+    assert lib.mppi_load_plugin(build_plugin().encode()) == 0, lib.mppi_last_error(None)
+    return lib
+
+
+def test_plugin_builds_alone_and_registers(plugin):
+    """the user's translation unit compiles against include/ only, and its static initialiser registers the model"""
+    assert "user_pendulum" in plugin.mppi_list_models().decode().split("\n")
+    # the plugin's own kernels live in the plugin, not in libmppi_amd.so
+    syms = subprocess.run(["nm", "-D", "--defined-only", PLUGIN], capture_output=True, text=True).stdout
+    assert "PendulumDynamics" in syms and "mppi_create" not in syms
+
+
+def test_register_model_argument_checks(plugin):
+    fn = C.cast(plugin.mppi_device_count, C.c_void_p)  # any non-null function pointer
+    assert plugin.mppi_register_model(None, 0, fn, 0) == 1
+    assert plugin.mppi_register_model(b"x", 7, fn, 0) == 1
+    assert plugin.mppi_register_model(b"x", 0, fn, 12345) == 1  # header / library skew: sizeof(ModelBase) differs
+    assert b"different mppi_amd/engine/model_instance.hpp" in plugin.mppi_last_error(None)
+    assert plugin.mppi_load_plugin(b"/nonexistent/libnothing.so") == 1
+
+
+def _numpy_rollout_costs(v, x0, dt, p, c):
+    """float64 Euler rollout of the pendulum + cost, same loop structure as the rollout kernel (cost of the state AFTER the
+    step, averaged over T; reference: tests/include/kernel_tests/core/rollout_kernel_test.cu:505-541)"""
+    K, T, _ = v.shape
+    th = np.full(K, x0[0], np.float64)
+    om = np.full(K, x0[1], np.float64)
+    total = np.zeros(K)
+    inertia = p.mass * p.length ** 2
+    for t in range(T):
+        u = v[:, t, 0].astype(np.float64)
+        acc = (u - p.damping * om - p.mass * p.gravity * p.length * np.sin(th)) / inertia
+        th, om = th + om * dt, om + acc * dt
+        total += c.angle_coeff * (1.0 - np.cos(th - c.goal_angle)) + c.velocity_coeff * om ** 2
+    return total / T
+
+
+def _make(K, T, dt, lam, **kw):
+    eng = m.VanillaMPPIController("user_pendulum", K, T, dt, lam, 0.0, 1, seed=SEED, **kw)
+    p = PendulumParams(1.0, 1.0, 0.1, 9.81)
+    c = PendulumCostParams((C.c_float * 1)(0.0), 1.0, 10.0, 0.1, 0.0, np.pi)
+    eng.setDynamicsParams(p)
+    eng.setCostParams(c)
+    eng.setControlRanges([[-4.0, 4.0]])
+    return eng, p, c
+
+
+@pytest.mark.gpu
+def test_user_model_runs_and_matches_float64_rollout(gpu, plugin):
+    K, T, dt = 2048, 60, 0.02
+    eng, p, c = _make(K, T, dt, 1.0, save_samples=True)
+    eng.setSamplingParams([2.0], [0.0])
+    x0 = np.array([0.3, 0.0], np.float32)
+    eng.injectNoise(host_noise(1, K, T, 1))
+    eng.uploadState(x0)
+    eng.optimize(1)  # one optimisation iteration, no smoothing: u* is the plain weighted mean
+    costs = eng.getSampledCostSeq()[0]
+    v = eng.getSampledControls()[0]
+    assert np.abs(v).max() <= 4.0 and np.all(v[0] == 0.0)
+    want = _numpy_rollout_costs(v, x0, dt, p, c)
+    np.testing.assert_allclose(costs, want, rtol=1e-4)  # the reference's own GPU-vs-CPU bar (rollout_kernel_tests.cu:200-261)
+    w = np.exp(-(costs.astype(np.float64) - costs.min()) / 1.0)
+    u_direct = (w[:, None, None] * v.astype(np.float64)).sum(0) / w.sum()
+    assert np.abs(eng.getOptimalControlSeq()[0] - u_direct).max() <= 1e-5
+    # both kernel structures give the same bits for the user's model too
+    eng2, _, _ = _make(K, T, dt, 1.0, kernel_variant=1)
+    eng2.setSamplingParams([2.0], [0.0])
+    eng2.injectNoise(host_noise(1, K, T, 1))
+    eng2.uploadState(x0)
+    eng2.optimize(1)
+    assert np.array_equal(eng2.getSampledCostSeq()[0], costs)
+
+
+@pytest.mark.gpu
+def test_user_model_swings_up_in_closed_loop(gpu, plugin):
+    eng, _, _ = _make(4096, 100, 0.02, 0.1)
+    eng.setControlRanges([[-7.0, 7.0]])  # below m g l = 9.81: the pendulum has to pump energy to get up
+    eng.setSamplingParams([3.0], [0.0])
+    x = np.array([0.0, 0.0], np.float32)
+    for _ in range(600):
+        eng.computeControl(x, 1)
+        u = eng.getControlSeq()[0]
+        x, _ = eng.modelStep(x, u)
+        eng.slideControlSequence(1)
+    err = np.arctan2(np.sin(x[0] - np.pi), np.cos(x[0] - np.pi))
+    assert abs(err) < 0.4 and abs(x[1]) < 2.0, x
