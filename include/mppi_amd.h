@@ -161,8 +161,9 @@ typedef enum mppi_sampler_kind
 } mppi_sampler_kind;
 /** returns a new mppi::engine::ModelBase* (owned by the handle that asked for it) */
 typedef void* (*mppi_model_factory)(void);
-/** model_base_size = sizeof(mppi::engine::ModelBase) in the caller's build: a mismatch (header / library skew) is refused */
-mppi_status mppi_register_model(const char* name, int sampler_kind, mppi_model_factory factory, int model_base_size);
+/** abi_fingerprint = mppi::engine::engineAbiFingerprint() in the caller's build (sizes of ModelBase and of the kernel argument
+ *  blocks): a mismatch (header / library skew) is refused */
+mppi_status mppi_register_model(const char* name, int sampler_kind, mppi_model_factory factory, int abi_fingerprint);
 /** dlopen()s a library whose static initialisers call mppi_register_model; the library stays loaded */
 mppi_status mppi_load_plugin(const char* path);
 
@@ -253,8 +254,12 @@ mppi_status mppi_inject_noise(mppi_handle h, const float* eps, int n_iters);
  *   Vanilla  controllers/MPPI/mppi_controller.cu:151-241       x0 = [S]
  *   Tube     controllers/Tube-MPPI/tube_mppi_controller.cu:157-299   x0 = actual state [S]
  * Runs num_iters optimisation iterations on the device, then smoothing, state-trajectory propagation and constraint
- * enforcement (controllers/controller.cuh:557-586, 643-663; mppi_controller.cu:225-231) and returns when the results are
- * on the host.
+ * enforcement (controllers/controller.cuh:557-586, 643-663; mppi_controller.cu:225-231).
+ * Vanilla / Colored: inputs and results travel through host memory mapped into the device (no copy command, no stream
+ * synchronisation: the host spins on a flag the last kernel raises) and the call returns as soon as the CONTROL sequence and
+ * the statistics are on the host — the state / output trajectories of u* (a T-step serial re-rollout) land a little later;
+ * mppi_get_state_seq / mppi_get_output_seq wait for them and report a non-finite state trajectory (MPPI_ERR_NAN) then.
+ * Tube / Robust, or MPPI_AMD_NO_SPIN=1 in the environment: returns when all results are on the host.
  */
 mppi_status mppi_compute_control(mppi_handle h, const float* x0, int optimization_stride);
 /** getControlSeq (controllers/controller.cuh:433-436): u_out[T][C]; Tube: the actual system's sequence */

@@ -40,7 +40,67 @@ struct FinalizeArgs
   int constrain_mode;         ///< 0: Dynamics::enforceConstraints (mppi_controller.cu:227-231);
                               ///< 1: ColoredMPPI — only control channel 1 is clamped to its range, no deadband
                               ///<    (controllers/ColoredMPPI/colored_mppi_controller.cu:232-237)
+  /* Low-latency hand-over (single-system controllers): the *_out_d pointers then are host memory mapped into the device,
+   * the kernel copies the merge statistics next to them and raises flags the host spins on — flags_d[0] <- seq as soon as
+   * the control sequence (and the statistics) are out, i.e. BEFORE the T-step re-rollout of the state trajectory, and
+   * flags_d[1] <- seq when the trajectories are complete.  nullptr: no flags (results fetched with a copy + synchronise). */
+  unsigned* flags_d;
+  unsigned seq;
+  const float* stats_in_d;    ///< [stats_floats] merge statistics (combineKernel), or nullptr
+  float* stats_out_d;
+  int stats_floats;
 };
+
+/** all stores of the block are out (barrier), then one lane publishes `seq` at system scope: the host sees the data it guards */
+__device__ inline void raiseHostFlag(unsigned* flags_d, const int idx, const unsigned seq, const bool one_lane)
+{
+  __syncthreads();
+  if (flags_d && one_lane)
+  {
+    __threadfence_system();
+    __hip_atomic_store(flags_d + idx, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+/**
+ * enforceConstraints on every column of the smoothed control (mppi_controller.cu:227-231; ColoredMPPI: channel 1 only) and
+ * write-out.  Works on a COPY (`work`, the smoothing buffer that is free by now): the re-rollout that follows applies the
+ * constraints to its own copy of each column, and with a deadband the rule is not idempotent.  NL lanes share the element-
+ * wise loops; `column_lane` / `column_stride`: which columns this thread constrains (BY == 1: one column per lane; contract
+ * variant: every y lane takes its share of each column inside Dynamics::enforceConstraints).
+ */
+template <class DYN_T>
+__device__ inline void finalizeEmitControl(DYN_T* dynamics, const FinalizeArgs& a, const int z, const float* ctrl, float* work,
+                                           float* zero_state, const int elem_lane, const int elem_stride,
+                                           const int column_lane, const int column_stride)
+{
+  constexpr int C = DYN_T::CONTROL_DIM;
+  const int T = a.num_timesteps;
+  for (int e = elem_lane; e < T * C; e += elem_stride)
+    work[e] = ctrl[e];
+  __syncthreads();
+  if ((a.constrain_mask >> z) & 1)
+  {
+    if (a.constrain_mode == 1)
+    {
+      if constexpr (C > 1)
+        for (int t = elem_lane; t < T; t += elem_stride)
+          work[t * C + 1] = fminf(fmaxf(work[t * C + 1], dynamics->control_rngs_[1].x), dynamics->control_rngs_[1].y);
+    }
+    else
+    {
+      for (int t = column_lane; t < T; t += column_stride)
+        dynamics->enforceConstraints(zero_state, &work[t * C]);
+    }
+  }
+  __syncthreads();
+  for (int e = elem_lane; e < T * C; e += elem_stride)
+    a.control_out_d[(size_t)z * T * C + e] = work[e];
+  if (a.stats_in_d && a.stats_out_d)
+    for (int e = elem_lane; e < a.stats_floats; e += elem_stride)
+      a.stats_out_d[e] = a.stats_in_d[e];
+  raiseHostFlag(a.flags_d, 0, a.seq, elem_lane == 0);
+}
 
 /** by > 1 (LDS + barrier contract): the state and output trajectories are collected in LDS and written out once at the end —
  *  a block barrier waits for the wave's outstanding global stores, so storing every step put a memory round trip on
@@ -98,6 +158,8 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
   float* y_traj = x_traj + math::nearest_multiple_4(T * S);    // [T][O], BY > 1 only
 
   const float* uin = a.control_in_d + (size_t)z * T * C;
+  for (int i = ty; i < S; i += NL)
+    zero_state[i] = 0.0f;
 
   if ((a.smooth_mask >> z) & 1)
   {
@@ -128,9 +190,11 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
     for (int e = ty; e < T * C; e += NL)
       ctrl[e] = uin[e];
   }
+  __syncthreads();  // ctrl is complete
+  // the constrained control sequence goes out first: the host can act on it while the trajectory below is re-rolled
+  finalizeEmitControl(dynamics, a, z, ctrl, buf, zero_state, ty, NL, (BY == 1) ? lx : 0, LX);
   if constexpr (BY == 1)
   {
-    __syncthreads();  // ctrl is complete
     if (lx == 0)
     {
     // One lane per rollout: the whole trajectory is one thread's serial chain, so the state lives in registers and there
@@ -143,7 +207,6 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
       xr[i] = a.x0_d[(size_t)z * S + i];
       xdr[i] = 0.0f;
       xnr[i] = 0.0f;
-      zero_state[i] = 0.0f;
       a.state_out_d[((size_t)z * T + 0) * S + i] = xr[i];
     }
 #pragma unroll
@@ -181,7 +244,6 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
       }
     }
     }
-    __syncthreads();  // zero_state
   }
   else
   {
@@ -189,7 +251,6 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
   {
     x[i] = a.x0_d[(size_t)z * S + i];
     xdot[i] = 0.0f;
-    zero_state[i] = 0.0f;
     x_traj[i] = x[i];
   }
   for (int i = ty; i < O; i += BY)
@@ -228,27 +289,7 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
     for (int e = ty; e < T * O; e += BY)
       a.output_out_d[(size_t)z * T * O + e] = y_traj[e];
   }
-  // enforceConstraints on every column of the control (mppi_controller.cu:227-231)
-  if ((a.constrain_mask >> z) & 1)
-  {
-    if (a.constrain_mode == 1)
-    {
-      if constexpr (C > 1)
-        for (int t = ty; t < T; t += NL)
-          ctrl[t * C + 1] = fminf(fmaxf(ctrl[t * C + 1], dynamics->control_rngs_[1].x), dynamics->control_rngs_[1].y);
-    }
-    else
-    {
-      // BY == 1: one column per lane; contract variant: every y lane takes its share of each column
-      for (int t = (BY == 1) ? lx : 0; t < T; t += LX)
-      {
-        dynamics->enforceConstraints(zero_state, &ctrl[t * C]);
-      }
-    }
-  }
-  __syncthreads();
-  for (int e = ty; e < T * C; e += NL)
-    a.control_out_d[(size_t)z * T * C + e] = ctrl[e];
+  raiseHostFlag(a.flags_d, 1, a.seq, ty == 0 && lx == 0);
 }
 
 /**
@@ -320,15 +361,22 @@ __global__ void __launch_bounds__(64) finalizeRepKernel(DYN_T dynamics_obj, cons
       ctrl[e] = uin[e];
   }
   __syncthreads();
+  // the constrained control sequence goes out first (see finalizeKernel)
+  {
+    float zero_state[S];
+#pragma unroll
+    for (int i = 0; i < S; i++)
+      zero_state[i] = 0.0f;
+    finalizeEmitControl(dynamics, a, z, ctrl, buf, zero_state, lane, 64, lane, 64);
+  }
 
-  float x[S], xn[S], xdot[S], u[C], y[O], zero_state[S];
+  float x[S], xn[S], xdot[S], u[C], y[O];
 #pragma unroll
   for (int i = 0; i < S; i++)
   {
     x[i] = a.x0_d[(size_t)z * S + i];
     xn[i] = 0.0f;
     xdot[i] = 0.0f;
-    zero_state[i] = 0.0f;
   }
 #pragma unroll
   for (int i = 0; i < O; i++)
@@ -374,33 +422,7 @@ __global__ void __launch_bounds__(64) finalizeRepKernel(DYN_T dynamics_obj, cons
     for (int i = 0; i < S; i++)
       x[i] = xn[i];
   }
-  // enforceConstraints on every column of the control (mppi_controller.cu:227-231)
-  if ((a.constrain_mask >> z) & 1)
-  {
-    if (a.constrain_mode == 1)
-    {
-      if constexpr (C > 1)
-        for (int t = lane; t < T; t += 64)
-          ctrl[t * C + 1] = fminf(fmaxf(ctrl[t * C + 1], dynamics->control_rngs_[1].x), dynamics->control_rngs_[1].y);
-    }
-    else
-    {
-      for (int t = lane; t < T; t += 64)
-      {
-        float uc[C];
-#pragma unroll
-        for (int i = 0; i < C; i++)
-          uc[i] = ctrl[t * C + i];
-        dynamics->enforceConstraints(zero_state, uc);
-#pragma unroll
-        for (int i = 0; i < C; i++)
-          ctrl[t * C + i] = uc[i];
-      }
-    }
-  }
-  __syncthreads();
-  for (int e = lane; e < T * C; e += 64)
-    a.control_out_d[(size_t)z * T * C + e] = ctrl[e];
+  raiseHostFlag(a.flags_d, 1, a.seq, lane == 0);
 }
 
 }  // namespace kernels

@@ -143,6 +143,14 @@ struct ModelBase
                                       std::string& err) = 0;
 };
 
+/** fingerprint of the structures a model translation unit and libmppi_amd.so exchange (mppi_register_model refuses a
+ *  plugin built against other headers: its kernels would read the argument blocks with the wrong layout) */
+constexpr int engineAbiFingerprint()
+{
+  return (int)(sizeof(ModelBase) + 131 * sizeof(kernels::RolloutArgs) + 131 * 131 * sizeof(kernels::FinalizeArgs) +
+               7 * sizeof(kernels::RMPPIArgs) + 17 * sizeof(kernels::InitEvalArgs) + 31 * sizeof(SamplerLaunchState));
+}
+
 template <class DYN_T, int BY>
 __global__ void __launch_bounds__(BY) modelStepKernel(DYN_T dynamics_obj, float* x_d, float* u_d, float dt, int enforce)
 {

@@ -37,7 +37,7 @@ struct ModelRegistrar
 {
   ModelRegistrar(const char* name, int sampler_kind, mppi_model_factory factory)
   {
-    (void)mppi_register_model(name, sampler_kind, factory, (int)sizeof(ModelBase));
+    (void)mppi_register_model(name, sampler_kind, factory, engineAbiFingerprint());
   }
 };
 }  // namespace engine

@@ -13,7 +13,9 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -40,6 +42,8 @@ struct ModelRegistry
   std::mutex mu;
   std::map<std::pair<std::string, int>, mppi_model_factory> factories;
   std::string listing;
+  int refused = 0;  // registrations turned down so far (mppi_load_plugin reports the ones of the library it loaded)
+  std::string last_refusal;
 };
 static ModelRegistry& registry()
 {
@@ -103,6 +107,19 @@ struct mppi_handle_s
   float* out_block_d = nullptr;
   float* in_pin_h = nullptr;
   float* out_pin_h = nullptr;
+  /* low-latency hand-over of the single-system controllers (computeControlVanilla): host memory mapped into the device —
+   * the first kernel reads the inputs from io_in, the finalize kernel writes the results to io_out and raises io_flags the
+   * host spins on (flag 0: control sequence + statistics out; flag 1: state / output trajectories out) */
+  float* io_in_h = nullptr;
+  float* io_in_dev = nullptr;
+  float* io_out_h = nullptr;
+  float* io_out_dev = nullptr;
+  unsigned* io_flags_h = nullptr;
+  unsigned* io_flags_dev = nullptr;
+  unsigned io_seq = 0;
+  bool results_in_io = false;      // the last finalize pass wrote to io_out_h (low-latency path), not to out_block_d
+  bool traj_pending = false;       // state_h / output of the last call are still being written by the finalize kernel
+  bool low_latency = true;         // MPPI_AMD_NO_SPIN=1 in the environment: copy + hipStreamSynchronize hand-over instead
   float* step_pin_h = nullptr;     // [S + C] pinned mirror of step_x_d | step_u_d (one block too)
   size_t in_floats = 0, out_floats = 0;
   bool out_pin_fresh = false;      // out_pin_h holds the results (incl. stats) of the last finalize pass; reset by launches
@@ -236,11 +253,18 @@ mppi_status mppi_register_model(const char* name, int sampler_kind, mppi_model_f
 {
   if (!name || !*name || !factory || (sampler_kind != MPPI_SAMPLER_GAUSSIAN && sampler_kind != MPPI_SAMPLER_COLORED))
     return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_register_model: null name / factory or unknown sampler kind");
-  if (model_base_size != (int)sizeof(ModelBase))
+  if (model_base_size != engineAbiFingerprint())
+  {
+    ModelRegistry& rr = registry();
+    std::lock_guard<std::mutex> lock(rr.mu);
+    rr.refused++;
+    rr.last_refusal = std::string("model '") + name + "' was built against other mppi_amd/engine headers than this library";
+  }
+  if (model_base_size != engineAbiFingerprint())
     return fail(nullptr, MPPI_ERR_INVALID_ARG,
                 std::string("mppi_register_model('") + name + "'): built against a different mppi_amd/engine/model_instance.hpp "
-                "than this library (sizeof(ModelBase) " + std::to_string(model_base_size) + " vs " +
-                std::to_string(sizeof(ModelBase)) + ")");
+                "than this library (ABI fingerprint " + std::to_string(model_base_size) + " vs " +
+                std::to_string(engineAbiFingerprint()) + "): rebuild the plugin");
   ModelRegistry& r = registry();
   std::lock_guard<std::mutex> lock(r.mu);
   r.factories[{ name, sampler_kind }] = factory;  // a later registration of the same name replaces the earlier one
@@ -251,11 +275,21 @@ mppi_status mppi_load_plugin(const char* path)
 {
   if (!path)
     return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_load_plugin: null path");
+  int refused_before = 0;
+  {
+    std::lock_guard<std::mutex> lock(registry().mu);
+    refused_before = registry().refused;
+  }
   void* lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
   if (!lib)
   {
     const char* e = dlerror();
     return fail(nullptr, MPPI_ERR_INVALID_ARG, std::string("mppi_load_plugin: ") + (e ? e : "dlopen failed"));
+  }
+  {
+    std::lock_guard<std::mutex> lock(registry().mu);
+    if (registry().refused != refused_before)
+      return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_load_plugin: " + registry().last_refusal + " — rebuild the plugin");
   }
   return MPPI_OK;  // its static initialisers have registered the models; the library stays loaded
 }
@@ -270,6 +304,14 @@ static void freeAll(mppi_handle h)
 {
   // x0_d, mean_d, history_d and ctrl_out_d, state_out_d, output_out_d, stats_d are slices of in_block_d / out_block_d
   h->x0_d = h->mean_d = h->history_d = h->ctrl_out_d = h->state_out_d = h->output_out_d = h->stats_d = nullptr;
+  if (h->io_in_h)
+    (void)hipHostFree(h->io_in_h);
+  if (h->io_out_h)
+    (void)hipHostFree(h->io_out_h);
+  if (h->io_flags_h)
+    (void)hipHostFree(h->io_flags_h);
+  h->io_in_h = h->io_out_h = nullptr;
+  h->io_flags_h = nullptr;
   if (h->in_pin_h)
     (void)hipHostFree(h->in_pin_h);
   if (h->out_pin_h)
@@ -479,6 +521,22 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     }
     memset(h->in_pin_h, 0, h->in_floats * sizeof(float));
     memset(h->out_pin_h, 0, h->out_floats * sizeof(float));
+    const char* no_spin = getenv("MPPI_AMD_NO_SPIN");
+    h->low_latency = !(no_spin && no_spin[0] == '1');
+    const unsigned map_flags = hipHostMallocMapped | hipHostMallocCoherent;
+    if (hipHostMalloc((void**)&h->io_in_h, h->in_floats * sizeof(float), map_flags) != hipSuccess ||
+        hipHostMalloc((void**)&h->io_out_h, h->out_floats * sizeof(float), map_flags) != hipSuccess ||
+        hipHostMalloc((void**)&h->io_flags_h, 64, map_flags) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->io_in_dev, h->io_in_h, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->io_out_dev, h->io_out_h, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->io_flags_dev, h->io_flags_h, 0) != hipSuccess)
+    {
+      freeAll(hp);
+      return fail(nullptr, MPPI_ERR_HIP, "hipHostMalloc of the device-mapped hand-over buffers failed");
+    }
+    memset(h->io_in_h, 0, h->in_floats * sizeof(float));
+    memset(h->io_out_h, 0, h->out_floats * sizeof(float));
+    memset(h->io_flags_h, 0, 64);
   }
   ALLOC_OR_FAIL(h->costs_d, (size_t)D * K);
   ALLOC_OR_FAIL(h->partials_d, (size_t)D * h->num_blocks * h->PS);
@@ -1017,6 +1075,7 @@ static mppi_status finalize(mppi_handle h, const float* ctrl_in_d, int smooth_ma
   mppi_status st = h->model->launchFinalize(nsys, a, h->stream, err);
   if (st != MPPI_OK)
     return fail(h, st, err);
+  h->results_in_io = false;
   // controls, states, outputs and the merge statistics come back with ONE copy into pinned memory and one synchronisation
   HIP_TRY(h, hipMemcpyAsync(h->out_pin_h, h->out_block_d, sizeof(float) * h->out_floats, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1102,26 +1161,54 @@ static void parseStats(mppi_handle h, const float* st)
   }
 }
 
+/** spins on a flag the finalize kernel raises in host memory; falls back to a stream synchronisation when the flag does not
+ *  show within the limit (a failed launch, a wedged device): the caller then sees the HIP error instead of a hang */
+static mppi_status waitHostFlag(mppi_handle h, int idx, unsigned seq)
+{
+  using clock = std::chrono::steady_clock;
+  const clock::time_point t0 = clock::now();
+  volatile unsigned* flag = h->io_flags_h + idx;
+  unsigned spins = 0;
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+  {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+    if ((++spins & 0x3ff) == 0 && std::chrono::duration<double>(clock::now() - t0).count() > 2.0)
+    {
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+        return fail(h, MPPI_ERR_HIP, "the finalize kernel finished without raising its hand-over flag");
+      break;
+    }
+  }
+  return MPPI_OK;
+}
+
+/** the state / output trajectories of the last low-latency computeControl: wait for the finalize kernel's second flag */
+static mppi_status ensureTrajectories(mppi_handle h)
+{
+  if (!h->traj_pending)
+    return MPPI_OK;
+  MPPI_TRY(waitHostFlag(h, 1, h->io_seq));
+  h->traj_pending = false;
+  const int T = h->cfg.num_timesteps;
+  const float* out = h->io_out_h;
+  std::copy(out + (h->state_out_d - h->out_block_d), out + (h->state_out_d - h->out_block_d) + (size_t)T * h->S,
+            h->state_h.begin());
+  if (!allFinite(h->state_h))  // base_plant.hpp:515-528 checks the state trajectory as well as the control
+    return fail(h, MPPI_ERR_NAN, "non-finite value in the state sequence of the last mppi_compute_control");
+  return MPPI_OK;
+}
+
 static mppi_status computeControlVanilla(mppi_handle h, const float* x0, int stride)
 {
-  // one hand-over in (x0, nominal control, control history), one back (control, state and output trajectories, stats):
-  // two copies through pinned memory and a single synchronisation per call
   const int T = h->cfg.num_timesteps;
-  float* in = h->in_pin_h;
-  std::copy(x0, x0 + h->S, in + (h->x0_d - h->in_block_d));
-  std::copy(h->control_h.begin(), h->control_h.end(), in + (h->mean_d - h->in_block_d));
-  std::copy(h->history_h.begin(), h->history_h.end(), in + (h->history_d - h->in_block_d));
-  HIP_TRY(h, hipMemcpyAsync(h->in_block_d, in, sizeof(float) * h->in_floats, hipMemcpyHostToDevice, h->stream));
-  for (int it = 0; it < h->cfg.num_iters; it++)
-    MPPI_TRY(iteration(h, it, stride));
   kernels::FinalizeArgs a{};
   a.control_in_d = h->mean_d;
   a.history_d = h->history_d;
   a.history_stride = 0;
   a.x0_d = h->x0_d;
-  a.control_out_d = h->ctrl_out_d;
-  a.state_out_d = h->state_out_d;
-  a.output_out_d = h->output_out_d;
   a.dt = h->cfg.dt;
   a.num_timesteps = T;
   a.smooth_mask = 1;
@@ -1129,6 +1216,57 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0, int str
   // ColoredMPPI clamps only control channel 1 after smoothing (colored_mppi_controller.cu:232-237)
   a.constrain_mode = h->cfg.controller == MPPI_CONTROLLER_COLORED ? 1 : 0;
   std::string err;
+  if (h->low_latency)
+  {
+    /* Inputs and results travel through host memory mapped into the device: no copy command, no stream synchronisation.
+     * The call returns when the control sequence and the merge statistics are out (flag 0), while the finalize kernel
+     * still re-rolls the state trajectory of u* — a T-step serial chain, ~1/3 of the call for Cartpole; the trajectory
+     * getters wait for flag 1 (tools/ubench/handover.hip: 3 kernels + spin 15 us against 23 us with copies + synchronise). */
+    if (h->traj_pending)  // a caller that never asked for the previous trajectories: the kernel must be done with io_out
+      MPPI_TRY(waitHostFlag(h, 1, h->io_seq));
+    h->traj_pending = false;
+    float* in = h->io_in_h;
+    std::copy(x0, x0 + h->S, in + (h->x0_d - h->in_block_d));
+    std::copy(h->control_h.begin(), h->control_h.end(), in + (h->mean_d - h->in_block_d));
+    std::copy(h->history_h.begin(), h->history_h.end(), in + (h->history_d - h->in_block_d));
+    hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+    HIP_TRY(h, hipGetLastError());
+    for (int it = 0; it < h->cfg.num_iters; it++)
+      MPPI_TRY(iteration(h, it, stride));
+    a.control_out_d = h->io_out_dev + (h->ctrl_out_d - h->out_block_d);
+    a.state_out_d = h->io_out_dev + (h->state_out_d - h->out_block_d);
+    a.output_out_d = h->io_out_dev + (h->output_out_d - h->out_block_d);
+    a.stats_in_d = h->stats_d;
+    a.stats_out_d = h->io_out_dev + (h->stats_d - h->out_block_d);
+    a.stats_floats = kernels::STATS_STRIDE;
+    a.flags_d = h->io_flags_dev;
+    a.seq = ++h->io_seq;
+    const mppi_status st = h->model->launchFinalize(1, a, h->stream, err);
+    if (st != MPPI_OK)
+      return fail(h, st, err);
+    h->out_pin_fresh = false;
+    h->results_in_io = true;
+    h->traj_pending = true;  // set before the wait: a failing wait must not leave io_out unguarded for the next call
+    MPPI_TRY(waitHostFlag(h, 0, h->io_seq));
+    const float* out = h->io_out_h;
+    std::copy(out, out + (size_t)T * h->C, h->control_h.begin());
+    parseStats(h, out + (h->stats_d - h->out_block_d));
+    if (!allFinite(h->control_h))
+      return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control sequence");
+    return MPPI_OK;
+  }
+  // one hand-over in (x0, nominal control, control history), one back (control, state and output trajectories, stats):
+  // two copies through pinned memory and a single synchronisation per call
+  float* in = h->in_pin_h;
+  std::copy(x0, x0 + h->S, in + (h->x0_d - h->in_block_d));
+  std::copy(h->control_h.begin(), h->control_h.end(), in + (h->mean_d - h->in_block_d));
+  std::copy(h->history_h.begin(), h->history_h.end(), in + (h->history_d - h->in_block_d));
+  HIP_TRY(h, hipMemcpyAsync(h->in_block_d, in, sizeof(float) * h->in_floats, hipMemcpyHostToDevice, h->stream));
+  for (int it = 0; it < h->cfg.num_iters; it++)
+    MPPI_TRY(iteration(h, it, stride));
+  a.control_out_d = h->ctrl_out_d;
+  a.state_out_d = h->state_out_d;
+  a.output_out_d = h->output_out_d;
   const mppi_status st = h->model->launchFinalize(1, a, h->stream, err);
   if (st != MPPI_OK)
     return fail(h, st, err);
@@ -1139,6 +1277,8 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0, int str
   std::copy(out + (h->state_out_d - h->out_block_d), out + (h->state_out_d - h->out_block_d) + (size_t)T * h->S,
             h->state_h.begin());
   parseStats(h, out + (h->stats_d - h->out_block_d));
+  h->out_pin_fresh = true;
+  h->results_in_io = false;
   // base_plant.hpp:515-528 checks both the control and the state trajectory
   if (!allFinite(h->control_h) || !allFinite(h->state_h))
     return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control or state sequence");
@@ -1386,6 +1526,9 @@ mppi_status mppi_compute_control(mppi_handle h, const float* x0, int stride)
   CHECK_HANDLE(h);
   if (!x0 || stride < 0)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_compute_control: null state or negative stride");
+  for (int i = 0; i < h->S; i++)  // base_plant.hpp:466-470 skips the iteration on a non-finite state; here the call says so
+    if (!std::isfinite(x0[i]))
+      return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite initial state");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   h->last_stride = stride;
   if (h->cfg.controller == MPPI_CONTROLLER_TUBE)
@@ -1408,6 +1551,7 @@ mppi_status mppi_get_state_seq(mppi_handle h, float* x)
   CHECK_HANDLE(h);
   if (!x)
     return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  MPPI_TRY(ensureTrajectories(h));
   // RobustMPPI::getTargetStateSeq returns the nominal state trajectory (robust_mppi_controller.cuh:131-134)
   const std::vector<float>& src = h->cfg.controller == MPPI_CONTROLLER_ROBUST ? h->nominal_state_h : h->state_h;
   std::copy(src.begin(), src.end(), x);
@@ -1420,6 +1564,13 @@ mppi_status mppi_get_output_seq(mppi_handle h, float* y)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_get_output_seq: null");
   // system 0 of the last finalize pass is the trajectory mppi_get_state_seq reports (real system for Vanilla / Tube, the
   // nominal one for Robust MPPI)
+  if (h->results_in_io)
+  {  // the last finalize pass wrote its outputs to the device-mapped host block
+    MPPI_TRY(ensureTrajectories(h));
+    const float* src = h->io_out_h + (h->output_out_d - h->out_block_d);
+    std::copy(src, src + (size_t)h->cfg.num_timesteps * h->O, y);
+    return MPPI_OK;
+  }
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipMemcpyAsync(y, h->output_out_d, sizeof(float) * h->cfg.num_timesteps * h->O, hipMemcpyDeviceToHost,
                             h->stream));

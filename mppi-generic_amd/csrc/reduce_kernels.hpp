@@ -211,6 +211,17 @@ __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineAr
   }
 }
 
+/**
+ * First kernel of a low-latency mppi_compute_control: the inputs of the call (x0 | nominal control | control history, the
+ * handle's input block) are read straight from host memory mapped into the device and written to the device-resident
+ * block the rollout kernels read — one launch boundary (~1.5 us) instead of a copy command (~3 us, tools/ubench/handover.hip).
+ */
+__global__ void __launch_bounds__(256) ingestKernel(const float* __restrict__ host_mapped, float* __restrict__ dst, int n)
+{
+  for (int i = (int)threadIdx.x; i < n; i += 256)
+    dst[i] = host_mapped[i];
+}
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Unfused kernel-level operators with the reference's launch-wrapper semantics, exported through the C ABI for the
  * kernel-level parity tests (reference tests: tests/mppi_core/normexp_kernel_tests.cu, weightedreduction_kernel_tests.cu)

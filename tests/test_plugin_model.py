@@ -29,8 +29,11 @@ class PendulumCostParams(C.Structure):
 
 
 def build_plugin():
-    if os.path.exists(PLUGIN) and os.path.getmtime(PLUGIN) >= max(
-            os.path.getmtime(SRC), os.path.getmtime(os.path.join(REPO, "include", "mppi_amd", "engine", "model_instance.hpp"))):
+    newest = os.path.getmtime(SRC)
+    for d, _, files in os.walk(os.path.join(REPO, "include")):
+        for f in files:
+            newest = max(newest, os.path.getmtime(os.path.join(d, f)))
+    if os.path.exists(PLUGIN) and os.path.getmtime(PLUGIN) >= newest:
         return PLUGIN
     os.makedirs(OUT_DIR, exist_ok=True)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
@@ -59,7 +62,7 @@ def test_register_model_argument_checks(plugin):
     fn = C.cast(plugin.mppi_device_count, C.c_void_p)  # any non-null function pointer
     assert plugin.mppi_register_model(None, 0, fn, 0) == 1
     assert plugin.mppi_register_model(b"x", 7, fn, 0) == 1
-    assert plugin.mppi_register_model(b"x", 0, fn, 12345) == 1  # header / library skew: sizeof(ModelBase) differs
+    assert plugin.mppi_register_model(b"x", 0, fn, 12345) == 1  # header / library skew: the ABI fingerprint differs
     assert b"different mppi_amd/engine/model_instance.hpp" in plugin.mppi_last_error(None)
     assert plugin.mppi_load_plugin(b"/nonexistent/libnothing.so") == 1
 

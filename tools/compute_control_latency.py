@@ -27,4 +27,19 @@ for K in (2048, 16384):
         eng.getControlSeq()
         eng.slideControlSequence(1)
     t2 = time.perf_counter()
-    print("K=%d: computeControl %.1f us; + getControlSeq + slide %.1f us" % (K, (t1 - t0) / n * 1e6, (t2 - t1) / n * 1e6))
+    # time until the CONTROL is back, from an idle stream (the state trajectory of the previous call has landed)
+    acc = 0.0
+    for _ in range(n):
+        eng.getTargetStateSeq()
+        ta = time.perf_counter()
+        eng.computeControl(x, 1)
+        acc += time.perf_counter() - ta
+    # ... and until control AND state trajectory are back
+    t3 = time.perf_counter()
+    for _ in range(n):
+        eng.computeControl(x, 1)
+        eng.getTargetStateSeq()
+    t4 = time.perf_counter()
+    print("K=%d: computeControl back to back %.1f us; + getControlSeq + slide %.1f us; control ready (idle stream) %.1f us; "
+          "control + state trajectory %.1f us" % (K, (t1 - t0) / n * 1e6, (t2 - t1) / n * 1e6, acc / n * 1e6,
+                                                   (t4 - t3) / n * 1e6))
