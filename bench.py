@@ -4,8 +4,15 @@
 A "step" is one pass of the optimisation-loop body (sample -> K x T rollout -> baseline/normExp -> weighted reduction,
 mean <- u*) with x0 and the control mean already resident in HBM.  Workload at every N: Cartpole
 (CartpoleDynamics + CartpoleQuadraticCost), K = 16384 rollouts PER GPU, T = 100, fp32, Philox noise drawn in the kernel.
-N > 1 is weak scaling: rank r owns rollouts [r*K, (r+1)*K) of a K*N-rollout problem and the ranks exchange one
+N > 1 defaults to weak scaling: rank r owns rollouts [r*K, (r+1)*K) of a K*N-rollout problem and the ranks exchange one
 (T*C+4)-float record per iteration (RCCL all-gather) — value counts K-rollout iteration units over all ranks.
+--scaling strong splits the SAME K = 16384 problem over the ranks (value = iterations/s of that one problem); --workload
+autorally runs AutoRally-NN K = 16384, T = 150 as the primary workload instead (7x the work per rollout: the configuration
+where sharding a fixed problem can pay — DESIGN.md §6).
+
+The timed region is EXACTLY --steps iterations between barrier + synchronize; because 20 Cartpole steps are 0.7 ms, the region
+is repeated (each repetition bracketed the same way) until at least --min-time seconds have been timed in total and
+ms_per_step is the median repetition — the driver's --steps 20 and a 2000-step run then agree.
 
 roofline: algorithmic bytes of the dominant kernel (rolloutKernel) per launch, B_alg = 4*(2*K*T*C + 2*K + 2*T*C)
 (SURVEY.md §8d), divided by its average duration measured with HIP events on the engine's own stream.
@@ -107,6 +114,67 @@ def cpu_baseline(cfg, budget_s=12.0):
     }
 
 
+def latency_model(device, iteration_us):
+    """What bounds an iteration of this design at K=16384 (t_floor ~ T * t_step + n_launch * t_launch), measured
+    live: the rollout kernel against T (slope = time of one dependent rollout step on the dynamics wave, intercept = launch
+    ramp + prologue + block softmin epilogue + one launch boundary, since the launches are timed back to back), and the
+    cost of a dependent kernel boundary on an idle stream (trivial kernels)."""
+    import numpy as np
+    import mppi_generic_amd as m
+    from common import cartpole_cfg, make_engine
+    ts, us = [25, 50, 100, 200], []
+    for tt in ts:
+        e = make_engine(cartpole_cfg(K=K_PER_GPU, T=tt), device=device)
+        e.uploadState(np.zeros(4, np.float32))
+        e.optimize(20, True)
+        _, ms_roll = e.timeIterations(100)
+        us.append(ms_roll / 100 * 1e3)
+        e.close()
+    slope, intercept = np.polyfit(np.asarray(ts, np.float64), np.asarray(us, np.float64), 1)
+    boundary = m.launch_boundary_us(device, 400)
+    floor = slope * T + intercept + boundary  # rollout kernel (its boundary is in the intercept) + the merge launch's boundary
+    return {"t_scan_T": ts, "t_scan_kernel_us": [round(u, 2) for u in us], "step_ns": round(slope * 1e3, 1),
+            "fixed_us": round(intercept, 2), "launch_boundary_us": round(boundary, 2), "n_launch": 2,
+            "latency_floor_us": round(floor, 2), "iteration_us": round(iteration_us, 2),
+            "frac_of_floor": round(floor / iteration_us, 4),
+            "definition": "latency_floor_us = step_ns * T + fixed_us + launch_boundary_us: the rollout kernel as it is plus the "
+                          "bare boundary of the merge launch; iteration - floor = the merge kernel's own two memory round trips"}
+
+
+def compute_control_latency(device, x0):
+    """what a control loop sees (wall time per compute_control): inputs handed over from the host, one
+    iteration, smoothing + constraints + re-rollout of u*, results back — PCIe-inclusive, never `value`"""
+    from common import cartpole_cfg, make_engine
+    eng = make_engine(cartpole_cfg(K=K_PER_GPU, T=T), device=device)
+    for _ in range(50):
+        eng.computeControl(x0, 1)
+    n = 300
+    ready = 0.0
+    for _ in range(n):
+        eng.getTargetStateSeq()  # the previous call's trajectory has landed: the stream is idle
+        t_a = time.perf_counter()
+        eng.computeControl(x0, 1)
+        ready += time.perf_counter() - t_a
+    t_a = time.perf_counter()
+    for _ in range(n):
+        eng.computeControl(x0, 1)
+        eng.getTargetStateSeq()
+    full = time.perf_counter() - t_a
+    t_a = time.perf_counter()
+    for _ in range(n):
+        eng.computeControl(x0, 1)
+        eng.getControlSeq()
+        eng.slideControlSequence(1)
+    loop = time.perf_counter() - t_a
+    eng.close()
+    return {"control_ready_us": round(ready / n * 1e6, 2), "control_and_state_trajectory_us": round(full / n * 1e6, 2),
+            "closed_loop_period_us": round(loop / n * 1e6, 2),
+            "definition": "control_ready: mppi_compute_control from an idle stream until the control sequence is on the host "
+                          "(the call returns then; the finalize kernel is still re-rolling the state trajectory); "
+                          "control_and_state_trajectory: + mppi_get_state_seq; closed_loop_period: computeControl + "
+                          "getControlSeq + slide back to back"}
+
+
 def autorally_leg(device):
     """AutoRally NeuralNetModel (FNN 6-32-32-4, synthetic weights) + ARStandardCost, K=16384, T=150, one GPU:
     iterations/s and the MFMA roofline of the NN forward (F_alg = 2 * sum(MAC) * K * T)."""
@@ -204,6 +272,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: K rollouts per GPU (default); strong: K rollouts in total, split over the GPUs")
+    ap.add_argument("--workload", choices=["cartpole", "autorally"], default="cartpole")
+    ap.add_argument("--min-time", type=float, default=0.25, help="repeat the K-step timed region until this many seconds are timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--primary-only", action="store_true", help="skip the secondary legs (AutoRally-NN, LSTM+colored, DI-Tube)")
     args = ap.parse_args()
@@ -230,57 +302,110 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="gloo")
 
-    cfg = cartpole_cfg(K=K_PER_GPU * world, T=T)
+    strong = args.scaling == "strong"
+    k_total = K_PER_GPU if strong else K_PER_GPU * world
+    assert k_total % world == 0
+    if args.workload == "autorally":
+        t_steps = 150
+        cfg = autorally_cfg(K=k_total, T=t_steps, lambda_=1.0)
+    else:
+        t_steps = T
+        cfg = cartpole_cfg(K=k_total, T=t_steps)
+    k_local = k_total // world
     eng = make_engine(cfg, device=local_rank, rank=rank, world_size=world)
     x0 = cfg["x0"]
     exchange = "none"
     run = lambda n: eng.optimize(n, True)  # noqa: E731
     if world > 1:
         import ctypes as C
+        import hashlib
+        import threading
         from mppi_generic_amd.distributed import HostStagedExchange
         lib = m.load_library()
-        uid = [None]
-        if rank == 0:
-            buf = C.create_string_buffer(128)
-            nb = C.c_size_t()
-            st = lib.mppi_rccl_unique_id(buf, 128, C.byref(nb))
-            uid[0] = bytes(buf.raw) if st == 0 else None
-        dist.broadcast_object_list(uid, src=0)
-        native_ok, why = False, "no RCCL unique id"
-        if uid[0] is not None:
-            # the first collective runs under a watchdog: a communicator that never forms must not hang the bench
-            import threading
-            res = {"ok": False, "why": "RCCL communicator setup or first all-gather did not finish within 120 s"}
+        want = os.environ.get("MPPI_BENCH_EXCHANGE", "auto")  # auto | p2p | rccl | host
+
+        def guarded(fn, limit_s, what):
+            """run fn under a watchdog: an exchange that never completes must not hang the bench"""
+            res = {"ok": False, "why": what + " did not finish within %d s" % limit_s}
 
             def attempt():
                 try:
-                    eng.commInitRccl(uid[0])
-                    eng.uploadState(x0)
-                    eng.optimize(1, True)
-                    res["ok"] = bool(np.isfinite(eng.getOptimalControlSeq()).all())
-                    res["why"] = "non-finite result after the first exchanged iteration"
+                    fn()
+                    res["ok"] = True
                 except Exception as e:  # noqa: BLE001
-                    res["why"] = str(e)
+                    res["why"] = what + ": " + str(e)
 
             th = threading.Thread(target=attempt, daemon=True)
             th.start()
-            th.join(120.0)
-            stuck = th.is_alive()
-            native_ok, why = (res["ok"] and not stuck), res["why"]
-            if stuck:
-                globals()["_HARD_EXIT"] = True  # a thread is parked inside the collective library: leave with os._exit
-        flags = [None] * world
-        dist.all_gather_object(flags, (native_ok, why))
-        if all(f[0] for f in flags):
-            exchange = "rccl all-gather of %d floats per rank per iteration (library-owned communicator)" % eng.exchangeBuffers()[2]
-        else:
-            # fall back to the host-staged exchange over the gloo group: slower, but independent of the collective library
-            reason = next(f[1] for f in flags if not f[0])
-            eng = make_engine(cfg, device=local_rank, rank=rank, world_size=world)
+            th.join(limit_s)
+            if th.is_alive():
+                globals()["_HARD_EXIT"] = True  # a thread is parked inside a library call: leave with os._exit
+                res["ok"] = False
+            return res["ok"], res["why"]
+
+        def first_iteration_agrees(e):
+            """one exchanged iteration: finite, and every rank ends with the same bits"""
+            e.uploadState(x0)
+            e.optimize(1, True)
+            u = e.getOptimalControlSeq()
+            if not np.isfinite(u).all():
+                raise RuntimeError("non-finite result after the first exchanged iteration")
+            digests = [None] * world
+            dist.all_gather_object(digests, hashlib.sha1(u.tobytes()).hexdigest())
+            if len(set(digests)) != 1:
+                raise RuntimeError("ranks disagree on u* after the first exchanged iteration")
+
+        def all_ok(flag_why):
+            flags = [None] * world
+            dist.all_gather_object(flags, flag_why)
+            return all(f[0] for f in flags), next((f[1] for f in flags if not f[0]), "")
+
+        done, reasons = False, []
+        # 1. P2P mailbox over xGMI: every rank writes its record straight into the peers' memory (hipIpc-mapped)
+        if want in ("auto", "p2p"):
+            def p2p_setup():
+                handles = [None] * world
+                dist.all_gather_object(handles, eng.p2pMailboxHandle())
+                eng.p2pConnect(handles)
+                first_iteration_agrees(eng)
+            ok, why = all_ok(guarded(p2p_setup, 120, "P2P mailbox setup"))
+            if ok:
+                done = True
+                exchange = "p2p mailbox over xGMI: one record of %d floats written into every peer's memory per iteration" % (
+                    eng.exchangeBuffers()[2])
+            else:
+                reasons.append(why[:160])
+                eng = make_engine(cfg, device=local_rank, rank=rank, world_size=world)
+        # 2. the library's own RCCL communicator
+        if not done and want in ("auto", "rccl"):
+            uid = [None]
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                nb = C.c_size_t()
+                st = lib.mppi_rccl_unique_id(buf, 128, C.byref(nb))
+                uid[0] = bytes(buf.raw) if st == 0 else None
+            dist.broadcast_object_list(uid, src=0)
+            if uid[0] is not None:
+                def rccl_setup():
+                    eng.commInitRccl(uid[0])
+                    first_iteration_agrees(eng)
+                ok, why = all_ok(guarded(rccl_setup, 120, "RCCL communicator setup / first all-gather"))
+            else:
+                ok, why = False, "no RCCL unique id"
+            if ok:
+                done = True
+                exchange = "rccl all-gather of %d floats per rank per iteration (library-owned communicator)" % eng.exchangeBuffers()[2]
+            else:
+                reasons.append(why[:160])
+                eng = make_engine(cfg, device=local_rank, rank=rank, world_size=world)
+        # 3. host-staged exchange over the gloo group: slower, but independent of device-side communication
+        if not done:
             hx = HostStagedExchange(eng)
             run = lambda n: (hx.iterate(n), eng.synchronize())  # noqa: E731
-            exchange = "host-staged all-gather over gloo of %d floats per rank per iteration (native RCCL unavailable: %s)" % (
-                eng.exchangeBuffers()[2], reason[:120])
+            exchange = "host-staged all-gather over gloo of %d floats per rank per iteration (%s)" % (
+                eng.exchangeBuffers()[2], "; ".join(reasons) if reasons else "requested")
+        elif reasons:
+            exchange += " [fell back after: " + "; ".join(reasons) + "]"
 
     eng.uploadState(x0)
 
@@ -290,17 +415,27 @@ def main():
         torch.cuda.synchronize()
 
     run(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+
+    def timed_region():
+        """EXACTLY --steps iterations between barrier + synchronize on both sides; max over ranks"""
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        barrier()
+        dt_ = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt_], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return dt_
+
+    # every rank repeats the region the same number of times (decided from the first, max-reduced, repetition)
+    reps = [timed_region()]
+    n_rep = int(min(400, max(1, -(-args.min_time // max(reps[0], 1e-6)))))
+    for _ in range(n_rep - 1):
+        reps.append(timed_region())
+    elapsed = float(np.median(reps))
     ok = bool(np.isfinite(eng.getOptimalControlSeq()).all())
 
     # dominant-kernel duration with HIP events on the engine's stream (separate, untimed pass)
@@ -312,62 +447,85 @@ def main():
     except Exception:  # noqa: BLE001
         ms_total = ms_roll = elapsed / args.steps * 1e3 * n_ev
     C_dim = eng.CONTROL_DIM
-    b_alg = 4.0 * (2.0 * K_PER_GPU * T * C_dim + 2.0 * K_PER_GPU + 2.0 * T * C_dim)
     roll_us = ms_roll / n_ev * 1e3
-    achieved = b_alg / (roll_us * 1e-6) / 1e9
+    iter_us = ms_total / n_ev * 1e3
+    if args.workload == "autorally":
+        f_alg = 2.0 * (6 * 32 + 32 * 32 + 32 * 4) * k_local * t_steps
+        achieved = f_alg / (roll_us * 1e-6) / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": "rolloutPipelineRepKernel<NeuralNetModelMFMA<7,2,3>,ARStandardCost,Gaussian,true>",
+            "achieved": round(achieved, 4), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 5),
+            "traffic": pmc_traffic("rolloutPipelineRepKernel<NeuralNetModelMFMA") if k_local == K_PER_GPU else None,
+            "algorithmic_flops_per_launch": f_alg, "avg_kernel_us": round(roll_us, 3),
+            "avg_iteration_us_event_timed": round(iter_us, 3),
+        }
+    else:
+        b_alg = 4.0 * (2.0 * k_local * t_steps * C_dim + 2.0 * k_local + 2.0 * t_steps * C_dim)
+        achieved = b_alg / (roll_us * 1e-6) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "rolloutPipelineKernel<CartpoleDynamics,CartpoleQuadraticCost,Gaussian,1,true>",
+            "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": pmc_traffic("rolloutPipelineKernel<CartpoleDynamics") if k_local == K_PER_GPU else None,
+            "pipe_utilisation_pmc": pmc_pipe_util("rolloutPipelineKernel<CartpoleDynamics"),
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, " + PMC_FILE + " "
+                              "(2*FETCH_SIZE + WRITE_SIZE): the sample tensor never reaches HBM, so traffic << algorithmic bytes",
+            "algorithmic_bytes_per_launch": b_alg, "avg_kernel_us": round(roll_us, 3),
+            "avg_iteration_us_event_timed": round(iter_us, 3),
+            "note": "the HBM roofline is the ceiling SURVEY.md §8d assigns, not the one that binds: the kernel is issue-bound on "
+                    "the dynamics wave (T dependent Euler steps per rollout, one wave per CU at K=16384 — K=32768 costs only "
+                    "~17 % more time, DESIGN.md §5); see latency_model for the floor of this design",
+        }
+        if world == 1:
+            try:
+                roofline["latency_model"] = latency_model(local_rank, iter_us)
+            except Exception as e:  # noqa: BLE001
+                roofline["latency_model"] = {"error": str(e)}
 
     if rank == 0:
-        value = world * args.steps / elapsed
+        units = args.steps if strong else world * args.steps
+        value = units / elapsed
+        if args.workload == "autorally":
+            wl = ("AutoRally NeuralNetModel<7,2,3> (FNN 6-32-32-4, synthetic weights) + ARStandardCost (600x600 generated track "
+                  "map) VanillaMPPI optimisation iteration, T=150, MFMA forward, Philox noise fused in the rollout kernel")
+        else:
+            wl = ("Cartpole (CartpoleDynamics + CartpoleQuadraticCost, examples/cartpole_example.cu config) VanillaMPPI "
+                  "optimisation iteration, T=100, dt=0.02, lambda=0.25, sigma=5, Philox noise fused in the rollout kernel")
+        wl += ", K=%d rollouts %s" % (K_PER_GPU, "in total, split over the GPUs" if strong else "per GPU")
         out = {
             "metric": "MPPI iters/sec (KxT rollouts)", "value": round(value, 3), "unit": "MPPI iters/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 6), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "Cartpole (CartpoleDynamics + CartpoleQuadraticCost, examples/cartpole_example.cu config) "
-                            "VanillaMPPI optimisation iteration, K=16384 rollouts per GPU, T=100, dt=0.02, lambda=0.25, "
-                            "sigma=5, Philox noise fused in the rollout kernel",
-                "rollouts_per_gpu": K_PER_GPU, "global_rollouts": K_PER_GPU * world, "num_timesteps": T,
+                "workload": wl,
+                "rollouts_per_gpu": k_local, "global_rollouts": k_total, "num_timesteps": t_steps,
                 "parallelism": "K-sharded x%d" % world, "exchange": exchange,
-                "unit_definition": "one optimisation-loop body over K=16384 rollouts; value sums the units of all ranks",
+                "unit_definition": ("one optimisation-loop body over the K=16384-rollout problem" if strong else
+                                    "one optimisation-loop body over K=16384 rollouts; value sums the units of all ranks"),
             },
+            "timed_region": {"repetitions": len(reps), "ms_per_step_min": round(min(reps) / args.steps * 1e3, 6),
+                             "ms_per_step_max": round(max(reps) / args.steps * 1e3, 6),
+                             "rule": "each repetition = exactly --steps iterations between barrier + synchronize; "
+                                     "ms_per_step is the median repetition"},
             "finite": ok,
-            "roofline": {
-                "bound": "hbm", "kernel": "rolloutPipelineKernel<CartpoleDynamics,CartpoleQuadraticCost,Gaussian,1,true>",
-                "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": pmc_traffic("rolloutPipelineKernel<CartpoleDynamics"),
-                "pipe_utilisation_pmc": pmc_pipe_util("rolloutPipelineKernel<CartpoleDynamics"),
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, " + PMC_FILE + " "
-                                  "(2*FETCH_SIZE + WRITE_SIZE): the sample tensor never reaches HBM, so traffic << algorithmic bytes",
-                "algorithmic_bytes_per_launch": b_alg, "avg_kernel_us": round(roll_us, 3),
-                "avg_iteration_us_event_timed": round(ms_total / n_ev * 1e3, 3),
-                "note": "issue-bound on the dynamics wave: T=100 dependent Euler steps per rollout at ~83 instructions each; K=16384 is 256 blocks of 4 role waves (2 samplers, dynamics, cost) on 256 CUs",
-            },
+            "roofline": roofline,
         }
         # secondary workload of the north star (not the headline `value`): AutoRally-NN, K=16384, T=150, MFMA forward
-        if not args.primary_only and world == 1:
+        if not args.primary_only and world == 1 and args.workload == "cartpole":
             for key, leg in (("autorally_nn", autorally_leg), ("lstm_colored", lstm_colored_leg), ("di_tube", di_tube_leg)):
                 try:
                     out[key] = leg(local_rank)
                 except Exception as e:  # noqa: BLE001
                     out[key] = {"error": str(e)}
-        if world == 1:
-            # what a control loop sees: one mppi_compute_control call (inputs handed over from the host, one iteration,
-            # smoothing + re-rollout of u*, results back) — the PCIe-inclusive figure, never `value`
+        if world == 1 and args.workload == "cartpole":
             try:
-                lat_eng = make_engine(cartpole_cfg(K=K_PER_GPU, T=T), device=local_rank)
-                for _ in range(50):
-                    lat_eng.computeControl(x0, 1)
-                t_a = time.perf_counter()
-                for _ in range(300):
-                    lat_eng.computeControl(x0, 1)
-                out["compute_control_latency_us"] = round((time.perf_counter() - t_a) / 300 * 1e6, 2)
-                lat_eng.close()
+                out["compute_control"] = compute_control_latency(local_rank, x0)
+                out["compute_control_latency_us"] = out["compute_control"]["control_ready_us"]
             except Exception as e:  # noqa: BLE001
-                out["compute_control_latency_us"] = {"error": str(e)}
+                out["compute_control"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(cartpole_cfg(K=K_PER_GPU, T=T))
+            out["cpu_baseline"] = cpu_baseline(cfg, budget_s=12.0 if args.workload == "cartpole" else 20.0)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

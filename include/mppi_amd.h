@@ -346,6 +346,19 @@ mppi_status mppi_write_recv_records(mppi_handle h, const float* in);
 /** one iteration split around the exchange: local rollout + local merge | (caller's all-gather) | global merge */
 mppi_status mppi_iteration_local(mppi_handle h);
 mppi_status mppi_iteration_merge(mppi_handle h);
+/**
+ * P2P mailbox exchange over xGMI — the second stage of SURVEY.md §8e: instead of an ncclAllGather of ~1 KB (10-20 us on a
+ * ~30 us iteration) every rank writes its merged record straight into a mailbox in each peer's memory (one kernel, one flag
+ * store per peer) and every rank's merge kernel spins on its own flags.  One process per GPU: every rank calls
+ * mppi_p2p_mailbox_handle (a 64-byte hipIpcMemHandle_t), the handles are exchanged over any control plane (bench.py: a gloo
+ * all-gather), then every rank calls mppi_p2p_connect(handles[world]).  Ranks living in ONE process (several handles, one or
+ * more devices) call mppi_p2p_connect_local(peers[world]) instead — hipIpc does not open a handle of its own process.
+ * From then on mppi_optimize / mppi_compute_control use the mailbox; RCCL (mppi_comm_init_rccl) stays the fallback.
+ * A merge kernel gives up after 2 s without a peer's record; mppi_get_stats then returns MPPI_ERR_COMM.
+ */
+mppi_status mppi_p2p_mailbox_handle(mppi_handle h, void* out_bytes, size_t capacity, size_t* nbytes);
+mppi_status mppi_p2p_connect(mppi_handle h, const void* handles, size_t stride_bytes);
+mppi_status mppi_p2p_connect_local(mppi_handle h, const mppi_handle* peers);
 /** native RCCL path: unique id created on rank 0 and shipped by the caller to every rank (ncclGetUniqueId / ncclCommInitRank) */
 mppi_status mppi_rccl_unique_id(void* out_bytes, size_t capacity, size_t* nbytes);
 mppi_status mppi_comm_init_rccl(mppi_handle h, const void* unique_id, size_t nbytes);
@@ -379,6 +392,11 @@ mppi_status mppi_weighted_reduction(const float* weights, const float* v, float 
 /** eps[k_begin..k_end)[T][C] exactly as the fused generator draws it (for generator parity tests) */
 mppi_status mppi_philox_normal(uint64_t seed, uint32_t generation, int num_rollouts, int num_timesteps,
                                int control_dim, int k_begin, int k_end, float* eps_out, int device);
+/**
+ * Measurement aid (bench.py's latency model): average time per launch of n dependent launches of a trivial 256-workgroup kernel
+ * on a stream of its own, i.e. what a kernel boundary costs on this device (MI355X_MICROARCH.md "boundary": ~1.45 us).
+ */
+mppi_status mppi_measure_launch_boundary(int device, int n, float* us_per_launch);
 /** elementwise det_math on the device (func ids as oracle_det_eval): host/device bit-parity test hook */
 mppi_status mppi_det_eval(int func, const float* x, float* y, int n, int device);
 

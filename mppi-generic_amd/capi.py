@@ -119,6 +119,9 @@ SIGNATURES = {
     "mppi_write_recv_records": (C.c_int, [H, _f32p]),
     "mppi_iteration_local": (C.c_int, [H]),
     "mppi_iteration_merge": (C.c_int, [H]),
+    "mppi_p2p_mailbox_handle": (C.c_int, [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mppi_p2p_connect": (C.c_int, [H, C.c_void_p, C.c_size_t]),
+    "mppi_p2p_connect_local": (C.c_int, [H, C.POINTER(C.c_void_p)]),
     "mppi_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mppi_comm_init_rccl": (C.c_int, [H, C.c_void_p, C.c_size_t]),
     "mppi_rollout_costs": (C.c_int, [H, _f32p, C.c_int]),
@@ -128,6 +131,7 @@ SIGNATURES = {
     "mppi_compute_weights": (C.c_int, [_f32p, C.c_int, C.c_float, _f32p, C.c_int]),
     "mppi_weighted_reduction": (C.c_int, [_f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
     "mppi_philox_normal": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
+    "mppi_measure_launch_boundary": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "mppi_det_eval": (C.c_int, [C.c_int, _f32p, _f32p, C.c_int, C.c_int]),
     "mppi_texture2d_query": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, _f32p, C.c_int, C.c_int, _f32p, C.c_int]),
 }

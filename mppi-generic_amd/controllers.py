@@ -422,6 +422,25 @@ class MPPIController:
     def iterationMerge(self):
         self._check(self._lib.mppi_iteration_merge(self._h))
 
+    def p2pMailboxHandle(self):
+        """64-byte hipIpcMemHandle_t of this rank's mailbox (to be exchanged between the processes)"""
+        buf = C.create_string_buffer(64)
+        n = C.c_size_t()
+        self._check(self._lib.mppi_p2p_mailbox_handle(self._h, buf, 64, C.byref(n)))
+        return bytes(buf.raw[:n.value])
+
+    def p2pConnect(self, handles):
+        """handles: list of world byte strings (rank order) from p2pMailboxHandle of every rank"""
+        blob = b"".join(h.ljust(64, b"\0") for h in handles)
+        self._check(self._lib.mppi_p2p_connect(self._h, blob, 64))
+
+    @staticmethod
+    def p2pConnectLocal(controllers):
+        """all ranks of one problem living in this process: wire their mailboxes together"""
+        arr = (C.c_void_p * len(controllers))(*[c._h.value for c in controllers])
+        for c in controllers:
+            c._check(c._lib.mppi_p2p_connect_local(c._h, arr))
+
     def commInitRccl(self, unique_id_bytes):
         buf = C.create_string_buffer(bytes(unique_id_bytes), 128)
         self._check(self._lib.mppi_comm_init_rccl(self._h, buf, 128))
@@ -537,6 +556,14 @@ def det_eval(func, x, device=0):
     y = np.empty_like(x)
     _op_check(lib, lib.mppi_det_eval(func, x, y, x.size, device))
     return y
+
+
+def launch_boundary_us(device=0, n=2000):
+    """average time per launch of n dependent trivial kernels (mppi_measure_launch_boundary)"""
+    lib = load_library()
+    out = C.c_float()
+    _op_check(lib, lib.mppi_measure_launch_boundary(device, n, C.byref(out)))
+    return float(out.value)
 
 
 def philox_normal(seed, generation, K, T, Cdim, k_begin=0, k_end=None, device=0):

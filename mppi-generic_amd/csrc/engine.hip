@@ -158,6 +158,18 @@ struct mppi_handle_s
   /* RCCL (loaded lazily) */
   void* rccl_lib = nullptr;
   void* comm = nullptr;
+
+  /* P2P mailbox exchange over xGMI (mppi_p2p_*): this rank's mailbox — records [2 parities][world][D * PS] followed by
+   * flags [2][world] — lives in this GPU's memory and is written by the peers' postRecordsKernel */
+  float* mbox_d = nullptr;
+  size_t mbox_bytes = 0;
+  bool mbox_uncached = false;
+  float* peer_mbox[16] = { nullptr };
+  bool peer_opened[16] = { false };  // hipIpcOpenMemHandle'd (to be closed)
+  bool p2p_ready = false;
+  bool p2p_auto = false;         // set around library-driven iterations (mppi_iteration_local keeps the caller-driven exchange)
+  bool exchange_failed = false;  // a merge kernel gave up waiting for a peer (stats[6] mark), sticky until mppi_p2p_connect
+  unsigned xseq = 0;  // exchange sequence number: flags carry it, its parity selects the mailbox half
 };
 
 /** the multi-rank path (local merge -> all-gather -> global merge) runs for world_size > 1, and for a world of ONE when
@@ -304,6 +316,17 @@ static void freeAll(mppi_handle h)
 {
   // x0_d, mean_d, history_d and ctrl_out_d, state_out_d, output_out_d, stats_d are slices of in_block_d / out_block_d
   h->x0_d = h->mean_d = h->history_d = h->ctrl_out_d = h->state_out_d = h->output_out_d = h->stats_d = nullptr;
+  for (int p = 0; p < 16; p++)
+  {
+    if (h->peer_opened[p] && h->peer_mbox[p])
+      (void)hipIpcCloseMemHandle(h->peer_mbox[p]);
+    h->peer_opened[p] = false;
+    h->peer_mbox[p] = nullptr;
+  }
+  if (h->mbox_d)
+    (void)hipFree(h->mbox_d);
+  h->mbox_d = nullptr;
+  h->p2p_ready = false;
   if (h->io_in_h)
     (void)hipHostFree(h->io_in_h);
   if (h->io_out_h)
@@ -888,11 +911,17 @@ mppi_status mppi_set_seed(mppi_handle h, uint64_t seed)
 
 /* ---------------------------------------------------------------- internals -------------------------------------- */
 static mppi_status launchCombine(mppi_handle h, const float* records, int num_records, int finalize, float* record_out,
-                                 int k_total)
+                                 int k_total, bool world_major = false, const unsigned* wait_flags = nullptr,
+                                 unsigned wait_seq = 0, const kernels::PostTargets* post = nullptr)
 {
   kernels::CombineArgs a{};
+  if (post)
+    a.post = *post;
   a.records_d = records;
   a.num_records = num_records;
+  // block records of the rollout kernel: [D][num_blocks][PS]; records gathered from the ranks: [world][D][PS]
+  a.z_stride = world_major ? h->PS : num_records * h->PS;
+  a.rec_stride = world_major ? h->D * h->PS : h->PS;
   a.TC = h->TC;
   a.PS = h->PS;
   a.lambda = h->cfg.lambda;
@@ -901,6 +930,9 @@ static mppi_status launchCombine(mppi_handle h, const float* records, int num_re
   a.mean_out_d = h->mean_d;
   a.record_out_d = record_out;
   a.stats_out_d = h->stats_d;
+  a.wait_flags_d = wait_flags;
+  a.wait_seq = wait_seq;
+  a.wait_limit_ticks = 200000000ull;  // 2 s of the 100 MHz wall clock
   const size_t smem = sizeof(float) * 4 * (size_t)num_records;
   hipLaunchKernelGGL(kernels::combineKernel, dim3(h->D, (h->TC + kernels::COMBINE_COLS - 1) / kernels::COMBINE_COLS),
                      dim3(kernels::COMBINE_THREADS), smem, h->stream, a);
@@ -962,18 +994,24 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
 typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
 static nccl_allgather_fn g_ncclAllGather = nullptr;
 
-/** regroup [world][D][PS] -> [D][world][PS] so that each system's records are contiguous for combineKernel */
-__global__ void regroupRecordsKernel(const float* __restrict__ in, float* __restrict__ out, int world, int D, int PS)
+/** where this rank's merged record of exchange `seq` goes in every peer's mailbox */
+static kernels::PostTargets p2pTargets(mppi_handle h, unsigned seq)
 {
-  const int n = world * D * PS;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+  kernels::PostTargets t{};
+  const int world = h->cfg.world_size;
+  const size_t dps = (size_t)h->D * h->PS;
+  const unsigned parity = seq & 1u;
+  for (int p = 0; p < world; p++)
   {
-    const int g = i / (D * PS);
-    const int r = i - g * D * PS;
-    const int z = r / PS;
-    const int j = r - z * PS;
-    out[((size_t)z * world + g) * PS + j] = in[i];
+    float* base = h->peer_mbox[p];
+    t.peer_slot[p] = base + ((size_t)parity * world + h->cfg.rank) * dps;
+    t.peer_flag[p] = reinterpret_cast<unsigned*>(base + (size_t)2 * world * dps) + parity * world + h->cfg.rank;
   }
+  t.world = world;
+  t.seq = seq;
+  // the ticket counter sits behind the flags of this rank's own mailbox
+  t.ticket_d = reinterpret_cast<unsigned*>(h->mbox_d + (size_t)2 * world * dps) + 2 * world;
+  return t;
 }
 
 static mppi_status iterationLocal(mppi_handle h, int iteration, int stride)
@@ -981,6 +1019,11 @@ static mppi_status iterationLocal(mppi_handle h, int iteration, int stride)
   MPPI_TRY(launchRollout(h, iteration, stride));
   if (!exchangeActive(h))
     return launchCombine(h, h->partials_d, h->num_blocks, 1, nullptr, h->cfg.num_rollouts);
+  if (h->p2p_ready && h->p2p_auto)
+  {  // the local merge delivers its record to the peers itself
+    const kernels::PostTargets t = p2pTargets(h, ++h->xseq);
+    return launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local, false, nullptr, 0, &t);
+  }
   return launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local);
 }
 
@@ -988,23 +1031,35 @@ static mppi_status iterationMerge(mppi_handle h)
 {
   if (!exchangeActive(h))
     return MPPI_OK;
-  if (h->D == 1)  // [world][1][PS] is already [1][world][PS]: no regroup launch (one kernel boundary less per iteration)
-    return launchCombine(h, h->recv_d, h->cfg.world_size, 1, nullptr, h->cfg.num_rollouts);
-  const int n = h->cfg.world_size * h->D * h->PS;
-  hipLaunchKernelGGL(regroupRecordsKernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->recv_d, h->gather_tmp_d,
-                     h->cfg.world_size, h->D, h->PS);
-  HIP_TRY(h, hipGetLastError());
-  return launchCombine(h, h->gather_tmp_d, h->cfg.world_size, 1, nullptr, h->cfg.num_rollouts);
+  // recv_d is [world][D][PS]: combineKernel walks it with world-major strides (no regroup launch)
+  return launchCombine(h, h->recv_d, h->cfg.world_size, 1, nullptr, h->cfg.num_rollouts, true);
+}
+
+/** P2P exchange: the local merge has posted this rank's record (iterationLocal); the global merge waits for the peers' flags */
+static mppi_status iterationMergeP2P(mppi_handle h)
+{
+  const int world = h->cfg.world_size;
+  const size_t dps = (size_t)h->D * h->PS;
+  const unsigned seq = h->xseq;
+  const unsigned parity = seq & 1u;
+  const float* records = h->mbox_d + (size_t)parity * world * dps;
+  const unsigned* flags = reinterpret_cast<const unsigned*>(h->mbox_d + (size_t)2 * world * dps) + parity * world;
+  return launchCombine(h, records, world, 1, nullptr, h->cfg.num_rollouts, true, flags, seq);
 }
 
 static mppi_status iteration(mppi_handle h, int it, int stride)
 {
-  MPPI_TRY(iterationLocal(h, it, stride));
+  h->p2p_auto = true;  // iterations driven by the library use the mailbox when it is connected
+  const mppi_status st_local = iterationLocal(h, it, stride);
+  h->p2p_auto = false;
+  MPPI_TRY(st_local);
   if (exchangeActive(h))
   {
+    if (h->p2p_ready)
+      return iterationMergeP2P(h);
     if (!h->comm || !g_ncclAllGather)
       return fail(h, MPPI_ERR_STATE,
-                  "world_size > 1: call mppi_comm_init_rccl first, or drive the exchange yourself with "
+                  "world_size > 1: call mppi_p2p_connect / mppi_comm_init_rccl first, or drive the exchange yourself with "
                   "mppi_iteration_local / mppi_get_exchange_buffers / mppi_iteration_merge");
     const int rc = g_ncclAllGather(h->send_d, h->recv_d, (size_t)h->D * h->PS, /*ncclFloat32*/ 7, h->comm, h->stream);
     if (rc != 0)
@@ -1158,6 +1213,8 @@ static void parseStats(mppi_handle h, const float* st)
     sys[z]->free_energy_mean = s[2];
     sys[z]->free_energy_variance = s[3];
     sys[z]->free_energy_modified_variance = s[4];
+    if (s[6] != 0.0f)  // combineKernel gave up waiting for a peer's record (P2P exchange)
+      h->exchange_failed = true;
   }
 }
 
@@ -1772,6 +1829,8 @@ mppi_status mppi_get_stats(mppi_handle h, mppi_stats* out)
   MPPI_TRY(fetchStats(h));
   h->stats_h.nominal_state_used = used;
   *out = h->stats_h;
+  if (h->exchange_failed)
+    return fail(h, MPPI_ERR_COMM, "P2P exchange: a peer's record did not arrive within 2 s; the merge was abandoned");
   return MPPI_OK;
 }
 mppi_status mppi_get_sampled_controls(mppi_handle h, float* v)
@@ -1883,7 +1942,7 @@ mppi_status mppi_time_iterations(mppi_handle h, int n, float* ms_total, float* m
   // pass 1: whole iterations between two events.  Sharded handle whose exchange is driven by the caller (no library
   // communicator): the iteration is not the library's to time — *ms_total = 0 and only the kernel pass below runs.
   *ms_total = 0.0f;
-  if (!exchangeActive(h) || (h->comm && g_ncclAllGather))
+  if (!exchangeActive(h) || h->p2p_ready || (h->comm && g_ncclAllGather))
   {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipEventRecord(h->ev_a, h->stream));
@@ -2006,6 +2065,129 @@ static void* loadRccl(std::string& err)
   }
   err = std::string("cannot dlopen librccl: ") + dlerror();
   return nullptr;
+}
+
+/* ---------------------------------------------------------------- P2P mailbox exchange ---------------------------- */
+static mppi_status ensureMailbox(mppi_handle h)
+{
+  if (h->mbox_d)
+    return MPPI_OK;
+  const int world = h->cfg.world_size;
+  if (world > 16)
+    return fail(h, MPPI_ERR_UNSUPPORTED, "P2P mailbox exchange supports up to 16 ranks");
+  const size_t dps = (size_t)h->D * h->PS;
+  h->mbox_bytes = sizeof(float) * 2 * world * dps + sizeof(unsigned) * (2 * world + 4);  // records, flags, ticket counter
+  h->mbox_bytes = (h->mbox_bytes + 4095) & ~(size_t)4095;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  // uncached device memory where the runtime offers it (the mailbox is written by other agents); every access to it is a
+  // system-scope atomic anyway, so ordinary device memory is a correct fallback
+  hipError_t e = hipExtMallocWithFlags((void**)&h->mbox_d, h->mbox_bytes, hipDeviceMallocUncached);
+  h->mbox_uncached = (e == hipSuccess);
+  if (e != hipSuccess)
+  {
+    (void)hipGetLastError();
+    HIP_TRY(h, hipMalloc((void**)&h->mbox_d, h->mbox_bytes));
+  }
+  HIP_TRY(h, hipMemsetAsync(h->mbox_d, 0, h->mbox_bytes, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+mppi_status mppi_p2p_mailbox_handle(mppi_handle h, void* out_bytes, size_t capacity, size_t* nbytes)
+{
+  CHECK_HANDLE(h);
+  if (!out_bytes || capacity < sizeof(hipIpcMemHandle_t))
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_p2p_mailbox_handle: buffer too small (needs 64 bytes)");
+  MPPI_TRY(ensureMailbox(h));
+  hipIpcMemHandle_t ipc;
+  hipError_t e = hipIpcGetMemHandle(&ipc, h->mbox_d);
+  if (e != hipSuccess && h->mbox_uncached)
+  {  // this runtime does not export uncached allocations: fall back to ordinary device memory
+    (void)hipGetLastError();
+    (void)hipFree(h->mbox_d);
+    h->mbox_d = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&h->mbox_d, h->mbox_bytes));
+    h->mbox_uncached = false;
+    HIP_TRY(h, hipMemsetAsync(h->mbox_d, 0, h->mbox_bytes, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    e = hipIpcGetMemHandle(&ipc, h->mbox_d);
+  }
+  if (e != hipSuccess)
+    return fail(h, MPPI_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e) +
+                                     " (multi-process GPU sharing needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver)");
+  memcpy(out_bytes, &ipc, sizeof(ipc));
+  if (nbytes)
+    *nbytes = sizeof(ipc);
+  return MPPI_OK;
+}
+
+mppi_status mppi_p2p_connect(mppi_handle h, const void* handles, size_t stride_bytes)
+{
+  CHECK_HANDLE(h);
+  const int world = h->cfg.world_size;
+  if (!handles || stride_bytes < sizeof(hipIpcMemHandle_t))
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_p2p_connect: handles[world] with a stride of at least 64 bytes expected");
+  MPPI_TRY(ensureMailbox(h));
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  for (int p = 0; p < world; p++)
+  {
+    if (p == h->cfg.rank)
+    {
+      h->peer_mbox[p] = h->mbox_d;
+      continue;
+    }
+    hipIpcMemHandle_t ipc;
+    memcpy(&ipc, (const char*)handles + (size_t)p * stride_bytes, sizeof(ipc));
+    void* ptr = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&ptr, ipc, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess)
+      return fail(h, MPPI_ERR_COMM, "hipIpcOpenMemHandle for rank " + std::to_string(p) + ": " + hipGetErrorString(e));
+    h->peer_mbox[p] = (float*)ptr;
+    h->peer_opened[p] = true;
+  }
+  h->xseq = 0;
+  h->exchange_failed = false;
+  h->p2p_ready = true;
+  return MPPI_OK;
+}
+
+mppi_status mppi_p2p_connect_local(mppi_handle h, const mppi_handle* peers)
+{
+  CHECK_HANDLE(h);
+  const int world = h->cfg.world_size;
+  if (!peers)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_p2p_connect_local: null");
+  MPPI_TRY(ensureMailbox(h));
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  for (int p = 0; p < world; p++)
+  {
+    mppi_handle q = peers[p];
+    if (!q || q->cfg.world_size != world || q->cfg.rank != p || q->D != h->D || q->PS != h->PS)
+      return fail(h, MPPI_ERR_INVALID_ARG, "mppi_p2p_connect_local: peers[p] must be the handle of rank p of the same problem");
+    if (q != h)
+    {
+      std::lock_guard<std::recursive_mutex> peer_lock(q->mu);
+      MPPI_TRY(ensureMailbox(q) == MPPI_OK ? MPPI_OK : fail(h, MPPI_ERR_HIP, "peer mailbox allocation failed"));
+      HIP_TRY(h, hipSetDevice(h->cfg.device));
+      if (q->cfg.device != h->cfg.device)
+      {
+        int can = 0;
+        HIP_TRY(h, hipDeviceCanAccessPeer(&can, h->cfg.device, q->cfg.device));
+        if (!can)
+          return fail(h, MPPI_ERR_COMM, "no peer access between device " + std::to_string(h->cfg.device) + " and " +
+                                            std::to_string(q->cfg.device));
+        const hipError_t e = hipDeviceEnablePeerAccess(q->cfg.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+          return fail(h, MPPI_ERR_COMM, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+      }
+    }
+    h->peer_mbox[p] = q->mbox_d;
+  }
+  h->xseq = 0;
+  h->exchange_failed = false;
+  h->p2p_ready = true;
+  return MPPI_OK;
 }
 
 mppi_status mppi_rccl_unique_id(void* out_bytes, size_t capacity, size_t* nbytes)
@@ -2336,6 +2518,70 @@ mppi_status mppi_texture2d_query(const float* data, int width, int height, int c
   MPPI_TRY(opDevice(device));
   return channels == 1 ? texture2dQuery<1>(data, width, height, p, points, n, frame, out) :
                          texture2dQuery<4>(data, width, height, p, points, n, frame, out);
+}
+
+extern "C++" {
+__global__ void boundaryProbeKernel(int* sink)
+{
+  if (sink && threadIdx.x == 1024)
+    *sink = 0;
+}
+}
+mppi_status mppi_measure_launch_boundary(int device, int n, float* us_per_launch)
+{
+  if (n <= 0 || !us_per_launch)
+    return MPPI_ERR_INVALID_ARG;
+  MPPI_TRY(opDevice(device));
+  hipStream_t s = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e == hipSuccess)
+    e = hipEventCreate(&a);
+  if (e == hipSuccess)
+    e = hipEventCreate(&b);
+  // the launches are replayed from a graph: enqueued one by one the host is the bottleneck (~3 us per launch), which is not
+  // what separates two kernels of an iteration whose launches were queued long before the first one finished
+  float ms = 0.0f;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (e == hipSuccess)
+    e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (e == hipSuccess)
+  {
+    for (int i = 0; i < n; i++)
+      hipLaunchKernelGGL(boundaryProbeKernel, dim3(256), dim3(64), 0, s, (int*)nullptr);
+    e = hipStreamEndCapture(s, &graph);
+  }
+  if (e == hipSuccess)
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e == hipSuccess)
+    e = hipGraphLaunch(exec, s);  // warm-up replay
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(s);
+  if (e == hipSuccess)
+    e = hipEventRecord(a, s);
+  if (e == hipSuccess)
+    e = hipGraphLaunch(exec, s);
+  if (e == hipSuccess)
+    e = hipEventRecord(b, s);
+  if (e == hipSuccess)
+    e = hipEventSynchronize(b);
+  if (e == hipSuccess)
+    e = hipEventElapsedTime(&ms, a, b);
+  if (exec)
+    (void)hipGraphExecDestroy(exec);
+  if (graph)
+    (void)hipGraphDestroy(graph);
+  if (a)
+    (void)hipEventDestroy(a);
+  if (b)
+    (void)hipEventDestroy(b);
+  if (s)
+    (void)hipStreamDestroy(s);
+  if (e != hipSuccess)
+    return opFail("mppi_measure_launch_boundary", e);
+  *us_per_launch = ms * 1e3f / (float)n;
+  return MPPI_OK;
 }
 
 mppi_status mppi_det_eval(int func, const float* x, float* y, int n, int device)

@@ -33,9 +33,27 @@ constexpr int COMBINE_THREADS = 1024;  ///< 16 waves: the merge is a chain of me
 /** floats per system in the stats buffer: rho, eta, fe_mean, fe_var, fe_modified_var, sum w^2, pad, pad */
 constexpr int STATS_STRIDE = 8;
 
+/**
+ * P2P exchange over xGMI (SURVEY.md §8e second stage): where this GPU's merged record [D][PS] goes — straight into the mailbox
+ * slot [rank] of every peer (peer memory mapped through hipIpc / peer access), written by the local merge itself
+ * (combineKernel, finalize == 0) with write-through system-scope stores; the block that finishes last raises one flag per
+ * peer, and each peer's global merge (combineKernel with wait_flags_d) spins on its own flags.  Replaces an ncclAllGather of
+ * ~1 KB (10-20 us of latency on a ~30 us iteration) by one hop inside a launch that exists anyway.
+ */
+struct PostTargets
+{
+  float* peer_slot[16];     ///< peer p's mailbox slot for THIS rank's record ([D][PS]); this rank's own mailbox included
+  unsigned* peer_flag[16];  ///< peer p's flag word for this rank
+  int world;                ///< 0: no posting (the record goes to record_out_d only)
+  unsigned seq;
+  unsigned* ticket_d;       ///< device counter (zero between launches): the last block to arrive raises the flags
+};
+
 struct CombineArgs
 {
-  const float* records_d;  ///< [D][num_records][PS]
+  const float* records_d;  ///< record b of system z at records_d + z * z_stride + b * rec_stride
+  int z_stride;            ///< [D][num_records][PS] (block records): num_records * PS;  [world][D][PS] (gathered): PS
+  int rec_stride;          ///<                                       PS;                                          D * PS
   int num_records;
   int TC;                  ///< T * C
   int PS;                  ///< record stride in floats (TC + 4)
@@ -45,7 +63,20 @@ struct CombineArgs
   float* mean_out_d;       ///< finalize: [D][T*C] new control mean (= u*)
   float* record_out_d;     ///< !finalize: [D][PS] merged record
   float* stats_out_d;      ///< finalize: [D][STATS_STRIDE]
+  /* records delivered by peers into this GPU's mailbox (P2P exchange over xGMI, postRecordsKernel): wait until every
+   * peer's flag shows `wait_seq`, then read the records with system-scope loads (they were written by other agents) */
+  const unsigned* wait_flags_d;  ///< [num_records] or nullptr
+  unsigned wait_seq;
+  unsigned long long wait_limit_ticks;  ///< give up after this many wall_clock64 ticks (100 MHz): stats[6] = 1 marks the failure
+  PostTargets post;        ///< !finalize: also deliver the merged record to the peers' mailboxes
 };
+
+/** a float another agent (peer GPU over xGMI, or a kernel of another process) may have written: system-scope load, which
+ *  bypasses the caches that are not coherent with that agent */
+__device__ inline float loadPeerWritten(const float* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ inline float blockMin(float v, float* red_s)
 {
@@ -96,9 +127,38 @@ __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineAr
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   constexpr int NW = COMBINE_THREADS / 64;
-  const float* rec = a.records_d + (size_t)z * a.num_records * a.PS;
+  const float* rec = a.records_d + (size_t)z * a.z_stride;
   const float lambda_inv = (float)(1.0 / (double)a.lambda);
 
+  __shared__ int wait_failed_s;
+  const bool mailbox = a.wait_flags_d != nullptr;
+  if (mailbox)
+  {
+    // one lane per peer spins on that peer's flag (bounded: a peer that never posts must not wedge the GPU)
+    if (tid == 0)
+      wait_failed_s = 0;
+    __syncthreads();
+    if (tid < a.num_records)
+    {
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load(a.wait_flags_d + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.wait_seq)
+      {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > a.wait_limit_ticks)
+        {
+          wait_failed_s = 1;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (wait_failed_s)
+    {  // leave a mark the host checks (mppi_synchronize / result getters) and no result: the mean is left untouched
+      if (tid == 0 && blockIdx.y == 0 && a.stats_out_d)
+        a.stats_out_d[(size_t)z * STATS_STRIDE + 6] = 1.0f;
+      return;
+    }
+  }
   // the column loads do not depend on the scale factors: issue the first batch before the reductions so that its
   // memory round trip overlaps theirs
   const int j = col0 + lane;
@@ -110,14 +170,15 @@ __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineAr
   for (int i = 0; i < BATCH; i++)
   {
     const int b = wave + i * NW;
-    v0[i] = (col_ok && b < a.num_records) ? col[(size_t)b * a.PS] : 0.0f;
+    v0[i] = (col_ok && b < a.num_records) ? (mailbox ? loadPeerWritten(col + (size_t)b * a.rec_stride) : col[(size_t)b * a.rec_stride]) : 0.0f;
   }
 
   float rho = INFINITY;
   for (int b = tid; b < a.num_records; b += COMBINE_THREADS)
   {
-    const float* r = rec + (size_t)b * a.PS + a.TC;
-    const float r0 = r[0], r1 = r[1], r2 = r[2];
+    const float* r = rec + (size_t)b * a.rec_stride + a.TC;
+    const float r0 = mailbox ? loadPeerWritten(r) : r[0], r1 = mailbox ? loadPeerWritten(r + 1) : r[1],
+                r2 = mailbox ? loadPeerWritten(r + 2) : r[2];
     rho_s[b] = r0;
     eta_s[b] = r1;
     eta2_s[b] = r2;
@@ -157,13 +218,13 @@ __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineAr
       float v[BATCH];
 #pragma unroll
       for (int i = 0; i < BATCH; i++)
-        v[i] = col[(size_t)(b + i * NW) * a.PS];
+        v[i] = mailbox ? loadPeerWritten(col + (size_t)(b + i * NW) * a.rec_stride) : col[(size_t)(b + i * NW) * a.rec_stride];
 #pragma unroll
       for (int i = 0; i < BATCH; i++)
         acc += s_b[b + i * NW] * v[i];
     }
     for (; b < a.num_records; b += NW)
-      acc += s_b[b] * col[(size_t)b * a.PS];
+      acc += s_b[b] * (mailbox ? loadPeerWritten(col + (size_t)b * a.rec_stride) : col[(size_t)b * a.rec_stride]);
   }
   part_s[wave][lane] = acc;
   __syncthreads();
@@ -176,7 +237,11 @@ __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineAr
     if (a.finalize)
       a.mean_out_d[(size_t)z * a.TC + j] = tot / eta_f;
     else
+    {
       a.record_out_d[(size_t)z * a.PS + j] = tot;
+      for (int p = 0; p < a.post.world; p++)
+        __hip_atomic_store(a.post.peer_slot[p] + (size_t)z * a.PS + j, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   if (tid == 0 && blockIdx.y == 0)
   {
@@ -202,11 +267,33 @@ __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineAr
     }
     else
     {
+      const float tail[4] = { rho, eta_f, (float)eta2, 0.0f };
       float* o = a.record_out_d + (size_t)z * a.PS + a.TC;
-      o[0] = rho;
-      o[1] = eta_f;
-      o[2] = (float)eta2;
-      o[3] = 0.0f;
+      for (int i = 0; i < 4; i++)
+        o[i] = tail[i];
+      for (int p = 0; p < a.post.world; p++)
+        for (int i = 0; i < 4; i++)
+          __hip_atomic_store(a.post.peer_slot[p] + (size_t)z * a.PS + a.TC + i, tail[i], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (!a.finalize && a.post.world > 0)
+  {
+    // every block's slice is out (barrier waits for the block's stores, the fence makes them visible system-wide) before it
+    // takes a ticket; the block that takes the last one publishes the sequence number to every peer
+    __syncthreads();
+    if (tid == 0)
+    {
+      __threadfence_system();
+      const unsigned nblocks = gridDim.x * gridDim.y;
+      const unsigned t = __hip_atomic_fetch_add(a.post.ticket_d, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == nblocks - 1)
+      {
+        __hip_atomic_store(a.post.ticket_d, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        for (int p = 0; p < a.post.world; p++)
+          __hip_atomic_store(a.post.peer_flag[p], a.post.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }

@@ -1,0 +1,143 @@
+"""P2P mailbox exchange (mppi_p2p_*; SURVEY.md §8e second stage): every rank writes its merged record straight into the peers'
+mailboxes and the merge kernels spin on their own flags — no collective library.  On one GPU the ranks are several handles
+of one process (mppi_p2p_connect_local) or several processes sharing the device through hipIpc (mppi_p2p_connect)."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import mppi_generic_amd as m
+from common import cartpole_cfg, di_cfg, make_engine, make_oracle
+import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_ranks(cfg, world, iters, x0):
+    ranks = [make_engine(cfg, rank=r, world_size=world) for r in range(world)]
+    m.MPPIController.p2pConnectLocal(ranks)
+    for c in ranks:
+        c.uploadState(x0)
+    for c in ranks:  # all ranks' kernels are enqueued before anybody waits: each merge kernel spins for the others' posts
+        c.optimize(iters, synchronize=False)
+    for c in ranks:
+        c.synchronize()
+    return ranks
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_local_matches_unsharded(gpu, world):
+    cfg = cartpole_cfg(K=4096, T=100, soft=True)
+    full = make_engine(cfg)
+    full.uploadState(cfg["x0"])
+    full.optimize(3)
+    u_full = full.getOptimalControlSeq()[0]
+    rho_full = full.getStats().real_sys.baseline
+    # ranks living in ONE process each need a hardware queue of their own (a merge kernel spins until the other ranks'
+    # kernels have run; HIP multiplexes streams onto GPU_MAX_HW_QUEUES = 4 queues): no other stream stays alive here
+    full.close()
+    ranks = _run_ranks(cfg, world, 3, cfg["x0"])
+    us = [c.getOptimalControlSeq()[0] for c in ranks]
+    for u in us:
+        assert np.abs(u - u_full).max() <= 5e-6, np.abs(u - u_full).max()
+        assert np.array_equal(u, us[0])  # every rank merges the same records in the same order: same bits
+    st = [c.getStats().real_sys for c in ranks]
+    assert all(s.baseline == rho_full for s in st)
+    for c in ranks:
+        c.close()
+    # and against the oracle's un-sharded single iteration on the same Philox stream
+    ranks = _run_ranks(cfg, world, 1, cfg["x0"])
+    orc = make_oracle(cfg)
+    u_orc = orc.iterate(cfg["x0"], np.zeros((cfg["T"], 1), np.float32), po.philox_normal(42, 0, cfg["K"], cfg["T"], 1))[0]
+    assert np.abs(ranks[0].getOptimalControlSeq()[0] - u_orc).max() <= 1e-5
+
+
+def test_p2p_local_two_systems(gpu):
+    """Tube-MPPI (two systems per record): the gathered records are [world][D][PS], merged with world-major strides"""
+    cfg = di_cfg(K=2048, T=60, tube=True)
+    x0 = np.tile(cfg["x0"], (2, 1))
+    full = make_engine(cfg)
+    full.uploadState(x0)
+    full.optimize(2)
+    u_full = full.getOptimalControlSeq()
+    full.close()
+    ranks = _run_ranks(cfg, 2, 2, x0)
+    for c in ranks:
+        assert np.abs(c.getOptimalControlSeq() - u_full).max() <= 5e-6
+
+
+def test_p2p_missing_peer_times_out_instead_of_hanging(gpu):
+    """a rank whose peer never posts: the merge kernel gives up after 2 s and the host is told (MPPI_ERR_COMM)"""
+    cfg = cartpole_cfg(K=1024, T=20, soft=True)
+    ranks = [make_engine(cfg, rank=r, world_size=2) for r in range(2)]
+    m.MPPIController.p2pConnectLocal(ranks)
+    ranks[0].uploadState(cfg["x0"])
+    ranks[0].optimize(1, synchronize=True)  # rank 1 never runs
+    with pytest.raises(m.MPPIError) as e:
+        ranks[0].getStats()
+    assert e.value.status == 9
+
+
+def _ipc_worker(rank, world, conn, repo):
+    for p in (repo, os.path.join(repo, "oracle"), os.path.join(repo, "tests")):
+        sys.path.insert(0, p)
+    import numpy as np  # noqa: F811
+    from common import cartpole_cfg, make_engine  # noqa: F811
+    cfg = cartpole_cfg(K=4096, T=100, soft=True)
+    eng = make_engine(cfg, rank=rank, world_size=world)
+    conn.send(eng.p2pMailboxHandle())
+    handles = conn.recv()
+    eng.p2pConnect(handles)
+    conn.send("connected")
+    conn.recv()  # everybody is connected: go
+    eng.uploadState(cfg["x0"])
+    eng.optimize(3, synchronize=True)
+    conn.send(eng.getOptimalControlSeq()[0].tobytes())
+    conn.recv()
+    eng.close()
+
+
+def test_p2p_two_processes_share_the_gpu_through_hipipc(gpu):
+    """one process per rank, as on a multi-GPU node — here both on the one device: mailbox handles travel as hipIpcMemHandle_t"""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ctx = mp.get_context("spawn")
+    world = 2
+    pipes, procs = [], []
+    for r in range(world):
+        a, b = ctx.Pipe()
+        p = ctx.Process(target=_ipc_worker, args=(r, world, b, repo))
+        p.start()
+        pipes.append(a)
+        procs.append(p)
+    try:
+        handles = []
+        for a in pipes:
+            assert a.poll(120), "worker did not produce its mailbox handle"
+            handles.append(a.recv())
+        for a in pipes:
+            a.send(handles)
+        for a in pipes:
+            assert a.poll(120) and a.recv() == "connected"
+        for a in pipes:
+            a.send("go")
+        us = []
+        for a in pipes:
+            assert a.poll(120), "worker did not finish"
+            us.append(np.frombuffer(a.recv(), np.float32))
+        for a in pipes:
+            a.send("bye")
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+    cfg = cartpole_cfg(K=4096, T=100, soft=True)
+    full = make_engine(cfg)
+    full.uploadState(cfg["x0"])
+    full.optimize(3)
+    u_full = full.getOptimalControlSeq()[0].reshape(-1)
+    assert np.array_equal(us[0], us[1])
+    assert np.abs(us[0] - u_full).max() <= 5e-6

@@ -27,3 +27,28 @@ eng.uploadState(cfg["x0"])
 eng.optimize(50)
 t, r = eng.timeIterations(300)
 print("exchange (1 rank): iteration %.1f us (rollout kernel %.1f us)" % (t / 300 * 1e3, r / 300 * 1e3))
+# the P2P mailbox path with a world of one rank (the rank posts into its own mailbox): rollout, local merge + post, global merge
+p2p = make_engine(cfg, force_exchange=True)
+m.MPPIController.p2pConnectLocal([p2p])
+p2p.uploadState(cfg["x0"])
+p2p.optimize(50)
+t, r = p2p.timeIterations(300)
+print("p2p mailbox (1 rank): iteration %.1f us (rollout kernel %.1f us)" % (t / 300 * 1e3, r / 300 * 1e3))
+# two ranks of a K = 16384 problem on ONE GPU (8192 rollouts each, both rollout kernels share the device): the strong-scaling
+# shape of the exchange, minus the xGMI hop
+import time  # noqa: E402
+half = [make_engine(cfg, rank=r_, world_size=2) for r_ in range(2)]
+plain.close(); eng.close(); p2p.close()
+m.MPPIController.p2pConnectLocal(half)
+for c in half:
+    c.uploadState(cfg["x0"])
+for c in half:
+    c.optimize(50, synchronize=False)
+for c in half:
+    c.synchronize()
+t0 = time.perf_counter()
+for c in half:
+    c.optimize(1000, synchronize=False)
+for c in half:
+    c.synchronize()
+print("p2p mailbox, 2 ranks x 8192 rollouts on one GPU: %.1f us per iteration" % ((time.perf_counter() - t0) / 1000 * 1e6))
