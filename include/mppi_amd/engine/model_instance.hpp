@@ -133,6 +133,15 @@ struct ModelBase
     return false;
   }
   virtual size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D, bool pipeline) = 0;
+  /** floats the sampler needs for the sample rows of `blocks` blocks of `slots` rollout slots in HBM (long horizons), 0: the
+   *  sampler keeps its rows in LDS only; setGlobalRows(ptr) switches the fused kernel over (nullptr: back to LDS) */
+  virtual size_t globalRowsFloats(int blocks, int slots, int T) const
+  {
+    return 0;
+  }
+  virtual void setGlobalRows(float* rows_d)
+  {
+  }
   /** every registered block shape as (bx, by, bz) triples, flattened */
   virtual void listShapes(std::vector<int>& out) const = 0;
   virtual mppi_status launchRollout(int bx, int by, int bz, bool pipeline, const kernels::RolloutArgs& args,
@@ -828,6 +837,17 @@ struct ModelT : ModelBase
     smp.setIteration(s.iteration, s.optimization_stride);
   }
 
+  size_t globalRowsFloats(int blocks, int slots, int T) const override
+  {
+    if constexpr (SAMPLING_T::SUPPORTS_GLOBAL_ROWS)
+      return (size_t)blocks * slots * SAMPLING_T::rowStride(T);
+    return 0;
+  }
+  void setGlobalRows(float* rows_d) override
+  {
+    if constexpr (SAMPLING_T::SUPPORTS_GLOBAL_ROWS)
+      smp.rows_global_d_ = rows_d;
+  }
   size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D, bool pipeline) override
   {
     smp.params_.num_timesteps = T;

@@ -295,8 +295,10 @@ __global__ void __launch_bounds__(BX* BY* BZ* replicated_lanes<DYN_T>::value)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* theta_s_shared = reinterpret_cast<float*>(smem_raw);
   float* theta_c_shared = theta_s_shared + calcClassSharedMemSize(dynamics, SLOTS) / (int)sizeof(float);
-  float* theta_d_shared = theta_c_shared + calcClassSharedMemSize(costs, SLOTS) / (int)sizeof(float);
-  float* next_shared = theta_d_shared + calcClassSharedMemSize(sampling, SLOTS) / (int)sizeof(float);
+  float* theta_d_lds = theta_c_shared + calcClassSharedMemSize(costs, SLOTS) / (int)sizeof(float);
+  float* next_shared = theta_d_lds + calcClassSharedMemSize(sampling, SLOTS) / (int)sizeof(float);
+  // the block's sample rows: in LDS, or — horizons whose rows do not fit — in the sampler's HBM buffer (generic pointers)
+  float* theta_d_shared = sampling->blockRows(theta_d_lds, block_idx, SLOTS);
 
   float x_priv[S], xn_priv[S], xdot_priv[S], u_priv[C], y_priv[O];
   int crash_priv = 0;

@@ -148,6 +148,7 @@ public:
   static const int CONTROL_DIM = PARENT::CONTROL_DIM;
   static constexpr bool IN_LOOP_DRAW = false;  ///< the rows are filled by the prologue GEMM
   static constexpr bool COLORED = true;
+  static constexpr bool SUPPORTS_GLOBAL_ROWS = false;  ///< the prologue GEMM writes the rows through the LDS
   static constexpr int MAX_TB = 16;            ///< time blocks (of 16 steps) accumulated per pass over the spectrum
 
   /* reference: ColoredNoiseParamsImpl, colored_noise/colored_noise.cuh:45-73 */

@@ -81,6 +81,8 @@ public:
   typedef GaussianDistribution<DYN_PARAMS_T> SAMPLING_T;
   static constexpr bool IN_LOOP_DRAW = true;  ///< single-lane rollouts may draw eps inside the step loop
   static constexpr bool COLORED = false;
+  /** the fused rollout kernel can keep this sampler's rows in global memory when they do not fit the LDS (long horizons) */
+  static constexpr bool SUPPORTS_GLOBAL_ROWS = true;
 
   SAMPLING_PARAMS_T params_;
 
@@ -88,6 +90,13 @@ public:
   float* control_means_d_ = nullptr;      ///< mu [D][T][C]              (reference: gaussian.cuh control_means_d_)
   const float* eps_d_ = nullptr;          ///< eps [K_local][T][C], NOISE_EPS_BUFFER only
   float* control_samples_d_ = nullptr;    ///< optional dump of the clamped samples v [D][K_local][T][C]
+  /**
+   * Long horizons: the sample rows of a block, [blocks][slots][rowStride], in HBM instead of LDS (the reference keeps its
+   * samples in global memory always and has no horizon limit, sampling_distribution.cu:169-205).  nullptr: rows in LDS.
+   * The kernels address the rows through sampleRow() / theta_d either way; a lane's accesses walk its own row (one cache
+   * line serves 16 / C steps), the weighted reduction of the epilogue reads them coalesced across the columns.
+   */
+  float* rows_global_d_ = nullptr;
 
   /* per-call state, refreshed by the engine before every launch (the engine passes the object by value) */
   int noise_source_ = NOISE_PHILOX_FUSED;
@@ -136,7 +145,12 @@ public:
   /** LDS request per rollout slot: one sample row (reference: managed.cuh:104-111 Blk request) */
   __host__ __device__ inline int getBlkSharedSizeBytes() const
   {
-    return rowStride(params_.num_timesteps) * (int)sizeof(float);
+    return rows_global_d_ ? 0 : rowStride(params_.num_timesteps) * (int)sizeof(float);
+  }
+  /** where the rows of block `block_idx` (slots_per_block rows) live: the LDS region the kernel reserved, or the HBM buffer */
+  __device__ inline float* blockRows(float* theta_d_lds, const int block_idx, const int slots_per_block) const
+  {
+    return rows_global_d_ ? rows_global_d_ + (size_t)block_idx * slots_per_block * rowStride(params_.num_timesteps) : theta_d_lds;
   }
   __host__ __device__ inline int getGrdSharedSizeBytes() const
   {

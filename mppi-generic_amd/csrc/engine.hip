@@ -95,6 +95,8 @@ struct mppi_handle_s
   float* stats_d = nullptr;        // [D][STATS_STRIDE]
   float* eps_d = nullptr;          // [n_eps_iters][K_local][T][C]
   float* samples_d = nullptr;      // [D][K_local][T][C]
+  float* rows_d = nullptr;         // [num_blocks][bx * bz][rowStride]: the sampler's rows when they do not fit the LDS
+  bool rows_in_hbm = false;
   float* history_d = nullptr;      // [2][C]
   float* ctrl_in_d = nullptr;      // [D][T][C]
   float* ctrl_out_d = nullptr;     // [D][T][C]
@@ -344,7 +346,7 @@ static void freeAll(mppi_handle h)
   h->in_pin_h = h->out_pin_h = h->step_pin_h = nullptr;
   h->step_u_d = nullptr;  // slice of the step_x_d block
   float** bufs[] = { &h->in_block_d, &h->out_block_d, &h->costs_d,   &h->partials_d,  &h->send_d,     &h->recv_d,
-                     &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->gather_tmp_d };
+                     &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->gather_tmp_d, &h->rows_d };
   for (float** b : bufs)
   {
     if (*b)
@@ -456,12 +458,36 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     h->pipeline = false;
     lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, false);
   }
+  const char* force_hbm_rows = getenv("MPPI_AMD_ROWS_IN_HBM");  // test hook: the HBM-row variant at any horizon
+  const bool want_hbm_rows = lds > MAX_LDS_BYTES || (force_hbm_rows && force_hbm_rows[0] == '1');
+  if (want_hbm_rows && cfg->controller != MPPI_CONTROLLER_ROBUST && cfg->kernel_variant != MPPI_KERNEL_PIPELINE &&
+      h->model->globalRowsFloats(1, 1, cfg->num_timesteps) > 0)
+  {
+    // Horizons whose sample rows do not fit the LDS next to the default block: the rows move to HBM (the reference's layout — it has no
+    // horizon limit, sampling_distribution.cu:169-205), the fused kernel with the default block shape runs on them.
+    // (Cartpole K=16384, T=1500: 1.2 ms per iteration against 3.7 ms with 16-rollout blocks whose rows fit the LDS.)
+    if (lds > MAX_LDS_BYTES)
+    {
+      h->bx = cfg->block_x > 0 ? cfg->block_x : h->model->default_bx;
+      h->by = cfg->block_y > 0 ? cfg->block_y : h->model->default_by;
+    }
+    if (h->model->supportsShape(h->bx, h->by, h->bz))
+    {
+      h->pipeline = false;
+      h->model->setGlobalRows(reinterpret_cast<float*>(16));  // placeholder until the buffer exists: sizes the LDS request
+      lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, false);
+      if (lds <= MAX_LDS_BYTES)
+        h->rows_in_hbm = true;
+      else
+        h->model->setGlobalRows(nullptr);
+    }
+  }
   if (lds > MAX_LDS_BYTES && cfg->block_x == 0 && cfg->block_y == 0 && cfg->controller != MPPI_CONTROLLER_ROBUST &&
       cfg->kernel_variant != MPPI_KERNEL_PIPELINE)
   {
-    // Long horizons: the sample rows of the default block (T * C floats per rollout and system) do not fit the 160 KiB of
-    // LDS.  No shape was requested, so take the registered shape with the most rollouts per block that does fit (fused
-    // variant; the reference keeps its samples in global memory and has no such limit — here they never leave the CU).
+    // Long horizons with a sampler / controller that has no rows-in-HBM form: the sample rows of the default block (T * C
+    // floats per rollout and system) do not fit the 160 KiB of LDS.  No shape was requested, so take the registered shape
+    // with the most rollouts per block that does fit (fused variant).
     std::vector<int> shapes;
     h->model->listShapes(shapes);
     int best = -1;
@@ -484,7 +510,8 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   if (lds > MAX_LDS_BYTES)
     return fail(nullptr, MPPI_ERR_LDS_OVERFLOW,
                 "mppi_create: rollout kernel needs " + std::to_string(lds) + " B of LDS per block (max 163840) — the sample "
-                "rows of a block live in LDS; shorten the horizon or register a block shape with fewer rollouts");
+                "rows of a block live in LDS and this sampler / controller / kernel variant has no rows-in-HBM form; shorten "
+                "the horizon or register a block shape with fewer rollouts");
   h->num_blocks = (h->K_local + h->bx - 1) / h->bx;
   h->TC = cfg->num_timesteps * h->C;
   h->PS = kernels::partialStride(cfg->num_timesteps, h->C);
@@ -576,6 +603,11 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   }
   if (cfg->save_samples)
     ALLOC_OR_FAIL(h->samples_d, (size_t)D * K * T * C);
+  if (h->rows_in_hbm)
+  {
+    ALLOC_OR_FAIL(h->rows_d, h->model->globalRowsFloats(h->num_blocks, h->bx * h->bz, T));
+    h->model->setGlobalRows(h->rows_d);
+  }
 #undef ALLOC_OR_FAIL
   {
     hipError_t e = hipEventCreate(&h->ev_a);

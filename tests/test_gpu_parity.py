@@ -138,9 +138,10 @@ def test_compute_control_short_and_odd_horizons(gpu, T):
         assert np.abs(eng.getTargetStateSeq() - orc.state_traj()).max() <= 1e-4
 
 
-def test_long_horizon_picks_a_smaller_block(gpu):
-    """T * C floats per rollout live in LDS: when the default block's rows do not fit the 160 KiB, mppi_create takes the
-    registered shape with the most rollouts per block that does (the reference has no such limit: samples in HBM)"""
+def test_long_horizon_moves_the_rows_or_picks_a_smaller_block(gpu):
+    """T * C floats per rollout live in LDS: when the default block's rows do not fit the 160 KiB, mppi_create moves the rows
+    to HBM (Gaussian sampler, fused kernel — tests/test_long_horizon.py) or, where that form does not exist (pipeline variant
+    requested explicitly, colored sampler), takes the registered shape with the most rollouts per block that does fit"""
     cfg = cartpole_cfg(K=300, T=700, soft=True)
     eps = host_noise(1, cfg["K"], cfg["T"], 1, seed=3)
     eng, orc = make_engine(cfg), make_oracle(cfg)
@@ -150,11 +151,13 @@ def test_long_horizon_picks_a_smaller_block(gpu):
     assert ulp_diff(eng.getSampledCostSeq(), orc.costs()).max() == 0
     assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
     import mppi_generic_amd as m
-    with pytest.raises(m.MPPIError) as e:  # an explicit shape is honoured, not replaced
-        make_engine(cfg, block_x=64, block_y=1)
-    assert e.value.status == 6
-    with pytest.raises(m.MPPIError) as e:  # nothing registered fits
-        make_engine(cartpole_cfg(K=300, T=20000))
+    with pytest.raises(m.MPPIError) as e:  # the pipeline variant keeps its rows in LDS: an explicit request is not replaced
+        make_engine(cfg, block_x=64, block_y=1, kernel_variant=2)
+    assert e.value.status in (5, 6)
+    ccfg = cartpole_cfg(K=300, T=20000)
+    ccfg["colored"] = ([1.0], 0.97, 0.0)
+    with pytest.raises(m.MPPIError) as e:  # nothing registered fits and the sampler has no rows-in-HBM form
+        make_engine(ccfg)
     assert e.value.status == 6 and "horizon" in str(e.value)
 
 

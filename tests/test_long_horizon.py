@@ -1,0 +1,70 @@
+"""Horizons whose sample rows do not fit the LDS: the rows-in-HBM form of the fused rollout kernel (the reference keeps its
+samples in global memory always and has no horizon limit, sampling_distributions/sampling_distribution.cu:169-205)."""
+import os
+
+import numpy as np
+import pytest
+
+import mppi_generic_amd as m
+import pyoracle as po
+from common import autorally_cfg, cartpole_cfg, cartpole_cfg_lr, di_cfg, host_noise, make_engine, make_oracle, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_with_hbm_rows(cfg, **kw):
+    os.environ["MPPI_AMD_ROWS_IN_HBM"] = "1"
+    try:
+        return make_engine(cfg, **kw)
+    finally:
+        del os.environ["MPPI_AMD_ROWS_IN_HBM"]
+
+
+@pytest.mark.parametrize("mk", [lambda: cartpole_cfg_lr(K=1000, T=50), lambda: di_cfg(K=512, T=33, tube=True),
+                                lambda: autorally_cfg(K=200, T=37)], ids=["cartpole", "di-tube", "autorally-mfma"])
+@pytest.mark.parametrize("noise", ["injected", "philox"])
+def test_hbm_rows_bit_identical_to_lds_rows(gpu, mk, noise):
+    """same kernel, same arithmetic, rows in HBM instead of LDS: costs, samples and u* are the same bits (ragged last block,
+    two systems per launch, replicated-lane dynamics)"""
+    cfg = mk()
+    a = make_engine(cfg, kernel_variant=1, save_samples=True)
+    b = _engine_with_hbm_rows(cfg, kernel_variant=1, save_samples=True)
+    x0 = np.tile(cfg["x0"], (cfg["D"], 1))
+    for eng in (a, b):
+        if noise == "injected":
+            eng.injectNoise(host_noise(1, cfg["K"], cfg["T"], eng.CONTROL_DIM))
+        eng.uploadState(x0)
+        eng.optimize(2)
+    assert np.array_equal(a.getSampledCostSeq(), b.getSampledCostSeq())
+    assert np.array_equal(a.getSampledControls(), b.getSampledControls())
+    assert np.array_equal(a.getOptimalControlSeq(), b.getOptimalControlSeq())
+
+
+def test_cartpole_T5000_vs_oracle(gpu):
+    """T = 5000: 20 KB of samples per rollout — no block shape fits the LDS; mppi_create moves the rows to HBM by itself"""
+    cfg = cartpole_cfg(K=2048, T=5000, soft=True)
+    eng, orc = make_engine(cfg), make_oracle(cfg)
+    eps = host_noise(1, cfg["K"], cfg["T"], 1)
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    orc.vanilla_compute_control(cfg["x0"], 1, eps)
+    assert ulp_diff(eng.getSampledCostSeq(), orc.costs()).max() == 0
+    assert np.abs(eng.getControlSeq() - orc.control()).max() <= 1e-5
+    assert eng.getStats().real_sys.baseline == orc.stats()["baseline"][0]
+    # and the in-kernel Philox stream at the same horizon
+    eng.injectNoise(None)
+    eng.setSeed(5)
+    eng.uploadState(cfg["x0"])
+    eng.updateImportanceSampler(np.zeros((cfg["T"], 1), np.float32))
+    eng.optimize(1)
+    u = orc.iterate(cfg["x0"], np.zeros((cfg["T"], 1), np.float32), po.philox_normal(5, 0, cfg["K"], cfg["T"], 1))[0]
+    assert np.abs(eng.getOptimalControlSeq()[0] - u).max() <= 1e-5
+
+
+def test_colored_sampler_still_reports_overflow(gpu):
+    """the colored-noise sampler writes its rows through the LDS (prologue GEMM): no HBM form, the error stays explicit"""
+    cfg = cartpole_cfg(K=256, T=5000)
+    cfg["colored"] = ([1.0], 0.97, 0.0)
+    with pytest.raises(m.MPPIError) as e:
+        make_engine(cfg)
+    assert e.value.status == 6
