@@ -76,7 +76,8 @@ def test_error_codes(gpu):
         m.VanillaMPPIController("cartpole", 128, 10, 0.02, 1.0, block_x=48, block_y=3)
     assert e.value.status == 5
     with pytest.raises(m.MPPIError) as e:  # LDS overflow (reference: runtime_error, mppi_controller.cu:64-76)
-        m.VanillaMPPIController("cartpole", 128, 2000, 0.02, 1.0, block_x=64, block_y=1)  # (no shape given: a smaller block is picked)
+        # (the fused kernel would move the rows to HBM; the pipeline variant keeps them in LDS and says so)
+        m.VanillaMPPIController("cartpole", 128, 2000, 0.02, 1.0, block_x=64, block_y=1, kernel_variant=2)
     assert e.value.status == 6
     with pytest.raises(m.MPPIError) as e:
         m.VanillaMPPIController("cartpole", 0, 10, 0.02, 1.0)
