@@ -191,6 +191,16 @@ mppi_status mppi_set_sampler_params(mppi_handle h, const mppi_gaussian_params* p
  *  mppi_set_sampler_params as for the Gaussian sampler (ColoredNoiseParams extends GaussianParams). */
 mppi_status mppi_set_colored_noise_params(mppi_handle h, const float* exponents, float offset_decay_rate, float fmin);
 /** Dynamics::setControlRanges (dynamics/dynamics.cu:19-36); lo_hi = [C][2] */
+/**
+ * ColoredMPPI options (controllers/ColoredMPPI/colored_mppi_controller.cuh:18-22, 95-193):
+ *  - gamma, r_exp: Tsallis weights w = (S - rho < gamma) ? exp(log(1 - (S - rho) / gamma) / (r - 1)) : 0 instead of the exponential
+ *    ones when BOTH are non-zero (core/mppi_common.cu:968-985; colored_mppi_controller.cu:198-206);
+ *  - state leash (setStateLeashLength / setLeashActive, colored_mppi_controller.cu:150-156): with the leash active every
+ *    mppi_compute_control starts from Dynamics::enforceLeash(measured state, previous state trajectory[leash_jump],
+ *    state_leash_dist[S]) instead of the measured state.  state_leash_dist may be NULL (keeps the previous / zero leash).
+ */
+mppi_status mppi_set_colored_mppi_params(mppi_handle h, float gamma, float r_exp, const float* state_leash_dist,
+                                         int leash_active, int leash_jump);
 mppi_status mppi_set_control_ranges(mppi_handle h, const float* lo_hi);
 /** Dynamics::setControlDeadbands (dynamics/dynamics.cu:38-55) */
 mppi_status mppi_set_control_deadband(mppi_handle h, const float* deadband);
@@ -327,6 +337,15 @@ mppi_status mppi_upload_state(mppi_handle h, const float* x0);
  * duration of the rollout kernel launches alone (events recorded around each rollout launch).
  */
 mppi_status mppi_time_iterations(mppi_handle h, int num_iterations, float* ms_total, float* ms_rollout_kernels);
+/**
+ * chooseAppropriateKernel (controllers/MPPI/mppi_controller.cu:44-143): times the rollout kernel structures that fit this
+ * configuration — the fused kernel and the role-pipelined one, the counterparts of the reference's "single" and "split"
+ * kernels — num_evaluations launches each on the handle's current state, mean and parameters (model blobs must be loaded),
+ * and keeps the faster one for all later launches.  The trial launches do not advance the noise stream.  chosen_variant
+ * (mppi_kernel_variant), fused_ms, pipeline_ms (time per launch; +inf where a structure does not apply) may be NULL.
+ * Without this call the handle runs cfg.kernel_variant (MPPI_KERNEL_AUTO: the pipelined kernel where it exists).
+ */
+mppi_status mppi_choose_kernel(mppi_handle h, int num_evaluations, int* chosen_variant, float* fused_ms, float* pipeline_ms);
 /** waits for everything enqueued on the handle's stream */
 mppi_status mppi_synchronize(mppi_handle h);
 

@@ -195,6 +195,14 @@ public:
   {
     check(mppi_enforce_constraints(h_, state.empty() ? nullptr : state.data(), u.data()));
   }
+  /** controllers/MPPI/mppi_controller.cu:44-143: time the fused and the role-pipelined rollout kernel, keep the faster;
+   *  returns the chosen mppi_kernel_variant */
+  int chooseAppropriateKernel(int num_evaluations = 10)
+  {
+    int v = 0;
+    check(mppi_choose_kernel(h_, num_evaluations, &v, nullptr, nullptr));
+    return v;
+  }
   /** device-resident iterations without host round trips (the unit bench.py times) */
   void optimize(int num_iterations, bool synchronize = true)
   {

@@ -64,6 +64,20 @@ struct ModelBase
   virtual void setControlRanges(const float* lo_hi) = 0;
   virtual void setControlDeadband(const float* db) = 0;
   virtual void getZeroControl(float* out) const = 0;
+  /** Dynamics::enforceLeash (dynamics/dynamics.cuh:448-466), host: per state dimension, the nominal state if it is within
+   *  the leash of the true state, else the true state moved towards it by the leash.  A plugin with an enforceLeash() host
+   *  method of its own (RacerDubins: position leash in the body frame, racer_dubins.cu:177-230) overrides it. */
+  virtual void hostEnforceLeash(const float* state_true, const float* state_nominal, const float* leash, float* out) const
+  {
+    for (int i = 0; i < S; i++)
+    {
+      const float diff = fabsf(state_nominal[i] - state_true[i]);
+      if (leash[i] < diff)
+        out[i] = state_true[i] + fminf(fmaxf(state_nominal[i] - state_true[i], -leash[i]), leash[i]);
+      else
+        out[i] = state_nominal[i];
+    }
+  }
   /** the base enforceConstraints rule on the host (dynamics.cu:97-116); false: the plugin overrides it, run the device code */
   virtual bool hostEnforceConstraints(float* u) const = 0;
   virtual void setSamplerParams(const mppi_gaussian_params* p, int D) = 0;
@@ -246,6 +260,16 @@ struct has_lstm_helper : std::false_type
 };
 template <class T>
 struct has_lstm_helper<T, std::void_t<decltype(std::declval<T&>().lstm_.weights_d_)>> : std::true_type
+{
+};
+template <class T, class = void>
+struct has_host_leash : std::false_type
+{
+};
+template <class T>
+struct has_host_leash<T, std::void_t<decltype(std::declval<const T&>().enforceLeash((const float*)nullptr, (const float*)nullptr,
+                                                                                     (const float*)nullptr, (float*)nullptr))>>
+  : std::true_type
 {
 };
 template <class T, class = void>
@@ -676,6 +700,13 @@ struct ModelT : ModelBase
   {
     for (int i = 0; i < DYN_T::CONTROL_DIM; i++)
       out[i] = dyn.zero_control_[i];
+  }
+  void hostEnforceLeash(const float* state_true, const float* state_nominal, const float* leash, float* out) const override
+  {
+    if constexpr (has_host_leash<DYN_T>::value)
+      dyn.enforceLeash(state_true, state_nominal, leash, out);
+    else
+      ModelBase::hostEnforceLeash(state_true, state_nominal, leash, out);
   }
   bool hostEnforceConstraints(float* u) const override
   {

@@ -86,6 +86,7 @@ SIGNATURES = {
     "mppi_set_feedback_gains": (C.c_int, [H, _f32p, C.c_int]),
     "mppi_update_importance_sampling_control": (C.c_int, [H, _f32p, C.c_int]),
     "mppi_get_rmppi_state": (C.c_int, [H, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
+    "mppi_set_colored_mppi_params": (C.c_int, [H, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int]),
     "mppi_set_control_ranges": (C.c_int, [H, _f32p]),
     "mppi_set_control_deadband": (C.c_int, [H, _f32p]),
     "mppi_set_lambda_alpha": (C.c_int, [H, C.c_float, C.c_float]),
@@ -113,6 +114,7 @@ SIGNATURES = {
     "mppi_optimize": (C.c_int, [H, C.c_int, C.c_int]),
     "mppi_upload_state": (C.c_int, [H, _f32p]),
     "mppi_time_iterations": (C.c_int, [H, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mppi_choose_kernel": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mppi_synchronize": (C.c_int, [H]),
     "mppi_get_exchange_buffers": (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "mppi_read_send_record": (C.c_int, [H, _f32p]),

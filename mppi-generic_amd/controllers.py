@@ -387,6 +387,13 @@ class MPPIController:
     def synchronize(self):
         self._check(self._lib.mppi_synchronize(self._h))
 
+    def chooseAppropriateKernel(self, num_evaluations=10):
+        """times the fused and the role-pipelined rollout kernel and keeps the faster (mppi_controller.cu:44-143);
+        returns (variant, fused_ms, pipeline_ms) with variant 1 = fused, 2 = pipeline"""
+        v, a, b = C.c_int(), C.c_float(), C.c_float()
+        self._check(self._lib.mppi_choose_kernel(self._h, num_evaluations, C.byref(v), C.byref(a), C.byref(b)))
+        return v.value, a.value, b.value
+
     def enforceConstraints(self, state, u):
         """Dynamics::enforceConstraints on one control vector (host-side and lock-free for the base rule)"""
         u = _f32(u).reshape(-1).copy()
@@ -458,6 +465,12 @@ class ColoredMPPIController(MPPIController):
 
     def setColoredNoiseParams(self, exponents, offset_decay_rate=0.97, fmin=0.0):
         self._check(self._lib.mppi_set_colored_noise_params(self._h, _f32(exponents).reshape(-1), offset_decay_rate, fmin))
+
+    def setColoredMPPIParams(self, gamma=0.0, r_exp=0.0, state_leash_dist=None, leash_active=False, leash_jump=1):
+        """setGamma / setRExp (Tsallis weights when both are non-zero) and the state leash (setStateLeashLength,
+        setLeashActive; colored_mppi_controller.cuh:95-193)"""
+        p = None if state_leash_dist is None else _f32(state_leash_dist).reshape(-1).ctypes.data
+        self._check(self._lib.mppi_set_colored_mppi_params(self._h, gamma, r_exp, p, int(leash_active), leash_jump))
 
     def _noise_shape(self):
         """spectrum noise, the reference's samples_in_freq_complex_d_ layout: [K][C][T+1][2]"""

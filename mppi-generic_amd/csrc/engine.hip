@@ -97,6 +97,12 @@ struct mppi_handle_s
   float* samples_d = nullptr;      // [D][K_local][T][C]
   float* rows_d = nullptr;         // [num_blocks][bx * bz][rowStride]: the sampler's rows when they do not fit the LDS
   bool rows_in_hbm = false;
+  /* ColoredMPPI options (controllers/ColoredMPPI/colored_mppi_controller.cuh:18-22, 159-193): Tsallis weights and state leash */
+  float tsallis_gamma = 0.0f, tsallis_r = 0.0f;
+  float* tsallis_weights_d = nullptr;  // [K_local]
+  bool leash_active = false;
+  int leash_jump = 1;
+  std::vector<float> leash_dist;       // [S]
   float* history_d = nullptr;      // [2][C]
   float* ctrl_in_d = nullptr;      // [D][T][C]
   float* ctrl_out_d = nullptr;     // [D][T][C]
@@ -346,7 +352,8 @@ static void freeAll(mppi_handle h)
   h->in_pin_h = h->out_pin_h = h->step_pin_h = nullptr;
   h->step_u_d = nullptr;  // slice of the step_x_d block
   float** bufs[] = { &h->in_block_d, &h->out_block_d, &h->costs_d,   &h->partials_d,  &h->send_d,     &h->recv_d,
-                     &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->gather_tmp_d, &h->rows_d };
+                     &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->gather_tmp_d, &h->rows_d,
+                     &h->tsallis_weights_d };
   for (float** b : bufs)
   {
     if (*b)
@@ -718,6 +725,39 @@ mppi_status mppi_set_colored_noise_params(mppi_handle h, const float* exponents,
   mppi_status s = h->model->setColoredNoiseParams(exponents, offset_decay_rate, fmin);
   return s == MPPI_OK ? s : fail(h, s, "mppi_set_colored_noise_params: the handle's sampler is Gaussian (create it with MPPI_CONTROLLER_COLORED)");
 }
+mppi_status mppi_set_colored_mppi_params(mppi_handle h, float gamma, float r_exp, const float* state_leash_dist,
+                                         int leash_active, int leash_jump)
+{
+  CHECK_HANDLE(h);
+  if (h->cfg.controller != MPPI_CONTROLLER_COLORED)
+    return fail(h, MPPI_ERR_STATE, "mppi_set_colored_mppi_params: not a ColoredMPPI handle");
+  if (leash_jump < 0 || leash_jump >= h->cfg.num_timesteps)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_colored_mppi_params: leash_jump must index the state trajectory");
+  if (gamma != 0.0f && r_exp != 0.0f)
+  {
+    if (r_exp == 1.0f || !(gamma > 0.0f))
+      return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_colored_mppi_params: Tsallis weights need gamma > 0 and r != 1");
+    if (exchangeActive(h))
+      return fail(h, MPPI_ERR_UNSUPPORTED, "Tsallis weights need the global baseline before any weight: not available on a "
+                                           "K-sharded handle");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!h->samples_d)  // the weighted mean is formed from the samples in HBM (control_samples_d_ of the reference)
+      HIP_TRY(h, hipMalloc((void**)&h->samples_d, sizeof(float) * (size_t)h->D * h->K_local * h->TC));
+    if (!h->tsallis_weights_d)
+      HIP_TRY(h, hipMalloc((void**)&h->tsallis_weights_d, sizeof(float) * (size_t)h->K_local));
+  }
+  h->tsallis_gamma = gamma;
+  h->tsallis_r = r_exp;
+  h->leash_active = leash_active != 0;
+  h->leash_jump = leash_jump;
+  if (state_leash_dist)
+    h->leash_dist.assign(state_leash_dist, state_leash_dist + h->S);
+  else if (h->leash_dist.empty())
+    h->leash_dist.assign(h->S, 0.0f);
+  return MPPI_OK;
+}
+
 mppi_status mppi_set_control_ranges(mppi_handle h, const float* lo_hi)
 {
   CHECK_HANDLE(h);
@@ -1046,9 +1086,24 @@ static kernels::PostTargets p2pTargets(mppi_handle h, unsigned seq)
   return t;
 }
 
+static inline bool tsallisActive(const mppi_handle_s* h)
+{  // colored_mppi_controller.cu:198: the exponential weights unless BOTH parameters are set
+  return h->cfg.controller == MPPI_CONTROLLER_COLORED && h->tsallis_gamma != 0.0f && h->tsallis_r != 0.0f;
+}
+
 static mppi_status iterationLocal(mppi_handle h, int iteration, int stride)
 {
   MPPI_TRY(launchRollout(h, iteration, stride));
+  if (tsallisActive(h))
+  {  // global baseline -> Tsallis weights -> weighted mean of the dumped samples (reduce_kernels.hpp)
+    hipLaunchKernelGGL(kernels::tsallisWeightsKernel, dim3(1), dim3(kernels::COMBINE_THREADS), 0, h->stream, h->K_local,
+                       h->costs_d, h->tsallis_gamma, h->tsallis_r, h->cfg.lambda, h->tsallis_weights_d, h->stats_d);
+    hipLaunchKernelGGL(kernels::tsallisMeanKernel, dim3((h->TC + kernels::COMBINE_COLS - 1) / kernels::COMBINE_COLS),
+                       dim3(kernels::COMBINE_THREADS), 0, h->stream, h->tsallis_weights_d, h->samples_d, h->stats_d, h->TC,
+                       h->K_local, h->mean_d);
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+  }
   if (!exchangeActive(h))
     return launchCombine(h, h->partials_d, h->num_blocks, 1, nullptr, h->cfg.num_rollouts);
   if (h->p2p_ready && h->p2p_auto)
@@ -1290,9 +1345,20 @@ static mppi_status ensureTrajectories(mppi_handle h)
   return MPPI_OK;
 }
 
-static mppi_status computeControlVanilla(mppi_handle h, const float* x0, int stride)
+static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, int stride)
 {
   const int T = h->cfg.num_timesteps;
+  // ColoredMPPI state leash (colored_mppi_controller.cu:150-156): the optimisation starts from the state of the previous
+  // solution at index leash_jump, pulled towards the measured state by at most the leash per dimension
+  std::vector<float> leashed;
+  const float* x0 = x0_true;
+  if (h->cfg.controller == MPPI_CONTROLLER_COLORED && h->leash_active)
+  {
+    MPPI_TRY(ensureTrajectories(h));
+    leashed.resize(h->S);
+    h->model->hostEnforceLeash(x0_true, &h->state_h[(size_t)h->leash_jump * h->S], h->leash_dist.data(), leashed.data());
+    x0 = leashed.data();
+  }
   kernels::FinalizeArgs a{};
   a.control_in_d = h->mean_d;
   a.history_d = h->history_d;
@@ -2005,6 +2071,61 @@ mppi_status mppi_time_iterations(mppi_handle h, int n, float* ms_total, float* m
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     *ms_rollout = sum;
   }
+  return MPPI_OK;
+}
+
+mppi_status mppi_choose_kernel(mppi_handle h, int num_evaluations, int* chosen_variant, float* fused_ms, float* pipeline_ms)
+{
+  CHECK_HANDLE(h);
+  if (num_evaluations <= 0)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_choose_kernel: num_evaluations must be > 0");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const bool pipe_ok = h->cfg.controller != MPPI_CONTROLLER_ROBUST && !h->rows_in_hbm &&
+                       ((h->model->supportsPipeline() && h->bx == 64 && h->by == 1) ||
+                        h->model->supportsPipelineFold(h->bx, h->by, h->bz) || h->model->supportsPipelineRep(h->bx, h->by, h->bz)) &&
+                       h->model->rolloutSharedBytes(h->bx, h->by, h->bz, h->cfg.num_timesteps, h->D, true) <= MAX_LDS_BYTES;
+  const bool fused_ok = h->cfg.controller == MPPI_CONTROLLER_ROBUST ||
+                        (h->model->supportsShape(h->bx, h->by, h->bz) &&
+                         h->model->rolloutSharedBytes(h->bx, h->by, h->bz, h->cfg.num_timesteps, h->D, false) <= MAX_LDS_BYTES);
+  float t_ms[2] = { INFINITY, INFINITY };  // [0] fused, [1] pipeline
+  const bool was = h->pipeline;
+  const uint32_t generation = h->generation;
+  for (int v = 0; v < 2; v++)
+  {
+    if ((v == 0 && !fused_ok) || (v == 1 && !pipe_ok))
+      continue;
+    h->pipeline = v == 1;
+    mppi_status st = launchRollout(h, 0, h->last_stride);  // warm-up (code object load, LDS attribute)
+    if (st == MPPI_OK)
+      st = hipStreamSynchronize(h->stream) == hipSuccess ? MPPI_OK : MPPI_ERR_HIP;
+    if (st == MPPI_OK && hipEventRecord(h->ev_a, h->stream) != hipSuccess)
+      st = MPPI_ERR_HIP;
+    for (int i = 0; st == MPPI_OK && i < num_evaluations; i++)
+      st = launchRollout(h, 0, h->last_stride);
+    if (st == MPPI_OK && (hipEventRecord(h->ev_b, h->stream) != hipSuccess || hipEventSynchronize(h->ev_b) != hipSuccess ||
+                          hipEventElapsedTime(&t_ms[v], h->ev_a, h->ev_b) != hipSuccess))
+      st = MPPI_ERR_HIP;
+    if (st != MPPI_OK)
+    {
+      h->pipeline = was;
+      h->generation = generation;
+      return st == MPPI_ERR_HIP ? fail(h, st, "mppi_choose_kernel: HIP error while timing the rollout kernels") : st;
+    }
+    t_ms[v] /= (float)num_evaluations;
+  }
+  h->generation = generation;  // the trial launches do not advance the noise stream
+  if (!fused_ok && !pipe_ok)
+  {
+    h->pipeline = was;
+    return fail(h, MPPI_ERR_LDS_OVERFLOW, "mppi_choose_kernel: neither kernel structure fits this configuration");
+  }
+  h->pipeline = t_ms[1] < t_ms[0];
+  if (chosen_variant)
+    *chosen_variant = h->pipeline ? MPPI_KERNEL_PIPELINE : MPPI_KERNEL_FUSED;
+  if (fused_ms)
+    *fused_ms = t_ms[0];
+  if (pipeline_ms)
+    *pipeline_ms = t_ms[1];
   return MPPI_OK;
 }
 

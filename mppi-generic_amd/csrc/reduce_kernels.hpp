@@ -356,6 +356,82 @@ __global__ void __launch_bounds__(COMBINE_THREADS)
 }
 
 /**
+ * ColoredMPPI's Tsallis weights (core/mppi_common.cu:968-985 TsallisTransform, launched by
+ * controllers/ColoredMPPI/colored_mppi_controller.cu:198-206 when gamma != 0 and r != 0):
+ *     w_k = (S_k - rho < gamma) ? exp(log(1 - (S_k - rho) / gamma) / (r - 1)) : 0
+ * The weights are not shift-invariant, so the block-local softmin records of the rollout kernel cannot be rescaled into them:
+ * this path takes the GLOBAL baseline first (one block over the K costs), writes the weights, the normaliser (double) and the
+ * free-energy statistics, and tsallisMeanKernel then forms the weighted mean from the samples the rollout kernel dumped to HBM.
+ */
+__global__ void __launch_bounds__(COMBINE_THREADS)
+    tsallisWeightsKernel(int num_rollouts, const float* __restrict__ costs_d, float gamma, float r, float lambda,
+                         float* __restrict__ weights_d, float* __restrict__ stats_out_d)
+{
+  __shared__ double red_d[COMBINE_THREADS / 64];
+  __shared__ float red_f[COMBINE_THREADS / 64];
+  const int tid = threadIdx.x;
+  float m = INFINITY;
+  for (int i = tid; i < num_rollouts; i += COMBINE_THREADS)
+    m = fminf(m, costs_d[i]);
+  m = blockMin(m, red_f);
+  double s = 0.0, s2 = 0.0;
+  const float inv = 1.0f / (r - 1.0f);
+  for (int i = tid; i < num_rollouts; i += COMBINE_THREADS)
+  {
+    const float cost_dif = costs_d[i] - m;
+    float w = 0.0f;
+    if (cost_dif < gamma)
+      w = mppi::det::exp(mppi::det::log(1.0f - cost_dif / gamma) * inv);
+    weights_d[i] = w;
+    s += (double)w;
+    s2 += (double)w * (double)w;
+  }
+  s = blockSum(s, red_d);
+  s2 = blockSum(s2, red_d);
+  if (tid == 0)
+  {
+    // the statistics of combineKernel (mppi_common.cu:1065-1081 computeFreeEnergy) on these weights
+    const float K = (float)num_rollouts, eta_f = (float)s, norm = eta_f / K, var = (float)s2;
+    const float fe_var = lambda * (var / K - norm * norm);
+    const float weird = fe_var / (norm * mppi::det::sqrt(K));
+    stats_out_d[0] = m;
+    stats_out_d[1] = eta_f;
+    stats_out_d[2] = -lambda * mppi::det::log(norm) + m;
+    stats_out_d[3] = fe_var;
+    stats_out_d[4] = lambda * (weird + 0.5f * (weird * weird));
+    stats_out_d[5] = var;
+    stats_out_d[6] = 0.0f;
+    stats_out_d[7] = 0.0f;
+  }
+}
+
+/** u*[j] = sum_k w_k v[k][j] / eta over samples in HBM (v: [K][T*C]); block = 64 columns x 16 waves, wave w takes rollouts
+ *  w, w + 16, ... in ascending order and the sixteen partials are added in a fixed order (reproducible run to run) */
+__global__ void __launch_bounds__(COMBINE_THREADS)
+    tsallisMeanKernel(const float* __restrict__ weights_d, const float* __restrict__ v_d, const float* __restrict__ stats_d,
+                      int TC, int num_rollouts, float* __restrict__ mean_out_d)
+{
+  __shared__ float part_s[COMBINE_THREADS / 64][COMBINE_COLS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int NW = COMBINE_THREADS / 64;
+  const int j = blockIdx.x * COMBINE_COLS + lane;
+  float acc = 0.0f;
+  if (j < TC)
+    for (int k = wave; k < num_rollouts; k += NW)
+      acc += weights_d[k] * v_d[(size_t)k * TC + j];
+  part_s[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && j < TC)
+  {
+    float tot = part_s[0][lane];
+#pragma unroll
+    for (int w = 1; w < NW; w++)
+      tot += part_s[w][lane];
+    mean_out_d[j] = tot / stats_d[1];
+  }
+}
+
+/**
  * u*[t][c] = sum_k (w_k / eta) v[k][t][c] for samples in HBM (v: [K][T][C], reference layout).
  * reference: weightedReductionKernel mppi_common.cu:710-737.  MI355X mapping: one block per chunk of rollouts reads its
  * rows fully coalesced (a row is contiguous), accumulates T*C columns in registers per thread, and merges chunks with

@@ -152,6 +152,17 @@ int oracle_ar_coor_transform(void* h, float x, float y, float* uvw)
   c->coorTransform(x, y, uvw, uvw + 1, uvw + 2);
   return 0;
 }
+void oracle_set_colored_mppi_params(void* h, float gamma, float r_exp, const float* leash_dist, int leash_active, int leash_jump)
+{
+  auto* c = (Controller*)h;
+  c->tsallis_gamma = gamma;
+  c->tsallis_r = r_exp;
+  c->leash_active = leash_active != 0;
+  c->leash_jump = leash_jump;
+  c->leash_dist.assign(c->dyn->S, 0.0f);
+  if (leash_dist)
+    c->leash_dist.assign(leash_dist, leash_dist + c->dyn->S);
+}
 void oracle_set_control_ranges(void* h, const float* lo_hi)
 {
   auto* c = (Controller*)h;

@@ -546,6 +546,12 @@ struct Controller
     slide_scale.assign(dyn->C, 0.0f);
   }
 
+  /* ColoredMPPI options (colored_mppi_controller.cuh:18-22, 159-193) */
+  float tsallis_gamma = 0.0f, tsallis_r = 0.0f;
+  bool leash_active = false;
+  int leash_jump = 1;
+  std::vector<float> leash_dist;
+
   /**
    * One pass of the optimisation-loop body for all D systems: sample shaping, rollout, baseline, normExp, normaliser,
    * free energy, weighted reduction.  mean: [D][T][C] in, u_new: [D][T][C] out.
@@ -560,8 +566,17 @@ struct Controller
     {
       float* wd = &w[(size_t)d * K];
       stats.baseline[d] = computeBaselineCost(wd, K);
-      /* mppi_controller.cu:201: launchNormExpKernel(..., 1.0 / lambda, ...): double 1.0/lambda narrowed to float */
-      normExpTransform(wd, K, (float)(1.0 / lambda), stats.baseline[d]);
+      if (tsallis_gamma != 0.0f && tsallis_r != 0.0f)
+      {  // ColoredMPPI: core/mppi_common.cu:968-985 TsallisTransform (colored_mppi_controller.cu:198-206); expf/logf -> det::
+        for (int i = 0; i < K; i++)
+        {
+          const float cost_dif = wd[i] - stats.baseline[d];
+          wd[i] = cost_dif < tsallis_gamma ? det::exp(det::log(1.0f - cost_dif / tsallis_gamma) / (tsallis_r - 1.0f)) : 0.0f;
+        }
+      }
+      else
+        /* mppi_controller.cu:201: launchNormExpKernel(..., 1.0 / lambda, ...): double 1.0/lambda narrowed to float */
+        normExpTransform(wd, K, (float)(1.0 / lambda), stats.baseline[d]);
       stats.normalizer[d] = computeNormalizer(wd, K);
       computeFreeEnergy(stats.free_energy[d], stats.free_energy_var[d], stats.free_energy_mod[d], wd, K,
                         stats.baseline[d], lambda);
@@ -592,10 +607,25 @@ struct Controller
    * one: eps here is its time-domain output, [num_iters][K][T][C]), then smoothing, state trajectory, and ONLY control
    * channel 1 clamped to its range (:232-237; the enforceConstraints call is commented out there).
    */
-  void coloredComputeControl(const float* x0, int stride, const float* eps)
+  void coloredComputeControl(const float* x0_true, int stride, const float* eps)
   {
-    const int C = dyn->C;
+    const int C = dyn->C, S = dyn->S;
     std::vector<float> u_new((size_t)T * C);
+    // state leash (colored_mppi_controller.cu:150-156; Dynamics::enforceLeash dynamics.cuh:448-466, base rule)
+    std::vector<float> local_state(x0_true, x0_true + S);
+    if (leash_active)
+    {
+      const float* nominal = &state_traj[(size_t)leash_jump * S];
+      for (int i = 0; i < S; i++)
+      {
+        const float diff = fabsf(nominal[i] - x0_true[i]);
+        if (leash_dist[i] < diff)
+          local_state[i] = x0_true[i] + fminf(fmaxf(nominal[i] - x0_true[i], -leash_dist[i]), leash_dist[i]);
+        else
+          local_state[i] = nominal[i];
+      }
+    }
+    const float* x0 = local_state.data();
     for (int it = 0; it < num_iters; it++)
     {
       iterate(x0, control.data(), eps + (size_t)it * K * T * C, stride, it, u_new.data());

@@ -50,6 +50,7 @@ def lib():
         L.oracle_ar_cost_term.restype = C.c_float
         L.oracle_ar_cost_term.argtypes = [C.c_void_p, C.c_int, _f32p, C.POINTER(C.c_int)]
         L.oracle_ar_coor_transform.argtypes = [C.c_void_p, C.c_float, C.c_float, _f32p]
+        L.oracle_set_colored_mppi_params.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int]
         L.oracle_set_control_ranges.argtypes = [C.c_void_p, _f32p]
         L.oracle_set_control_deadband.argtypes = [C.c_void_p, _f32p]
         L.oracle_set_sampler.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, C.c_int]
@@ -171,6 +172,10 @@ class Oracle:
         out = np.empty(3, np.float32)
         assert self.L.oracle_ar_coor_transform(self.h, x, y, out) == 0
         return out
+
+    def set_colored_mppi_params(self, gamma=0.0, r_exp=0.0, leash_dist=None, leash_active=False, leash_jump=1):
+        p = None if leash_dist is None else _f32(leash_dist).reshape(-1).ctypes.data
+        self.L.oracle_set_colored_mppi_params(self.h, gamma, r_exp, p, int(leash_active), leash_jump)
 
     def set_control_ranges(self, lo_hi):
         self.L.oracle_set_control_ranges(self.h, _f32(lo_hi).reshape(-1))

@@ -192,6 +192,62 @@ def test_colored_rollout_costs_bit_exact(gpu, mk, kw):
     assert ulp_diff(g, c).max() == 0
 
 
+def test_oracle_tsallis_weights_against_float64():
+    """core/mppi_common.cu:968-985: w = (S - rho < gamma) ? exp(log(1 - (S - rho)/gamma) / (r - 1)) : 0"""
+    cfg = cartpole_cfg(K=512, T=20, soft=True)
+    orc = make_oracle(cfg)
+    orc.set_colored_mppi_params(gamma=60.0, r_exp=1.5)
+    eps = np.random.default_rng(3).standard_normal((512, 20, 1)).astype(np.float32)
+    orc.iterate(cfg["x0"], np.zeros((20, 1), np.float32), eps)
+    S = orc.costs()[0].astype(np.float64)
+    d = S - S.min()
+    want = np.where(d < 60.0, np.exp(np.log(np.maximum(1.0 - d / 60.0, 1e-300)) / 0.5), 0.0)
+    np.testing.assert_allclose(orc.weights()[0], want, rtol=1e-4, atol=1e-7)  # fp32 costs ~2e4: 1 - d/gamma loses digits near the cut-off
+    assert (want == 0).sum() > 0 and (want > 0.5).sum() > 1, "the case should have cut-off and heavy rollouts"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tsallis,leash", [(True, False), (False, True), (True, True)])
+def test_colored_mppi_tsallis_and_leash_parity(gpu, tsallis, leash):
+    """ColoredMPPI's Tsallis weights (global baseline -> weights -> weighted mean of the samples in HBM) and state leash
+    against the oracle in closed loop; reference: colored_mppi_controller.cu:150-156, 198-206"""
+    cfg = _colored_cartpole(K=2048, T=60)
+    eng, orc = make_engine(cfg), make_oracle(cfg)
+    exps, decay, fmin = cfg["colored"]
+    kw = dict(gamma=400.0 if tsallis else 0.0, r_exp=1.7 if tsallis else 0.0,
+              state_leash_dist=np.array([0.05, 0.2, 0.02, 0.3], np.float32), leash_active=leash, leash_jump=1)
+    eng.setColoredMPPIParams(**kw)
+    orc.set_colored_mppi_params(kw["gamma"], kw["r_exp"], kw["state_leash_dist"], leash, 1)
+    x = cfg["x0"].copy()
+    for i in range(4):
+        z = host_spectrum(1, cfg["K"], cfg["T"], 1, seed=40 + i)
+        eng.injectNoise(z)
+        eng.computeControl(x, 1)
+        orc.colored_compute_control(x, 1, z, exps, decay, fmin)
+        assert np.abs(eng.getControlSeq() - orc.control()).max() <= 1e-5
+        assert np.abs(eng.getTargetStateSeq() - orc.state_traj()).max() <= 1e-4
+        st, so = eng.getStats().real_sys, orc.stats()
+        assert st.baseline == so["baseline"][0] or i > 0
+        assert abs(st.normalizer - so["normalizer"][0]) <= 1e-5 * so["normalizer"][0]
+        # the measured state drifts away from the model's prediction: the leash has something to do
+        x, _ = orc.model_step(x, orc.control()[0])
+        x = x + np.array([0.2, -0.4, 0.1, 0.5], np.float32)
+        eng.slideControlSequence(1)
+        orc.vanilla_slide(1)
+
+
+@pytest.mark.gpu
+def test_colored_mppi_params_argument_checks(gpu):
+    eng = make_engine(_colored_cartpole(K=256, T=20))
+    with pytest.raises(m.MPPIError) as e:
+        eng.setColoredMPPIParams(gamma=10.0, r_exp=1.0)  # r = 1: division by zero in the exponent
+    assert e.value.status == 1
+    van = m.VanillaMPPIController("cartpole", 128, 10, 0.02, 1.0)
+    with pytest.raises(m.MPPIError) as e:
+        van._check(van._lib.mppi_set_colored_mppi_params(van._h, 1.0, 2.0, None, 0, 1))
+    assert e.value.status == 7
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mk", [_colored_cartpole, _colored_bicycle])
 def test_colored_mppi_compute_control_parity(gpu, mk):

@@ -234,3 +234,24 @@ def test_full_size_properties(gpu):
     eng2.uploadState(cfg["x0"])
     eng2.optimize(1)
     assert np.array_equal(eng2.getSampledCostSeq()[0], costs)
+
+
+def test_choose_appropriate_kernel(gpu):
+    """reference: VanillaMPPI::chooseAppropriateKernel (mppi_controller.cu:44-143) — both structures timed, the faster kept,
+    results unchanged (the structures are bit-identical) and the noise stream not advanced by the trial launches"""
+    cfg = cartpole_cfg(K=16384, T=100, soft=True)
+    ref = make_engine(cfg)
+    ref.uploadState(cfg["x0"])
+    ref.optimize(2)
+    eng = make_engine(cfg)
+    eng.uploadState(cfg["x0"])
+    v, fused_ms, pipe_ms = eng.chooseAppropriateKernel(5)
+    assert v in (1, 2) and np.isfinite(fused_ms) and np.isfinite(pipe_ms)
+    assert (v == 2) == (pipe_ms < fused_ms)
+    eng.optimize(2)
+    assert np.array_equal(eng.getOptimalControlSeq(), ref.getOptimalControlSeq())
+    # a configuration with one structure only: block shape (64, 4) of the LDS contract variant
+    one = make_engine(cartpole_cfg(K=512, T=30), block_x=64, block_y=4)
+    one.uploadState(cfg["x0"])
+    v, fused_ms, pipe_ms = one.chooseAppropriateKernel(2)
+    assert v == 1 and np.isinf(pipe_ms)
