@@ -189,6 +189,12 @@ mppi_status mppi_set_sampler_params(mppi_handle h, const mppi_gaussian_params* p
 /** ColoredNoiseParamsImpl (sampling_distributions/colored_noise/colored_noise.cuh:45-73): exponents[C] (0 = white),
  *  offset_decay_rate, fmin.  Only for handles created with MPPI_CONTROLLER_COLORED; std_dev etc. come from
  *  mppi_set_sampler_params as for the Gaussian sampler (ColoredNoiseParams extends GaussianParams). */
+/**
+ * time_specific_std_dev (GaussianTimeVaryingStdDevParams, sampling_distributions/gaussian/gaussian.cuh:64-95; used by
+ * setGaussianControls, gaussian.cu:21-43, and by the likelihood-ratio cost, gaussian.cu:488-493): std_dev[D][T][C], one sigma per
+ * distribution, time step and control instead of mppi_gaussian_params.std_dev.  NULL switches back.
+ */
+mppi_status mppi_set_time_specific_std_dev(mppi_handle h, const float* std_dev);
 mppi_status mppi_set_colored_noise_params(mppi_handle h, const float* exponents, float offset_decay_rate, float fmin);
 /** Dynamics::setControlRanges (dynamics/dynamics.cu:19-36); lo_hi = [C][2] */
 /**

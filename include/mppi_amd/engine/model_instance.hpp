@@ -88,6 +88,8 @@ struct ModelBase
     err = "model has no blob named '" + name + "'";
     return MPPI_ERR_INVALID_ARG;
   }
+  /** time_specific_std_dev: sigma[D][T][C] table in device memory (owned by the engine), nullptr switches it off */
+  virtual void setTimeSpecificStdDev(const float* table_d) = 0;
   /** colored-noise sampler parameters (ColoredNoiseParamsImpl, colored_noise.cuh:45-73); default: Gaussian sampler */
   virtual mppi_status setColoredNoiseParams(const float* exponents, float offset_decay_rate, float fmin)
   {
@@ -736,6 +738,11 @@ struct ModelT : ModelBase
     smp.params_.sum_strides = p->sum_strides;
   }
 
+  void setTimeSpecificStdDev(const float* table_d) override
+  {
+    smp.std_dev_time_d_ = table_d;
+    smp.params_.time_specific_std_dev = table_d != nullptr;
+  }
   mppi_status setColoredNoiseParams(const float* exponents, float offset_decay_rate, float fmin) override
   {
     if constexpr (SAMPLING_T::COLORED)

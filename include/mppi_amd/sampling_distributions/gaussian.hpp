@@ -104,6 +104,10 @@ public:
   uint32_t generation_ = 0;          ///< number of generateSamples calls so far (cuRAND's advancing offset)
   int optimization_stride_ = 0;
   float std_dev_decayed_[CONTROL_DIM * 2];  ///< std_dev_decay^iteration * std_dev  (gaussian.cu:421, :86)
+  /** time_specific_std_dev (gaussian.cu:21-43; GaussianTimeVaryingStdDevParams, gaussian.cuh:64-95): sigma[d][t][c] in device
+   *  memory, undecayed; nullptr: one sigma per distribution and control (params_.std_dev) */
+  const float* std_dev_time_d_ = nullptr;
+  float decay_now_ = 1.0f;                  ///< std_dev_decay^iteration
   int rollout_offset_ = 0;           ///< global index of this GPU's first rollout
   int num_rollouts_global_ = 1;      ///< K over all GPUs
   /* thread mapping, set per thread by kernels whose blockDim.x is not "one thread per rollout" (replicated lanes):
@@ -165,6 +169,7 @@ public:
       decay *= params_.std_dev_decay;
     for (int i = 0; i < CONTROL_DIM * 2; i++)
       std_dev_decayed_[i] = decay * params_.std_dev[i];
+    decay_now_ = decay;
     optimization_stride_ = optimization_stride;
   }
 
@@ -290,6 +295,32 @@ public:
     }
   }
 
+  /** sigma of (distribution d, step t, control j): the per-step table when time_specific_std_dev is on (a wave-uniform
+   *  branch; like the means, the table is only written between launches), else the per-distribution value.  DECAYED: times
+   *  std_dev_decay^iteration, as setGaussianControls applies it (gaussian.cu:84-87); the likelihood-ratio cost reads the
+   *  undecayed value (gaussian.cu:488-493). */
+  template <bool LANE_D, bool DECAYED>
+  __device__ inline float sigmaValue(const int d, const int t, const int j) const
+  {
+    if (std_dev_time_d_)
+    {
+      const_float_ptr s0 = (const_float_ptr)(std_dev_time_d_ + (size_t)t * CONTROL_DIM);
+      float v;
+      if constexpr (LANE_D)
+      {
+        const_float_ptr s1 = s0 + (params_.num_distributions > 1 ? params_.num_timesteps * CONTROL_DIM : 0);
+        const float a = s0[j], b = s1[j];
+        v = d == 0 ? a : b;
+      }
+      else
+      {
+        v = s0[(size_t)params_.num_timesteps * d * CONTROL_DIM + j];
+      }
+      return DECAYED ? decay_now_ * v : v;
+    }
+    return DECAYED ? distValue<LANE_D>(std_dev_decayed_, d, j) : distValue<LANE_D>(params_.std_dev, d, j);
+  }
+
   /** the setGaussianControls rule (gaussian.cu:99-127), branch-free */
   __device__ inline float shapeSample(float m, float sd, float e, bool use_mean, bool pure) const
   {
@@ -317,7 +348,7 @@ public:
     const bool pure = isPureNoise(sample_index);
 #pragma unroll
     for (int i = 0; i < CONTROL_DIM; i++)
-      control[i] = shapeSample(meanValue<LANE_D>(d, t, i), distValue<LANE_D>(std_dev_decayed_, d, i), eps[i], use_mean,
+      control[i] = shapeSample(meanValue<LANE_D>(d, t, i), sigmaValue<LANE_D, true>(d, t, i), eps[i], use_mean,
                                pure);
   }
 
@@ -349,7 +380,7 @@ public:
         mppi::rng::normal4(seed_, generation_, 0u, (uint32_t)(sample_index + rollout_offset_), (uint32_t)(e >> 2), z);
         eps = (e & 3) == 0 ? z[0] : ((e & 3) == 1 ? z[1] : ((e & 3) == 2 ? z[2] : z[3]));
       }
-      control[i] = shapeSample(mean[i], std_dev_decayed_[CONTROL_DIM * d + i], eps, use_mean, pure);
+      control[i] = shapeSample(mean[i], sigmaValue<false, true>(d, t, i), eps, use_mean, pure);
     }
   }
 
@@ -370,7 +401,7 @@ public:
     const bool pure = isPureNoise(sample_index);
     for (int i = thread_index; i < CONTROL_DIM; i += block_size)
     {
-      control[i] = shapeSample(meanValue<LANE_D>(d, t, i), distValue<LANE_D>(std_dev_decayed_, d, i), row[i], use_mean,
+      control[i] = shapeSample(meanValue<LANE_D>(d, t, i), sigmaValue<LANE_D, true>(d, t, i), row[i], use_mean,
                                pure);
     }
   }
@@ -427,7 +458,7 @@ public:
           const int j = i * W + l;
           const float mu = meanValue<LANE_D>(d, t, j);  // unconditional: a wave-uniform (scalar) load
           const float mean_i = pure ? 0.0f : mu;
-          const float sd = distValue<LANE_D>(params_.std_dev, d, j);
+          const float sd = sigmaValue<LANE_D, false>(d, t, j);
           lane[l] += control_cost_coeff[j] * mean_i * (mean_i - 2.0f * u[j]) / (sd * sd);
         }
       }
@@ -442,7 +473,7 @@ public:
       {
         const float mu = meanValue<LANE_D>(d, t, i);  // unconditional: a wave-uniform (scalar) load
         const float mean_i = pure ? 0.0f : mu;
-        const float sd = distValue<LANE_D>(params_.std_dev, d, i);
+        const float sd = sigmaValue<LANE_D, false>(d, t, i);
         cost += control_cost_coeff[i] * mean_i * (mean_i - 2.0f * u[i]) / (sd * sd);
       }
     }

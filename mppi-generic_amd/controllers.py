@@ -262,6 +262,15 @@ class MPPIController:
                                pure_noise_trajectories_percentage, std_dev_decay, sum_strides)
         self._check(self._lib.mppi_set_sampler_params(self._h, C.byref(p)))
 
+    def setTimeSpecificStdDev(self, std_dev):
+        """std_dev [D][T][C] (or [T][C] for one distribution), None switches back to one sigma per control"""
+        if std_dev is None:
+            self._check(self._lib.mppi_set_time_specific_std_dev(self._h, None))
+            return
+        a = _f32(std_dev).reshape(-1)
+        assert a.size == self.num_systems * self.num_timesteps * self.CONTROL_DIM, a.size
+        self._check(self._lib.mppi_set_time_specific_std_dev(self._h, a.ctypes.data))
+
     def setModelBlob(self, name, array):
         """bulk model data (NN weights, costmap) — see mppi_set_model_blob"""
         a = _f32(array)

@@ -100,6 +100,7 @@ struct mppi_handle_s
   /* ColoredMPPI options (controllers/ColoredMPPI/colored_mppi_controller.cuh:18-22, 159-193): Tsallis weights and state leash */
   float tsallis_gamma = 0.0f, tsallis_r = 0.0f;
   float* tsallis_weights_d = nullptr;  // [K_local]
+  float* std_dev_time_d = nullptr;     // [D][T][C] time_specific_std_dev table
   bool leash_active = false;
   int leash_jump = 1;
   std::vector<float> leash_dist;       // [S]
@@ -163,6 +164,11 @@ struct mppi_handle_s
   int* cand_strides_d = nullptr;
   int cand_capacity = 0;
 
+  /* rocRAND host API (MPPI_NOISE_ROCRAND_HOST; librocrand.so loaded lazily): the reference's structure — a library
+   * generator fills an eps buffer in HBM (curandGenerateNormal, sampling_distributions/gaussian/gaussian.cu:380-394) */
+  void* rocrand_lib = nullptr;
+  void* rocrand_gen = nullptr;
+  float* rocrand_eps_d = nullptr;  // [K_local][noise floats per rollout], refilled before every rollout launch
   /* RCCL (loaded lazily) */
   void* rccl_lib = nullptr;
   void* comm = nullptr;
@@ -179,6 +185,20 @@ struct mppi_handle_s
   bool exchange_failed = false;  // a merge kernel gave up waiting for a peer (stats[6] mark), sticky until mppi_p2p_connect
   unsigned xseq = 0;  // exchange sequence number: flags carry it, its parity selects the mailbox half
 };
+
+namespace
+{
+struct RocrandApi
+{
+  int (*create)(void**, int) = nullptr;
+  int (*destroy)(void*) = nullptr;
+  int (*set_seed)(void*, unsigned long long) = nullptr;
+  int (*set_offset)(void*, unsigned long long) = nullptr;
+  int (*set_stream)(void*, hipStream_t) = nullptr;
+  int (*normal)(void*, float*, size_t, float, float) = nullptr;
+};
+RocrandApi g_rocrand;
+}  // namespace
 
 /** the multi-rank path (local merge -> all-gather -> global merge) runs for world_size > 1, and for a world of ONE when
  *  the caller asks for it (cfg.force_exchange): that exercises the RCCL plumbing on a single GPU */
@@ -324,6 +344,9 @@ static void freeAll(mppi_handle h)
 {
   // x0_d, mean_d, history_d and ctrl_out_d, state_out_d, output_out_d, stats_d are slices of in_block_d / out_block_d
   h->x0_d = h->mean_d = h->history_d = h->ctrl_out_d = h->state_out_d = h->output_out_d = h->stats_d = nullptr;
+  if (h->rocrand_gen && g_rocrand.destroy)
+    (void)g_rocrand.destroy(h->rocrand_gen);
+  h->rocrand_gen = nullptr;
   for (int p = 0; p < 16; p++)
   {
     if (h->peer_opened[p] && h->peer_mbox[p])
@@ -353,7 +376,7 @@ static void freeAll(mppi_handle h)
   h->step_u_d = nullptr;  // slice of the step_x_d block
   float** bufs[] = { &h->in_block_d, &h->out_block_d, &h->costs_d,   &h->partials_d,  &h->send_d,     &h->recv_d,
                      &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->gather_tmp_d, &h->rows_d,
-                     &h->tsallis_weights_d };
+                     &h->tsallis_weights_d, &h->rocrand_eps_d, &h->std_dev_time_d };
   for (float** b : bufs)
   {
     if (*b)
@@ -524,8 +547,8 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   h->PS = kernels::partialStride(cfg->num_timesteps, h->C);
   h->noise_source = cfg->noise_source;
   h->noise_floats = h->model->noiseFloatsPerRollout(cfg->num_timesteps);
-  if (h->noise_source == MPPI_NOISE_ROCRAND_HOST)
-    return fail(nullptr, MPPI_ERR_UNSUPPORTED, "mppi_create: MPPI_NOISE_ROCRAND_HOST is not available in this build");
+  if (h->noise_source < 0 || h->noise_source > MPPI_NOISE_ROCRAND_HOST)
+    return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_create: unknown noise_source");
 
   HIP_TRY(nullptr, hipSetDevice(cfg->device));
   if (cfg->stream)
@@ -712,6 +735,28 @@ mppi_status mppi_set_sampler_params(mppi_handle h, const mppi_gaussian_params* p
   h->model->setSamplerParams(p, h->D);
   return MPPI_OK;
 }
+mppi_status mppi_set_time_specific_std_dev(mppi_handle h, const float* std_dev)
+{
+  CHECK_HANDLE(h);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // earlier launches may still read the table
+  if (!std_dev)
+  {
+    h->model->setTimeSpecificStdDev(nullptr);
+    return MPPI_OK;
+  }
+  const size_t n = (size_t)h->D * h->TC;
+  for (size_t i = 0; i < n; i++)
+    if (!(std_dev[i] > 0.0f))
+      return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_time_specific_std_dev: every sigma[d][t][c] must be > 0");
+  if (!h->std_dev_time_d)
+    HIP_TRY(h, hipMalloc((void**)&h->std_dev_time_d, n * sizeof(float)));
+  HIP_TRY(h, hipMemcpyAsync(h->std_dev_time_d, std_dev, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->model->setTimeSpecificStdDev(h->std_dev_time_d);
+  return MPPI_OK;
+}
+
 mppi_status mppi_set_colored_noise_params(mppi_handle h, const float* exponents, float offset_decay_rate, float fmin)
 {
   CHECK_HANDLE(h);
@@ -981,6 +1026,49 @@ mppi_status mppi_set_seed(mppi_handle h, uint64_t seed)
   return MPPI_OK;
 }
 
+/* ---------------------------------------------------------------- rocRAND host API ------------------------------- */
+
+/** one rocrand_generate_normal per rollout launch into rocrand_eps_d: PHILOX4_32_10, seeded with the handle's seed, the
+ *  offset advanced so that rank r of a sharded problem and every later generation draw disjoint stretches of the stream.
+ *  (Statistically equivalent to the in-kernel Philox mode, not bit-identical: rocRAND orders its counter / Box-Muller
+ *  differently — the reference's own sampler tests are statistical too, tests/sampling_distributions/.) */
+static mppi_status rocrandFill(mppi_handle h)
+{
+  const size_t n = ((size_t)h->K_local * h->noise_floats + 1) & ~(size_t)1;  // the generator wants an even count
+  if (!h->rocrand_lib)
+  {
+    h->rocrand_lib = dlopen("librocrand.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h->rocrand_lib)
+      h->rocrand_lib = dlopen("librocrand.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h->rocrand_lib)
+      return fail(h, MPPI_ERR_UNSUPPORTED, std::string("MPPI_NOISE_ROCRAND_HOST: cannot load librocrand.so: ") + dlerror());
+    g_rocrand.create = (int (*)(void**, int))dlsym(h->rocrand_lib, "rocrand_create_generator");
+    g_rocrand.destroy = (int (*)(void*))dlsym(h->rocrand_lib, "rocrand_destroy_generator");
+    g_rocrand.set_seed = (int (*)(void*, unsigned long long))dlsym(h->rocrand_lib, "rocrand_set_seed");
+    g_rocrand.set_offset = (int (*)(void*, unsigned long long))dlsym(h->rocrand_lib, "rocrand_set_offset");
+    g_rocrand.set_stream = (int (*)(void*, hipStream_t))dlsym(h->rocrand_lib, "rocrand_set_stream");
+    g_rocrand.normal = (int (*)(void*, float*, size_t, float, float))dlsym(h->rocrand_lib, "rocrand_generate_normal");
+    if (!g_rocrand.create || !g_rocrand.destroy || !g_rocrand.set_seed || !g_rocrand.set_offset || !g_rocrand.set_stream ||
+        !g_rocrand.normal)
+      return fail(h, MPPI_ERR_UNSUPPORTED, "MPPI_NOISE_ROCRAND_HOST: librocrand.so lacks an expected entry point");
+  }
+  if (!h->rocrand_gen)
+  {
+    if (g_rocrand.create(&h->rocrand_gen, /*ROCRAND_RNG_PSEUDO_PHILOX4_32_10*/ 404) != 0 ||
+        g_rocrand.set_stream(h->rocrand_gen, h->stream) != 0)
+      return fail(h, MPPI_ERR_HIP, "rocrand_create_generator / rocrand_set_stream failed");
+  }
+  if (!h->rocrand_eps_d)
+    HIP_TRY(h, hipMalloc((void**)&h->rocrand_eps_d, n * sizeof(float)));
+  // stretch of the stream for (generation, rank): offsets count Philox outputs; a normal consumes one 32-bit output
+  const unsigned long long per_gen = (unsigned long long)n * (unsigned long long)h->cfg.world_size;
+  const unsigned long long offset = (unsigned long long)h->generation * per_gen + (unsigned long long)h->cfg.rank * n;
+  if (g_rocrand.set_seed(h->rocrand_gen, (unsigned long long)h->cfg.seed) != 0 ||
+      g_rocrand.set_offset(h->rocrand_gen, offset) != 0 || g_rocrand.normal(h->rocrand_gen, h->rocrand_eps_d, n, 0.0f, 1.0f) != 0)
+    return fail(h, MPPI_ERR_HIP, "rocrand_generate_normal failed");
+  return MPPI_OK;
+}
+
 /* ---------------------------------------------------------------- internals -------------------------------------- */
 static mppi_status launchCombine(mppi_handle h, const float* records, int num_records, int finalize, float* record_out,
                                  int k_total, bool world_major = false, const unsigned* wait_flags = nullptr,
@@ -1037,6 +1125,11 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
     if (!h->eps_d || h->n_eps_iters <= 0)
       return fail(h, MPPI_ERR_STATE, "noise source is MPPI_NOISE_INJECTED but no noise has been injected");
     s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * h->K_local * h->noise_floats;
+  }
+  else if (h->noise_source == MPPI_NOISE_ROCRAND_HOST)
+  {
+    MPPI_TRY(rocrandFill(h));
+    s.eps_d = h->rocrand_eps_d;
   }
   s.control_samples_d = h->samples_d;
   s.seed = h->cfg.seed;
@@ -1628,6 +1721,9 @@ static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, in
       return fail(h, MPPI_ERR_STATE, "noise source is MPPI_NOISE_INJECTED but no noise has been injected");
     s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * h->K_local * h->noise_floats;
   }
+  else if (h->noise_source == MPPI_NOISE_ROCRAND_HOST)
+    return fail(h, MPPI_ERR_UNSUPPORTED, "this call draws through the sampler's random-access path: use the Philox or the "
+                                         "injected noise source (MPPI_NOISE_ROCRAND_HOST fills the rollout kernel's eps buffer only)");
   s.control_samples_d = nullptr;
   s.seed = h->cfg.seed;
   s.generation = h->generation;
@@ -1965,6 +2061,9 @@ mppi_status mppi_sample_noise(mppi_handle h, int optimization_stride, float* eps
       return fail(h, MPPI_ERR_STATE, "noise source is MPPI_NOISE_INJECTED but no noise has been injected");
     s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * h->K_local * h->noise_floats;
   }
+  else if (h->noise_source == MPPI_NOISE_ROCRAND_HOST)
+    return fail(h, MPPI_ERR_UNSUPPORTED, "this call draws through the sampler's random-access path: use the Philox or the "
+                                         "injected noise source (MPPI_NOISE_ROCRAND_HOST fills the rollout kernel's eps buffer only)");
   s.control_samples_d = nullptr;
   s.seed = h->cfg.seed;
   s.generation = h->generation;

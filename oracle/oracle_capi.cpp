@@ -190,6 +190,14 @@ void oracle_set_sampler(void* h, const float* std_dev /*[D][C]*/, const float* c
   c->smp.std_dev_decay = std_dev_decay;
   c->smp.sum_strides = sum_strides;
 }
+void oracle_set_time_specific_std_dev(void* h, const float* std_dev /*[D][T][C] or NULL*/)
+{
+  auto* c = (Controller*)h;
+  if (std_dev)
+    c->smp.std_dev_time.assign(std_dev, std_dev + (size_t)c->smp.D * c->smp.T * c->smp.C);
+  else
+    c->smp.std_dev_time.clear();
+}
 void oracle_set_controller_params(void* h, float nominal_threshold, const float* slide_scale)
 {
   auto* c = (Controller*)h;

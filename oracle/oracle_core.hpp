@@ -151,6 +151,7 @@ struct GaussianSampler
 {
   int C = 0, D = 1, K = 0, T = 0;
   std::vector<float> std_dev;            /* [D][C]  (time_specific_std_dev == false) */
+  std::vector<float> std_dev_time;       /* [D][T][C] when time_specific_std_dev is on (gaussian.cuh:64-95), else empty */
   std::vector<float> control_cost_coeff; /* [C] */
   float pure_noise_trajectories_percentage = 0.01f;
   float std_dev_decay = 1.0f;
@@ -188,7 +189,8 @@ struct GaussianSampler
             const size_t vi = (((size_t)d * K + k) * T + t) * C + c;
             const float e = eps[((size_t)k * T + t) * C + c];
             const float m = mean[((size_t)d * T + t) * C + c];
-            const float sd = decay * std_dev[(size_t)d * C + c];
+            /* gaussian.cu:21-43: the std-dev index carries the time step when time_specific_std_dev is set */
+            const float sd = decay * (std_dev_time.empty() ? std_dev[(size_t)d * C + c] : std_dev_time[((size_t)d * T + t) * C + c]);
             if (k == 0 || t < optimization_stride)
               v[vi] = m;
             else if (isPureNoise(k))
@@ -213,9 +215,10 @@ struct GaussianSampler
    * (blockDim.y == 1): the CONTROL_DIM % 4 / % 2 / scalar branches accumulate per vector lane and then add the lanes.
    */
   float likelihoodRatioCost(const float* u, const float* mean_dt /* mean[d][t][:] */, int k, int d, float lambda,
-                            float alpha) const
+                            float alpha, int t = 0) const
   {
-    const float* sd = &std_dev[(size_t)d * C];
+    /* gaussian.cu:488-493: std_dev[(d * T + t) * C] when time_specific_std_dev */
+    const float* sd = std_dev_time.empty() ? &std_dev[(size_t)d * C] : &std_dev_time[((size_t)d * T + t) * C];
     const bool pure = isPureNoise(k);
     float cost = 0.0f;
     const int width = (C % 4 == 0) ? 4 : ((C % 2 == 0) ? 2 : 1);
@@ -290,7 +293,7 @@ inline void rolloutCosts(Dynamics& dyn, Cost& cost, const GaussianSampler& smp, 
         dyn.step(x, xn, xdot.data(), u.data(), y.data(), theta.data(), t, dt);
         /* mppi_common.cu:122-124: running += (runningCost + likelihoodRatioCost) */
         running += cost.computeRunningCost(y.data(), u.data(), t, &crash) +
-                   smp.likelihoodRatioCost(u.data(), &mean[((size_t)d * T + t) * C], k, d, lambda, alpha);
+                   smp.likelihoodRatioCost(u.data(), &mean[((size_t)d * T + t) * C], k, d, lambda, alpha, t);
         std::swap(x, xn);
       }
       /* mppi_common.cu:144 and computeAndSaveCost :843-853: running/T + terminal/T */

@@ -148,7 +148,7 @@ inline void rmppiRolloutCosts(Dynamics& dyn, Cost& cost, const GaussianSampler& 
           vk[z][i] = u[z][i];
         dyn.step(x, xn, xdot[z].data(), u[z].data(), y[z].data(), theta[z].data(), t, dt);
         const float curr_cost = cost.computeRunningCost(y[z].data(), u[z].data(), t, &crash[z]);
-        const float lr = smp.likelihoodRatioCost(u[z].data(), &mean[((size_t)z * T + t) * C], k, z, lambda, alpha);
+        const float lr = smp.likelihoodRatioCost(u[z].data(), &mean[((size_t)z * T + t) * C], k, z, lambda, alpha, t);
         if (z == NOM)
         {
           acc_a[z] += curr_cost;
@@ -214,7 +214,7 @@ inline void initEvalCosts(Dynamics& dyn, Cost& cost, const GaussianSampler& smp,
       dyn.enforceConstraints(x, u.data());
       dyn.step(x, xn, xdot.data(), u.data(), y.data(), theta.data(), t, dt);
       running += cost.computeRunningCost(y.data(), u.data(), t, &crash) +
-                 smp.likelihoodRatioCost(u.data(), &mean0[(size_t)t * C], g, 0, lambda, alpha);
+                 smp.likelihoodRatioCost(u.data(), &mean0[(size_t)t * C], g, 0, lambda, alpha, t);
       std::swap(x, xn);
     }
     costs[g] = running / (float)T + cost.terminalCost(y.data()) / (float)T;

@@ -54,6 +54,7 @@ def lib():
         L.oracle_set_control_ranges.argtypes = [C.c_void_p, _f32p]
         L.oracle_set_control_deadband.argtypes = [C.c_void_p, _f32p]
         L.oracle_set_sampler.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, C.c_int]
+        L.oracle_set_time_specific_std_dev.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_set_controller_params.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
         L.oracle_set_gaussian_controls.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, _f32p]
         L.oracle_rollout_costs.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_int]
@@ -189,6 +190,11 @@ class Oracle:
             sd = np.concatenate([sd, sd])
         cc = _f32(np.zeros(self.C) if control_cost_coeff is None else control_cost_coeff).reshape(-1)
         self.L.oracle_set_sampler(self.h, sd, cc, pure_noise_pct, std_dev_decay, sum_strides)
+
+    def set_time_specific_std_dev(self, std_dev):
+        """std_dev [D][T][C] or None (gaussian.cuh:64-95 GaussianTimeVaryingStdDevParams)"""
+        p = None if std_dev is None else _f32(std_dev).reshape(-1).ctypes.data
+        self.L.oracle_set_time_specific_std_dev(self.h, p)
 
     def set_controller_params(self, nominal_threshold=20.0, slide_scale=None):
         p = None if slide_scale is None else _f32(slide_scale).ctypes.data

@@ -255,3 +255,38 @@ def test_choose_appropriate_kernel(gpu):
     one.uploadState(cfg["x0"])
     v, fused_ms, pipe_ms = one.chooseAppropriateKernel(2)
     assert v == 1 and np.isinf(pipe_ms)
+
+
+def test_rocrand_host_noise_source(gpu):
+    """MPPI_NOISE_ROCRAND_HOST: rocrand_generate_normal (PHILOX4_32_10) fills an eps buffer in HBM before every rollout launch
+    — the reference's structure (curandGenerateNormal, gaussian.cu:380-394).  Statistical checks only, like the reference's
+    own sampler tests: the stream is rocRAND's, not the in-kernel Philox order."""
+    cfg = cartpole_cfg(K=8192, T=64, soft=True)
+    eng = make_engine(cfg, noise_source=2, save_samples=True)
+    eng.uploadState(cfg["x0"])
+    eng.optimize(1)
+    v0 = eng.getSampledControls()[0].copy()
+    # sigma = 5, clamp to [-5, 5]: look at the unclamped interior through the quantiles of the standard normal
+    body = v0[1:int(0.99 * cfg["K"])]  # without the noise-free rollout 0 and the zero-mean tail (mean is 0 here anyway)
+    frac_inside = np.mean(np.abs(body) < 4.999)
+    assert abs(frac_inside - 0.6827) < 0.01  # |eps| < 1  <=>  |v| < sigma
+    assert abs(np.median(body)) < 0.05
+    assert np.all(v0[0] == 0.0)
+    eng.updateImportanceSampler(np.zeros((cfg["T"], 1), np.float32))
+    eng.uploadState(cfg["x0"])
+    eng.optimize(1)
+    v1 = eng.getSampledControls()[0]
+    assert np.mean(v1[1:100] == v0[1:100]) < 0.3  # the next generation draws a new stretch of the stream (clamped values tie)
+    # two ranks of a sharded problem draw disjoint stretches
+    r = [make_engine(cfg, noise_source=2, save_samples=True, rank=i, world_size=2) for i in range(2)]
+    for c in r:
+        c.uploadState(cfg["x0"])
+        c.iterationLocal()
+        c.synchronize()
+    a, b = r[0].getSampledControls()[0], r[1].getSampledControls()[0]
+    assert np.mean(a[1:100] == b[1:100]) < 0.3
+    # and the optimisation behaves like the Philox mode on the same problem (same baseline to a few percent)
+    ph = make_engine(cfg)
+    ph.uploadState(cfg["x0"])
+    ph.optimize(1)
+    assert abs(eng.getStats().real_sys.baseline / ph.getStats().real_sys.baseline - 1.0) < 0.05

@@ -260,3 +260,60 @@ def test_di_lds_contract_path(gpu):
     _, _, g1, c, _ = _rollout_both(cfg, eps, block_x=64, block_y=1)
     _, _, g2, _, _ = _rollout_both(cfg, eps, block_x=64, block_y=2)
     assert ulp_diff(g1, c).max() == 0 and ulp_diff(g2, c).max() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [{}, {"kernel_variant": 1}, {"block_x": 64, "block_y": 4}], ids=["pipeline", "fused", "lds-contract"])
+def test_time_specific_std_dev(gpu, kw):
+    """time_specific_std_dev (gaussian.cuh:64-95, setGaussianControls gaussian.cu:21-43, LR cost :488-493): one sigma per
+    (distribution, time step, control); costs 0 ulp against the oracle, with a non-zero likelihood-ratio coefficient and
+    std_dev_decay so that both the decayed and the raw table are read"""
+    cfg = cartpole_cfg_lr(K=1000, T=50)
+    cfg["decay"] = 0.9
+    sd = (2.0 + 3.0 * np.abs(np.sin(np.arange(cfg["T"], dtype=np.float32) * 0.37))).reshape(cfg["T"], 1)
+    eng, orc = make_engine(cfg, save_samples=True, **kw), make_oracle(cfg)
+    eng.setTimeSpecificStdDev(sd)
+    orc.set_time_specific_std_dev(sd[None])
+    mean = (0.5 * np.cos(np.arange(cfg["T"], dtype=np.float32) * 0.2)).reshape(cfg["T"], 1)
+    eps = host_noise(1, cfg["K"], cfg["T"], 1, seed=8)[0]
+    eng.updateImportanceSampler(mean)
+    eng.injectNoise(eps)
+    g = eng.rolloutCosts(cfg["x0"], 1)
+    v = orc.set_gaussian_controls(mean[None], eps, 1, 0)
+    c, vc = orc.rollout_costs(cfg["x0"], mean[None], v)
+    assert ulp_diff(g, c).max() == 0
+    assert ulp_diff(eng.getSampledControls(), vc).max() == 0
+    # second optimisation iteration: sigma * decay
+    eng2, orc2 = make_engine(dict(cfg, num_iters=2), **kw), make_oracle(dict(cfg, num_iters=2))
+    eng2.setTimeSpecificStdDev(sd)
+    orc2.set_time_specific_std_dev(sd[None])
+    e2 = host_noise(2, cfg["K"], cfg["T"], 1, seed=9)
+    eng2.injectNoise(e2)
+    eng2.computeControl(cfg["x0"], 1)
+    orc2.vanilla_compute_control(cfg["x0"], 1, e2)
+    assert np.abs(eng2.getControlSeq() - orc2.control()).max() <= U_TOL
+    # switching it off restores the per-control sigma
+    eng.setTimeSpecificStdDev(None)
+    orc.set_time_specific_std_dev(None)
+    eng.injectNoise(eps)
+    g = eng.rolloutCosts(cfg["x0"], 1)
+    c, _ = orc.rollout_costs(cfg["x0"], mean[None], orc.set_gaussian_controls(mean[None], eps, 1, 0))
+    assert ulp_diff(g, c).max() == 0
+
+
+@pytest.mark.gpu
+def test_time_specific_std_dev_two_systems(gpu):
+    """Tube (two distributions, folded kernel: the distribution index differs between the lanes of a wave)"""
+    cfg = di_cfg(K=512, T=33, tube=True)
+    cfg["control_cost_coeff"] = [0.4, 0.2]
+    sd = 0.5 + np.random.default_rng(1).random((2, cfg["T"], 2)).astype(np.float32)
+    for kw in ({}, {"kernel_variant": 1}):
+        eng, orc = make_engine(cfg, **kw), make_oracle(cfg)
+        eng.setTimeSpecificStdDev(sd)
+        orc.set_time_specific_std_dev(sd)
+        eps = host_noise(1, cfg["K"], cfg["T"], 2, seed=4)
+        eng.injectNoise(eps)
+        eng.computeControl(cfg["x0"], 1)
+        orc.tube_compute_control(cfg["x0"], 1, eps)
+        assert ulp_diff(eng.getSampledCostSeq(), orc.costs()).max() == 0
+        assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
