@@ -190,6 +190,13 @@ mppi_status mppi_set_sampler_params(mppi_handle h, const mppi_gaussian_params* p
  *  offset_decay_rate, fmin.  Only for handles created with MPPI_CONTROLLER_COLORED; std_dev etc. come from
  *  mppi_set_sampler_params as for the Gaussian sampler (ColoredNoiseParams extends GaussianParams). */
 /**
+ * use_same_noise_for_all_distributions (sampling_distributions/sampling_distribution.cuh:20; gaussian.cu:378-394).  Default
+ * (0): the systems of a Tube / Robust controller see the SAME noise, as the reference's default.  independent != 0: every
+ * distribution draws its own — Philox stream d in the generator modes, slab d of the buffer for injected noise, which then is
+ * eps[n_iters][D][K_local][T][C].
+ */
+mppi_status mppi_set_independent_noise(mppi_handle h, int independent);
+/**
  * time_specific_std_dev (GaussianTimeVaryingStdDevParams, sampling_distributions/gaussian/gaussian.cuh:64-95; used by
  * setGaussianControls, gaussian.cu:21-43, and by the likelihood-ratio cost, gaussian.cu:488-493): std_dev[D][T][C], one sigma per
  * distribution, time step and control instead of mppi_gaussian_params.std_dev.  NULL switches back.

@@ -52,6 +52,7 @@ struct SamplerLaunchState
   uint32_t generation;
   int iteration;  // opt_iter for std_dev_decay
   int optimization_stride;
+  int independent_noise;  // != 0: use_same_noise_for_all_distributions off (every distribution its own stream / eps slab)
 };
 
 struct ModelBase
@@ -872,6 +873,7 @@ struct ModelT : ModelBase
     smp.generation_ = s.generation;
     smp.rollout_offset_ = s.rollout_offset;
     smp.num_rollouts_global_ = s.num_rollouts_global;
+    smp.params_.use_same_noise_for_all_distributions = s.independent_noise == 0;
     smp.setIteration(s.iteration, s.optimization_stride);
   }
 

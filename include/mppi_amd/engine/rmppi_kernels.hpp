@@ -194,6 +194,7 @@ __global__ void __launch_bounds__(BX * 2 * replicated_lanes<DYN_T>::value)
   const int global_idx = BX * block_idx + thread_idx;
   const int shared_idx = BX * thread_idz + thread_idx;
   const int distribution_idx = thread_idz;
+  sampling->setNoiseStream(distribution_idx);  // Philox stream of this thread's draws (independent-noise option)
   const int tid_flat = tid_x + BX * REP * thread_idz;
   const bool is_nominal = thread_idz == RMPPI_NOMINAL_IDX;
   const int num_timesteps = args.num_timesteps;

@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(BX* BY* BZ* replicated_lanes<DYN_T>::value)
   const int global_idx = BX * block_idx + thread_idx;
   const int shared_idx = BX * thread_idz + thread_idx;
   const int distribution_idx = thread_idz;
+  sampling->setNoiseStream(distribution_idx);  // Philox stream of this thread's draws (independent-noise option)
   const int tid_flat = tid_x + BX * REP * (thread_idy + BY * thread_idz);
   constexpr int NTHREADS = BX * REP * BY * BZ;
   const bool writer = (rep_lane == 0) && (thread_idy == 0);  // the one thread that publishes a rollout's results

@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
   const int global_idx = BX * block_idx + thread_idx;
   const int shared_idx = BX * thread_idz + thread_idx;
   const int distribution_idx = thread_idz;
+  sampling->setNoiseStream(distribution_idx);  // Philox stream of this thread's draws (independent-noise option)
   const int tid_flat = tid_x + WX * ring_z;
   const int num_timesteps = args.num_timesteps;
   const int num_rollouts = args.num_rollouts;
@@ -215,14 +216,22 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
     for (int t = STEPS * smp_id; t < num_timesteps; t += STEPS * NS)
     {
       float zq[4], e[8];
-      sampling->drawQuad(global_idx, t * C / 4 + thread_idz, zq);
+      if (sampling->independentNoise())
+      {  // every system draws its own stream: both quads of the trip on this lane, nothing to share (wave-uniform branch)
+        sampling->drawQuad(global_idx, t * C / 4, &e[0]);
+        sampling->drawQuad(global_idx, t * C / 4 + 1, &e[4]);
+      }
+      else
+      {
+        sampling->drawQuad(global_idx, t * C / 4 + thread_idz, zq);
 #pragma unroll
-      for (int l = 0; l < 4; l++)
-      {  // r[0]: the value held by the pair's z = 0 lane, r[1]: by its z = 1 lane
-        const unsigned v = __float_as_uint(zq[l]);
-        auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-        e[l] = __uint_as_float(r[0]);
-        e[4 + l] = __uint_as_float(r[1]);
+        for (int l = 0; l < 4; l++)
+        {  // r[0]: the value held by the pair's z = 0 lane, r[1]: by its z = 1 lane
+          const unsigned v = __float_as_uint(zq[l]);
+          auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+          e[l] = __uint_as_float(r[0]);
+          e[4 + l] = __uint_as_float(r[1]);
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < STEPS; s2++)

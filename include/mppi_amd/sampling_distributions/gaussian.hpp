@@ -112,6 +112,8 @@ public:
   int num_rollouts_global_ = 1;      ///< K over all GPUs
   /* thread mapping, set per thread by kernels whose blockDim.x is not "one thread per rollout" (replicated lanes):
    * the kernel's copy of the object is private to the thread, so these are ordinary registers */
+  unsigned noise_stream_ = 0;        ///< Philox stream of this thread's draws: 0, or the distribution index when
+                                     ///< use_same_noise_for_all_distributions is off (setNoiseStream)
   int thread_slot_ = -1;             ///< rollout slot of this thread, -1: blockDim.x * threadIdx.z + threadIdx.x
   int block_rollouts_ = 0;           ///< rollouts per block, 0: blockDim.x
   int block_systems_ = 0;            ///< systems per block, 0: blockDim.z
@@ -121,6 +123,16 @@ public:
     thread_slot_ = slot;
     block_rollouts_ = block_rollouts;
     block_systems_ = block_systems;
+  }
+  /** use_same_noise_for_all_distributions == false (gaussian.cu:378-394: one curandGenerateNormal over all distributions
+   *  instead of a copy of distribution 0's noise): distribution d draws Philox stream d / reads slab d of the eps buffer */
+  __device__ inline bool independentNoise() const
+  {
+    return !params_.use_same_noise_for_all_distributions;
+  }
+  __device__ inline void setNoiseStream(const int distribution_index)
+  {
+    noise_stream_ = independentNoise() ? (unsigned)distribution_index : 0u;
   }
   __device__ inline int systemsPerBlock() const
   {
@@ -221,11 +233,11 @@ public:
         col -= TC;
         row++;
       }
+      const size_t slab = independentNoise() ? (size_t)params_.num_rollouts * TC : 0;  // eps [D][K_local][T][C]
       for (int e = tid_flat; e < total; e += nthreads)
       {
-        const float v = src[e];
         for (int z = 0; z < nz; z++)
-          theta_d[(z * bx + row) * stride + col] = v;
+          theta_d[(z * bx + row) * stride + col] = src[e + z * slab];
         col += nthreads;
         while (col >= TC)
         {
@@ -242,15 +254,23 @@ public:
       {
         const int row = i / qpr;
         const int q = i - row * qpr;
-        float zn[4];
-        mppi::rng::normal4(seed_, generation_, 0u, (uint32_t)(row0 + row + rollout_offset_), (uint32_t)q, zn);
-#pragma unroll
-        for (int l = 0; l < 4; l++)
+        for (int z = 0; z < (independentNoise() ? nz : 1); z++)
         {
-          const int col = q * 4 + l;
-          if (col < TC)
-            for (int z = 0; z < nz; z++)
-              theta_d[(z * bx + row) * stride + col] = zn[l];
+          float zn[4];
+          mppi::rng::normal4(seed_, generation_, (uint32_t)z, (uint32_t)(row0 + row + rollout_offset_), (uint32_t)q, zn);
+#pragma unroll
+          for (int l = 0; l < 4; l++)
+          {
+            const int col = q * 4 + l;
+            if (col < TC)
+            {
+              if (independentNoise())
+                theta_d[(z * bx + row) * stride + col] = zn[l];
+              else
+                for (int zz = 0; zz < nz; zz++)
+                  theta_d[(zz * bx + row) * stride + col] = zn[l];
+            }
+          }
         }
       }
     }
@@ -332,7 +352,7 @@ public:
   /** quad `quad` (row elements 4*quad .. 4*quad+3) of local rollout `sample_index`, into registers */
   __device__ inline void drawQuad(const int sample_index, const int quad, float z[4]) const
   {
-    mppi::rng::normal4(seed_, generation_, 0u, (uint32_t)(sample_index + rollout_offset_), (uint32_t)quad, z);
+    mppi::rng::normal4(seed_, generation_, noise_stream_, (uint32_t)(sample_index + rollout_offset_), (uint32_t)quad, z);
   }
 
   /**
@@ -372,12 +392,14 @@ public:
       float eps;
       if (noise_source_ == NOISE_EPS_BUFFER)
       {
-        eps = eps_d_[(size_t)sample_index * params_.num_timesteps * CONTROL_DIM + e];
+        const size_t slab = independentNoise() ? (size_t)d * params_.num_rollouts * params_.num_timesteps * CONTROL_DIM : 0;
+        eps = eps_d_[slab + (size_t)sample_index * params_.num_timesteps * CONTROL_DIM + e];
       }
       else
       {
         float z[4];
-        mppi::rng::normal4(seed_, generation_, 0u, (uint32_t)(sample_index + rollout_offset_), (uint32_t)(e >> 2), z);
+        mppi::rng::normal4(seed_, generation_, independentNoise() ? (uint32_t)d : 0u,
+                           (uint32_t)(sample_index + rollout_offset_), (uint32_t)(e >> 2), z);
         eps = (e & 3) == 0 ? z[0] : ((e & 3) == 1 ? z[1] : ((e & 3) == 2 ? z[2] : z[3]));
       }
       control[i] = shapeSample(mean[i], sigmaValue<false, true>(d, t, i), eps, use_mean, pure);

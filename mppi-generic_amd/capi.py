@@ -80,6 +80,7 @@ SIGNATURES = {
     "mppi_set_dynamics_params": (C.c_int, [H, C.c_void_p, C.c_size_t]),
     "mppi_set_cost_params": (C.c_int, [H, C.c_void_p, C.c_size_t]),
     "mppi_set_sampler_params": (C.c_int, [H, C.POINTER(MppiGaussianParams)]),
+    "mppi_set_independent_noise": (C.c_int, [H, C.c_int]),
     "mppi_set_time_specific_std_dev": (C.c_int, [H, C.c_void_p]),
     "mppi_set_colored_noise_params": (C.c_int, [H, _f32p, C.c_float, C.c_float]),
     "mppi_sample_noise": (C.c_int, [H, C.c_int, _f32p]),

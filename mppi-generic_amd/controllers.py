@@ -319,7 +319,14 @@ class MPPIController:
         self._check(self._lib.mppi_inject_noise(self._h, eps.ctypes.data, eps.shape[0]))
 
     def _noise_shape(self):
-        return (self.num_rollouts_local, self.num_timesteps, self.CONTROL_DIM)
+        base = (self.num_rollouts_local, self.num_timesteps, self.CONTROL_DIM)
+        return ((self.num_systems,) + base) if getattr(self, "_independent_noise", False) else base
+
+    def setIndependentNoise(self, independent=True):
+        """use_same_noise_for_all_distributions = not independent (sampling_distribution.cuh:20); injected noise then is
+        eps[n_iters][D][K_local][T][C]"""
+        self._check(self._lib.mppi_set_independent_noise(self._h, int(independent)))
+        self._independent_noise = bool(independent)
 
     def sampleNoise(self, optimization_stride=1):
         """raw eps[K_local][T][C] of the next iteration (generator tests; see mppi_sample_noise)"""

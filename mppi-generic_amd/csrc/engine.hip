@@ -145,6 +145,7 @@ struct mppi_handle_s
   mppi_stats stats_h{};
   uint32_t generation = 0;
   int last_stride = 1;
+  bool independent_noise = false;  // use_same_noise_for_all_distributions == false (sampling_distribution.cuh:20)
   int external_iteration = 0;  // opt_iter of a caller-driven loop (mppi_iteration_local), reset by mppi_upload_state
   int noise_source = MPPI_NOISE_PHILOX_FUSED;
 
@@ -199,6 +200,13 @@ struct RocrandApi
 };
 RocrandApi g_rocrand;
 }  // namespace
+
+/** floats of injected / library-generated noise one rollout launch consumes: [K_local][noise floats], times D slabs when every
+ *  distribution draws its own noise */
+static inline size_t epsFloatsPerIteration(const mppi_handle_s* h)
+{
+  return (size_t)h->K_local * h->noise_floats * (h->independent_noise ? (size_t)h->D : 1);
+}
 
 /** the multi-rank path (local merge -> all-gather -> global merge) runs for world_size > 1, and for a world of ONE when
  *  the caller asks for it (cfg.force_exchange): that exercises the RCCL plumbing on a single GPU */
@@ -735,6 +743,29 @@ mppi_status mppi_set_sampler_params(mppi_handle h, const mppi_gaussian_params* p
   h->model->setSamplerParams(p, h->D);
   return MPPI_OK;
 }
+mppi_status mppi_set_independent_noise(mppi_handle h, int independent)
+{
+  CHECK_HANDLE(h);
+  if (independent && h->cfg.controller == MPPI_CONTROLLER_COLORED)
+    return fail(h, MPPI_ERR_UNSUPPORTED, "independent noise per distribution: the colored-noise sampler has one distribution");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if ((independent != 0) != h->independent_noise)
+  {  // buffers sized for the other layout are dropped; injected noise has to be injected again
+    if (h->eps_d)
+      HIP_TRY(h, hipFree(h->eps_d));
+    h->eps_d = nullptr;
+    h->n_eps_iters = 0;
+    if (h->rocrand_eps_d)
+      HIP_TRY(h, hipFree(h->rocrand_eps_d));
+    h->rocrand_eps_d = nullptr;
+    if (h->noise_source == MPPI_NOISE_INJECTED)
+      h->noise_source = h->cfg.noise_source == MPPI_NOISE_INJECTED ? MPPI_NOISE_PHILOX_FUSED : h->cfg.noise_source;
+  }
+  h->independent_noise = independent != 0;
+  return MPPI_OK;
+}
+
 mppi_status mppi_set_time_specific_std_dev(mppi_handle h, const float* std_dev)
 {
   CHECK_HANDLE(h);
@@ -1034,7 +1065,7 @@ mppi_status mppi_set_seed(mppi_handle h, uint64_t seed)
  *  differently — the reference's own sampler tests are statistical too, tests/sampling_distributions/.) */
 static mppi_status rocrandFill(mppi_handle h)
 {
-  const size_t n = ((size_t)h->K_local * h->noise_floats + 1) & ~(size_t)1;  // the generator wants an even count
+  const size_t n = (epsFloatsPerIteration(h) + 1) & ~(size_t)1;  // the generator wants an even count
   if (!h->rocrand_lib)
   {
     h->rocrand_lib = dlopen("librocrand.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -1124,7 +1155,7 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   {
     if (!h->eps_d || h->n_eps_iters <= 0)
       return fail(h, MPPI_ERR_STATE, "noise source is MPPI_NOISE_INJECTED but no noise has been injected");
-    s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * h->K_local * h->noise_floats;
+    s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * epsFloatsPerIteration(h);
   }
   else if (h->noise_source == MPPI_NOISE_ROCRAND_HOST)
   {
@@ -1136,6 +1167,7 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   s.generation = h->generation;
   s.iteration = iteration;
   s.optimization_stride = stride;
+  s.independent_noise = h->independent_noise ? 1 : 0;
   std::string err;
   mppi_status st;
   if (h->cfg.controller == MPPI_CONTROLLER_ROBUST)
@@ -1348,7 +1380,7 @@ mppi_status mppi_inject_noise(mppi_handle h, const float* eps, int n_iters)
     h->noise_source = h->cfg.noise_source == MPPI_NOISE_INJECTED ? MPPI_NOISE_PHILOX_FUSED : h->cfg.noise_source;
     return MPPI_OK;
   }
-  const size_t n = (size_t)n_iters * h->K_local * h->noise_floats;
+  const size_t n = (size_t)n_iters * epsFloatsPerIteration(h);
   if (n_iters != h->n_eps_iters)
   {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1719,7 +1751,7 @@ static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, in
   {
     if (!h->eps_d || h->n_eps_iters <= 0)
       return fail(h, MPPI_ERR_STATE, "noise source is MPPI_NOISE_INJECTED but no noise has been injected");
-    s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * h->K_local * h->noise_floats;
+    s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * epsFloatsPerIteration(h);
   }
   else if (h->noise_source == MPPI_NOISE_ROCRAND_HOST)
     return fail(h, MPPI_ERR_UNSUPPORTED, "this call draws through the sampler's random-access path: use the Philox or the "
@@ -1729,6 +1761,7 @@ static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, in
   s.generation = h->generation;
   s.iteration = 0;  // generateSamples(stride, 0, gen) (:596)
   s.optimization_stride = stride;
+  s.independent_noise = h->independent_noise ? 1 : 0;
   std::string err;
   mppi_status st = h->model->launchInitEval(a, s, h->stream, err);
   if (st != MPPI_OK)
@@ -2059,7 +2092,7 @@ mppi_status mppi_sample_noise(mppi_handle h, int optimization_stride, float* eps
   {
     if (!h->eps_d || h->n_eps_iters <= 0)
       return fail(h, MPPI_ERR_STATE, "noise source is MPPI_NOISE_INJECTED but no noise has been injected");
-    s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * h->K_local * h->noise_floats;
+    s.eps_d = h->eps_d + (size_t)(h->generation % (uint32_t)h->n_eps_iters) * epsFloatsPerIteration(h);
   }
   else if (h->noise_source == MPPI_NOISE_ROCRAND_HOST)
     return fail(h, MPPI_ERR_UNSUPPORTED, "this call draws through the sampler's random-access path: use the Philox or the "
@@ -2069,6 +2102,7 @@ mppi_status mppi_sample_noise(mppi_handle h, int optimization_stride, float* eps
   s.generation = h->generation;
   s.iteration = 0;
   s.optimization_stride = optimization_stride;
+  s.independent_noise = h->independent_noise ? 1 : 0;
   const size_t n = (size_t)h->K_local * h->TC;
   float* out_d = nullptr;
   HIP_TRY(h, hipMalloc((void**)&out_d, n * sizeof(float)));

@@ -190,6 +190,10 @@ void oracle_set_sampler(void* h, const float* std_dev /*[D][C]*/, const float* c
   c->smp.std_dev_decay = std_dev_decay;
   c->smp.sum_strides = sum_strides;
 }
+void oracle_set_independent_noise(void* h, int independent)
+{
+  ((Controller*)h)->smp.independent_noise = independent != 0;
+}
 void oracle_set_time_specific_std_dev(void* h, const float* std_dev /*[D][T][C] or NULL*/)
 {
   auto* c = (Controller*)h;

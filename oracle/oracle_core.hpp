@@ -151,6 +151,7 @@ struct GaussianSampler
 {
   int C = 0, D = 1, K = 0, T = 0;
   std::vector<float> std_dev;            /* [D][C]  (time_specific_std_dev == false) */
+  bool independent_noise = false;        /* use_same_noise_for_all_distributions == false: eps is [D][K][T][C] */
   std::vector<float> std_dev_time;       /* [D][T][C] when time_specific_std_dev is on (gaussian.cuh:64-95), else empty */
   std::vector<float> control_cost_coeff; /* [C] */
   float pure_noise_trajectories_percentage = 0.01f;
@@ -187,7 +188,8 @@ struct GaussianSampler
           for (int c = 0; c < C; c++)
           {
             const size_t vi = (((size_t)d * K + k) * T + t) * C + c;
-            const float e = eps[((size_t)k * T + t) * C + c];
+            /* gaussian.cu:378-394: one block of noise copied to every distribution, or one block per distribution */
+            const float e = eps[(independent_noise ? (size_t)d * K * T * C : 0) + ((size_t)k * T + t) * C + c];
             const float m = mean[((size_t)d * T + t) * C + c];
             /* gaussian.cu:21-43: the std-dev index carries the time step when time_specific_std_dev is set */
             const float sd = decay * (std_dev_time.empty() ? std_dev[(size_t)d * C + c] : std_dev_time[((size_t)d * T + t) * C + c]);
@@ -661,7 +663,7 @@ struct Controller
       }
       std::copy(control.begin(), control.end(), mean.begin());
       std::copy(nominal_control.begin(), nominal_control.end(), mean.begin() + (size_t)T * C);
-      iterate(x0.data(), mean.data(), eps + (size_t)it * K * T * C, stride, it, u_new.data());
+      iterate(x0.data(), mean.data(), eps + (size_t)it * K * T * C * (smp.independent_noise ? D : 1), stride, it, u_new.data());
       std::copy(u_new.begin(), u_new.begin() + (size_t)T * C, control.begin());
       std::copy(u_new.begin() + (size_t)T * C, u_new.end(), nominal_control.begin());
       tubeComputeStateTrajectory(x0_actual);

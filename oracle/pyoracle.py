@@ -54,6 +54,7 @@ def lib():
         L.oracle_set_control_ranges.argtypes = [C.c_void_p, _f32p]
         L.oracle_set_control_deadband.argtypes = [C.c_void_p, _f32p]
         L.oracle_set_sampler.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, C.c_int]
+        L.oracle_set_independent_noise.argtypes = [C.c_void_p, C.c_int]
         L.oracle_set_time_specific_std_dev.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_set_controller_params.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
         L.oracle_set_gaussian_controls.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, _f32p]
@@ -190,6 +191,10 @@ class Oracle:
             sd = np.concatenate([sd, sd])
         cc = _f32(np.zeros(self.C) if control_cost_coeff is None else control_cost_coeff).reshape(-1)
         self.L.oracle_set_sampler(self.h, sd, cc, pure_noise_pct, std_dev_decay, sum_strides)
+
+    def set_independent_noise(self, independent=True):
+        """eps then is [D][K][T][C] (use_same_noise_for_all_distributions = false, gaussian.cu:378-394)"""
+        self.L.oracle_set_independent_noise(self.h, int(independent))
 
     def set_time_specific_std_dev(self, std_dev):
         """std_dev [D][T][C] or None (gaussian.cuh:64-95 GaussianTimeVaryingStdDevParams)"""

@@ -317,3 +317,42 @@ def test_time_specific_std_dev_two_systems(gpu):
         orc.tube_compute_control(cfg["x0"], 1, eps)
         assert ulp_diff(eng.getSampledCostSeq(), orc.costs()).max() == 0
         assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [{}, {"kernel_variant": 1}, {"block_x": 64, "block_y": 1}, {"block_x": 32, "block_y": 2}],
+                         ids=["folded-pipeline", "fused", "pipeline-64x1x2", "lds-contract"])
+def test_independent_noise_per_distribution(gpu, kw):
+    """use_same_noise_for_all_distributions = false (sampling_distribution.cuh:20; gaussian.cu:378-394): the two systems of
+    Tube-MPPI draw their own noise — slab d of the injected buffer, Philox stream d in the generator mode"""
+    cfg = di_cfg(K=1000, T=33, tube=True)
+    eng, orc = make_engine(cfg, save_samples=True, **kw), make_oracle(cfg)
+    eng.setIndependentNoise(True)
+    orc.set_independent_noise(True)
+    eps = np.random.default_rng(12).standard_normal((1, 2, cfg["K"], cfg["T"], 2)).astype(np.float32)
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    orc.tube_compute_control(cfg["x0"], 1, eps)
+    assert ulp_diff(eng.getSampledCostSeq(), orc.costs()).max() == 0
+    assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
+    assert np.abs(eng.getNominalControlSeq() - orc.nominal_control()).max() <= U_TOL
+    v = eng.getSampledControls()
+    assert not np.array_equal(v[0], v[1])
+    # generator mode: distribution d == Philox stream d of the oracle's generator
+    eng2, orc2 = make_engine(cfg, **kw), make_oracle(cfg)
+    eng2.setIndependentNoise(True)
+    orc2.set_independent_noise(True)
+    eng2.setSeed(77)
+    eng2.computeControl(cfg["x0"], 1)
+    epsp = np.stack([po.philox_normal(77, 0, cfg["K"], cfg["T"], 2, stream=d) for d in range(2)])[None]
+    orc2.tube_compute_control(cfg["x0"], 1, epsp)
+    assert ulp_diff(eng2.getSampledCostSeq(), orc2.costs()).max() == 0
+    assert np.abs(eng2.getControlSeq() - orc2.control()).max() <= U_TOL
+    # back to shared noise
+    eng2.setIndependentNoise(False)
+    orc2.set_independent_noise(False)
+    e1 = host_noise(1, cfg["K"], cfg["T"], 2, seed=2)
+    eng2.injectNoise(e1)
+    eng2.computeControl(cfg["x0"], 1)
+    orc2.tube_compute_control(cfg["x0"], 1, e1)
+    assert np.abs(eng2.getControlSeq() - orc2.control()).max() <= U_TOL
