@@ -150,6 +150,16 @@ MPPI_HD static inline float normalizeAngle(float angle)
  */
 MPPI_HD static inline void sincos(float x, float* s_out, float* c_out)
 {
+#if defined(MPPI_DET_MATH_LIBM) && !defined(__HIPCC__)
+  /* HOST-ONLY study switch (oracle/Makefile target libm, tests/test_det_math.py::test_libm_flavour_deviation): the oracle
+   * rebuilt on libm's sinf / cosf / expf / logf / tanhf / atanf measures how far the bit-reproducible functions of this
+   * header move a control sequence away from a build on the platform's own math library — the distance that separates ANY
+   * two implementations of the reference's formulas (its CUDA device path uses __sinf / __cosf / tanhf, none of them
+   * correctly rounded).  Never defined for the product. */
+  *s_out = ::sinf(x);
+  *c_out = ::cosf(x);
+  return;
+#endif
   const float k = rint(x * 0.636619746685028076171875f);   /* x * 2/pi */
   float r = fma(-k, 1.57079637050628662109375f, x);        /* pi/2 hi  */
   r = fma(-k, -4.37113882867379277013e-08f, r);            /* pi/2 mid */
@@ -212,6 +222,9 @@ MPPI_HD static inline float scalbn_small(float z, int n)
 /** exp(x): n = rint(x*log2(e)); r = x - n*ln2 (3-term, fused); Cephes expf kernel; exact 2^n scaling. */
 MPPI_HD static inline float exp(float x)
 {
+#if defined(MPPI_DET_MATH_LIBM) && !defined(__HIPCC__)
+  return ::expf(x);
+#endif
   if (!(x > -104.0f))
     return (x != x) ? x : 0.0f;
   if (x > 88.72283935546875f)
@@ -232,6 +245,9 @@ MPPI_HD static inline float exp(float x)
 /** log(x), Cephes logf structure (frexp by bit manipulation, sqrt(1/2) split, degree-8 kernel). */
 MPPI_HD static inline float log(float x)
 {
+#if defined(MPPI_DET_MATH_LIBM) && !defined(__HIPCC__)
+  return ::logf(x);
+#endif
   if (!(x > 0.0f))
     return (x == 0.0f) ? -u2f(0x7f800000u) : u2f(0x7fc00000u);
   if (x == u2f(0x7f800000u))
@@ -336,6 +352,9 @@ MPPI_HD static inline void rcp_benign2(const float xa, const float xb, float* ra
  */
 MPPI_HD static inline float tanh(float x)
 {
+#if defined(MPPI_DET_MATH_LIBM) && !defined(__HIPCC__)
+  return ::tanhf(x);
+#endif
   const float xc = fminf(fmaxf(x, -7.90531110763549805f), 7.90531110763549805f);
   const float x2 = xc * xc;
   float p = fma(x2, -2.76076847742355e-16f, 2.00018790482477e-13f);
@@ -429,6 +448,9 @@ MPPI_HD static inline void sigmoid_n(float (&v)[N])
 /** atan(x), Cephes atanf structure. */
 MPPI_HD static inline float atan(float x)
 {
+#if defined(MPPI_DET_MATH_LIBM) && !defined(__HIPCC__)
+  return ::atanf(x);
+#endif
   const float ax = fabs(x);
   float y, t;
   if (ax > 2.414213562373095f)

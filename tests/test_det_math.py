@@ -50,3 +50,27 @@ def test_normalize_angle_matches_fmodf_formula():
     r = np.fmod((a + pi).astype(np.float32), np.float32(2) * pi).astype(np.float32)
     want = np.where(r <= 0, r + pi, r - pi).astype(np.float32)
     assert np.array_equal(po.det_eval(6, a), want)
+
+
+def test_libm_flavour_deviation():
+    """common-mode check: oracle and engine share det_math.h, so their 0-ulp agreement says nothing about the distance to an
+    implementation on other transcendentals (the reference's CUDA path: __sinf / __cosf / tanhf / expf).  The same oracle
+    rebuilt on glibc's sinf / cosf / expf / logf / tanhf / atanf (make -C oracle libm) stays within the north-star bar:
+    u* L-inf <= 1e-5, trajectory costs <= 1e-4 relative (the reference's own GPU-vs-CPU tolerance).  At the BASELINE sizes
+    tools/libm_flavour_study.py measures u* <= 4.1e-7 and costs <= 1.3e-5."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "libm_flavour_study", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "libm_flavour_study.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import sys
+    argv = sys.argv
+    sys.argv = ["libm_flavour_study.py", "--small"]
+    try:
+        res = mod.main()
+    finally:
+        sys.argv = argv
+    for name, rel_cost, du in res:
+        assert du <= 1e-5, (name, du)
+        assert rel_cost <= 1e-4, (name, rel_cost)
