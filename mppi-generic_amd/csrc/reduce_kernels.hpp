@@ -114,12 +114,9 @@ constexpr int COMBINE_COLS = 64;
 __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* s_b = reinterpret_cast<float*>(smem_raw);  // [num_records] scale factors
-  float* rho_s = s_b + a.num_records;               // [num_records] record tails, fetched from memory ONCE
+  float* rho_s = reinterpret_cast<float*>(smem_raw);  // [num_records] record tails, fetched from memory ONCE
   float* eta_s = rho_s + a.num_records;
   float* eta2_s = eta_s + a.num_records;
-  __shared__ double red_d[COMBINE_THREADS / 64];
-  __shared__ float red_f[COMBINE_THREADS / 64];
   __shared__ float part_s[COMBINE_THREADS / 64][COMBINE_COLS];
 
   const int z = blockIdx.x;
@@ -173,58 +170,81 @@ __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineAr
     v0[i] = (col_ok && b < a.num_records) ? (mailbox ? loadPeerWritten(col + (size_t)b * a.rec_stride) : col[(size_t)b * a.rec_stride]) : 0.0f;
   }
 
-  float rho = INFINITY;
   for (int b = tid; b < a.num_records; b += COMBINE_THREADS)
   {
     const float* r = rec + (size_t)b * a.rec_stride + a.TC;
-    const float r0 = mailbox ? loadPeerWritten(r) : r[0], r1 = mailbox ? loadPeerWritten(r + 1) : r[1],
-                r2 = mailbox ? loadPeerWritten(r + 2) : r[2];
-    rho_s[b] = r0;
-    eta_s[b] = r1;
-    eta2_s[b] = r2;
-    rho = fminf(rho, r0);
+    rho_s[b] = mailbox ? loadPeerWritten(r) : r[0];
+    eta_s[b] = mailbox ? loadPeerWritten(r + 1) : r[1];
+    eta2_s[b] = mailbox ? loadPeerWritten(r + 2) : r[2];
   }
-  rho = blockMin(rho, red_f);
+  __syncthreads();  // the only barrier before the partial sums
 
-  double eta = 0.0, eta2 = 0.0;
-  for (int b = tid; b < a.num_records; b += COMBINE_THREADS)
-  {
-    // a record whose rollouts all cost +inf has rho_b = inf and U_b = eta_b = 0: scale 0 (inf - inf would be NaN when
-    // the global minimum is inf as well — then nothing has weight, as with the reference's global baseline)
+  // rho, eta, sum w^2 over ALL records, redundantly in every wave — lane-strided partials joined by shuffle trees in a fixed
+  // order, so every wave (and every block, and every rank merging the same records) gets the same bits.  A block-wide
+  // reduction would cost three barrier pairs on a kernel that is nothing but latency; this costs num_records / 64 exps a lane.
+  float rho = INFINITY;
+  for (int b = lane; b < a.num_records; b += 64)
+    rho = fminf(rho, rho_s[b]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    rho = fminf(rho, __shfl_xor(rho, off, 64));
+  // a record whose rollouts all cost +inf has rho_b = inf and U_b = eta_b = 0: scale 0 (inf - inf would be NaN when the
+  // global minimum is inf as well — then nothing has weight, as with the reference's global baseline)
+  auto scale = [&](const int b) {
     const float dist = rho_s[b] - rho;
-    const float s = (dist == dist) ? mppi::det::exp(-lambda_inv * dist) : 0.0f;
-    s_b[b] = s;
+    return (dist == dist) ? mppi::det::exp(-lambda_inv * dist) : 0.0f;
+  };
+  double eta = 0.0, eta2 = 0.0;
+  for (int b = lane; b < a.num_records; b += 64)
+  {
+    const float s = scale(b);
     eta += (double)s * (double)eta_s[b];
     eta2 += (double)s * (double)s * (double)eta2_s[b];
   }
-  eta = blockSum(eta, red_d);
-  eta2 = blockSum(eta2, red_d);  // blockSum's barriers also publish s_b
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    eta += __shfl_xor(eta, off, 64);
+    eta2 += __shfl_xor(eta2, off, 64);
+  }
   const float eta_f = (float)eta;
 
-  // wave w sums records w, w + NW, ... in ascending order (fixed order => run-to-run reproducible)
+  // wave w sums records w, w + NW, ... in ascending order (fixed order => run-to-run reproducible).  The scale factors of a
+  // batch of 16 records are computed by lanes 0..15 of the wave — one exp each, side by side — and read back lane by lane
+  // (v_readlane: a scalar operand), instead of travelling through LDS behind a barrier.
   float acc = 0.0f;
+  {
+    const int bl = wave + (lane & (BATCH - 1)) * NW;
+    const float s_mine = bl < a.num_records ? scale(bl) : 0.0f;
 #pragma unroll
-  for (int i = 0; i < BATCH; i++)
-  {
-    const int b = wave + i * NW;
-    if (b < a.num_records)
-      acc += s_b[b] * v0[i];
+    for (int i = 0; i < BATCH; i++)
+    {
+      const float s_i = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s_mine), i));
+      acc += s_i * v0[i];  // v0[i] is 0 beyond the last record
+    }
   }
-  if (col_ok)
+  if (a.num_records > BATCH * NW)
   {
-    int b = wave + BATCH * NW;
-    for (; b + (BATCH - 1) * NW < a.num_records; b += BATCH * NW)
+    for (int b = wave + BATCH * NW; b < a.num_records; b += BATCH * NW)
     {
       float v[BATCH];
 #pragma unroll
       for (int i = 0; i < BATCH; i++)
-        v[i] = mailbox ? loadPeerWritten(col + (size_t)(b + i * NW) * a.rec_stride) : col[(size_t)(b + i * NW) * a.rec_stride];
+      {
+        const int bi = b + i * NW;
+        v[i] = (col_ok && bi < a.num_records) ?
+                   (mailbox ? loadPeerWritten(col + (size_t)bi * a.rec_stride) : col[(size_t)bi * a.rec_stride]) :
+                   0.0f;
+      }
+      const int bl = b + (lane & (BATCH - 1)) * NW;
+      const float s_mine = bl < a.num_records ? scale(bl) : 0.0f;
 #pragma unroll
       for (int i = 0; i < BATCH; i++)
-        acc += s_b[b + i * NW] * v[i];
+      {
+        const float s_i = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s_mine), i));
+        acc += s_i * v[i];
+      }
     }
-    for (; b < a.num_records; b += NW)
-      acc += s_b[b] * (mailbox ? loadPeerWritten(col + (size_t)b * a.rec_stride) : col[(size_t)b * a.rec_stride]);
   }
   part_s[wave][lane] = acc;
   __syncthreads();

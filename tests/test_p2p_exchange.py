@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _run_ranks(cfg, world, iters, x0):
+    import gc
+    gc.collect()  # engines of earlier tests that were only dropped, not closed, still hold streams
     ranks = [make_engine(cfg, rank=r, world_size=world) for r in range(world)]
     m.MPPIController.p2pConnectLocal(ranks)
     for c in ranks:
@@ -51,7 +53,10 @@ def test_p2p_local_matches_unsharded(gpu, world):
     ranks = _run_ranks(cfg, world, 1, cfg["x0"])
     orc = make_oracle(cfg)
     u_orc = orc.iterate(cfg["x0"], np.zeros((cfg["T"], 1), np.float32), po.philox_normal(42, 0, cfg["K"], cfg["T"], 1))[0]
-    assert np.abs(ranks[0].getOptimalControlSeq()[0] - u_orc).max() <= 1e-5
+    u0 = ranks[0].getOptimalControlSeq()[0]
+    for c in ranks:  # leave no stream behind: the next test's ranks need the hardware queues
+        c.close()
+    assert np.abs(u0 - u_orc).max() <= 1e-5
 
 
 def test_p2p_local_two_systems(gpu):
@@ -64,8 +69,11 @@ def test_p2p_local_two_systems(gpu):
     u_full = full.getOptimalControlSeq()
     full.close()
     ranks = _run_ranks(cfg, 2, 2, x0)
+    us = [c.getOptimalControlSeq() for c in ranks]
     for c in ranks:
-        assert np.abs(c.getOptimalControlSeq() - u_full).max() <= 5e-6
+        c.close()
+    for u in us:
+        assert np.abs(u - u_full).max() <= 5e-6
 
 
 def test_p2p_missing_peer_times_out_instead_of_hanging(gpu):
@@ -77,6 +85,8 @@ def test_p2p_missing_peer_times_out_instead_of_hanging(gpu):
     ranks[0].optimize(1, synchronize=True)  # rank 1 never runs
     with pytest.raises(m.MPPIError) as e:
         ranks[0].getStats()
+    for c in ranks:
+        c.close()
     assert e.value.status == 9
 
 
