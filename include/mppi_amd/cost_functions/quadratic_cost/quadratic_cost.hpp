@@ -4,6 +4,11 @@
  * computeStateCost / terminalCost).  One goal (the reference's SIM_TIME_HORIZON = 1 instantiation: getIndex() clamps
  * every timestep to the single stored goal).  powf(x, 2) of the reference is x * x (what the CUDA compiler emits for a
  * constant exponent 2).
+ *
+ * SKIP_ZERO_COEFF = true: an output with coefficient 0 contributes exactly 0 even when it is not finite.  The elevation-map
+ * RACER models mark outputs they do not model with NaN (racer_dubins_elevation.cu:131-139), which the reference's sum
+ * turns into a NaN cost for every rollout (NaN * 0); this form is what lets QuadraticCost weigh the outputs those models
+ * DO produce.  For finite outputs both forms give the same value (x * 0 = 0).
  */
 #ifndef MPPI_AMD_QUADRATIC_COST_HPP_
 #define MPPI_AMD_QUADRATIC_COST_HPP_
@@ -30,8 +35,9 @@ struct QuadraticCostParams : public CostParams<DYN_T::CONTROL_DIM>
   }
 };
 
-template <class DYN_T>
-class QuadraticCost : public Cost<QuadraticCost<DYN_T>, QuadraticCostParams<DYN_T>, typename DYN_T::DYN_PARAMS_T>
+template <class DYN_T, bool SKIP_ZERO_COEFF = false>
+class QuadraticCost
+  : public Cost<QuadraticCost<DYN_T, SKIP_ZERO_COEFF>, QuadraticCostParams<DYN_T>, typename DYN_T::DYN_PARAMS_T>
 {
 public:
   static constexpr float MAX_COST_VALUE = 1e16;
@@ -48,7 +54,8 @@ public:
 #pragma unroll
     for (int i = 0; i < DYN_T::OUTPUT_DIM; i++)
     {
-      cost += ((s[i] - desired_state[i]) * (s[i] - desired_state[i])) * this->params_.s_coeffs[i];
+      const float term = ((s[i] - desired_state[i]) * (s[i] - desired_state[i])) * this->params_.s_coeffs[i];
+      cost += (SKIP_ZERO_COEFF && this->params_.s_coeffs[i] == 0.0f) ? 0.0f : term;
     }
     return cost;
   }

@@ -476,6 +476,31 @@ MPPI_HD static inline float atan(float x)
   return (x != x) ? x : copysign(y, x);
 }
 
+/** asin(x), Cephes asinf structure: a polynomial in x^2 on |x| <= 1/2, asin(x) = pi/2 - 2 asin(sqrt((1 - |x|) / 2)) above.
+ *  |x| > 1 and NaN return NaN (libm's domain rule; the RACER static-settling code tests the result with isfinite()). */
+MPPI_HD static inline float asin(float x)
+{
+#if defined(MPPI_DET_MATH_LIBM) && !defined(__HIPCC__)
+  return ::asinf(x);
+#endif
+  const float a = fabs(x);
+  if (!(a <= 1.0f))
+    return u2f(0x7fc00000u);
+  if (a < 1.0e-4f)
+    return x;
+  const bool upper = a > 0.5f;
+  const float z = upper ? 0.5f * (1.0f - a) : a * a;
+  const float w = upper ? sqrt(z) : a;
+  float p = fma(4.2163199048e-2f, z, 2.4181311049e-2f);
+  p = fma(p, z, 4.5470025998e-2f);
+  p = fma(p, z, 7.4953002686e-2f);
+  p = fma(p, z, 1.6666752422e-1f);
+  float y = fma(p * z, w, w);
+  if (upper)
+    y = 1.57079637050628662109375f - (y + y);
+  return copysign(y, x);
+}
+
 /** x^y for x > 0 as exp(y*log(x)); used only for slowly varying discount factors (|y*log x| small). */
 MPPI_HD static inline float pow_pos(float x, float y)
 {

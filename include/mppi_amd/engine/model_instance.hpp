@@ -276,6 +276,15 @@ struct has_host_leash<T, std::void_t<decltype(std::declval<const T&>().enforceLe
 {
 };
 template <class T, class = void>
+struct has_elevation_map : std::false_type
+{
+};
+/** dynamics with a TwoDTextureHelper member `tex_helper_` (the elevation-map RACER models) */
+template <class T>
+struct has_elevation_map<T, std::void_t<decltype(std::declval<T&>().tex_helper_.textures_[0].data)>> : std::true_type
+{
+};
+template <class T, class = void>
 struct has_costmap : std::false_type
 {
 };
@@ -526,6 +535,7 @@ struct ModelT : ModelBase
   float* weights_d = nullptr;
   float* weights2_d = nullptr;
   float* costmap_d = nullptr;
+  float* elevation_d = nullptr;
 
   ~ModelT() override
   {
@@ -539,6 +549,8 @@ struct ModelT : ModelBase
       (void)hipFree(weights2_d);
     if (costmap_d)
       (void)hipFree(costmap_d);
+    if (elevation_d)
+      (void)hipFree(elevation_d);
   }
 
   static mppi_status upload(float** dst, const float* src, size_t count, hipStream_t stream, std::string& err)
@@ -602,6 +614,43 @@ struct ModelT : ModelBase
         mppi_status st = upload(&weights2_d, data, count, stream, err);
         dyn.lstm_.output_nn_.theta_d_ = weights2_d;
         return st;
+      }
+    }
+    if constexpr (has_elevation_map<DYN_T>::value)
+    {
+      /* TwoDTextureHelper::updateTexture + enableTexture (texture_helper.cu:135-190): {height, width} heights, row-major */
+      if (name == "elevation_map")
+      {
+        if (ndims != 2 || dims[0] <= 0 || dims[1] <= 0 || (size_t)dims[0] * dims[1] != count)
+        {
+          err = "elevation_map: dims must be {height, width} with height*width == count";
+          return MPPI_ERR_INVALID_ARG;
+        }
+        mppi_status st = upload(&elevation_d, data, count, stream, err);
+        auto& tex = dyn.tex_helper_.textures_[0];
+        tex.data = elevation_d;
+        tex.height = dims[0];
+        tex.width = dims[1];
+        tex.use = (st == MPPI_OK);
+        return st;
+      }
+      /* updateOrigin / updateRotation / updateResolution (texture_helper.cu:192-268): origin[3], rotations[9] row-major,
+       * resolution[3] */
+      if (name == "elevation_map_transform")
+      {
+        if (count != 15)
+        {
+          err = "elevation_map_transform: expected 15 floats (origin[3], rotations[9], resolution[3])";
+          return MPPI_ERR_INVALID_ARG;
+        }
+        auto& tex = dyn.tex_helper_.textures_[0];
+        for (int i = 0; i < 3; i++)
+          tex.origin[i] = data[i];
+        for (int i = 0; i < 9; i++)
+          tex.rotations[i] = data[3 + i];
+        for (int i = 0; i < 3; i++)
+          tex.resolution[i] = data[12 + i];
+        return MPPI_OK;
       }
     }
     if constexpr (has_costmap<COST_T>::value)

@@ -9,6 +9,7 @@
  *   mppi_di_dynamics_params         <- DoubleIntegratorParams        dynamics/double_integrator/di_dynamics.cuh:9-37
  *   mppi_di_circle_cost_params      <- DoubleIntegratorCircleCostParams  cost_functions/double_integrator/double_integrator_circle_cost.cuh:8-23
  *   mppi_racer_dubins_params        <- RacerDubinsParams             dynamics/racer_dubins/racer_dubins.cuh:67-87
+ *   mppi_racer_dubins_elevation_params <- RacerDubinsElevationParams dynamics/racer_dubins/racer_dubins_elevation.cuh:16-60
  *   mppi_quadratic_cost_params_28   <- QuadraticCostTrajectoryParams<RacerDubins, 1>  cost_functions/quadratic_cost/quadratic_cost.cuh:11-63
  * (paths relative to the reference's include/mppi/).
  */
@@ -77,6 +78,23 @@ typedef struct mppi_racer_dubins_params
   float gravity;                   /* -9.81 */
   int gear_sign;                   /* 1 */
 } mppi_racer_dubins_params;
+
+/** RacerDubinsElevationParams: the RacerDubins block followed by the acceleration clamp and the coefficients of the
+ *  covariance propagation (feedback gains K_*, process-noise coefficients Q_*) */
+typedef struct mppi_racer_dubins_elevation_params
+{
+  mppi_racer_dubins_params base;
+  float clamp_ax;         /* 5.5 */
+  float K_x;              /* 1 */
+  float K_y;              /* 1 */
+  float K_yaw;            /* 1 */
+  float K_vel_x;          /* 1 */
+  float Q_x_acc;          /* 1 */
+  float Q_x_v[3];         /* {41.74219, -0.8187027, -2.2131343} */
+  float Q_y_f;            /* 0.1 */
+  float Q_omega_v;        /* 0.001 */
+  float Q_omega_steering; /* 0 */
+} mppi_racer_dubins_elevation_params;
 
 /** QuadraticCost over the 28 outputs of the RACER models, one goal (SIM_TIME_HORIZON = 1) */
 typedef struct mppi_quadratic_cost_params_28

@@ -113,6 +113,24 @@ class RacerDubinsParams(C.Structure):
         self.gear_sign = 1
 
 
+class RacerDubinsElevationParams(C.Structure):
+    """mppi_racer_dubins_elevation_params (reference: dynamics/racer_dubins/racer_dubins_elevation.cuh:16-60)"""
+    _fields_ = [("base", RacerDubinsParams), ("clamp_ax", C.c_float), ("K_x", C.c_float), ("K_y", C.c_float),
+                ("K_yaw", C.c_float), ("K_vel_x", C.c_float), ("Q_x_acc", C.c_float), ("Q_x_v", C.c_float * 3),
+                ("Q_y_f", C.c_float), ("Q_omega_v", C.c_float), ("Q_omega_steering", C.c_float)]
+
+    def __init__(self):
+        super().__init__()
+        RacerDubinsParams.__init__(self.base)
+        self.clamp_ax = 5.5
+        self.K_x = self.K_y = self.K_yaw = self.K_vel_x = 1.0
+        self.Q_x_acc = 1.0
+        self.Q_x_v[:] = [41.74219, -0.8187027, -2.2131343]
+        self.Q_y_f = 0.1
+        self.Q_omega_v = 0.001
+        self.Q_omega_steering = 0.0
+
+
 class QuadraticCostParams28(C.Structure):
     """mppi_quadratic_cost_params_28 (reference: QuadraticCostTrajectoryParams<RacerDubins, 1>,
     cost_functions/quadratic_cost/quadratic_cost.cuh:11-63)"""

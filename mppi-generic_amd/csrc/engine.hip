@@ -2739,6 +2739,7 @@ __global__ void detEvalKernel(int func, const float* x, float* y, int n)
         break;
       }
       case 12: r = mppi::det::tan(x[i]); break;
+      case 13: r = mppi::det::asin(x[i]); break;
     }
     y[i] = r;
   }

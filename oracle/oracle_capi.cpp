@@ -74,6 +74,15 @@ int oracle_set_blob(void* h, const char* name, const float* data, size_t count, 
     std::copy(data, data + count, dst.begin());
     return 0;
   }
+  if (n == "elevation_map" || n == "elevation_map_transform")
+  {
+    auto* m = dynamic_cast<RacerDubinsElevation*>(c->dyn.get());
+    if (!m)
+      return -1;
+    if (n == "elevation_map")
+      return ndims == 2 ? m->setMap(data, dims[0], dims[1]) : -1;
+    return m->setMapTransform(data, count);
+  }
   if (n == "costmap")
   {
     auto* m = dynamic_cast<ARStandardCost*>(c->cost.get());
@@ -295,6 +304,18 @@ void oracle_model_step(void* h, float* x, float* u, float dt)
   c->dyn->step(x, xn.data(), xdot.data(), u, y.data(), th.data(), 0, dt);
   for (int i = 0; i < S; i++)
     x[i] = xn[i];
+}
+
+/** one step with everything it produces: next state, the derivative entries the model writes, the output */
+void oracle_model_step_full(void* h, const float* x_in, const float* u_in, float dt, float* xn, float* xdot, float* y)
+{
+  auto* c = (Controller*)h;
+  const int S = c->dyn->S, Cd = c->dyn->C, O = c->dyn->O;
+  std::vector<float> x(x_in, x_in + S), u(u_in, u_in + Cd), th(std::max(1, c->dyn->scratchFloats()), 0.0f);
+  std::fill(xdot, xdot + S, 0.0f);
+  std::fill(y, y + O, 0.0f);
+  c->dyn->initializeDynamics(x.data(), u.data(), y, th.data(), 0.0f, dt);
+  c->dyn->step(x.data(), xn, xdot, u.data(), y, th.data(), 0, dt);
 }
 
 /* ----- controller level ----- */
@@ -530,6 +551,7 @@ void oracle_det_eval(int func, const float* x, float* y, int n)
         y[i] = det::sigmoid(x[i]) + det::sigmoid(x[i] * 0.5f) + det::sigmoid(-x[i]) + det::sigmoid(x[i] + 1.0f);
         break;
       case 12: y[i] = det::tan(x[i]); break;
+      case 13: y[i] = det::asin(x[i]); break;
       default: y[i] = 0.0f;
     }
   }

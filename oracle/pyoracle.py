@@ -78,6 +78,7 @@ def lib():
         L.oracle_state_trajectory.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
         L.oracle_output_trajectory.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p]
         L.oracle_model_step.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float]
+        L.oracle_model_step_full.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, _f32p, _f32p, _f32p]
         L.oracle_set_nominal_control.argtypes = [C.c_void_p, _f32p]
         L.oracle_iterate.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _f32p]
         L.oracle_vanilla_compute_control.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p]
@@ -244,6 +245,12 @@ class Oracle:
         u = _f32(u).reshape(-1).copy()
         self.L.oracle_model_step(self.h, x, u, self.dt if dt is None else dt)
         return x, u
+
+    def model_step_full(self, x, u, dt=None):
+        """initializeDynamics + one step(): (next state, state derivative, output)"""
+        xn, xd, y = np.zeros(self.S, np.float32), np.zeros(self.S, np.float32), np.zeros(self.O, np.float32)
+        self.L.oracle_model_step_full(self.h, _f32(x).reshape(-1), _f32(u).reshape(-1), self.dt if dt is None else dt, xn, xd, y)
+        return xn, xd, y
 
     # controller level
     def set_nominal_control(self, u):

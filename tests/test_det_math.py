@@ -24,6 +24,15 @@ def test_accuracy(func, ref, lo, hi, tol):
     assert _ulp_err(got, ref(x.astype(np.float64))).max() <= tol
 
 
+def test_asin_accuracy_and_edges():
+    rng = np.random.default_rng(13)
+    x = rng.uniform(-1, 1, 1_000_000).astype(np.float32)
+    assert _ulp_err(po.det_eval(13, x), np.arcsin(x.astype(np.float64))).max() <= 2.5
+    e = po.det_eval(13, np.array([0.0, 1.0, -1.0, 1.0000001, np.nan, 5e-5, 0.5], np.float32))
+    assert e[0] == 0 and e[1] == np.float32(np.pi / 2) and e[2] == -e[1] and np.isnan(e[3]) and np.isnan(e[4])
+    assert e[5] == np.float32(5e-5) and abs(e[6] - np.pi / 6) < 1e-7
+
+
 def test_log_accuracy_and_edges():
     rng = np.random.default_rng(9)
     x = np.exp(rng.uniform(np.log(1e-38), np.log(1e38), 1_000_000)).astype(np.float32)

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("func,lo,hi", [(0, -50, 50), (1, -50, 50), (2, -100, 88), (3, 1e-30, 1e30), (4, -12, 12),
                                         (5, -100, 100), (6, -1000, 1000), (7, -30, 30), (8, 0, 1e20), (9, -1e3, 1e3),
-                                        (10, -12, 12), (11, -20, 20), (4, -1e-3, 1e-3), (10, -1e-3, 1e-3), (12, -20, 20)])
+                                        (10, -12, 12), (11, -20, 20), (4, -1e-3, 1e-3), (10, -1e-3, 1e-3), (12, -20, 20), (13, -1.01, 1.01)])
 def test_det_math_device_equals_host_bitwise(gpu, func, lo, hi):
     """func 4 / 7 / 10 / 11: tanh and sigmoid run a hand-written division core on the device (det::div_benign, packed in
     tanh2) that must reproduce the host's IEEE division bit for bit — 2 M samples each, plus tiny and subnormal inputs"""
