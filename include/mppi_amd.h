@@ -235,6 +235,22 @@ mppi_status mppi_set_nominal_threshold(mppi_handle h, float threshold);
 mppi_status mppi_set_model_blob(mppi_handle h, const char* name, const float* data, size_t count, const int* dims,
                                 int ndims);
 /**
+ * Models with an LSTM in the rollout (bicycle_slip_lstm, racer_dubins_elevation_lstm_steering): new initial hidden / cell
+ * state [H] each for every rollout of the following iterations — LSTMHelper::setHiddenState / setCellState +
+ * copyHiddenCellToDevice (utils/nn_helpers/lstm_helper.cu:476-500) — without re-uploading the weights.
+ */
+mppi_status mppi_set_lstm_initial_state(mppi_handle h, const float* hidden, const float* cell);
+/**
+ * LSTMLSTMHelper::initializeLSTM (utils/nn_helpers/lstm_lstm_helper.cu:50-76) on the host, as in the reference: the
+ * initialiser LSTM(init_input_dim, init_hidden_dim) with output network init_output_layers[num_init_output_layers]
+ * (first entry init_hidden_dim + init_input_dim, last entry 2 * hidden_dim) and parameter blobs in the device helpers'
+ * layouts reads the last init_len samples of buffer[cols][init_input_dim] and emits hidden_cell_out[2 * hidden_dim] =
+ * [hidden | cell], the argument of mppi_set_lstm_initial_state().  No handle and no device involved.
+ */
+mppi_status mppi_lstm_lstm_initialize(int init_input_dim, int init_hidden_dim, const int* init_output_layers,
+                                      int num_init_output_layers, const float* init_lstm_blob, const float* init_output_blob,
+                                      int hidden_dim, int init_len, const float* buffer, int cols, float* hidden_cell_out);
+/**
  * The same data straight from the reference's .npz files (read with cnpy there; a ZIP + NPY reader with zlib here):
  *   kind "dynamics"  FNNHelper::loadParams (utils/nn_helpers/fnn_helper.cu:96-174): keys {prefix}dynamics_W{i},
  *                    {prefix}dynamics_b{i}, i = 1.., float64

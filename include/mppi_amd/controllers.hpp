@@ -109,6 +109,12 @@ public:
   {
     check(mppi_set_model_blob(h_, name.c_str(), data.data(), data.size(), dims.data(), (int)dims.size()));
   }
+  /** LSTMHelper::setHiddenState / setCellState + copyHiddenCellToDevice; produce the values with mppi::LSTMLSTMHelper
+   *  (utils/nn_helpers/lstm_lstm_helper.hpp) from the history buffer, as Dynamics::updateFromBuffer does in the reference */
+  void setLSTMInitialState(const std::vector<float>& hidden, const std::vector<float>& cell)
+  {
+    check(mppi_set_lstm_initial_state(h_, hidden.data(), cell.data()));
+  }
   /** kind: "dynamics" | "lstm" | "costmap" (the reference's .npz layouts; mppi_load_npz) */
   void loadNpz(const std::string& kind, const std::string& path, const std::string& prefix = "")
   {

@@ -33,6 +33,11 @@
 #define U_IND_CLASS(CLASS, enum_val) E_INDEX(CLASS::UncertaintyIndex, enum_val)
 #define U_INDEX(enum_val) U_IND_CLASS(PARENT_CLASS::DYN_PARAMS_T, enum_val)
 #endif
+/* index shorthands on the (non-dependent) parameter struct: the classes below are templates over the derived class */
+#define RDE_S(enum_val) S_IND_CLASS(RacerDubinsElevationParams, enum_val)
+#define RDE_C(enum_val) C_IND_CLASS(RacerDubinsElevationParams, enum_val)
+#define RDE_O(enum_val) O_IND_CLASS(RacerDubinsElevationParams, enum_val)
+#define RDE_U(enum_val) U_IND_CLASS(RacerDubinsElevationParams, enum_val)
 
 /** reference: racer_dubins_elevation.cuh:16-60 */
 struct RacerDubinsElevationParams : public RacerDubinsParams
@@ -80,17 +85,23 @@ struct RacerDubinsElevationParams : public RacerDubinsParams
   float Q_omega_steering = 0.0f;                             ///< yaw from |steering angle|
 };
 
-class RacerDubinsElevation : public MPPI_internal::Dynamics<RacerDubinsElevation, RacerDubinsElevationParams>
+/** reference: RacerDubinsElevationImpl<CLASS_T, PARAMS_T> (racer_dubins_elevation.cuh:62-150); CLASS_T is the model that is
+ *  instantiated (RacerDubinsElevation below, RacerDubinsElevationLSTMSteering in its own header) */
+template <class CLASS_T>
+class RacerDubinsElevationImpl : public MPPI_internal::Dynamics<CLASS_T, RacerDubinsElevationParams>
 {
 public:
-  using PARENT_CLASS = MPPI_internal::Dynamics<RacerDubinsElevation, RacerDubinsElevationParams>;
+  using PARENT_CLASS = MPPI_internal::Dynamics<CLASS_T, RacerDubinsElevationParams>;
+  static constexpr int STATE_DIM = RDE_S(NUM_STATES);
+  static constexpr int CONTROL_DIM = RDE_C(NUM_CONTROLS);
+  static constexpr int OUTPUT_DIM = RDE_O(NUM_OUTPUTS);
   static const int UNCERTAINTY_DIM = U_IND_CLASS(RacerDubinsElevationParams, NUM_UNCERTAINTIES);
   static constexpr int UD = UNCERTAINTY_DIM;
 
   /** the elevation map (texture 0), reference: tex_helper_ of racer_dubins_elevation.cuh:88-96 */
   mppi::texture::TwoDTextureHelper<1, 1> tex_helper_;
 
-  RacerDubinsElevation(hipStream_t stream = nullptr) : PARENT_CLASS(stream)
+  RacerDubinsElevationImpl(hipStream_t stream = nullptr) : PARENT_CLASS(stream)
   {
   }
   static const char* getDynamicsModelName()
@@ -141,9 +152,9 @@ public:
   __device__ inline void computeParametricDelayDeriv(const float* state, const float* control, float* state_der) const
   {
     const RacerDubinsElevationParams& p = this->params_;
-    const bool enable_brake = control[C_INDEX(THROTTLE_BRAKE)] < 0.0f;
-    const float brake_error = (enable_brake * -control[C_INDEX(THROTTLE_BRAKE)] - state[S_INDEX(BRAKE_STATE)]);
-    state_der[S_INDEX(BRAKE_STATE)] = fminf(fmaxf((brake_error > 0) * brake_error * p.brake_delay_constant +
+    const bool enable_brake = control[RDE_C(THROTTLE_BRAKE)] < 0.0f;
+    const float brake_error = (enable_brake * -control[RDE_C(THROTTLE_BRAKE)] - state[RDE_S(BRAKE_STATE)]);
+    state_der[RDE_S(BRAKE_STATE)] = fminf(fmaxf((brake_error > 0) * brake_error * p.brake_delay_constant +
                                                       (brake_error < 0) * brake_error * p.brake_delay_constant_neg,
                                                   -p.max_brake_rate_neg),
                                             p.max_brake_rate_pos);
@@ -151,8 +162,8 @@ public:
   __device__ inline void computeParametricSteerDeriv(const float* state, const float* control, float* state_der) const
   {
     const RacerDubinsElevationParams& p = this->params_;
-    state_der[S_INDEX(STEER_ANGLE)] =
-        fmaxf(fminf((control[C_INDEX(STEER_CMD)] * p.steer_command_angle_scale - state[S_INDEX(STEER_ANGLE)]) *
+    state_der[RDE_S(STEER_ANGLE)] =
+        fmaxf(fminf((control[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - state[RDE_S(STEER_ANGLE)]) *
                         p.steering_constant,
                     p.max_steer_rate),
               -p.max_steer_rate);
@@ -163,32 +174,32 @@ public:
   __device__ inline void computeParametricAccelDeriv(const float* state, const float* control, float* state_der) const
   {
     const RacerDubinsElevationParams& p = this->params_;
-    const float vx = state[S_INDEX(VEL_X)];
+    const float vx = state[RDE_S(VEL_X)];
     const float linear_brake_slope = 0.2f;
-    const bool enable_brake = control[C_INDEX(THROTTLE_BRAKE)] < 0.0f;
+    const bool enable_brake = control[RDE_C(THROTTLE_BRAKE)] < 0.0f;
     const int index = speedRegime(vx);
-    const float brake_state = fminf(fmaxf(state[S_INDEX(BRAKE_STATE)], 0.0f), 0.25f);
+    const float brake_state = fminf(fmaxf(state[RDE_S(BRAKE_STATE)], 0.0f), 0.25f);
     const float c_t = pick3(p.c_t, index), c_b = pick3(p.c_b, index), c_v = pick3(p.c_v, index);
-    float throttle = c_t * control[C_INDEX(THROTTLE_BRAKE)];
+    float throttle = c_t * control[RDE_C(THROTTLE_BRAKE)];
     float brake = c_b * brake_state * (vx >= 0.0f ? -1.0f : 1.0f);
     if (fabsf(vx) <= linear_brake_slope)
     {
-      throttle = c_t * fmaxf(control[C_INDEX(THROTTLE_BRAKE)] - p.low_min_throttle, 0.0f);
+      throttle = c_t * fmaxf(control[RDE_C(THROTTLE_BRAKE)] - p.low_min_throttle, 0.0f);
       brake = c_b * brake_state * -vx;
     }
     float ax = (!enable_brake) * throttle * p.gear_sign + brake - c_v * vx + p.c_0;
     ax = fminf(fmaxf(ax, -p.clamp_ax), p.clamp_ax);
-    if (fabsf(state[S_INDEX(PITCH)]) < 1.57079637050628662109375f)
+    if (fabsf(state[RDE_S(PITCH)]) < 1.57079637050628662109375f)
     {
-      ax -= p.gravity * mppi::det::sin(angle_utils::normalizeAngle(state[S_INDEX(PITCH)]));
+      ax -= p.gravity * mppi::det::sin(angle_utils::normalizeAngle(state[RDE_S(PITCH)]));
     }
-    state_der[S_INDEX(VEL_X)] = ax;
-    state_der[S_INDEX(YAW)] =
-        (vx / p.wheel_base) * mppi::det::tan(angle_utils::normalizeAngle(state[S_INDEX(STEER_ANGLE)] / p.steer_angle_scale));
+    state_der[RDE_S(VEL_X)] = ax;
+    state_der[RDE_S(YAW)] =
+        (vx / p.wheel_base) * mppi::det::tan(angle_utils::normalizeAngle(state[RDE_S(STEER_ANGLE)] / p.steer_angle_scale));
     float s_yaw, c_yaw;
-    mppi::det::sincos(angle_utils::normalizeAngle(state[S_INDEX(YAW)]), &s_yaw, &c_yaw);
-    state_der[S_INDEX(POS_X)] = vx * c_yaw;
-    state_der[S_INDEX(POS_Y)] = vx * s_yaw;
+    mppi::det::sincos(angle_utils::normalizeAngle(state[RDE_S(YAW)]), &s_yaw, &c_yaw);
+    state_der[RDE_S(POS_X)] = vx * c_yaw;
+    state_der[RDE_S(POS_Y)] = vx * s_yaw;
   }
 
   /** racer_dubins_elevation.cu:800-834: Euler step of the six integrated states, as in RacerDubins */
@@ -201,14 +212,14 @@ public:
       float xn = state[i] + state_der[i] * dt;
       switch (i)
       {
-        case S_INDEX(YAW):
+        case RDE_S(YAW):
           xn = angle_utils::normalizeAngle(xn);
           break;
-        case S_INDEX(STEER_ANGLE):
+        case RDE_S(STEER_ANGLE):
           xn = fmaxf(fminf(xn, p.max_steer_angle), -p.max_steer_angle);
-          next_state[S_INDEX(STEER_ANGLE_RATE)] = state_der[S_INDEX(STEER_ANGLE)];
+          next_state[RDE_S(STEER_ANGLE_RATE)] = state_der[RDE_S(STEER_ANGLE)];
           break;
-        case S_INDEX(BRAKE_STATE):
+        case RDE_S(BRAKE_STATE):
           xn = fminf(fmaxf(xn, 0.0f), 1.0f);
           break;
         default:
@@ -222,96 +233,96 @@ public:
   __device__ inline void computeUncertaintyJacobian(const float* state, float* A) const
   {
     const RacerDubinsElevationParams& p = this->params_;
-    const float vx = state[S_INDEX(VEL_X)];
+    const float vx = state[RDE_S(VEL_X)];
     float sin_yaw, cos_yaw;
-    mppi::det::sincos(angle_utils::normalizeAngle(state[S_INDEX(YAW)]), &sin_yaw, &cos_yaw);
-    const float delta = state[S_INDEX(STEER_ANGLE)] / p.steer_angle_scale;
+    mppi::det::sincos(angle_utils::normalizeAngle(state[RDE_S(YAW)]), &sin_yaw, &cos_yaw);
+    const float delta = state[RDE_S(STEER_ANGLE)] / p.steer_angle_scale;
     const float tan_steer_angle = mppi::det::tan(delta);
     const float cos_delta = mppi::det::cos(delta);
     const float cos_2_delta = cos_delta * cos_delta;
     const int index = speedRegime(vx);
-    const float brake_state = fminf(fmaxf(state[S_INDEX(BRAKE_STATE)], 0.0f), 0.25f);
+    const float brake_state = fminf(fmaxf(state[RDE_S(BRAKE_STATE)], 0.0f), 0.25f);
 
-    A[cm(U_INDEX(VEL_X), U_INDEX(VEL_X))] = -pick3(p.c_v, index) - p.K_vel_x - (index == 0 ? 1.0f : 0.0f) * p.c_b[0] * brake_state;
-    A[cm(U_INDEX(VEL_X), U_INDEX(YAW))] = 0.0f;
-    A[cm(U_INDEX(VEL_X), U_INDEX(POS_X))] = -p.K_x * cos_yaw;
-    A[cm(U_INDEX(VEL_X), U_INDEX(POS_Y))] = -p.K_x * sin_yaw;
+    A[cm(RDE_U(VEL_X), RDE_U(VEL_X))] = -pick3(p.c_v, index) - p.K_vel_x - (index == 0 ? 1.0f : 0.0f) * p.c_b[0] * brake_state;
+    A[cm(RDE_U(VEL_X), RDE_U(YAW))] = 0.0f;
+    A[cm(RDE_U(VEL_X), RDE_U(POS_X))] = -p.K_x * cos_yaw;
+    A[cm(RDE_U(VEL_X), RDE_U(POS_Y))] = -p.K_x * sin_yaw;
 
-    A[cm(U_INDEX(YAW), U_INDEX(VEL_X))] = tan_steer_angle / (p.wheel_base);
-    A[cm(U_INDEX(YAW), U_INDEX(YAW))] = -fabsf(vx) * p.K_yaw / (p.wheel_base * cos_2_delta);
-    A[cm(U_INDEX(YAW), U_INDEX(POS_X))] = vx * p.K_y * sin_yaw / (p.wheel_base * cos_2_delta);
-    A[cm(U_INDEX(YAW), U_INDEX(POS_Y))] = -vx * p.K_y * cos_yaw / (p.wheel_base * cos_2_delta);
+    A[cm(RDE_U(YAW), RDE_U(VEL_X))] = tan_steer_angle / (p.wheel_base);
+    A[cm(RDE_U(YAW), RDE_U(YAW))] = -fabsf(vx) * p.K_yaw / (p.wheel_base * cos_2_delta);
+    A[cm(RDE_U(YAW), RDE_U(POS_X))] = vx * p.K_y * sin_yaw / (p.wheel_base * cos_2_delta);
+    A[cm(RDE_U(YAW), RDE_U(POS_Y))] = -vx * p.K_y * cos_yaw / (p.wheel_base * cos_2_delta);
 
-    A[cm(U_INDEX(POS_X), U_INDEX(VEL_X))] = cos_yaw;
-    A[cm(U_INDEX(POS_X), U_INDEX(YAW))] = -sin_yaw * vx;
-    A[cm(U_INDEX(POS_X), U_INDEX(POS_X))] = 0.0f;
-    A[cm(U_INDEX(POS_X), U_INDEX(POS_Y))] = 0.0f;
+    A[cm(RDE_U(POS_X), RDE_U(VEL_X))] = cos_yaw;
+    A[cm(RDE_U(POS_X), RDE_U(YAW))] = -sin_yaw * vx;
+    A[cm(RDE_U(POS_X), RDE_U(POS_X))] = 0.0f;
+    A[cm(RDE_U(POS_X), RDE_U(POS_Y))] = 0.0f;
 
-    A[cm(U_INDEX(POS_Y), U_INDEX(VEL_X))] = sin_yaw;
-    A[cm(U_INDEX(POS_Y), U_INDEX(YAW))] = cos_yaw * vx;
-    A[cm(U_INDEX(POS_Y), U_INDEX(POS_X))] = 0.0f;
-    A[cm(U_INDEX(POS_Y), U_INDEX(POS_Y))] = 0.0f;
+    A[cm(RDE_U(POS_Y), RDE_U(VEL_X))] = sin_yaw;
+    A[cm(RDE_U(POS_Y), RDE_U(YAW))] = cos_yaw * vx;
+    A[cm(RDE_U(POS_Y), RDE_U(POS_X))] = 0.0f;
+    A[cm(RDE_U(POS_Y), RDE_U(POS_Y))] = 0.0f;
   }
 
   /** racer_dubins_elevation.cu:421-506 (device branch): process noise from |a_x|, |v|, steering and the side force */
   __device__ inline void computeQ(const float* state, const float* state_der, float* Q) const
   {
     const RacerDubinsElevationParams& p = this->params_;
-    const float abs_vx = fabsf(state[S_INDEX(VEL_X)]);
-    const float abs_acc_x = fabsf(state_der[S_INDEX(VEL_X)]);
-    const float delta = state[S_INDEX(STEER_ANGLE)] / p.steer_angle_scale;
+    const float abs_vx = fabsf(state[RDE_S(VEL_X)]);
+    const float abs_acc_x = fabsf(state_der[RDE_S(VEL_X)]);
+    const float delta = state[RDE_S(STEER_ANGLE)] / p.steer_angle_scale;
     float sin_yaw, cos_yaw;
-    mppi::det::sincos(angle_utils::normalizeAngle(state[S_INDEX(YAW)]), &sin_yaw, &cos_yaw);
+    mppi::det::sincos(angle_utils::normalizeAngle(state[RDE_S(YAW)]), &sin_yaw, &cos_yaw);
     const float tan_steer_angle = mppi::det::tan(delta);
-    const float sin_roll = mppi::det::sin(angle_utils::normalizeAngle(state[S_INDEX(ROLL)]));
+    const float sin_roll = mppi::det::sin(angle_utils::normalizeAngle(state[RDE_S(ROLL)]));
     const float side_force = (abs_vx * abs_vx) * tan_steer_angle / p.wheel_base + p.gravity * sin_roll;
     const float Q_11 = fabsf(p.Q_y_f * fabsf(side_force) * fmaxf(abs_vx - 2, 0.0f));
-    const int index = speedRegime(state[S_INDEX(VEL_X)]);
+    const int index = speedRegime(state[RDE_S(VEL_X)]);
 #pragma unroll
     for (int i = 0; i < UD * UD; i++)
       Q[i] = 0.0f;
-    Q[cm(U_INDEX(VEL_X), U_INDEX(VEL_X))] = p.Q_x_acc * abs_acc_x + pick3(p.Q_x_v, index) * abs_vx;
-    Q[cm(U_INDEX(YAW), U_INDEX(YAW))] = abs_vx * (p.Q_omega_steering * fabsf(delta) + p.Q_omega_v);
-    Q[cm(U_INDEX(POS_X), U_INDEX(POS_X))] = Q_11 * sin_yaw * sin_yaw;
-    Q[cm(U_INDEX(POS_X), U_INDEX(POS_Y))] = -Q_11 * sin_yaw * cos_yaw;
-    Q[cm(U_INDEX(POS_Y), U_INDEX(POS_Y))] = Q_11 * cos_yaw * cos_yaw;
-    Q[cm(U_INDEX(POS_Y), U_INDEX(POS_X))] = -Q_11 * sin_yaw * cos_yaw;
+    Q[cm(RDE_U(VEL_X), RDE_U(VEL_X))] = p.Q_x_acc * abs_acc_x + pick3(p.Q_x_v, index) * abs_vx;
+    Q[cm(RDE_U(YAW), RDE_U(YAW))] = abs_vx * (p.Q_omega_steering * fabsf(delta) + p.Q_omega_v);
+    Q[cm(RDE_U(POS_X), RDE_U(POS_X))] = Q_11 * sin_yaw * sin_yaw;
+    Q[cm(RDE_U(POS_X), RDE_U(POS_Y))] = -Q_11 * sin_yaw * cos_yaw;
+    Q[cm(RDE_U(POS_Y), RDE_U(POS_Y))] = Q_11 * cos_yaw * cos_yaw;
+    Q[cm(RDE_U(POS_Y), RDE_U(POS_X))] = -Q_11 * sin_yaw * cos_yaw;
   }
 
   /** racer_dubins_elevation.cu:508-565 */
   __device__ static inline void uncertaintyStateToMatrix(const float* state, float* M)
   {
-    M[cm(U_INDEX(VEL_X), U_INDEX(VEL_X))] = state[S_INDEX(UNCERTAINTY_VEL_X)];
-    M[cm(U_INDEX(YAW), U_INDEX(VEL_X))] = state[S_INDEX(UNCERTAINTY_YAW_VEL_X)];
-    M[cm(U_INDEX(POS_X), U_INDEX(VEL_X))] = state[S_INDEX(UNCERTAINTY_POS_X_VEL_X)];
-    M[cm(U_INDEX(POS_Y), U_INDEX(VEL_X))] = state[S_INDEX(UNCERTAINTY_POS_Y_VEL_X)];
-    M[cm(U_INDEX(VEL_X), U_INDEX(YAW))] = state[S_INDEX(UNCERTAINTY_YAW_VEL_X)];
-    M[cm(U_INDEX(YAW), U_INDEX(YAW))] = state[S_INDEX(UNCERTAINTY_YAW)];
-    M[cm(U_INDEX(POS_X), U_INDEX(YAW))] = state[S_INDEX(UNCERTAINTY_POS_X_YAW)];
-    M[cm(U_INDEX(POS_Y), U_INDEX(YAW))] = state[S_INDEX(UNCERTAINTY_POS_Y_YAW)];
-    M[cm(U_INDEX(VEL_X), U_INDEX(POS_X))] = state[S_INDEX(UNCERTAINTY_POS_X_VEL_X)];
-    M[cm(U_INDEX(YAW), U_INDEX(POS_X))] = state[S_INDEX(UNCERTAINTY_POS_X_YAW)];
-    M[cm(U_INDEX(POS_X), U_INDEX(POS_X))] = state[S_INDEX(UNCERTAINTY_POS_X)];
-    M[cm(U_INDEX(POS_Y), U_INDEX(POS_X))] = state[S_INDEX(UNCERTAINTY_POS_X_Y)];
-    M[cm(U_INDEX(VEL_X), U_INDEX(POS_Y))] = state[S_INDEX(UNCERTAINTY_POS_Y_VEL_X)];
-    M[cm(U_INDEX(YAW), U_INDEX(POS_Y))] = state[S_INDEX(UNCERTAINTY_POS_Y_YAW)];
-    M[cm(U_INDEX(POS_X), U_INDEX(POS_Y))] = state[S_INDEX(UNCERTAINTY_POS_X_Y)];
-    M[cm(U_INDEX(POS_Y), U_INDEX(POS_Y))] = state[S_INDEX(UNCERTAINTY_POS_Y)];
+    M[cm(RDE_U(VEL_X), RDE_U(VEL_X))] = state[RDE_S(UNCERTAINTY_VEL_X)];
+    M[cm(RDE_U(YAW), RDE_U(VEL_X))] = state[RDE_S(UNCERTAINTY_YAW_VEL_X)];
+    M[cm(RDE_U(POS_X), RDE_U(VEL_X))] = state[RDE_S(UNCERTAINTY_POS_X_VEL_X)];
+    M[cm(RDE_U(POS_Y), RDE_U(VEL_X))] = state[RDE_S(UNCERTAINTY_POS_Y_VEL_X)];
+    M[cm(RDE_U(VEL_X), RDE_U(YAW))] = state[RDE_S(UNCERTAINTY_YAW_VEL_X)];
+    M[cm(RDE_U(YAW), RDE_U(YAW))] = state[RDE_S(UNCERTAINTY_YAW)];
+    M[cm(RDE_U(POS_X), RDE_U(YAW))] = state[RDE_S(UNCERTAINTY_POS_X_YAW)];
+    M[cm(RDE_U(POS_Y), RDE_U(YAW))] = state[RDE_S(UNCERTAINTY_POS_Y_YAW)];
+    M[cm(RDE_U(VEL_X), RDE_U(POS_X))] = state[RDE_S(UNCERTAINTY_POS_X_VEL_X)];
+    M[cm(RDE_U(YAW), RDE_U(POS_X))] = state[RDE_S(UNCERTAINTY_POS_X_YAW)];
+    M[cm(RDE_U(POS_X), RDE_U(POS_X))] = state[RDE_S(UNCERTAINTY_POS_X)];
+    M[cm(RDE_U(POS_Y), RDE_U(POS_X))] = state[RDE_S(UNCERTAINTY_POS_X_Y)];
+    M[cm(RDE_U(VEL_X), RDE_U(POS_Y))] = state[RDE_S(UNCERTAINTY_POS_Y_VEL_X)];
+    M[cm(RDE_U(YAW), RDE_U(POS_Y))] = state[RDE_S(UNCERTAINTY_POS_Y_YAW)];
+    M[cm(RDE_U(POS_X), RDE_U(POS_Y))] = state[RDE_S(UNCERTAINTY_POS_X_Y)];
+    M[cm(RDE_U(POS_Y), RDE_U(POS_Y))] = state[RDE_S(UNCERTAINTY_POS_Y)];
   }
 
   /** racer_dubins_elevation.cu:567-612: the lower triangle goes back into the state */
   __device__ static inline void uncertaintyMatrixToState(const float* M, float* state)
   {
-    state[S_INDEX(UNCERTAINTY_VEL_X)] = M[cm(U_INDEX(VEL_X), U_INDEX(VEL_X))];
-    state[S_INDEX(UNCERTAINTY_YAW_VEL_X)] = M[cm(U_INDEX(YAW), U_INDEX(VEL_X))];
-    state[S_INDEX(UNCERTAINTY_POS_X_VEL_X)] = M[cm(U_INDEX(POS_X), U_INDEX(VEL_X))];
-    state[S_INDEX(UNCERTAINTY_POS_Y_VEL_X)] = M[cm(U_INDEX(POS_Y), U_INDEX(VEL_X))];
-    state[S_INDEX(UNCERTAINTY_YAW)] = M[cm(U_INDEX(YAW), U_INDEX(YAW))];
-    state[S_INDEX(UNCERTAINTY_POS_X_YAW)] = M[cm(U_INDEX(POS_X), U_INDEX(YAW))];
-    state[S_INDEX(UNCERTAINTY_POS_Y_YAW)] = M[cm(U_INDEX(POS_Y), U_INDEX(YAW))];
-    state[S_INDEX(UNCERTAINTY_POS_X)] = M[cm(U_INDEX(POS_X), U_INDEX(POS_X))];
-    state[S_INDEX(UNCERTAINTY_POS_X_Y)] = M[cm(U_INDEX(POS_Y), U_INDEX(POS_X))];
-    state[S_INDEX(UNCERTAINTY_POS_Y)] = M[cm(U_INDEX(POS_Y), U_INDEX(POS_Y))];
+    state[RDE_S(UNCERTAINTY_VEL_X)] = M[cm(RDE_U(VEL_X), RDE_U(VEL_X))];
+    state[RDE_S(UNCERTAINTY_YAW_VEL_X)] = M[cm(RDE_U(YAW), RDE_U(VEL_X))];
+    state[RDE_S(UNCERTAINTY_POS_X_VEL_X)] = M[cm(RDE_U(POS_X), RDE_U(VEL_X))];
+    state[RDE_S(UNCERTAINTY_POS_Y_VEL_X)] = M[cm(RDE_U(POS_Y), RDE_U(VEL_X))];
+    state[RDE_S(UNCERTAINTY_YAW)] = M[cm(RDE_U(YAW), RDE_U(YAW))];
+    state[RDE_S(UNCERTAINTY_POS_X_YAW)] = M[cm(RDE_U(POS_X), RDE_U(YAW))];
+    state[RDE_S(UNCERTAINTY_POS_Y_YAW)] = M[cm(RDE_U(POS_Y), RDE_U(YAW))];
+    state[RDE_S(UNCERTAINTY_POS_X)] = M[cm(RDE_U(POS_X), RDE_U(POS_X))];
+    state[RDE_S(UNCERTAINTY_POS_X_Y)] = M[cm(RDE_U(POS_Y), RDE_U(POS_X))];
+    state[RDE_S(UNCERTAINTY_POS_Y)] = M[cm(RDE_U(POS_Y), RDE_U(POS_Y))];
   }
 
   /**
@@ -439,32 +450,32 @@ public:
   __device__ static inline void setOutputs(const float* state_der, const float* next_state, float* output)
   {
     const float nan = __builtin_nanf("");
-    output[O_INDEX(BASELINK_VEL_B_X)] = next_state[S_INDEX(VEL_X)];
-    output[O_INDEX(BASELINK_VEL_B_Y)] = 0.0f;
-    output[O_INDEX(BASELINK_POS_I_X)] = next_state[S_INDEX(POS_X)];
-    output[O_INDEX(BASELINK_POS_I_Y)] = next_state[S_INDEX(POS_Y)];
-    output[O_INDEX(PITCH)] = next_state[S_INDEX(PITCH)];
-    output[O_INDEX(ROLL)] = next_state[S_INDEX(ROLL)];
-    output[O_INDEX(YAW)] = next_state[S_INDEX(YAW)];
-    output[O_INDEX(STEER_ANGLE)] = next_state[S_INDEX(STEER_ANGLE)];
-    output[O_INDEX(STEER_ANGLE_RATE)] = next_state[S_INDEX(STEER_ANGLE_RATE)];
-    output[O_INDEX(WHEEL_FORCE_UP_MAX)] = nan;
-    output[O_INDEX(WHEEL_FORCE_FWD_MAX)] = nan;
-    output[O_INDEX(WHEEL_FORCE_SIDE_MAX)] = nan;
-    output[O_INDEX(ACCEL_X)] = state_der[S_INDEX(VEL_X)];
-    output[O_INDEX(ACCEL_Y)] = 0.0f;
-    output[O_INDEX(OMEGA_Z)] = state_der[S_INDEX(YAW)];
-    output[O_INDEX(UNCERTAINTY_VEL_X)] = next_state[S_INDEX(UNCERTAINTY_VEL_X)];
-    output[O_INDEX(UNCERTAINTY_YAW_VEL_X)] = next_state[S_INDEX(UNCERTAINTY_YAW_VEL_X)];
-    output[O_INDEX(UNCERTAINTY_POS_X_VEL_X)] = next_state[S_INDEX(UNCERTAINTY_POS_X_VEL_X)];
-    output[O_INDEX(UNCERTAINTY_POS_Y_VEL_X)] = next_state[S_INDEX(UNCERTAINTY_POS_Y_VEL_X)];
-    output[O_INDEX(UNCERTAINTY_YAW)] = next_state[S_INDEX(UNCERTAINTY_YAW)];
-    output[O_INDEX(UNCERTAINTY_POS_X_YAW)] = next_state[S_INDEX(UNCERTAINTY_POS_X_YAW)];
-    output[O_INDEX(UNCERTAINTY_POS_Y_YAW)] = next_state[S_INDEX(UNCERTAINTY_POS_Y_YAW)];
-    output[O_INDEX(UNCERTAINTY_POS_X)] = next_state[S_INDEX(UNCERTAINTY_POS_X)];
-    output[O_INDEX(UNCERTAINTY_POS_X_Y)] = next_state[S_INDEX(UNCERTAINTY_POS_X_Y)];
-    output[O_INDEX(UNCERTAINTY_POS_Y)] = next_state[S_INDEX(UNCERTAINTY_POS_Y)];
-    output[O_INDEX(TOTAL_VELOCITY)] = fabsf(next_state[S_INDEX(VEL_X)]);
+    output[RDE_O(BASELINK_VEL_B_X)] = next_state[RDE_S(VEL_X)];
+    output[RDE_O(BASELINK_VEL_B_Y)] = 0.0f;
+    output[RDE_O(BASELINK_POS_I_X)] = next_state[RDE_S(POS_X)];
+    output[RDE_O(BASELINK_POS_I_Y)] = next_state[RDE_S(POS_Y)];
+    output[RDE_O(PITCH)] = next_state[RDE_S(PITCH)];
+    output[RDE_O(ROLL)] = next_state[RDE_S(ROLL)];
+    output[RDE_O(YAW)] = next_state[RDE_S(YAW)];
+    output[RDE_O(STEER_ANGLE)] = next_state[RDE_S(STEER_ANGLE)];
+    output[RDE_O(STEER_ANGLE_RATE)] = next_state[RDE_S(STEER_ANGLE_RATE)];
+    output[RDE_O(WHEEL_FORCE_UP_MAX)] = nan;
+    output[RDE_O(WHEEL_FORCE_FWD_MAX)] = nan;
+    output[RDE_O(WHEEL_FORCE_SIDE_MAX)] = nan;
+    output[RDE_O(ACCEL_X)] = state_der[RDE_S(VEL_X)];
+    output[RDE_O(ACCEL_Y)] = 0.0f;
+    output[RDE_O(OMEGA_Z)] = state_der[RDE_S(YAW)];
+    output[RDE_O(UNCERTAINTY_VEL_X)] = next_state[RDE_S(UNCERTAINTY_VEL_X)];
+    output[RDE_O(UNCERTAINTY_YAW_VEL_X)] = next_state[RDE_S(UNCERTAINTY_YAW_VEL_X)];
+    output[RDE_O(UNCERTAINTY_POS_X_VEL_X)] = next_state[RDE_S(UNCERTAINTY_POS_X_VEL_X)];
+    output[RDE_O(UNCERTAINTY_POS_Y_VEL_X)] = next_state[RDE_S(UNCERTAINTY_POS_Y_VEL_X)];
+    output[RDE_O(UNCERTAINTY_YAW)] = next_state[RDE_S(UNCERTAINTY_YAW)];
+    output[RDE_O(UNCERTAINTY_POS_X_YAW)] = next_state[RDE_S(UNCERTAINTY_POS_X_YAW)];
+    output[RDE_O(UNCERTAINTY_POS_Y_YAW)] = next_state[RDE_S(UNCERTAINTY_POS_Y_YAW)];
+    output[RDE_O(UNCERTAINTY_POS_X)] = next_state[RDE_S(UNCERTAINTY_POS_X)];
+    output[RDE_O(UNCERTAINTY_POS_X_Y)] = next_state[RDE_S(UNCERTAINTY_POS_X_Y)];
+    output[RDE_O(UNCERTAINTY_POS_Y)] = next_state[RDE_S(UNCERTAINTY_POS_Y)];
+    output[RDE_O(TOTAL_VELOCITY)] = fabsf(next_state[RDE_S(VEL_X)]);
   }
 
   /** racer_dubins_elevation.cu:836-874 */
@@ -484,10 +495,10 @@ public:
     computeParametricAccelDeriv(x, u, xd);
     updateState(x, xn, xd, dt);
     computeUncertaintyPropagation(x, xd, xn, dt);
-    float roll = x[S_INDEX(ROLL)], pitch = x[S_INDEX(PITCH)], height;
-    computeStaticSettling(xn[S_INDEX(YAW)], xn[S_INDEX(POS_X)], xn[S_INDEX(POS_Y)], roll, pitch, height);
-    xn[S_INDEX(PITCH)] = pitch;
-    xn[S_INDEX(ROLL)] = roll;
+    float roll = x[RDE_S(ROLL)], pitch = x[RDE_S(PITCH)], height;
+    computeStaticSettling(xn[RDE_S(YAW)], xn[RDE_S(POS_X)], xn[RDE_S(POS_Y)], roll, pitch, height);
+    xn[RDE_S(PITCH)] = pitch;
+    xn[RDE_S(ROLL)] = roll;
     mppi::lane_sync();  // BY > 1: nobody overwrites a buffer a sibling lane may still be reading
 #pragma unroll
     for (int i = 0; i < 6; i++)
@@ -495,8 +506,16 @@ public:
 #pragma unroll
     for (int i = 0; i < STATE_DIM; i++)
       next_state[i] = xn[i];
-    output[O_INDEX(BASELINK_POS_I_Z)] = height;
+    output[RDE_O(BASELINK_POS_I_Z)] = height;
     setOutputs(xd, xn, output);
+  }
+};
+
+class RacerDubinsElevation : public RacerDubinsElevationImpl<RacerDubinsElevation>
+{
+public:
+  RacerDubinsElevation(hipStream_t stream = nullptr) : RacerDubinsElevationImpl<RacerDubinsElevation>(stream)
+  {
   }
 };
 

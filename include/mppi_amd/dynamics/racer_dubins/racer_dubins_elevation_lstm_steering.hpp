@@ -1,0 +1,199 @@
+/**
+ * RacerDubinsElevationLSTMSteering plugin — the elevation-map RACER Dubins car whose steering column is a second-order
+ * parametric model plus an LSTM correction evaluated at every step of every rollout.
+ *
+ * Reference: include/mppi/dynamics/racer_dubins/racer_dubins_elevation_lstm_steering.cuh:18-117,
+ * racer_dubins_elevation_lstm_steering.cu:131-167 (device computeLSTMSteering), :169-213 (device step), :115-129 (device
+ * initializeDynamics), :243-268 (device updateState); everything else is RacerDubinsElevationImpl
+ * (racer_dubins_elevation.hpp).  What changes against the plain elevation model:
+ *   steering rate   d(rate)/dt = clamp((k (u1 k_cmd - steer) - rate) k_acc - rate k_drag, +-max_steer_rate) + 5 LSTM(.)[0]
+ *   steering angle  d(steer)/dt = rate;  the rate is an integrated state (rate' = rate + d(rate)/dt dt)
+ *   network input   [0.2 steer, 0.2 rate, u1, 0.2 parametric d(rate)/dt]   (I = 4)
+ *   t = 0 outputs   setOutputs(state, state) — not the base class's state copy
+ * Network: LSTMHelper(I = 4, H, output MLP {H + 4, ..., 1}); the shape the reference's tests use is H = 4, {8, 20, 1}
+ * (tests/dynamics/racer_dubins_elevation_lstm_steering_model_test.cu:26-32) and is the default here; another hidden size
+ * or output network comes with the "lstm_structure" blob before the weights.  The INITIAL hidden / cell state of every
+ * rollout is the tail of the "lstm_weights" blob; producing it from the recent steering history is host work in the
+ * reference too (LSTMLSTMHelper::initializeLSTM on the state-estimator thread, utils/nn_helpers/lstm_lstm_helper.cu:50-76)
+ * — here mppi::LSTMLSTMHelper (utils/nn_helpers/lstm_lstm_helper.hpp, mppi_lstm_lstm_initialize in the C ABI).
+ *
+ * On the device the default shape runs on registers (utils/nn_helpers/lstm_registers.hpp): the 345 parameters come through
+ * the scalar unit, the activations are VGPRs, and between two steps the 2 x 4 recurrent values of a rollout rest in LDS,
+ * laid out [value][slot] so that the lanes of a wave hit 64 different banks (carrying them in members of the lane's copy
+ * of this object would move the whole object — parameters, map descriptor — into scratch memory).  Any other shape falls back to the reference's LDS contract
+ * (utils/nn_helpers/lstm_helper.hpp: parameters in LDS once per block, [h | c | activations] per rollout slot) — same
+ * arithmetic, same bits, several times slower for a network this small.  The rest of the step runs on registers as in
+ * the parent.
+ */
+#ifndef MPPI_AMD_RACER_DUBINS_ELEVATION_LSTM_STEERING_HPP_
+#define MPPI_AMD_RACER_DUBINS_ELEVATION_LSTM_STEERING_HPP_
+
+#include "mppi_amd/dynamics/racer_dubins/racer_dubins_elevation.hpp"
+#include "mppi_amd/utils/nn_helpers/lstm_helper.hpp"
+#include "mppi_amd/utils/nn_helpers/lstm_registers.hpp"
+
+class RacerDubinsElevationLSTMSteering : public RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteering>
+{
+public:
+  using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteering>;
+  static constexpr int LSTM_INPUT_DIM = 4;
+
+  static constexpr int FAST_H = 4, FAST_L1 = 20;
+  using FAST_NET = mppi::LSTMRegisters<LSTM_INPUT_DIM, FAST_H, FAST_L1, 1>;
+
+  /** the prediction LSTM (reference: lstm_lstm_helper_->getLSTMModel(), network_d_ on the device) */
+  mppi::LSTMHelper lstm_;
+  /** true while the network has the shape FAST_NET is compiled for */
+  bool register_form_ = true;
+
+  RacerDubinsElevationLSTMSteering(hipStream_t stream = nullptr) : ELEVATION(stream)
+  {
+    const int out_layers[3] = { 4 + LSTM_INPUT_DIM, 20, 1 };
+    lstm_.setStructure(LSTM_INPUT_DIM, 4, out_layers, 3);
+  }
+  static const char* getDynamicsModelName()
+  {
+    return "RACER Dubins LSTM Steering Model";
+  }
+  /** host: another hidden size / output network, {H, layer sizes of the output MLP ...}; the LSTM input stays 4 */
+  bool setLSTMStructure(const int* desc, int n)
+  {
+    if (n < 3 || desc[1] != desc[0] + LSTM_INPUT_DIM || desc[n - 1] < 1)
+      return false;
+    if (!lstm_.setStructure(LSTM_INPUT_DIM, desc[0], desc + 1, n - 1))
+      return false;
+    register_form_ = (n == 4 && desc[0] == FAST_H && desc[2] == FAST_L1 && desc[3] == 1);
+    return true;
+  }
+  __host__ __device__ int getGrdSharedSizeBytes() const
+  {
+    return register_form_ ? 0 : lstm_.getGrdSharedSizeBytes();
+  }
+  __host__ __device__ int getBlkSharedSizeBytes() const
+  {
+    return register_form_ ? 2 * FAST_H * (int)sizeof(float) : lstm_.getBlkSharedSizeBytes();
+  }
+  /** register form: value i of this lane's rollout slot at theta_s[i * slots + slot] */
+  __device__ static inline void loadRecurrent(const float* theta_s, float (&h)[FAST_H], float (&c)[FAST_H])
+  {
+    const int slots = (int)(blockDim.x * blockDim.z), slot = (int)(blockDim.x * threadIdx.z + threadIdx.x);
+#pragma unroll
+    for (int i = 0; i < FAST_H; i++)
+    {
+      h[i] = theta_s[i * slots + slot];
+      c[i] = theta_s[(FAST_H + i) * slots + slot];
+    }
+  }
+  __device__ static inline void storeRecurrent(float* theta_s, const float (&h)[FAST_H], const float (&c)[FAST_H])
+  {
+    const int slots = (int)(blockDim.x * blockDim.z), slot = (int)(blockDim.x * threadIdx.z + threadIdx.x);
+#pragma unroll
+    for (int i = 0; i < FAST_H; i++)
+    {
+      theta_s[i * slots + slot] = h[i];
+      theta_s[(FAST_H + i) * slots + slot] = c[i];
+    }
+  }
+
+  /** racer_dubins_elevation_lstm_steering.cu:115-129: network parameters and (h0, c0) into LDS, outputs from the state */
+  __device__ inline void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
+                                            float dt)
+  {
+    if (register_form_)
+    {
+      float h[FAST_H], c[FAST_H];
+      FAST_NET::initialState(lstm_.weights_d_, h, c);
+      storeRecurrent(theta_s, h, c);  // this lane's own slot: nothing to synchronise with
+    }
+    else
+      lstm_.initialize(theta_s);
+    int first, stride;
+    mppi::p1::getParallel1DIndex<mppi::p1::Parallel1Dir::THREAD_Y>(first, stride);
+    if (first == 0)
+    {
+      output[RDE_O(BASELINK_POS_I_Z)] = 0.0f;  // not written by setOutputs: defined instead of the buffer's content
+      output[RDE_O(FILLER_1)] = 0.0f;
+      setOutputs(state, state, output);
+    }
+    mppi::lane_sync();
+  }
+
+  /** racer_dubins_elevation_lstm_steering.cu:131-167 */
+  __device__ inline void computeLSTMSteering(const float* state, const float* control, float* state_der,
+                                             float* theta_s) const
+  {
+    const RacerDubinsElevationParams& p = this->params_;
+    const float steer = state[RDE_S(STEER_ANGLE)], rate = state[RDE_S(STEER_ANGLE_RATE)];
+    const float parametric_accel = (control[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - steer) * p.steering_constant;
+    float rate_dot = fmaxf(fminf((parametric_accel - rate) * p.steer_accel_constant - rate * p.steer_accel_drag_constant,
+                                 p.max_steer_rate),
+                           -p.max_steer_rate);
+    // network input; the parametric part is its fourth entry
+    const float input[LSTM_INPUT_DIM] = { steer * 0.2f, rate * 0.2f, control[RDE_C(STEER_CMD)], rate_dot * 0.2f };
+    if (register_form_)
+    {
+      float nn_output[1], h[FAST_H], c[FAST_H];
+      loadRecurrent(theta_s, h, c);
+      FAST_NET::forward(lstm_.weights_d_, lstm_.output_nn_.theta_d_, input, h, c, nn_output);
+      mppi::lane_sync();  // BY > 1: sibling lanes have read the slot before anyone rewrites it (with the same values)
+      storeRecurrent(theta_s, h, c);
+      rate_dot += nn_output[0] * 5.0f;
+    }
+    else
+    {
+      float* input_loc = lstm_.getInputLocation(theta_s);
+      if (__builtin_amdgcn_workitem_id_y() == 0)
+      {
+#pragma unroll
+        for (int i = 0; i < LSTM_INPUT_DIM; i++)
+          input_loc[i] = input[i];
+      }
+      mppi::lane_sync();
+      const float* nn_output = lstm_.forward(nullptr, theta_s);
+      rate_dot += nn_output[0] * 5.0f;
+    }
+    state_der[RDE_S(STEER_ANGLE_RATE)] = rate_dot;
+    state_der[RDE_S(STEER_ANGLE)] = rate;
+  }
+
+  /** racer_dubins_elevation_lstm_steering.cu:243-268: as the parent, but the steering rate is integrated */
+  __device__ inline void updateState(const float* state, float* next_state, const float* state_der, const float dt) const
+  {
+    ELEVATION::updateState(state, next_state, state_der, dt);
+    next_state[RDE_S(STEER_ANGLE_RATE)] = state[RDE_S(STEER_ANGLE_RATE)] + state_der[RDE_S(STEER_ANGLE_RATE)] * dt;
+  }
+
+  /** racer_dubins_elevation_lstm_steering.cu:169-213 */
+  __device__ inline void step(float* state, float* next_state, float* state_der, float* control, float* output,
+                              float* theta_s, const float t, const float dt)
+  {
+    float x[STATE_DIM], xn[STATE_DIM], xd[RDE_S(STEER_ANGLE_RATE) + 1], u[CONTROL_DIM];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+      x[i] = state[i];
+#pragma unroll
+    for (int i = 0; i < CONTROL_DIM; i++)
+      u[i] = control[i];
+    computeParametricDelayDeriv(x, u, xd);
+    computeParametricAccelDeriv(x, u, xd);
+    computeLSTMSteering(x, u, xd, theta_s);
+    updateState(x, xn, xd, dt);
+    computeUncertaintyPropagation(x, xd, xn, dt);
+    float roll = x[RDE_S(ROLL)], pitch = x[RDE_S(PITCH)], height;
+    computeStaticSettling(xn[RDE_S(YAW)], xn[RDE_S(POS_X)], xn[RDE_S(POS_Y)], roll, pitch, height);
+    xn[RDE_S(PITCH)] = pitch;
+    xn[RDE_S(ROLL)] = roll;
+    mppi::lane_sync();
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+      state_der[i] = xd[i];
+    state_der[RDE_S(STEER_ANGLE_RATE)] = xd[RDE_S(STEER_ANGLE_RATE)];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+      next_state[i] = xn[i];
+    output[RDE_O(BASELINK_POS_I_Z)] = height;
+    setOutputs(xd, xn, output);
+  }
+};
+
+#endif

@@ -89,6 +89,13 @@ struct ModelBase
     err = "model has no blob named '" + name + "'";
     return MPPI_ERR_INVALID_ARG;
   }
+  /** LSTMHelper::copyHiddenCellToDevice (lstm_helper.cu:480-500): new initial hidden / cell state of the rollouts' LSTM,
+   *  on the engine's stream without re-uploading the weights; default: the model has no LSTM */
+  virtual mppi_status setLSTMInitialState(const float* hidden, const float* cell, hipStream_t stream, std::string& err)
+  {
+    err = "model has no LSTM";
+    return MPPI_ERR_INVALID_ARG;
+  }
   /** time_specific_std_dev: sigma[D][T][C] table in device memory (owned by the engine), nullptr switches it off */
   virtual void setTimeSpecificStdDev(const float* table_d) = 0;
   /** colored-noise sampler parameters (ColoredNoiseParamsImpl, colored_noise.cuh:45-73); default: Gaussian sampler */
@@ -273,6 +280,15 @@ template <class T>
 struct has_host_leash<T, std::void_t<decltype(std::declval<const T&>().enforceLeash((const float*)nullptr, (const float*)nullptr,
                                                                                      (const float*)nullptr, (float*)nullptr))>>
   : std::true_type
+{
+};
+template <class T, class = void>
+struct has_lstm_structure : std::false_type
+{
+};
+/** dynamics whose LSTM shape can be changed at run time (setLSTMStructure, the "lstm_structure" blob) */
+template <class T>
+struct has_lstm_structure<T, std::void_t<decltype(std::declval<T&>().setLSTMStructure((const int*)nullptr, 0))>> : std::true_type
 {
 };
 template <class T, class = void>
@@ -589,6 +605,25 @@ struct ModelT : ModelBase
         return st;
       }
     }
+    if constexpr (has_lstm_structure<DYN_T>::value)
+    {
+      /* the reference sizes its LSTM from the network file (LSTMHelper(npz), lstm_helper.cu:13-62); here the shape is
+       * {hidden size, output-network layer sizes ...} as floats, given before the weights */
+      if (name == "lstm_structure")
+      {
+        std::vector<int> desc(count);
+        for (size_t i = 0; i < count; i++)
+          desc[i] = (int)data[i];
+        if (!dyn.setLSTMStructure(desc.data(), (int)count))
+        {
+          err = "lstm_structure: expected {H, H + inputs, ..., outputs} with at least one output-network layer";
+          return MPPI_ERR_INVALID_ARG;
+        }
+        dyn.lstm_.weights_d_ = nullptr;  // blobs of the previous shape no longer fit
+        dyn.lstm_.output_nn_.theta_d_ = nullptr;
+        return MPPI_OK;
+      }
+    }
     if constexpr (has_lstm_helper<DYN_T>::value)
     {
       if (name == "lstm_weights")
@@ -670,6 +705,32 @@ struct ModelT : ModelBase
       }
     }
     return ModelBase::setBlob(name, data, count, dims, ndims, stream, err);
+  }
+
+  mppi_status setLSTMInitialState(const float* hidden, const float* cell, hipStream_t stream, std::string& err) override
+  {
+    if constexpr (has_lstm_helper<DYN_T>::value)
+    {
+      if (!weights_d || !dyn.lstm_.weights_d_)
+      {
+        err = "set the 'lstm_weights' blob before the initial hidden / cell state";
+        return MPPI_ERR_STATE;
+      }
+      const int H = dyn.lstm_.HIDDEN_DIM;
+      float* tail = weights_d + dyn.lstm_.LSTM_NUM_PARAMS;
+      hipError_t e = hipMemcpyAsync(tail, hidden, H * sizeof(float), hipMemcpyHostToDevice, stream);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(tail + H, cell, H * sizeof(float), hipMemcpyHostToDevice, stream);
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(stream);  // the caller's buffers are pageable: they may go away after the call
+      if (e != hipSuccess)
+      {
+        err = std::string("LSTM initial state upload: ") + hipGetErrorString(e);
+        return MPPI_ERR_HIP;
+      }
+      return MPPI_OK;
+    }
+    return ModelBase::setLSTMInitialState(hidden, cell, stream, err);
   }
 
   mppi_status setCostmapTransform(const float* r_c1, const float* r_c2, const float* trs) override

@@ -96,6 +96,9 @@ SIGNATURES = {
     "mppi_set_slide_control_scale": (C.c_int, [H, _f32p]),
     "mppi_set_nominal_threshold": (C.c_int, [H, C.c_float]),
     "mppi_set_model_blob": (C.c_int, [H, C.c_char_p, _f32p, C.c_size_t, C.POINTER(C.c_int), C.c_int]),
+    "mppi_set_lstm_initial_state": (C.c_int, [H, _f32p, _f32p]),
+    "mppi_lstm_lstm_initialize": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _f32p, _f32p, C.c_int, C.c_int,
+                                           _f32p, C.c_int, _f32p]),
     "mppi_load_npz": (C.c_int, [H, C.c_char_p, C.c_char_p, C.c_char_p]),
     "mppi_npz_read_array": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),

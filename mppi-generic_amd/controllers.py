@@ -295,6 +295,11 @@ class MPPIController:
         dims = (C.c_int * a.ndim)(*a.shape)
         self._check(self._lib.mppi_set_model_blob(self._h, name.encode(), a.reshape(-1), a.size, dims, a.ndim))
 
+    def setLSTMInitialState(self, hidden, cell):
+        """new initial hidden / cell state of the rollouts' LSTM (LSTMHelper::setHiddenState / setCellState +
+        copyHiddenCellToDevice, utils/nn_helpers/lstm_helper.cu:476-500)"""
+        self._check(self._lib.mppi_set_lstm_initial_state(self._h, _f32(hidden).reshape(-1), _f32(cell).reshape(-1)))
+
     def loadNpz(self, kind, path, prefix=None):
         """model data straight from the reference's .npz layout (kind: "dynamics" | "lstm" | "costmap"); mppi_load_npz"""
         self._check(self._lib.mppi_load_npz(self._h, kind.encode(), str(path).encode(),
@@ -595,6 +600,44 @@ def texture2d_query(data, points, frame, params=None, device=0):
     _op_check(lib, lib.mppi_texture2d_query(d.reshape(-1), w, h, ch, C.byref(p), pts.reshape(-1), pts.shape[0], frame,
                                             out.reshape(-1), device))
     return out
+
+
+class LSTMLSTMHelper:
+    """Host side of the reference's LSTMLSTMHelper (utils/nn_helpers/lstm_lstm_helper.cuh; C++ in
+    include/mppi_amd/utils/nn_helpers/lstm_lstm_helper.hpp): the initialiser LSTM that turns the recent history buffer into
+    the initial (hidden, cell) of the prediction LSTM inside the rollouts.  initializeLSTM() returns them; hand them to
+    controller.setLSTMInitialState()."""
+
+    def __init__(self, init_input_dim, init_hidden_dim, init_output_layers, input_dim, hidden_dim, output_layers, init_len):
+        assert init_output_layers[0] == init_input_dim + init_hidden_dim and init_output_layers[-1] == 2 * hidden_dim
+        self.init_input_dim, self.init_hidden_dim = init_input_dim, init_hidden_dim
+        self.init_output_layers = list(init_output_layers)
+        self.input_dim, self.hidden_dim, self.output_layers, self.init_len = input_dim, hidden_dim, list(output_layers), init_len
+        H, I = init_hidden_dim, init_input_dim
+        self.init_lstm = np.zeros(4 * H * H + 4 * H * I + 6 * H, np.float32)
+        n = sum(self.init_output_layers[i + 1] * (self.init_output_layers[i] + 1) for i in range(len(init_output_layers) - 1))
+        self.init_output = np.zeros(n, np.float32)
+
+    def setInitParams(self, lstm_blob, output_blob):
+        """initialiser parameters in the device helpers' blob layouts (lstm_blob_from_npz_dict(d, "init_") builds them)"""
+        lstm_blob, output_blob = _f32(lstm_blob).reshape(-1), _f32(output_blob).reshape(-1)
+        assert lstm_blob.size == self.init_lstm.size and output_blob.size == self.init_output.size
+        self.init_lstm, self.init_output = lstm_blob.copy(), output_blob.copy()
+
+    def initializeLSTM(self, buffer):
+        """buffer[init_input_dim][cols] as the reference's Eigen matrix (one column per time step); returns (hidden, cell)"""
+        buffer = _f32(buffer)
+        if buffer.ndim != 2 or buffer.shape[0] != self.init_input_dim or buffer.shape[1] < self.init_len:
+            raise ValueError("history buffer must be [init_input_dim][>= init_len]")
+        lib = load_library()
+        cols = buffer.shape[1]
+        samples = np.ascontiguousarray(buffer.T).reshape(-1)
+        out = np.zeros(2 * self.hidden_dim, np.float32)
+        layers = (C.c_int * len(self.init_output_layers))(*self.init_output_layers)
+        _op_check(lib, lib.mppi_lstm_lstm_initialize(self.init_input_dim, self.init_hidden_dim, layers,
+                                                     len(self.init_output_layers), self.init_lstm, self.init_output,
+                                                     self.hidden_dim, self.init_len, samples, cols, out))
+        return out[:self.hidden_dim].copy(), out[self.hidden_dim:].copy()
 
 
 def det_eval(func, x, device=0):

@@ -28,6 +28,7 @@
 #include "mppi_amd/engine/model_instance.hpp"
 #include "reduce_kernels.hpp"
 #include "mppi_amd/utils/texture_helpers/two_d_texture_helper.hpp"
+#include "mppi_amd/utils/nn_helpers/lstm_lstm_helper.hpp"
 
 using namespace mppi;
 using namespace mppi::engine;
@@ -905,6 +906,38 @@ mppi_status mppi_set_model_blob(mppi_handle h, const char* name, const float* da
   return MPPI_OK;
 }
 
+
+mppi_status mppi_set_lstm_initial_state(mppi_handle h, const float* hidden, const float* cell)
+{
+  CHECK_HANDLE(h);
+  if (!hidden || !cell)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_lstm_initial_state: null");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  std::string err;
+  mppi_status st = h->model->setLSTMInitialState(hidden, cell, h->stream, err);
+  return st == MPPI_OK ? MPPI_OK : fail(h, st, err);
+}
+
+mppi_status mppi_lstm_lstm_initialize(int init_input_dim, int init_hidden_dim, const int* init_output_layers,
+                                      int num_init_output_layers, const float* init_lstm_blob, const float* init_output_blob,
+                                      int hidden_dim, int init_len, const float* buffer, int cols, float* hidden_cell_out)
+{
+  if (!init_output_layers || !init_lstm_blob || !init_output_blob || !buffer || !hidden_cell_out || num_init_output_layers < 2)
+    return MPPI_ERR_INVALID_ARG;
+  try
+  {
+    const std::vector<int> init_layers(init_output_layers, init_output_layers + num_init_output_layers);
+    // the prediction network's own shape plays no part in the initialisation (only its hidden size does)
+    mppi::LSTMLSTMHelper helper(init_input_dim, init_hidden_dim, init_layers, 1, hidden_dim, { hidden_dim + 1, 1 }, init_len);
+    helper.getInitModel()->setAllValues(init_lstm_blob, init_output_blob);
+    helper.initializeLSTM(buffer, cols, hidden_cell_out, hidden_cell_out + hidden_dim);
+  }
+  catch (const std::exception&)
+  {
+    return MPPI_ERR_INVALID_ARG;
+  }
+  return MPPI_OK;
+}
 
 /* ---------------------------------------------------------------- .npz model data ---------------------------------- */
 static mppi_status setBlobD(mppi_handle h, const char* name, const std::vector<double>& v, const std::vector<int>& dims)

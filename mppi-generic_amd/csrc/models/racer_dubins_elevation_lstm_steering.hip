@@ -1,0 +1,36 @@
+/**
+ * racer_dubins_elevation_lstm_steering.hip — registered instantiation(s) of libmppi_amd.so: the elevation-map RACER Dubins
+ * car with the LSTM steering column (LSTMHelper I = 4, H = 4, output MLP {8, 20, 1} by default) + QuadraticCost, Gaussian
+ * and colored-noise samplers.
+ *
+ * The analogue of the reference's include/mppi/instantiations/ + src/controllers/ (explicit template instantiations
+ * compiled into shared libraries, e.g. src/controllers/cartpole/cartpole_mppi.cu:30-42).  One translation unit per
+ * model, so a new or changed model recompiles alone (buildlib.py compiles the units in parallel).
+ *
+ * Block shapes: BY == 1 — a rollout is one lane (19 states and the covariance matrices in VGPRs); the LSTM parameters
+ * are shared by the block in LDS and every rollout slot keeps its hidden / cell state there (lstm_helper.hpp).  The
+ * fused rollout kernel only: LSTMHelper::initialize() is a whole-block load with a block barrier, which the
+ * role-pipelined kernel's dynamics waves cannot execute on their own.  For the same reason the trajectory pass after the
+ * iterations (finalize kernel) and the single model step run the two-lane contract form (FIN_BY = 2: every thread of
+ * the block takes part in initialize()), not the one-lane-of-a-wave form of the analytic models.
+ */
+#include "mppi_amd/engine/model_registry.hpp"
+#include "mppi_amd/sampling_distributions/gaussian.hpp"
+#include "mppi_amd/sampling_distributions/colored_noise.hpp"
+#include "mppi_amd/dynamics/racer_dubins/racer_dubins_elevation_lstm_steering.hpp"
+#include "mppi_amd/cost_functions/quadratic_cost/quadratic_cost.hpp"
+
+using namespace mppi;
+using namespace mppi::engine;
+
+using SteeringCost = QuadraticCost<RacerDubinsElevationLSTMSteering, /*SKIP_ZERO_COEFF=*/true>;
+using RacerLSTMSteeringModel =
+    ModelT<RacerDubinsElevationLSTMSteering, SteeringCost,
+           sampling_distributions::GaussianDistribution<RacerDubinsElevationParams>,
+           Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/2, void, Shapes<>, /*PIPELINE=*/false>;
+using RacerLSTMSteeringColoredModel =
+    ModelT<RacerDubinsElevationLSTMSteering, SteeringCost,
+           sampling_distributions::ColoredNoiseDistribution<RacerDubinsElevationParams>, Shapes<Shape<64, 1, 1>>,
+           /*FIN_BY=*/2, void, Shapes<>, /*PIPELINE=*/false>;
+MPPI_REGISTER_MODEL("racer_dubins_elevation_lstm_steering", MPPI_SAMPLER_GAUSSIAN, RacerLSTMSteeringModel, 64, 1)
+MPPI_REGISTER_MODEL("racer_dubins_elevation_lstm_steering", MPPI_SAMPLER_COLORED, RacerLSTMSteeringColoredModel, 64, 1)

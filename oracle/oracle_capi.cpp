@@ -63,12 +63,21 @@ int oracle_set_blob(void* h, const char* name, const float* data, size_t count, 
     auto* m = dynamic_cast<ARNeuralNetModel*>(c->dyn.get());
     return m ? m->setWeights(data, count) : -1;
   }
+  if (n == "lstm_structure")
+  {
+    auto* m = dynamic_cast<RacerDubinsElevationLSTMSteering*>(c->dyn.get());
+    return m ? m->setStructure(data, count) : -1;
+  }
   if (n == "lstm_weights" || n == "lstm_output_weights")
   {
-    auto* m = dynamic_cast<BicycleSlipLSTM*>(c->dyn.get());
-    if (!m)
+    LSTM* net = nullptr;
+    if (auto* m = dynamic_cast<BicycleSlipLSTM*>(c->dyn.get()))
+      net = &m->net;
+    if (auto* m = dynamic_cast<RacerDubinsElevationLSTMSteering*>(c->dyn.get()))
+      net = &m->net;
+    if (!net)
       return -1;
-    std::vector<float>& dst = (n == "lstm_weights") ? m->net.w : m->net.out_net.theta;
+    std::vector<float>& dst = (n == "lstm_weights") ? net->w : net->out_net.theta;
     if (count != dst.size())
       return -1;
     std::copy(data, data + count, dst.begin());

@@ -937,6 +937,77 @@ struct RacerDubinsElevation : Dynamics
   }
 };
 
+/**
+ * reference (DEVICE flavour): dynamics/racer_dubins/racer_dubins_elevation_lstm_steering.cu:131-167 (computeLSTMSteering),
+ * :169-213 (step), :115-129 (initializeDynamics), :243-268 (updateState); the rest is RacerDubinsElevation above.
+ * The reference's own known-answer tests for this class are disabled at this snapshot (TestStep: GTEST_SKIP,
+ * tests/dynamics/racer_dubins_elevation_lstm_steering_model_test.cu:322-324; ComputeDynamics / TestUpdateState commented
+ * out) and its network files are git-LFS stubs, so the pins are: the live property test compareToElevationWithoutSteering
+ * (:775-945 — with a zero network every state, derivative and output except the steering ones equals the plain elevation
+ * model's), the LSTMHelper known answers (tests/test_lstm_helper.py) and the steering equations checked by hand below.
+ */
+struct RacerDubinsElevationLSTMSteering : RacerDubinsElevation
+{
+  LSTM net;
+  RacerDubinsElevationLSTMSteering()
+  {
+    net.setStructure(4, 4, { 8, 20, 1 });
+  }
+  int setStructure(const float* desc, size_t n)
+  {
+    if (n < 3 || (int)desc[1] != (int)desc[0] + 4)
+      return -1;
+    std::vector<int> layers;
+    for (size_t i = 1; i < n; i++)
+      layers.push_back((int)desc[i]);
+    net.setStructure(4, (int)desc[0], layers);
+    return 0;
+  }
+  int scratchFloats() const override
+  {
+    return 2 * net.H;
+  }
+  void initializeDynamics(const float* x, const float* u, float* y, float* theta_s, float t0, float dt) override
+  {
+    for (int i = 0; i < net.H; i++)
+    {
+      theta_s[i] = net.h0()[i];
+      theta_s[net.H + i] = net.c0()[i];
+    }
+    y[O_BASELINK_POS_I_Z] = 0.0f; /* not written by setOutputs: defined (the reference leaves the buffer's content) */
+    y[O_FILLER_1] = 0.0f;
+    setOutputs(x, x, y);
+  }
+  void step(float* x, float* xn, float* xdot, const float* u, float* y, float* theta_s, int t, float dt) override
+  {
+    const mppi_racer_dubins_params& b = p.base;
+    computeDynamics(x, u, xdot, theta_s); /* brake lag and acceleration; the first-order steering lag is replaced below */
+    const float parametric_accel = (u[1] * b.steer_command_angle_scale - x[STEER_ANGLE]) * b.steering_constant;
+    xdot[STEER_ANGLE_RATE] =
+        fmaxf(fminf((parametric_accel - x[STEER_ANGLE_RATE]) * b.steer_accel_constant - x[STEER_ANGLE_RATE] * b.steer_accel_drag_constant,
+                    b.max_steer_rate),
+              -b.max_steer_rate);
+    float in[4];
+    in[0] = x[STEER_ANGLE] * 0.2f;
+    in[1] = x[STEER_ANGLE_RATE] * 0.2f;
+    in[2] = u[1];
+    in[3] = xdot[STEER_ANGLE_RATE] * 0.2f;
+    std::vector<float> nn_out(net.out_net.layers.back());
+    net.forward(in, theta_s, theta_s + net.H, nn_out.data());
+    xdot[STEER_ANGLE_RATE] += nn_out[0] * 5.0f;
+    xdot[STEER_ANGLE] = x[STEER_ANGLE_RATE];
+    updateState(x, xn, xdot, dt);
+    xn[STEER_ANGLE_RATE] = x[STEER_ANGLE_RATE] + xdot[STEER_ANGLE_RATE] * dt;
+    uncertaintyPropagation(x, xdot, xn, dt);
+    float roll = x[ROLL], pitch = x[PITCH], height;
+    staticSettling(xn[YAW], xn[POS_X], xn[POS_Y], roll, pitch, height);
+    y[O_BASELINK_POS_I_Z] = height;
+    xn[PITCH] = pitch;
+    xn[ROLL] = roll;
+    setOutputs(xdot, xn, y);
+  }
+};
+
 /** reference: cost_functions/quadratic_cost/quadratic_cost.cu:39-60 (device), SIM_TIME_HORIZON = 1 */
 struct QuadraticCost28 : Cost
 {
@@ -996,6 +1067,12 @@ inline bool makeModel(const std::string& name, std::unique_ptr<Dynamics>& dyn, s
   {
     dyn.reset(new DoubleIntegratorDynamics());
     cost.reset(new DoubleIntegratorCircleCost());
+    return true;
+  }
+  if (name == "racer_dubins_elevation_lstm_steering")
+  {
+    dyn.reset(new RacerDubinsElevationLSTMSteering());
+    cost.reset(new QuadraticCost28(true));
     return true;
   }
   if (name == "racer_dubins_elevation")

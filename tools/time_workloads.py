@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times optimisation iterations of the registered workloads for several block shapes (HIP events on the engine's
-stream).  Usage: python tools/time_workloads.py [cartpole|autorally|di|lstm] ..."""
+stream).  Usage: python tools/time_workloads.py [cartpole|autorally|di|lstm|racer] ..."""
 import os
 import sys
 
@@ -29,7 +29,7 @@ def run(name, cfg, shapes, n=100):
         eng.close()
 
 
-which = sys.argv[1:] or ["cartpole", "autorally", "di", "lstm"]
+which = sys.argv[1:] or ["cartpole", "autorally", "di", "lstm", "racer"]
 if "cartpole" in which:
     run("cartpole", cartpole_cfg(K=16384, T=100), [(64, 1, 1), (64, 1, 2), (32, 1)])
     run("cartpole", cartpole_cfg(K=2048, T=100), [(64, 1)])
@@ -45,3 +45,14 @@ if "lstm" in which:
     cfg = cartpole_cfg(K=16384, T=100)
     cfg["colored"] = ([1.0], 0.97, 0.0)
     run("cartpole+colored", cfg, [(64, 1, 1), (64, 1, 2)], n=50)
+if "racer" in which:
+    from common import racer_cfg  # noqa: E402
+    from test_racer_dubins_elevation import elevation_cfg  # noqa: E402
+    from test_racer_dubins_lstm_steering import steering_cfg  # noqa: E402
+    run("racer", racer_cfg(K=16384, T=100), [(64, 1, 1), (64, 1, 2)], n=50)
+    run("racer-elev", elevation_cfg(K=16384, T=100), [(64, 1, 1), (64, 1, 2), (32, 1, 2)], n=50)
+    run("racer-flat", elevation_cfg(K=16384, T=100, with_map=False), [(64, 1, 2)], n=50)
+    run("racer-lstm", steering_cfg(K=16384, T=100), [(64, 1, 1), (32, 1, 1)], n=50)
+    cfg = steering_cfg(K=16384, T=100)
+    cfg["colored"] = ([1.0, 1.0], 0.97, 0.0)
+    run("racer-lstm+colored", cfg, [(64, 1, 1)], n=30)
