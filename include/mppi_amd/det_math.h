@@ -484,10 +484,6 @@ MPPI_HD static inline float asin(float x)
   return ::asinf(x);
 #endif
   const float a = fabs(x);
-  if (!(a <= 1.0f))
-    return u2f(0x7fc00000u);
-  if (a < 1.0e-4f)
-    return x;
   const bool upper = a > 0.5f;
   const float z = upper ? 0.5f * (1.0f - a) : a * a;
   const float w = upper ? sqrt(z) : a;
@@ -496,9 +492,10 @@ MPPI_HD static inline float asin(float x)
   p = fma(p, z, 7.4953002686e-2f);
   p = fma(p, z, 1.6666752422e-1f);
   float y = fma(p * z, w, w);
-  if (upper)
-    y = 1.57079637050628662109375f - (y + y);
-  return copysign(y, x);
+  y = upper ? 1.57079637050628662109375f - (y + y) : y;
+  y = copysign(y, x);
+  y = (a < 1.0e-4f) ? x : y;  // selects, not early returns: no divergent branch in a rollout step
+  return (a <= 1.0f) ? y : u2f(0x7fc00000u);
 }
 
 /** x^y for x > 0 as exp(y*log(x)); used only for slowly varying discount factors (|y*log x| small). */

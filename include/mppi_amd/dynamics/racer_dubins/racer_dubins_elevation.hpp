@@ -400,11 +400,10 @@ public:
     const float body_pose[3] = { x, y, 0.0f };
     // front left, front right, rear left, rear right (racer_dubins.cu:363-366)
     const float offsets[4][3] = { { 2.981f, 0.737f, 0.0f }, { 2.981f, -0.737f, 0.0f }, { 0.0f, 0.737f, 0.0f }, { 0.0f, -0.737f, 0.0f } };
-    float h[4];
+    float h[4], world[4][3];
 #pragma unroll
     for (int w = 0; w < 4; w++)
     {
-      float world[3];
 #pragma unroll
       for (int r = 0; r < 3; r++)
       {  // RotatePointByDCM -> gemm1<3, 3, 1>: three terms accumulated from zero, then the body pose
@@ -412,10 +411,10 @@ public:
         acc += M[r][0] * offsets[w][0];
         acc += M[r][1] * offsets[w][1];
         acc += M[r][2] * offsets[w][2];
-        world[r] = acc + body_pose[r];
+        world[w][r] = acc + body_pose[r];
       }
-      tex_helper_.queryTextureAtWorldPose(0, world, &h[w]);
     }
+    tex_helper_.template queryTextureAtWorldPoseBatch<4>(0, world, h);  // the sixteen loads of the four wheels in flight together
     const float front_left_height = h[0], front_right_height = h[1], rear_left_height = h[2], rear_right_height = h[3];
 
     float front_diff = front_left_height - front_right_height;

@@ -87,10 +87,19 @@ struct TwoDTextureHelper
   }
 
   /**
-   * two_d_texture_helper.cu:151-245 (queryTextureCPU): normalised coordinate -> texel units, minus half a cell (values sit
-   * at the cell centres), addressing, then bilinear interpolation between the four neighbours or the nearest texel.
+   * The four taps and weights of one bilinear lookup (two_d_texture_helper.cu:151-245, queryTextureCPU): normalised
+   * coordinate -> texel units, minus half a cell (values sit at the cell centres), addressing, the 2 x 2 neighbourhood.
+   * Branch-free: in border mode an outside point is only FLAGGED and its taps are those of the clamped coordinate (valid
+   * addresses; the caller substitutes the border colour), so that a caller can compute several footprints, issue all their
+   * loads, and only then combine — see queryTextureAtWorldPoseBatch().
    */
-  MPPI_TEX_HD inline void queryTexture(const int index, const float* point, float* out) const
+  struct LinearFootprint
+  {
+    int i11, i12, i21, i22;  ///< texel indices (row-major, before the channel stride): (y_min, x_min), (y_min, x_max), (y_max, ..)
+    float wx0, wx1, wy0, wy1;
+    bool border;
+  };
+  MPPI_TEX_HD inline LinearFootprint linearFootprint(const int index, const float* point) const
   {
     const TextureParams2D& p = textures_[index];
     const int w = p.width, h = p.height;
@@ -99,44 +108,118 @@ struct TwoDTextureHelper
     // a NaN coordinate (a diverged rollout) would reach (int)floorf(NaN); it samples texel 0 like ARStandardCost's lookup
     qx = (qx == qx) ? qx : 0.0f;
     qy = (qy == qy) ? qy : 0.0f;
-    bool border = false;
-    if (p.address_mode[0] == ADDRESS_CLAMP)
-      qx = (qx > (float)(w - 1)) ? (float)(w - 1) : ((qx <= 0.0f) ? 0.0f : qx);
-    else
-      border = border || (qx > (float)(w - 1)) || (qx <= 0.0f);
-    if (p.address_mode[1] == ADDRESS_CLAMP)
-      qy = (qy > (float)(h - 1)) ? (float)(h - 1) : ((qy <= 0.0f) ? 0.0f : qy);
-    else
-      border = border || (qy > (float)(h - 1)) || (qy <= 0.0f);
-    if (border)
-    {
-      for (int ch = 0; ch < NC; ch++)
-        out[ch] = p.border_color[ch];
-      return;
-    }
-    if (p.filter_mode == FILTER_POINT)
-    {
-      const int idx = (int)roundf(qy) * w + (int)roundf(qx);
-      for (int ch = 0; ch < NC; ch++)
-        out[ch] = p.data[(size_t)idx * NC + ch];
-      return;
-    }
+    LinearFootprint f;
+    const bool out_x = (qx > (float)(w - 1)) || (qx <= 0.0f), out_y = (qy > (float)(h - 1)) || (qy <= 0.0f);
+    f.border = (p.address_mode[0] != ADDRESS_CLAMP && out_x) || (p.address_mode[1] != ADDRESS_CLAMP && out_y);
+    // clamp addressing; for an inside point of border addressing these are the identity
+    qx = (qx > (float)(w - 1)) ? (float)(w - 1) : ((qx <= 0.0f) ? 0.0f : qx);
+    qy = (qy > (float)(h - 1)) ? (float)(h - 1) : ((qy <= 0.0f) ? 0.0f : qy);
     // a 1-texel axis has no second sample: both taps read texel 0 (weights still sum to one)
     const int x_min = max(min((int)floorf(qx), w - 2), 0), x_max = min(x_min + 1, w - 1) > x_min ? x_min + 1 : x_min;
     const int y_min = max(min((int)floorf(qy), h - 2), 0), y_max = min(y_min + 1, h - 1) > y_min ? y_min + 1 : y_min;
-    // weights exactly as the reference writes them: (x_max - q) / (x_max - x_min) with the denominator 1
-    const float wx0 = (x_max > x_min) ? ((float)x_max - qx) / (float)(x_max - x_min) : 1.0f;
-    const float wx1 = (x_max > x_min) ? (qx - (float)x_min) / (float)(x_max - x_min) : 0.0f;
-    const float wy0 = (y_max > y_min) ? ((float)y_max - qy) / (float)(y_max - y_min) : 1.0f;
-    const float wy1 = (y_max > y_min) ? (qy - (float)y_min) / (float)(y_max - y_min) : 0.0f;
+    // the reference writes (x_max - q) / (x_max - x_min); the denominator is 1 whenever there are two taps, and a division
+    // by 1.0f returns its numerator bit for bit
+    f.wx0 = (x_max > x_min) ? ((float)x_max - qx) : 1.0f;
+    f.wx1 = (x_max > x_min) ? (qx - (float)x_min) : 0.0f;
+    f.wy0 = (y_max > y_min) ? ((float)y_max - qy) : 1.0f;
+    f.wy1 = (y_max > y_min) ? (qy - (float)y_min) : 0.0f;
+    f.i11 = y_min * w + x_min;
+    f.i12 = y_min * w + x_max;
+    f.i21 = y_max * w + x_min;
+    f.i22 = y_max * w + x_max;
+    return f;
+  }
+  /** the interpolation itself, in the reference's order: along x on both rows, then along y */
+  MPPI_TEX_HD static inline float interpolate(const LinearFootprint& f, const float q11, const float q12, const float q21,
+                                              const float q22)
+  {
+    const float lo = q11 * f.wx0 + q12 * f.wx1;
+    const float hi = q21 * f.wx0 + q22 * f.wx1;
+    return lo * f.wy0 + hi * f.wy1;
+  }
+
+  /** two_d_texture_helper.cu:151-245 (queryTextureCPU): bilinear interpolation or the nearest texel, clamp or border */
+  MPPI_TEX_HD inline void queryTexture(const int index, const float* point, float* out) const
+  {
+    const TextureParams2D& p = textures_[index];
+    if (p.filter_mode == FILTER_POINT)
+    {
+      const int w = p.width, h = p.height;
+      float qx = point[0] * (float)w - 0.5f;
+      float qy = point[1] * (float)h - 0.5f;
+      qx = (qx == qx) ? qx : 0.0f;
+      qy = (qy == qy) ? qy : 0.0f;
+      bool border = false;
+      if (p.address_mode[0] == ADDRESS_CLAMP)
+        qx = (qx > (float)(w - 1)) ? (float)(w - 1) : ((qx <= 0.0f) ? 0.0f : qx);
+      else
+        border = border || (qx > (float)(w - 1)) || (qx <= 0.0f);
+      if (p.address_mode[1] == ADDRESS_CLAMP)
+        qy = (qy > (float)(h - 1)) ? (float)(h - 1) : ((qy <= 0.0f) ? 0.0f : qy);
+      else
+        border = border || (qy > (float)(h - 1)) || (qy <= 0.0f);
+      const int idx = border ? 0 : (int)roundf(qy) * w + (int)roundf(qx);
+      for (int ch = 0; ch < NC; ch++)
+        out[ch] = border ? p.border_color[ch] : p.data[(size_t)idx * NC + ch];
+      return;
+    }
+    const LinearFootprint f = linearFootprint(index, point);
     for (int ch = 0; ch < NC; ch++)
     {
-      const float q11 = p.data[((size_t)y_min * w + x_min) * NC + ch], q12 = p.data[((size_t)y_min * w + x_max) * NC + ch];
-      const float q21 = p.data[((size_t)y_max * w + x_min) * NC + ch], q22 = p.data[((size_t)y_max * w + x_max) * NC + ch];
-      const float lo = q11 * wx0 + q12 * wx1;
-      const float hi = q21 * wx0 + q22 * wx1;
-      out[ch] = lo * wy0 + hi * wy1;
+      const float v = interpolate(f, p.data[(size_t)f.i11 * NC + ch], p.data[(size_t)f.i12 * NC + ch],
+                                  p.data[(size_t)f.i21 * NC + ch], p.data[(size_t)f.i22 * NC + ch]);
+      out[ch] = f.border ? p.border_color[ch] : v;
     }
+  }
+
+  /**
+   * N lookups at world poses whose loads are all in flight together: footprints first, then the 4 N NC loads, then the
+   * interpolations.  One lane per rollout sees a full memory round trip per dependent load; a loop over
+   * queryTextureAtWorldPose() pays it N times (the elevation-map RACER step: four wheels).  Same values as N single
+   * calls.  world: [N][3], out: [N][NC].
+   */
+  template <int N>
+  MPPI_TEX_HD inline void queryTextureAtWorldPoseBatch(const int index, const float (*world)[3], float* out) const
+  {
+    const TextureParams2D& p = textures_[index];
+    if (p.filter_mode == FILTER_POINT)
+    {
+      for (int n = 0; n < N; n++)
+        queryTextureAtWorldPose(index, world[n], out + n * NC);
+      return;
+    }
+    LinearFootprint f[N];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int n = 0; n < N; n++)
+    {
+      float map[3], tex[3];
+      worldPoseToMapPose(index, world[n], map);
+      mapPoseToTexCoord(index, map, tex);
+      f[n] = linearFootprint(index, tex);
+    }
+    float q[N][4 * NC];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int n = 0; n < N; n++)
+      for (int ch = 0; ch < NC; ch++)
+      {
+        q[n][4 * ch + 0] = p.data[(size_t)f[n].i11 * NC + ch];
+        q[n][4 * ch + 1] = p.data[(size_t)f[n].i12 * NC + ch];
+        q[n][4 * ch + 2] = p.data[(size_t)f[n].i21 * NC + ch];
+        q[n][4 * ch + 3] = p.data[(size_t)f[n].i22 * NC + ch];
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int n = 0; n < N; n++)
+      for (int ch = 0; ch < NC; ch++)
+      {
+        const float v = interpolate(f[n], q[n][4 * ch + 0], q[n][4 * ch + 1], q[n][4 * ch + 2], q[n][4 * ch + 3]);
+        out[n * NC + ch] = f[n].border ? p.border_color[ch] : v;
+      }
   }
 
   /** texture_helper.cu:274-280 */
