@@ -145,7 +145,8 @@ public:
    *  table into scratch memory) */
   __device__ static inline float pick3(const float (&a)[3], const int index)
   {
-    return index == 0 ? a[0] : (index == 1 ? a[1] : a[2]);
+    const float a0 = a[0], a1 = a[1], a2 = a[2];  // three scalar loads, then selects (not a select of three addresses)
+    return index == 0 ? a0 : (index == 1 ? a1 : a2);
   }
 
   /** racer_dubins.cu:281-293 (brake lag, faster on release) and :295-305 (steering lag) */
@@ -169,9 +170,39 @@ public:
               -p.max_steer_rate);
   }
 
+  /**
+   * Every trigonometric value a step takes from the CURRENT state, evaluated once (the reference re-evaluates the same
+   * expressions in computeParametricAccelDeriv, computeUncertaintyJacobian, computeQ and Euler2DCM_NWU).  det::tan is
+   * sin / cos of one det::sincos, det::sin and det::cos are its two results, so sharing them changes no bit.
+   */
+  struct StepTrig
+  {
+    float sin_yaw, cos_yaw;      ///< of normalizeAngle(yaw)
+    float tan_steer_n;           ///< tan(normalizeAngle(steer / steer_angle_scale)): the yaw rate
+    float tan_delta, cos_delta;  ///< of steer / steer_angle_scale, not wrapped: Jacobian and process noise
+    float sin_pitch, cos_pitch;  ///< of normalizeAngle(pitch): gravity, body rotation
+    float sin_roll, cos_roll;    ///< of normalizeAngle(roll): side force, body rotation
+  };
+  __device__ inline StepTrig stateTrig(const float* state) const
+  {
+    StepTrig g;
+    const float delta = state[RDE_S(STEER_ANGLE)] / this->params_.steer_angle_scale;
+    float s, c;
+    mppi::det::sincos(angle_utils::normalizeAngle(state[RDE_S(YAW)]), &g.sin_yaw, &g.cos_yaw);
+    mppi::det::sincos(angle_utils::normalizeAngle(delta), &s, &c);
+    g.tan_steer_n = s / c;
+    mppi::det::sincos(delta, &s, &c);
+    g.tan_delta = s / c;
+    g.cos_delta = c;
+    mppi::det::sincos(angle_utils::normalizeAngle(state[RDE_S(PITCH)]), &g.sin_pitch, &g.cos_pitch);
+    mppi::det::sincos(angle_utils::normalizeAngle(state[RDE_S(ROLL)]), &g.sin_roll, &g.cos_roll);
+    return g;
+  }
+
   /** racer_dubins_elevation.cu:753-798: longitudinal acceleration per speed regime, clamp, gravity along the pitch; yaw
    *  rate of the bicycle; position rate */
-  __device__ inline void computeParametricAccelDeriv(const float* state, const float* control, float* state_der) const
+  __device__ inline void computeParametricAccelDeriv(const float* state, const float* control, float* state_der,
+                                                     const StepTrig& g) const
   {
     const RacerDubinsElevationParams& p = this->params_;
     const float vx = state[RDE_S(VEL_X)];
@@ -191,15 +222,12 @@ public:
     ax = fminf(fmaxf(ax, -p.clamp_ax), p.clamp_ax);
     if (fabsf(state[RDE_S(PITCH)]) < 1.57079637050628662109375f)
     {
-      ax -= p.gravity * mppi::det::sin(angle_utils::normalizeAngle(state[RDE_S(PITCH)]));
+      ax -= p.gravity * g.sin_pitch;
     }
     state_der[RDE_S(VEL_X)] = ax;
-    state_der[RDE_S(YAW)] =
-        (vx / p.wheel_base) * mppi::det::tan(angle_utils::normalizeAngle(state[RDE_S(STEER_ANGLE)] / p.steer_angle_scale));
-    float s_yaw, c_yaw;
-    mppi::det::sincos(angle_utils::normalizeAngle(state[RDE_S(YAW)]), &s_yaw, &c_yaw);
-    state_der[RDE_S(POS_X)] = vx * c_yaw;
-    state_der[RDE_S(POS_Y)] = vx * s_yaw;
+    state_der[RDE_S(YAW)] = (vx / p.wheel_base) * g.tan_steer_n;
+    state_der[RDE_S(POS_X)] = vx * g.cos_yaw;
+    state_der[RDE_S(POS_Y)] = vx * g.sin_yaw;
   }
 
   /** racer_dubins_elevation.cu:800-834: Euler step of the six integrated states, as in RacerDubins */
@@ -230,16 +258,13 @@ public:
   }
 
   /** racer_dubins_elevation.cu:336-419 (device branch): A = df/dx + df/du K of the (v, yaw, x, y) error dynamics */
-  __device__ inline void computeUncertaintyJacobian(const float* state, float* A) const
+  __device__ inline void computeUncertaintyJacobian(const float* state, const StepTrig& g, float* A) const
   {
     const RacerDubinsElevationParams& p = this->params_;
     const float vx = state[RDE_S(VEL_X)];
-    float sin_yaw, cos_yaw;
-    mppi::det::sincos(angle_utils::normalizeAngle(state[RDE_S(YAW)]), &sin_yaw, &cos_yaw);
-    const float delta = state[RDE_S(STEER_ANGLE)] / p.steer_angle_scale;
-    const float tan_steer_angle = mppi::det::tan(delta);
-    const float cos_delta = mppi::det::cos(delta);
-    const float cos_2_delta = cos_delta * cos_delta;
+    const float sin_yaw = g.sin_yaw, cos_yaw = g.cos_yaw;
+    const float tan_steer_angle = g.tan_delta;
+    const float cos_2_delta = g.cos_delta * g.cos_delta;
     const int index = speedRegime(vx);
     const float brake_state = fminf(fmaxf(state[RDE_S(BRAKE_STATE)], 0.0f), 0.25f);
 
@@ -265,16 +290,15 @@ public:
   }
 
   /** racer_dubins_elevation.cu:421-506 (device branch): process noise from |a_x|, |v|, steering and the side force */
-  __device__ inline void computeQ(const float* state, const float* state_der, float* Q) const
+  __device__ inline void computeQ(const float* state, const float* state_der, const StepTrig& g, float* Q) const
   {
     const RacerDubinsElevationParams& p = this->params_;
     const float abs_vx = fabsf(state[RDE_S(VEL_X)]);
     const float abs_acc_x = fabsf(state_der[RDE_S(VEL_X)]);
     const float delta = state[RDE_S(STEER_ANGLE)] / p.steer_angle_scale;
-    float sin_yaw, cos_yaw;
-    mppi::det::sincos(angle_utils::normalizeAngle(state[RDE_S(YAW)]), &sin_yaw, &cos_yaw);
-    const float tan_steer_angle = mppi::det::tan(delta);
-    const float sin_roll = mppi::det::sin(angle_utils::normalizeAngle(state[RDE_S(ROLL)]));
+    const float sin_yaw = g.sin_yaw, cos_yaw = g.cos_yaw;
+    const float tan_steer_angle = g.tan_delta;
+    const float sin_roll = g.sin_roll;
     const float side_force = (abs_vx * abs_vx) * tan_steer_angle / p.wheel_base + p.gravity * sin_roll;
     const float Q_11 = fabsf(p.Q_y_f * fabsf(side_force) * fmaxf(abs_vx - 2, 0.0f));
     const int index = speedRegime(state[RDE_S(VEL_X)]);
@@ -330,10 +354,10 @@ public:
    * (matrix_mult_utils.cuh:82-192): accumulator from zero, k ascending, one multiply and one add per term.
    */
   __device__ inline void computeUncertaintyPropagation(const float* state, const float* state_der, float* next_state,
-                                                       const float dt) const
+                                                       const float dt, const StepTrig& g) const
   {
     float A[UD * UD], Sigma_a[UD * UD], Sigma_b[UD * UD];
-    computeUncertaintyJacobian(state, A);
+    computeUncertaintyJacobian(state, g, A);
     uncertaintyStateToMatrix(state, Sigma_a);
 #pragma unroll
     for (int i = 0; i < UD * UD; i++)
@@ -360,34 +384,17 @@ public:
           acc += Sigma_b[cm(m, k)] * A[cm(n, k)];
         Sigma_a[cm(m, n)] = acc;
       }
-    computeQ(state, state_der, Sigma_b);
+    computeQ(state, state_der, g, Sigma_b);
 #pragma unroll
     for (int i = 0; i < UD * UD; i++)
       Sigma_a[i] += Sigma_b[i] * dt;
     uncertaintyMatrixToState(Sigma_a, next_state);
   }
 
-  /**
-   * RACER::computeStaticSettling (racer_dubins.cu:358-434): the four wheel contact points of the body at (x, y, yaw) with
-   * the CURRENT roll and pitch are looked up in the elevation map; roll and pitch for the next state follow from the
-   * height differences across the track width (2 x 0.737 m) and the wheel base (2.981 m).
-   */
-  __device__ inline void computeStaticSettling(const float yaw, const float x, const float y, float& roll, float& pitch,
-                                               float& height) const
+  /** Euler2DCM_NWU, device branch (math_utils.h:457-482): roll / pitch of the CURRENT state (g), yaw of the next one */
+  __device__ static inline void bodyRotation(const StepTrig& g, const float sin_psi, const float cos_psi, float (&M)[3][3])
   {
-    height = 0.0f;
-    if (!tex_helper_.checkTextureUse(0))
-    {
-      roll = 0.0f;
-      pitch = 0.0f;
-      return;
-    }
-    // Euler2DCM_NWU, device branch (math_utils.h:457-482)
-    float sin_phi, cos_phi, sin_theta, cos_theta, sin_psi, cos_psi;
-    mppi::det::sincos(angle_utils::normalizeAngle(roll), &sin_phi, &cos_phi);
-    mppi::det::sincos(angle_utils::normalizeAngle(pitch), &sin_theta, &cos_theta);
-    mppi::det::sincos(angle_utils::normalizeAngle(yaw), &sin_psi, &cos_psi);
-    float M[3][3];
+    const float sin_phi = g.sin_roll, cos_phi = g.cos_roll, sin_theta = g.sin_pitch, cos_theta = g.cos_pitch;
     M[0][0] = cos_theta * cos_psi;
     M[0][1] = sin_phi * sin_theta * cos_psi - cos_phi * sin_psi;
     M[0][2] = cos_phi * sin_theta * cos_psi + sin_phi * sin_psi;
@@ -397,44 +404,43 @@ public:
     M[2][0] = -sin_theta;
     M[2][1] = sin_phi * cos_theta;
     M[2][2] = cos_phi * cos_theta;
+  }
+  /** bodyOffsetToWorldPoseEuler (math_utils.h:585-597) of a wheel contact point (off_x, off_y, 0): RotatePointByDCM is
+   *  gemm1<3, 3, 1>, three terms accumulated from zero, then the body pose (x, y, 0) */
+  __device__ static inline void wheelWorldPoint(const float (&M)[3][3], const float off_x, const float off_y, const float x,
+                                                const float y, float (&world)[3])
+  {
     const float body_pose[3] = { x, y, 0.0f };
-    // front left, front right, rear left, rear right (racer_dubins.cu:363-366)
-    const float offsets[4][3] = { { 2.981f, 0.737f, 0.0f }, { 2.981f, -0.737f, 0.0f }, { 0.0f, 0.737f, 0.0f }, { 0.0f, -0.737f, 0.0f } };
-    float h[4], world[4][3];
 #pragma unroll
-    for (int w = 0; w < 4; w++)
+    for (int r = 0; r < 3; r++)
     {
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-      {  // RotatePointByDCM -> gemm1<3, 3, 1>: three terms accumulated from zero, then the body pose
-        float acc = 0.0f;
-        acc += M[r][0] * offsets[w][0];
-        acc += M[r][1] * offsets[w][1];
-        acc += M[r][2] * offsets[w][2];
-        world[w][r] = acc + body_pose[r];
-      }
+      float acc = 0.0f;
+      acc += M[r][0] * off_x;
+      acc += M[r][1] * off_y;
+      acc += M[r][2] * 0.0f;
+      world[r] = acc + body_pose[r];
     }
-    tex_helper_.template queryTextureAtWorldPoseBatch<4>(0, world, h);  // the sixteen loads of the four wheels in flight together
-    const float front_left_height = h[0], front_right_height = h[1], rear_left_height = h[2], rear_right_height = h[3];
-
-    float front_diff = front_left_height - front_right_height;
-    front_diff = fmaxf(fminf(front_diff, 0.736f * 2.0f), -0.736f * 2.0f);
-    float rear_diff = rear_left_height - rear_right_height;
-    rear_diff = fmaxf(fminf(rear_diff, 0.736f * 2.0f), -0.736f * 2.0f);
-    const float front_roll = mppi::det::asin(front_diff / (0.737f * 2.0f));
-    const float rear_roll = mppi::det::asin(rear_diff / (0.737f * 2.0f));
-    roll = (front_roll + rear_roll) / 2.0f;
-
-    float left_diff = rear_left_height - front_left_height;
-    left_diff = fmaxf(fminf(left_diff, 2.98f), -2.98f);
-    float right_diff = rear_right_height - front_right_height;
-    right_diff = fmaxf(fminf(right_diff, 2.98f), -2.98f);
-    const float left_pitch = mppi::det::asin((left_diff) / 2.981f);
-    const float right_pitch = mppi::det::asin((right_diff) / 2.981f);
-    pitch = (left_pitch + right_pitch) / 2.0f;
-
-    height = (rear_left_height + rear_right_height) / 2.0f;
-
+  }
+  /** which = 0 front roll, 1 rear roll, 2 left pitch, 3 right pitch: the clamped height difference over the track width
+   *  (2 x 0.737 m) or the wheel base (2.981 m) whose asin is that angle; h = heights front-left, front-right, rear-left,
+   *  rear-right (racer_dubins.cu:389-404) */
+  __device__ static inline float settlingSine(const int which, const float (&h)[4])
+  {
+    const bool roll_pair = which < 2;
+    const float a = which == 0 ? h[0] : (which == 1 ? h[2] : (which == 2 ? h[2] : h[3]));
+    const float b = which == 0 ? h[1] : (which == 1 ? h[3] : (which == 2 ? h[0] : h[1]));
+    const float lim = roll_pair ? 0.736f * 2.0f : 2.98f;
+    const float den = roll_pair ? 0.737f * 2.0f : 2.981f;
+    float diff = a - b;
+    diff = fmaxf(fminf(diff, lim), -lim);
+    return diff / den;
+  }
+  /** racer_dubins.cu:393-424: roll, pitch, height from the four angles and the rear heights; non-finite results replaced */
+  __device__ static inline void settle(const float (&angle)[4], const float (&h)[4], float& roll, float& pitch, float& height)
+  {
+    roll = (angle[0] + angle[1]) / 2.0f;
+    pitch = (angle[2] + angle[3]) / 2.0f;
+    height = (h[2] + h[3]) / 2.0f;
     // 2 pi: a rotation that accidentally uses such a value is the identity
     const float two_pi = 2.0f * 3.14159274101257324219f;
     if (!isfinite(roll) || fabsf(roll) > 3.14159274101257324219f)
@@ -443,6 +449,45 @@ public:
       pitch = two_pi;
     if (!isfinite(height))
       height = 0.0f;
+  }
+  /** front left, front right, rear left, rear right (racer_dubins.cu:363-366) */
+  __device__ static inline float wheelOffsetX(const int w)
+  {
+    return w < 2 ? 2.981f : 0.0f;
+  }
+  __device__ static inline float wheelOffsetY(const int w)
+  {
+    return (w & 1) ? -0.737f : 0.737f;
+  }
+
+  /**
+   * RACER::computeStaticSettling (racer_dubins.cu:358-434): the four wheel contact points of the body at (x, y, yaw) with
+   * the CURRENT roll and pitch are looked up in the elevation map; roll and pitch for the next state follow from the
+   * height differences across the track width and the wheel base.
+   */
+  __device__ inline void computeStaticSettling(const float yaw, const float x, const float y, const StepTrig& g, float& roll,
+                                               float& pitch, float& height) const
+  {
+    height = 0.0f;
+    if (!tex_helper_.checkTextureUse(0))
+    {
+      roll = 0.0f;
+      pitch = 0.0f;
+      return;
+    }
+    float sin_psi, cos_psi, M[3][3];
+    mppi::det::sincos(angle_utils::normalizeAngle(yaw), &sin_psi, &cos_psi);
+    bodyRotation(g, sin_psi, cos_psi, M);
+    float h[4], world[4][3];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+      wheelWorldPoint(M, wheelOffsetX(w), wheelOffsetY(w), x, y, world[w]);
+    tex_helper_.template queryTextureAtWorldPoseBatch<4>(0, world, h);  // the sixteen loads of the four wheels in flight together
+    float angle[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+      angle[w] = mppi::det::asin(settlingSine(w, h));
+    settle(angle, h, roll, pitch, height);
   }
 
   /** racer_dubins_elevation.cu:72-237: every output but BASELINK_POS_I_Z (static settling) and FILLER_1 */
@@ -477,6 +522,147 @@ public:
     output[RDE_O(TOTAL_VELOCITY)] = fabsf(next_state[RDE_S(VEL_X)]);
   }
 
+  /* ---------------------------------------------------------------------------------------------------------------
+   * Four lanes per rollout (REPLICATED_LANES = 4; see RacerDubinsElevationQuad below): lane = column + 16 * replica.
+   * ------------------------------------------------------------------------------------------------------------- */
+  /** value of replica `src` of this lane's rollout */
+  __device__ static inline float fromReplica(const float v, const int src)
+  {
+    return __shfl(v, (int)(threadIdx.x & 15) + 16 * src, 64);
+  }
+  /** out[r] = v of replica r */
+  __device__ static inline void allReplicas(const float v, float (&out)[4])
+  {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      out[r] = fromReplica(v, r);
+  }
+  __device__ static inline float pick4(const int r, const float a, const float b, const float c, const float d)
+  {
+    return r == 0 ? a : (r == 1 ? b : (r == 2 ? c : d));
+  }
+  /**
+   * One step with the work of a rollout shared out over its four replica lanes; every replica holds the whole state
+   * before and after.  steer(x, u, xd) fills the steering entries of the derivative, post(x, xd, xn) runs after the
+   * Euler update of the six integrated states (the LSTM-steering model integrates its steering rate there).
+   * XD: entries of the derivative the model produces (6, or 9 with the steering-rate derivative).
+   */
+  template <int XD, class STEER, class POST>
+  __device__ inline void stepFourLanes(float* state, float* next_state, float* state_der, float* control, float* output,
+                                       const float dt, STEER&& steer, POST&& post)
+  {
+    const RacerDubinsElevationParams& p = this->params_;
+    const int rep = (int)(threadIdx.x & 63) >> 4;
+    float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+      x[i] = state[i];
+#pragma unroll
+    for (int i = 0; i < CONTROL_DIM; i++)
+      u[i] = control[i];
+
+    // ---- angles of the current state: replica 0 yaw, 1 wrapped steering angle, 2 raw steering angle, 3 pitch
+    StepTrig g;
+    {
+      const float delta = x[RDE_S(STEER_ANGLE)] / p.steer_angle_scale;
+      const float raw = pick4(rep, x[RDE_S(YAW)], delta, delta, x[RDE_S(PITCH)]);
+      const float wrapped = angle_utils::normalizeAngle(raw);
+      float s, c, sa[4], ca[4];
+      mppi::det::sincos(rep == 2 ? raw : wrapped, &s, &c);
+      allReplicas(s, sa);
+      allReplicas(c, ca);
+      g.sin_yaw = sa[0];
+      g.cos_yaw = ca[0];
+      g.tan_steer_n = sa[1] / ca[1];
+      g.tan_delta = sa[2] / ca[2];
+      g.cos_delta = ca[2];
+      g.sin_pitch = sa[3];
+      g.cos_pitch = ca[3];
+    }
+    computeParametricDelayDeriv(x, u, xd);
+    steer(x, u, xd);
+    // the acceleration does not look at the roll: g.sin_roll / g.cos_roll are filled in below
+    computeParametricAccelDeriv(x, u, xd, g);
+    updateState(x, xn, xd, dt);
+    post(x, xd, xn);
+
+    // ---- replicas 0, 1: roll of the current state; replicas 2, 3: yaw of the next one
+    float sin_psi, cos_psi;
+    {
+      float s, c;
+      mppi::det::sincos(angle_utils::normalizeAngle(rep < 2 ? x[RDE_S(ROLL)] : xn[RDE_S(YAW)]), &s, &c);
+      g.sin_roll = fromReplica(s, 0);
+      g.cos_roll = fromReplica(c, 0);
+      sin_psi = fromReplica(s, 2);
+      cos_psi = fromReplica(c, 2);
+    }
+
+    // ---- static settling: wheel `rep`, then angle `rep`
+    float roll = 0.0f, pitch = 0.0f, height = 0.0f;
+    if (tex_helper_.checkTextureUse(0))
+    {
+      float M[3][3], world[3], h_own, h[4], angle[4];
+      bodyRotation(g, sin_psi, cos_psi, M);
+      wheelWorldPoint(M, wheelOffsetX(rep), wheelOffsetY(rep), xn[RDE_S(POS_X)], xn[RDE_S(POS_Y)], world);
+      tex_helper_.queryTextureAtWorldPose(0, world, &h_own);
+      allReplicas(h_own, h);
+      allReplicas(mppi::det::asin(settlingSine(rep, h)), angle);
+      settle(angle, h, roll, pitch, height);
+    }
+    xn[RDE_S(PITCH)] = pitch;
+    xn[RDE_S(ROLL)] = roll;
+
+    // ---- covariance: row `rep` of (I + A dt) Sigma (I + A dt)^T + Q dt
+    {
+      float A[UD * UD], Sigma[UD * UD], Q[UD * UD], Ar[UD], Sb[UD], row[UD];
+      computeUncertaintyJacobian(x, g, A);
+      uncertaintyStateToMatrix(x, Sigma);
+#pragma unroll
+      for (int i = 0; i < UD * UD; i++)
+        A[i] = (i % (UD + 1) == 0) + A[i] * dt;
+#pragma unroll
+      for (int k = 0; k < UD; k++)
+        Ar[k] = pick4(rep, A[cm(0, k)], A[cm(1, k)], A[cm(2, k)], A[cm(3, k)]);
+#pragma unroll
+      for (int n = 0; n < UD; n++)
+      {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < UD; k++)
+          acc += Ar[k] * Sigma[cm(k, n)];
+        Sb[n] = acc;
+      }
+      computeQ(x, xd, g, Q);
+#pragma unroll
+      for (int n = 0; n < UD; n++)
+      {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < UD; k++)
+          acc += Sb[k] * A[cm(n, k)];
+        acc += pick4(rep, Q[cm(0, n)], Q[cm(1, n)], Q[cm(2, n)], Q[cm(3, n)]) * dt;
+        row[n] = acc;
+      }
+#pragma unroll
+      for (int m = 0; m < UD; m++)
+#pragma unroll
+        for (int n = 0; n < UD; n++)
+          Sigma[cm(m, n)] = fromReplica(row[n], m);
+      uncertaintyMatrixToState(Sigma, xn);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+      state_der[i] = xd[i];
+    if (XD > RDE_S(STEER_ANGLE_RATE))
+      state_der[RDE_S(STEER_ANGLE_RATE)] = xd[XD - 1];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+      next_state[i] = xn[i];
+    output[RDE_O(BASELINK_POS_I_Z)] = height;
+    setOutputs(xd, xn, output);
+  }
+
   /** racer_dubins_elevation.cu:836-874 */
   __device__ inline void step(float* state, float* next_state, float* state_der, float* control, float* output,
                               float* theta_s, const float t, const float dt)
@@ -489,13 +675,14 @@ public:
 #pragma unroll
     for (int i = 0; i < CONTROL_DIM; i++)
       u[i] = control[i];
+    const StepTrig g = stateTrig(x);
     computeParametricDelayDeriv(x, u, xd);
     computeParametricSteerDeriv(x, u, xd);
-    computeParametricAccelDeriv(x, u, xd);
+    computeParametricAccelDeriv(x, u, xd, g);
     updateState(x, xn, xd, dt);
-    computeUncertaintyPropagation(x, xd, xn, dt);
-    float roll = x[RDE_S(ROLL)], pitch = x[RDE_S(PITCH)], height;
-    computeStaticSettling(xn[RDE_S(YAW)], xn[RDE_S(POS_X)], xn[RDE_S(POS_Y)], roll, pitch, height);
+    computeUncertaintyPropagation(x, xd, xn, dt, g);
+    float roll, pitch, height;
+    computeStaticSettling(xn[RDE_S(YAW)], xn[RDE_S(POS_X)], xn[RDE_S(POS_Y)], g, roll, pitch, height);
     xn[RDE_S(PITCH)] = pitch;
     xn[RDE_S(ROLL)] = roll;
     mppi::lane_sync();  // BY > 1: nobody overwrites a buffer a sibling lane may still be reading
@@ -515,6 +702,51 @@ class RacerDubinsElevation : public RacerDubinsElevationImpl<RacerDubinsElevatio
 public:
   RacerDubinsElevation(hipStream_t stream = nullptr) : RacerDubinsElevationImpl<RacerDubinsElevation>(stream)
   {
+  }
+};
+
+/**
+ * The same model with FOUR lanes per rollout (REPLICATED_LANES, include/mppi_amd/engine/rollout_kernel.hpp): a wave
+ * carries 16 rollouts, lane (column c, replica r) = c + 16 r, every replica keeps a private register copy of the whole
+ * state and all four end a step with identical values.  Inside the step the replicas run the SAME instructions on
+ * DIFFERENT data wherever the model has four of something:
+ *   - the six angles whose sine / cosine a step needs: two passes of one det::sincos per lane (yaw, wrapped and raw
+ *     steering angle, pitch | roll, next yaw) instead of six,
+ *   - the four wheels: one bilinear map lookup per lane (4 loads in flight instead of 16), one asin per lane,
+ *   - the four rows of the covariance update: 2 x 16 multiply-adds per lane instead of 2 x 64,
+ * and exchange the results with ds_bpermute (`__shfl`): 36 values per step.  Each value is produced by exactly the
+ * operations of the one-lane form, so the two forms and the oracle agree bit for bit.  What it buys: a lone wave issues
+ * one instruction every ~2 ns whatever its dependences, so a step costs its instruction count on the lane
+ * that carries the rollout — this form roughly halves it, and a block of 64 rollouts becomes four dynamics waves, one per
+ * SIMD of the CU, where the one-lane form leaves three SIMDs to the helper waves.
+ * The reference strides the same work over threadIdx.y with shared memory and block barriers
+ * (racer_dubins_elevation.cu:336-419, 672-738: `for (i = pi; i < 16; i += step)`).
+ */
+class RacerDubinsElevationQuad : public RacerDubinsElevationImpl<RacerDubinsElevationQuad>
+{
+public:
+  using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationQuad>;
+  static constexpr int REPLICATED_LANES = 4;
+
+  RacerDubinsElevationQuad(const RacerDubinsElevation& other) : ELEVATION(other.stream_)
+  {
+    this->params_ = other.params_;
+    for (int i = 0; i < CONTROL_DIM; i++)
+    {
+      this->control_rngs_[i] = other.control_rngs_[i];
+      this->control_deadband_[i] = other.control_deadband_[i];
+      this->zero_control_[i] = other.zero_control_[i];
+    }
+    this->tex_helper_ = other.tex_helper_;
+  }
+
+  __device__ inline void step(float* state, float* next_state, float* state_der, float* control, float* output,
+                              float* theta_s, const float t, const float dt)
+  {
+    stepFourLanes<6>(
+        state, next_state, state_der, control, output, dt,
+        [this](const float* x, const float* u, float* xd) { computeParametricSteerDeriv(x, u, xd); },
+        [](const float*, const float*, float*) {});
   }
 };
 

@@ -174,13 +174,14 @@ public:
 #pragma unroll
     for (int i = 0; i < CONTROL_DIM; i++)
       u[i] = control[i];
+    const StepTrig g = stateTrig(x);
     computeParametricDelayDeriv(x, u, xd);
-    computeParametricAccelDeriv(x, u, xd);
+    computeParametricAccelDeriv(x, u, xd, g);
     computeLSTMSteering(x, u, xd, theta_s);
     updateState(x, xn, xd, dt);
-    computeUncertaintyPropagation(x, xd, xn, dt);
-    float roll = x[RDE_S(ROLL)], pitch = x[RDE_S(PITCH)], height;
-    computeStaticSettling(xn[RDE_S(YAW)], xn[RDE_S(POS_X)], xn[RDE_S(POS_Y)], roll, pitch, height);
+    computeUncertaintyPropagation(x, xd, xn, dt, g);
+    float roll, pitch, height;
+    computeStaticSettling(xn[RDE_S(YAW)], xn[RDE_S(POS_X)], xn[RDE_S(POS_Y)], g, roll, pitch, height);
     xn[RDE_S(PITCH)] = pitch;
     xn[RDE_S(ROLL)] = roll;
     mppi::lane_sync();
@@ -193,6 +194,166 @@ public:
       next_state[i] = xn[i];
     output[RDE_O(BASELINK_POS_I_Z)] = height;
     setOutputs(xd, xn, output);
+  }
+};
+
+/**
+ * Four lanes per rollout (see RacerDubinsElevationQuad): on top of the shared-out trigonometry, wheels and covariance
+ * rows, replica r of a rollout evaluates hidden unit r of the LSTM (its four gates: 32 multiply-adds, 5 transcendentals)
+ * and five of the twenty neurons of the output network's hidden layer; the new hidden state (4 values) and the layer's
+ * activations (20 values) are exchanged with `__shfl`, the last layer's 20-term sum runs on every replica in the order
+ * of the one-lane form.  The weights a replica needs differ from lane to lane, so they cannot be scalar operands: each
+ * lane loads its 81 once in initializeDynamics() and keeps them in VGPRs for the whole rollout (members of the lane's
+ * by-value copy of this object, like the recurrent state: h of all four units, c of its own).  Default network shape
+ * only (H = 4, MLP {8, 20, 1}).  Same arithmetic per value as LSTMRegisters / LSTMHelper / the oracle.
+ */
+class RacerDubinsElevationLSTMSteeringQuad : public RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteeringQuad>
+{
+public:
+  using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteeringQuad>;
+  static constexpr int REPLICATED_LANES = 4;
+  static constexpr int I = 4, H = 4, L1 = 20, PER = L1 / 4;
+  static constexpr int HH = H * H, HI = H * I, LSTM_NUM_PARAMS = 4 * HH + 4 * HI + 4 * H;
+
+  const float* lstm_d_ = nullptr;
+  const float* fnn_d_ = nullptr;
+  float wg_[4][I + H] = { { 0.0f } };  ///< gates i, f, o, c of hidden unit `replica`: input weights, then recurrent weights
+  float bg_[4] = { 0.0f };
+  float w1_[PER][H + I] = { { 0.0f } };  ///< neurons 5 * replica .. + 4 of the output network's hidden layer
+  float b1_[PER] = { 0.0f };
+  float h_[H] = { 0.0f };  ///< hidden state of all four units
+  float c_ = 0.0f;         ///< cell state of unit `replica`
+
+  RacerDubinsElevationLSTMSteeringQuad(const RacerDubinsElevationLSTMSteering& other) : ELEVATION(other.stream_)
+  {
+    this->params_ = other.params_;
+    for (int i = 0; i < CONTROL_DIM; i++)
+    {
+      this->control_rngs_[i] = other.control_rngs_[i];
+      this->control_deadband_[i] = other.control_deadband_[i];
+      this->zero_control_[i] = other.zero_control_[i];
+    }
+    this->tex_helper_ = other.tex_helper_;
+    lstm_d_ = other.lstm_.weights_d_;
+    fnn_d_ = other.lstm_.output_nn_.theta_d_;
+  }
+
+  __device__ inline void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
+                                            float dt)
+  {
+    const int rep = (int)(threadIdx.x & 63) >> 4;
+    const float* Wm = lstm_d_;
+    const float* Wi = lstm_d_ + 4 * HH;
+    const float* B = Wi + 4 * HI;
+#pragma unroll
+    for (int gate = 0; gate < 4; gate++)
+    {
+#pragma unroll
+      for (int j = 0; j < I; j++)
+        wg_[gate][j] = Wi[gate * HI + rep * I + j];
+#pragma unroll
+      for (int j = 0; j < H; j++)
+        wg_[gate][I + j] = Wm[gate * HH + rep * H + j];
+      bg_[gate] = B[gate * H + rep];
+    }
+    const float* W1 = fnn_d_;
+    const float* B1 = W1 + L1 * (H + I);
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+    {
+#pragma unroll
+      for (int k = 0; k < H + I; k++)
+        w1_[i][k] = W1[(PER * rep + i) * (H + I) + k];
+      b1_[i] = B1[PER * rep + i];
+    }
+#pragma unroll
+    for (int j = 0; j < H; j++)
+      h_[j] = lstm_d_[LSTM_NUM_PARAMS + j];
+    c_ = lstm_d_[LSTM_NUM_PARAMS + H + rep];
+    output[RDE_O(BASELINK_POS_I_Z)] = 0.0f;
+    output[RDE_O(FILLER_1)] = 0.0f;
+    setOutputs(state, state, output);
+  }
+
+  /** racer_dubins_elevation_lstm_steering.cu:131-167, the network shared out over the four replicas */
+  __device__ inline void computeLSTMSteering(const float* state, const float* control, float* state_der)
+  {
+    const RacerDubinsElevationParams& p = this->params_;
+    const float steer = state[RDE_S(STEER_ANGLE)], rate = state[RDE_S(STEER_ANGLE_RATE)];
+    const float parametric_accel = (control[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - steer) * p.steering_constant;
+    float rate_dot = fmaxf(fminf((parametric_accel - rate) * p.steer_accel_constant - rate * p.steer_accel_drag_constant,
+                                 p.max_steer_rate),
+                           -p.max_steer_rate);
+    const float input[I] = { steer * 0.2f, rate * 0.2f, control[RDE_C(STEER_CMD)], rate_dot * 0.2f };
+    // hidden unit `replica`
+    float gate[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+    {
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < I; j++)
+        acc = mppi::det::fma(wg_[g][j], input[j], acc);
+#pragma unroll
+      for (int j = 0; j < H; j++)
+        acc = mppi::det::fma(wg_[g][I + j], h_[j], acc);
+      gate[g] = acc + bg_[g];
+    }
+    float sg[3] = { gate[0], gate[1], gate[2] };
+    mppi::det::sigmoid_n<3>(sg);
+    const float gc = mppi::det::tanh(gate[3]);
+    const float in_part = sg[0] * gc;
+    const float keep_part = sg[1] * c_;
+    c_ = in_part + keep_part;
+    const float h_own = mppi::det::tanh(c_) * sg[2];
+    allReplicas(h_own, h_);
+    // five neurons of the hidden layer on [h ; x]
+    float act[H + I];
+#pragma unroll
+    for (int j = 0; j < H; j++)
+      act[j] = h_[j];
+#pragma unroll
+    for (int j = 0; j < I; j++)
+      act[H + j] = input[j];
+    float hid_own[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+    {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < H + I; k++)
+        acc = mppi::det::fma(w1_[i][k], act[k], acc);
+      hid_own[i] = acc + b1_[i];
+    }
+    mppi::det::tanh_n<PER>(hid_own);
+    float hid[L1];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+      for (int i = 0; i < PER; i++)
+        hid[PER * s + i] = fromReplica(hid_own[i], s);
+    // the output neuron: the same 20-term chain on every replica, its weights through the scalar unit
+#if defined(__HIP_DEVICE_COMPILE__)
+    mppi::lstm_const_f32* W2 = mppi::lstmScalarView(fnn_d_ + L1 * (H + I) + L1);
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < L1; k++)
+      acc = mppi::det::fma(W2[k], hid[k], acc);
+    rate_dot += (acc + W2[L1]) * 5.0f;
+#endif
+    state_der[RDE_S(STEER_ANGLE_RATE)] = rate_dot;
+    state_der[RDE_S(STEER_ANGLE)] = rate;
+  }
+
+  __device__ inline void step(float* state, float* next_state, float* state_der, float* control, float* output,
+                              float* theta_s, const float t, const float dt)
+  {
+    stepFourLanes<RDE_S(STEER_ANGLE_RATE) + 1>(
+        state, next_state, state_der, control, output, dt,
+        [this](const float* x, const float* u, float* xd) { computeLSTMSteering(x, u, xd); },
+        [dt](const float* x, const float* xd, float* xn) {
+          xn[RDE_S(STEER_ANGLE_RATE)] = x[RDE_S(STEER_ANGLE_RATE)] + xd[RDE_S(STEER_ANGLE_RATE)] * dt;
+        });
   }
 };
 

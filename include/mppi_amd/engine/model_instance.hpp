@@ -292,6 +292,15 @@ struct has_lstm_structure<T, std::void_t<decltype(std::declval<T&>().setLSTMStru
 {
 };
 template <class T, class = void>
+struct has_register_form : std::false_type
+{
+};
+/** dynamics whose replicated-lane (FAST) variant exists for one network shape only (`register_form_`) */
+template <class T>
+struct has_register_form<T, std::void_t<decltype(std::declval<T&>().register_form_)>> : std::true_type
+{
+};
+template <class T, class = void>
 struct has_elevation_map : std::false_type
 {
 };
@@ -1130,6 +1139,15 @@ struct ModelT : ModelBase
       if (st != MPPI_OK)
         return st;
     }
+    if constexpr (has_register_form<DYN_T>::value && !std::is_void<DYN_FAST_T>::value)
+    {
+      if (!dyn.register_form_ && hasShape(FAST_SHAPES{}, bx, by, bz))
+      {
+        err = "the replicated-lane block shapes of this model exist for its default network shape only: create the "
+              "controller with block_y = 1 for a network set through 'lstm_structure'";
+        return MPPI_ERR_LAUNCH_SHAPE;
+      }
+    }
     if (pipeline && supportsPipelineRep(bx, by, bz))
       return launchPipelineRep(args, stream, err);
     if (pipeline && supportsPipelineFold(bx, by, bz))
@@ -1154,7 +1172,10 @@ struct ModelT : ModelBase
     {  // replicated-lane (MFMA) dynamics: the register-resident single-wave variant
       DYN_FAST_T fast(dyn);
       const size_t smem_rep = kernels::finalizeRepSharedBytes(fast, a.num_timesteps);
-      if (smem_rep <= MAX_LDS_BYTES)
+      bool usable = smem_rep <= MAX_LDS_BYTES;
+      if constexpr (has_register_form<DYN_T>::value)
+        usable = usable && dyn.register_form_;
+      if (usable)
       {
         auto krep = kernels::finalizeRepKernel<DYN_FAST_T>;
         if (smem_rep > 48 * 1024)

@@ -7,8 +7,9 @@
  * compiled into shared libraries, e.g. src/controllers/cartpole/cartpole_mppi.cu:30-42).  One translation unit per
  * model, so a new or changed model recompiles alone (buildlib.py compiles the units in parallel).
  *
- * Block shapes (BX rollouts, BY lanes per rollout, BZ systems per launch): BY == 1 only — a rollout is one lane with its
- * 19 states and the three 4x4 matrices of the covariance step in VGPRs (racer_dubins_elevation.hpp).
+ * Block shapes (BX rollouts, BY lanes per rollout, BZ systems per launch): BY == 1 — a rollout is one lane with its
+ * 19 states and the three 4x4 matrices of the covariance step in VGPRs — or BY == 4: four replica lanes per rollout
+ * that share out the wheels, the covariance rows and the trigonometry of a step (RacerDubinsElevationQuad).
  *
  * The cost is QuadraticCost over the 28 outputs with SKIP_ZERO_COEFF: the model marks the three wheel-force outputs it
  * does not produce with NaN (racer_dubins_elevation.cu:131-139); give them coefficient 0.
@@ -25,9 +26,11 @@ using namespace mppi::engine;
 using ElevationCost = QuadraticCost<RacerDubinsElevation, /*SKIP_ZERO_COEFF=*/true>;
 using RacerElevationModel =
     ModelT<RacerDubinsElevation, ElevationCost, sampling_distributions::GaussianDistribution<RacerDubinsElevationParams>,
-           Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/1, void, Shapes<>, /*PIPELINE=*/true>;
+           Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/1,
+           /* four lanes per rollout: one wheel, one covariance row, one angle each (racer_dubins_elevation.hpp) */
+           RacerDubinsElevationQuad, Shapes<Shape<64, 4, 1>, Shape<64, 4, 2>>, /*PIPELINE=*/true>;
 using RacerElevationColoredModel =
     ModelT<RacerDubinsElevation, ElevationCost, sampling_distributions::ColoredNoiseDistribution<RacerDubinsElevationParams>,
-           Shapes<Shape<64, 1, 1>>, /*FIN_BY=*/1, void, Shapes<>, /*PIPELINE=*/true>;
-MPPI_REGISTER_MODEL("racer_dubins_elevation", MPPI_SAMPLER_GAUSSIAN, RacerElevationModel, 64, 1)
-MPPI_REGISTER_MODEL("racer_dubins_elevation", MPPI_SAMPLER_COLORED, RacerElevationColoredModel, 64, 1)
+           Shapes<Shape<64, 1, 1>>, /*FIN_BY=*/1, RacerDubinsElevationQuad, Shapes<Shape<64, 4, 1>>, /*PIPELINE=*/true>;
+MPPI_REGISTER_MODEL("racer_dubins_elevation", MPPI_SAMPLER_GAUSSIAN, RacerElevationModel, 64, 4)
+MPPI_REGISTER_MODEL("racer_dubins_elevation", MPPI_SAMPLER_COLORED, RacerElevationColoredModel, 64, 4)

@@ -7,10 +7,12 @@
  * compiled into shared libraries, e.g. src/controllers/cartpole/cartpole_mppi.cu:30-42).  One translation unit per
  * model, so a new or changed model recompiles alone (buildlib.py compiles the units in parallel).
  *
- * Block shapes: BY == 1 — a rollout is one lane (19 states and the covariance matrices in VGPRs); the LSTM parameters
- * are shared by the block in LDS and every rollout slot keeps its hidden / cell state there (lstm_helper.hpp).  The
- * fused rollout kernel only: LSTMHelper::initialize() is a whole-block load with a block barrier, which the
- * role-pipelined kernel's dynamics waves cannot execute on their own.  For the same reason the trajectory pass after the
+ * Block shapes: (64, 4) — the default — runs a rollout on four replica lanes that share out the hidden units of the LSTM,
+ * the neurons of the output network, the wheels of the static settling and the rows of the covariance update
+ * (RacerDubinsElevationLSTMSteeringQuad; fused and role-pipelined kernel; default network shape only).  BY == 1: a rollout
+ * is one lane; the default network runs on registers (lstm_registers.hpp), any other shape on LSTMHelper's LDS contract.
+ * One-lane shapes use the fused rollout kernel only: LSTMHelper::initialize() is a whole-block load with a block barrier,
+ * which the role-pipelined kernel's dynamics waves cannot execute on their own.  For the same reason the trajectory pass after the
  * iterations (finalize kernel) and the single model step run the two-lane contract form (FIN_BY = 2: every thread of
  * the block takes part in initialize()), not the one-lane-of-a-wave form of the analytic models.
  */
@@ -27,10 +29,12 @@ using SteeringCost = QuadraticCost<RacerDubinsElevationLSTMSteering, /*SKIP_ZERO
 using RacerLSTMSteeringModel =
     ModelT<RacerDubinsElevationLSTMSteering, SteeringCost,
            sampling_distributions::GaussianDistribution<RacerDubinsElevationParams>,
-           Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/2, void, Shapes<>, /*PIPELINE=*/false>;
+           Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/2,
+           /* four lanes per rollout: a wheel, a covariance row, a hidden unit and five MLP neurons each */
+           RacerDubinsElevationLSTMSteeringQuad, Shapes<Shape<64, 4, 1>, Shape<64, 4, 2>>, /*PIPELINE=*/false>;
 using RacerLSTMSteeringColoredModel =
     ModelT<RacerDubinsElevationLSTMSteering, SteeringCost,
            sampling_distributions::ColoredNoiseDistribution<RacerDubinsElevationParams>, Shapes<Shape<64, 1, 1>>,
-           /*FIN_BY=*/2, void, Shapes<>, /*PIPELINE=*/false>;
-MPPI_REGISTER_MODEL("racer_dubins_elevation_lstm_steering", MPPI_SAMPLER_GAUSSIAN, RacerLSTMSteeringModel, 64, 1)
-MPPI_REGISTER_MODEL("racer_dubins_elevation_lstm_steering", MPPI_SAMPLER_COLORED, RacerLSTMSteeringColoredModel, 64, 1)
+           /*FIN_BY=*/2, RacerDubinsElevationLSTMSteeringQuad, Shapes<Shape<64, 4, 1>>, /*PIPELINE=*/false>;
+MPPI_REGISTER_MODEL("racer_dubins_elevation_lstm_steering", MPPI_SAMPLER_GAUSSIAN, RacerLSTMSteeringModel, 64, 4)
+MPPI_REGISTER_MODEL("racer_dubins_elevation_lstm_steering", MPPI_SAMPLER_COLORED, RacerLSTMSteeringColoredModel, 64, 4)

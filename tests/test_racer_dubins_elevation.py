@@ -298,6 +298,31 @@ def test_elevation_rollout_costs_bit_exact(gpu, variant, with_map):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant,with_map,D", [(1, True, 1), (2, True, 1), (2, False, 1), (1, True, 2)])
+def test_elevation_four_lanes_per_rollout_bit_exact(gpu, variant, with_map, D):
+    """RacerDubinsElevationQuad (block shape (64, 4)): wheels, covariance rows and angles of a step shared out over four
+    replica lanes — same bits as the one-lane form and the oracle; fused and role-pipelined kernel, Tube"""
+    cfg = elevation_cfg(K=1000, T=60, with_map=with_map, D=D)
+    eps = host_noise(1, cfg["K"], cfg["T"], 2, seed=3)
+    o = make_oracle(cfg)
+    if D == 2:
+        o.tube_compute_control(cfg["x0"], 1, eps)
+    else:
+        o.vanilla_compute_control(cfg["x0"], 1, eps)
+    eng = make_engine(cfg, block_x=64, block_y=4, kernel_variant=variant)
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    assert ulp_diff(eng.getSampledCostSeq(), o.costs()).max() == 0
+    assert np.abs(eng.getControlSeq() - o.control()).max() <= 1e-5
+    assert np.abs(eng.getTargetStateSeq() - o.state_traj()).max() <= 1e-4
+    if D == 1:
+        y = eng.getTargetOutputSeq()
+        xs, ys = o.output_trajectory(cfg["x0"], o.control())
+        finite = np.isfinite(ys)
+        assert np.array_equal(np.isfinite(y), finite) and np.abs(y[finite] - ys[finite]).max() <= 1e-4
+
+
+@pytest.mark.gpu
 def test_elevation_model_step_equals_oracle(gpu):
     """modelStep on the device (enforceConstraints + step) against the oracle, bit for bit: the reference's TestStep inputs
     and random states over the map"""

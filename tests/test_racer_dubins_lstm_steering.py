@@ -145,13 +145,15 @@ def test_oracle_network_state_carries_over_steps():
 
 # ------------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("with_map", [True, False])
-def test_lstm_steering_rollout_costs_bit_exact(gpu, with_map):
+@pytest.mark.parametrize("with_map,block_y,variant", [(True, 1, 1), (False, 1, 1), (True, 4, 1), (True, 4, 2), (False, 4, 2)])
+def test_lstm_steering_rollout_costs_bit_exact(gpu, with_map, block_y, variant):
+    """block_y = 1: one lane per rollout (network on registers, LSTMRegisters); block_y = 4: four replica lanes share the
+    hidden units, the MLP neurons, the wheels and the covariance rows (fused and role-pipelined kernel)"""
     cfg = steering_cfg(K=1000, T=60, with_map=with_map)
     eps = host_noise(1, cfg["K"], cfg["T"], 2, seed=3)
     o = make_oracle(cfg)
     o.vanilla_compute_control(cfg["x0"], 1, eps)
-    eng = make_engine(cfg)
+    eng = make_engine(cfg, block_x=64, block_y=block_y, kernel_variant=variant)
     eng.injectNoise(eps)
     eng.computeControl(cfg["x0"], 1)
     assert np.isfinite(o.costs()).all()
@@ -209,10 +211,15 @@ def test_lstm_steering_initial_state_and_structure(gpu):
     cfg["blobs"] = dict(sorted(cfg["blobs"].items(), key=lambda kv: 0 if kv[0] == "lstm_structure" else 1))
     o = make_oracle(cfg)
     o.vanilla_compute_control(cfg["x0"], 1, eps)
-    eng = make_engine(cfg)
+    with pytest.raises(m.MPPIError):   # the four-lane form (the default block shape) is compiled for the default network
+        eng = make_engine(cfg)
+        eng.injectNoise(eps)
+        eng.computeControl(cfg["x0"], 1)
+    eng = make_engine(cfg, block_x=64, block_y=1)
     eng.injectNoise(eps)
     eng.computeControl(cfg["x0"], 1)
     assert ulp_diff(eng.getSampledCostSeq(), o.costs()).max() == 0
+    assert np.abs(eng.getTargetStateSeq() - o.state_traj()).max() <= 1e-4
 
     cfg = steering_cfg(K=512, T=40, D=2)
     o = make_oracle(cfg)
