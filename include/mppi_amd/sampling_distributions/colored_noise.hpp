@@ -236,11 +236,49 @@ public:
       if (active)
       {
         const float* __restrict__ a_tile = stage + (size_t)(j & 1) * 4 * NTBP * 64 + lane;
+#if !defined(MPPI_COLORED_SIMPLE_READS)
+        // The A fragments of k-step e + 1 are fetched from LDS while the matrix pipe works on k-step e.  Left to itself the
+        // compiler places every ds_read directly in front of the two MFMAs that use it, followed by s_waitcnt lgkmcnt(0):
+        // 2 * NTBP exposed LDS round trips per tile on a wave that is alone on its SIMD.  The empty asm statements pin the
+        // order (values tied to VGPRs must have arrived; the "memory" clobber keeps the reads of the next row above it; the
+        // tie on acc[0] keeps this row's MFMA chain below it): one exposed round trip per tile instead.
+        float a_cur[NTBP], a_nxt[NTBP];
+#pragma unroll
+        for (int tb = 0; tb < NTBP; tb++)
+          a_cur[tb] = a_tile[tb * 64];
+#pragma unroll
+        for (int tb = 0; tb < NTBP; tb++)
+          asm volatile("" : "+v"(a_cur[tb]));
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+          if (e < 3)
+          {
+#pragma unroll
+            for (int tb = 0; tb < NTBP; tb++)
+              a_nxt[tb] = a_tile[((e + 1) * NTBP + tb) * 64];
+            asm volatile("" : "+v"(acc[0]) : : "memory");
+          }
+#pragma unroll
+          for (int tb = 0; tb < NTBP; tb++)
+            acc[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[tb], zq[e], acc[tb], 0, 0, 0);
+          if (e < 3)
+          {
+#pragma unroll
+            for (int tb = 0; tb < NTBP; tb++)
+            {
+              asm volatile("" : "+v"(a_nxt[tb]));
+              a_cur[tb] = a_nxt[tb];
+            }
+          }
+        }
+#else
 #pragma unroll
         for (int e = 0; e < 4; e++)
 #pragma unroll
           for (int tb = 0; tb < NTBP; tb++)
             acc[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_tile[(e * NTBP + tb) * 64], zq[e], acc[tb], 0, 0, 0);
+#endif
         // the next tile's draw (~300 VALU instructions) does not depend on these MFMAs, so the scheduler is free to
         // interleave the two (measured: neutral with ROCm 7.2's hipcc, which keeps them apart)
         float zn[4];
