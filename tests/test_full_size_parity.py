@@ -210,3 +210,22 @@ def test_full_size_weighted_mean_of_dumped_samples(gpu):
     w = np.exp(-(costs - costs.min()) / cfg["lambda_"])
     u_direct = (w[:, None, None] * v).sum(0) / w.sum()
     assert np.abs(eng.getOptimalControlSeq()[0] - u_direct).max() <= 2e-6
+
+
+# ------------------------------------------------------------------ §8(f)-4: elevation-map RACER models K=16384 T=100 --
+@pytest.mark.parametrize("model,block_y,variant", [("elevation", 4, 0), ("elevation", 1, 0), ("lstm_steering", 4, 0),
+                                                   ("lstm_steering", 4, 1), ("lstm_steering", 1, 1)],
+                         ids=["elev-4lanes-pipeline", "elev-1lane-pipeline", "lstm-4lanes-pipeline", "lstm-4lanes-fused",
+                              "lstm-1lane-fused"])
+def test_racer_elevation_16384x100_vs_oracle(gpu, model, block_y, variant):
+    """RacerDubinsElevation / RacerDubinsElevationLSTMSteering over the synthetic hills at the size DESIGN.md §5 quotes
+    (one block per CU): four lanes per rollout and one lane per rollout against the oracle, injected noise"""
+    from test_racer_dubins_elevation import elevation_cfg
+    from test_racer_dubins_lstm_steering import steering_cfg
+    cfg = (elevation_cfg if model == "elevation" else steering_cfg)(K=16384, T=100)
+    eng, orc = make_engine(cfg, block_x=64, block_y=block_y, kernel_variant=variant), make_oracle(cfg)
+    eps = host_noise(1, cfg["K"], cfg["T"], 2)
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    orc.vanilla_compute_control(cfg["x0"], 1, eps)
+    _check_vanilla(eng, orc)
