@@ -262,6 +262,30 @@ def di_tube_leg(device):
             "ms_per_step": round(wall / n * 1e3, 6)}
 
 
+def racer_elevation_leg(device):
+    """the elevation-map RACER models (RacerDubinsElevation, RacerDubinsElevationLSTMSteering with the
+    colored-noise sampler of the RACER controllers) over a synthetic terrain, K=16384, T=100, four lanes per rollout"""
+    from common import make_engine
+    from test_racer_dubins_elevation import elevation_cfg
+    from test_racer_dubins_lstm_steering import steering_cfg
+    out = {}
+    for key, cfg in (("elevation", elevation_cfg(K=16384, T=100)), ("lstm_steering_colored", steering_cfg(K=16384, T=100))):
+        if key.endswith("colored"):
+            cfg["colored"] = ([1.0, 1.0], 0.97, 0.0)
+        eng = make_engine(cfg, device=device)
+        eng.uploadState(np_tile(cfg["x0"], 1))
+        eng.optimize(20, True)
+        n = 200
+        t0 = time.perf_counter()
+        eng.optimize(n, True)
+        wall = time.perf_counter() - t0
+        out[key] = {"value": round(n / wall, 3), "unit": "MPPI iters/s", "ms_per_step": round(wall / n * 1e3, 6)}
+        eng.close()
+    out["workload"] = ("RacerDubinsElevation + QuadraticCost (Gaussian sampler) and RacerDubinsElevationLSTMSteering + "
+                       "QuadraticCost (colored noise), 240 x 240 elevation map, K=16384, T=100, block shape (64, 4)")
+    return out
+
+
 def np_tile(x, d):
     import numpy as np
     return np.tile(x, (d, 1))
@@ -277,7 +301,7 @@ def main():
     ap.add_argument("--workload", choices=["cartpole", "autorally"], default="cartpole")
     ap.add_argument("--min-time", type=float, default=0.25, help="repeat the K-step timed region until this many seconds are timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--primary-only", action="store_true", help="skip the secondary legs (AutoRally-NN, LSTM+colored, DI-Tube)")
+    ap.add_argument("--primary-only", action="store_true", help="skip the secondary legs (AutoRally-NN, LSTM+colored, DI-Tube, RACER elevation)")
     args = ap.parse_args()
 
     import numpy as np
@@ -513,7 +537,8 @@ def main():
         }
         # secondary workload of the north star (not the headline `value`): AutoRally-NN, K=16384, T=150, MFMA forward
         if not args.primary_only and world == 1 and args.workload == "cartpole":
-            for key, leg in (("autorally_nn", autorally_leg), ("lstm_colored", lstm_colored_leg), ("di_tube", di_tube_leg)):
+            for key, leg in (("autorally_nn", autorally_leg), ("lstm_colored", lstm_colored_leg), ("di_tube", di_tube_leg),
+                             ("racer_elevation", racer_elevation_leg)):
                 try:
                     out[key] = leg(local_rank)
                 except Exception as e:  # noqa: BLE001
