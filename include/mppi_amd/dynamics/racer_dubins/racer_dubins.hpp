@@ -135,6 +135,50 @@ public:
   }
 
   /**
+   * HOST: ColoredMPPI's state leash for the RACER models (reference: RacerDubinsImpl::enforceLeash,
+   * dynamics/racer_dubins/racer_dubins.cu:176-240): the position error is rotated into the body frame of the true state,
+   * clamped there to +-leash[POS_X] / +-leash[POS_Y] and rotated back; the yaw error is the shortest angular distance
+   * and the leashed yaw is wrapped; every other state follows the base rule (dynamics.cuh:448-466).  Plain libm on the
+   * host, as the reference.
+   */
+  void enforceLeash(const float* state_true, const float* state_nominal, const float* leash_values, float* state_output) const
+  {
+    constexpr int YAW = S_INDEX(YAW), POS_X = S_INDEX(POS_X), POS_Y = S_INDEX(POS_Y);
+    for (int i = 0; i < STATE_DIM; i++)
+      state_output[i] = state_true[i];
+    float dx = state_nominal[POS_X] - state_true[POS_X];
+    float dy = state_nominal[POS_Y] - state_true[POS_Y];
+    const float c = cosf(state_true[YAW]), s = sinf(state_true[YAW]);
+    float dx_body = dx * c + dy * s;
+    float dy_body = -dx * s + dy * c;
+    const float y_leash = leash_values[POS_Y], x_leash = leash_values[POS_X];
+    dx_body = fminf(fmaxf(dx_body, -x_leash), x_leash);
+    dy_body = fminf(fmaxf(dy_body, -y_leash), y_leash);
+    dx = dx_body * c + -dy_body * s;
+    dy = dx_body * s + dy_body * c;
+    state_output[POS_X] += dx;
+    state_output[POS_Y] += dy;
+    for (int i = 0; i < STATE_DIM; i++)
+    {
+      if (i == POS_X || i == POS_Y)
+        continue;
+      const float diff = (i == YAW) ? angle_utils::shortestAngularDistance(state_true[i], state_nominal[i]) :
+                                      state_nominal[i] - state_true[i];
+      if (leash_values[i] < fabsf(diff))
+      {
+        const float leash_dir = fminf(fmaxf(diff, -leash_values[i]), leash_values[i]);
+        state_output[i] = state_true[i] + leash_dir;
+        if (i == YAW)
+          state_output[i] = angle_utils::normalizeAngle(state_output[i]);
+      }
+      else
+      {
+        state_output[i] = state_nominal[i];
+      }
+    }
+  }
+
+  /**
    * Euler step of the six integrated states (reference: racer_dubins.cu:73-98): the yaw is wrapped, the steering angle
    * and the brake state are clamped to their physical ranges, and the seventh state simply records the steering rate
    * that was applied.

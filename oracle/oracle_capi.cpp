@@ -315,6 +315,12 @@ void oracle_model_step(void* h, float* x, float* u, float dt)
     x[i] = xn[i];
 }
 
+/** Dynamics::enforceLeash of the model (base rule, or the RACER body-frame rule) */
+void oracle_enforce_leash(void* h, const float* x_true, const float* x_nominal, const float* leash, float* out)
+{
+  ((Controller*)h)->dyn->enforceLeash(x_true, x_nominal, leash, out);
+}
+
 /** one step with everything it produces: next state, the derivative entries the model writes, the output */
 void oracle_model_step_full(void* h, const float* x_in, const float* u_in, float dt, float* xn, float* xdot, float* y)
 {

@@ -95,6 +95,18 @@ struct Dynamics
       u[i] = fminf(fmaxf(rng_lo[i], u[i]), rng_hi[i]);
     }
   }
+  /** reference: Dynamics::enforceLeash, dynamics/dynamics.cuh:448-466 (base rule; the RACER models override it) */
+  virtual void enforceLeash(const float* x_true, const float* x_nominal, const float* leash, float* out) const
+  {
+    for (int i = 0; i < S; i++)
+    {
+      const float diff = fabsf(x_nominal[i] - x_true[i]);
+      if (leash[i] < diff)
+        out[i] = x_true[i] + fminf(fmaxf(x_nominal[i] - x_true[i], -leash[i]), leash[i]);
+      else
+        out[i] = x_nominal[i];
+    }
+  }
   /** reference: dynamics/dynamics.cu:118-128 */
   virtual void updateState(const float* x, float* x_next, const float* xdot, float dt) const
   {
@@ -621,14 +633,7 @@ struct Controller
     if (leash_active)
     {
       const float* nominal = &state_traj[(size_t)leash_jump * S];
-      for (int i = 0; i < S; i++)
-      {
-        const float diff = fabsf(nominal[i] - x0_true[i]);
-        if (leash_dist[i] < diff)
-          local_state[i] = x0_true[i] + fminf(fmaxf(nominal[i] - x0_true[i], -leash_dist[i]), leash_dist[i]);
-        else
-          local_state[i] = nominal[i];
-      }
+      dyn->enforceLeash(x0_true, nominal, leash_dist.data(), local_state.data());
     }
     const float* x0 = local_state.data();
     for (int it = 0; it < num_iters; it++)

@@ -502,6 +502,46 @@ struct RacerDubins : Dynamics
   RacerDubins() : Dynamics(7, 2, 28)
   {
   }
+  /** reference: RacerDubinsImpl::enforceLeash, dynamics/racer_dubins/racer_dubins.cu:176-240 (host; position error leashed
+   *  in the body frame, yaw by the shortest angular distance) */
+  void enforceLeash(const float* state_true, const float* state_nominal, const float* leash_values, float* state_output) const override
+  {
+    for (int i = 0; i < S; i++)
+      state_output[i] = state_true[i];
+    float dx = state_nominal[POS_X] - state_true[POS_X];
+    float dy = state_nominal[POS_Y] - state_true[POS_Y];
+    float dx_body = dx * cosf(state_true[YAW]) + dy * sinf(state_true[YAW]);
+    float dy_body = -dx * sinf(state_true[YAW]) + dy * cosf(state_true[YAW]);
+    float y_leash = leash_values[POS_Y];
+    float x_leash = leash_values[POS_X];
+    dx_body = fminf(fmaxf(dx_body, -x_leash), x_leash);
+    dy_body = fminf(fmaxf(dy_body, -y_leash), y_leash);
+    dx = dx_body * cosf(state_true[YAW]) + -dy_body * sinf(state_true[YAW]);
+    dy = dx_body * sinf(state_true[YAW]) + dy_body * cosf(state_true[YAW]);
+    state_output[POS_X] += dx;
+    state_output[POS_Y] += dy;
+    float diff;
+    for (int i = 0; i < S; i++)
+    {
+      if (i == POS_X || i == POS_Y)
+        continue;
+      else if (i == YAW)
+        diff = det::normalizeAngle(state_nominal[i] - state_true[i]); /* shortestAngularDistance, utils/angle_utils.cuh */
+      else
+        diff = state_nominal[i] - state_true[i];
+      if (leash_values[i] < fabsf(diff))
+      {
+        float leash_dir = fminf(fmaxf(diff, -leash_values[i]), leash_values[i]);
+        state_output[i] = state_true[i] + leash_dir;
+        if (i == YAW)
+          state_output[i] = det::normalizeAngle(state_output[i]);
+      }
+      else
+      {
+        state_output[i] = state_nominal[i];
+      }
+    }
+  }
   int setParams(const void* pod, size_t n) override
   {
     if (n != sizeof(p))
@@ -628,6 +668,46 @@ struct RacerDubinsElevation : Dynamics
   };
   RacerDubinsElevation() : Dynamics(19, 2, 28)
   {
+  }
+  /** reference: RacerDubinsImpl::enforceLeash, dynamics/racer_dubins/racer_dubins.cu:176-240 (host; position error leashed
+   *  in the body frame, yaw by the shortest angular distance) */
+  void enforceLeash(const float* state_true, const float* state_nominal, const float* leash_values, float* state_output) const override
+  {
+    for (int i = 0; i < S; i++)
+      state_output[i] = state_true[i];
+    float dx = state_nominal[POS_X] - state_true[POS_X];
+    float dy = state_nominal[POS_Y] - state_true[POS_Y];
+    float dx_body = dx * cosf(state_true[YAW]) + dy * sinf(state_true[YAW]);
+    float dy_body = -dx * sinf(state_true[YAW]) + dy * cosf(state_true[YAW]);
+    float y_leash = leash_values[POS_Y];
+    float x_leash = leash_values[POS_X];
+    dx_body = fminf(fmaxf(dx_body, -x_leash), x_leash);
+    dy_body = fminf(fmaxf(dy_body, -y_leash), y_leash);
+    dx = dx_body * cosf(state_true[YAW]) + -dy_body * sinf(state_true[YAW]);
+    dy = dx_body * sinf(state_true[YAW]) + dy_body * cosf(state_true[YAW]);
+    state_output[POS_X] += dx;
+    state_output[POS_Y] += dy;
+    float diff;
+    for (int i = 0; i < S; i++)
+    {
+      if (i == POS_X || i == POS_Y)
+        continue;
+      else if (i == YAW)
+        diff = det::normalizeAngle(state_nominal[i] - state_true[i]); /* shortestAngularDistance, utils/angle_utils.cuh */
+      else
+        diff = state_nominal[i] - state_true[i];
+      if (leash_values[i] < fabsf(diff))
+      {
+        float leash_dir = fminf(fmaxf(diff, -leash_values[i]), leash_values[i]);
+        state_output[i] = state_true[i] + leash_dir;
+        if (i == YAW)
+          state_output[i] = det::normalizeAngle(state_output[i]);
+      }
+      else
+      {
+        state_output[i] = state_nominal[i];
+      }
+    }
   }
   int setParams(const void* pod, size_t n) override
   {

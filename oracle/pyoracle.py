@@ -78,6 +78,7 @@ def lib():
         L.oracle_state_trajectory.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
         L.oracle_output_trajectory.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p]
         L.oracle_model_step.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float]
+        L.oracle_enforce_leash.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p]
         L.oracle_model_step_full.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, _f32p, _f32p, _f32p]
         L.oracle_set_nominal_control.argtypes = [C.c_void_p, _f32p]
         L.oracle_iterate.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _f32p]
@@ -245,6 +246,11 @@ class Oracle:
         u = _f32(u).reshape(-1).copy()
         self.L.oracle_model_step(self.h, x, u, self.dt if dt is None else dt)
         return x, u
+
+    def enforce_leash(self, x_true, x_nominal, leash):
+        out = np.zeros(self.S, np.float32)
+        self.L.oracle_enforce_leash(self.h, _f32(x_true).reshape(-1), _f32(x_nominal).reshape(-1), _f32(leash).reshape(-1), out)
+        return out
 
     def model_step_full(self, x, u, dt=None):
         """initializeDynamics + one step(): (next state, state derivative, output)"""

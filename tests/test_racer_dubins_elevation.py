@@ -383,3 +383,50 @@ def test_elevation_colored_noise_runs(gpu):
         x, _ = eng.modelStep(x, u)
         eng.slideControlSequence(1)
     assert np.isfinite(x).all() and np.isfinite(eng.getControlSeq()).all() and x[S_VEL] > 1.5
+
+
+def test_oracle_racer_leash_in_body_frame():
+    """RacerDubinsImpl::enforceLeash (racer_dubins.cu:176-240) through ColoredMPPI's leash: a position error of (3, 0) in the
+    map frame for a car heading 90 deg left is (0, -3) in its body frame, so the y leash limits it; yaw takes the short way
+    round"""
+    cfg = elevation_cfg(K=64, T=8, with_map=False)
+    o = make_oracle(cfg)
+    leash = np.full(19, 100.0, np.float32)
+    leash[S_X], leash[S_Y], leash[S_YAW] = 1.0, 0.5, 0.2
+    o.set_colored_mppi_params(0.0, 0.0, leash, True, 1)
+    # nominal trajectory: put a known state at index 1 through one compute_control from a chosen start
+    x_true = st(0.0, math.pi / 2, 0.0, 0.0)
+    nominal = st(0.0, -math.pi + 0.1, 3.0, 0.0)
+    out = o.enforce_leash(x_true, nominal, leash)
+    # body frame of the true state (x forward = +Y map): dx_body = dx cos + dy sin = 0, dy_body = -dx sin + dy cos = -3 -> -0.5
+    assert abs(out[S_X] - 0.5) <= 1e-6 and abs(out[S_Y]) <= 1e-6
+    # yaw: from pi/2 to -pi + 0.1 the short way is +(pi/2 + 0.1) -> limited to +0.2
+    assert abs(out[S_YAW] - (math.pi / 2 + 0.2)) <= 1e-6
+    assert out[S_VEL] == nominal[S_VEL]
+
+
+@pytest.mark.gpu
+def test_elevation_colored_mppi_leash_parity(gpu):
+    """ColoredMPPI with the state leash on the elevation model: the engine applies the RACER body-frame rule on the host
+    (has_host_leash) as the oracle does; closed loop with a drifting measured state"""
+    cfg = elevation_cfg(K=1024, T=48)
+    cfg["colored"] = ([1.0, 1.0], 0.97, 0.0)
+    from common import host_spectrum
+    eng, orc = make_engine(cfg), make_oracle(cfg)
+    leash = np.full(19, 0.5, np.float32)
+    leash[S_X], leash[S_Y], leash[S_YAW], leash[S_VEL] = 0.3, 0.1, 0.05, 0.2
+    eng.setColoredMPPIParams(gamma=0.0, r_exp=0.0, state_leash_dist=leash, leash_active=True, leash_jump=1)
+    orc.set_colored_mppi_params(0.0, 0.0, leash, True, 1)
+    exps, decay, fmin = cfg["colored"]
+    x = cfg["x0"].copy()
+    for i in range(4):
+        z = host_spectrum(1, cfg["K"], cfg["T"], 2, seed=60 + i)
+        eng.injectNoise(z)
+        eng.computeControl(x, 1)
+        orc.colored_compute_control(x, 1, z, exps, decay, fmin)
+        assert np.abs(eng.getControlSeq() - orc.control()).max() <= 1e-5
+        assert np.abs(eng.getTargetStateSeq() - orc.state_traj()).max() <= 1e-4
+        x, _ = orc.model_step(x, orc.control()[0])
+        x[:4] += np.array([0.3, 0.1, 0.4, -0.3], np.float32)   # the measured state drifts: the leash has something to do
+        eng.slideControlSequence(1)
+        orc.vanilla_slide(1)
