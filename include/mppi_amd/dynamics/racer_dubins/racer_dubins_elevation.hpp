@@ -33,11 +33,12 @@
 #define U_IND_CLASS(CLASS, enum_val) E_INDEX(CLASS::UncertaintyIndex, enum_val)
 #define U_INDEX(enum_val) U_IND_CLASS(PARENT_CLASS::DYN_PARAMS_T, enum_val)
 #endif
-/* index shorthands on the (non-dependent) parameter struct: the classes below are templates over the derived class */
-#define RDE_S(enum_val) S_IND_CLASS(RacerDubinsElevationParams, enum_val)
-#define RDE_C(enum_val) C_IND_CLASS(RacerDubinsElevationParams, enum_val)
-#define RDE_O(enum_val) O_IND_CLASS(RacerDubinsElevationParams, enum_val)
-#define RDE_U(enum_val) U_IND_CLASS(RacerDubinsElevationParams, enum_val)
+/* index shorthands on PARAMS_T — the parameter struct of the class they are used in (a template parameter in the *Impl
+ * classes, a member alias in the concrete ones): the RACER subclasses re-number the states */
+#define RDE_S(enum_val) S_IND_CLASS(PARAMS_T, enum_val)
+#define RDE_C(enum_val) C_IND_CLASS(PARAMS_T, enum_val)
+#define RDE_O(enum_val) O_IND_CLASS(PARAMS_T, enum_val)
+#define RDE_U(enum_val) U_IND_CLASS(PARAMS_T, enum_val)
 
 /** reference: racer_dubins_elevation.cuh:16-60 */
 struct RacerDubinsElevationParams : public RacerDubinsParams
@@ -87,15 +88,17 @@ struct RacerDubinsElevationParams : public RacerDubinsParams
 
 /** reference: RacerDubinsElevationImpl<CLASS_T, PARAMS_T> (racer_dubins_elevation.cuh:62-150); CLASS_T is the model that is
  *  instantiated (RacerDubinsElevation below, RacerDubinsElevationLSTMSteering in its own header) */
-template <class CLASS_T>
-class RacerDubinsElevationImpl : public MPPI_internal::Dynamics<CLASS_T, RacerDubinsElevationParams>
+template <class CLASS_T, class PARAMS_T = RacerDubinsElevationParams>
+class RacerDubinsElevationImpl : public MPPI_internal::Dynamics<CLASS_T, PARAMS_T>
 {
 public:
-  using PARENT_CLASS = MPPI_internal::Dynamics<CLASS_T, RacerDubinsElevationParams>;
+  using PARENT_CLASS = MPPI_internal::Dynamics<CLASS_T, PARAMS_T>;
   static constexpr int STATE_DIM = RDE_S(NUM_STATES);
   static constexpr int CONTROL_DIM = RDE_C(NUM_CONTROLS);
   static constexpr int OUTPUT_DIM = RDE_O(NUM_OUTPUTS);
-  static const int UNCERTAINTY_DIM = U_IND_CLASS(RacerDubinsElevationParams, NUM_UNCERTAINTIES);
+  static const int UNCERTAINTY_DIM = U_IND_CLASS(PARAMS_T, NUM_UNCERTAINTIES);
+  /** states advanced by the explicit Euler step of updateState(): the first six here, more in the suspension models */
+  static constexpr int NUM_EULER_STATES = 6;
   static constexpr int UD = UNCERTAINTY_DIM;
 
   /** the elevation map (texture 0), reference: tex_helper_ of racer_dubins_elevation.cuh:88-96 */
@@ -196,7 +199,7 @@ public:
   /** racer_dubins.cu:281-293 (brake lag, faster on release) and :295-305 (steering lag) */
   __device__ inline void computeParametricDelayDeriv(const float* state, const float* control, float* state_der) const
   {
-    const RacerDubinsElevationParams& p = this->params_;
+    const PARAMS_T& p = this->params_;
     const bool enable_brake = control[RDE_C(THROTTLE_BRAKE)] < 0.0f;
     const float brake_error = (enable_brake * -control[RDE_C(THROTTLE_BRAKE)] - state[RDE_S(BRAKE_STATE)]);
     state_der[RDE_S(BRAKE_STATE)] = fminf(fmaxf((brake_error > 0) * brake_error * p.brake_delay_constant +
@@ -206,7 +209,7 @@ public:
   }
   __device__ inline void computeParametricSteerDeriv(const float* state, const float* control, float* state_der) const
   {
-    const RacerDubinsElevationParams& p = this->params_;
+    const PARAMS_T& p = this->params_;
     state_der[RDE_S(STEER_ANGLE)] =
         fmaxf(fminf((control[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - state[RDE_S(STEER_ANGLE)]) *
                         p.steering_constant,
@@ -248,7 +251,7 @@ public:
   __device__ inline void computeParametricAccelDeriv(const float* state, const float* control, float* state_der,
                                                      const StepTrig& g) const
   {
-    const RacerDubinsElevationParams& p = this->params_;
+    const PARAMS_T& p = this->params_;
     const float vx = state[RDE_S(VEL_X)];
     const float linear_brake_slope = 0.2f;
     const bool enable_brake = control[RDE_C(THROTTLE_BRAKE)] < 0.0f;
@@ -277,9 +280,9 @@ public:
   /** racer_dubins_elevation.cu:800-834: Euler step of the six integrated states, as in RacerDubins */
   __device__ inline void updateState(const float* state, float* next_state, const float* state_der, const float dt) const
   {
-    const RacerDubinsElevationParams& p = this->params_;
+    const PARAMS_T& p = this->params_;
 #pragma unroll
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < CLASS_T::NUM_EULER_STATES; i++)
     {
       float xn = state[i] + state_der[i] * dt;
       switch (i)
@@ -304,7 +307,7 @@ public:
   /** racer_dubins_elevation.cu:336-419 (device branch): A = df/dx + df/du K of the (v, yaw, x, y) error dynamics */
   __device__ inline void computeUncertaintyJacobian(const float* state, const StepTrig& g, float* A) const
   {
-    const RacerDubinsElevationParams& p = this->params_;
+    const PARAMS_T& p = this->params_;
     const float vx = state[RDE_S(VEL_X)];
     const float sin_yaw = g.sin_yaw, cos_yaw = g.cos_yaw;
     const float tan_steer_angle = g.tan_delta;
@@ -336,7 +339,7 @@ public:
   /** racer_dubins_elevation.cu:421-506 (device branch): process noise from |a_x|, |v|, steering and the side force */
   __device__ inline void computeQ(const float* state, const float* state_der, const StepTrig& g, float* Q) const
   {
-    const RacerDubinsElevationParams& p = this->params_;
+    const PARAMS_T& p = this->params_;
     const float abs_vx = fabsf(state[RDE_S(VEL_X)]);
     const float abs_acc_x = fabsf(state_der[RDE_S(VEL_X)]);
     const float delta = state[RDE_S(STEER_ANGLE)] / p.steer_angle_scale;
@@ -595,7 +598,7 @@ public:
   __device__ inline void stepFourLanes(float* state, float* next_state, float* state_der, float* control, float* output,
                                        const float dt, STEER&& steer, POST&& post)
   {
-    const RacerDubinsElevationParams& p = this->params_;
+    const PARAMS_T& p = this->params_;
     const int rep = (int)(threadIdx.x & 63) >> 4;
     float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM];
 #pragma unroll
@@ -744,6 +747,7 @@ public:
 class RacerDubinsElevation : public RacerDubinsElevationImpl<RacerDubinsElevation>
 {
 public:
+  using PARAMS_T = RacerDubinsElevationParams;
   RacerDubinsElevation(hipStream_t stream = nullptr) : RacerDubinsElevationImpl<RacerDubinsElevation>(stream)
   {
   }
@@ -770,6 +774,7 @@ class RacerDubinsElevationQuad : public RacerDubinsElevationImpl<RacerDubinsElev
 {
 public:
   using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationQuad>;
+  using PARAMS_T = RacerDubinsElevationParams;
   static constexpr int REPLICATED_LANES = 4;
 
   RacerDubinsElevationQuad(const RacerDubinsElevation& other) : ELEVATION(other.stream_)

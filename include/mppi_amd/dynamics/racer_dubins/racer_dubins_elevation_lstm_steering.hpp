@@ -32,10 +32,22 @@
 #include "mppi_amd/utils/nn_helpers/lstm_helper.hpp"
 #include "mppi_amd/utils/nn_helpers/lstm_registers.hpp"
 
-class RacerDubinsElevationLSTMSteering : public RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteering>
+/** reference: RacerDubinsElevationLSTMSteeringImpl<CLASS_T, PARAMS_T> (racer_dubins_elevation_lstm_steering.cuh:18-117);
+ *  CLASS_T is the instantiated model — RacerDubinsElevationLSTMSteering below, the suspension models in their own header */
+template <class CLASS_T, class PARAMS_T = RacerDubinsElevationParams>
+class RacerDubinsElevationLSTMSteeringImpl : public RacerDubinsElevationImpl<CLASS_T, PARAMS_T>
 {
 public:
-  using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteering>;
+  using ELEVATION = RacerDubinsElevationImpl<CLASS_T, PARAMS_T>;
+  using StepTrig = typename ELEVATION::StepTrig;
+  static constexpr int STATE_DIM = ELEVATION::STATE_DIM, CONTROL_DIM = ELEVATION::CONTROL_DIM,
+                       OUTPUT_DIM = ELEVATION::OUTPUT_DIM;
+  using ELEVATION::computeParametricAccelDeriv;
+  using ELEVATION::computeParametricDelayDeriv;
+  using ELEVATION::computeStaticSettling;
+  using ELEVATION::computeUncertaintyPropagation;
+  using ELEVATION::setOutputs;
+  using ELEVATION::stateTrig;
   static constexpr int LSTM_INPUT_DIM = 4;
 
   static constexpr int FAST_H = 4, FAST_L1 = 20;
@@ -46,7 +58,7 @@ public:
   /** true while the network has the shape FAST_NET is compiled for */
   bool register_form_ = true;
 
-  RacerDubinsElevationLSTMSteering(hipStream_t stream = nullptr) : ELEVATION(stream)
+  RacerDubinsElevationLSTMSteeringImpl(hipStream_t stream = nullptr) : ELEVATION(stream)
   {
     const int out_layers[3] = { 4 + LSTM_INPUT_DIM, 20, 1 };
     lstm_.setStructure(LSTM_INPUT_DIM, 4, out_layers, 3);
@@ -122,7 +134,7 @@ public:
   __device__ inline void computeLSTMSteering(const float* state, const float* control, float* state_der,
                                              float* theta_s) const
   {
-    const RacerDubinsElevationParams& p = this->params_;
+    const PARAMS_T& p = this->params_;
     const float steer = state[RDE_S(STEER_ANGLE)], rate = state[RDE_S(STEER_ANGLE_RATE)];
     const float parametric_accel = (control[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - steer) * p.steering_constant;
     float rate_dot = fmaxf(fminf((parametric_accel - rate) * p.steer_accel_constant - rate * p.steer_accel_drag_constant,
@@ -197,6 +209,16 @@ public:
   }
 };
 
+class RacerDubinsElevationLSTMSteering : public RacerDubinsElevationLSTMSteeringImpl<RacerDubinsElevationLSTMSteering>
+{
+public:
+  using PARAMS_T = RacerDubinsElevationParams;
+  RacerDubinsElevationLSTMSteering(hipStream_t stream = nullptr)
+    : RacerDubinsElevationLSTMSteeringImpl<RacerDubinsElevationLSTMSteering>(stream)
+  {
+  }
+};
+
 /**
  * Four lanes per rollout (see RacerDubinsElevationQuad): on top of the shared-out trigonometry, wheels and covariance
  * rows, replica r of a rollout evaluates hidden unit r of the LSTM (its four gates: 32 multiply-adds, 5 transcendentals)
@@ -211,6 +233,7 @@ class RacerDubinsElevationLSTMSteeringQuad : public RacerDubinsElevationImpl<Rac
 {
 public:
   using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteeringQuad>;
+  using PARAMS_T = RacerDubinsElevationParams;
   static constexpr int REPLICATED_LANES = 4;
   static constexpr int I = 4, H = 4, L1 = 20, PER = L1 / 4;
   static constexpr int HH = H * H, HI = H * I, LSTM_NUM_PARAMS = 4 * HH + 4 * HI + 4 * H;
@@ -278,7 +301,7 @@ public:
   /** racer_dubins_elevation_lstm_steering.cu:131-167, the network shared out over the four replicas */
   __device__ inline void computeLSTMSteering(const float* state, const float* control, float* state_der)
   {
-    const RacerDubinsElevationParams& p = this->params_;
+    const PARAMS_T& p = this->params_;
     const float steer = state[RDE_S(STEER_ANGLE)], rate = state[RDE_S(STEER_ANGLE_RATE)];
     const float parametric_accel = (control[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - steer) * p.steering_constant;
     float rate_dot = fmaxf(fminf((parametric_accel - rate) * p.steer_accel_constant - rate * p.steer_accel_drag_constant,

@@ -11,6 +11,8 @@ for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
 import numpy as np  # noqa: E402
 import mppi_generic_amd as m  # noqa: E402
 from common import autorally_cfg, bicycle_lstm_cfg, cartpole_cfg, di_cfg, make_engine, racer_cfg  # noqa: E402
+from test_racer_dubins_elevation import elevation_cfg as _elev  # noqa: E402
+from test_racer_dubins_lstm_steering import steering_cfg as _steer  # noqa: E402
 
 MODELS = {
     "cartpole": lambda: cartpole_cfg(K=16384, T=100),
@@ -18,10 +20,15 @@ MODELS = {
     "autorally_nn": lambda: autorally_cfg(K=16384, T=150, lambda_=1.0),
     "bicycle_slip_lstm": lambda: bicycle_lstm_cfg(K=16384, T=200, lambda_=1.0),
     "racer_dubins": lambda: racer_cfg(K=16384, T=100),
+    "racer_dubins_elevation": lambda: _elev(K=16384, T=100),
+    "racer_dubins_elevation_lstm_steering": lambda: _steer(K=16384, T=100),
 }
+ROBUST_MODELS = ("cartpole", "double_integrator", "autorally_nn", "bicycle_slip_lstm", "racer_dubins")
 bad = 0
 for name, mk in MODELS.items():
     for kind in ("vanilla", "tube", "colored", "robust"):
+        if kind == "robust" and name not in ROBUST_MODELS:
+            continue   # the elevation-map models are registered for Vanilla, Tube and Colored MPPI
         cfg = mk()
         S = len(cfg["x0"])
         try:
