@@ -39,6 +39,7 @@
 #define RDE_C(enum_val) C_IND_CLASS(PARAMS_T, enum_val)
 #define RDE_O(enum_val) O_IND_CLASS(PARAMS_T, enum_val)
 #define RDE_U(enum_val) U_IND_CLASS(PARAMS_T, enum_val)
+#define RDE_W(enum_val) E_INDEX(PARAMS_T::WheelIndex, enum_val)
 
 /** reference: racer_dubins_elevation.cuh:16-60 */
 struct RacerDubinsElevationParams : public RacerDubinsParams

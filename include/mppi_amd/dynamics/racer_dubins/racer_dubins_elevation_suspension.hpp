@@ -1,0 +1,275 @@
+/**
+ * RacerDubinsElevationSuspension plugin — the elevation-map RACER Dubins car with the LSTM steering column and a
+ * spring / damper suspension in place of the static settling: roll, pitch and the height of the centre of gravity are
+ * dynamic states driven by the four wheel forces, which follow from the terrain height and the terrain NORMAL under
+ * each wheel (a second, four-channel map).
+ *
+ * Reference: include/mppi/dynamics/racer_dubins/racer_dubins_elevation_suspension_lstm.cuh:17-66 (parameters, the 24-entry
+ * state layout), racer_dubins_elevation_suspension_lstm.cu:199-340 (device computeSimpleSuspensionStep), :342-392 (device
+ * step), :394-417 (device updateState), :437-525 (setOutputs).  Kept as the reference has them:
+ *   - the front wheels' heading is yaw + S_INDEX(STEER_ANGLE) / -9.1 — the state INDEX (4), not the steering angle
+ *     (:253-259);
+ *   - rear-right sits at y = +0.737, rear-left at y = -0.737 (:261-266; the front pair is the other way round);
+ *   - roll and pitch enter the force geometry as angles (small-angle form), un-wrapped;
+ *   - initializeDynamics() fills the t = 0 outputs with the ELEVATION model's setOutputs (the parent's using-declaration,
+ *     racer_dubins_elevation_lstm_steering.cuh:28), i.e. NaN wheel forces at t = 0 and real ones from the first step on.
+ * Defined here where the reference leaves it open: the three derivatives the wheels add to (vertical acceleration, roll
+ * and pitch acceleration) are accumulated in the order FL, FR, BL, BR (the reference uses atomicAdd from up to four
+ * threadIdx.y lanes, i.e. no fixed order).
+ * One lane per rollout; the eight map lookups of a step (4 heights, 4 normals x 4 channels) are issued together
+ * (TwoDTextureHelper::queryTextureAtWorldPoseBatch).  Maps: "elevation_map" / "elevation_map_transform" as for the parent,
+ * "normals_map" ({height, width, 4}: nx, ny, nz, unused) with "normals_map_transform" (defaults to the elevation map's).
+ */
+#ifndef MPPI_AMD_RACER_DUBINS_ELEVATION_SUSPENSION_HPP_
+#define MPPI_AMD_RACER_DUBINS_ELEVATION_SUSPENSION_HPP_
+
+#include "mppi_amd/dynamics/racer_dubins/racer_dubins_elevation_lstm_steering.hpp"
+
+/** reference: racer_dubins_elevation_suspension_lstm.cuh:17-66 */
+struct RacerDubinsElevationSuspensionParams : public RacerDubinsElevationParams
+{
+  enum class WheelIndex : int
+  {
+    FL = 0,
+    FR,
+    BL,
+    BR,
+    NUM_WHEELS,
+  };
+  enum class StateIndex : int
+  {
+    VEL_X = 0,
+    YAW,
+    POS_X,
+    POS_Y,
+    STEER_ANGLE,
+    BRAKE_STATE,
+    ROLL,
+    PITCH,
+    CG_POS_Z,
+    CG_VEL_I_Z,
+    ROLL_RATE,
+    PITCH_RATE,
+    STEER_ANGLE_RATE,
+    UNCERTAINTY_POS_X,
+    UNCERTAINTY_POS_Y,
+    UNCERTAINTY_YAW,
+    UNCERTAINTY_VEL_X,
+    UNCERTAINTY_POS_X_Y,
+    UNCERTAINTY_POS_X_YAW,
+    UNCERTAINTY_POS_X_VEL_X,
+    UNCERTAINTY_POS_Y_YAW,
+    UNCERTAINTY_POS_Y_VEL_X,
+    UNCERTAINTY_YAW_VEL_X,
+    FILLER_1,
+    NUM_STATES
+  };
+  float spring_k = 14000.0f;                                           ///< [N / m]
+  float drag_c = 1000.0f;                                              ///< [N s / m]
+  float mass = 1447.0f;                                                ///< [kg]
+  float I_xx = 1.0f / 12 * 1447.0f * 2 * (1.5f * 1.5f);                ///< [kg m^2]
+  float I_yy = 1.0f / 12 * 1447.0f * ((1.5f * 1.5f) + (3.0f * 3.0f));  ///< [kg m^2]
+  float wheel_radius = 0.32f;                                          ///< [m]
+  float c_g[3] = { 2.981f * 0.5f, 0.0f, 0.0f };                        ///< centre of gravity in the body frame
+};
+
+template <class CLASS_T, class PARAMS_T = RacerDubinsElevationSuspensionParams>
+class RacerDubinsElevationSuspensionImpl : public RacerDubinsElevationLSTMSteeringImpl<CLASS_T, PARAMS_T>
+{
+public:
+  using STEERING = RacerDubinsElevationLSTMSteeringImpl<CLASS_T, PARAMS_T>;
+  using ELEVATION = typename STEERING::ELEVATION;
+  using StepTrig = typename ELEVATION::StepTrig;
+  static constexpr int STATE_DIM = ELEVATION::STATE_DIM, CONTROL_DIM = ELEVATION::CONTROL_DIM,
+                       OUTPUT_DIM = ELEVATION::OUTPUT_DIM;
+  /** every state in front of STEER_ANGLE_RATE takes the explicit Euler step (racer_dubins_elevation_suspension_lstm.cu:401) */
+  static constexpr int NUM_EULER_STATES = RDE_S(STEER_ANGLE_RATE);
+  static constexpr int XD = RDE_S(STEER_ANGLE_RATE) + 1;
+  using ELEVATION::bodyRotation;
+  using ELEVATION::computeParametricAccelDeriv;
+  using ELEVATION::computeParametricDelayDeriv;
+  using ELEVATION::computeUncertaintyPropagation;
+  using ELEVATION::stateTrig;
+  using ELEVATION::wheelWorldPoint;
+  using STEERING::computeLSTMSteering;
+  using STEERING::updateState;
+
+  /** terrain normals (texture 0, four channels), reference: normals_tex_helper_ (…suspension_lstm.cuh:131-146) */
+  mppi::texture::TwoDTextureHelper<1, 4> normals_tex_helper_;
+
+  RacerDubinsElevationSuspensionImpl(hipStream_t stream = nullptr) : STEERING(stream)
+  {
+  }
+  static const char* getDynamicsModelName()
+  {
+    return "RACER Dubins LSTM Steering and Suspension Model";
+  }
+
+  /** wheel i = FL, FR, BL, BR: body-frame contact point (…suspension_lstm.cu:249-269) */
+  __device__ static inline float wheelBodyX(const int i)
+  {
+    return i < 2 ? 2.981f : 0.0f;
+  }
+  __device__ static inline float wheelBodyY(const int i)
+  {
+    return (i == RDE_W(FL) || i == RDE_W(BR)) ? 0.737f : -0.737f;
+  }
+
+  /**
+   * racer_dubins_elevation_suspension_lstm.cu:199-340: spring / damper force of every wheel from its height above the
+   * terrain and its vertical speed relative to the terrain, the resulting vertical, roll and pitch accelerations, and the
+   * largest upward / forward / sideways wheel force (outputs).  g: trigonometry of the current state.
+   */
+  __device__ inline void computeSimpleSuspensionStep(const float* state, float* state_der, const StepTrig& g,
+                                                     float* output) const
+  {
+    const PARAMS_T& p = this->params_;
+    state_der[RDE_S(ROLL)] = state[RDE_S(ROLL_RATE)];
+    state_der[RDE_S(PITCH)] = state[RDE_S(PITCH_RATE)];
+    state_der[RDE_S(CG_POS_Z)] = state[RDE_S(CG_VEL_I_Z)];
+    const float roll = state[RDE_S(ROLL)], pitch = state[RDE_S(PITCH)], yaw = state[RDE_S(YAW)];
+    float M[3][3];
+    bodyRotation(g, g.sin_yaw, g.cos_yaw, M);  // Euler2DCM_NWU(roll, pitch, yaw), device branch
+    float world[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      wheelWorldPoint(M, wheelBodyX(i), wheelBodyY(i), state[RDE_S(POS_X)], state[RDE_S(POS_Y)], world[i]);
+    float height[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    float normal[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+      normal[i][0] = 0.0f;
+      normal[i][1] = 0.0f;
+      normal[i][2] = 1.0f;
+      normal[i][3] = 0.0f;
+    }
+    if (this->tex_helper_.checkTextureUse(0))
+    {
+      this->tex_helper_.template queryTextureAtWorldPoseBatch<4>(0, world, height);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (!isfinite(height[i]))
+          height[i] = state[RDE_S(CG_POS_Z)] - p.wheel_radius;
+    }
+    if (normals_tex_helper_.checkTextureUse(0))
+    {
+      normals_tex_helper_.template queryTextureAtWorldPoseBatch<4>(0, world, &normal[0][0]);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (!isfinite(normal[i][0]) || !isfinite(normal[i][1]) || !isfinite(normal[i][2]))
+        {
+          normal[i][0] = 0.0f;
+          normal[i][1] = 0.0f;
+          normal[i][2] = 1.0f;
+          normal[i][3] = 0.0f;
+        }
+    }
+    float acc_z = 0.0f, acc_roll = 0.0f, acc_pitch = 0.0f;
+    float up[4], fwd[4], side[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+      // front wheels: the reference adds the state INDEX of the steering angle over -9.1 (kept, see the header)
+      const float wheel_yaw = (i < 2) ? yaw + (float)RDE_S(STEER_ANGLE) / -9.1f : yaw;
+      float sin_wheel_yaw, cos_wheel_yaw;
+      mppi::det::sincos(wheel_yaw, &sin_wheel_yaw, &cos_wheel_yaw);
+      const float cg_x = wheelBodyX(i) - p.c_g[0], cg_y = wheelBodyY(i) - p.c_g[1];
+      const float wheel_pos_z = state[RDE_S(CG_POS_Z)] + roll * cg_y - pitch * cg_x - p.wheel_radius;
+      const float wheel_vel_z = state[RDE_S(CG_VEL_I_Z)] + state[RDE_S(ROLL_RATE)] * cg_y - state[RDE_S(PITCH_RATE)] * cg_x;
+      const float nx = normal[i][0], ny = normal[i][1], nz = normal[i][2];
+      const float h_dot = -(state[RDE_S(VEL_X)] * cos_wheel_yaw * nx + state[RDE_S(VEL_X)] * sin_wheel_yaw * ny);
+      const float wheel_force = -p.spring_k * (wheel_pos_z - height[i]) - p.drag_c * (wheel_vel_z - h_dot);
+      const float fwd_wheel_force = wheel_force / nz * (nx * cos_wheel_yaw + ny * sin_wheel_yaw + nz * (-pitch));
+      const float side_wheel_force = wheel_force / nz * (-nx * sin_wheel_yaw + ny * cos_wheel_yaw + nz * roll);
+      up[i] = wheel_force;
+      fwd[i] = fabsf(fwd_wheel_force);
+      side[i] = fabsf(side_wheel_force);
+      acc_z += wheel_force / p.mass;
+      acc_roll += wheel_force * cg_y / p.I_xx;
+      acc_pitch += -wheel_force * cg_x / p.I_yy;
+    }
+    state_der[RDE_S(CG_VEL_I_Z)] = acc_z;
+    state_der[RDE_S(ROLL_RATE)] = acc_roll;
+    state_der[RDE_S(PITCH_RATE)] = acc_pitch;
+    output[RDE_O(WHEEL_FORCE_UP_MAX)] = fmaxf(up[0], fmaxf(up[1], fmaxf(up[2], up[3])));
+    output[RDE_O(WHEEL_FORCE_FWD_MAX)] = fmaxf(fwd[0], fmaxf(fwd[1], fmaxf(fwd[2], fwd[3])));
+    output[RDE_O(WHEEL_FORCE_SIDE_MAX)] = fmaxf(side[0], fmaxf(side[1], fmaxf(side[2], side[3])));
+  }
+
+  /** racer_dubins_elevation_suspension_lstm.cu:437-525: as the elevation model's, but the body height comes from the centre
+   *  of gravity and the wheel-force outputs are those of the suspension step */
+  __device__ inline void setSuspensionOutputs(const float* state_der, const float* next_state, float* output) const
+  {
+    output[RDE_O(BASELINK_VEL_B_X)] = next_state[RDE_S(VEL_X)];
+    output[RDE_O(BASELINK_VEL_B_Y)] = 0.0f;
+    output[RDE_O(BASELINK_POS_I_X)] = next_state[RDE_S(POS_X)];
+    output[RDE_O(BASELINK_POS_I_Y)] = next_state[RDE_S(POS_Y)];
+    output[RDE_O(BASELINK_POS_I_Z)] = next_state[RDE_S(CG_POS_Z)] - next_state[RDE_S(PITCH)] * (-this->params_.c_g[0]);
+    output[RDE_O(PITCH)] = next_state[RDE_S(PITCH)];
+    output[RDE_O(ROLL)] = next_state[RDE_S(ROLL)];
+    output[RDE_O(YAW)] = next_state[RDE_S(YAW)];
+    output[RDE_O(STEER_ANGLE)] = next_state[RDE_S(STEER_ANGLE)];
+    output[RDE_O(STEER_ANGLE_RATE)] = next_state[RDE_S(STEER_ANGLE_RATE)];
+    output[RDE_O(ACCEL_X)] = state_der[RDE_S(VEL_X)];
+    output[RDE_O(ACCEL_Y)] = 0.0f;
+    output[RDE_O(OMEGA_Z)] = state_der[RDE_S(YAW)];
+    output[RDE_O(UNCERTAINTY_VEL_X)] = next_state[RDE_S(UNCERTAINTY_VEL_X)];
+    output[RDE_O(UNCERTAINTY_YAW_VEL_X)] = next_state[RDE_S(UNCERTAINTY_YAW_VEL_X)];
+    output[RDE_O(UNCERTAINTY_POS_X_VEL_X)] = next_state[RDE_S(UNCERTAINTY_POS_X_VEL_X)];
+    output[RDE_O(UNCERTAINTY_POS_Y_VEL_X)] = next_state[RDE_S(UNCERTAINTY_POS_Y_VEL_X)];
+    output[RDE_O(UNCERTAINTY_YAW)] = next_state[RDE_S(UNCERTAINTY_YAW)];
+    output[RDE_O(UNCERTAINTY_POS_X_YAW)] = next_state[RDE_S(UNCERTAINTY_POS_X_YAW)];
+    output[RDE_O(UNCERTAINTY_POS_Y_YAW)] = next_state[RDE_S(UNCERTAINTY_POS_Y_YAW)];
+    output[RDE_O(UNCERTAINTY_POS_X)] = next_state[RDE_S(UNCERTAINTY_POS_X)];
+    output[RDE_O(UNCERTAINTY_POS_X_Y)] = next_state[RDE_S(UNCERTAINTY_POS_X_Y)];
+    output[RDE_O(UNCERTAINTY_POS_Y)] = next_state[RDE_S(UNCERTAINTY_POS_Y)];
+    output[RDE_O(TOTAL_VELOCITY)] = fabsf(next_state[RDE_S(VEL_X)]);
+  }
+
+  /** racer_dubins_elevation_suspension_lstm.cu:342-392 */
+  __device__ inline void step(float* state, float* next_state, float* state_der, float* control, float* output,
+                              float* theta_s, const float t, const float dt)
+  {
+    float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM], wheel_out[OUTPUT_DIM];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+    {
+      x[i] = state[i];
+      xn[i] = state[i];  // FILLER_1 is carried along (the reference never writes it)
+    }
+#pragma unroll
+    for (int i = 0; i < CONTROL_DIM; i++)
+      u[i] = control[i];
+    const StepTrig g = stateTrig(x);
+    computeParametricDelayDeriv(x, u, xd);
+    computeParametricAccelDeriv(x, u, xd, g);
+    computeLSTMSteering(x, u, xd, theta_s);
+    computeSimpleSuspensionStep(x, xd, g, wheel_out);
+    updateState(x, xn, xd, dt);
+    computeUncertaintyPropagation(x, xd, xn, dt, g);
+    mppi::lane_sync();
+#pragma unroll
+    for (int i = 0; i < XD; i++)
+      state_der[i] = xd[i];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+      next_state[i] = xn[i];
+    output[RDE_O(WHEEL_FORCE_UP_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_UP_MAX)];
+    output[RDE_O(WHEEL_FORCE_FWD_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_FWD_MAX)];
+    output[RDE_O(WHEEL_FORCE_SIDE_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_SIDE_MAX)];
+    setSuspensionOutputs(xd, xn, output);
+  }
+};
+
+class RacerDubinsElevationSuspension : public RacerDubinsElevationSuspensionImpl<RacerDubinsElevationSuspension>
+{
+public:
+  using PARAMS_T = RacerDubinsElevationSuspensionParams;
+  RacerDubinsElevationSuspension(hipStream_t stream = nullptr)
+    : RacerDubinsElevationSuspensionImpl<RacerDubinsElevationSuspension>(stream)
+  {
+  }
+};
+
+#endif

@@ -310,6 +310,15 @@ struct has_elevation_map<T, std::void_t<decltype(std::declval<T&>().tex_helper_.
 {
 };
 template <class T, class = void>
+struct has_normals_map : std::false_type
+{
+};
+/** dynamics with a second, four-channel map `normals_tex_helper_` (the suspension RACER models) */
+template <class T>
+struct has_normals_map<T, std::void_t<decltype(std::declval<T&>().normals_tex_helper_.textures_[0].data)>> : std::true_type
+{
+};
+template <class T, class = void>
 struct has_costmap : std::false_type
 {
 };
@@ -561,6 +570,8 @@ struct ModelT : ModelBase
   float* weights2_d = nullptr;
   float* costmap_d = nullptr;
   float* elevation_d = nullptr;
+  float* normals_d = nullptr;
+  bool normals_transform_set = false;
 
   ~ModelT() override
   {
@@ -576,6 +587,8 @@ struct ModelT : ModelBase
       (void)hipFree(costmap_d);
     if (elevation_d)
       (void)hipFree(elevation_d);
+    if (normals_d)
+      (void)hipFree(normals_d);
   }
 
   static mppi_status upload(float** dst, const float* src, size_t count, hipStream_t stream, std::string& err)
@@ -694,6 +707,57 @@ struct ModelT : ModelBase
           tex.rotations[i] = data[3 + i];
         for (int i = 0; i < 3; i++)
           tex.resolution[i] = data[12 + i];
+        if constexpr (has_normals_map<DYN_T>::value)
+        {  // the normals map shares the frame unless it was given its own
+          if (!normals_transform_set)
+          {
+            auto& ntex = dyn.normals_tex_helper_.textures_[0];
+            for (int i = 0; i < 3; i++)
+            {
+              ntex.origin[i] = tex.origin[i];
+              ntex.resolution[i] = tex.resolution[i];
+            }
+            for (int i = 0; i < 9; i++)
+              ntex.rotations[i] = tex.rotations[i];
+          }
+        }
+        return MPPI_OK;
+      }
+    }
+    if constexpr (has_normals_map<DYN_T>::value)
+    {
+      /* getTextureHelperNormals()->updateTexture(0, float4 data) (racer_dubins_elevation_suspension_lstm.cuh:131-134; the tests'
+       * set-up tests/dynamics/racer_dubins_elevation_suspension_test.cu:170-190): {height, width, 4} = nx, ny, nz, unused */
+      if (name == "normals_map")
+      {
+        if (ndims != 3 || dims[0] <= 0 || dims[1] <= 0 || dims[2] != 4 || (size_t)dims[0] * dims[1] * 4 != count)
+        {
+          err = "normals_map: dims must be {height, width, 4} with height*width*4 == count";
+          return MPPI_ERR_INVALID_ARG;
+        }
+        mppi_status st = upload(&normals_d, data, count, stream, err);
+        auto& tex = dyn.normals_tex_helper_.textures_[0];
+        tex.data = normals_d;
+        tex.height = dims[0];
+        tex.width = dims[1];
+        tex.use = (st == MPPI_OK);
+        return st;
+      }
+      if (name == "normals_map_transform")
+      {
+        if (count != 15)
+        {
+          err = "normals_map_transform: expected 15 floats (origin[3], rotations[9], resolution[3])";
+          return MPPI_ERR_INVALID_ARG;
+        }
+        auto& tex = dyn.normals_tex_helper_.textures_[0];
+        for (int i = 0; i < 3; i++)
+          tex.origin[i] = data[i];
+        for (int i = 0; i < 9; i++)
+          tex.rotations[i] = data[3 + i];
+        for (int i = 0; i < 3; i++)
+          tex.resolution[i] = data[12 + i];
+        normals_transform_set = true;
         return MPPI_OK;
       }
     }

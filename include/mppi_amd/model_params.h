@@ -10,6 +10,7 @@
  *   mppi_di_circle_cost_params      <- DoubleIntegratorCircleCostParams  cost_functions/double_integrator/double_integrator_circle_cost.cuh:8-23
  *   mppi_racer_dubins_params        <- RacerDubinsParams             dynamics/racer_dubins/racer_dubins.cuh:67-87
  *   mppi_racer_dubins_elevation_params <- RacerDubinsElevationParams dynamics/racer_dubins/racer_dubins_elevation.cuh:16-60
+ *   mppi_racer_dubins_suspension_params <- RacerDubinsElevationSuspensionParams dynamics/racer_dubins/racer_dubins_elevation_suspension_lstm.cuh:17-66
  *   mppi_quadratic_cost_params_28   <- QuadraticCostTrajectoryParams<RacerDubins, 1>  cost_functions/quadratic_cost/quadratic_cost.cuh:11-63
  * (paths relative to the reference's include/mppi/).
  */
@@ -95,6 +96,20 @@ typedef struct mppi_racer_dubins_elevation_params
   float Q_omega_v;        /* 0.001 */
   float Q_omega_steering; /* 0 */
 } mppi_racer_dubins_elevation_params;
+
+/** RacerDubinsElevationSuspensionParams (dynamics/racer_dubins/racer_dubins_elevation_suspension_lstm.cuh:17-66): the
+ *  elevation block followed by the spring / damper suspension */
+typedef struct mppi_racer_dubins_suspension_params
+{
+  mppi_racer_dubins_elevation_params elevation;
+  float spring_k;     /* 14000 N/m */
+  float drag_c;       /* 1000 N s/m */
+  float mass;         /* 1447 kg */
+  float I_xx;         /* mass / 12 * 2 * 1.5^2 */
+  float I_yy;         /* mass / 12 * (1.5^2 + 3^2) */
+  float wheel_radius; /* 0.32 m */
+  float c_g[3];       /* {2.981 / 2, 0, 0} */
+} mppi_racer_dubins_suspension_params;
 
 /** QuadraticCost over the 28 outputs of the RACER models, one goal (SIM_TIME_HORIZON = 1) */
 typedef struct mppi_quadratic_cost_params_28

@@ -131,6 +131,26 @@ class RacerDubinsElevationParams(C.Structure):
         self.Q_omega_steering = 0.0
 
 
+class RacerDubinsSuspensionParams(C.Structure):
+    """mppi_racer_dubins_suspension_params (reference: dynamics/racer_dubins/racer_dubins_elevation_suspension_lstm.cuh:17-66)"""
+    _fields_ = [("elevation", RacerDubinsElevationParams), ("spring_k", C.c_float), ("drag_c", C.c_float),
+                ("mass", C.c_float), ("I_xx", C.c_float), ("I_yy", C.c_float), ("wheel_radius", C.c_float),
+                ("c_g", C.c_float * 3)]
+
+    def __init__(self):
+        super().__init__()
+        RacerDubinsElevationParams.__init__(self.elevation)
+        self.spring_k, self.drag_c, self.mass = 14000.0, 1000.0, 1447.0
+        self.I_xx = np.float32(1.0) / np.float32(12) * np.float32(1447.0) * np.float32(2) * np.float32(2.25)
+        self.I_yy = np.float32(1.0) / np.float32(12) * np.float32(1447.0) * np.float32(11.25)
+        self.wheel_radius = 0.32
+        self.c_g[:] = [2.981 * 0.5, 0.0, 0.0]
+
+    @property
+    def base(self):
+        return self.elevation.base
+
+
 class QuadraticCostParams28(C.Structure):
     """mppi_quadratic_cost_params_28 (reference: QuadraticCostTrajectoryParams<RacerDubins, 1>,
     cost_functions/quadratic_cost/quadratic_cost.cuh:11-63)"""

@@ -1,0 +1,32 @@
+/**
+ * racer_dubins_elevation_suspension.hip — registered instantiation(s) of libmppi_amd.so: the elevation-map RACER Dubins car
+ * with LSTM steering and a spring / damper suspension (24 states; terrain heights + terrain normals maps) + QuadraticCost,
+ * Gaussian and colored-noise samplers.
+ *
+ * The analogue of the reference's include/mppi/instantiations/ + src/controllers/ (explicit template instantiations
+ * compiled into shared libraries, e.g. src/controllers/cartpole/cartpole_mppi.cu:30-42).  One translation unit per
+ * model, so a new or changed model recompiles alone (buildlib.py compiles the units in parallel).
+ *
+ * Block shapes: BY == 1, one lane per rollout (racer_dubins_elevation_suspension.hpp); fused rollout kernel (the LDS
+ * fallback of the steering network needs a block barrier in initializeDynamics, see racer_dubins_elevation_lstm_steering.hip).
+ */
+#include "mppi_amd/engine/model_registry.hpp"
+#include "mppi_amd/sampling_distributions/gaussian.hpp"
+#include "mppi_amd/sampling_distributions/colored_noise.hpp"
+#include "mppi_amd/dynamics/racer_dubins/racer_dubins_elevation_suspension.hpp"
+#include "mppi_amd/cost_functions/quadratic_cost/quadratic_cost.hpp"
+
+using namespace mppi;
+using namespace mppi::engine;
+
+using SuspensionCost = QuadraticCost<RacerDubinsElevationSuspension, /*SKIP_ZERO_COEFF=*/true>;
+using RacerSuspensionModel =
+    ModelT<RacerDubinsElevationSuspension, SuspensionCost,
+           sampling_distributions::GaussianDistribution<RacerDubinsElevationSuspensionParams>,
+           Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/2, void, Shapes<>, /*PIPELINE=*/false>;
+using RacerSuspensionColoredModel =
+    ModelT<RacerDubinsElevationSuspension, SuspensionCost,
+           sampling_distributions::ColoredNoiseDistribution<RacerDubinsElevationSuspensionParams>, Shapes<Shape<64, 1, 1>>,
+           /*FIN_BY=*/2, void, Shapes<>, /*PIPELINE=*/false>;
+MPPI_REGISTER_MODEL("racer_dubins_elevation_suspension", MPPI_SAMPLER_GAUSSIAN, RacerSuspensionModel, 64, 1)
+MPPI_REGISTER_MODEL("racer_dubins_elevation_suspension", MPPI_SAMPLER_COLORED, RacerSuspensionColoredModel, 64, 1)

@@ -63,6 +63,15 @@ int oracle_set_blob(void* h, const char* name, const float* data, size_t count, 
     auto* m = dynamic_cast<ARNeuralNetModel*>(c->dyn.get());
     return m ? m->setWeights(data, count) : -1;
   }
+  if (n == "normals_map" || n == "normals_map_transform")
+  {
+    auto* m = dynamic_cast<RacerDubinsElevationSuspension*>(c->dyn.get());
+    if (!m)
+      return -1;
+    if (n == "normals_map")
+      return (ndims == 3 && dims[2] == 4) ? m->setNormals(data, dims[0], dims[1]) : -1;
+    return m->setNormalsTransform(data, count);
+  }
   if (n == "lstm_structure")
   {
     auto* m = dynamic_cast<RacerDubinsElevationLSTMSteering*>(c->dyn.get());

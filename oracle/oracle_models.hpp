@@ -614,18 +614,24 @@ struct RacerDubinsElevation : Dynamics
     STEER_ANGLE,
     BRAKE_STATE,
     ROLL,
-    PITCH,
-    STEER_ANGLE_RATE,
-    UNCERTAINTY_POS_X,
-    UNCERTAINTY_POS_Y,
-    UNCERTAINTY_YAW,
-    UNCERTAINTY_VEL_X,
-    UNCERTAINTY_POS_X_Y,
-    UNCERTAINTY_POS_X_YAW,
-    UNCERTAINTY_POS_X_VEL_X,
-    UNCERTAINTY_POS_Y_YAW,
-    UNCERTAINTY_POS_Y_VEL_X,
-    UNCERTAINTY_YAW_VEL_X
+    PITCH
+  };
+  /* the subclasses re-number what follows (racer_dubins_elevation_suspension_lstm.cuh:27-54): index of the steering rate
+   * and of the first covariance entry; the ten covariance entries keep their order */
+  int STEER_ANGLE_RATE = 8, UNC = 9;
+  int num_euler = 6; /* states advanced by the explicit Euler step of updateState */
+  enum
+  {
+    K_POS_X = 0,
+    K_POS_Y,
+    K_YAW,
+    K_VEL_X,
+    K_POS_X_Y,
+    K_POS_X_YAW,
+    K_POS_X_VEL_X,
+    K_POS_Y_YAW,
+    K_POS_Y_VEL_X,
+    K_YAW_VEL_X
   };
   enum /* racer_dubins.cuh:37-66 */
   {
@@ -666,7 +672,7 @@ struct RacerDubinsElevation : Dynamics
     U_POS_Y,
     UD
   };
-  RacerDubinsElevation() : Dynamics(19, 2, 28)
+  explicit RacerDubinsElevation(int num_states = 19) : Dynamics(num_states, 2, 28)
   {
   }
   /** reference: RacerDubinsImpl::enforceLeash, dynamics/racer_dubins/racer_dubins.cu:176-240 (host; position error leashed
@@ -793,7 +799,7 @@ struct RacerDubinsElevation : Dynamics
   void updateState(const float* x, float* xn, const float* xdot, float dt) const override
   {
     const mppi_racer_dubins_params& b = p.base;
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < num_euler; i++)
     {
       xn[i] = x[i] + xdot[i] * dt;
       if (i == YAW)
@@ -856,31 +862,31 @@ struct RacerDubinsElevation : Dynamics
     Q[cm(U_POS_Y, U_POS_Y)] = Q_11 * cos_yaw * cos_yaw;
     Q[cm(U_POS_Y, U_POS_X)] = -Q_11 * sin_yaw * cos_yaw;
   }
-  static void stateToMatrix(const float* x, float* M)
+  void stateToMatrix(const float* x, float* M) const
   {
-    M[cm(U_VEL_X, U_VEL_X)] = x[UNCERTAINTY_VEL_X];
-    M[cm(U_YAW, U_VEL_X)] = M[cm(U_VEL_X, U_YAW)] = x[UNCERTAINTY_YAW_VEL_X];
-    M[cm(U_POS_X, U_VEL_X)] = M[cm(U_VEL_X, U_POS_X)] = x[UNCERTAINTY_POS_X_VEL_X];
-    M[cm(U_POS_Y, U_VEL_X)] = M[cm(U_VEL_X, U_POS_Y)] = x[UNCERTAINTY_POS_Y_VEL_X];
-    M[cm(U_YAW, U_YAW)] = x[UNCERTAINTY_YAW];
-    M[cm(U_POS_X, U_YAW)] = M[cm(U_YAW, U_POS_X)] = x[UNCERTAINTY_POS_X_YAW];
-    M[cm(U_POS_Y, U_YAW)] = M[cm(U_YAW, U_POS_Y)] = x[UNCERTAINTY_POS_Y_YAW];
-    M[cm(U_POS_X, U_POS_X)] = x[UNCERTAINTY_POS_X];
-    M[cm(U_POS_Y, U_POS_X)] = M[cm(U_POS_X, U_POS_Y)] = x[UNCERTAINTY_POS_X_Y];
-    M[cm(U_POS_Y, U_POS_Y)] = x[UNCERTAINTY_POS_Y];
+    M[cm(U_VEL_X, U_VEL_X)] = x[(UNC + K_VEL_X)];
+    M[cm(U_YAW, U_VEL_X)] = M[cm(U_VEL_X, U_YAW)] = x[(UNC + K_YAW_VEL_X)];
+    M[cm(U_POS_X, U_VEL_X)] = M[cm(U_VEL_X, U_POS_X)] = x[(UNC + K_POS_X_VEL_X)];
+    M[cm(U_POS_Y, U_VEL_X)] = M[cm(U_VEL_X, U_POS_Y)] = x[(UNC + K_POS_Y_VEL_X)];
+    M[cm(U_YAW, U_YAW)] = x[(UNC + K_YAW)];
+    M[cm(U_POS_X, U_YAW)] = M[cm(U_YAW, U_POS_X)] = x[(UNC + K_POS_X_YAW)];
+    M[cm(U_POS_Y, U_YAW)] = M[cm(U_YAW, U_POS_Y)] = x[(UNC + K_POS_Y_YAW)];
+    M[cm(U_POS_X, U_POS_X)] = x[(UNC + K_POS_X)];
+    M[cm(U_POS_Y, U_POS_X)] = M[cm(U_POS_X, U_POS_Y)] = x[(UNC + K_POS_X_Y)];
+    M[cm(U_POS_Y, U_POS_Y)] = x[(UNC + K_POS_Y)];
   }
-  static void matrixToState(const float* M, float* x)
+  void matrixToState(const float* M, float* x) const
   {
-    x[UNCERTAINTY_VEL_X] = M[cm(U_VEL_X, U_VEL_X)];
-    x[UNCERTAINTY_YAW_VEL_X] = M[cm(U_YAW, U_VEL_X)];
-    x[UNCERTAINTY_POS_X_VEL_X] = M[cm(U_POS_X, U_VEL_X)];
-    x[UNCERTAINTY_POS_Y_VEL_X] = M[cm(U_POS_Y, U_VEL_X)];
-    x[UNCERTAINTY_YAW] = M[cm(U_YAW, U_YAW)];
-    x[UNCERTAINTY_POS_X_YAW] = M[cm(U_POS_X, U_YAW)];
-    x[UNCERTAINTY_POS_Y_YAW] = M[cm(U_POS_Y, U_YAW)];
-    x[UNCERTAINTY_POS_X] = M[cm(U_POS_X, U_POS_X)];
-    x[UNCERTAINTY_POS_X_Y] = M[cm(U_POS_Y, U_POS_X)];
-    x[UNCERTAINTY_POS_Y] = M[cm(U_POS_Y, U_POS_Y)];
+    x[(UNC + K_VEL_X)] = M[cm(U_VEL_X, U_VEL_X)];
+    x[(UNC + K_YAW_VEL_X)] = M[cm(U_YAW, U_VEL_X)];
+    x[(UNC + K_POS_X_VEL_X)] = M[cm(U_POS_X, U_VEL_X)];
+    x[(UNC + K_POS_Y_VEL_X)] = M[cm(U_POS_Y, U_VEL_X)];
+    x[(UNC + K_YAW)] = M[cm(U_YAW, U_YAW)];
+    x[(UNC + K_POS_X_YAW)] = M[cm(U_POS_X, U_YAW)];
+    x[(UNC + K_POS_Y_YAW)] = M[cm(U_POS_Y, U_YAW)];
+    x[(UNC + K_POS_X)] = M[cm(U_POS_X, U_POS_X)];
+    x[(UNC + K_POS_X_Y)] = M[cm(U_POS_Y, U_POS_X)];
+    x[(UNC + K_POS_Y)] = M[cm(U_POS_Y, U_POS_Y)];
   }
   void uncertaintyPropagation(const float* x, const float* xdot, float* xn, float dt) const
   {
@@ -991,16 +997,16 @@ struct RacerDubinsElevation : Dynamics
     y[O_ACCEL_X] = xdot[VEL_X];
     y[O_ACCEL_Y] = 0.0f;
     y[O_OMEGA_Z] = xdot[YAW];
-    y[O_UNCERTAINTY_VEL_X] = xn[UNCERTAINTY_VEL_X];
-    y[O_UNCERTAINTY_YAW_VEL_X] = xn[UNCERTAINTY_YAW_VEL_X];
-    y[O_UNCERTAINTY_POS_X_VEL_X] = xn[UNCERTAINTY_POS_X_VEL_X];
-    y[O_UNCERTAINTY_POS_Y_VEL_X] = xn[UNCERTAINTY_POS_Y_VEL_X];
-    y[O_UNCERTAINTY_YAW] = xn[UNCERTAINTY_YAW];
-    y[O_UNCERTAINTY_POS_X_YAW] = xn[UNCERTAINTY_POS_X_YAW];
-    y[O_UNCERTAINTY_POS_Y_YAW] = xn[UNCERTAINTY_POS_Y_YAW];
-    y[O_UNCERTAINTY_POS_X] = xn[UNCERTAINTY_POS_X];
-    y[O_UNCERTAINTY_POS_X_Y] = xn[UNCERTAINTY_POS_X_Y];
-    y[O_UNCERTAINTY_POS_Y] = xn[UNCERTAINTY_POS_Y];
+    y[O_UNCERTAINTY_VEL_X] = xn[(UNC + K_VEL_X)];
+    y[O_UNCERTAINTY_YAW_VEL_X] = xn[(UNC + K_YAW_VEL_X)];
+    y[O_UNCERTAINTY_POS_X_VEL_X] = xn[(UNC + K_POS_X_VEL_X)];
+    y[O_UNCERTAINTY_POS_Y_VEL_X] = xn[(UNC + K_POS_Y_VEL_X)];
+    y[O_UNCERTAINTY_YAW] = xn[(UNC + K_YAW)];
+    y[O_UNCERTAINTY_POS_X_YAW] = xn[(UNC + K_POS_X_YAW)];
+    y[O_UNCERTAINTY_POS_Y_YAW] = xn[(UNC + K_POS_Y_YAW)];
+    y[O_UNCERTAINTY_POS_X] = xn[(UNC + K_POS_X)];
+    y[O_UNCERTAINTY_POS_X_Y] = xn[(UNC + K_POS_X_Y)];
+    y[O_UNCERTAINTY_POS_Y] = xn[(UNC + K_POS_Y)];
     y[O_TOTAL_VELOCITY] = fabsf(xn[VEL_X]);
   }
   void step(float* x, float* xn, float* xdot, const float* u, float* y, float* theta_s, int t, float dt) override
@@ -1029,7 +1035,7 @@ struct RacerDubinsElevation : Dynamics
 struct RacerDubinsElevationLSTMSteering : RacerDubinsElevation
 {
   LSTM net;
-  RacerDubinsElevationLSTMSteering()
+  explicit RacerDubinsElevationLSTMSteering(int num_states = 19) : RacerDubinsElevation(num_states)
   {
     net.setStructure(4, 4, { 8, 20, 1 });
   }
@@ -1058,10 +1064,10 @@ struct RacerDubinsElevationLSTMSteering : RacerDubinsElevation
     y[O_FILLER_1] = 0.0f;
     setOutputs(x, x, y);
   }
-  void step(float* x, float* xn, float* xdot, const float* u, float* y, float* theta_s, int t, float dt) override
+  /** racer_dubins_elevation_lstm_steering.cu:131-167 */
+  void lstmSteering(const float* x, const float* u, float* xdot, float* theta_s)
   {
     const mppi_racer_dubins_params& b = p.base;
-    computeDynamics(x, u, xdot, theta_s); /* brake lag and acceleration; the first-order steering lag is replaced below */
     const float parametric_accel = (u[1] * b.steer_command_angle_scale - x[STEER_ANGLE]) * b.steering_constant;
     xdot[STEER_ANGLE_RATE] =
         fmaxf(fminf((parametric_accel - x[STEER_ANGLE_RATE]) * b.steer_accel_constant - x[STEER_ANGLE_RATE] * b.steer_accel_drag_constant,
@@ -1076,6 +1082,11 @@ struct RacerDubinsElevationLSTMSteering : RacerDubinsElevation
     net.forward(in, theta_s, theta_s + net.H, nn_out.data());
     xdot[STEER_ANGLE_RATE] += nn_out[0] * 5.0f;
     xdot[STEER_ANGLE] = x[STEER_ANGLE_RATE];
+  }
+  void step(float* x, float* xn, float* xdot, const float* u, float* y, float* theta_s, int t, float dt) override
+  {
+    computeDynamics(x, u, xdot, theta_s); /* brake lag and acceleration; the first-order steering lag is replaced below */
+    lstmSteering(x, u, xdot, theta_s);
     updateState(x, xn, xdot, dt);
     xn[STEER_ANGLE_RATE] = x[STEER_ANGLE_RATE] + xdot[STEER_ANGLE_RATE] * dt;
     uncertaintyPropagation(x, xdot, xn, dt);
@@ -1085,6 +1096,195 @@ struct RacerDubinsElevationLSTMSteering : RacerDubinsElevation
     xn[PITCH] = pitch;
     xn[ROLL] = roll;
     setOutputs(xdot, xn, y);
+  }
+};
+
+/**
+ * reference (DEVICE flavour): dynamics/racer_dubins/racer_dubins_elevation_suspension_lstm.cu:199-340
+ * (computeSimpleSuspensionStep), :342-392 (step), :394-417 (updateState), :437-525 (setOutputs); parameters and the 24-entry
+ * state layout: racer_dubins_elevation_suspension_lstm.cuh:17-66.  The wheel contributions to the three accelerations are
+ * summed in the order FL, FR, BL, BR (the reference: atomicAdd, no fixed order).  The reference's tests for this class
+ * compare its GPU and CPU paths with each other on random data (tests/dynamics/racer_dubins_elevation_suspension_test.cu);
+ * there is no known answer to pin on — see tests/test_racer_dubins_suspension.py for what is checked instead.
+ */
+struct RacerDubinsElevationSuspension : RacerDubinsElevationLSTMSteering
+{
+  enum
+  {
+    CG_POS_Z = 8,
+    CG_VEL_I_Z,
+    ROLL_RATE,
+    PITCH_RATE,
+    FILLER_1 = 23
+  };
+  mppi_racer_dubins_suspension_params sp;
+  Texture2D normals;
+  std::vector<float> normals_values;
+  bool use_normals = false, normals_transform_set = false;
+  RacerDubinsElevationSuspension() : RacerDubinsElevationLSTMSteering(24)
+  {
+    STEER_ANGLE_RATE = 12;
+    UNC = 13;
+    num_euler = 12;
+    sp.elevation = p;
+    sp.spring_k = 14000.0f;
+    sp.drag_c = 1000.0f;
+    sp.mass = 1447.0f;
+    sp.I_xx = 1.0f / 12 * sp.mass * 2 * ORACLE_SQ(1.5f);
+    sp.I_yy = 1.0f / 12 * sp.mass * (ORACLE_SQ(1.5f) + ORACLE_SQ(3.0f));
+    sp.wheel_radius = 0.32f;
+    sp.c_g[0] = 2.981f * 0.5f;
+    sp.c_g[1] = 0.0f;
+    sp.c_g[2] = 0.0f;
+    normals.channels = 4;
+  }
+  int setParams(const void* pod, size_t n) override
+  {
+    if (n != sizeof(sp))
+      return -1;
+    memcpy(&sp, pod, n);
+    p = sp.elevation;
+    return 0;
+  }
+  int setNormals(const float* data, int height, int width)
+  {
+    normals_values.assign(data, data + (size_t)height * width * 4);
+    normals.values = normals_values.data();
+    normals.height = height;
+    normals.width = width;
+    use_normals = true;
+    return 0;
+  }
+  void copyFrame(const Texture2D& from, Texture2D& to)
+  {
+    for (int i = 0; i < 3; i++)
+    {
+      to.origin[i] = from.origin[i];
+      to.resolution[i] = from.resolution[i];
+      for (int j = 0; j < 3; j++)
+        to.rot[i][j] = from.rot[i][j];
+    }
+  }
+  int setNormalsTransform(const float* t, size_t count)
+  {
+    if (count != 15)
+      return -1;
+    for (int i = 0; i < 3; i++)
+      normals.origin[i] = t[i];
+    for (int i = 0; i < 9; i++)
+      normals.rot[i / 3][i % 3] = t[3 + i];
+    for (int i = 0; i < 3; i++)
+      normals.resolution[i] = t[12 + i];
+    normals_transform_set = true;
+    return 0;
+  }
+  void suspensionStep(const float* x, float* xdot, float* y) const
+  {
+    xdot[ROLL] = x[ROLL_RATE];
+    xdot[PITCH] = x[PITCH_RATE];
+    xdot[CG_POS_Z] = x[CG_VEL_I_Z];
+    const float roll = x[ROLL], pitch = x[PITCH], yaw = x[YAW];
+    /* Euler2DCM_NWU, device branch (utils/math_utils.h:457-482) */
+    float sin_phi, cos_phi, sin_theta, cos_theta, sin_psi, cos_psi;
+    det::sincos(det::normalizeAngle(roll), &sin_phi, &cos_phi);
+    det::sincos(det::normalizeAngle(pitch), &sin_theta, &cos_theta);
+    det::sincos(det::normalizeAngle(yaw), &sin_psi, &cos_psi);
+    float M[3][3];
+    M[0][0] = cos_theta * cos_psi;
+    M[0][1] = sin_phi * sin_theta * cos_psi - cos_phi * sin_psi;
+    M[0][2] = cos_phi * sin_theta * cos_psi + sin_phi * sin_psi;
+    M[1][0] = cos_theta * sin_psi;
+    M[1][1] = sin_phi * sin_theta * sin_psi + cos_phi * cos_psi;
+    M[1][2] = cos_phi * sin_theta * sin_psi - sin_phi * cos_psi;
+    M[2][0] = -sin_theta;
+    M[2][1] = sin_phi * cos_theta;
+    M[2][2] = cos_phi * cos_theta;
+    /* FL, FR, BL, BR (:249-269; rear-right at y = +0.737, rear-left at -0.737, as the reference) */
+    const float body[4][3] = { { 2.981f, 0.737f, 0.0f }, { 2.981f, -0.737f, 0.0f }, { 0.0f, -0.737f, 0.0f }, { 0.0f, 0.737f, 0.0f } };
+    const float body_pose[3] = { x[POS_X], x[POS_Y], 0.0f };
+    float wheel_height = 0.0f;
+    float n[4] = { 0.0f, 0.0f, 1.0f, 0.0f };
+    float up[4], fwd[4], side[4];
+    float acc_z = 0.0f, acc_roll = 0.0f, acc_pitch = 0.0f;
+    for (int i = 0; i < 4; i++)
+    {
+      float wheel_yaw = yaw;
+      if (i < 2)
+        wheel_yaw += STEER_ANGLE / -9.1f; /* the state INDEX (4), :253 and :257 */
+      float sin_wheel_yaw, cos_wheel_yaw;
+      det::sincos(wheel_yaw, &sin_wheel_yaw, &cos_wheel_yaw); /* __sincosf */
+      const float cg[3] = { body[i][0] - sp.c_g[0], body[i][1] - sp.c_g[1], body[i][2] - sp.c_g[2] };
+      float world[3], mp[3], tc[3];
+      for (int r = 0; r < 3; r++)
+      {
+        float accumulator = 0;
+        for (int k = 0; k < 3; k++)
+          accumulator += M[r][k] * body[i][k];
+        world[r] = 1.0f * accumulator;
+        world[r] += body_pose[r];
+      }
+      if (use_map)
+      {
+        map.worldToMap(world, mp);
+        map.mapToTex(mp, tc);
+        map.query(tc, &wheel_height);
+        if (!std::isfinite(wheel_height))
+          wheel_height = x[CG_POS_Z] - sp.wheel_radius;
+      }
+      if (use_normals)
+      {
+        normals.worldToMap(world, mp);
+        normals.mapToTex(mp, tc);
+        normals.query(tc, n);
+        if (!std::isfinite(n[0]) || !std::isfinite(n[1]) || !std::isfinite(n[2]))
+        {
+          n[0] = 0.0f;
+          n[1] = 0.0f;
+          n[2] = 1.0f;
+          n[3] = 0.0f;
+        }
+      }
+      const float wheel_pos_z = x[CG_POS_Z] + roll * cg[1] - pitch * cg[0] - sp.wheel_radius;
+      const float wheel_vel_z = x[CG_VEL_I_Z] + x[ROLL_RATE] * cg[1] - x[PITCH_RATE] * cg[0];
+      const float h_dot = -(x[VEL_X] * cos_wheel_yaw * n[0] + x[VEL_X] * sin_wheel_yaw * n[1]);
+      float wheel_force = -sp.spring_k * (wheel_pos_z - wheel_height) - sp.drag_c * (wheel_vel_z - h_dot);
+      float fwd_wheel_force = wheel_force / n[2] * (n[0] * cos_wheel_yaw + n[1] * sin_wheel_yaw + n[2] * (-pitch));
+      float side_wheel_force = wheel_force / n[2] * (-n[0] * sin_wheel_yaw + n[1] * cos_wheel_yaw + n[2] * roll);
+      up[i] = wheel_force;
+      fwd[i] = fabsf(fwd_wheel_force);
+      side[i] = fabsf(side_wheel_force);
+      acc_z += wheel_force / sp.mass;
+      acc_roll += wheel_force * cg[1] / sp.I_xx;
+      acc_pitch += -wheel_force * cg[0] / sp.I_yy;
+    }
+    xdot[CG_VEL_I_Z] = acc_z;
+    xdot[ROLL_RATE] = acc_roll;
+    xdot[PITCH_RATE] = acc_pitch;
+    y[O_WHEEL_FORCE_UP_MAX] = fmaxf(up[0], fmaxf(up[1], fmaxf(up[2], up[3])));
+    y[O_WHEEL_FORCE_FWD_MAX] = fmaxf(fwd[0], fmaxf(fwd[1], fmaxf(fwd[2], fwd[3])));
+    y[O_WHEEL_FORCE_SIDE_MAX] = fmaxf(side[0], fmaxf(side[1], fmaxf(side[2], side[3])));
+  }
+  void setSuspensionOutputs(const float* xdot, const float* xn, float* y) const
+  {
+    const float fwd = y[O_WHEEL_FORCE_FWD_MAX], side = y[O_WHEEL_FORCE_SIDE_MAX], up = y[O_WHEEL_FORCE_UP_MAX];
+    setOutputs(xdot, xn, y); /* the elevation model's list ... */
+    y[O_WHEEL_FORCE_UP_MAX] = up; /* ... without its NaN wheel forces (:437-525 has no such case) */
+    y[O_WHEEL_FORCE_FWD_MAX] = fwd;
+    y[O_WHEEL_FORCE_SIDE_MAX] = side;
+    y[O_BASELINK_POS_I_Z] = xn[CG_POS_Z] - xn[PITCH] * (-sp.c_g[0]);
+  }
+  void step(float* x, float* xn, float* xdot, const float* u, float* y, float* theta_s, int t, float dt) override
+  {
+    if (!normals_transform_set)
+      copyFrame(map, normals);
+    computeDynamics(x, u, xdot, theta_s); /* brake lag, acceleration, yaw and position rates */
+    lstmSteering(x, u, xdot, theta_s);
+    suspensionStep(x, xdot, y);
+    xn[FILLER_1] = x[FILLER_1];
+    updateState(x, xn, xdot, dt);
+    xn[STEER_ANGLE_RATE] = x[STEER_ANGLE_RATE] + xdot[STEER_ANGLE_RATE] * dt;
+    uncertaintyPropagation(x, xdot, xn, dt);
+    setSuspensionOutputs(xdot, xn, y);
   }
 };
 
@@ -1147,6 +1347,12 @@ inline bool makeModel(const std::string& name, std::unique_ptr<Dynamics>& dyn, s
   {
     dyn.reset(new DoubleIntegratorDynamics());
     cost.reset(new DoubleIntegratorCircleCost());
+    return true;
+  }
+  if (name == "racer_dubins_elevation_suspension")
+  {
+    dyn.reset(new RacerDubinsElevationSuspension());
+    cost.reset(new QuadraticCost28(true));
     return true;
   }
   if (name == "racer_dubins_elevation_lstm_steering")
