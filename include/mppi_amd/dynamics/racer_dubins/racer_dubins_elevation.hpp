@@ -130,7 +130,7 @@ public:
    * base initializeDynamics (output <- first states), plus a defined value in the outputs step() never writes
    * (FILLER_1; the reference leaves them to whatever the output buffer held)
    */
-  __device__ inline void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
+  __device__ __forceinline__ void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
                                             float dt)
   {
     PARENT_CLASS::initializeDynamics(state, control, output, theta_s, t_0, dt);
@@ -401,8 +401,17 @@ public:
    * racer_dubins_elevation.cu:672-738: Sigma' = (I + A dt) Sigma (I + A dt)^T + Q dt.  The two products are gemm1's sums
    * (matrix_mult_utils.cuh:82-192): accumulator from zero, k ascending, one multiply and one add per term.
    */
-  __device__ inline void computeUncertaintyPropagation(const float* state, const float* state_der, float* next_state,
+  __device__ __forceinline__ void computeUncertaintyPropagation(const float* state, const float* state_der, float* next_state,
                                                        const float dt, const StepTrig& g) const
+  {
+    computeUncertaintyPropagation(state, state_der, next_state, dt, g,
+                                  [this, state, state_der, &g](float* Q) { computeQ(state, state_der, g, Q); });
+  }
+  /** the same with the process noise supplied by the caller: process_noise(Q) fills the sixteen entries (the LSTM
+   *  uncertainty model has a network produce them, racer_dubins_elevation_lstm_unc.cu:300-494) */
+  template <class QFN>
+  __device__ __forceinline__ void computeUncertaintyPropagation(const float* state, const float* state_der, float* next_state,
+                                                       const float dt, const StepTrig& g, QFN&& process_noise) const
   {
     float A[UD * UD], Sigma_a[UD * UD], Sigma_b[UD * UD];
     computeUncertaintyJacobian(state, g, A);
@@ -432,7 +441,7 @@ public:
           acc += Sigma_b[cm(m, k)] * A[cm(n, k)];
         Sigma_a[cm(m, n)] = acc;
       }
-    computeQ(state, state_der, g, Sigma_b);
+    process_noise(Sigma_b);
 #pragma unroll
     for (int i = 0; i < UD * UD; i++)
       Sigma_a[i] += Sigma_b[i] * dt;
@@ -513,7 +522,7 @@ public:
    * the CURRENT roll and pitch are looked up in the elevation map; roll and pitch for the next state follow from the
    * height differences across the track width and the wheel base.
    */
-  __device__ inline void computeStaticSettling(const float yaw, const float x, const float y, const StepTrig& g, float& roll,
+  __device__ __forceinline__ void computeStaticSettling(const float yaw, const float x, const float y, const StepTrig& g, float& roll,
                                                float& pitch, float& height) const
   {
     height = 0.0f;
@@ -596,7 +605,7 @@ public:
    * XD: entries of the derivative the model produces (6, or 9 with the steering-rate derivative).
    */
   template <int XD, class STEER, class POST>
-  __device__ inline void stepFourLanes(float* state, float* next_state, float* state_der, float* control, float* output,
+  __device__ __forceinline__ void stepFourLanes(float* state, float* next_state, float* state_der, float* control, float* output,
                                        const float dt, STEER&& steer, POST&& post)
   {
     const PARAMS_T& p = this->params_;
@@ -712,7 +721,7 @@ public:
   }
 
   /** racer_dubins_elevation.cu:836-874 */
-  __device__ inline void step(float* state, float* next_state, float* state_der, float* control, float* output,
+  __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
                               float* theta_s, const float t, const float dt)
   {
     // every lane of a rollout works on private copies and stores the same results (see the header)
@@ -790,7 +799,7 @@ public:
     this->tex_helper_ = other.tex_helper_;
   }
 
-  __device__ inline void step(float* state, float* next_state, float* state_der, float* control, float* output,
+  __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
                               float* theta_s, const float t, const float dt)
   {
     stepFourLanes<6>(

@@ -86,29 +86,31 @@ public:
     return register_form_ ? 2 * FAST_H * (int)sizeof(float) : lstm_.getBlkSharedSizeBytes();
   }
   /** register form: value i of this lane's rollout slot at theta_s[i * slots + slot] */
-  __device__ static inline void loadRecurrent(const float* theta_s, float (&h)[FAST_H], float (&c)[FAST_H])
+  /** `net`: which of the rollout's networks (0 = steering; the uncertainty model keeps two more sets behind it) */
+  __device__ static inline void loadRecurrent(const float* theta_s, float (&h)[FAST_H], float (&c)[FAST_H], const int net = 0)
   {
     const int slots = (int)(blockDim.x * blockDim.z), slot = (int)(blockDim.x * threadIdx.z + threadIdx.x);
 #pragma unroll
     for (int i = 0; i < FAST_H; i++)
     {
-      h[i] = theta_s[i * slots + slot];
-      c[i] = theta_s[(FAST_H + i) * slots + slot];
+      h[i] = theta_s[(2 * FAST_H * net + i) * slots + slot];
+      c[i] = theta_s[(2 * FAST_H * net + FAST_H + i) * slots + slot];
     }
   }
-  __device__ static inline void storeRecurrent(float* theta_s, const float (&h)[FAST_H], const float (&c)[FAST_H])
+  __device__ static inline void storeRecurrent(float* theta_s, const float (&h)[FAST_H], const float (&c)[FAST_H],
+                                               const int net = 0)
   {
     const int slots = (int)(blockDim.x * blockDim.z), slot = (int)(blockDim.x * threadIdx.z + threadIdx.x);
 #pragma unroll
     for (int i = 0; i < FAST_H; i++)
     {
-      theta_s[i * slots + slot] = h[i];
-      theta_s[(FAST_H + i) * slots + slot] = c[i];
+      theta_s[(2 * FAST_H * net + i) * slots + slot] = h[i];
+      theta_s[(2 * FAST_H * net + FAST_H + i) * slots + slot] = c[i];
     }
   }
 
   /** racer_dubins_elevation_lstm_steering.cu:115-129: network parameters and (h0, c0) into LDS, outputs from the state */
-  __device__ inline void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
+  __device__ __forceinline__ void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
                                             float dt)
   {
     if (register_form_)
@@ -131,7 +133,7 @@ public:
   }
 
   /** racer_dubins_elevation_lstm_steering.cu:131-167 */
-  __device__ inline void computeLSTMSteering(const float* state, const float* control, float* state_der,
+  __device__ __forceinline__ void computeLSTMSteering(const float* state, const float* control, float* state_der,
                                              float* theta_s) const
   {
     const PARAMS_T& p = this->params_;
@@ -176,7 +178,7 @@ public:
   }
 
   /** racer_dubins_elevation_lstm_steering.cu:169-213 */
-  __device__ inline void step(float* state, float* next_state, float* state_der, float* control, float* output,
+  __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
                               float* theta_s, const float t, const float dt)
   {
     float x[STATE_DIM], xn[STATE_DIM], xd[RDE_S(STEER_ANGLE_RATE) + 1], u[CONTROL_DIM];
@@ -261,7 +263,7 @@ public:
     fnn_d_ = other.lstm_.output_nn_.theta_d_;
   }
 
-  __device__ inline void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
+  __device__ __forceinline__ void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
                                             float dt)
   {
     const int rep = (int)(threadIdx.x & 63) >> 4;
@@ -299,7 +301,7 @@ public:
   }
 
   /** racer_dubins_elevation_lstm_steering.cu:131-167, the network shared out over the four replicas */
-  __device__ inline void computeLSTMSteering(const float* state, const float* control, float* state_der)
+  __device__ __forceinline__ void computeLSTMSteering(const float* state, const float* control, float* state_der)
   {
     const PARAMS_T& p = this->params_;
     const float steer = state[RDE_S(STEER_ANGLE)], rate = state[RDE_S(STEER_ANGLE_RATE)];
@@ -368,7 +370,7 @@ public:
     state_der[RDE_S(STEER_ANGLE)] = rate;
   }
 
-  __device__ inline void step(float* state, float* next_state, float* state_der, float* control, float* output,
+  __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
                               float* theta_s, const float t, const float dt)
   {
     stepFourLanes<RDE_S(STEER_ANGLE_RATE) + 1>(

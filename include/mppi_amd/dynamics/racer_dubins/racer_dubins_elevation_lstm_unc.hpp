@@ -1,0 +1,245 @@
+/**
+ * RacerDubinsElevationLSTMUncertainty plugin — the complete RACER vehicle model of the reference: the suspension model
+ * (LSTM steering column, spring / damper body) with a quadratic brake lag, a "mean" LSTM that corrects the longitudinal
+ * acceleration and the yaw rate, an "uncertainty" LSTM whose outputs are the process noise of the covariance
+ * propagation, and the static settling of the plain elevation model kept alongside as two extra states.
+ *
+ * Reference: include/mppi/dynamics/racer_dubins/racer_dubins_elevation_lstm_unc.cuh:5-48 (parameters, the 26-entry state
+ * layout), racer_dubins_elevation_lstm_unc.cu:496-605 (device step), :300-494 (computeQ), :607-618 (device
+ * initializeDynamics).  Per step, in the reference's order:
+ *   brake lag       clamp([e > 0] (c0+ e + c1+ e |e|) + [e < 0] (c0- e + c1- e |e|), -r_neg, +r_pos),  e = brake_cmd - brake
+ *   acceleration, yaw and position rates (elevation model), LSTM steering, suspension forces (parents)
+ *   forward gear:   (dv/dt, dyaw/dt) += mean LSTM([v, omega_z, brake, steer, steer rate, throttle cmd, brake cmd, steer cmd,
+ *                   sin(static pitch), dv/dt, dyaw/dt])
+ *   omega_z' = dyaw/dt;  Euler step (suspension model);  covariance with Q from the uncertainty LSTM:
+ *                   o = |sigmoid(LSTM([..., sin(static roll), sin(static pitch), dv/dt, dyaw/dt])) * unc_scale|
+ *                   Q_vv = o0 + (c_b [idx == 0 ? v : 1])^2 o4 (+ o5),  Q_yaw = o1 + (v / L / (cos^2(delta) k))^2 o3 (+ o6),
+ *                   Q_xy block = o2 [sin^2, -sin cos; -sin cos, cos^2](yaw)
+ *   static settling from (static roll, static pitch) at the next pose -> the next static roll / pitch
+ * (In reverse gear the reference first calls the parent's computeQ and then overwrites every entry with the network's —
+ * :306-309 has no return; only the overwrite is restated here.  Network inputs the step does not fill are zero, as the
+ * reference's host path has them.)
+ *
+ * Networks: the shapes of the reference's tests (tests/dynamics/racer_dubins_elevation_lstm_uncertainty_model_test.cu:
+ * 26-48): steering LSTM(4, 4) + {8, 20, 1}, mean LSTM(12, 4) + {16, 20, 2}, uncertainty LSTM(13, 4) + {17, 20, 5}.  All
+ * three run on registers (utils/nn_helpers/lstm_registers.hpp: parameters through the scalar unit, activations in VGPRs);
+ * the 3 x (4 + 4) recurrent values of a rollout rest in LDS between steps, laid out [value][slot].  Blobs: the steering
+ * pair of the parent, "mean_lstm_weights" / "mean_lstm_output_weights", "unc_lstm_weights" / "unc_lstm_output_weights"
+ * (layouts of lstm_helper.hpp, initial hidden / cell state in the tail), and "mean_lstm_state" / "unc_lstm_state"
+ * ([hidden | cell]) for the per-cycle update the reference does in updateFromBuffer (:98-141; host: mppi::LSTMLSTMHelper).
+ */
+#ifndef MPPI_AMD_RACER_DUBINS_ELEVATION_LSTM_UNC_HPP_
+#define MPPI_AMD_RACER_DUBINS_ELEVATION_LSTM_UNC_HPP_
+
+#include "mppi_amd/dynamics/racer_dubins/racer_dubins_elevation_suspension.hpp"
+
+/** reference: racer_dubins_elevation_lstm_unc.cuh:5-48 */
+struct RacerDubinsElevationUncertaintyParams : public RacerDubinsElevationSuspensionParams
+{
+  enum class StateIndex : int
+  {
+    VEL_X = 0,
+    YAW,
+    POS_X,
+    POS_Y,
+    STEER_ANGLE,
+    BRAKE_STATE,
+    ROLL,
+    PITCH,
+    CG_POS_Z,
+    CG_VEL_I_Z,
+    ROLL_RATE,
+    PITCH_RATE,
+    STEER_ANGLE_RATE,
+    OMEGA_Z,
+    STATIC_ROLL,
+    STATIC_PITCH,
+    UNCERTAINTY_POS_X,
+    UNCERTAINTY_POS_Y,
+    UNCERTAINTY_YAW,
+    UNCERTAINTY_VEL_X,
+    UNCERTAINTY_POS_X_Y,
+    UNCERTAINTY_POS_X_YAW,
+    UNCERTAINTY_POS_X_VEL_X,
+    UNCERTAINTY_POS_Y_YAW,
+    UNCERTAINTY_POS_Y_VEL_X,
+    UNCERTAINTY_YAW_VEL_X,
+    NUM_STATES
+  };
+  float unc_scale[7] = { 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f };
+  float pos_quad_brake_c[3] = { 2.0f, 0.5f, 0.3f };
+  float neg_quad_brake_c[3] = { 5.84f, 0.15f, 1.7f };
+  int use_static_settling = 1;  ///< carried for layout compatibility (the reference's bool); the device step always settles
+};
+
+class RacerDubinsElevationLSTMUncertainty
+  : public RacerDubinsElevationSuspensionImpl<RacerDubinsElevationLSTMUncertainty, RacerDubinsElevationUncertaintyParams>
+{
+public:
+  using PARAMS_T = RacerDubinsElevationUncertaintyParams;
+  using SUSPENSION = RacerDubinsElevationSuspensionImpl<RacerDubinsElevationLSTMUncertainty, PARAMS_T>;
+  using MEAN_NET = mppi::LSTMRegisters<12, 4, 20, 2>;
+  using UNC_NET = mppi::LSTMRegisters<13, 4, 20, 5>;
+  static constexpr int NUM_NETWORKS = 3, NET_H = 4;
+  /** a step of this model is ~10^4 instructions: one copy of it per kernel (engine/rollout_kernel.hpp) */
+  static constexpr bool SINGLE_STEP_SITE = true;
+
+  const float* mean_lstm_d_ = nullptr;  ///< mean network: LSTM blob / output-network blob (device, owned by the engine)
+  const float* mean_fnn_d_ = nullptr;
+  const float* unc_lstm_d_ = nullptr;   ///< uncertainty network
+  const float* unc_fnn_d_ = nullptr;
+
+  RacerDubinsElevationLSTMUncertainty(hipStream_t stream = nullptr) : SUSPENSION(stream)
+  {
+  }
+  static const char* getDynamicsModelName()
+  {
+    return "RACER Dubins LSTM Uncertainty Model";
+  }
+  /** the three networks have the shapes this class is compiled for */
+  bool setLSTMStructure(const int*, int)
+  {
+    return false;
+  }
+  __host__ __device__ int getGrdSharedSizeBytes() const
+  {
+    return 0;
+  }
+  __host__ __device__ int getBlkSharedSizeBytes() const
+  {
+    return NUM_NETWORKS * 2 * NET_H * (int)sizeof(float);
+  }
+
+  /** racer_dubins_elevation_lstm_unc.cu:607-618: the parent's (steering state + outputs from the state), then the two
+   *  other networks' initial hidden / cell state */
+  __device__ __forceinline__ void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
+                                            float dt)
+  {
+    SUSPENSION::initializeDynamics(state, control, output, theta_s, t_0, dt);
+    float h[NET_H], c[NET_H];
+    MEAN_NET::initialState(mean_lstm_d_, h, c);
+    storeRecurrent(theta_s, h, c, 1);
+    UNC_NET::initialState(unc_lstm_d_, h, c);
+    storeRecurrent(theta_s, h, c, 2);
+  }
+
+  /** racer_dubins_elevation_lstm_unc.cu:300-494 (device branch) */
+  __device__ __forceinline__ void computeNetworkQ(const float* state, const float* control, const float* state_der,
+                                         const StepTrig& g, float* theta_s, float* Q) const
+  {
+    const PARAMS_T& p = this->params_;
+    const float vx = state[RDE_S(VEL_X)];
+    const float tb = control[RDE_C(THROTTLE_BRAKE)];
+    const float input[13] = { vx,
+                              state[RDE_S(OMEGA_Z)],
+                              state[RDE_S(BRAKE_STATE)],
+                              state[RDE_S(STEER_ANGLE)],
+                              state[RDE_S(STEER_ANGLE_RATE)],
+                              tb >= 0.0f ? tb : 0.0f,
+                              tb <= 0.0f ? -tb : 0.0f,
+                              control[RDE_C(STEER_CMD)],
+                              mppi::det::sin(state[RDE_S(STATIC_ROLL)]),
+                              mppi::det::sin(state[RDE_S(STATIC_PITCH)]),
+                              state_der[RDE_S(VEL_X)],
+                              state_der[RDE_S(YAW)],
+                              0.0f };
+    float o[5], h[NET_H], c[NET_H];
+    loadRecurrent(theta_s, h, c, 2);
+    UNC_NET::forward(unc_lstm_d_, unc_fnn_d_, input, h, c, o);
+    mppi::lane_sync();
+    storeRecurrent(theta_s, h, c, 2);
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+      o[i] = fabsf(mppi::det::sigmoid(o[i]) * p.unc_scale[i]);
+    const int index = speedRegime(vx);
+#pragma unroll
+    for (int i = 0; i < UD * UD; i++)
+      Q[i] = 0.0f;
+    const float brake_gain = pick3(p.c_b, index) * (index == 0 ? vx : 1.0f);
+    Q[cm(RDE_U(VEL_X), RDE_U(VEL_X))] = o[0] + (brake_gain * brake_gain) * o[4];
+    const float yaw_gain = (vx / p.wheel_base) * 1.0f / ((g.cos_delta * g.cos_delta) * p.steer_angle_scale);
+    Q[cm(RDE_U(YAW), RDE_U(YAW))] = o[1] + (yaw_gain * yaw_gain) * o[3];
+    Q[cm(RDE_U(POS_X), RDE_U(POS_X))] = o[2] * g.sin_yaw * g.sin_yaw;
+    Q[cm(RDE_U(POS_X), RDE_U(POS_Y))] = -o[2] * g.sin_yaw * g.cos_yaw;
+    Q[cm(RDE_U(POS_Y), RDE_U(POS_Y))] = o[2] * g.cos_yaw * g.cos_yaw;
+    Q[cm(RDE_U(POS_Y), RDE_U(POS_X))] = -o[2] * g.sin_yaw * g.cos_yaw;
+  }
+
+  /** racer_dubins_elevation_lstm_unc.cu:496-605 */
+  __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
+                              float* theta_s, const float t, const float dt)
+  {
+    const PARAMS_T& p = this->params_;
+    float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM], wheel_out[OUTPUT_DIM];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+      x[i] = state[i];
+#pragma unroll
+    for (int i = 0; i < CONTROL_DIM; i++)
+      u[i] = control[i];
+    const StepTrig g = stateTrig(x);
+    // the brake lag with linear + quadratic gains
+    {
+      const bool enable_brake = u[RDE_C(THROTTLE_BRAKE)] < 0.0f;
+      const float e = (enable_brake * -u[RDE_C(THROTTLE_BRAKE)] - x[RDE_S(BRAKE_STATE)]);
+      xd[RDE_S(BRAKE_STATE)] =
+          fminf(fmaxf((e > 0) * (e * p.pos_quad_brake_c[0] + e * fabsf(e) * p.pos_quad_brake_c[1]) +
+                          (e < 0) * (e * p.neg_quad_brake_c[0] + e * fabsf(e) * p.neg_quad_brake_c[1]),
+                      -p.max_brake_rate_neg),
+                p.max_brake_rate_pos);
+    }
+    computeParametricAccelDeriv(x, u, xd, g);
+    computeLSTMSteering(x, u, xd, theta_s);
+    computeSimpleSuspensionStep(x, xd, g, wheel_out);
+    if (p.gear_sign == 1)
+    {
+      const float tb = u[RDE_C(THROTTLE_BRAKE)];
+      const float input[12] = { x[RDE_S(VEL_X)],
+                                x[RDE_S(OMEGA_Z)],
+                                x[RDE_S(BRAKE_STATE)],
+                                x[RDE_S(STEER_ANGLE)],
+                                x[RDE_S(STEER_ANGLE_RATE)],
+                                tb >= 0.0f ? tb : 0.0f,
+                                tb <= 0.0f ? -tb : 0.0f,
+                                u[RDE_C(STEER_CMD)],
+                                mppi::det::sin(x[RDE_S(STATIC_PITCH)]),
+                                xd[RDE_S(VEL_X)],
+                                xd[RDE_S(YAW)],
+                                0.0f };
+      float mean_output[2], h[NET_H], c[NET_H];
+      loadRecurrent(theta_s, h, c, 1);
+      MEAN_NET::forward(mean_lstm_d_, mean_fnn_d_, input, h, c, mean_output);
+      mppi::lane_sync();
+      storeRecurrent(theta_s, h, c, 1);
+      xd[RDE_S(VEL_X)] += mean_output[0];
+      xd[RDE_S(YAW)] += mean_output[1];
+    }
+    updateState(x, xn, xd, dt);
+    xn[RDE_S(OMEGA_Z)] = xd[RDE_S(YAW)];
+    computeUncertaintyPropagation(x, xd, xn, dt, g,
+                                  [this, &x, &u, &xd, &g, theta_s](float* Q) { computeNetworkQ(x, u, xd, g, theta_s, Q); });
+    // static settling from the settled angles of the current state (the body's own roll / pitch are suspension states)
+    {
+      StepTrig gs = g;
+      mppi::det::sincos(angle_utils::normalizeAngle(x[RDE_S(STATIC_ROLL)]), &gs.sin_roll, &gs.cos_roll);
+      mppi::det::sincos(angle_utils::normalizeAngle(x[RDE_S(STATIC_PITCH)]), &gs.sin_pitch, &gs.cos_pitch);
+      float roll, pitch, height;
+      computeStaticSettling(xn[RDE_S(YAW)], xn[RDE_S(POS_X)], xn[RDE_S(POS_Y)], gs, roll, pitch, height);
+      xn[RDE_S(STATIC_PITCH)] = pitch;
+      xn[RDE_S(STATIC_ROLL)] = roll;
+    }
+    mppi::lane_sync();
+#pragma unroll
+    for (int i = 0; i < XD; i++)
+      state_der[i] = xd[i];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+      next_state[i] = xn[i];
+    output[RDE_O(WHEEL_FORCE_UP_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_UP_MAX)];
+    output[RDE_O(WHEEL_FORCE_FWD_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_FWD_MAX)];
+    output[RDE_O(WHEEL_FORCE_SIDE_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_SIDE_MAX)];
+    setSuspensionOutputs(xd, xn, output);
+  }
+};
+
+#endif

@@ -120,7 +120,7 @@ public:
    * terrain and its vertical speed relative to the terrain, the resulting vertical, roll and pitch accelerations, and the
    * largest upward / forward / sideways wheel force (outputs).  g: trigonometry of the current state.
    */
-  __device__ inline void computeSimpleSuspensionStep(const float* state, float* state_der, const StepTrig& g,
+  __device__ __forceinline__ void computeSimpleSuspensionStep(const float* state, float* state_der, const StepTrig& g,
                                                      float* output) const
   {
     const PARAMS_T& p = this->params_;
@@ -228,7 +228,7 @@ public:
   }
 
   /** racer_dubins_elevation_suspension_lstm.cu:342-392 */
-  __device__ inline void step(float* state, float* next_state, float* state_der, float* control, float* output,
+  __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
                               float* theta_s, const float t, const float dt)
   {
     float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM], wheel_out[OUTPUT_DIM];

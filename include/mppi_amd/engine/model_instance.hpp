@@ -310,6 +310,16 @@ struct has_elevation_map<T, std::void_t<decltype(std::declval<T&>().tex_helper_.
 {
 };
 template <class T, class = void>
+struct has_mean_unc_networks : std::false_type
+{
+};
+/** dynamics with the mean and uncertainty LSTMs of RacerDubinsElevationLSTMUncertainty next to the steering one */
+template <class T>
+struct has_mean_unc_networks<T, std::void_t<decltype(std::declval<T&>().mean_lstm_d_), decltype(std::declval<T&>().unc_lstm_d_)>>
+  : std::true_type
+{
+};
+template <class T, class = void>
 struct has_normals_map : std::false_type
 {
 };
@@ -572,6 +582,7 @@ struct ModelT : ModelBase
   float* elevation_d = nullptr;
   float* normals_d = nullptr;
   bool normals_transform_set = false;
+  float* extra_net_d[4] = { nullptr, nullptr, nullptr, nullptr };  ///< mean LSTM, mean MLP, uncertainty LSTM, uncertainty MLP
 
   ~ModelT() override
   {
@@ -589,6 +600,9 @@ struct ModelT : ModelBase
       (void)hipFree(elevation_d);
     if (normals_d)
       (void)hipFree(normals_d);
+    for (float* q : extra_net_d)
+      if (q)
+        (void)hipFree(q);
   }
 
   static mppi_status upload(float** dst, const float* src, size_t count, hipStream_t stream, std::string& err)
@@ -724,6 +738,58 @@ struct ModelT : ModelBase
         return MPPI_OK;
       }
     }
+    if constexpr (has_mean_unc_networks<DYN_T>::value)
+    {
+      /* LSTMLSTMHelper(path, "terra/mean_network/") / (…, "terra/uncertainty_network/") (racer_dubins_elevation_lstm_unc.cu:30-33):
+       * parameter blobs in the layouts of lstm_helper.hpp / fnn_helper.hpp; "<net>_lstm_state" = [hidden | cell], the
+       * per-cycle update of updateFromBuffer (:98-141), written in place */
+      const struct
+      {
+        const char* name;
+        int slot;
+        size_t count;
+      } nets[6] = { { "mean_lstm_weights", 0, (size_t)DYN_T::MEAN_NET::LSTM_NUM_PARAMS + 2 * DYN_T::NET_H },
+                    { "mean_lstm_output_weights", 1, (size_t)DYN_T::MEAN_NET::FNN_NUM_PARAMS },
+                    { "unc_lstm_weights", 2, (size_t)DYN_T::UNC_NET::LSTM_NUM_PARAMS + 2 * DYN_T::NET_H },
+                    { "unc_lstm_output_weights", 3, (size_t)DYN_T::UNC_NET::FNN_NUM_PARAMS },
+                    { "mean_lstm_state", 0, (size_t)2 * DYN_T::NET_H },
+                    { "unc_lstm_state", 2, (size_t)2 * DYN_T::NET_H } };
+      for (int i = 0; i < 6; i++)
+      {
+        if (name != nets[i].name)
+          continue;
+        if (count != nets[i].count)
+        {
+          err = name + ": expected " + std::to_string(nets[i].count) + " floats, got " + std::to_string(count);
+          return MPPI_ERR_INVALID_ARG;
+        }
+        if (i >= 4)
+        {  // initial hidden / cell state into the tail of the uploaded LSTM blob
+          float* blob = extra_net_d[nets[i].slot];
+          if (!blob)
+          {
+            err = "set the network's weights before its state";
+            return MPPI_ERR_STATE;
+          }
+          const size_t params = (i == 4 ? (size_t)DYN_T::MEAN_NET::LSTM_NUM_PARAMS : (size_t)DYN_T::UNC_NET::LSTM_NUM_PARAMS);
+          hipError_t e = hipMemcpyAsync(blob + params, data, count * sizeof(float), hipMemcpyHostToDevice, stream);
+          if (e == hipSuccess)
+            e = hipStreamSynchronize(stream);
+          if (e != hipSuccess)
+          {
+            err = std::string("LSTM state upload: ") + hipGetErrorString(e);
+            return MPPI_ERR_HIP;
+          }
+          return MPPI_OK;
+        }
+        mppi_status st = upload(&extra_net_d[nets[i].slot], data, count, stream, err);
+        dyn.mean_lstm_d_ = extra_net_d[0];
+        dyn.mean_fnn_d_ = extra_net_d[1];
+        dyn.unc_lstm_d_ = extra_net_d[2];
+        dyn.unc_fnn_d_ = extra_net_d[3];
+        return st;
+      }
+    }
     if constexpr (has_normals_map<DYN_T>::value)
     {
       /* getTextureHelperNormals()->updateTexture(0, float4 data) (racer_dubins_elevation_suspension_lstm.cuh:131-134; the tests'
@@ -840,6 +906,13 @@ struct ModelT : ModelBase
       if (!cost.costmap_d_)
       {
         err = "model needs the 'costmap' blob (mppi_set_model_blob) before it can run";
+        return false;
+      }
+    if constexpr (has_mean_unc_networks<DYN_T>::value)
+      if (!dyn.mean_lstm_d_ || !dyn.mean_fnn_d_ || !dyn.unc_lstm_d_ || !dyn.unc_fnn_d_)
+      {
+        err = "model needs the 'mean_lstm_weights', 'mean_lstm_output_weights', 'unc_lstm_weights' and "
+              "'unc_lstm_output_weights' blobs (mppi_set_model_blob) before it can run";
         return false;
       }
     return true;

@@ -44,6 +44,21 @@ __host__ __device__ inline int partialStride(int num_timesteps, int control_dim)
   return num_timesteps * control_dim + 4;
 }
 
+/** SINGLE_STEP_SITE of a Dynamics plugin (default false): the fused kernel calls step() from ONE place in its time loop.
+ *  For models whose step is thousands of instructions (the RACER suspension / uncertainty models) the usual unrolled pair
+ *  of steps + tail would either triple the code (instruction cache) or, as the compiler then decides, turn the step into
+ *  an out-of-line function whose state travels through scratch memory. */
+template <class T, class = void>
+struct single_step_site
+{
+  static constexpr bool value = false;
+};
+template <class T>
+struct single_step_site<T, std::void_t<decltype(T::SINGLE_STEP_SITE)>>
+{
+  static constexpr bool value = T::SINGLE_STEP_SITE;
+};
+
 /** REPLICATED_LANES of a Dynamics plugin (default 1): the number of wave lanes that carry private copies of one rollout
  *  and cooperate only inside the plugin (e.g. as MFMA k-groups, utils/nn_helpers/fnn_mfma.hpp) */
 template <class T, class = void>
@@ -576,6 +591,40 @@ __global__ void __launch_bounds__(BX* BY* BZ* replicated_lanes<DYN_T>::value)
       for (int i = 0; i < S; i++)
         x[i] = x_next[i];
       running_cost += step_cost(y, t, crash_status);
+    }
+  }
+  else if constexpr (single_step_site<DYN_T>::value && BY == 1)
+  {
+    for (; t < num_timesteps; t += STEPS)
+    {
+      float zq[4 * QUADS];
+      if (DRAW_IN_LOOP)
+      {
+#pragma unroll
+        for (int q = 0; q < QUADS; q++)
+          sampling->drawQuad(global_idx, t * C / 4 + q, &zq[4 * q]);
+      }
+#pragma unroll 1
+      for (int s2 = 0; s2 < STEPS; s2++)
+      {
+        if (t + s2 < num_timesteps)
+        {
+          float eps[C];
+#pragma unroll
+          for (int i = 0; i < C; i++)
+          {  // zq[s2 * C + i] without a run-time index into the register array
+            float v = zq[i];
+#pragma unroll
+            for (int q = 1; q < STEPS; q++)
+              v = (s2 == q) ? zq[q * C + i] : v;
+            eps[i] = v;
+          }
+          one_step(x, x_next, t + s2, eps);
+#pragma unroll
+          for (int i = 0; i < S; i++)
+            x[i] = x_next[i];
+        }
+      }
     }
   }
   else

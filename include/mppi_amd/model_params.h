@@ -111,6 +111,16 @@ typedef struct mppi_racer_dubins_suspension_params
   float c_g[3];       /* {2.981 / 2, 0, 0} */
 } mppi_racer_dubins_suspension_params;
 
+/** RacerDubinsElevationUncertaintyParams (dynamics/racer_dubins/racer_dubins_elevation_lstm_unc.cuh:5-48) */
+typedef struct mppi_racer_dubins_uncertainty_params
+{
+  mppi_racer_dubins_suspension_params suspension;
+  float unc_scale[7];        /* 1 */
+  float pos_quad_brake_c[3]; /* {2.0, 0.5, 0.3} */
+  float neg_quad_brake_c[3]; /* {5.84, 0.15, 1.7} */
+  int use_static_settling;   /* 1 (the reference's bool) */
+} mppi_racer_dubins_uncertainty_params;
+
 /** QuadraticCost over the 28 outputs of the RACER models, one goal (SIM_TIME_HORIZON = 1) */
 typedef struct mppi_quadratic_cost_params_28
 {

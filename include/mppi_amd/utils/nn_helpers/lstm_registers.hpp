@@ -53,7 +53,7 @@ struct LSTMRegisters
 #endif
   }
 
-  __device__ static inline void forward(const float* lstm_blob, const float* fnn_blob, const float (&x)[I], float (&h)[H],
+  __device__ static __forceinline__ void forward(const float* lstm_blob, const float* fnn_blob, const float (&x)[I], float (&h)[H],
                                         float (&c)[H], float (&out)[OUT])
   {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -95,6 +95,9 @@ struct LSTMRegisters
       sg[H + i] = gf + b_f[i];
       sg[2 * H + i] = go + b_o[i];
       gc[i] = g + b_c[i];
+      // keeps the scalar loads of the next unit's weights below this point: left alone the compiler hoists every s_load of
+      // the network to the top, hundreds of live SGPRs that spill into VGPRs and from there into scratch
+      asm volatile("" ::: "memory");
     }
     mppi::det::sigmoid_n<3 * H>(sg);  // pairwise packed evaluation, same bits as det::sigmoid / det::tanh
     mppi::det::tanh_n<H>(gc);
@@ -132,6 +135,7 @@ struct LSTMRegisters
       for (int k = 0; k < H + I; k++)
         acc = mppi::det::fma(W1[j * (H + I) + k], act[k], acc);
       hid[j] = acc + b1[j];
+      asm volatile("" ::: "memory");
     }
     mppi::det::tanh_n<L1>(hid);
 #pragma unroll
@@ -142,6 +146,7 @@ struct LSTMRegisters
       for (int k = 0; k < L1; k++)
         acc = mppi::det::fma(W2[j * L1 + k], hid[k], acc);
       out[j] = acc + b2[j];
+      asm volatile("" ::: "memory");
     }
 #endif
   }

@@ -151,6 +151,28 @@ class RacerDubinsSuspensionParams(C.Structure):
         return self.elevation.base
 
 
+class RacerDubinsUncertaintyParams(C.Structure):
+    """mppi_racer_dubins_uncertainty_params (reference: dynamics/racer_dubins/racer_dubins_elevation_lstm_unc.cuh:5-48)"""
+    _fields_ = [("suspension", RacerDubinsSuspensionParams), ("unc_scale", C.c_float * 7),
+                ("pos_quad_brake_c", C.c_float * 3), ("neg_quad_brake_c", C.c_float * 3), ("use_static_settling", C.c_int)]
+
+    def __init__(self):
+        super().__init__()
+        RacerDubinsSuspensionParams.__init__(self.suspension)
+        self.unc_scale[:] = [1.0] * 7
+        self.pos_quad_brake_c[:] = [2.0, 0.5, 0.3]
+        self.neg_quad_brake_c[:] = [5.84, 0.15, 1.7]
+        self.use_static_settling = 1
+
+    @property
+    def base(self):
+        return self.suspension.elevation.base
+
+    @property
+    def elevation(self):
+        return self.suspension.elevation
+
+
 class QuadraticCostParams28(C.Structure):
     """mppi_quadratic_cost_params_28 (reference: QuadraticCostTrajectoryParams<RacerDubins, 1>,
     cost_functions/quadratic_cost/quadratic_cost.cuh:11-63)"""

@@ -63,6 +63,25 @@ int oracle_set_blob(void* h, const char* name, const float* data, size_t count, 
     auto* m = dynamic_cast<ARNeuralNetModel*>(c->dyn.get());
     return m ? m->setWeights(data, count) : -1;
   }
+  if (n.rfind("mean_lstm", 0) == 0 || n.rfind("unc_lstm", 0) == 0)
+  {
+    auto* m = dynamic_cast<RacerDubinsElevationLSTMUncertainty*>(c->dyn.get());
+    if (!m)
+      return -1;
+    LSTM& net = (n.rfind("mean", 0) == 0) ? m->mean_net : m->unc_net;
+    if (n == "mean_lstm_state" || n == "unc_lstm_state")
+    {
+      if (count != (size_t)2 * net.H)
+        return -1;
+      std::copy(data, data + count, net.w.end() - 2 * net.H);
+      return 0;
+    }
+    std::vector<float>& dst = (n == "mean_lstm_weights" || n == "unc_lstm_weights") ? net.w : net.out_net.theta;
+    if (count != dst.size())
+      return -1;
+    std::copy(data, data + count, dst.begin());
+    return 0;
+  }
   if (n == "normals_map" || n == "normals_map_transform")
   {
     auto* m = dynamic_cast<RacerDubinsElevationSuspension*>(c->dyn.get());

@@ -1121,7 +1121,7 @@ struct RacerDubinsElevationSuspension : RacerDubinsElevationLSTMSteering
   Texture2D normals;
   std::vector<float> normals_values;
   bool use_normals = false, normals_transform_set = false;
-  RacerDubinsElevationSuspension() : RacerDubinsElevationLSTMSteering(24)
+  explicit RacerDubinsElevationSuspension(int num_states = 24) : RacerDubinsElevationLSTMSteering(num_states)
   {
     STEER_ANGLE_RATE = 12;
     UNC = 13;
@@ -1288,6 +1288,183 @@ struct RacerDubinsElevationSuspension : RacerDubinsElevationLSTMSteering
   }
 };
 
+/**
+ * reference (DEVICE flavour): dynamics/racer_dubins/racer_dubins_elevation_lstm_unc.cu:496-605 (step), :300-494 (computeQ),
+ * :607-618 (initializeDynamics); parameters and the 26-entry state layout: racer_dubins_elevation_lstm_unc.cuh:5-48.
+ * Network inputs the step does not fill are zero (the reference's host path: getZeroInputVector).  The reference's tests
+ * for this class compare GPU and CPU paths on random data or need a network file that is an LFS stub here
+ * (TestMatchesPython): no known answer to pin on — see tests/test_racer_dubins_lstm_unc.py.
+ */
+struct RacerDubinsElevationLSTMUncertainty : RacerDubinsElevationSuspension
+{
+  enum
+  {
+    OMEGA_Z = 13,
+    STATIC_ROLL = 14,
+    STATIC_PITCH = 15
+  };
+  mppi_racer_dubins_uncertainty_params up;
+  LSTM mean_net, unc_net;
+  RacerDubinsElevationLSTMUncertainty() : RacerDubinsElevationSuspension(26)
+  {
+    STEER_ANGLE_RATE = 12;
+    UNC = 16;
+    num_euler = 12;
+    mean_net.setStructure(12, 4, { 16, 20, 2 });
+    unc_net.setStructure(13, 4, { 17, 20, 5 });
+    up.suspension = sp;
+    for (int i = 0; i < 7; i++)
+      up.unc_scale[i] = 1.0f;
+    const float pq[3] = { 2.0f, 0.5f, 0.3f }, nq[3] = { 5.84f, 0.15f, 1.7f };
+    for (int i = 0; i < 3; i++)
+    {
+      up.pos_quad_brake_c[i] = pq[i];
+      up.neg_quad_brake_c[i] = nq[i];
+    }
+    up.use_static_settling = 1;
+  }
+  int setParams(const void* pod, size_t n) override
+  {
+    if (n != sizeof(up))
+      return -1;
+    memcpy(&up, pod, n);
+    sp = up.suspension;
+    p = sp.elevation;
+    return 0;
+  }
+  int scratchFloats() const override
+  {
+    return 2 * net.H + 2 * mean_net.H + 2 * unc_net.H;
+  }
+  float* meanState(float* theta_s) const
+  {
+    return theta_s + 2 * net.H;
+  }
+  float* uncState(float* theta_s) const
+  {
+    return theta_s + 2 * net.H + 2 * mean_net.H;
+  }
+  void initializeDynamics(const float* x, const float* u, float* y, float* theta_s, float t0, float dt) override
+  {
+    RacerDubinsElevationSuspension::initializeDynamics(x, u, y, theta_s, t0, dt);
+    for (int i = 0; i < mean_net.H; i++)
+    {
+      meanState(theta_s)[i] = mean_net.h0()[i];
+      meanState(theta_s)[mean_net.H + i] = mean_net.c0()[i];
+    }
+    for (int i = 0; i < unc_net.H; i++)
+    {
+      uncState(theta_s)[i] = unc_net.h0()[i];
+      uncState(theta_s)[unc_net.H + i] = unc_net.c0()[i];
+    }
+  }
+  void networkQ(const float* x, const float* u, const float* xdot, float* theta_s, float* Q)
+  {
+    const mppi_racer_dubins_params& b = p.base;
+    float sin_yaw, cos_yaw;
+    det::sincos(det::normalizeAngle(x[YAW]), &sin_yaw, &cos_yaw);
+    float in[13];
+    in[0] = x[VEL_X];
+    in[1] = x[OMEGA_Z];
+    in[2] = x[BRAKE_STATE];
+    in[3] = x[STEER_ANGLE];
+    in[4] = x[STEER_ANGLE_RATE];
+    in[5] = u[0] >= 0.0f ? u[0] : 0.0f;
+    in[6] = u[0] <= 0.0f ? -u[0] : 0.0f;
+    in[7] = u[1];
+    in[8] = det::sin(x[STATIC_ROLL]);  /* __sinf */
+    in[9] = det::sin(x[STATIC_PITCH]);
+    in[10] = xdot[VEL_X];
+    in[11] = xdot[YAW];
+    in[12] = 0.0f;
+    float o[5];
+    unc_net.forward(in, uncState(theta_s), uncState(theta_s) + unc_net.H, o);
+    for (int i = 0; i < 5; i++)
+      o[i] = fabsf(det::sigmoid(o[i]) * up.unc_scale[i]);
+    const int index = regime(x[VEL_X]);
+    for (int i = 0; i < UD * UD; i++)
+      Q[i] = 0.0f;
+    Q[cm(U_VEL_X, U_VEL_X)] = o[0] + ORACLE_SQ(b.c_b[index] * (index == 0 ? x[VEL_X] : 1.0f)) * o[4];
+    Q[cm(U_YAW, U_YAW)] =
+        o[1] + ORACLE_SQ((x[VEL_X] / b.wheel_base) * 1.0f / (ORACLE_SQ(det::cos(x[STEER_ANGLE] / b.steer_angle_scale)) * b.steer_angle_scale)) * o[3];
+    Q[cm(U_POS_X, U_POS_X)] = o[2] * sin_yaw * sin_yaw;
+    Q[cm(U_POS_X, U_POS_Y)] = -o[2] * sin_yaw * cos_yaw;
+    Q[cm(U_POS_Y, U_POS_Y)] = o[2] * cos_yaw * cos_yaw;
+    Q[cm(U_POS_Y, U_POS_X)] = -o[2] * sin_yaw * cos_yaw;
+  }
+  void step(float* x, float* xn, float* xdot, const float* u, float* y, float* theta_s, int t, float dt) override
+  {
+    const mppi_racer_dubins_params& b = p.base;
+    if (!normals_transform_set)
+      copyFrame(map, normals);
+    computeDynamics(x, u, xdot, theta_s); /* acceleration, yaw and position rates (the two lags are replaced below) */
+    bool enable_brake = u[0] < 0.0f;
+    const float brake_error = (enable_brake * -u[0] - x[BRAKE_STATE]);
+    xdot[BRAKE_STATE] = fminf(
+        fmaxf((brake_error > 0) * (brake_error * up.pos_quad_brake_c[0] + brake_error * fabsf(brake_error) * up.pos_quad_brake_c[1]) +
+                  (brake_error < 0) * (brake_error * up.neg_quad_brake_c[0] + brake_error * fabsf(brake_error) * up.neg_quad_brake_c[1]),
+              -b.max_brake_rate_neg),
+        b.max_brake_rate_pos);
+    lstmSteering(x, u, xdot, theta_s);
+    suspensionStep(x, xdot, y);
+    if (b.gear_sign == 1)
+    {
+      float in[12], mean_output[2];
+      in[0] = x[VEL_X];
+      in[1] = x[OMEGA_Z];
+      in[2] = x[BRAKE_STATE];
+      in[3] = x[STEER_ANGLE];
+      in[4] = x[STEER_ANGLE_RATE];
+      in[5] = u[0] >= 0.0f ? u[0] : 0.0f;
+      in[6] = u[0] <= 0.0f ? -u[0] : 0.0f;
+      in[7] = u[1];
+      in[8] = det::sin(x[STATIC_PITCH]);
+      in[9] = xdot[VEL_X];
+      in[10] = xdot[YAW];
+      in[11] = 0.0f;
+      mean_net.forward(in, meanState(theta_s), meanState(theta_s) + mean_net.H, mean_output);
+      xdot[VEL_X] += mean_output[0];
+      xdot[YAW] += mean_output[1];
+    }
+    xn[OMEGA_Z] = xdot[YAW];
+    updateState(x, xn, xdot, dt);
+    xn[STEER_ANGLE_RATE] = x[STEER_ANGLE_RATE] + xdot[STEER_ANGLE_RATE] * dt;
+    /* computeUncertaintyPropagation with this class's computeQ */
+    {
+      float A[UD * UD], Sigma_a[UD * UD], Sigma_b[UD * UD];
+      uncertaintyJacobian(x, A);
+      stateToMatrix(x, Sigma_a);
+      for (int i = 0; i < UD * UD; i++)
+        A[i] = (i % (UD + 1) == 0) + A[i] * dt;
+      for (int pidx = 0; pidx < UD * UD; pidx++)
+      {
+        const int m = pidx % UD, n = pidx / UD;
+        float accumulator = 0;
+        for (int k = 0; k < UD; k++)
+          accumulator += A[cm(m, k)] * Sigma_a[cm(k, n)];
+        Sigma_b[pidx] = 1.0f * accumulator;
+      }
+      for (int pidx = 0; pidx < UD * UD; pidx++)
+      {
+        const int m = pidx % UD, n = pidx / UD;
+        float accumulator = 0;
+        for (int k = 0; k < UD; k++)
+          accumulator += Sigma_b[cm(m, k)] * A[k * UD + n];
+        Sigma_a[pidx] = 1.0f * accumulator;
+      }
+      networkQ(x, u, xdot, theta_s, Sigma_b);
+      for (int i = 0; i < UD * UD; i++)
+        Sigma_a[i] += Sigma_b[i] * dt;
+      matrixToState(Sigma_a, xn);
+    }
+    float roll = x[STATIC_ROLL], pitch = x[STATIC_PITCH], height;
+    staticSettling(xn[YAW], xn[POS_X], xn[POS_Y], roll, pitch, height);
+    xn[STATIC_PITCH] = pitch;
+    xn[STATIC_ROLL] = roll;
+    setSuspensionOutputs(xdot, xn, y);
+  }
+};
+
 /** reference: cost_functions/quadratic_cost/quadratic_cost.cu:39-60 (device), SIM_TIME_HORIZON = 1 */
 struct QuadraticCost28 : Cost
 {
@@ -1347,6 +1524,12 @@ inline bool makeModel(const std::string& name, std::unique_ptr<Dynamics>& dyn, s
   {
     dyn.reset(new DoubleIntegratorDynamics());
     cost.reset(new DoubleIntegratorCircleCost());
+    return true;
+  }
+  if (name == "racer_dubins_elevation_lstm_unc")
+  {
+    dyn.reset(new RacerDubinsElevationLSTMUncertainty());
+    cost.reset(new QuadraticCost28(true));
     return true;
   }
   if (name == "racer_dubins_elevation_suspension")

@@ -14,6 +14,7 @@ from common import autorally_cfg, bicycle_lstm_cfg, cartpole_cfg, di_cfg, make_e
 from test_racer_dubins_elevation import elevation_cfg as _elev  # noqa: E402
 from test_racer_dubins_lstm_steering import steering_cfg as _steer  # noqa: E402
 from test_racer_dubins_suspension import suspension_cfg as _susp  # noqa: E402
+from test_racer_dubins_lstm_unc import uncertainty_cfg as _unc  # noqa: E402
 
 MODELS = {
     "cartpole": lambda: cartpole_cfg(K=16384, T=100),
@@ -24,6 +25,7 @@ MODELS = {
     "racer_dubins_elevation": lambda: _elev(K=16384, T=100),
     "racer_dubins_elevation_lstm_steering": lambda: _steer(K=16384, T=100),
     "racer_dubins_elevation_suspension": lambda: _susp(K=16384, T=100),
+    "racer_dubins_elevation_lstm_unc": lambda: _unc(K=16384, T=100),
 }
 ROBUST_MODELS = ("cartpole", "double_integrator", "autorally_nn", "bicycle_slip_lstm", "racer_dubins")
 bad = 0
