@@ -81,8 +81,6 @@ public:
   using MEAN_NET = mppi::LSTMRegisters<12, 4, 20, 2>;
   using UNC_NET = mppi::LSTMRegisters<13, 4, 20, 5>;
   static constexpr int NUM_NETWORKS = 3, NET_H = 4;
-  /** a step of this model is ~10^4 instructions: one copy of it per kernel (engine/rollout_kernel.hpp) */
-  static constexpr bool SINGLE_STEP_SITE = true;
 
   const float* mean_lstm_d_ = nullptr;  ///< mean network: LSTM blob / output-network blob (device, owned by the engine)
   const float* mean_fnn_d_ = nullptr;

@@ -85,6 +85,10 @@ public:
   /** every state in front of STEER_ANGLE_RATE takes the explicit Euler step (racer_dubins_elevation_suspension_lstm.cu:401) */
   static constexpr int NUM_EULER_STATES = RDE_S(STEER_ANGLE_RATE);
   static constexpr int XD = RDE_S(STEER_ANGLE_RATE) + 1;
+  /** a step of these models is thousands of instructions: one copy of it per kernel (engine/rollout_kernel.hpp; three
+   *  inlined copies overflow the instruction cache: 1177 -> 855 us at K = 16384, T = 100; for the smaller LSTM-steering
+   *  step the single site is slightly slower, 688 -> 713 us, and is not used) */
+  static constexpr bool SINGLE_STEP_SITE = true;
   using ELEVATION::bodyRotation;
   using ELEVATION::computeParametricAccelDeriv;
   using ELEVATION::computeParametricDelayDeriv;
