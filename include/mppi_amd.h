@@ -256,7 +256,10 @@ mppi_status mppi_lstm_lstm_initialize(int init_input_dim, int init_hidden_dim, c
  *                    {prefix}dynamics_b{i}, i = 1.., float64
  *   kind "lstm"      LSTMHelper::loadParams (utils/nn_helpers/lstm_helper.cu:514-585): [model/]{prefix}lstm/weight_hh_l0,
  *                    weight_ih_l0, bias_hh_l0, bias_ih_l0 (PyTorch gate order, re-ordered and summed as there) and
- *                    {prefix}output/dynamics_W{i}, _b{i}; optional {prefix}lstm/h0, c0 (default zeros)
+ *                    {prefix}output/dynamics_W{i}, _b{i}; optional {prefix}lstm/h0, c0 (default zeros).  kinds "mean_lstm" and
+ *                    "unc_lstm": the same layout into the mean / uncertainty network of racer_dubins_elevation_lstm_unc
+ *                    (the reference reads them from one archive with the prefixes "terra/mean_network/" and
+ *                    "terra/uncertainty_network/", dynamics/racer_dubins/racer_dubins_elevation_lstm_unc.cu:30-33)
  *   kind "costmap"   ARStandardCost::loadTrackData (cost_functions/autorally/ar_standard_cost.cu:84-142): xBounds, yBounds,
  *                    pixelsPerMeter, channel0; also sets the world -> texture transform of the cost
  * prefix may be NULL.  A git-LFS pointer file in place of the archive is reported as such.

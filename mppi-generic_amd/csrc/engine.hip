@@ -987,8 +987,12 @@ mppi_status mppi_load_npz(mppi_handle h, const char* kind, const char* path, con
       return fail(h, MPPI_ERR_INVALID_ARG, "mppi_load_npz: " + err);
     return setBlobD(h, "dynamics_weights", blob, { (int)blob.size() });
   }
-  if (k == "lstm")
+  if (k == "lstm" || k == "mean_lstm" || k == "unc_lstm")
   {
+    // which network of the model: the steering / only LSTM, or the mean / uncertainty LSTM of RacerDubinsElevationLSTMUncertainty
+    // (its constructor reads all three from one archive: "steering/model/", "terra/mean_network/", "terra/uncertainty_network/",
+    // racer_dubins_elevation_lstm_unc.cu:30-33)
+    const std::string blob_stem = k;
     // LSTMHelper::loadParams (lstm_helper.cu:514-585): optional trailing '/', optional "model/" in front, PyTorch gate
     // order i, f, g, o re-ordered to i, f, o, c, the two bias vectors summed; output network under {prefix}output/
     if (!prefix.empty() && prefix.back() != '/')
@@ -1020,11 +1024,11 @@ mppi_status mppi_load_npz(mppi_handle h, const char* kind, const char* path, con
       for (int i = 0; i < H; i++)
         blob.push_back(it != d.end() && (int)it->second.size() == H ? it->second.data[i] : 0.0);
     }
-    MPPI_TRY(setBlobD(h, "lstm_weights", blob, { (int)blob.size() }));
+    MPPI_TRY(setBlobD(h, (blob_stem + "_weights").c_str(), blob, { (int)blob.size() }));
     std::vector<double> out_blob;
     if (!fnnBlobFromNpz(d, prefix + "output/", out_blob, err))
       return fail(h, MPPI_ERR_INVALID_ARG, "mppi_load_npz: " + err);
-    return setBlobD(h, "lstm_output_weights", out_blob, { (int)out_blob.size() });
+    return setBlobD(h, (blob_stem + "_output_weights").c_str(), out_blob, { (int)out_blob.size() });
   }
   if (k == "costmap")
   {

@@ -109,3 +109,35 @@ def test_load_npz_lstm_equals_blob_path_and_oracle(gpu, tmp_path, prefix, model_
     v = orc.set_gaussian_controls(mean, eps[0], 1, 0)
     want, _ = orc.rollout_costs(cfg["x0"], mean, v)
     assert ulp_diff(got, want).max() == 0
+
+
+@pytest.mark.gpu
+def test_load_npz_three_networks_of_the_racer_uncertainty_model(gpu, tmp_path):
+    """one archive with the prefixes the reference's RacerDubinsElevationLSTMUncertainty(path) reads (steering/model/,
+    terra/mean_network/, terra/uncertainty_network/; racer_dubins_elevation_lstm_unc.cu:30-33) through mppi_load_npz kinds
+    "lstm" / "mean_lstm" / "unc_lstm" == the same networks through the blob path"""
+    from test_racer_dubins_lstm_unc import uncertainty_cfg
+    nets = {"steering/model/": lstm_npz(seed=1, scale=0.06, I=4, H=4, M=20, OUT=1),
+            "terra/mean_network/": lstm_npz(seed=2, scale=0.06, I=12, H=4, M=20, OUT=2),
+            "terra/uncertainty_network/": lstm_npz(seed=3, scale=0.06, I=13, H=4, M=20, OUT=5)}
+    np.savez(tmp_path / "rde.npz", **{pre + k: v for pre, d in nets.items() for k, v in d.items()})
+    cfg = uncertainty_cfg(K=512, T=30)
+    for stem, pre in (("lstm", "steering/model/"), ("mean_lstm", "terra/mean_network/"), ("unc_lstm", "terra/uncertainty_network/")):
+        lstm_blob, out_blob = m.lstm_blob_from_npz_dict(nets[pre])
+        cfg["blobs"][stem + "_weights"], cfg["blobs"][stem + "_output_weights"] = lstm_blob, out_blob
+    eps = host_noise(1, cfg["K"], cfg["T"], 2)
+    a = make_engine(cfg)
+    a.injectNoise(eps)
+    want = a.rolloutCosts(cfg["x0"], 1)
+    b = make_engine(cfg)
+    b.loadNpz("lstm", tmp_path / "rde.npz", "steering/model")
+    b.loadNpz("mean_lstm", tmp_path / "rde.npz", "terra/mean_network")
+    b.loadNpz("unc_lstm", tmp_path / "rde.npz", "terra/uncertainty_network/")
+    b.injectNoise(eps)
+    got = b.rolloutCosts(cfg["x0"], 1)
+    assert np.isfinite(want).all() and ulp_diff(got, want).max() == 0
+    orc = make_oracle(cfg)
+    mean = np.zeros((1, cfg["T"], 2), np.float32)
+    v = orc.set_gaussian_controls(mean, eps[0], 1, 0)
+    ref, _ = orc.rollout_costs(cfg["x0"], mean, v)
+    assert ulp_diff(got, ref).max() == 0
