@@ -38,6 +38,10 @@ struct LSTMRegisters
   static constexpr int HH = H * H, HI = H * I;
   static constexpr int LSTM_NUM_PARAMS = 4 * HH + 4 * HI + 4 * H;  ///< h0, c0 follow
   static constexpr int FNN_NUM_PARAMS = L1 * (H + I) + L1 + OUT * L1 + OUT;
+#ifndef MPPI_LSTM_REGISTERS_SGPR_BUDGET
+#define MPPI_LSTM_REGISTERS_SGPR_BUDGET 64
+#endif
+  static constexpr int MLP_GROUP = (MPPI_LSTM_REGISTERS_SGPR_BUDGET / (H + I + 1)) > 0 ? (MPPI_LSTM_REGISTERS_SGPR_BUDGET / (H + I + 1)) : 1;
 
   /** (h, c) <- (h0, c0) of the blob */
   __device__ static inline void initialState(const float* lstm_blob, float (&h)[H], float (&c)[H])
@@ -135,7 +139,11 @@ struct LSTMRegisters
       for (int k = 0; k < H + I; k++)
         acc = mppi::det::fma(W1[j * (H + I) + k], act[k], acc);
       hid[j] = acc + b1[j];
-      asm volatile("" ::: "memory");
+      // a group of neurons per fence: their scalar loads are issued together and pay the scalar-memory latency once
+      // (results of scalar loads return out of order, so every use waits for ALL loads in flight); the group is sized to
+      // what the ~100 SGPRs of a wave hold next to the kernel's arguments
+      if ((j + 1) % MLP_GROUP == 0)
+        asm volatile("" ::: "memory");
     }
     mppi::det::tanh_n<L1>(hid);
 #pragma unroll
