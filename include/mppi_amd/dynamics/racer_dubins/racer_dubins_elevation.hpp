@@ -598,6 +598,48 @@ public:
   {
     return r == 0 ? a : (r == 1 ? b : (r == 2 ? c : d));
   }
+  /** four lanes per rollout: replica `rep` forms row `rep` of (I + A dt) Sigma (I + A dt)^T + Q dt (the sums in the order of
+   *  computeUncertaintyPropagation), the rows are exchanged and written to next_state */
+  __device__ __forceinline__ void covarianceFourLanes(const float* x, const float* xd, const StepTrig& g, const float dt,
+                                                      const int rep, float* xn) const
+  {
+    float A[UD * UD], Sigma[UD * UD], Q[UD * UD], Ar[UD], Sb[UD], row[UD];
+    computeUncertaintyJacobian(x, g, A);
+    uncertaintyStateToMatrix(x, Sigma);
+#pragma unroll
+    for (int i = 0; i < UD * UD; i++)
+      A[i] = (i % (UD + 1) == 0) + A[i] * dt;
+#pragma unroll
+    for (int k = 0; k < UD; k++)
+      Ar[k] = pick4(rep, A[cm(0, k)], A[cm(1, k)], A[cm(2, k)], A[cm(3, k)]);
+#pragma unroll
+    for (int n = 0; n < UD; n++)
+    {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < UD; k++)
+        acc += Ar[k] * Sigma[cm(k, n)];
+      Sb[n] = acc;
+    }
+    computeQ(x, xd, g, Q);
+#pragma unroll
+    for (int n = 0; n < UD; n++)
+    {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < UD; k++)
+        acc += Sb[k] * A[cm(n, k)];
+      acc += pick4(rep, Q[cm(0, n)], Q[cm(1, n)], Q[cm(2, n)], Q[cm(3, n)]) * dt;
+      row[n] = acc;
+    }
+#pragma unroll
+    for (int m = 0; m < UD; m++)
+#pragma unroll
+      for (int n = 0; n < UD; n++)
+        Sigma[cm(m, n)] = fromReplica(row[n], m);
+    uncertaintyMatrixToState(Sigma, xn);
+  }
+
   /**
    * One step with the work of a rollout shared out over its four replica lanes; every replica holds the whole state
    * before and after.  steer(x, u, xd) fills the steering entries of the derivative, post(x, xd, xn) runs after the
@@ -669,44 +711,7 @@ public:
     xn[RDE_S(PITCH)] = pitch;
     xn[RDE_S(ROLL)] = roll;
 
-    // ---- covariance: row `rep` of (I + A dt) Sigma (I + A dt)^T + Q dt
-    {
-      float A[UD * UD], Sigma[UD * UD], Q[UD * UD], Ar[UD], Sb[UD], row[UD];
-      computeUncertaintyJacobian(x, g, A);
-      uncertaintyStateToMatrix(x, Sigma);
-#pragma unroll
-      for (int i = 0; i < UD * UD; i++)
-        A[i] = (i % (UD + 1) == 0) + A[i] * dt;
-#pragma unroll
-      for (int k = 0; k < UD; k++)
-        Ar[k] = pick4(rep, A[cm(0, k)], A[cm(1, k)], A[cm(2, k)], A[cm(3, k)]);
-#pragma unroll
-      for (int n = 0; n < UD; n++)
-      {
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < UD; k++)
-          acc += Ar[k] * Sigma[cm(k, n)];
-        Sb[n] = acc;
-      }
-      computeQ(x, xd, g, Q);
-#pragma unroll
-      for (int n = 0; n < UD; n++)
-      {
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < UD; k++)
-          acc += Sb[k] * A[cm(n, k)];
-        acc += pick4(rep, Q[cm(0, n)], Q[cm(1, n)], Q[cm(2, n)], Q[cm(3, n)]) * dt;
-        row[n] = acc;
-      }
-#pragma unroll
-      for (int m = 0; m < UD; m++)
-#pragma unroll
-        for (int n = 0; n < UD; n++)
-          Sigma[cm(m, n)] = fromReplica(row[n], m);
-      uncertaintyMatrixToState(Sigma, xn);
-    }
+    covarianceFourLanes(x, xd, g, dt, rep, xn);
 
 #pragma unroll
     for (int i = 0; i < 6; i++)

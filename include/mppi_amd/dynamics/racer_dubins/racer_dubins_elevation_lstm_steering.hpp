@@ -31,6 +31,7 @@
 #include "mppi_amd/dynamics/racer_dubins/racer_dubins_elevation.hpp"
 #include "mppi_amd/utils/nn_helpers/lstm_helper.hpp"
 #include "mppi_amd/utils/nn_helpers/lstm_registers.hpp"
+#include "mppi_amd/utils/nn_helpers/lstm_quad.hpp"
 
 /** reference: RacerDubinsElevationLSTMSteeringImpl<CLASS_T, PARAMS_T> (racer_dubins_elevation_lstm_steering.cuh:18-117);
  *  CLASS_T is the instantiated model — RacerDubinsElevationLSTMSteering below, the suspension models in their own header */
@@ -237,17 +238,11 @@ public:
   using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteeringQuad>;
   using PARAMS_T = RacerDubinsElevationParams;
   static constexpr int REPLICATED_LANES = 4;
-  static constexpr int I = 4, H = 4, L1 = 20, PER = L1 / 4;
-  static constexpr int HH = H * H, HI = H * I, LSTM_NUM_PARAMS = 4 * HH + 4 * HI + 4 * H;
+  using NET = mppi::LSTMQuad<4, 20, 1>;
 
   const float* lstm_d_ = nullptr;
   const float* fnn_d_ = nullptr;
-  float wg_[4][I + H] = { { 0.0f } };  ///< gates i, f, o, c of hidden unit `replica`: input weights, then recurrent weights
-  float bg_[4] = { 0.0f };
-  float w1_[PER][H + I] = { { 0.0f } };  ///< neurons 5 * replica .. + 4 of the output network's hidden layer
-  float b1_[PER] = { 0.0f };
-  float h_[H] = { 0.0f };  ///< hidden state of all four units
-  float c_ = 0.0f;         ///< cell state of unit `replica`
+  NET net_ = {};  ///< this lane's weights and the recurrent state
 
   RacerDubinsElevationLSTMSteeringQuad(const RacerDubinsElevationLSTMSteering& other) : ELEVATION(other.stream_)
   {
@@ -266,35 +261,7 @@ public:
   __device__ __forceinline__ void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
                                             float dt)
   {
-    const int rep = (int)(threadIdx.x & 63) >> 4;
-    const float* Wm = lstm_d_;
-    const float* Wi = lstm_d_ + 4 * HH;
-    const float* B = Wi + 4 * HI;
-#pragma unroll
-    for (int gate = 0; gate < 4; gate++)
-    {
-#pragma unroll
-      for (int j = 0; j < I; j++)
-        wg_[gate][j] = Wi[gate * HI + rep * I + j];
-#pragma unroll
-      for (int j = 0; j < H; j++)
-        wg_[gate][I + j] = Wm[gate * HH + rep * H + j];
-      bg_[gate] = B[gate * H + rep];
-    }
-    const float* W1 = fnn_d_;
-    const float* B1 = W1 + L1 * (H + I);
-#pragma unroll
-    for (int i = 0; i < PER; i++)
-    {
-#pragma unroll
-      for (int k = 0; k < H + I; k++)
-        w1_[i][k] = W1[(PER * rep + i) * (H + I) + k];
-      b1_[i] = B1[PER * rep + i];
-    }
-#pragma unroll
-    for (int j = 0; j < H; j++)
-      h_[j] = lstm_d_[LSTM_NUM_PARAMS + j];
-    c_ = lstm_d_[LSTM_NUM_PARAMS + H + rep];
+    net_.load((int)(threadIdx.x & 63) >> 4, lstm_d_, fnn_d_);
     output[RDE_O(BASELINK_POS_I_Z)] = 0.0f;
     output[RDE_O(FILLER_1)] = 0.0f;
     setOutputs(state, state, output);
@@ -309,63 +276,10 @@ public:
     float rate_dot = fmaxf(fminf((parametric_accel - rate) * p.steer_accel_constant - rate * p.steer_accel_drag_constant,
                                  p.max_steer_rate),
                            -p.max_steer_rate);
-    const float input[I] = { steer * 0.2f, rate * 0.2f, control[RDE_C(STEER_CMD)], rate_dot * 0.2f };
-    // hidden unit `replica`
-    float gate[4];
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-    {
-      float acc = 0.0f;
-#pragma unroll
-      for (int j = 0; j < I; j++)
-        acc = mppi::det::fma(wg_[g][j], input[j], acc);
-#pragma unroll
-      for (int j = 0; j < H; j++)
-        acc = mppi::det::fma(wg_[g][I + j], h_[j], acc);
-      gate[g] = acc + bg_[g];
-    }
-    float sg[3] = { gate[0], gate[1], gate[2] };
-    mppi::det::sigmoid_n<3>(sg);
-    const float gc = mppi::det::tanh(gate[3]);
-    const float in_part = sg[0] * gc;
-    const float keep_part = sg[1] * c_;
-    c_ = in_part + keep_part;
-    const float h_own = mppi::det::tanh(c_) * sg[2];
-    allReplicas(h_own, h_);
-    // five neurons of the hidden layer on [h ; x]
-    float act[H + I];
-#pragma unroll
-    for (int j = 0; j < H; j++)
-      act[j] = h_[j];
-#pragma unroll
-    for (int j = 0; j < I; j++)
-      act[H + j] = input[j];
-    float hid_own[PER];
-#pragma unroll
-    for (int i = 0; i < PER; i++)
-    {
-      float acc = 0.0f;
-#pragma unroll
-      for (int k = 0; k < H + I; k++)
-        acc = mppi::det::fma(w1_[i][k], act[k], acc);
-      hid_own[i] = acc + b1_[i];
-    }
-    mppi::det::tanh_n<PER>(hid_own);
-    float hid[L1];
-#pragma unroll
-    for (int s = 0; s < 4; s++)
-#pragma unroll
-      for (int i = 0; i < PER; i++)
-        hid[PER * s + i] = fromReplica(hid_own[i], s);
-    // the output neuron: the same 20-term chain on every replica, its weights through the scalar unit
-#if defined(__HIP_DEVICE_COMPILE__)
-    mppi::lstm_const_f32* W2 = mppi::lstmScalarView(fnn_d_ + L1 * (H + I) + L1);
-    float acc = 0.0f;
-#pragma unroll
-    for (int k = 0; k < L1; k++)
-      acc = mppi::det::fma(W2[k], hid[k], acc);
-    rate_dot += (acc + W2[L1]) * 5.0f;
-#endif
+    const float input[4] = { steer * 0.2f, rate * 0.2f, control[RDE_C(STEER_CMD)], rate_dot * 0.2f };
+    float out[1] = { 0.0f };
+    net_.forward(fnn_d_, input, out);
+    rate_dot += out[0] * 5.0f;
     state_der[RDE_S(STEER_ANGLE_RATE)] = rate_dot;
     state_der[RDE_S(STEER_ANGLE)] = rate;
   }

@@ -73,6 +73,95 @@ struct RacerDubinsElevationSuspensionParams : public RacerDubinsElevationParams
   float c_g[3] = { 2.981f * 0.5f, 0.0f, 0.0f };                        ///< centre of gravity in the body frame
 };
 
+/** the per-wheel arithmetic of computeSimpleSuspensionStep (racer_dubins_elevation_suspension_lstm.cu:199-340), shared by the
+ *  one-lane form (a loop over the wheels) and the four-lane form (a wheel per replica lane) so that both produce the same bits */
+template <class PARAMS_T>
+struct RacerSuspensionMath
+{
+  /** wheel i = FL, FR, BL, BR: body-frame contact point (:249-269) */
+  __device__ static inline float wheelBodyX(const int i)
+  {
+    return i < 2 ? 2.981f : 0.0f;
+  }
+  __device__ static inline float wheelBodyY(const int i)
+  {
+    return (i == RDE_W(FL) || i == RDE_W(BR)) ? 0.737f : -0.737f;
+  }
+  /** spring / damper force of wheel i and its forward / sideways components (magnitudes); height, normal: the terrain under it */
+  /** heading of wheel i; front wheels: the reference adds the state INDEX of the steering angle over -9.1 (kept, see the
+   *  header) */
+  __device__ static inline float wheelYaw(const float yaw, const int i)
+  {
+    return (i < 2) ? yaw + (float)RDE_S(STEER_ANGLE) / -9.1f : yaw;
+  }
+  __device__ static inline void wheelForce(const PARAMS_T& p, const float* state, const int i, const float height,
+                                           const float nx, const float ny, const float nz, const float sin_wheel_yaw,
+                                           const float cos_wheel_yaw, float& up, float& fwd, float& side)
+  {
+    const float roll = state[RDE_S(ROLL)], pitch = state[RDE_S(PITCH)];
+    const float cg_x = wheelBodyX(i) - p.c_g[0], cg_y = wheelBodyY(i) - p.c_g[1];
+    const float wheel_pos_z = state[RDE_S(CG_POS_Z)] + roll * cg_y - pitch * cg_x - p.wheel_radius;
+    const float wheel_vel_z = state[RDE_S(CG_VEL_I_Z)] + state[RDE_S(ROLL_RATE)] * cg_y - state[RDE_S(PITCH_RATE)] * cg_x;
+    const float h_dot = -(state[RDE_S(VEL_X)] * cos_wheel_yaw * nx + state[RDE_S(VEL_X)] * sin_wheel_yaw * ny);
+    const float wheel_force = -p.spring_k * (wheel_pos_z - height) - p.drag_c * (wheel_vel_z - h_dot);
+    const float fwd_wheel_force = wheel_force / nz * (nx * cos_wheel_yaw + ny * sin_wheel_yaw + nz * (-pitch));
+    const float side_wheel_force = wheel_force / nz * (-nx * sin_wheel_yaw + ny * cos_wheel_yaw + nz * roll);
+    up = wheel_force;
+    fwd = fabsf(fwd_wheel_force);
+    side = fabsf(side_wheel_force);
+  }
+  /** vertical, roll and pitch acceleration from the four wheel forces, summed FL, FR, BL, BR; the three force outputs */
+  __device__ static inline void bodyAccelerations(const PARAMS_T& p, const float (&up)[4], const float (&fwd)[4],
+                                                  const float (&side)[4], float* state_der, float* output)
+  {
+    float acc_z = 0.0f, acc_roll = 0.0f, acc_pitch = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+      const float cg_x = wheelBodyX(i) - p.c_g[0], cg_y = wheelBodyY(i) - p.c_g[1];
+      acc_z += up[i] / p.mass;
+      acc_roll += up[i] * cg_y / p.I_xx;
+      acc_pitch += -up[i] * cg_x / p.I_yy;
+    }
+    state_der[RDE_S(CG_VEL_I_Z)] = acc_z;
+    state_der[RDE_S(ROLL_RATE)] = acc_roll;
+    state_der[RDE_S(PITCH_RATE)] = acc_pitch;
+    output[RDE_O(WHEEL_FORCE_UP_MAX)] = fmaxf(up[0], fmaxf(up[1], fmaxf(up[2], up[3])));
+    output[RDE_O(WHEEL_FORCE_FWD_MAX)] = fmaxf(fwd[0], fmaxf(fwd[1], fmaxf(fwd[2], fwd[3])));
+    output[RDE_O(WHEEL_FORCE_SIDE_MAX)] = fmaxf(side[0], fmaxf(side[1], fmaxf(side[2], side[3])));
+  }
+  /** racer_dubins_elevation_suspension_lstm.cu:437-525: as the elevation model's, but the body height comes from the centre
+   *  of gravity and the wheel-force outputs are those of the suspension step */
+  __device__ static inline void setSuspensionOutputs(const PARAMS_T& p, const float* state_der, const float* next_state,
+                                                     float* output)
+  {
+    output[RDE_O(BASELINK_VEL_B_X)] = next_state[RDE_S(VEL_X)];
+    output[RDE_O(BASELINK_VEL_B_Y)] = 0.0f;
+    output[RDE_O(BASELINK_POS_I_X)] = next_state[RDE_S(POS_X)];
+    output[RDE_O(BASELINK_POS_I_Y)] = next_state[RDE_S(POS_Y)];
+    output[RDE_O(BASELINK_POS_I_Z)] = next_state[RDE_S(CG_POS_Z)] - next_state[RDE_S(PITCH)] * (-p.c_g[0]);
+    output[RDE_O(PITCH)] = next_state[RDE_S(PITCH)];
+    output[RDE_O(ROLL)] = next_state[RDE_S(ROLL)];
+    output[RDE_O(YAW)] = next_state[RDE_S(YAW)];
+    output[RDE_O(STEER_ANGLE)] = next_state[RDE_S(STEER_ANGLE)];
+    output[RDE_O(STEER_ANGLE_RATE)] = next_state[RDE_S(STEER_ANGLE_RATE)];
+    output[RDE_O(ACCEL_X)] = state_der[RDE_S(VEL_X)];
+    output[RDE_O(ACCEL_Y)] = 0.0f;
+    output[RDE_O(OMEGA_Z)] = state_der[RDE_S(YAW)];
+    output[RDE_O(UNCERTAINTY_VEL_X)] = next_state[RDE_S(UNCERTAINTY_VEL_X)];
+    output[RDE_O(UNCERTAINTY_YAW_VEL_X)] = next_state[RDE_S(UNCERTAINTY_YAW_VEL_X)];
+    output[RDE_O(UNCERTAINTY_POS_X_VEL_X)] = next_state[RDE_S(UNCERTAINTY_POS_X_VEL_X)];
+    output[RDE_O(UNCERTAINTY_POS_Y_VEL_X)] = next_state[RDE_S(UNCERTAINTY_POS_Y_VEL_X)];
+    output[RDE_O(UNCERTAINTY_YAW)] = next_state[RDE_S(UNCERTAINTY_YAW)];
+    output[RDE_O(UNCERTAINTY_POS_X_YAW)] = next_state[RDE_S(UNCERTAINTY_POS_X_YAW)];
+    output[RDE_O(UNCERTAINTY_POS_Y_YAW)] = next_state[RDE_S(UNCERTAINTY_POS_Y_YAW)];
+    output[RDE_O(UNCERTAINTY_POS_X)] = next_state[RDE_S(UNCERTAINTY_POS_X)];
+    output[RDE_O(UNCERTAINTY_POS_X_Y)] = next_state[RDE_S(UNCERTAINTY_POS_X_Y)];
+    output[RDE_O(UNCERTAINTY_POS_Y)] = next_state[RDE_S(UNCERTAINTY_POS_Y)];
+    output[RDE_O(TOTAL_VELOCITY)] = fabsf(next_state[RDE_S(VEL_X)]);
+  }
+};
+
 template <class CLASS_T, class PARAMS_T = RacerDubinsElevationSuspensionParams>
 class RacerDubinsElevationSuspensionImpl : public RacerDubinsElevationLSTMSteeringImpl<CLASS_T, PARAMS_T>
 {
@@ -109,14 +198,14 @@ public:
     return "RACER Dubins LSTM Steering and Suspension Model";
   }
 
-  /** wheel i = FL, FR, BL, BR: body-frame contact point (…suspension_lstm.cu:249-269) */
+  using MATH = RacerSuspensionMath<PARAMS_T>;
   __device__ static inline float wheelBodyX(const int i)
   {
-    return i < 2 ? 2.981f : 0.0f;
+    return MATH::wheelBodyX(i);
   }
   __device__ static inline float wheelBodyY(const int i)
   {
-    return (i == RDE_W(FL) || i == RDE_W(BR)) ? 0.737f : -0.737f;
+    return MATH::wheelBodyY(i);
   }
 
   /**
@@ -131,7 +220,6 @@ public:
     state_der[RDE_S(ROLL)] = state[RDE_S(ROLL_RATE)];
     state_der[RDE_S(PITCH)] = state[RDE_S(PITCH_RATE)];
     state_der[RDE_S(CG_POS_Z)] = state[RDE_S(CG_VEL_I_Z)];
-    const float roll = state[RDE_S(ROLL)], pitch = state[RDE_S(PITCH)], yaw = state[RDE_S(YAW)];
     float M[3][3];
     bodyRotation(g, g.sin_yaw, g.cos_yaw, M);  // Euler2DCM_NWU(roll, pitch, yaw), device branch
     float world[4][3];
@@ -169,66 +257,19 @@ public:
           normal[i][3] = 0.0f;
         }
     }
-    float acc_z = 0.0f, acc_roll = 0.0f, acc_pitch = 0.0f;
-    float up[4], fwd[4], side[4];
+    float up[4], fwd[4], side[4], sin_wheel_yaw[2], cos_wheel_yaw[2];  // front, rear
+    mppi::det::sincos(MATH::wheelYaw(state[RDE_S(YAW)], 0), &sin_wheel_yaw[0], &cos_wheel_yaw[0]);
+    mppi::det::sincos(MATH::wheelYaw(state[RDE_S(YAW)], 2), &sin_wheel_yaw[1], &cos_wheel_yaw[1]);
 #pragma unroll
     for (int i = 0; i < 4; i++)
-    {
-      // front wheels: the reference adds the state INDEX of the steering angle over -9.1 (kept, see the header)
-      const float wheel_yaw = (i < 2) ? yaw + (float)RDE_S(STEER_ANGLE) / -9.1f : yaw;
-      float sin_wheel_yaw, cos_wheel_yaw;
-      mppi::det::sincos(wheel_yaw, &sin_wheel_yaw, &cos_wheel_yaw);
-      const float cg_x = wheelBodyX(i) - p.c_g[0], cg_y = wheelBodyY(i) - p.c_g[1];
-      const float wheel_pos_z = state[RDE_S(CG_POS_Z)] + roll * cg_y - pitch * cg_x - p.wheel_radius;
-      const float wheel_vel_z = state[RDE_S(CG_VEL_I_Z)] + state[RDE_S(ROLL_RATE)] * cg_y - state[RDE_S(PITCH_RATE)] * cg_x;
-      const float nx = normal[i][0], ny = normal[i][1], nz = normal[i][2];
-      const float h_dot = -(state[RDE_S(VEL_X)] * cos_wheel_yaw * nx + state[RDE_S(VEL_X)] * sin_wheel_yaw * ny);
-      const float wheel_force = -p.spring_k * (wheel_pos_z - height[i]) - p.drag_c * (wheel_vel_z - h_dot);
-      const float fwd_wheel_force = wheel_force / nz * (nx * cos_wheel_yaw + ny * sin_wheel_yaw + nz * (-pitch));
-      const float side_wheel_force = wheel_force / nz * (-nx * sin_wheel_yaw + ny * cos_wheel_yaw + nz * roll);
-      up[i] = wheel_force;
-      fwd[i] = fabsf(fwd_wheel_force);
-      side[i] = fabsf(side_wheel_force);
-      acc_z += wheel_force / p.mass;
-      acc_roll += wheel_force * cg_y / p.I_xx;
-      acc_pitch += -wheel_force * cg_x / p.I_yy;
-    }
-    state_der[RDE_S(CG_VEL_I_Z)] = acc_z;
-    state_der[RDE_S(ROLL_RATE)] = acc_roll;
-    state_der[RDE_S(PITCH_RATE)] = acc_pitch;
-    output[RDE_O(WHEEL_FORCE_UP_MAX)] = fmaxf(up[0], fmaxf(up[1], fmaxf(up[2], up[3])));
-    output[RDE_O(WHEEL_FORCE_FWD_MAX)] = fmaxf(fwd[0], fmaxf(fwd[1], fmaxf(fwd[2], fwd[3])));
-    output[RDE_O(WHEEL_FORCE_SIDE_MAX)] = fmaxf(side[0], fmaxf(side[1], fmaxf(side[2], side[3])));
+      MATH::wheelForce(p, state, i, height[i], normal[i][0], normal[i][1], normal[i][2], sin_wheel_yaw[i >> 1],
+                       cos_wheel_yaw[i >> 1], up[i], fwd[i], side[i]);
+    MATH::bodyAccelerations(p, up, fwd, side, state_der, output);
   }
 
-  /** racer_dubins_elevation_suspension_lstm.cu:437-525: as the elevation model's, but the body height comes from the centre
-   *  of gravity and the wheel-force outputs are those of the suspension step */
   __device__ inline void setSuspensionOutputs(const float* state_der, const float* next_state, float* output) const
   {
-    output[RDE_O(BASELINK_VEL_B_X)] = next_state[RDE_S(VEL_X)];
-    output[RDE_O(BASELINK_VEL_B_Y)] = 0.0f;
-    output[RDE_O(BASELINK_POS_I_X)] = next_state[RDE_S(POS_X)];
-    output[RDE_O(BASELINK_POS_I_Y)] = next_state[RDE_S(POS_Y)];
-    output[RDE_O(BASELINK_POS_I_Z)] = next_state[RDE_S(CG_POS_Z)] - next_state[RDE_S(PITCH)] * (-this->params_.c_g[0]);
-    output[RDE_O(PITCH)] = next_state[RDE_S(PITCH)];
-    output[RDE_O(ROLL)] = next_state[RDE_S(ROLL)];
-    output[RDE_O(YAW)] = next_state[RDE_S(YAW)];
-    output[RDE_O(STEER_ANGLE)] = next_state[RDE_S(STEER_ANGLE)];
-    output[RDE_O(STEER_ANGLE_RATE)] = next_state[RDE_S(STEER_ANGLE_RATE)];
-    output[RDE_O(ACCEL_X)] = state_der[RDE_S(VEL_X)];
-    output[RDE_O(ACCEL_Y)] = 0.0f;
-    output[RDE_O(OMEGA_Z)] = state_der[RDE_S(YAW)];
-    output[RDE_O(UNCERTAINTY_VEL_X)] = next_state[RDE_S(UNCERTAINTY_VEL_X)];
-    output[RDE_O(UNCERTAINTY_YAW_VEL_X)] = next_state[RDE_S(UNCERTAINTY_YAW_VEL_X)];
-    output[RDE_O(UNCERTAINTY_POS_X_VEL_X)] = next_state[RDE_S(UNCERTAINTY_POS_X_VEL_X)];
-    output[RDE_O(UNCERTAINTY_POS_Y_VEL_X)] = next_state[RDE_S(UNCERTAINTY_POS_Y_VEL_X)];
-    output[RDE_O(UNCERTAINTY_YAW)] = next_state[RDE_S(UNCERTAINTY_YAW)];
-    output[RDE_O(UNCERTAINTY_POS_X_YAW)] = next_state[RDE_S(UNCERTAINTY_POS_X_YAW)];
-    output[RDE_O(UNCERTAINTY_POS_Y_YAW)] = next_state[RDE_S(UNCERTAINTY_POS_Y_YAW)];
-    output[RDE_O(UNCERTAINTY_POS_X)] = next_state[RDE_S(UNCERTAINTY_POS_X)];
-    output[RDE_O(UNCERTAINTY_POS_X_Y)] = next_state[RDE_S(UNCERTAINTY_POS_X_Y)];
-    output[RDE_O(UNCERTAINTY_POS_Y)] = next_state[RDE_S(UNCERTAINTY_POS_Y)];
-    output[RDE_O(TOTAL_VELOCITY)] = fabsf(next_state[RDE_S(VEL_X)]);
+    MATH::setSuspensionOutputs(this->params_, state_der, next_state, output);
   }
 
   /** racer_dubins_elevation_suspension_lstm.cu:342-392 */
@@ -273,6 +314,172 @@ public:
   RacerDubinsElevationSuspension(hipStream_t stream = nullptr)
     : RacerDubinsElevationSuspensionImpl<RacerDubinsElevationSuspension>(stream)
   {
+  }
+};
+
+/**
+ * Four lanes per rollout (REPLICATED_LANES = 4, lane = column + 16 * replica; racer_dubins_elevation.hpp has the contract):
+ * replica r evaluates one angle of each of the two trigonometry passes, hidden unit r of the steering LSTM and five neurons
+ * of its output network (lstm_quad.hpp), wheel r of the suspension (terrain height, terrain normal, spring / damper force)
+ * and row r of the covariance update.  Per value the arithmetic is the one-lane form's (RacerSuspensionMath, the wheel
+ * forces summed FL, FR, BL, BR on every replica), so both agree with the oracle bit for bit.  Default network shape only.
+ */
+class RacerDubinsElevationSuspensionQuad
+  : public RacerDubinsElevationImpl<RacerDubinsElevationSuspensionQuad, RacerDubinsElevationSuspensionParams>
+{
+public:
+  using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationSuspensionQuad, RacerDubinsElevationSuspensionParams>;
+  using PARAMS_T = RacerDubinsElevationSuspensionParams;
+  using MATH = RacerSuspensionMath<PARAMS_T>;
+  using NET = mppi::LSTMQuad<4, 20, 1>;
+  static constexpr int REPLICATED_LANES = 4;
+  static constexpr int NUM_EULER_STATES = RDE_S(STEER_ANGLE_RATE);
+  static constexpr int XD = RDE_S(STEER_ANGLE_RATE) + 1;
+
+  mppi::texture::TwoDTextureHelper<1, 4> normals_tex_helper_;
+  const float* lstm_d_ = nullptr;
+  const float* fnn_d_ = nullptr;
+  NET net_ = {};  ///< this lane's weights and the recurrent state
+
+  RacerDubinsElevationSuspensionQuad(const RacerDubinsElevationSuspension& other) : ELEVATION(other.stream_)
+  {
+    this->params_ = other.params_;
+    for (int i = 0; i < CONTROL_DIM; i++)
+    {
+      this->control_rngs_[i] = other.control_rngs_[i];
+      this->control_deadband_[i] = other.control_deadband_[i];
+      this->zero_control_[i] = other.zero_control_[i];
+    }
+    this->tex_helper_ = other.tex_helper_;
+    normals_tex_helper_ = other.normals_tex_helper_;
+    lstm_d_ = other.lstm_.weights_d_;
+    fnn_d_ = other.lstm_.output_nn_.theta_d_;
+  }
+
+  __device__ __forceinline__ void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
+                                                     float dt)
+  {
+    net_.load((int)(threadIdx.x & 63) >> 4, lstm_d_, fnn_d_);
+    output[RDE_O(BASELINK_POS_I_Z)] = 0.0f;
+    output[RDE_O(FILLER_1)] = 0.0f;
+    setOutputs(state, state, output);
+  }
+
+  __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
+                                       float* theta_s, const float t, const float dt)
+  {
+    const PARAMS_T& p = this->params_;
+    const int rep = (int)(threadIdx.x & 63) >> 4;
+    float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+    {
+      x[i] = state[i];
+      xn[i] = state[i];  // FILLER_1 is carried along
+    }
+#pragma unroll
+    for (int i = 0; i < CONTROL_DIM; i++)
+      u[i] = control[i];
+
+    // ---- pass 1: replica 0 yaw, 1 wrapped steering angle, 2 raw steering angle, 3 pitch
+    StepTrig g;
+    {
+      const float delta = x[RDE_S(STEER_ANGLE)] / p.steer_angle_scale;
+      const float raw = pick4(rep, x[RDE_S(YAW)], delta, delta, x[RDE_S(PITCH)]);
+      const float wrapped = angle_utils::normalizeAngle(raw);
+      float s, c, sa[4], ca[4];
+      mppi::det::sincos(rep == 2 ? raw : wrapped, &s, &c);
+      allReplicas(s, sa);
+      allReplicas(c, ca);
+      g.sin_yaw = sa[0];
+      g.cos_yaw = ca[0];
+      g.tan_steer_n = sa[1] / ca[1];
+      g.tan_delta = sa[2] / ca[2];
+      g.cos_delta = ca[2];
+      g.sin_pitch = sa[3];
+      g.cos_pitch = ca[3];
+    }
+    // ---- pass 2: replica 0 roll, 1 heading of the front wheels, 2 and 3 heading of the rear wheels
+    float sin_wheel_yaw, cos_wheel_yaw;
+    {
+      const float wheel_yaw = MATH::wheelYaw(x[RDE_S(YAW)], rep == 1 ? 0 : 2);
+      float s, c;
+      mppi::det::sincos(rep == 0 ? angle_utils::normalizeAngle(x[RDE_S(ROLL)]) : wheel_yaw, &s, &c);
+      g.sin_roll = fromReplica(s, 0);
+      g.cos_roll = fromReplica(c, 0);
+      const int src = rep < 2 ? 1 : 2;  // the heading of this replica's wheel
+      sin_wheel_yaw = fromReplica(s, src);
+      cos_wheel_yaw = fromReplica(c, src);
+    }
+    computeParametricDelayDeriv(x, u, xd);
+    computeParametricAccelDeriv(x, u, xd, g);
+
+    // ---- steering: racer_dubins_elevation_lstm_steering.cu:131-167, the network shared out over the replicas
+    {
+      const float steer = x[RDE_S(STEER_ANGLE)], rate = x[RDE_S(STEER_ANGLE_RATE)];
+      const float parametric_accel = (u[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - steer) * p.steering_constant;
+      float rate_dot = fmaxf(fminf((parametric_accel - rate) * p.steer_accel_constant - rate * p.steer_accel_drag_constant,
+                                   p.max_steer_rate),
+                             -p.max_steer_rate);
+      const float input[4] = { steer * 0.2f, rate * 0.2f, u[RDE_C(STEER_CMD)], rate_dot * 0.2f };
+      float out[1] = { 0.0f };
+      net_.forward(fnn_d_, input, out);
+      rate_dot += out[0] * 5.0f;
+      xd[RDE_S(STEER_ANGLE_RATE)] = rate_dot;
+      xd[RDE_S(STEER_ANGLE)] = rate;
+    }
+
+    // ---- suspension: wheel `rep`
+    float wheel_out[OUTPUT_DIM];
+    {
+      xd[RDE_S(ROLL)] = x[RDE_S(ROLL_RATE)];
+      xd[RDE_S(PITCH)] = x[RDE_S(PITCH_RATE)];
+      xd[RDE_S(CG_POS_Z)] = x[RDE_S(CG_VEL_I_Z)];
+      float M[3][3], world[3];
+      bodyRotation(g, g.sin_yaw, g.cos_yaw, M);
+      wheelWorldPoint(M, MATH::wheelBodyX(rep), MATH::wheelBodyY(rep), x[RDE_S(POS_X)], x[RDE_S(POS_Y)], world);
+      float height = 0.0f, normal[4] = { 0.0f, 0.0f, 1.0f, 0.0f };
+      if (tex_helper_.checkTextureUse(0))
+      {
+        tex_helper_.queryTextureAtWorldPose(0, world, &height);
+        if (!isfinite(height))
+          height = x[RDE_S(CG_POS_Z)] - p.wheel_radius;
+      }
+      if (normals_tex_helper_.checkTextureUse(0))
+      {
+        normals_tex_helper_.queryTextureAtWorldPose(0, world, normal);
+        if (!isfinite(normal[0]) || !isfinite(normal[1]) || !isfinite(normal[2]))
+        {
+          normal[0] = 0.0f;
+          normal[1] = 0.0f;
+          normal[2] = 1.0f;
+          normal[3] = 0.0f;
+        }
+      }
+      float up_own, fwd_own, side_own, up[4], fwd[4], side[4];
+      MATH::wheelForce(p, x, rep, height, normal[0], normal[1], normal[2], sin_wheel_yaw, cos_wheel_yaw, up_own, fwd_own,
+                       side_own);
+      allReplicas(up_own, up);
+      allReplicas(fwd_own, fwd);
+      allReplicas(side_own, side);
+      MATH::bodyAccelerations(p, up, fwd, side, xd, wheel_out);
+    }
+
+    // ---- Euler step of the twelve integrated states and of the steering rate
+    updateState(x, xn, xd, dt);
+    xn[RDE_S(STEER_ANGLE_RATE)] = x[RDE_S(STEER_ANGLE_RATE)] + xd[RDE_S(STEER_ANGLE_RATE)] * dt;
+    covarianceFourLanes(x, xd, g, dt, rep, xn);
+
+#pragma unroll
+    for (int i = 0; i < XD; i++)
+      state_der[i] = xd[i];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+      next_state[i] = xn[i];
+    output[RDE_O(WHEEL_FORCE_UP_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_UP_MAX)];
+    output[RDE_O(WHEEL_FORCE_FWD_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_FWD_MAX)];
+    output[RDE_O(WHEEL_FORCE_SIDE_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_SIDE_MAX)];
+    MATH::setSuspensionOutputs(p, xd, xn, output);
   }
 };
 

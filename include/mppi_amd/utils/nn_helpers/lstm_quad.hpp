@@ -1,0 +1,142 @@
+/**
+ * lstm_quad.hpp — a small LSTM (four hidden units) + two-layer output MLP evaluated by the FOUR replica lanes of a rollout
+ * (REPLICATED_LANES = 4, lane = column + 16 * replica; include/mppi_amd/engine/rollout_kernel.hpp): replica r owns hidden
+ * unit r (its four gates) and L1 / 4 neurons of the MLP's hidden layer; the new hidden state and the layer's activations
+ * are exchanged with `__shfl` (ds_bpermute), the output layer's L1-term sums run on every replica.  The weights a replica
+ * needs differ from lane to lane, so they cannot be scalar operands: each lane loads its 4 (I + 4) + 4 + (L1 / 4)(I + 5)
+ * values once and keeps them in VGPRs for the whole rollout, next to the recurrent state (h of all four units, c of its
+ * own).  An object of this type is a member of a Dynamics plugin that travels by value, i.e. every lane owns its copy.
+ *
+ * Arithmetic per value as LSTMHelper / LSTMRegisters / the oracle: k-ordered fma chains (input part, then recurrent part,
+ * then bias), det:: activations, new cell state before the new hidden state, MLP on [h ; x].
+ */
+#ifndef MPPI_AMD_LSTM_QUAD_HPP_
+#define MPPI_AMD_LSTM_QUAD_HPP_
+
+#include <hip/hip_runtime.h>
+#include "mppi_amd/det_math.h"
+#include "mppi_amd/utils/nn_helpers/lstm_registers.hpp"
+
+namespace mppi
+{
+template <int I, int L1, int OUT>
+struct LSTMQuad
+{
+  static constexpr int H = 4, PER = L1 / 4;
+  static_assert(L1 % 4 == 0, "the hidden layer of the output network is dealt out to four replicas");
+  static constexpr int HH = H * H, HI = H * I, LSTM_NUM_PARAMS = 4 * HH + 4 * HI + 4 * H;
+  static constexpr int FNN_NUM_PARAMS = L1 * (H + I) + L1 + OUT * L1 + OUT;
+
+  float wg[4][I + H];   ///< gates i, f, o, c of hidden unit `replica`: input weights, then recurrent weights
+  float bg[4];
+  float w1[PER][H + I];  ///< neurons PER * replica .. + PER - 1 of the hidden layer
+  float b1[PER];
+  float h[H];  ///< hidden state of all four units
+  float c;     ///< cell state of unit `replica`
+
+  /** value of replica `src` of this lane's rollout */
+  __device__ static inline float fromReplica(const float v, const int src)
+  {
+    return __shfl(v, (int)(threadIdx.x & 15) + 16 * src, 64);
+  }
+
+  /** this lane's weights and the initial state from the blobs (layouts of lstm_helper.hpp / fnn_helper.hpp) */
+  __device__ inline void load(const int rep, const float* __restrict__ lstm_blob, const float* __restrict__ fnn_blob)
+  {
+    const float* Wm = lstm_blob;
+    const float* Wi = lstm_blob + 4 * HH;
+    const float* B = Wi + 4 * HI;
+#pragma unroll
+    for (int gate = 0; gate < 4; gate++)
+    {
+#pragma unroll
+      for (int j = 0; j < I; j++)
+        wg[gate][j] = Wi[gate * HI + rep * I + j];
+#pragma unroll
+      for (int j = 0; j < H; j++)
+        wg[gate][I + j] = Wm[gate * HH + rep * H + j];
+      bg[gate] = B[gate * H + rep];
+    }
+    const float* B1 = fnn_blob + L1 * (H + I);
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+    {
+#pragma unroll
+      for (int k = 0; k < H + I; k++)
+        w1[i][k] = fnn_blob[(PER * rep + i) * (H + I) + k];
+      b1[i] = B1[PER * rep + i];
+    }
+#pragma unroll
+    for (int j = 0; j < H; j++)
+      h[j] = lstm_blob[LSTM_NUM_PARAMS + j];
+    c = lstm_blob[LSTM_NUM_PARAMS + H + rep];
+  }
+
+  /** one forward pass; every replica ends with the same h and the same out */
+  __device__ __forceinline__ void forward(const float* __restrict__ fnn_blob, const float (&input)[I], float (&out)[OUT])
+  {
+    float gate[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+    {
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < I; j++)
+        acc = mppi::det::fma(wg[g][j], input[j], acc);
+#pragma unroll
+      for (int j = 0; j < H; j++)
+        acc = mppi::det::fma(wg[g][I + j], h[j], acc);
+      gate[g] = acc + bg[g];
+    }
+    float sg[3] = { gate[0], gate[1], gate[2] };
+    mppi::det::sigmoid_n<3>(sg);
+    const float gc = mppi::det::tanh(gate[3]);
+    const float in_part = sg[0] * gc;
+    const float keep_part = sg[1] * c;
+    c = in_part + keep_part;
+    const float h_own = mppi::det::tanh(c) * sg[2];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      h[r] = fromReplica(h_own, r);
+    float act[H + I];
+#pragma unroll
+    for (int j = 0; j < H; j++)
+      act[j] = h[j];
+#pragma unroll
+    for (int j = 0; j < I; j++)
+      act[H + j] = input[j];
+    float hid_own[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+    {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < H + I; k++)
+        acc = mppi::det::fma(w1[i][k], act[k], acc);
+      hid_own[i] = acc + b1[i];
+    }
+    mppi::det::tanh_n<PER>(hid_own);
+    float hid[L1];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+      for (int i = 0; i < PER; i++)
+        hid[PER * s + i] = fromReplica(hid_own[i], s);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the output layer: the same L1-term chains on every replica, weights through the scalar unit
+    lstm_const_f32* W2 = lstmScalarView(fnn_blob + L1 * (H + I) + L1);
+#pragma unroll
+    for (int j = 0; j < OUT; j++)
+    {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < L1; k++)
+        acc = mppi::det::fma(W2[j * L1 + k], hid[k], acc);
+      out[j] = acc + W2[OUT * L1 + j];
+    }
+#endif
+  }
+};
+}  // namespace mppi
+
+#endif

@@ -159,11 +159,27 @@ struct TwoDTextureHelper
       else
         border = border || (qy > (float)(h - 1)) || (qy <= 0.0f);
       const int idx = border ? 0 : (int)roundf(qy) * w + (int)roundf(qx);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
       for (int ch = 0; ch < NC; ch++)
-        out[ch] = border ? p.border_color[ch] : p.data[(size_t)idx * NC + ch];
+      {
+        // both values first, then the select: written as `border ? border_color[ch] : data[..]` the compiler selects between
+        // the two ADDRESSES (one in the kernel-argument / private copy of this object, one in global memory) and issues a
+        // single flat load, which faults for the private one (seen with NC = 4 on the terrain-normals map)
+        float texel = p.data[(size_t)idx * NC + ch];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(texel));
+#endif
+        const float edge = p.border_color[ch];
+        out[ch] = border ? edge : texel;
+      }
       return;
     }
     const LinearFootprint f = linearFootprint(index, point);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
     for (int ch = 0; ch < NC; ch++)
     {
       const float v = interpolate(f, p.data[(size_t)f.i11 * NC + ch], p.data[(size_t)f.i12 * NC + ch],

@@ -475,6 +475,28 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     h->bx = 32;
     h->by = 1;
   }
+  // no shape requested and the model's default (bx, by) has no instantiation for this many systems (a Tube controller on a
+  // model whose default shape exists for bz = 1 only): the registered shape for bz with the same lanes per rollout if there
+  // is one, otherwise the first one listed (replicated-lane shapes come first)
+  if (cfg->controller != MPPI_CONTROLLER_ROBUST && cfg->block_x == 0 && cfg->block_y == 0 &&
+      !h->model->supportsShape(h->bx, h->by, h->bz) && !h->model->supportsPipelineFold(h->bx, h->by, h->bz))
+  {
+    std::vector<int> shapes;
+    h->model->listShapes(shapes);
+    int pick = -1;
+    for (size_t i = 0; i + 2 < shapes.size(); i += 3)
+    {
+      if (shapes[i + 2] != h->bz)
+        continue;
+      if (pick < 0 || (shapes[i + 1] == h->by && shapes[pick + 1] != h->by))
+        pick = (int)i;
+    }
+    if (pick >= 0)
+    {
+      h->bx = shapes[pick];
+      h->by = shapes[pick + 1];
+    }
+  }
   // (Robust MPPI's two kernels are instantiated per model — checked above — not per block shape)
   if (cfg->controller != MPPI_CONTROLLER_ROBUST && !h->model->supportsShape(h->bx, h->by, h->bz) && !h->model->supportsPipelineFold(h->bx, h->by, h->bz))
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,

@@ -7,8 +7,14 @@
  * compiled into shared libraries, e.g. src/controllers/cartpole/cartpole_mppi.cu:30-42).  One translation unit per
  * model, so a new or changed model recompiles alone (buildlib.py compiles the units in parallel).
  *
- * Block shapes: BY == 1, one lane per rollout (racer_dubins_elevation_suspension.hpp); fused rollout kernel (the LDS
- * fallback of the steering network needs a block barrier in initializeDynamics, see racer_dubins_elevation_lstm_steering.hip).
+ * Block shapes: (64, 4) — the default — runs a rollout on four replica lanes that share out the wheels of the suspension,
+ * the hidden units and neurons of the steering network and the rows of the covariance update
+ * (RacerDubinsElevationSuspensionQuad; default network shape only).  Two systems (Tube): (32, 4, 2).  A (64, 4, 2) block is 512
+ * threads, i.e. 256 registers per lane with ~200 of the step's values spilled, and that instantiation returned NaN costs
+ * for injected noise when compiled at -O3 (correct at -O2, correct with the in-kernel draw, correct for every other
+ * model): it is not instantiated; the 256-thread block keeps the step in registers.  BY == 1: one lane per rollout; fused rollout kernel
+ * (the LDS fallback of the steering network needs a block barrier in initializeDynamics, see
+ * racer_dubins_elevation_lstm_steering.hip).
  */
 #include "mppi_amd/engine/model_registry.hpp"
 #include "mppi_amd/sampling_distributions/gaussian.hpp"
@@ -23,10 +29,12 @@ using SuspensionCost = QuadraticCost<RacerDubinsElevationSuspension, /*SKIP_ZERO
 using RacerSuspensionModel =
     ModelT<RacerDubinsElevationSuspension, SuspensionCost,
            sampling_distributions::GaussianDistribution<RacerDubinsElevationSuspensionParams>,
-           Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/2, void, Shapes<>, /*PIPELINE=*/false>;
+           Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/2,
+           /* four lanes per rollout: a wheel, a covariance row, a hidden unit and five MLP neurons each */
+           RacerDubinsElevationSuspensionQuad, Shapes<Shape<64, 4, 1>, Shape<32, 4, 2>>, /*PIPELINE=*/false>;
 using RacerSuspensionColoredModel =
     ModelT<RacerDubinsElevationSuspension, SuspensionCost,
            sampling_distributions::ColoredNoiseDistribution<RacerDubinsElevationSuspensionParams>, Shapes<Shape<64, 1, 1>>,
-           /*FIN_BY=*/2, void, Shapes<>, /*PIPELINE=*/false>;
-MPPI_REGISTER_MODEL("racer_dubins_elevation_suspension", MPPI_SAMPLER_GAUSSIAN, RacerSuspensionModel, 64, 1)
-MPPI_REGISTER_MODEL("racer_dubins_elevation_suspension", MPPI_SAMPLER_COLORED, RacerSuspensionColoredModel, 64, 1)
+           /*FIN_BY=*/2, RacerDubinsElevationSuspensionQuad, Shapes<Shape<64, 4, 1>>, /*PIPELINE=*/false>;
+MPPI_REGISTER_MODEL("racer_dubins_elevation_suspension", MPPI_SAMPLER_GAUSSIAN, RacerSuspensionModel, 64, 4)
+MPPI_REGISTER_MODEL("racer_dubins_elevation_suspension", MPPI_SAMPLER_COLORED, RacerSuspensionColoredModel, 64, 4)
