@@ -600,8 +600,9 @@ public:
   }
   /** four lanes per rollout: replica `rep` forms row `rep` of (I + A dt) Sigma (I + A dt)^T + Q dt (the sums in the order of
    *  computeUncertaintyPropagation), the rows are exchanged and written to next_state */
+  template <class QFN>
   __device__ __forceinline__ void covarianceFourLanes(const float* x, const float* xd, const StepTrig& g, const float dt,
-                                                      const int rep, float* xn) const
+                                                      const int rep, float* xn, QFN&& process_noise) const
   {
     float A[UD * UD], Sigma[UD * UD], Q[UD * UD], Ar[UD], Sb[UD], row[UD];
     computeUncertaintyJacobian(x, g, A);
@@ -621,7 +622,7 @@ public:
         acc += Ar[k] * Sigma[cm(k, n)];
       Sb[n] = acc;
     }
-    computeQ(x, xd, g, Q);
+    process_noise(Q);
 #pragma unroll
     for (int n = 0; n < UD; n++)
     {
@@ -638,6 +639,33 @@ public:
       for (int n = 0; n < UD; n++)
         Sigma[cm(m, n)] = fromReplica(row[n], m);
     uncertaintyMatrixToState(Sigma, xn);
+  }
+
+  __device__ __forceinline__ void covarianceFourLanes(const float* x, const float* xd, const StepTrig& g, const float dt,
+                                                      const int rep, float* xn) const
+  {
+    covarianceFourLanes(x, xd, g, dt, rep, xn, [this, x, xd, &g](float* Q) { computeQ(x, xd, g, Q); });
+  }
+
+  /** static settling on four lanes: wheel `rep`'s map lookup at the pose (x, y, heading sin_psi / cos_psi) with the body
+   *  angles of g, then angle `rep` of the four arcsines; returns (0, 0, 0) without a map */
+  __device__ __forceinline__ void settleFourLanes(const StepTrig& g, const float sin_psi, const float cos_psi, const float x,
+                                                  const float y, const int rep, float& roll, float& pitch,
+                                                  float& height) const
+  {
+    roll = 0.0f;
+    pitch = 0.0f;
+    height = 0.0f;
+    if (tex_helper_.checkTextureUse(0))
+    {
+      float M[3][3], world[3], h_own, h[4], angle[4];
+      bodyRotation(g, sin_psi, cos_psi, M);
+      wheelWorldPoint(M, wheelOffsetX(rep), wheelOffsetY(rep), x, y, world);
+      tex_helper_.queryTextureAtWorldPose(0, world, &h_own);
+      allReplicas(h_own, h);
+      allReplicas(mppi::det::asin(settlingSine(rep, h)), angle);
+      settle(angle, h, roll, pitch, height);
+    }
   }
 
   /**
@@ -697,17 +725,8 @@ public:
     }
 
     // ---- static settling: wheel `rep`, then angle `rep`
-    float roll = 0.0f, pitch = 0.0f, height = 0.0f;
-    if (tex_helper_.checkTextureUse(0))
-    {
-      float M[3][3], world[3], h_own, h[4], angle[4];
-      bodyRotation(g, sin_psi, cos_psi, M);
-      wheelWorldPoint(M, wheelOffsetX(rep), wheelOffsetY(rep), xn[RDE_S(POS_X)], xn[RDE_S(POS_Y)], world);
-      tex_helper_.queryTextureAtWorldPose(0, world, &h_own);
-      allReplicas(h_own, h);
-      allReplicas(mppi::det::asin(settlingSine(rep, h)), angle);
-      settle(angle, h, roll, pitch, height);
-    }
+    float roll, pitch, height;
+    settleFourLanes(g, sin_psi, cos_psi, xn[RDE_S(POS_X)], xn[RDE_S(POS_Y)], rep, roll, pitch, height);
     xn[RDE_S(PITCH)] = pitch;
     xn[RDE_S(ROLL)] = roll;
 

@@ -72,6 +72,44 @@ struct RacerDubinsElevationUncertaintyParams : public RacerDubinsElevationSuspen
   int use_static_settling = 1;  ///< carried for layout compatibility (the reference's bool); the device step always settles
 };
 
+/** racer_dubins_elevation_lstm_unc.cu:440-494: the process noise from the five outputs of the uncertainty network (shared by
+ *  the one-lane and the four-lane form) */
+template <class PARAMS_T, class TRIG>
+__device__ __forceinline__ void networkOutputsToQ(const PARAMS_T& p, const float vx, const TRIG& g, const int index, float* o,
+                                                  float* Q)
+{
+  constexpr int UD = 4;
+  auto cm = [](int r, int c) { return r + UD * c; };
+#pragma unroll
+  for (int i = 0; i < 5; i++)
+    o[i] = fabsf(mppi::det::sigmoid(o[i]) * p.unc_scale[i]);
+#pragma unroll
+  for (int i = 0; i < UD * UD; i++)
+    Q[i] = 0.0f;
+  const float b0 = p.c_b[0], b1 = p.c_b[1], b2 = p.c_b[2];  // values first, then selects (not a select of addresses)
+  const float c_b = index == 0 ? b0 : (index == 1 ? b1 : b2);
+  const float brake_gain = c_b * (index == 0 ? vx : 1.0f);
+  Q[cm(RDE_U(VEL_X), RDE_U(VEL_X))] = o[0] + (brake_gain * brake_gain) * o[4];
+  const float yaw_gain = (vx / p.wheel_base) * 1.0f / ((g.cos_delta * g.cos_delta) * p.steer_angle_scale);
+  Q[cm(RDE_U(YAW), RDE_U(YAW))] = o[1] + (yaw_gain * yaw_gain) * o[3];
+  Q[cm(RDE_U(POS_X), RDE_U(POS_X))] = o[2] * g.sin_yaw * g.sin_yaw;
+  Q[cm(RDE_U(POS_X), RDE_U(POS_Y))] = -o[2] * g.sin_yaw * g.cos_yaw;
+  Q[cm(RDE_U(POS_Y), RDE_U(POS_Y))] = o[2] * g.cos_yaw * g.cos_yaw;
+  Q[cm(RDE_U(POS_Y), RDE_U(POS_X))] = -o[2] * g.sin_yaw * g.cos_yaw;
+}
+
+/** racer_dubins_elevation_lstm_unc.cu:527-533: the brake lag with linear + quadratic gains */
+template <class PARAMS_T>
+__device__ __forceinline__ float quadraticBrakeLag(const PARAMS_T& p, const float throttle_brake, const float brake_state)
+{
+  const bool enable_brake = throttle_brake < 0.0f;
+  const float e = (enable_brake * -throttle_brake - brake_state);
+  return fminf(fmaxf((e > 0) * (e * p.pos_quad_brake_c[0] + e * fabsf(e) * p.pos_quad_brake_c[1]) +
+                         (e < 0) * (e * p.neg_quad_brake_c[0] + e * fabsf(e) * p.neg_quad_brake_c[1]),
+                     -p.max_brake_rate_neg),
+               p.max_brake_rate_pos);
+}
+
 class RacerDubinsElevationLSTMUncertainty
   : public RacerDubinsElevationSuspensionImpl<RacerDubinsElevationLSTMUncertainty, RacerDubinsElevationUncertaintyParams>
 {
@@ -146,21 +184,7 @@ public:
     UNC_NET::forward(unc_lstm_d_, unc_fnn_d_, input, h, c, o);
     mppi::lane_sync();
     storeRecurrent(theta_s, h, c, 2);
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-      o[i] = fabsf(mppi::det::sigmoid(o[i]) * p.unc_scale[i]);
-    const int index = speedRegime(vx);
-#pragma unroll
-    for (int i = 0; i < UD * UD; i++)
-      Q[i] = 0.0f;
-    const float brake_gain = pick3(p.c_b, index) * (index == 0 ? vx : 1.0f);
-    Q[cm(RDE_U(VEL_X), RDE_U(VEL_X))] = o[0] + (brake_gain * brake_gain) * o[4];
-    const float yaw_gain = (vx / p.wheel_base) * 1.0f / ((g.cos_delta * g.cos_delta) * p.steer_angle_scale);
-    Q[cm(RDE_U(YAW), RDE_U(YAW))] = o[1] + (yaw_gain * yaw_gain) * o[3];
-    Q[cm(RDE_U(POS_X), RDE_U(POS_X))] = o[2] * g.sin_yaw * g.sin_yaw;
-    Q[cm(RDE_U(POS_X), RDE_U(POS_Y))] = -o[2] * g.sin_yaw * g.cos_yaw;
-    Q[cm(RDE_U(POS_Y), RDE_U(POS_Y))] = o[2] * g.cos_yaw * g.cos_yaw;
-    Q[cm(RDE_U(POS_Y), RDE_U(POS_X))] = -o[2] * g.sin_yaw * g.cos_yaw;
+    networkOutputsToQ(p, vx, g, speedRegime(vx), o, Q);
   }
 
   /** racer_dubins_elevation_lstm_unc.cu:496-605 */
@@ -176,16 +200,7 @@ public:
     for (int i = 0; i < CONTROL_DIM; i++)
       u[i] = control[i];
     const StepTrig g = stateTrig(x);
-    // the brake lag with linear + quadratic gains
-    {
-      const bool enable_brake = u[RDE_C(THROTTLE_BRAKE)] < 0.0f;
-      const float e = (enable_brake * -u[RDE_C(THROTTLE_BRAKE)] - x[RDE_S(BRAKE_STATE)]);
-      xd[RDE_S(BRAKE_STATE)] =
-          fminf(fmaxf((e > 0) * (e * p.pos_quad_brake_c[0] + e * fabsf(e) * p.pos_quad_brake_c[1]) +
-                          (e < 0) * (e * p.neg_quad_brake_c[0] + e * fabsf(e) * p.neg_quad_brake_c[1]),
-                      -p.max_brake_rate_neg),
-                p.max_brake_rate_pos);
-    }
+    xd[RDE_S(BRAKE_STATE)] = quadraticBrakeLag(p, u[RDE_C(THROTTLE_BRAKE)], x[RDE_S(BRAKE_STATE)]);
     computeParametricAccelDeriv(x, u, xd, g);
     computeLSTMSteering(x, u, xd, theta_s);
     computeSimpleSuspensionStep(x, xd, g, wheel_out);
@@ -237,6 +252,150 @@ public:
     output[RDE_O(WHEEL_FORCE_FWD_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_FWD_MAX)];
     output[RDE_O(WHEEL_FORCE_SIDE_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_SIDE_MAX)];
     setSuspensionOutputs(xd, xn, output);
+  }
+};
+
+/**
+ * Four lanes per rollout (racer_dubins_elevation_suspension.hpp: RacerDubinsElevationSuspensionQuadImpl has the angles, the
+ * steering network, the wheels and the covariance rows).  Added here: the static angles' trigonometry in a third pass (the
+ * two raw sines the networks read, the two wrapped sine / cosine pairs of the settling), the mean and the uncertainty
+ * network on LSTMQuadRows (a hidden unit and five neurons of the output network per replica, the replica's weights kept once
+ * per 16-lane row and fetched with DPP row broadcasts), the static settling as in the elevation model's four-lane form.
+ * Same arithmetic per value as the one-lane class above.
+ */
+class RacerDubinsElevationLSTMUncertaintyQuad
+  : public RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationLSTMUncertaintyQuad, RacerDubinsElevationUncertaintyParams>
+{
+public:
+  using PARAMS_T = RacerDubinsElevationUncertaintyParams;
+  using QUAD = RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationLSTMUncertaintyQuad, PARAMS_T>;
+  using MEAN_NET = mppi::LSTMQuadRows<12, 20, 2>;
+  using UNC_NET = mppi::LSTMQuadRows<13, 20, 5>;
+  /** the role-pipelined kernel's dynamics waves have 256 registers per lane, this step wants ~390 (147 spilled there:
+   *  1197 us against 946 us fused at K = 16384, T = 100) */
+  static constexpr bool PREFER_FUSED_KERNEL = true;
+
+  const float* mean_lstm_d_ = nullptr;
+  const float* mean_fnn_d_ = nullptr;
+  const float* unc_lstm_d_ = nullptr;
+  const float* unc_fnn_d_ = nullptr;
+  MEAN_NET mean_ = {};
+  UNC_NET unc_ = {};
+
+  RacerDubinsElevationLSTMUncertaintyQuad(const RacerDubinsElevationLSTMUncertainty& other) : QUAD(other.stream_)
+  {
+    copyFrom(other);
+    mean_lstm_d_ = other.mean_lstm_d_;
+    mean_fnn_d_ = other.mean_fnn_d_;
+    unc_lstm_d_ = other.unc_lstm_d_;
+    unc_fnn_d_ = other.unc_fnn_d_;
+  }
+
+  __device__ __forceinline__ void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
+                                                     float dt)
+  {
+    QUAD::initializeDynamics(state, control, output, theta_s, t_0, dt);
+    mean_.load(replica(), mean_lstm_d_, mean_fnn_d_);
+    unc_.load(replica(), unc_lstm_d_, unc_fnn_d_);
+  }
+
+  /** racer_dubins_elevation_lstm_unc.cu:496-605 */
+  __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
+                                       float* theta_s, const float t, const float dt)
+  {
+    const PARAMS_T& p = this->params_;
+    const int rep = replica();
+    float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM], wheel_out[OUTPUT_DIM];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+    {
+      x[i] = state[i];
+      xn[i] = state[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CONTROL_DIM; i++)
+      u[i] = control[i];
+    StepTrig g;
+    float sin_wheel_yaw, cos_wheel_yaw;
+    quadTrig(x, rep, g, sin_wheel_yaw, cos_wheel_yaw);
+    // ---- pass 3, the settled angles: replica 0 / 1 the raw static roll / pitch (network inputs), 2 / 3 the wrapped ones
+    float sin_static_roll, sin_static_pitch;
+    StepTrig gs = g;
+    {
+      const float raw = (rep & 1) ? x[RDE_S(STATIC_PITCH)] : x[RDE_S(STATIC_ROLL)];
+      float s, c;
+      mppi::det::sincos(rep < 2 ? raw : angle_utils::normalizeAngle(raw), &s, &c);
+      sin_static_roll = fromReplica(s, 0);
+      sin_static_pitch = fromReplica(s, 1);
+      gs.sin_roll = fromReplica(s, 2);
+      gs.cos_roll = fromReplica(c, 2);
+      gs.sin_pitch = fromReplica(s, 3);
+      gs.cos_pitch = fromReplica(c, 3);
+    }
+    xd[RDE_S(BRAKE_STATE)] = quadraticBrakeLag(p, u[RDE_C(THROTTLE_BRAKE)], x[RDE_S(BRAKE_STATE)]);
+    this->computeParametricAccelDeriv(x, u, xd, g);
+    quadSteering(x, u, xd);
+    quadSuspension(x, g, rep, sin_wheel_yaw, cos_wheel_yaw, xd, wheel_out);
+    const float tb = u[RDE_C(THROTTLE_BRAKE)];
+    if (p.gear_sign == 1)
+    {
+      const float input[12] = { x[RDE_S(VEL_X)],
+                                x[RDE_S(OMEGA_Z)],
+                                x[RDE_S(BRAKE_STATE)],
+                                x[RDE_S(STEER_ANGLE)],
+                                x[RDE_S(STEER_ANGLE_RATE)],
+                                tb >= 0.0f ? tb : 0.0f,
+                                tb <= 0.0f ? -tb : 0.0f,
+                                u[RDE_C(STEER_CMD)],
+                                sin_static_pitch,
+                                xd[RDE_S(VEL_X)],
+                                xd[RDE_S(YAW)],
+                                0.0f };
+      float mean_output[2];
+      mean_.forward(mean_fnn_d_, input, mean_output);
+      xd[RDE_S(VEL_X)] += mean_output[0];
+      xd[RDE_S(YAW)] += mean_output[1];
+    }
+    this->updateState(x, xn, xd, dt);
+    xn[RDE_S(STEER_ANGLE_RATE)] = x[RDE_S(STEER_ANGLE_RATE)] + xd[RDE_S(STEER_ANGLE_RATE)] * dt;
+    xn[RDE_S(OMEGA_Z)] = xd[RDE_S(YAW)];
+    // ---- covariance, the process noise from the uncertainty network (:300-494)
+    this->covarianceFourLanes(x, xd, g, dt, rep, xn, [&](float* Q) {
+      const float input[13] = { x[RDE_S(VEL_X)],
+                                x[RDE_S(OMEGA_Z)],
+                                x[RDE_S(BRAKE_STATE)],
+                                x[RDE_S(STEER_ANGLE)],
+                                x[RDE_S(STEER_ANGLE_RATE)],
+                                tb >= 0.0f ? tb : 0.0f,
+                                tb <= 0.0f ? -tb : 0.0f,
+                                u[RDE_C(STEER_CMD)],
+                                sin_static_roll,
+                                sin_static_pitch,
+                                xd[RDE_S(VEL_X)],
+                                xd[RDE_S(YAW)],
+                                0.0f };
+      float o[5];
+      unc_.forward(unc_fnn_d_, input, o);
+      networkOutputsToQ(p, x[RDE_S(VEL_X)], g, speedRegime(x[RDE_S(VEL_X)]), o, Q);
+    });
+    // ---- static settling at the next pose from the settled angles of the current state
+    {
+      float sin_psi, cos_psi, roll, pitch, height;
+      mppi::det::sincos(angle_utils::normalizeAngle(xn[RDE_S(YAW)]), &sin_psi, &cos_psi);
+      this->settleFourLanes(gs, sin_psi, cos_psi, xn[RDE_S(POS_X)], xn[RDE_S(POS_Y)], rep, roll, pitch, height);
+      xn[RDE_S(STATIC_PITCH)] = pitch;
+      xn[RDE_S(STATIC_ROLL)] = roll;
+    }
+#pragma unroll
+    for (int i = 0; i < XD; i++)
+      state_der[i] = xd[i];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+      next_state[i] = xn[i];
+    output[RDE_O(WHEEL_FORCE_UP_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_UP_MAX)];
+    output[RDE_O(WHEEL_FORCE_FWD_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_FWD_MAX)];
+    output[RDE_O(WHEEL_FORCE_SIDE_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_SIDE_MAX)];
+    MATH::setSuspensionOutputs(p, xd, xn, output);
   }
 };
 

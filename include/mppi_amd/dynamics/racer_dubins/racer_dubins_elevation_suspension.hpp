@@ -323,25 +323,39 @@ public:
  * of its output network (lstm_quad.hpp), wheel r of the suspension (terrain height, terrain normal, spring / damper force)
  * and row r of the covariance update.  Per value the arithmetic is the one-lane form's (RacerSuspensionMath, the wheel
  * forces summed FL, FR, BL, BR on every replica), so both agree with the oracle bit for bit.  Default network shape only.
+ * The pieces of the step are members of their own so that the complete RACER model (racer_dubins_elevation_lstm_unc.hpp)
+ * composes its step from them.
  */
-class RacerDubinsElevationSuspensionQuad
-  : public RacerDubinsElevationImpl<RacerDubinsElevationSuspensionQuad, RacerDubinsElevationSuspensionParams>
+template <class CLASS_T, class PARAMS_T = RacerDubinsElevationSuspensionParams, class STEER_NET = mppi::LSTMQuad<4, 20, 1>>
+class RacerDubinsElevationSuspensionQuadImpl : public RacerDubinsElevationImpl<CLASS_T, PARAMS_T>
 {
 public:
-  using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationSuspensionQuad, RacerDubinsElevationSuspensionParams>;
-  using PARAMS_T = RacerDubinsElevationSuspensionParams;
+  using ELEVATION = RacerDubinsElevationImpl<CLASS_T, PARAMS_T>;
+  using StepTrig = typename ELEVATION::StepTrig;
   using MATH = RacerSuspensionMath<PARAMS_T>;
-  using NET = mppi::LSTMQuad<4, 20, 1>;
+  static constexpr int STATE_DIM = ELEVATION::STATE_DIM, CONTROL_DIM = ELEVATION::CONTROL_DIM,
+                       OUTPUT_DIM = ELEVATION::OUTPUT_DIM;
   static constexpr int REPLICATED_LANES = 4;
   static constexpr int NUM_EULER_STATES = RDE_S(STEER_ANGLE_RATE);
   static constexpr int XD = RDE_S(STEER_ANGLE_RATE) + 1;
+  using ELEVATION::allReplicas;
+  using ELEVATION::bodyRotation;
+  using ELEVATION::fromReplica;
+  using ELEVATION::pick4;
+  using ELEVATION::setOutputs;
+  using ELEVATION::wheelWorldPoint;
 
   mppi::texture::TwoDTextureHelper<1, 4> normals_tex_helper_;
   const float* lstm_d_ = nullptr;
   const float* fnn_d_ = nullptr;
-  NET net_ = {};  ///< this lane's weights and the recurrent state
+  STEER_NET net_ = {};  ///< this lane's share of the steering network and its recurrent state
 
-  RacerDubinsElevationSuspensionQuad(const RacerDubinsElevationSuspension& other) : ELEVATION(other.stream_)
+  RacerDubinsElevationSuspensionQuadImpl(hipStream_t stream = nullptr) : ELEVATION(stream)
+  {
+  }
+  /** parameters, control limits, maps and the steering network of the one-lane model */
+  template <class OTHER>
+  void copyFrom(const OTHER& other)
   {
     this->params_ = other.params_;
     for (int i = 0; i < CONTROL_DIM; i++)
@@ -356,33 +370,27 @@ public:
     fnn_d_ = other.lstm_.output_nn_.theta_d_;
   }
 
+  __device__ static inline int replica()
+  {
+    return (int)(threadIdx.x & 63) >> 4;
+  }
+
   __device__ __forceinline__ void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
                                                      float dt)
   {
-    net_.load((int)(threadIdx.x & 63) >> 4, lstm_d_, fnn_d_);
+    net_.load(replica(), lstm_d_, fnn_d_);
     output[RDE_O(BASELINK_POS_I_Z)] = 0.0f;
     output[RDE_O(FILLER_1)] = 0.0f;
     setOutputs(state, state, output);
   }
 
-  __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
-                                       float* theta_s, const float t, const float dt)
+  /** the trigonometry of the current state in two passes: 1) replica 0 yaw, 1 wrapped steering angle, 2 raw steering angle,
+   *  3 pitch; 2) replica 0 roll, 1 heading of the front wheels, 2 and 3 heading of the rear wheels (returned for THIS
+   *  replica's wheel) */
+  __device__ __forceinline__ void quadTrig(const float* x, const int rep, StepTrig& g, float& sin_wheel_yaw,
+                                           float& cos_wheel_yaw) const
   {
     const PARAMS_T& p = this->params_;
-    const int rep = (int)(threadIdx.x & 63) >> 4;
-    float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM];
-#pragma unroll
-    for (int i = 0; i < STATE_DIM; i++)
-    {
-      x[i] = state[i];
-      xn[i] = state[i];  // FILLER_1 is carried along
-    }
-#pragma unroll
-    for (int i = 0; i < CONTROL_DIM; i++)
-      u[i] = control[i];
-
-    // ---- pass 1: replica 0 yaw, 1 wrapped steering angle, 2 raw steering angle, 3 pitch
-    StepTrig g;
     {
       const float delta = x[RDE_S(STEER_ANGLE)] / p.steer_angle_scale;
       const float raw = pick4(rep, x[RDE_S(YAW)], delta, delta, x[RDE_S(PITCH)]);
@@ -399,8 +407,6 @@ public:
       g.sin_pitch = sa[3];
       g.cos_pitch = ca[3];
     }
-    // ---- pass 2: replica 0 roll, 1 heading of the front wheels, 2 and 3 heading of the rear wheels
-    float sin_wheel_yaw, cos_wheel_yaw;
     {
       const float wheel_yaw = MATH::wheelYaw(x[RDE_S(YAW)], rep == 1 ? 0 : 2);
       float s, c;
@@ -411,65 +417,90 @@ public:
       sin_wheel_yaw = fromReplica(s, src);
       cos_wheel_yaw = fromReplica(c, src);
     }
-    computeParametricDelayDeriv(x, u, xd);
-    computeParametricAccelDeriv(x, u, xd, g);
+  }
 
-    // ---- steering: racer_dubins_elevation_lstm_steering.cu:131-167, the network shared out over the replicas
+  /** racer_dubins_elevation_lstm_steering.cu:131-167, the network shared out over the replicas */
+  __device__ __forceinline__ void quadSteering(const float* x, const float* u, float* xd)
+  {
+    const PARAMS_T& p = this->params_;
+    const float steer = x[RDE_S(STEER_ANGLE)], rate = x[RDE_S(STEER_ANGLE_RATE)];
+    const float parametric_accel = (u[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - steer) * p.steering_constant;
+    float rate_dot = fmaxf(fminf((parametric_accel - rate) * p.steer_accel_constant - rate * p.steer_accel_drag_constant,
+                                 p.max_steer_rate),
+                           -p.max_steer_rate);
+    const float input[4] = { steer * 0.2f, rate * 0.2f, u[RDE_C(STEER_CMD)], rate_dot * 0.2f };
+    float out[1] = { 0.0f };
+    net_.forward(fnn_d_, input, out);
+    rate_dot += out[0] * 5.0f;
+    xd[RDE_S(STEER_ANGLE_RATE)] = rate_dot;
+    xd[RDE_S(STEER_ANGLE)] = rate;
+  }
+
+  /** racer_dubins_elevation_suspension_lstm.cu:199-340 with wheel `rep` on this lane; fills the suspension entries of xd and
+   *  the three wheel-force outputs */
+  __device__ __forceinline__ void quadSuspension(const float* x, const StepTrig& g, const int rep, const float sin_wheel_yaw,
+                                                 const float cos_wheel_yaw, float* xd, float* wheel_out) const
+  {
+    const PARAMS_T& p = this->params_;
+    xd[RDE_S(ROLL)] = x[RDE_S(ROLL_RATE)];
+    xd[RDE_S(PITCH)] = x[RDE_S(PITCH_RATE)];
+    xd[RDE_S(CG_POS_Z)] = x[RDE_S(CG_VEL_I_Z)];
+    float M[3][3], world[3];
+    bodyRotation(g, g.sin_yaw, g.cos_yaw, M);
+    wheelWorldPoint(M, MATH::wheelBodyX(rep), MATH::wheelBodyY(rep), x[RDE_S(POS_X)], x[RDE_S(POS_Y)], world);
+    float height = 0.0f, normal[4] = { 0.0f, 0.0f, 1.0f, 0.0f };
+    if (this->tex_helper_.checkTextureUse(0))
     {
-      const float steer = x[RDE_S(STEER_ANGLE)], rate = x[RDE_S(STEER_ANGLE_RATE)];
-      const float parametric_accel = (u[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - steer) * p.steering_constant;
-      float rate_dot = fmaxf(fminf((parametric_accel - rate) * p.steer_accel_constant - rate * p.steer_accel_drag_constant,
-                                   p.max_steer_rate),
-                             -p.max_steer_rate);
-      const float input[4] = { steer * 0.2f, rate * 0.2f, u[RDE_C(STEER_CMD)], rate_dot * 0.2f };
-      float out[1] = { 0.0f };
-      net_.forward(fnn_d_, input, out);
-      rate_dot += out[0] * 5.0f;
-      xd[RDE_S(STEER_ANGLE_RATE)] = rate_dot;
-      xd[RDE_S(STEER_ANGLE)] = rate;
+      this->tex_helper_.queryTextureAtWorldPose(0, world, &height);
+      if (!isfinite(height))
+        height = x[RDE_S(CG_POS_Z)] - p.wheel_radius;
     }
-
-    // ---- suspension: wheel `rep`
-    float wheel_out[OUTPUT_DIM];
+    if (normals_tex_helper_.checkTextureUse(0))
     {
-      xd[RDE_S(ROLL)] = x[RDE_S(ROLL_RATE)];
-      xd[RDE_S(PITCH)] = x[RDE_S(PITCH_RATE)];
-      xd[RDE_S(CG_POS_Z)] = x[RDE_S(CG_VEL_I_Z)];
-      float M[3][3], world[3];
-      bodyRotation(g, g.sin_yaw, g.cos_yaw, M);
-      wheelWorldPoint(M, MATH::wheelBodyX(rep), MATH::wheelBodyY(rep), x[RDE_S(POS_X)], x[RDE_S(POS_Y)], world);
-      float height = 0.0f, normal[4] = { 0.0f, 0.0f, 1.0f, 0.0f };
-      if (tex_helper_.checkTextureUse(0))
+      normals_tex_helper_.queryTextureAtWorldPose(0, world, normal);
+      if (!isfinite(normal[0]) || !isfinite(normal[1]) || !isfinite(normal[2]))
       {
-        tex_helper_.queryTextureAtWorldPose(0, world, &height);
-        if (!isfinite(height))
-          height = x[RDE_S(CG_POS_Z)] - p.wheel_radius;
+        normal[0] = 0.0f;
+        normal[1] = 0.0f;
+        normal[2] = 1.0f;
+        normal[3] = 0.0f;
       }
-      if (normals_tex_helper_.checkTextureUse(0))
-      {
-        normals_tex_helper_.queryTextureAtWorldPose(0, world, normal);
-        if (!isfinite(normal[0]) || !isfinite(normal[1]) || !isfinite(normal[2]))
-        {
-          normal[0] = 0.0f;
-          normal[1] = 0.0f;
-          normal[2] = 1.0f;
-          normal[3] = 0.0f;
-        }
-      }
-      float up_own, fwd_own, side_own, up[4], fwd[4], side[4];
-      MATH::wheelForce(p, x, rep, height, normal[0], normal[1], normal[2], sin_wheel_yaw, cos_wheel_yaw, up_own, fwd_own,
-                       side_own);
-      allReplicas(up_own, up);
-      allReplicas(fwd_own, fwd);
-      allReplicas(side_own, side);
-      MATH::bodyAccelerations(p, up, fwd, side, xd, wheel_out);
     }
+    float up_own, fwd_own, side_own, up[4], fwd[4], side[4];
+    MATH::wheelForce(p, x, rep, height, normal[0], normal[1], normal[2], sin_wheel_yaw, cos_wheel_yaw, up_own, fwd_own,
+                     side_own);
+    allReplicas(up_own, up);
+    allReplicas(fwd_own, fwd);
+    allReplicas(side_own, side);
+    MATH::bodyAccelerations(p, up, fwd, side, xd, wheel_out);
+  }
 
-    // ---- Euler step of the twelve integrated states and of the steering rate
-    updateState(x, xn, xd, dt);
+  __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
+                                       float* theta_s, const float t, const float dt)
+  {
+    const PARAMS_T& p = this->params_;
+    const int rep = replica();
+    float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM], wheel_out[OUTPUT_DIM];
+#pragma unroll
+    for (int i = 0; i < STATE_DIM; i++)
+    {
+      x[i] = state[i];
+      xn[i] = state[i];  // FILLER_1 is carried along
+    }
+#pragma unroll
+    for (int i = 0; i < CONTROL_DIM; i++)
+      u[i] = control[i];
+    StepTrig g;
+    float sin_wheel_yaw, cos_wheel_yaw;
+    quadTrig(x, rep, g, sin_wheel_yaw, cos_wheel_yaw);
+    this->computeParametricDelayDeriv(x, u, xd);
+    this->computeParametricAccelDeriv(x, u, xd, g);
+    quadSteering(x, u, xd);
+    quadSuspension(x, g, rep, sin_wheel_yaw, cos_wheel_yaw, xd, wheel_out);
+    // Euler step of the twelve integrated states and of the steering rate
+    this->updateState(x, xn, xd, dt);
     xn[RDE_S(STEER_ANGLE_RATE)] = x[RDE_S(STEER_ANGLE_RATE)] + xd[RDE_S(STEER_ANGLE_RATE)] * dt;
-    covarianceFourLanes(x, xd, g, dt, rep, xn);
-
+    this->covarianceFourLanes(x, xd, g, dt, rep, xn);
 #pragma unroll
     for (int i = 0; i < XD; i++)
       state_der[i] = xd[i];
@@ -480,6 +511,17 @@ public:
     output[RDE_O(WHEEL_FORCE_FWD_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_FWD_MAX)];
     output[RDE_O(WHEEL_FORCE_SIDE_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_SIDE_MAX)];
     MATH::setSuspensionOutputs(p, xd, xn, output);
+  }
+};
+
+class RacerDubinsElevationSuspensionQuad : public RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationSuspensionQuad>
+{
+public:
+  using PARAMS_T = RacerDubinsElevationSuspensionParams;
+  RacerDubinsElevationSuspensionQuad(const RacerDubinsElevationSuspension& other)
+    : RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationSuspensionQuad>(other.stream_)
+  {
+    copyFrom(other);
   }
 };
 

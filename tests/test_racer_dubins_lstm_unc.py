@@ -142,14 +142,18 @@ def test_oracle_closed_loop_over_the_hills():
 
 # ------------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("maps,gear", [("both", 1), ("none", 1), ("both", -1)])
-def test_uncertainty_rollout_costs_bit_exact(gpu, maps, gear):
+@pytest.mark.parametrize("maps,gear,block_y,variant", [("both", 1, 4, 1), ("both", 1, 4, 2), ("none", 1, 4, 1), ("both", -1, 4, 2),
+                                                       ("both", 1, 1, 1), ("none", 1, 1, 1), ("both", -1, 1, 1)])
+def test_uncertainty_rollout_costs_bit_exact(gpu, maps, gear, block_y, variant):
+    """block_y = 4 (the default shape): four replica lanes per rollout (RacerDubinsElevationLSTMUncertaintyQuad; the mean /
+    uncertainty networks' weights once per 16-lane row, DPP row broadcasts), fused (1) and role-pipelined (2) kernel;
+    block_y = 1: one lane per rollout, the networks on registers with scalar-unit weights"""
     cfg = uncertainty_cfg(K=1000, T=60, maps=maps)
     cfg["dyn"].base.gear_sign = gear
     eps = host_noise(1, cfg["K"], cfg["T"], 2, seed=3)
     o = make_oracle(cfg)
     o.vanilla_compute_control(cfg["x0"], 1, eps)
-    eng = make_engine(cfg)
+    eng = make_engine(cfg, block_x=64, block_y=block_y, kernel_variant=variant)
     eng.injectNoise(eps)
     eng.computeControl(cfg["x0"], 1)
     assert np.isfinite(o.costs()).all()
@@ -198,11 +202,13 @@ def test_uncertainty_tube_and_colored_closed_loop(gpu):
     eps = host_noise(1, cfg["K"], cfg["T"], 2, seed=4)
     o = make_oracle(cfg)
     o.tube_compute_control(cfg["x0"], 1, eps)
-    eng = make_engine(cfg)
-    eng.injectNoise(eps)
-    eng.computeControl(cfg["x0"], 1)
-    assert ulp_diff(eng.getSampledCostSeq(), o.costs()).max() == 0
-    assert np.abs(eng.getControlSeq() - o.control()).max() <= 1e-5
+    # no shape: (32, 4, 2), the four-lane form for two systems; (64, 1, 2): one lane per rollout
+    for shape in ({}, dict(block_x=32, block_y=4), dict(block_x=64, block_y=1)):
+        eng = make_engine(cfg, **shape)
+        eng.injectNoise(eps)
+        eng.computeControl(cfg["x0"], 1)
+        assert ulp_diff(eng.getSampledCostSeq(), o.costs()).max() == 0, shape
+        assert np.abs(eng.getControlSeq() - o.control()).max() <= 1e-5
     cfg = uncertainty_cfg(K=2048, T=64)
     cfg["colored"] = ([1.0, 1.0], 0.97, 0.0)
     eng = make_engine(cfg)

@@ -56,7 +56,7 @@ if "racer" in which:
     from test_racer_dubins_suspension import suspension_cfg  # noqa: E402
     run("racer-suspension", suspension_cfg(K=16384, T=100), [(64, 1, 1), (64, 4, 1), (64, 4, 2)], n=30)
     from test_racer_dubins_lstm_unc import uncertainty_cfg  # noqa: E402
-    run("racer-uncertainty", uncertainty_cfg(K=16384, T=100), [(64, 1, 1)], n=30)
+    run("racer-uncertainty", uncertainty_cfg(K=16384, T=100), [(64, 1, 1), (64, 4, 1), (64, 4, 2)], n=30)
     cfg = steering_cfg(K=16384, T=100)
     cfg["colored"] = ([1.0, 1.0], 0.97, 0.0)
     run("racer-lstm+colored", cfg, [(0, 0, 0)], n=30)
