@@ -264,12 +264,16 @@ def di_tube_leg(device):
 
 def racer_elevation_leg(device):
     """the elevation-map RACER models (RacerDubinsElevation, RacerDubinsElevationLSTMSteering with the
-    colored-noise sampler of the RACER controllers) over a synthetic terrain, K=16384, T=100, four lanes per rollout"""
+    colored-noise sampler of the RACER controllers, the suspension model and the complete model with the mean / uncertainty
+    networks) over a synthetic terrain, K=16384, T=100, four lanes per rollout"""
     from common import make_engine
     from test_racer_dubins_elevation import elevation_cfg
     from test_racer_dubins_lstm_steering import steering_cfg
+    from test_racer_dubins_lstm_unc import uncertainty_cfg
+    from test_racer_dubins_suspension import suspension_cfg
     out = {}
-    for key, cfg in (("elevation", elevation_cfg(K=16384, T=100)), ("lstm_steering_colored", steering_cfg(K=16384, T=100))):
+    for key, cfg in (("elevation", elevation_cfg(K=16384, T=100)), ("lstm_steering_colored", steering_cfg(K=16384, T=100)),
+                     ("suspension", suspension_cfg(K=16384, T=100)), ("complete_model", uncertainty_cfg(K=16384, T=100))):
         if key.endswith("colored"):
             cfg["colored"] = ([1.0, 1.0], 0.97, 0.0)
         eng = make_engine(cfg, device=device)
@@ -281,8 +285,10 @@ def racer_elevation_leg(device):
         wall = time.perf_counter() - t0
         out[key] = {"value": round(n / wall, 3), "unit": "MPPI iters/s", "ms_per_step": round(wall / n * 1e3, 6)}
         eng.close()
-    out["workload"] = ("RacerDubinsElevation + QuadraticCost (Gaussian sampler) and RacerDubinsElevationLSTMSteering + "
-                       "QuadraticCost (colored noise), 240 x 240 elevation map, K=16384, T=100, block shape (64, 4)")
+    out["workload"] = ("RacerDubinsElevation + QuadraticCost (Gaussian sampler), RacerDubinsElevationLSTMSteering + "
+                       "QuadraticCost (colored noise), RacerDubinsElevationSuspension and RacerDubinsElevationLSTMUncertainty "
+                       "(the complete RACER model; Gaussian sampler), 240 x 240 elevation / normals maps, K=16384, T=100, "
+                       "block shape (64, 4)")
     return out
 
 

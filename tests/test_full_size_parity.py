@@ -214,15 +214,23 @@ def test_full_size_weighted_mean_of_dumped_samples(gpu):
 
 # ------------------------------------------------------------------ §8(f)-4: elevation-map RACER models K=16384 T=100 --
 @pytest.mark.parametrize("model,block_y,variant", [("elevation", 4, 0), ("elevation", 1, 0), ("lstm_steering", 4, 0),
-                                                   ("lstm_steering", 4, 1), ("lstm_steering", 1, 1)],
+                                                   ("lstm_steering", 4, 1), ("lstm_steering", 1, 1), ("suspension", 4, 0),
+                                                   ("suspension", 4, 1), ("suspension", 1, 1), ("uncertainty", 4, 0),
+                                                   ("uncertainty", 4, 2), ("uncertainty", 1, 1)],
                          ids=["elev-4lanes-pipeline", "elev-1lane-pipeline", "lstm-4lanes-pipeline", "lstm-4lanes-fused",
-                              "lstm-1lane-fused"])
+                              "lstm-1lane-fused", "suspension-4lanes-pipeline", "suspension-4lanes-fused",
+                              "suspension-1lane-fused", "complete-4lanes-fused", "complete-4lanes-pipeline",
+                              "complete-1lane-fused"])
 def test_racer_elevation_16384x100_vs_oracle(gpu, model, block_y, variant):
-    """RacerDubinsElevation / RacerDubinsElevationLSTMSteering over the synthetic hills at the size DESIGN.md §5 quotes
-    (one block per CU): four lanes per rollout and one lane per rollout against the oracle, injected noise"""
+    """The elevation-map RACER models (plain, LSTM steering, suspension, the complete model with the mean / uncertainty
+    networks) over the synthetic hills at the size DESIGN.md §5 quotes (one block per CU): four lanes per rollout and one
+    lane per rollout against the oracle, injected noise"""
     from test_racer_dubins_elevation import elevation_cfg
     from test_racer_dubins_lstm_steering import steering_cfg
-    cfg = (elevation_cfg if model == "elevation" else steering_cfg)(K=16384, T=100)
+    from test_racer_dubins_lstm_unc import uncertainty_cfg
+    from test_racer_dubins_suspension import suspension_cfg
+    cfg = {"elevation": elevation_cfg, "lstm_steering": steering_cfg, "suspension": suspension_cfg,
+           "uncertainty": uncertainty_cfg}[model](K=16384, T=100)
     eng, orc = make_engine(cfg, block_x=64, block_y=block_y, kernel_variant=variant), make_oracle(cfg)
     eps = host_noise(1, cfg["K"], cfg["T"], 2)
     eng.injectNoise(eps)
