@@ -179,6 +179,27 @@ struct LSTMQuadRows
   {
     return __shfl(v, (int)(threadIdx.x & 15) + 16 * src, 64);
   }
+  /**
+   * acc <- fma(weight N of this lane's replica, x, acc).  One instruction: `v_fmac_f32_dpp` with the row broadcast on its
+   * first source.  Written as inline assembly because the compiler's DPP combiner leaves `v_mov_b32_dpp` + `v_fmac_f32`
+   * (310 extra instructions per step of the complete RACER model); -DMPPI_LSTM_QUAD_ROWS_MOV restores that form.  The
+   * hardware wants two wait states between a VALU write of a register and a DPP read of it, and the compiler's hazard
+   * recogniser does not look into inline assembly: the weight registers are written once per rollout, but a register
+   * allocator copy could land in front of a use — tools/dpp_hazard_lint.py checks the built library for that
+   * (tests/test_abi.py runs it).
+   */
+  template <int N>
+  __device__ __forceinline__ void fmaWeight(float& acc, const float x) const
+  {
+    static_assert(N >= 0 && N < NW, "weight index");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MPPI_LSTM_QUAD_ROWS_MOV)
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc)
+        : "v"(wv[N / 16]), "v"(x), "n"(N % 16));
+#else
+    acc = mppi::det::fma(weight<N>(), x, acc);
+#endif
+  }
   /** weight N of this lane's replica */
   template <int N>
   __device__ __forceinline__ float weight() const
@@ -235,11 +256,11 @@ struct LSTMQuadRows
       float acc = 0.0f;
       staticFor<I>([&](auto j_) {
         constexpr int j = decltype(j_)::value;
-        acc = mppi::det::fma(weight<GATE0 + g * (I + H) + j>(), input[j], acc);
+        fmaWeight<GATE0 + g * (I + H) + j>(acc, input[j]);
       });
       staticFor<H>([&](auto j_) {
         constexpr int j = decltype(j_)::value;
-        acc = mppi::det::fma(weight<GATE0 + g * (I + H) + I + j>(), h[j], acc);
+        fmaWeight<GATE0 + g * (I + H) + I + j>(acc, h[j]);
       });
       gate[g] = acc + weight<BIAS0 + g>();
     });
@@ -266,7 +287,7 @@ struct LSTMQuadRows
       float acc = 0.0f;
       staticFor<H + I>([&](auto k_) {
         constexpr int k = decltype(k_)::value;
-        acc = mppi::det::fma(weight<W1_0 + i * (H + I) + k>(), act[k], acc);
+        fmaWeight<W1_0 + i * (H + I) + k>(acc, act[k]);
       });
       hid_own[i] = acc + weight<B1_0 + i>();
     });

@@ -59,3 +59,15 @@ def test_list_models_and_status_strings(lib):
     models = lib.mppi_list_models().decode().split("\n")
     assert {"cartpole", "double_integrator", "autorally_nn", "bicycle_slip_lstm", "racer_dubins"} <= set(models)
     assert lib.mppi_status_string(0) == b"ok" and lib.mppi_status_string(3) != b"ok"
+
+
+def test_hand_written_dpp_instructions_have_no_hazard(lib):
+    """LSTMQuadRows issues v_fmac_f32_dpp from inline assembly, which the compiler's hazard recogniser does not see: the
+    built code objects must not write a DPP source register (or EXEC) with the VALU inside the hardware's wait-state window"""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "dpp_hazard_lint.py"), m.library_path()],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 hazard(s)" in r.stdout and not r.stdout.startswith("0 DPP"), r.stdout
