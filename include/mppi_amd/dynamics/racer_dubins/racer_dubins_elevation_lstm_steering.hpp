@@ -238,7 +238,7 @@ public:
   using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteeringQuad>;
   using PARAMS_T = RacerDubinsElevationParams;
   static constexpr int REPLICATED_LANES = 4;
-  using NET = mppi::LSTMQuad<4, 20, 1>;
+  using NET = mppi::LSTMQuadRows<4, 20, 1>;
 
   const float* lstm_d_ = nullptr;
   const float* fnn_d_ = nullptr;

@@ -271,9 +271,6 @@ public:
   using QUAD = RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationLSTMUncertaintyQuad, PARAMS_T>;
   using MEAN_NET = mppi::LSTMQuadRows<12, 20, 2>;
   using UNC_NET = mppi::LSTMQuadRows<13, 20, 5>;
-  /** the role-pipelined kernel's dynamics waves have 256 registers per lane, this step wants ~390 (147 spilled there:
-   *  1197 us against 946 us fused at K = 16384, T = 100) */
-  static constexpr bool PREFER_FUSED_KERNEL = true;
 
   const float* mean_lstm_d_ = nullptr;
   const float* mean_fnn_d_ = nullptr;

@@ -326,7 +326,7 @@ public:
  * The pieces of the step are members of their own so that the complete RACER model (racer_dubins_elevation_lstm_unc.hpp)
  * composes its step from them.
  */
-template <class CLASS_T, class PARAMS_T = RacerDubinsElevationSuspensionParams, class STEER_NET = mppi::LSTMQuad<4, 20, 1>>
+template <class CLASS_T, class PARAMS_T = RacerDubinsElevationSuspensionParams, class STEER_NET = mppi::LSTMQuadRows<4, 20, 1>>
 class RacerDubinsElevationSuspensionQuadImpl : public RacerDubinsElevationImpl<CLASS_T, PARAMS_T>
 {
 public:

@@ -156,11 +156,6 @@ struct ModelBase
   {
     return false;
   }
-  /** the plugin asks for the fused kernel where both exist and the caller did not choose (MPPI_KERNEL_AUTO) */
-  virtual bool prefersFusedKernel(int bx, int by, int bz) const
-  {
-    return false;
-  }
   virtual size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D, bool pipeline) = 0;
   /** floats the sampler needs for the sample rows of `blocks` blocks of `slots` rollout slots in HBM (long horizons), 0: the
    *  sampler keeps its rows in LDS only; setGlobalRows(ptr) switches the fused kernel over (nullptr: back to LDS) */
@@ -303,16 +298,6 @@ struct has_register_form : std::false_type
 /** dynamics whose replicated-lane (FAST) variant exists for one network shape only (`register_form_`) */
 template <class T>
 struct has_register_form<T, std::void_t<decltype(std::declval<T&>().register_form_)>> : std::true_type
-{
-};
-template <class T, class = void>
-struct prefers_fused : std::false_type
-{
-};
-/** replicated-lane dynamics whose step does not fit the 256 registers of the role-pipelined kernel's lanes
- *  (`PREFER_FUSED_KERNEL`): the fused kernel unless the caller asks for the other */
-template <class T>
-struct prefers_fused<T, std::void_t<decltype(T::PREFER_FUSED_KERNEL)>> : std::bool_constant<T::PREFER_FUSED_KERNEL>
 {
 };
 template <class T, class = void>
@@ -510,12 +495,6 @@ struct ModelT : ModelBase
   {
     if constexpr (!std::is_void<DYN_FAST_T>::value)
       return bx == 64 && bz == 1 && by == kernels::replicated_lanes<DYN_FAST_T>::value && hasShape(FAST_SHAPES{}, bx, by, bz);
-    return false;
-  }
-  bool prefersFusedKernel(int bx, int by, int bz) const override
-  {
-    if constexpr (!std::is_void<DYN_FAST_T>::value)
-      return prefers_fused<DYN_FAST_T>::value && supportsPipelineRep(bx, by, bz);
     return false;
   }
   template <class FAST = DYN_FAST_T>

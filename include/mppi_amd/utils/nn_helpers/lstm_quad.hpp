@@ -2,10 +2,10 @@
  * lstm_quad.hpp — a small LSTM (four hidden units) + two-layer output MLP evaluated by the FOUR replica lanes of a rollout
  * (REPLICATED_LANES = 4, lane = column + 16 * replica; include/mppi_amd/engine/rollout_kernel.hpp): replica r owns hidden
  * unit r (its four gates) and L1 / 4 neurons of the MLP's hidden layer; the new hidden state and the layer's activations
- * are exchanged with `__shfl` (ds_bpermute), the output layer's L1-term sums run on every replica.  The weights a replica
- * needs differ from lane to lane, so they cannot be scalar operands: each lane loads its 4 (I + 4) + 4 + (L1 / 4)(I + 5)
- * values once and keeps them in VGPRs for the whole rollout, next to the recurrent state (h of all four units, c of its
- * own).  An object of this type is a member of a Dynamics plugin that travels by value, i.e. every lane owns its copy.
+ * are exchanged with `__shfl` (ds_bpermute), the output layer's L1-term sums run on every replica with scalar-unit weights.
+ * The weights a replica needs differ from lane to lane, so they cannot be scalar operands — see LSTMQuadRows below for where
+ * they live.  An object of this type is a member of a Dynamics plugin that travels by value, i.e. every lane owns its copy
+ * (weights and recurrent state: h of all four units, c of its own).
  *
  * Arithmetic per value as LSTMHelper / LSTMRegisters / the oracle: k-ordered fma chains (input part, then recurrent part,
  * then bias), det:: activations, new cell state before the new hidden state, MLP on [h ; x].
@@ -21,124 +21,6 @@
 
 namespace mppi
 {
-template <int I, int L1, int OUT>
-struct LSTMQuad
-{
-  static constexpr int H = 4, PER = L1 / 4;
-  static_assert(L1 % 4 == 0, "the hidden layer of the output network is dealt out to four replicas");
-  static constexpr int HH = H * H, HI = H * I, LSTM_NUM_PARAMS = 4 * HH + 4 * HI + 4 * H;
-  static constexpr int FNN_NUM_PARAMS = L1 * (H + I) + L1 + OUT * L1 + OUT;
-
-  float wg[4][I + H];   ///< gates i, f, o, c of hidden unit `replica`: input weights, then recurrent weights
-  float bg[4];
-  float w1[PER][H + I];  ///< neurons PER * replica .. + PER - 1 of the hidden layer
-  float b1[PER];
-  float h[H];  ///< hidden state of all four units
-  float c;     ///< cell state of unit `replica`
-
-  /** value of replica `src` of this lane's rollout */
-  __device__ static inline float fromReplica(const float v, const int src)
-  {
-    return __shfl(v, (int)(threadIdx.x & 15) + 16 * src, 64);
-  }
-
-  /** this lane's weights and the initial state from the blobs (layouts of lstm_helper.hpp / fnn_helper.hpp) */
-  __device__ inline void load(const int rep, const float* __restrict__ lstm_blob, const float* __restrict__ fnn_blob)
-  {
-    const float* Wm = lstm_blob;
-    const float* Wi = lstm_blob + 4 * HH;
-    const float* B = Wi + 4 * HI;
-#pragma unroll
-    for (int gate = 0; gate < 4; gate++)
-    {
-#pragma unroll
-      for (int j = 0; j < I; j++)
-        wg[gate][j] = Wi[gate * HI + rep * I + j];
-#pragma unroll
-      for (int j = 0; j < H; j++)
-        wg[gate][I + j] = Wm[gate * HH + rep * H + j];
-      bg[gate] = B[gate * H + rep];
-    }
-    const float* B1 = fnn_blob + L1 * (H + I);
-#pragma unroll
-    for (int i = 0; i < PER; i++)
-    {
-#pragma unroll
-      for (int k = 0; k < H + I; k++)
-        w1[i][k] = fnn_blob[(PER * rep + i) * (H + I) + k];
-      b1[i] = B1[PER * rep + i];
-    }
-#pragma unroll
-    for (int j = 0; j < H; j++)
-      h[j] = lstm_blob[LSTM_NUM_PARAMS + j];
-    c = lstm_blob[LSTM_NUM_PARAMS + H + rep];
-  }
-
-  /** one forward pass; every replica ends with the same h and the same out */
-  __device__ __forceinline__ void forward(const float* __restrict__ fnn_blob, const float (&input)[I], float (&out)[OUT])
-  {
-    float gate[4];
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-    {
-      float acc = 0.0f;
-#pragma unroll
-      for (int j = 0; j < I; j++)
-        acc = mppi::det::fma(wg[g][j], input[j], acc);
-#pragma unroll
-      for (int j = 0; j < H; j++)
-        acc = mppi::det::fma(wg[g][I + j], h[j], acc);
-      gate[g] = acc + bg[g];
-    }
-    float sg[3] = { gate[0], gate[1], gate[2] };
-    mppi::det::sigmoid_n<3>(sg);
-    const float gc = mppi::det::tanh(gate[3]);
-    const float in_part = sg[0] * gc;
-    const float keep_part = sg[1] * c;
-    c = in_part + keep_part;
-    const float h_own = mppi::det::tanh(c) * sg[2];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-      h[r] = fromReplica(h_own, r);
-    float act[H + I];
-#pragma unroll
-    for (int j = 0; j < H; j++)
-      act[j] = h[j];
-#pragma unroll
-    for (int j = 0; j < I; j++)
-      act[H + j] = input[j];
-    float hid_own[PER];
-#pragma unroll
-    for (int i = 0; i < PER; i++)
-    {
-      float acc = 0.0f;
-#pragma unroll
-      for (int k = 0; k < H + I; k++)
-        acc = mppi::det::fma(w1[i][k], act[k], acc);
-      hid_own[i] = acc + b1[i];
-    }
-    mppi::det::tanh_n<PER>(hid_own);
-    float hid[L1];
-#pragma unroll
-    for (int s = 0; s < 4; s++)
-#pragma unroll
-      for (int i = 0; i < PER; i++)
-        hid[PER * s + i] = fromReplica(hid_own[i], s);
-#if defined(__HIP_DEVICE_COMPILE__)
-    // the output layer: the same L1-term chains on every replica, weights through the scalar unit
-    lstm_const_f32* W2 = lstmScalarView(fnn_blob + L1 * (H + I) + L1);
-#pragma unroll
-    for (int j = 0; j < OUT; j++)
-    {
-      float acc = 0.0f;
-#pragma unroll
-      for (int k = 0; k < L1; k++)
-        acc = mppi::det::fma(W2[j * L1 + k], hid[k], acc);
-      out[j] = acc + W2[OUT * L1 + j];
-    }
-#endif
-  }
-};
 /** compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}) */
 template <class F, int... Is>
 __device__ __forceinline__ void staticForImpl(F&& f, std::integer_sequence<int, Is...>)
@@ -152,13 +34,13 @@ __device__ __forceinline__ void staticFor(F&& f)
 }
 
 /**
- * The same network and the same division of labour as LSTMQuad, for networks whose per-replica weights do not fit a lane's
- * registers next to the model's state (the mean / uncertainty networks of the complete RACER model: 153 / 162 values per
- * replica).  A replica's sixteen lanes form one DPP row (lane = column + 16 * replica), and all sixteen need the SAME
- * weights: weight n of the replica is kept ONCE per row, in lane n % 16 of register n / 16, and a multiply-add fetches it
- * with the row-broadcast data-parallel primitive (`v_mov_b32_dpp ... row_newbcast:n`, gfx90a+: every lane of a row reads the
- * given lane of its row; no LDS, no memory, one extra VALU instruction per multiply-add).  10 / 11 registers instead of
- * 153 / 162.  Arithmetic per value as LSTMQuad (and therefore LSTMHelper / LSTMRegisters / the oracle).
+ * Where the weights live.  A replica's sixteen lanes form one DPP row (lane = column + 16 * replica), and all sixteen need the
+ * SAME weights: weight n of the replica is kept ONCE per row, in lane n % 16 of register n / 16, and a multiply-add fetches it
+ * with the row-broadcast data-parallel primitive (`row_newbcast:n`, gfx90a+: every lane of a row reads the given lane of its
+ * row; no LDS, no memory).  6 registers for the steering network (81 values per replica), 10 / 11 for the mean / uncertainty
+ * networks of the complete RACER model (153 / 162).  The first version kept each lane's 81 steering weights in 81 of its own
+ * registers: same speed for the LSTM-steering model, but 20 us slower per iteration for the suspension model and 35 / 245 us
+ * (fused / role-pipelined kernel, whose lanes have 256 registers) for the complete model, where the registers are needed.
  */
 template <int I, int L1, int OUT>
 struct LSTMQuadRows

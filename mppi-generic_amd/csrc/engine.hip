@@ -510,8 +510,7 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
                 "mppi_create: the pipeline variant needs a model registered for it and block shape (64, 1), or (64, REP, 1) "
                 "for replicated-lane (MFMA) dynamics");
-  h->pipeline = pipe_ok && cfg->kernel_variant != MPPI_KERNEL_FUSED &&
-                !(cfg->kernel_variant == MPPI_KERNEL_AUTO && h->model->prefersFusedKernel(h->bx, h->by, h->bz));
+  h->pipeline = pipe_ok && cfg->kernel_variant != MPPI_KERNEL_FUSED;
   size_t lds = cfg->controller == MPPI_CONTROLLER_ROBUST ?
                    h->model->rmppiSharedBytes(h->bx, cfg->num_timesteps) :
                    h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, h->pipeline);
