@@ -10,9 +10,11 @@
  * Block shapes: (64, 4) — the default — runs a rollout on four replica lanes that share out the wheels of the suspension,
  * the hidden units and neurons of the steering network and the rows of the covariance update
  * (RacerDubinsElevationSuspensionQuad; default network shape only).  Two systems (Tube): (32, 4, 2).  A (64, 4, 2) block is 512
- * threads, i.e. 256 registers per lane with ~200 of the step's values spilled, and that instantiation returned NaN costs
- * for injected noise when compiled at -O3 (correct at -O2, correct with the in-kernel draw, correct for every other
- * model): it is not instantiated; the 256-thread block keeps the step in registers.  BY == 1: one lane per rollout; fused rollout kernel
+ * threads, i.e. 256 registers per lane.  While every lane kept its own copy of the steering weights (81 registers, ~200
+ * values of the step spilled) that instantiation returned NaN costs for injected noise when compiled at -O3 — correct at
+ * -O2, correct with the in-kernel draw, correct for every other model, and correct again since the weights moved into
+ * DPP rows (lstm_quad.hpp) and the spills went away.  Not understood beyond that, so it stays un-instantiated; the
+ * 256-thread block keeps the step in registers with room to spare.  BY == 1: one lane per rollout; fused rollout kernel
  * (the LDS fallback of the steering network needs a block barrier in initializeDynamics, see
  * racer_dubins_elevation_lstm_steering.hip).
  */
