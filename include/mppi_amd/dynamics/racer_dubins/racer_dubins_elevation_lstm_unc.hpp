@@ -20,13 +20,17 @@
  * :306-309 has no return; only the overwrite is restated here.  Network inputs the step does not fill are zero, as the
  * reference's host path has them.)
  *
- * Networks: the shapes of the reference's tests (tests/dynamics/racer_dubins_elevation_lstm_uncertainty_model_test.cu:
- * 26-48): steering LSTM(4, 4) + {8, 20, 1}, mean LSTM(12, 4) + {16, 20, 2}, uncertainty LSTM(13, 4) + {17, 20, 5}.  All
- * three run on registers (utils/nn_helpers/lstm_registers.hpp: parameters through the scalar unit, activations in VGPRs);
- * the 3 x (4 + 4) recurrent values of a rollout rest in LDS between steps, laid out [value][slot].  Blobs: the steering
- * pair of the parent, "mean_lstm_weights" / "mean_lstm_output_weights", "unc_lstm_weights" / "unc_lstm_output_weights"
- * (layouts of lstm_helper.hpp, initial hidden / cell state in the tail), and "mean_lstm_state" / "unc_lstm_state"
- * ([hidden | cell]) for the per-cycle update the reference does in updateFromBuffer (:98-141; host: mppi::LSTMLSTMHelper).
+ * Networks: for the shapes of the reference's tests (tests/dynamics/racer_dubins_elevation_lstm_uncertainty_model_test.cu:
+ * 26-48: steering LSTM(4, 4) + {8, 20, 1}, mean LSTM(12, 4) + {16, 20, 2}, uncertainty LSTM(13, 4) + {17, 20, 5}) all three
+ * run on registers (utils/nn_helpers/lstm_registers.hpp: parameters through the scalar unit, activations in VGPRs; the
+ * 3 x (4 + 4) recurrent values of a rollout rest in LDS between steps, laid out [value][slot]) or, four lanes per rollout,
+ * on LSTMQuadRows (the class at the end of this file).  Any other shape ("lstm_structure", "mean_lstm_structure",
+ * "unc_lstm_structure": {H, H + inputs, output-network layers ...}; mppi_load_npz sizes the networks from the archive as the
+ * reference's constructor does) runs the general form: three LSTMHelper regions [parameters | slots x (h, c, activations)]
+ * in LDS, the reference's contract, one lane per rollout.  Blobs: the steering pair of the parent, "mean_lstm_weights" /
+ * "mean_lstm_output_weights", "unc_lstm_weights" / "unc_lstm_output_weights" (layouts of lstm_helper.hpp, initial hidden /
+ * cell state in the tail), and "mean_lstm_state" / "unc_lstm_state" ([hidden | cell]) for the per-cycle update the
+ * reference does in updateFromBuffer (:98-141; host: mppi::LSTMLSTMHelper).
  */
 #ifndef MPPI_AMD_RACER_DUBINS_ELEVATION_LSTM_UNC_HPP_
 #define MPPI_AMD_RACER_DUBINS_ELEVATION_LSTM_UNC_HPP_
@@ -125,25 +129,86 @@ public:
   const float* unc_lstm_d_ = nullptr;   ///< uncertainty network
   const float* unc_fnn_d_ = nullptr;
 
+  /** the two networks in the general form (LSTMHelper's LDS contract): used when any of the three networks has another
+   *  shape than the register forms above are compiled for (`register_form_` false) */
+  mppi::LSTMHelper mean_lstm_, unc_lstm_;
+  static constexpr int MEAN_INPUT_DIM = 12, MEAN_OUTPUT_DIM = 2, UNC_INPUT_DIM = 13, UNC_OUTPUT_DIM = 5;
+
   RacerDubinsElevationLSTMUncertainty(hipStream_t stream = nullptr) : SUSPENSION(stream)
   {
+    const int mean_layers[3] = { NET_H + MEAN_INPUT_DIM, 20, MEAN_OUTPUT_DIM };
+    const int unc_layers[3] = { NET_H + UNC_INPUT_DIM, 20, UNC_OUTPUT_DIM };
+    mean_lstm_.setStructure(MEAN_INPUT_DIM, NET_H, mean_layers, 3);
+    unc_lstm_.setStructure(UNC_INPUT_DIM, NET_H, unc_layers, 3);
   }
   static const char* getDynamicsModelName()
   {
     return "RACER Dubins LSTM Uncertainty Model";
   }
-  /** the three networks have the shapes this class is compiled for */
-  bool setLSTMStructure(const int*, int)
+  /** all three networks have the shapes the register forms are compiled for */
+  bool defaultShapes() const
   {
-    return false;
+    auto is = [](const mppi::LSTMHelper& n, int I, int OUT) {
+      return n.HIDDEN_DIM == NET_H && n.INPUT_DIM == I && n.output_nn_.NUM_LAYERS == 3 && n.output_nn_.net_structure_[1] == 20 &&
+             n.OUTPUT_DIM == OUT;
+    };
+    return is(this->lstm_, 4, 1) && is(mean_lstm_, MEAN_INPUT_DIM, MEAN_OUTPUT_DIM) && is(unc_lstm_, UNC_INPUT_DIM, UNC_OUTPUT_DIM);
   }
+  /** host: the steering network's shape ("lstm_structure") */
+  bool setLSTMStructure(const int* desc, int n)
+  {
+    const bool ok = SUSPENSION::setLSTMStructure(desc, n);
+    this->register_form_ = defaultShapes();
+    return ok;
+  }
+  /** host: the mean (which = 1) or uncertainty (2) network's shape, {H, H + inputs, ..., outputs} ("mean_lstm_structure",
+   *  "unc_lstm_structure"); the input and output sizes are the model's (12 -> 2, 13 -> 5) */
+  bool setNetworkStructure(const int which, const int* desc, const int n)
+  {
+    const int I = which == 1 ? MEAN_INPUT_DIM : UNC_INPUT_DIM, OUT = which == 1 ? MEAN_OUTPUT_DIM : UNC_OUTPUT_DIM;
+    if ((which != 1 && which != 2) || n < 3 || desc[1] != desc[0] + I || desc[n - 1] != OUT)
+      return false;
+    if (!(which == 1 ? mean_lstm_ : unc_lstm_).setStructure(I, desc[0], desc + 1, n - 1))
+      return false;
+    this->register_form_ = defaultShapes();
+    return true;
+  }
+  /** LDS: register form — the 3 x (4 + 4) recurrent values per slot; general form — three LSTMHelper regions
+   *  [parameters | slots x (h, c, activations)] one after the other */
   __host__ __device__ int getGrdSharedSizeBytes() const
   {
-    return 0;
+    return this->register_form_ ? 0 :
+                                  this->lstm_.getGrdSharedSizeBytes() + mean_lstm_.getGrdSharedSizeBytes() +
+                                      unc_lstm_.getGrdSharedSizeBytes();
   }
   __host__ __device__ int getBlkSharedSizeBytes() const
   {
-    return NUM_NETWORKS * 2 * NET_H * (int)sizeof(float);
+    return this->register_form_ ? NUM_NETWORKS * 2 * NET_H * (int)sizeof(float) :
+                                  this->lstm_.getBlkSharedSizeBytes() + mean_lstm_.getBlkSharedSizeBytes() +
+                                      unc_lstm_.getBlkSharedSizeBytes();
+  }
+  /** general form: start of the mean (1) / uncertainty (2) network's region */
+  __device__ inline float* networkRegion(float* theta_s, const int which) const
+  {
+    const int slots = (int)(blockDim.x * blockDim.z);
+    int off = (this->lstm_.getGrdSharedSizeBytes() + slots * this->lstm_.getBlkSharedSizeBytes()) / (int)sizeof(float);
+    if (which == 2)
+      off += (mean_lstm_.getGrdSharedSizeBytes() + slots * mean_lstm_.getBlkSharedSizeBytes()) / (int)sizeof(float);
+    return theta_s + off;
+  }
+  /** general form: one forward pass of `net` living at `region` on the N inputs */
+  template <int N>
+  __device__ inline const float* generalForward(const mppi::LSTMHelper& net, float* region, const float (&input)[N]) const
+  {
+    float* input_loc = net.getInputLocation(region);
+    if (__builtin_amdgcn_workitem_id_y() == 0)
+    {
+#pragma unroll
+      for (int i = 0; i < N; i++)
+        input_loc[i] = input[i];
+    }
+    mppi::lane_sync();
+    return net.forward(nullptr, region);
   }
 
   /** racer_dubins_elevation_lstm_unc.cu:607-618: the parent's (steering state + outputs from the state), then the two
@@ -152,11 +217,19 @@ public:
                                             float dt)
   {
     SUSPENSION::initializeDynamics(state, control, output, theta_s, t_0, dt);
-    float h[NET_H], c[NET_H];
-    MEAN_NET::initialState(mean_lstm_d_, h, c);
-    storeRecurrent(theta_s, h, c, 1);
-    UNC_NET::initialState(unc_lstm_d_, h, c);
-    storeRecurrent(theta_s, h, c, 2);
+    if (this->register_form_)
+    {
+      float h[NET_H], c[NET_H];
+      MEAN_NET::initialState(mean_lstm_d_, h, c);
+      storeRecurrent(theta_s, h, c, 1);
+      UNC_NET::initialState(unc_lstm_d_, h, c);
+      storeRecurrent(theta_s, h, c, 2);
+    }
+    else
+    {
+      mean_lstm_.initialize(networkRegion(theta_s, 1));  // whole-block loads, each ends with a block barrier
+      unc_lstm_.initialize(networkRegion(theta_s, 2));
+    }
   }
 
   /** racer_dubins_elevation_lstm_unc.cu:300-494 (device branch) */
@@ -179,11 +252,22 @@ public:
                               state_der[RDE_S(VEL_X)],
                               state_der[RDE_S(YAW)],
                               0.0f };
-    float o[5], h[NET_H], c[NET_H];
-    loadRecurrent(theta_s, h, c, 2);
-    UNC_NET::forward(unc_lstm_d_, unc_fnn_d_, input, h, c, o);
-    mppi::lane_sync();
-    storeRecurrent(theta_s, h, c, 2);
+    float o[5];
+    if (this->register_form_)
+    {
+      float h[NET_H], c[NET_H];
+      loadRecurrent(theta_s, h, c, 2);
+      UNC_NET::forward(unc_lstm_d_, unc_fnn_d_, input, h, c, o);
+      mppi::lane_sync();
+      storeRecurrent(theta_s, h, c, 2);
+    }
+    else
+    {
+      const float* out = generalForward(unc_lstm_, networkRegion(theta_s, 2), input);
+#pragma unroll
+      for (int i = 0; i < 5; i++)
+        o[i] = out[i];
+    }
     networkOutputsToQ(p, vx, g, speedRegime(vx), o, Q);
   }
 
@@ -219,11 +303,21 @@ public:
                                 xd[RDE_S(VEL_X)],
                                 xd[RDE_S(YAW)],
                                 0.0f };
-      float mean_output[2], h[NET_H], c[NET_H];
-      loadRecurrent(theta_s, h, c, 1);
-      MEAN_NET::forward(mean_lstm_d_, mean_fnn_d_, input, h, c, mean_output);
-      mppi::lane_sync();
-      storeRecurrent(theta_s, h, c, 1);
+      float mean_output[2];
+      if (this->register_form_)
+      {
+        float h[NET_H], c[NET_H];
+        loadRecurrent(theta_s, h, c, 1);
+        MEAN_NET::forward(mean_lstm_d_, mean_fnn_d_, input, h, c, mean_output);
+        mppi::lane_sync();
+        storeRecurrent(theta_s, h, c, 1);
+      }
+      else
+      {
+        const float* out = generalForward(mean_lstm_, networkRegion(theta_s, 1), input);
+        mean_output[0] = out[0];
+        mean_output[1] = out[1];
+      }
       xd[RDE_S(VEL_X)] += mean_output[0];
       xd[RDE_S(YAW)] += mean_output[1];
     }

@@ -743,17 +743,43 @@ struct ModelT : ModelBase
       /* LSTMLSTMHelper(path, "terra/mean_network/") / (…, "terra/uncertainty_network/") (racer_dubins_elevation_lstm_unc.cu:30-33):
        * parameter blobs in the layouts of lstm_helper.hpp / fnn_helper.hpp; "<net>_lstm_state" = [hidden | cell], the
        * per-cycle update of updateFromBuffer (:98-141), written in place */
+      if (name == "mean_lstm_structure" || name == "unc_lstm_structure")
+      {
+        /* another hidden size / output network than the reference's test shapes: {H, H + inputs, ..., outputs} as floats,
+         * given before the weights (the reference sizes the networks from the file, lstm_helper.cu:13-62) */
+        const int which = name[0] == 'm' ? 1 : 2;
+        std::vector<int> desc(count);
+        for (size_t i = 0; i < count; i++)
+          desc[i] = (int)data[i];
+        if (!dyn.setNetworkStructure(which, desc.data(), (int)count))
+        {
+          err = name + ": expected {H, H + inputs, ..., outputs} with the model's input / output sizes (12 -> 2, 13 -> 5)";
+          return MPPI_ERR_INVALID_ARG;
+        }
+        // blobs of the previous shape no longer fit
+        for (int k = 2 * (which - 1); k < 2 * which; k++)
+        {
+          if (extra_net_d[k])
+            (void)hipFree(extra_net_d[k]);
+          extra_net_d[k] = nullptr;
+        }
+        (which == 1 ? dyn.mean_lstm_d_ : dyn.unc_lstm_d_) = nullptr;
+        (which == 1 ? dyn.mean_fnn_d_ : dyn.unc_fnn_d_) = nullptr;
+        (which == 1 ? dyn.mean_lstm_ : dyn.unc_lstm_).weights_d_ = nullptr;
+        (which == 1 ? dyn.mean_lstm_ : dyn.unc_lstm_).output_nn_.theta_d_ = nullptr;
+        return MPPI_OK;
+      }
       const struct
       {
         const char* name;
         int slot;
         size_t count;
-      } nets[6] = { { "mean_lstm_weights", 0, (size_t)DYN_T::MEAN_NET::LSTM_NUM_PARAMS + 2 * DYN_T::NET_H },
-                    { "mean_lstm_output_weights", 1, (size_t)DYN_T::MEAN_NET::FNN_NUM_PARAMS },
-                    { "unc_lstm_weights", 2, (size_t)DYN_T::UNC_NET::LSTM_NUM_PARAMS + 2 * DYN_T::NET_H },
-                    { "unc_lstm_output_weights", 3, (size_t)DYN_T::UNC_NET::FNN_NUM_PARAMS },
-                    { "mean_lstm_state", 0, (size_t)2 * DYN_T::NET_H },
-                    { "unc_lstm_state", 2, (size_t)2 * DYN_T::NET_H } };
+      } nets[6] = { { "mean_lstm_weights", 0, (size_t)dyn.mean_lstm_.getNumParams() },
+                    { "mean_lstm_output_weights", 1, (size_t)dyn.mean_lstm_.output_nn_.NUM_PARAMS },
+                    { "unc_lstm_weights", 2, (size_t)dyn.unc_lstm_.getNumParams() },
+                    { "unc_lstm_output_weights", 3, (size_t)dyn.unc_lstm_.output_nn_.NUM_PARAMS },
+                    { "mean_lstm_state", 0, (size_t)2 * dyn.mean_lstm_.HIDDEN_DIM },
+                    { "unc_lstm_state", 2, (size_t)2 * dyn.unc_lstm_.HIDDEN_DIM } };
       for (int i = 0; i < 6; i++)
       {
         if (name != nets[i].name)
@@ -771,7 +797,7 @@ struct ModelT : ModelBase
             err = "set the network's weights before its state";
             return MPPI_ERR_STATE;
           }
-          const size_t params = (i == 4 ? (size_t)DYN_T::MEAN_NET::LSTM_NUM_PARAMS : (size_t)DYN_T::UNC_NET::LSTM_NUM_PARAMS);
+          const size_t params = (size_t)(i == 4 ? dyn.mean_lstm_.LSTM_NUM_PARAMS : dyn.unc_lstm_.LSTM_NUM_PARAMS);
           hipError_t e = hipMemcpyAsync(blob + params, data, count * sizeof(float), hipMemcpyHostToDevice, stream);
           if (e == hipSuccess)
             e = hipStreamSynchronize(stream);
@@ -783,10 +809,15 @@ struct ModelT : ModelBase
           return MPPI_OK;
         }
         mppi_status st = upload(&extra_net_d[nets[i].slot], data, count, stream, err);
-        dyn.mean_lstm_d_ = extra_net_d[0];
-        dyn.mean_fnn_d_ = extra_net_d[1];
-        dyn.unc_lstm_d_ = extra_net_d[2];
-        dyn.unc_fnn_d_ = extra_net_d[3];
+        // only what was uploaded for the present shapes (a structure blob clears its network's pair)
+        if (nets[i].slot == 0)
+          dyn.mean_lstm_.weights_d_ = dyn.mean_lstm_d_ = extra_net_d[0];
+        else if (nets[i].slot == 1)
+          dyn.mean_lstm_.output_nn_.theta_d_ = dyn.mean_fnn_d_ = extra_net_d[1];
+        else if (nets[i].slot == 2)
+          dyn.unc_lstm_.weights_d_ = dyn.unc_lstm_d_ = extra_net_d[2];
+        else
+          dyn.unc_lstm_.output_nn_.theta_d_ = dyn.unc_fnn_d_ = extra_net_d[3];
         return st;
       }
     }

@@ -1046,10 +1046,26 @@ mppi_status mppi_load_npz(mppi_handle h, const char* kind, const char* path, con
       for (int i = 0; i < H; i++)
         blob.push_back(it != d.end() && (int)it->second.size() == H ? it->second.data[i] : 0.0);
     }
-    MPPI_TRY(setBlobD(h, (blob_stem + "_weights").c_str(), blob, { (int)blob.size() }));
     std::vector<double> out_blob;
     if (!fnnBlobFromNpz(d, prefix + "output/", out_blob, err))
       return fail(h, MPPI_ERR_INVALID_ARG, "mppi_load_npz: " + err);
+    {
+      // the reference sizes the network from the file (LSTMHelper(path, prefix), lstm_helper.cu:13-62): models that take a
+      // "<network>_structure" blob get {H, H + I, output-network layer sizes ...} first; for the others the weight blobs
+      // below are checked against the compiled shape
+      std::vector<double> desc = { (double)H, (double)(H + I) };
+      for (int i = 1;; i++)
+      {
+        auto b = d.find(prefix + "output/dynamics_b" + std::to_string(i));
+        if (b == d.end())
+          break;
+        desc.push_back((double)b->second.size());
+      }
+      const mppi_status st = setBlobD(h, (blob_stem + "_structure").c_str(), desc, { (int)desc.size() });
+      if (st == MPPI_ERR_INVALID_ARG && h->last_error.find("has no blob named") == std::string::npos)
+        return st;  // the model knows the blob and refused this shape
+    }
+    MPPI_TRY(setBlobD(h, (blob_stem + "_weights").c_str(), blob, { (int)blob.size() }));
     return setBlobD(h, (blob_stem + "_output_weights").c_str(), out_blob, { (int)out_blob.size() });
   }
   if (k == "costmap")

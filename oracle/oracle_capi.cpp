@@ -68,6 +68,8 @@ int oracle_set_blob(void* h, const char* name, const float* data, size_t count, 
     auto* m = dynamic_cast<RacerDubinsElevationLSTMUncertainty*>(c->dyn.get());
     if (!m)
       return -1;
+    if (n == "mean_lstm_structure" || n == "unc_lstm_structure")
+      return m->setNetworkStructure(n.rfind("mean", 0) == 0 ? 1 : 2, data, count);
     LSTM& net = (n.rfind("mean", 0) == 0) ? m->mean_net : m->unc_net;
     if (n == "mean_lstm_state" || n == "unc_lstm_state")
     {

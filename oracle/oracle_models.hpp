@@ -1323,6 +1323,19 @@ struct RacerDubinsElevationLSTMUncertainty : RacerDubinsElevationSuspension
     }
     up.use_static_settling = 1;
   }
+  /** another hidden size / output network for the mean (which = 1) or the uncertainty (2) network: {H, H + I, ..., outputs};
+   *  the input and output sizes are the model's (12 -> 2, 13 -> 5) */
+  int setNetworkStructure(int which, const float* desc, size_t n)
+  {
+    const int I = which == 1 ? 12 : 13, OUT = which == 1 ? 2 : 5;
+    if (n < 3 || (int)desc[1] != (int)desc[0] + I || (int)desc[n - 1] != OUT)
+      return -1;
+    std::vector<int> layers;
+    for (size_t i = 1; i < n; i++)
+      layers.push_back((int)desc[i]);
+    (which == 1 ? mean_net : unc_net).setStructure(I, (int)desc[0], layers);
+    return 0;
+  }
   int setParams(const void* pod, size_t n) override
   {
     if (n != sizeof(up))

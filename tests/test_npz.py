@@ -112,24 +112,37 @@ def test_load_npz_lstm_equals_blob_path_and_oracle(gpu, tmp_path, prefix, model_
 
 
 @pytest.mark.gpu
-def test_load_npz_three_networks_of_the_racer_uncertainty_model(gpu, tmp_path):
+@pytest.mark.parametrize("sizes", [((4, 20), (4, 20), (4, 20)), ((4, 20), (6, 10), (5, 12))], ids=["reference-test-shapes", "other-shapes"])
+def test_load_npz_three_networks_of_the_racer_uncertainty_model(gpu, tmp_path, sizes):
     """one archive with the prefixes the reference's RacerDubinsElevationLSTMUncertainty(path) reads (steering/model/,
     terra/mean_network/, terra/uncertainty_network/; racer_dubins_elevation_lstm_unc.cu:30-33) through mppi_load_npz kinds
-    "lstm" / "mean_lstm" / "unc_lstm" == the same networks through the blob path"""
+    "lstm" / "mean_lstm" / "unc_lstm" == the same networks through the blob path.  The loader sizes the networks from the
+    archive as the reference does; other shapes than the reference's test shapes run one lane per rollout"""
     from test_racer_dubins_lstm_unc import uncertainty_cfg
-    nets = {"steering/model/": lstm_npz(seed=1, scale=0.06, I=4, H=4, M=20, OUT=1),
-            "terra/mean_network/": lstm_npz(seed=2, scale=0.06, I=12, H=4, M=20, OUT=2),
-            "terra/uncertainty_network/": lstm_npz(seed=3, scale=0.06, I=13, H=4, M=20, OUT=5)}
+    (hs, ms), (hm, mm), (hu, mu) = sizes
+    nets = {"steering/model/": lstm_npz(seed=1, scale=0.06, I=4, H=hs, M=ms, OUT=1),
+            "terra/mean_network/": lstm_npz(seed=2, scale=0.06, I=12, H=hm, M=mm, OUT=2),
+            "terra/uncertainty_network/": lstm_npz(seed=3, scale=0.06, I=13, H=hu, M=mu, OUT=5)}
     np.savez(tmp_path / "rde.npz", **{pre + k: v for pre, d in nets.items() for k, v in d.items()})
     cfg = uncertainty_cfg(K=512, T=30)
-    for stem, pre in (("lstm", "steering/model/"), ("mean_lstm", "terra/mean_network/"), ("unc_lstm", "terra/uncertainty_network/")):
+    general = sizes != ((4, 20), (4, 20), (4, 20))
+    shape = dict(block_x=64, block_y=1) if general else {}
+    blobs = dict(cfg["blobs"])
+    for stem, pre, (H, M), I, OUT in (("lstm", "steering/model/", sizes[0], 4, 1), ("mean_lstm", "terra/mean_network/", sizes[1], 12, 2),
+                                      ("unc_lstm", "terra/uncertainty_network/", sizes[2], 13, 5)):
         lstm_blob, out_blob = m.lstm_blob_from_npz_dict(nets[pre])
-        cfg["blobs"][stem + "_weights"], cfg["blobs"][stem + "_output_weights"] = lstm_blob, out_blob
+        blobs[stem + "_weights"], blobs[stem + "_output_weights"] = lstm_blob, out_blob
+        if general:
+            blobs[stem + "_structure"] = np.array([H, H + I, M, OUT], np.float32)
+    cfg["blobs"] = dict(sorted(blobs.items(), key=lambda kv: 0 if kv[0].endswith("_structure") else 1))
     eps = host_noise(1, cfg["K"], cfg["T"], 2)
-    a = make_engine(cfg)
+    a = make_engine(cfg, **shape)
     a.injectNoise(eps)
     want = a.rolloutCosts(cfg["x0"], 1)
-    b = make_engine(cfg)
+    # the second engine gets the networks from the archive only: shapes included
+    cfg_b = dict(cfg)
+    cfg_b["blobs"] = {k: v for k, v in cfg["blobs"].items() if "lstm" not in k}
+    b = make_engine(cfg_b, **shape)
     b.loadNpz("lstm", tmp_path / "rde.npz", "steering/model")
     b.loadNpz("mean_lstm", tmp_path / "rde.npz", "terra/mean_network")
     b.loadNpz("unc_lstm", tmp_path / "rde.npz", "terra/uncertainty_network/")

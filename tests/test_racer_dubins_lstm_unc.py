@@ -219,3 +219,68 @@ def test_uncertainty_tube_and_colored_closed_loop(gpu):
         x, _ = eng.modelStep(x, u)
         eng.slideControlSequence(1)
     assert np.isfinite(x).all() and x[S_VEL] > 1.0 and abs(x[S_ROLL]) < 0.5 and abs(x[S_PITCH]) < 0.5
+
+
+def _lstm_sizes(desc, I):
+    H = desc[0]
+    layers = desc[1:]
+    return 4 * H * H + 4 * H * I + 4 * H + 2 * H, sum(layers[i] * layers[i + 1] + layers[i + 1] for i in range(len(layers) - 1))
+
+
+def general_shape_cfg(steering=None, **kw):
+    """the mean / uncertainty networks with other hidden sizes and output networks than the register forms are compiled
+    for (and optionally the steering network too): the model's general form, LSTMHelper's LDS contract"""
+    cfg = uncertainty_cfg(**kw)
+    mean, unc = [6, 18, 10, 2], [5, 18, 12, 7, 5]
+    rng = np.random.default_rng(91)
+    mk = lambda n: rng.uniform(-0.06, 0.06, n).astype(np.float32)  # noqa: E731
+    blobs = {}
+    if steering is not None:
+        ls, lo = _lstm_sizes(steering, 4)
+        blobs["lstm_structure"] = np.array(steering, np.float32)
+        blobs["lstm_weights"], blobs["lstm_output_weights"] = mk(ls), mk(lo)
+    for name, desc, I in (("mean", mean, 12), ("unc", unc, 13)):
+        ls, lo = _lstm_sizes(desc, I)
+        blobs[name + "_lstm_structure"] = np.array(desc, np.float32)
+        blobs[name + "_lstm_weights"], blobs[name + "_lstm_output_weights"] = mk(ls), mk(lo)
+    merged = {k: v for k, v in cfg["blobs"].items() if k not in blobs}
+    merged.update(blobs)
+    # the structure blobs first: they size what the weight blobs are checked against
+    cfg["blobs"] = dict(sorted(merged.items(), key=lambda kv: 0 if kv[0].endswith("_structure") else 1))
+    return cfg
+
+
+def test_oracle_general_network_shapes_run():
+    cfg = general_shape_cfg(K=64, T=20)
+    o = make_oracle(cfg)
+    eps = host_noise(1, cfg["K"], cfg["T"], 2, seed=2)
+    o.vanilla_compute_control(cfg["x0"], 1, eps)
+    assert np.isfinite(o.costs()).all() and np.ptp(o.costs()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("steering,D", [(None, 1), ([6, 10, 12, 1], 1), (None, 2)])
+def test_uncertainty_general_network_shapes_bit_exact(gpu, steering, D):
+    """networks of other shapes than the reference's test shapes (set through "<net>_lstm_structure"): one lane per rollout,
+    the three networks on LSTMHelper's LDS contract; the four-lane block shapes refuse them"""
+    cfg = general_shape_cfg(steering=steering, K=1000, T=40, D=D)
+    eps = host_noise(1, cfg["K"], cfg["T"], 2, seed=6)
+    o = make_oracle(cfg)
+    (o.tube_compute_control if D == 2 else o.vanilla_compute_control)(cfg["x0"], 1, eps)
+    eng = make_engine(cfg, block_x=64, block_y=1)
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    assert np.isfinite(o.costs()).all()
+    assert ulp_diff(eng.getSampledCostSeq(), o.costs()).max() == 0
+    assert np.abs(eng.getControlSeq() - o.control()).max() <= 1e-5
+    if D == 1:
+        assert np.abs(eng.getTargetStateSeq() - o.state_traj()).max() <= 1e-4
+        x = cfg["x0"].copy()
+        u = np.array([0.4, -0.2], np.float32)
+        xe, _ = eng.modelStep(x, u)
+        xo, _ = o.model_step(x, u)
+        assert np.array_equal(xe.view(np.uint32), xo.view(np.uint32))
+        quad = make_engine(cfg)  # the default shape is the four-lane form
+        quad.injectNoise(eps)
+        with pytest.raises(m.MPPIError):
+            quad.computeControl(cfg["x0"], 1)
