@@ -156,6 +156,12 @@ struct ModelBase
   {
     return false;
   }
+  /** the shape is a replicated-lane one that the model's present data rule out (networks of another shape than the
+   *  replicated-lane form is compiled for) */
+  virtual bool fastShapeRefused(int bx, int by, int bz) const
+  {
+    return false;
+  }
   virtual size_t rolloutSharedBytes(int bx, int by, int bz, int T, int D, bool pipeline) = 0;
   /** floats the sampler needs for the sample rows of `blocks` blocks of `slots` rollout slots in HBM (long horizons), 0: the
    *  sampler keeps its rows in LDS only; setGlobalRows(ptr) switches the fused kernel over (nullptr: back to LDS) */
@@ -495,6 +501,12 @@ struct ModelT : ModelBase
   {
     if constexpr (!std::is_void<DYN_FAST_T>::value)
       return bx == 64 && bz == 1 && by == kernels::replicated_lanes<DYN_FAST_T>::value && hasShape(FAST_SHAPES{}, bx, by, bz);
+    return false;
+  }
+  bool fastShapeRefused(int bx, int by, int bz) const override
+  {
+    if constexpr (has_register_form<DYN_T>::value && !std::is_void<DYN_FAST_T>::value)
+      return !dyn.register_form_ && hasShape(FAST_SHAPES{}, bx, by, bz);
     return false;
   }
   template <class FAST = DYN_FAST_T>

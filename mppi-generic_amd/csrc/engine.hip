@@ -919,6 +919,30 @@ mppi_status mppi_set_model_blob(mppi_handle h, const char* name, const float* da
   mppi_status st = h->model->setBlob(name, data, count, dims, ndims, h->stream, err);
   if (st != MPPI_OK)
     return fail(h, st, err);
+  // Networks of another shape than the replicated-lane (four lanes per rollout) form of the model is compiled for: no block
+  // shape was asked for, so move to the registered one-lane shape (same or more rollouts per block: the per-block buffers
+  // stay large enough) instead of refusing the next launch
+  if (h->cfg.block_x == 0 && h->cfg.block_y == 0 && h->cfg.controller != MPPI_CONTROLLER_ROBUST &&
+      h->model->fastShapeRefused(h->bx, h->by, h->bz))
+  {
+    std::vector<int> shapes;
+    h->model->listShapes(shapes);
+    int pick = -1;
+    for (size_t i = 0; i + 2 < shapes.size(); i += 3)
+    {
+      if (shapes[i + 2] != h->bz || shapes[i] < h->bx || h->model->fastShapeRefused(shapes[i], shapes[i + 1], shapes[i + 2]))
+        continue;
+      if (pick < 0 || shapes[i] < shapes[pick])
+        pick = (int)i;
+    }
+    if (pick >= 0)
+    {
+      h->bx = shapes[pick];
+      h->by = shapes[pick + 1];
+      h->pipeline = false;
+      h->num_blocks = (h->K_local + h->bx - 1) / h->bx;
+    }
+  }
   // the LDS request may depend on the blob (network size): re-check it
   const size_t lds = h->cfg.controller == MPPI_CONTROLLER_ROBUST ?
                          h->model->rmppiSharedBytes(h->bx, h->cfg.num_timesteps) :

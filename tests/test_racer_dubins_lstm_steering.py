@@ -211,10 +211,14 @@ def test_lstm_steering_initial_state_and_structure(gpu):
     cfg["blobs"] = dict(sorted(cfg["blobs"].items(), key=lambda kv: 0 if kv[0] == "lstm_structure" else 1))
     o = make_oracle(cfg)
     o.vanilla_compute_control(cfg["x0"], 1, eps)
-    with pytest.raises(m.MPPIError):   # the four-lane form (the default block shape) is compiled for the default network
-        eng = make_engine(cfg)
+    with pytest.raises(m.MPPIError):   # the four-lane form is compiled for the default network: asked for, it refuses
+        eng = make_engine(cfg, block_x=64, block_y=4)
         eng.injectNoise(eps)
         eng.computeControl(cfg["x0"], 1)
+    eng = make_engine(cfg)   # no shape asked for: the default (four lanes) gives way to the one-lane shape
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    assert ulp_diff(eng.getSampledCostSeq(), o.costs()).max() == 0
     eng = make_engine(cfg, block_x=64, block_y=1)
     eng.injectNoise(eps)
     eng.computeControl(cfg["x0"], 1)

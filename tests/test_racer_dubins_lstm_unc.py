@@ -280,7 +280,16 @@ def test_uncertainty_general_network_shapes_bit_exact(gpu, steering, D):
         xe, _ = eng.modelStep(x, u)
         xo, _ = o.model_step(x, u)
         assert np.array_equal(xe.view(np.uint32), xo.view(np.uint32))
-        quad = make_engine(cfg)  # the default shape is the four-lane form
+        quad = make_engine(cfg, block_x=64, block_y=4)  # asked for explicitly, the four-lane form refuses
         quad.injectNoise(eps)
         with pytest.raises(m.MPPIError):
             quad.computeControl(cfg["x0"], 1)
+        auto = make_engine(cfg)  # no shape asked for: the default (four lanes) gives way to the one-lane shape
+        auto.injectNoise(eps)
+        auto.computeControl(cfg["x0"], 1)
+        assert ulp_diff(auto.getSampledCostSeq(), o.costs()).max() == 0
+    else:
+        auto = make_engine(cfg)  # Tube: (32, 4, 2) gives way to (64, 1, 2)
+        auto.injectNoise(eps)
+        auto.computeControl(cfg["x0"], 1)
+        assert ulp_diff(auto.getSampledCostSeq(), o.costs()).max() == 0
