@@ -4,8 +4,8 @@
  * unit r (its four gates) and L1 / 4 neurons of the MLP's hidden layer; the new hidden state and the layer's activations
  * are exchanged with `__shfl` (ds_bpermute), the output layer's L1-term sums run on every replica with scalar-unit weights.
  * The weights a replica needs differ from lane to lane, so they cannot be scalar operands — see LSTMQuadRows below for where
- * they live.  An object of this type is a member of a Dynamics plugin that travels by value, i.e. every lane owns its copy
- * (weights and recurrent state: h of all four units, c of its own).
+ * they live.  An object of this type is a member of a Dynamics plugin that travels by value, i.e. every lane has its own
+ * (its sixteenth of the replica's weights and the recurrent state: h of all four units, c of its own).
  *
  * Arithmetic per value as LSTMHelper / LSTMRegisters / the oracle: k-ordered fma chains (input part, then recurrent part,
  * then bias), det:: activations, new cell state before the new hidden state, MLP on [h ; x].
