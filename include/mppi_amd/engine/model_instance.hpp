@@ -393,6 +393,19 @@ struct ModelT : ModelBase
     }
     return ModelBase::setFeedbackGains(gains, T, accumulate_all_states, stream, err);
   }
+  /** Robust MPPI runs a model with a replicated-lane form on that form only: networks of another shape rule it out */
+  bool rmppiFormUsable(std::string& err) const
+  {
+    if constexpr (has_register_form<DYN_T>::value && !std::is_void<DYN_FAST_T>::value)
+    {
+      if (!dyn.register_form_)
+      {
+        err = "Robust MPPI runs this model on its replicated-lane form, which exists for the default network shapes only";
+        return false;
+      }
+    }
+    return true;
+  }
   size_t rmppiSharedBytes(int bx, int T) override
   {
     if constexpr (RMPPI)
@@ -416,6 +429,8 @@ struct ModelT : ModelBase
     {
       if (!blobsReady(err))
         return MPPI_ERR_STATE;
+      if (!rmppiFormUsable(err))
+        return MPPI_ERR_LAUNCH_SHAPE;
       prepSampler(s);
       constexpr int BX = 64;
       // models with replicated-lane (MFMA) dynamics run both Robust MPPI kernels on them
@@ -482,6 +497,8 @@ struct ModelT : ModelBase
         err = "Robust MPPI needs the DDP feedback gains [T][S][C] (mppi_set_feedback_gains) before it can run";
         return MPPI_ERR_STATE;
       }
+      if (!rmppiFormUsable(err))
+        return MPPI_ERR_LAUNCH_SHAPE;
       prepSampler(s);
       if (bx == 64)
         return launchRMPPIShape<64>(a, stream, err);

@@ -13,6 +13,7 @@
  *
  * The cost is QuadraticCost over the 28 outputs with SKIP_ZERO_COEFF: the model marks the three wheel-force outputs it
  * does not produce with NaN (racer_dubins_elevation.cu:131-139); give them coefficient 0.
+ * Robust MPPI (RMPPI = true): both of its kernels run the four-lanes-per-rollout form.
  */
 #include "mppi_amd/engine/model_registry.hpp"
 #include "mppi_amd/sampling_distributions/gaussian.hpp"
@@ -28,7 +29,7 @@ using RacerElevationModel =
     ModelT<RacerDubinsElevation, ElevationCost, sampling_distributions::GaussianDistribution<RacerDubinsElevationParams>,
            Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/1,
            /* four lanes per rollout: one wheel, one covariance row, one angle each (racer_dubins_elevation.hpp) */
-           RacerDubinsElevationQuad, Shapes<Shape<64, 4, 1>, Shape<64, 4, 2>>, /*PIPELINE=*/true>;
+           RacerDubinsElevationQuad, Shapes<Shape<64, 4, 1>, Shape<64, 4, 2>>, /*PIPELINE=*/true, /*RMPPI=*/true>;
 using RacerElevationColoredModel =
     ModelT<RacerDubinsElevation, ElevationCost, sampling_distributions::ColoredNoiseDistribution<RacerDubinsElevationParams>,
            Shapes<Shape<64, 1, 1>>, /*FIN_BY=*/1, RacerDubinsElevationQuad, Shapes<Shape<64, 4, 1>>, /*PIPELINE=*/true>;

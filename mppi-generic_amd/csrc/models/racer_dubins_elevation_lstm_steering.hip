@@ -15,6 +15,7 @@
  * which the role-pipelined kernel's dynamics waves cannot execute on their own.  For the same reason the trajectory pass after the
  * iterations (finalize kernel) and the single model step run the two-lane contract form (FIN_BY = 2: every thread of
  * the block takes part in initialize()), not the one-lane-of-a-wave form of the analytic models.
+ * Robust MPPI (RMPPI = true): both of its kernels run the four-lanes-per-rollout form.
  */
 #include "mppi_amd/engine/model_registry.hpp"
 #include "mppi_amd/sampling_distributions/gaussian.hpp"
@@ -31,7 +32,7 @@ using RacerLSTMSteeringModel =
            sampling_distributions::GaussianDistribution<RacerDubinsElevationParams>,
            Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/2,
            /* four lanes per rollout: a wheel, a covariance row, a hidden unit and five MLP neurons each */
-           RacerDubinsElevationLSTMSteeringQuad, Shapes<Shape<64, 4, 1>, Shape<64, 4, 2>>, /*PIPELINE=*/false>;
+           RacerDubinsElevationLSTMSteeringQuad, Shapes<Shape<64, 4, 1>, Shape<64, 4, 2>>, /*PIPELINE=*/false, /*RMPPI=*/true>;
 using RacerLSTMSteeringColoredModel =
     ModelT<RacerDubinsElevationLSTMSteering, SteeringCost,
            sampling_distributions::ColoredNoiseDistribution<RacerDubinsElevationParams>, Shapes<Shape<64, 1, 1>>,

@@ -11,6 +11,7 @@
  * (RacerDubinsElevationLSTMUncertaintyQuad: wheels, covariance rows, hidden units and output-network neurons shared out, the
  * mean / uncertainty networks' weights kept once per 16-lane row and fetched with DPP row broadcasts).  BY == 1: one lane per
  * rollout, the three networks on registers with scalar-unit weights (racer_dubins_elevation_lstm_unc.hpp).
+ * Robust MPPI (RMPPI = true): both of its kernels run the four-lanes-per-rollout form.
  */
 #include "mppi_amd/engine/model_registry.hpp"
 #include "mppi_amd/sampling_distributions/gaussian.hpp"
@@ -28,7 +29,7 @@ using RacerUncertaintyModel =
            Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/2,
            /* four lanes per rollout: a wheel, a covariance row, a hidden unit and five output-network neurons of each of the
               three networks per lane */
-           RacerDubinsElevationLSTMUncertaintyQuad, Shapes<Shape<64, 4, 1>, Shape<32, 4, 2>>, /*PIPELINE=*/false>;
+           RacerDubinsElevationLSTMUncertaintyQuad, Shapes<Shape<64, 4, 1>, Shape<32, 4, 2>>, /*PIPELINE=*/false, /*RMPPI=*/true>;
 using RacerUncertaintyColoredModel =
     ModelT<RacerDubinsElevationLSTMUncertainty, UncertaintyCost,
            sampling_distributions::ColoredNoiseDistribution<RacerDubinsElevationUncertaintyParams>, Shapes<Shape<64, 1, 1>>,

@@ -17,6 +17,7 @@
  * 256-thread block keeps the step in registers with room to spare.  BY == 1: one lane per rollout; fused rollout kernel
  * (the LDS fallback of the steering network needs a block barrier in initializeDynamics, see
  * racer_dubins_elevation_lstm_steering.hip).
+ * Robust MPPI (RMPPI = true): both of its kernels run the four-lanes-per-rollout form.
  */
 #include "mppi_amd/engine/model_registry.hpp"
 #include "mppi_amd/sampling_distributions/gaussian.hpp"
@@ -33,7 +34,7 @@ using RacerSuspensionModel =
            sampling_distributions::GaussianDistribution<RacerDubinsElevationSuspensionParams>,
            Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/2,
            /* four lanes per rollout: a wheel, a covariance row, a hidden unit and five MLP neurons each */
-           RacerDubinsElevationSuspensionQuad, Shapes<Shape<64, 4, 1>, Shape<32, 4, 2>>, /*PIPELINE=*/false>;
+           RacerDubinsElevationSuspensionQuad, Shapes<Shape<64, 4, 1>, Shape<32, 4, 2>>, /*PIPELINE=*/false, /*RMPPI=*/true>;
 using RacerSuspensionColoredModel =
     ModelT<RacerDubinsElevationSuspension, SuspensionCost,
            sampling_distributions::ColoredNoiseDistribution<RacerDubinsElevationSuspensionParams>, Shapes<Shape<64, 1, 1>>,

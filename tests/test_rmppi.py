@@ -19,6 +19,15 @@ def _rm_cfg(model="di", K=1024, T=40, num_iters=1):
         cfg = racer_cfg(K=K, T=T, num_iters=num_iters)
         cfg["D"] = 2
         cfg["control_cost_coeff"] = [0.2, 0.1]
+    elif model in ("elevation", "lstm_steering", "suspension", "complete"):
+        from test_racer_dubins_elevation import elevation_cfg
+        from test_racer_dubins_lstm_steering import steering_cfg
+        from test_racer_dubins_lstm_unc import uncertainty_cfg
+        from test_racer_dubins_suspension import suspension_cfg
+        mk = {"elevation": elevation_cfg, "lstm_steering": steering_cfg, "suspension": suspension_cfg, "complete": uncertainty_cfg}
+        cfg = mk[model](K=K, T=T, D=2)
+        cfg["num_iters"] = num_iters
+        cfg["control_cost_coeff"] = [0.2, 0.1]
     elif model in ("autorally", "lstm"):
         # the NN models: Robust MPPI runs them one lane per rollout and system (LDS forward)
         cfg = autorally_cfg(K=K, T=T, num_iters=num_iters) if model == "autorally" else bicycle_lstm_cfg(K=K, T=T, num_iters=num_iters)
@@ -126,7 +135,11 @@ def test_rmppi_rollout_zero_gains_identical_systems():
                                                 ("racer", False, "injected"), ("racer", True, "philox"),
                                                 ("cartpole", False, "injected"), ("cartpole", False, "philox"),
                                                 ("autorally", False, "injected"), ("autorally", True, "philox"),
-                                                ("lstm", False, "injected")])
+                                                ("lstm", False, "injected"),
+                                                ("elevation", False, "injected"), ("elevation", True, "philox"),
+                                                ("lstm_steering", False, "injected"), ("lstm_steering", False, "philox"),
+                                                ("suspension", False, "injected"), ("suspension", True, "philox"),
+                                                ("complete", False, "injected"), ("complete", True, "philox")])
 def test_rmppi_rollout_costs_bit_exact(gpu, model, acc_all, mode):
     cfg = _rm_cfg(model, K=1000, T=37)  # ragged last block, odd horizon
     eng, orc, rob = _make_pair(cfg, thr=40.0, save_samples=True)
@@ -141,7 +154,9 @@ def test_rmppi_rollout_costs_bit_exact(gpu, model, acc_all, mode):
         eng.injectNoise(eps)
     else:
         eps = po.philox_normal(42, 0, K, T, C)
-    x0 = np.stack([cfg["x0"], cfg["x0"] + np.array([0.3, -0.2, 0.1, 0.05, 0.02, 0.01, 0.0], np.float32)[:S]])
+    dx = np.zeros(S, np.float32)
+    dx[:min(S, 7)] = np.array([0.3, -0.2, 0.1, 0.05, 0.02, 0.01, 0.0], np.float32)[:S]
+    x0 = np.stack([cfg["x0"], cfg["x0"] + dx])
     got = eng.rolloutCosts(x0, 2)
     means = np.tile(mean, (2, 1, 1))
     v = orc.set_gaussian_controls(means, eps, 2, 0)
@@ -248,3 +263,22 @@ def test_rmppi_error_paths(gpu):
     with pytest.raises(m.MPPIError) as e:
         v._check(v._lib.mppi_set_feedback_gains(v._h, np.zeros(40, np.float32), 0))
     assert e.value.status == 7
+
+
+@pytest.mark.gpu
+def test_rmppi_refuses_networks_the_four_lane_form_is_not_compiled_for(gpu):
+    """Robust MPPI runs the elevation-map RACER models on their four-lanes-per-rollout form, which exists for the default
+    network shapes: another steering network ("lstm_structure") is an error, not a silent wrong answer"""
+    cfg = _rm_cfg("lstm_steering", K=512, T=12)
+    Hn = 6
+    rng = np.random.default_rng(3)
+    blobs = {k: v for k, v in cfg["blobs"].items() if k.startswith("elevation")}
+    blobs["lstm_structure"] = np.array([Hn, Hn + 4, 12, 1], np.float32)
+    blobs["lstm_weights"] = rng.uniform(-0.4, 0.4, 4 * Hn * Hn + 4 * Hn * 4 + 6 * Hn).astype(np.float32)
+    blobs["lstm_output_weights"] = rng.uniform(-0.4, 0.4, (Hn + 4) * 12 + 12 + 12 + 1).astype(np.float32)
+    cfg["blobs"] = dict(sorted(blobs.items(), key=lambda kv: 0 if kv[0] == "lstm_structure" else 1))
+    eng, _, _ = _make_pair(cfg)
+    eng.setFeedbackGains(_gains(cfg["T"], eng.STATE_DIM, eng.CONTROL_DIM), False)
+    with pytest.raises(m.MPPIError) as e:
+        eng.computeControl(cfg["x0"], 1)
+    assert "default network shapes" in str(e.value)

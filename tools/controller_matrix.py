@@ -27,7 +27,8 @@ MODELS = {
     "racer_dubins_elevation_suspension": lambda: _susp(K=16384, T=100),
     "racer_dubins_elevation_lstm_unc": lambda: _unc(K=16384, T=100),
 }
-ROBUST_MODELS = ("cartpole", "double_integrator", "autorally_nn", "bicycle_slip_lstm", "racer_dubins")
+ROBUST_MODELS = ("cartpole", "double_integrator", "autorally_nn", "bicycle_slip_lstm", "racer_dubins", "racer_dubins_elevation", "racer_dubins_elevation_lstm_steering",
+                 "racer_dubins_elevation_suspension", "racer_dubins_elevation_lstm_unc")
 bad = 0
 for name, mk in MODELS.items():
     for kind in ("vanilla", "tube", "colored", "robust"):
