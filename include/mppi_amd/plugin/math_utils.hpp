@@ -1,5 +1,5 @@
 /**
- * math_utils.hpp — small helpers with the reference's names (reference: include/mppi/utils/math_utils.h:15-110, 738-747).
+ * math_utils.hpp — small helpers with the reference's names (reference: include/mppi/utils/math_utils.h:15-110, 149-156, 738-747).
  */
 #ifndef MPPI_AMD_PLUGIN_MATH_UTILS_HPP_
 #define MPPI_AMD_PLUGIN_MATH_UTILS_HPP_
@@ -32,6 +32,19 @@ inline __host__ __device__ float clamp(float value, float min, float max)
 inline __host__ __device__ float sign(float value)
 {
   return value >= 0 ? 1 : -1;
+}
+/** reference: utils/math_utils.h:90-94 */
+inline __host__ __device__ float linInterp(const float x, const float x_min, const float x_max, const float y_min,
+                                           const float y_max)
+{
+  return (x - x_min) / (x_max - x_min) * (y_max - y_min) + y_min;
+}
+/** |r - centre line| in units of half the track width (reference: utils/math_utils.h:149-156) */
+inline __host__ __device__ float normDistFromCenter(const float r, const float r_in, const float r_out)
+{
+  const float r_center = (r_in + r_out) / 2.0f;
+  const float r_width = r_out - r_in;
+  return fabsf(r - r_center) / (r_width * 0.5f);
 }
 }  // namespace math
 }  // namespace mppi

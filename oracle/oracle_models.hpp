@@ -148,6 +148,50 @@ struct DoubleIntegratorCircleCost : Cost
   }
 };
 
+/**
+ * reference: cost_functions/double_integrator/double_integrator_robust_cost.cu:10-41 — the DEVICE overload (knee at half
+ * the track width with half the crash cost; the host overload's 0.75 / 0.1 constants, :55-56, are never what a rollout
+ * kernel evaluates), utils/math_utils.h:90-94 (linInterp), :149-156 (normDistFromCenter).  powf(x, 2) == x * x.
+ */
+struct DoubleIntegratorRobustCost : DoubleIntegratorCircleCost
+{
+  float computeStateCost(const float* s, int timestep, int* crash) override
+  {
+    float radial_position = s[0] * s[0] + s[1] * s[1];
+    float current_velocity = det::sqrt(s[2] * s[2] + s[3] * s[3]);
+    float current_angular_momentum = s[0] * s[3] - s[1] * s[2];
+    float r = det::sqrt(radial_position), r_in = det::sqrt(params_.inner_path_radius2),
+          r_out = det::sqrt(params_.outer_path_radius2);
+    float r_center = (r_in + r_out) / 2.0f;
+    float r_width = (r_out - r_in);
+    float normalized_dist_from_center = fabsf(r - r_center) / (r_width * 0.5f);
+    float steep_percent_boundary = 0.5f;
+    float steep_cost = 0.5f * params_.crash_cost;
+    float cost = 0;
+    if (normalized_dist_from_center <= steep_percent_boundary)
+    {
+      cost += lin(normalized_dist_from_center, 0, steep_percent_boundary, 0, steep_cost);
+    }
+    if (normalized_dist_from_center > steep_percent_boundary && normalized_dist_from_center <= 1.0f)
+    {
+      cost += lin(normalized_dist_from_center, steep_percent_boundary, 1, steep_cost, params_.crash_cost);
+    }
+    if (normalized_dist_from_center > 1.0f)
+    {
+      cost += params_.crash_cost;
+    }
+    float dv = current_velocity - params_.velocity_desired;
+    float dl = current_angular_momentum - params_.angular_momentum_desired;
+    cost += params_.velocity_cost * (dv * dv);
+    cost += params_.velocity_cost * (dl * dl);
+    return cost;
+  }
+  static float lin(float x, float x_min, float x_max, float y_min, float y_max)
+  {
+    return (x - x_min) / (x_max - x_min) * (y_max - y_min) + y_min;
+  }
+};
+
 /* ------------------------------------------------------------------ AutoRally NN ---------------------------------- */
 /**
  * Fully connected network, device flavour of FNNHelper::forward (utils/nn_helpers/fnn_helper.cu:420-484):
@@ -1531,6 +1575,12 @@ inline bool makeModel(const std::string& name, std::unique_ptr<Dynamics>& dyn, s
   {
     dyn.reset(new CartpoleDynamics());
     cost.reset(new CartpoleQuadraticCost());
+    return true;
+  }
+  if (name == "double_integrator_robust")
+  {
+    dyn.reset(new DoubleIntegratorDynamics());
+    cost.reset(new DoubleIntegratorRobustCost());
     return true;
   }
   if (name == "double_integrator")
