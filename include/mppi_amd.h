@@ -406,6 +406,9 @@ mppi_status mppi_iteration_merge(mppi_handle h);
  * more devices) call mppi_p2p_connect_local(peers[world]) instead — hipIpc does not open a handle of its own process.
  * From then on mppi_optimize / mppi_compute_control use the mailbox; RCCL (mppi_comm_init_rccl) stays the fallback.
  * A merge kernel gives up after 2 s without a peer's record; mppi_get_stats then returns MPPI_ERR_COMM.
+ * Reconnecting: a session begins with mppi_p2p_mailbox_handle (or mppi_p2p_connect_local), which clear the flags and records
+ * of the previous session — sequence numbers restart at 1 — and mppi_p2p_connect closes the mappings it opened before; every
+ * rank of the new session exports / connects before any of them runs its first exchange.
  */
 mppi_status mppi_p2p_mailbox_handle(mppi_handle h, void* out_bytes, size_t capacity, size_t* nbytes);
 mppi_status mppi_p2p_connect(mppi_handle h, const void* handles, size_t stride_bytes);
@@ -448,6 +451,12 @@ mppi_status mppi_philox_normal(uint64_t seed, uint32_t generation, int num_rollo
  * on a stream of its own, i.e. what a kernel boundary costs on this device (MI355X_MICROARCH.md "boundary": ~1.45 us).
  */
 mppi_status mppi_measure_launch_boundary(int device, int n, float* us_per_launch);
+/**
+ * Measurement aid (bench.py's issue floor): nanoseconds per instruction of a wave that is ALONE on its SIMD and runs a chain
+ * of dependent 4-byte v_fmac_f32 — the cheapest VALU instruction; 256 one-wave workgroups, two chain lengths differenced.
+ * A rollout step cannot cost less than its instruction count on the dynamics wave times this interval.
+ */
+mppi_status mppi_measure_issue_interval(int device, float* ns_per_instruction);
 /** elementwise det_math on the device (func ids as oracle_det_eval): host/device bit-parity test hook */
 mppi_status mppi_det_eval(int func, const float* x, float* y, int n, int device);
 

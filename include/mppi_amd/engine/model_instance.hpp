@@ -184,9 +184,15 @@ struct ModelBase
 
 /** fingerprint of the structures a model translation unit and libmppi_amd.so exchange (mppi_register_model refuses a
  *  plugin built against other headers: its kernels would read the argument blocks with the wrong layout) */
+/** bumped BY HAND whenever ModelBase's virtual methods are added, removed or reordered or a field of an argument struct is
+ *  swapped at equal size — changes sizeof() cannot see (a stale plugin would dispatch to the wrong vtable slot).
+ *  3: round 3 (rows-in-HBM / release-flag arguments). */
+#define MPPI_ENGINE_ABI_VERSION 3
+
 constexpr int engineAbiFingerprint()
 {
-  return (int)(sizeof(ModelBase) + 131 * sizeof(kernels::RolloutArgs) + 131 * 131 * sizeof(kernels::FinalizeArgs) +
+  return MPPI_ENGINE_ABI_VERSION * 1000003 +
+         (int)(sizeof(ModelBase) + 131 * sizeof(kernels::RolloutArgs) + 131 * 131 * sizeof(kernels::FinalizeArgs) +
                7 * sizeof(kernels::RMPPIArgs) + 17 * sizeof(kernels::InitEvalArgs) + 31 * sizeof(SamplerLaunchState));
 }
 

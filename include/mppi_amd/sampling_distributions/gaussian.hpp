@@ -508,7 +508,6 @@ public:
                                               const float alpha = 0.0f)
   {
     const int d = distribution_idx >= params_.num_distributions ? 0 : distribution_idx;
-    const float* std_dev = &params_.std_dev[CONTROL_DIM * d];
     float cost = 0.0f;
     constexpr int W = (CONTROL_DIM % 4 == 0) ? 4 : ((CONTROL_DIM % 2 == 0) ? 2 : 1);
     float lane[W];
@@ -518,7 +517,8 @@ public:
       for (int l = 0; l < W; l++)
       {
         const int j = i * W + l;
-        lane[l] += params_.control_cost_coeff[j] * (u_fb[j] * u_fb[j]) / (std_dev[j] * std_dev[j]);
+        const float sd = sigmaValue<false, false>(d, t, j);  // the per-step table when time_specific_std_dev (:579-583)
+        lane[l] += params_.control_cost_coeff[j] * (u_fb[j] * u_fb[j]) / (sd * sd);
       }
     for (int l = 0; l < W; l++)
       cost += lane[l];

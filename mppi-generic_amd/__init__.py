@@ -12,7 +12,7 @@ from .controllers import (MPPI_CONTROLLER_TUBE, MPPI_CONTROLLER_VANILLA, MPPI_NO
                           MPPI_CONTROLLER_COLORED, CartpoleDynamicsParams,
                           CartpoleQuadraticCostParams, DoubleIntegratorParams, DoubleIntegratorCircleCostParams,
                           ARStandardCostParams, RacerDubinsParams, RacerDubinsElevationParams, RacerDubinsSuspensionParams, RacerDubinsUncertaintyParams, QuadraticCostParams28, fnn_blob_from_npz_dict, lstm_blob_from_npz_dict,
-                          det_eval, LSTMLSTMHelper, texture2d_query, npz_read_array, philox_normal, launch_boundary_us, norm_exp, compute_weights, weighted_reduction)
+                          det_eval, LSTMLSTMHelper, texture2d_query, npz_read_array, philox_normal, launch_boundary_us, issue_interval_ns, norm_exp, compute_weights, weighted_reduction)
 from .plant import BasePlant, SimulatedPlant, interpolateControls, interpolateFeedback, interpolateState
 
 __all__ = [

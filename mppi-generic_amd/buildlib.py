@@ -162,8 +162,13 @@ def build(force=False, verbose=False, jobs=None):
     os.makedirs(LIB_DIR, exist_ok=True)
     os.makedirs(BUILD_DIR, exist_ok=True)
     if force:
+        import shutil
         for f in os.listdir(BUILD_DIR):
-            os.remove(os.path.join(BUILD_DIR, f))
+            path = os.path.join(BUILD_DIR, f)
+            if os.path.isdir(path):  # build_variant()'s variant_<tag>/ directories
+                shutil.rmtree(path)
+            else:
+                os.remove(path)
     digest = source_hash()
     hash_cpp = os.path.join(BUILD_DIR, "source_hash.cpp")
     with open(hash_cpp, "w") as f:

@@ -139,6 +139,7 @@ SIGNATURES = {
     "mppi_weighted_reduction": (C.c_int, [_f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
     "mppi_philox_normal": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
     "mppi_measure_launch_boundary": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "mppi_measure_issue_interval": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
     "mppi_det_eval": (C.c_int, [C.c_int, _f32p, _f32p, C.c_int, C.c_int]),
     "mppi_texture2d_query": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, _f32p, C.c_int, C.c_int, _f32p, C.c_int]),
 }

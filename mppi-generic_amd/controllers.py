@@ -698,6 +698,14 @@ def launch_boundary_us(device=0, n=2000):
     return float(out.value)
 
 
+def issue_interval_ns(device=0):
+    """ns per dependent 4-byte VALU instruction of a wave alone on its SIMD (mppi_measure_issue_interval)"""
+    lib = load_library()
+    out = C.c_float()
+    _op_check(lib, lib.mppi_measure_issue_interval(device, C.byref(out)))
+    return float(out.value)
+
+
 def philox_normal(seed, generation, K, T, Cdim, k_begin=0, k_end=None, device=0):
     lib = load_library()
     k_end = K if k_end is None else k_end

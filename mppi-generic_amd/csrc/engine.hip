@@ -941,6 +941,18 @@ mppi_status mppi_set_model_blob(mppi_handle h, const char* name, const float* da
       h->by = shapes[pick + 1];
       h->pipeline = false;
       h->num_blocks = (h->K_local + h->bx - 1) / h->bx;
+      if (h->rows_in_hbm)
+      {  // ceil(K / bx) * bx can GROW with bx (K = 70: 3 x 32 = 96 rows, 2 x 64 = 128): the row buffer follows the shape
+        float* rows = nullptr;
+        const size_t n = h->model->globalRowsFloats(h->num_blocks, h->bx * h->bz, h->cfg.num_timesteps);
+        HIP_TRY(h, hipMalloc((void**)&rows, n * sizeof(float)));
+        HIP_TRY(h, hipMemsetAsync(rows, 0, n * sizeof(float), h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->rows_d)
+          HIP_TRY(h, hipFree(h->rows_d));
+        h->rows_d = rows;
+        h->model->setGlobalRows(h->rows_d);
+      }
     }
   }
   // the LDS request may depend on the blob (network size): re-check it
@@ -2478,12 +2490,32 @@ static mppi_status ensureMailbox(mppi_handle h)
   return MPPI_OK;
 }
 
+/**
+ * A new exchange session starts at sequence number 1 again, and the merge kernel waits for flag == sequence number: flags
+ * and records left by an earlier session (one that ended after 1-3 iterations would match sequence 1 / 2 of the new one)
+ * are cleared here.  Called where a session begins BEFORE a peer of the new session can reach the mailbox: when its IPC
+ * handle is exported (peers map it after that), and by mppi_p2p_connect_local (in-process ranks connect before their first
+ * exchange).
+ */
+static mppi_status resetMailboxSession(mppi_handle h)
+{
+  if (!h->mbox_d || h->xseq == 0)
+    return MPPI_OK;  // fresh (zeroed at allocation) or never used since the last reset
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->mbox_d, 0, h->mbox_bytes, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->xseq = 0;
+  return MPPI_OK;
+}
+
 mppi_status mppi_p2p_mailbox_handle(mppi_handle h, void* out_bytes, size_t capacity, size_t* nbytes)
 {
   CHECK_HANDLE(h);
   if (!out_bytes || capacity < sizeof(hipIpcMemHandle_t))
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_p2p_mailbox_handle: buffer too small (needs 64 bytes)");
   MPPI_TRY(ensureMailbox(h));
+  MPPI_TRY(resetMailboxSession(h));
   hipIpcMemHandle_t ipc;
   hipError_t e = hipIpcGetMemHandle(&ipc, h->mbox_d);
   if (e != hipSuccess && h->mbox_uncached)
@@ -2521,6 +2553,12 @@ mppi_status mppi_p2p_connect(mppi_handle h, const void* handles, size_t stride_b
       h->peer_mbox[p] = h->mbox_d;
       continue;
     }
+    if (h->peer_opened[p] && h->peer_mbox[p])
+    {  // a reconnect: the mapping of the previous session goes first
+      (void)hipIpcCloseMemHandle(h->peer_mbox[p]);
+      h->peer_opened[p] = false;
+      h->peer_mbox[p] = nullptr;
+    }
     hipIpcMemHandle_t ipc;
     memcpy(&ipc, (const char*)handles + (size_t)p * stride_bytes, sizeof(ipc));
     void* ptr = nullptr;
@@ -2543,6 +2581,7 @@ mppi_status mppi_p2p_connect_local(mppi_handle h, const mppi_handle* peers)
   if (!peers)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_p2p_connect_local: null");
   MPPI_TRY(ensureMailbox(h));
+  MPPI_TRY(resetMailboxSession(h));
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   for (int p = 0; p < world; p++)
   {
@@ -2967,6 +3006,70 @@ mppi_status mppi_measure_launch_boundary(int device, int n, float* us_per_launch
   if (e != hipSuccess)
     return opFail("mppi_measure_launch_boundary", e);
   *us_per_launch = ms * 1e3f / (float)n;
+  return MPPI_OK;
+}
+
+extern "C++" {
+/** one wave per workgroup, N_CHAIN dependent v_fmac_f32 (4-byte encoding) per loop trip: what a lone wave pays per
+ *  instruction on its SIMD (~1.9 ns whether or not the instruction depends on its predecessor) */
+template <int N_CHAIN>
+__global__ void __launch_bounds__(64) issueProbeKernel(float* sink, int trips, float a, float b)
+{
+  float x = (float)threadIdx.x * 1e-3f;
+  for (int i = 0; i < trips; i++)
+  {
+#pragma unroll
+    for (int j = 0; j < N_CHAIN; j++)
+      asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+  }
+  if (sink && x == 123.456f)
+    *sink = x;
+}
+}
+mppi_status mppi_measure_issue_interval(int device, float* ns_per_instruction)
+{
+  if (!ns_per_instruction)
+    return MPPI_ERR_INVALID_ARG;
+  MPPI_TRY(opDevice(device));
+  hipStream_t s = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e == hipSuccess)
+    e = hipEventCreate(&a);
+  if (e == hipSuccess)
+    e = hipEventCreate(&b);
+  // two chain lengths, differenced: launch ramp, loop overhead and the tail fall out
+  constexpr int CHAIN = 256;
+  const int trips[2] = { 64, 320 };
+  float ms[2] = { 0.0f, 0.0f };
+  for (int k = 0; k < 2 && e == hipSuccess; k++)
+  {
+    float best = 1e30f;
+    for (int rep = 0; rep < 6 && e == hipSuccess; rep++)
+    {
+      e = hipEventRecord(a, s);
+      hipLaunchKernelGGL((issueProbeKernel<CHAIN>), dim3(256), dim3(64), 0, s, (float*)nullptr, trips[k], 0.999f, 1e-3f);
+      if (e == hipSuccess)
+        e = hipEventRecord(b, s);
+      if (e == hipSuccess)
+        e = hipEventSynchronize(b);
+      float t = 0.0f;
+      if (e == hipSuccess)
+        e = hipEventElapsedTime(&t, a, b);
+      if (rep > 0 && t < best)
+        best = t;
+    }
+    ms[k] = best;
+  }
+  if (a)
+    (void)hipEventDestroy(a);
+  if (b)
+    (void)hipEventDestroy(b);
+  if (s)
+    (void)hipStreamDestroy(s);
+  if (e != hipSuccess)
+    return opFail("mppi_measure_issue_interval", e);
+  *ns_per_instruction = (ms[1] - ms[0]) * 1e6f / (float)((trips[1] - trips[0]) * CHAIN);
   return MPPI_OK;
 }
 

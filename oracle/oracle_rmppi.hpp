@@ -60,10 +60,11 @@ struct DDPFeedback
 };
 
 /** reference: gaussian.cu:571-629 as one thread evaluates it */
-inline float feedbackCost(const GaussianSampler& smp, const float* u_fb, int d, float lambda, float alpha)
+inline float feedbackCost(const GaussianSampler& smp, const float* u_fb, int d, int t, float lambda, float alpha)
 {
   const int C = smp.C;
-  const float* sd = &smp.std_dev[(size_t)d * C];
+  /* gaussian.cu:579-583: std_dev[(d * T + t) * C] when time_specific_std_dev */
+  const float* sd = smp.std_dev_time.empty() ? &smp.std_dev[(size_t)d * C] : &smp.std_dev_time[((size_t)d * smp.T + t) * C];
   float cost = 0.0f;
   const int width = (C % 4 == 0) ? 4 : ((C % 2 == 0) ? 2 : 1);
   if (width > 1)
@@ -157,7 +158,7 @@ inline void rmppiRolloutCosts(Dynamics& dyn, Cost& cost, const GaussianSampler& 
         else
         {
           acc_a[z] += curr_cost + lr;
-          acc_b[z] += curr_cost + feedbackCost(smp, fb_control.data(), z, lambda, alpha);
+          acc_b[z] += curr_cost + feedbackCost(smp, fb_control.data(), z, t, lambda, alpha);
         }
       }
       cur = 1 - cur;

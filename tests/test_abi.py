@@ -71,3 +71,25 @@ def test_hand_written_dpp_instructions_have_no_hazard(lib):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 hazard(s)" in r.stdout and not r.stdout.startswith("0 DPP"), r.stdout
+
+
+def test_committed_isa_step_counts_match_the_sources(lib):
+    """bench.py's issue floor multiplies a STATIC instruction count (profiles/r*_isa_step_counts.json) with issue intervals it
+    measures live: the committed counts must be what the current sources compile to (regenerate with
+    `python tools/isa_step_count.py profiles/r03_isa_step_counts.json` after touching a step loop)"""
+    import glob
+    import json
+    import subprocess
+    import sys
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_isa_step_counts.json")))
+    assert files, "no committed ISA step counts"
+    want = json.load(open(files[-1]))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "isa_step_count.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout)
+    for key, e in want.items():
+        assert "error" not in got.get(key, {"error": 1}), (key, got.get(key))
+        for f in ("loop_instructions", "steps_per_trip", "instructions_per_step", "vector_instructions_per_step"):
+            assert got[key][f] == e[f], "%s.%s: committed %s, sources compile to %s" % (key, f, e[f], got[key][f])
+    assert "double_integrator_robust" in lib.mppi_list_models().decode().split("\n")

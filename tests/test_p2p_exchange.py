@@ -151,3 +151,31 @@ def test_p2p_two_processes_share_the_gpu_through_hipipc(gpu):
     u_full = full.getOptimalControlSeq()[0].reshape(-1)
     assert np.array_equal(us[0], us[1])
     assert np.abs(us[0] - u_full).max() <= 5e-6
+
+
+def test_bench_self_launches_two_ranks_from_plain_python(gpu):
+    """`python3 bench.py --gpus 2` with NO launcher around it (the form the driver used for N = 1) spawns its own ranks,
+    negotiates the exchange, and prints ONE JSON line whose headline is the strong-scaling BASELINE problem with the weak line
+    and the other workload beside it.  Both ranks share this box's one GPU (MPPI_BENCH_DEVICE=0)."""
+    import json
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPPI_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--min-time", "0.05"], capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 20
+    assert out["config"]["global_rollouts"] == 16384 and out["config"]["rollouts_per_gpu"] == 8192
+    assert out["finite"] and out["value"] > 0
+    neg = out["config"]["exchange_negotiation"]
+    assert neg["mode"] in ("p2p", "rccl", "host") and neg["bit_equal_u_across_ranks"] is True
+    assert out["weak"]["global_rollouts"] == 32768 and out["weak"]["value"] > 0
+    for key in ("autorally_strong", "autorally_weak"):
+        assert "error" not in out[key], out[key]
+        assert out[key]["value"] > 0 and out[key]["finite"]
+    assert out["autorally_strong"]["global_rollouts"] == 16384

@@ -168,6 +168,38 @@ def test_rmppi_rollout_costs_bit_exact(gpu, model, acc_all, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model", ["di", "cartpole"])
+def test_rmppi_time_specific_std_dev(gpu, model):
+    """time_specific_std_dev on a Robust handle: setGaussianControls, the likelihood-ratio cost AND the feedback cost read
+    sigma[d][t][c] (gaussian.cu:21-43, :488-493, :579-583) — the feedback cost once kept the scalar sigma (round-2 advice)"""
+    cfg = _rm_cfg(model, K=500, T=29)
+    eng, orc, rob = _make_pair(cfg, thr=40.0, save_samples=True)
+    S, C, T, K = eng.STATE_DIM, eng.CONTROL_DIM, cfg["T"], cfg["K"]
+    sd = (0.4 + 1.2 * np.random.default_rng(5).random((2, T, C))).astype(np.float32)
+    eng.setTimeSpecificStdDev(sd)
+    orc.set_time_specific_std_dev(sd)
+    g = _gains(T, S, C)
+    eng.setFeedbackGains(g)
+    rob.set_gains(g)
+    mean = (0.3 * np.sin(np.arange(T * C, dtype=np.float32) * 0.2)).reshape(T, C)
+    eng.updateImportanceSampler(mean)
+    eps = host_noise(1, K, T, C)[0]
+    eng.injectNoise(eps)
+    x0 = np.stack([cfg["x0"], cfg["x0"] + np.array([0.3, -0.2, 0.1, 0.05], np.float32)[:S]])
+    got = eng.rolloutCosts(x0, 1)
+    means = np.tile(mean, (2, 1, 1))
+    v = orc.set_gaussian_controls(means, eps, 1, 0)
+    want, v_fb = rob.rollout_costs(x0, means, v)
+    assert ulp_diff(got, want).max() == 0
+    assert ulp_diff(eng.getSampledControls(), v_fb).max() == 0
+    # the table matters for the feedback term: with the scalar sigma the real system's costs are different numbers
+    orc.set_time_specific_std_dev(None)
+    v2 = orc.set_gaussian_controls(means, eps, 1, 0)
+    other, _ = rob.rollout_costs(x0, means, v2)
+    assert ulp_diff(got, other).max() > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model,T,block_x", [("autorally", 150, 0), ("di", 37, 32), ("di", 200, 0)])
 def test_rmppi_32_rollout_blocks(gpu, model, T, block_x):
     """horizons whose sample rows for 64 rollouts x 2 systems overflow the 160 KiB of LDS run with (32, 1, 2) blocks
