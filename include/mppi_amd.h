@@ -452,8 +452,8 @@ mppi_status mppi_philox_normal(uint64_t seed, uint32_t generation, int num_rollo
  */
 mppi_status mppi_measure_launch_boundary(int device, int n, float* us_per_launch);
 /**
- * Measurement aid (bench.py's issue floor): nanoseconds per instruction of a wave that is ALONE on its SIMD and runs a chain
- * of dependent 4-byte v_fmac_f32 — the cheapest VALU instruction; 256 one-wave workgroups, two chain lengths differenced.
+ * Measurement aid (bench.py's issue floor): nanoseconds per instruction of a wave that is ALONE on its SIMD and issues 4-byte
+ * v_fmac_f32 on eight independent accumulators — the cheapest VALU stream; 256 one-wave workgroups, two lengths differenced.
  * A rollout step cannot cost less than its instruction count on the dynamics wave times this interval.
  */
 mppi_status mppi_measure_issue_interval(int device, float* ns_per_instruction);

@@ -415,6 +415,94 @@ MPPI_HD static inline void tanh2(const float xa, const float xb, float* ra, floa
 #endif
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+/**
+ * tanh of NP packed pairs, evaluated in LOCKSTEP: every Horner / Newton step is issued for all pairs (and for the P and
+ * Q polynomials alternately) before the next step.  Same operations per element as tanh() — the results are bit-identical —
+ * but no two consecutive instructions depend on each other.  On gfx950 a packed-fp32 result may not be read by the very
+ * next instruction: the compiler fills that wait state with an `s_nop 0`, and a wave that is alone on its SIMD pays an
+ * issue slot for it (engine.hip's issue probe: 3.4 ns per dependent v_fmac + s_nop pair against 1.7 ns per independent
+ * v_fmac).  Evaluated pair after pair, the Newton-Raphson tail of every tanh2() is such a chain: 82 s_nop per AutoRally
+ * step.  (Round 2 tried this form and saw no gain — the cost waves' relay chain was as long as the dynamics waves then and
+ * hid it; see rollout_pipeline_kernel.hpp.)
+ */
+template <int NP>
+__device__ inline void tanh_pairs(float (&v)[2 * NP])
+{
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define MPPI_DET_PKFMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
+#define MPPI_DET_SPLAT(c) (f32x2{ (c), (c) })
+#define MPPI_DET_ALL for (int k = 0; k < NP; k++)
+  f32x2 x[NP], xc[NP], x2[NP], p[NP], q[NP], r[NP], y[NP];
+#pragma unroll
+  MPPI_DET_ALL
+  {
+    x[k] = f32x2{ v[2 * k], v[2 * k + 1] };
+    xc[k].x = fminf(fmaxf(x[k].x, -7.90531110763549805f), 7.90531110763549805f);
+    xc[k].y = fminf(fmaxf(x[k].y, -7.90531110763549805f), 7.90531110763549805f);
+  }
+#pragma unroll
+  MPPI_DET_ALL x2[k] = xc[k] * xc[k];
+#pragma unroll
+  MPPI_DET_ALL
+  {
+    p[k] = MPPI_DET_PKFMA(x2[k], MPPI_DET_SPLAT(-2.76076847742355e-16f), MPPI_DET_SPLAT(2.00018790482477e-13f));
+    q[k] = MPPI_DET_PKFMA(x2[k], MPPI_DET_SPLAT(1.19825839466702e-06f), MPPI_DET_SPLAT(1.18534705686654e-04f));
+  }
+#pragma unroll
+  MPPI_DET_ALL
+  {
+    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(-8.60467152213735e-11f));
+    q[k] = MPPI_DET_PKFMA(x2[k], q[k], MPPI_DET_SPLAT(2.26843463243900e-03f));
+  }
+#pragma unroll
+  MPPI_DET_ALL
+  {
+    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(5.12229709037114e-08f));
+    q[k] = MPPI_DET_PKFMA(x2[k], q[k], MPPI_DET_SPLAT(4.89352518554385e-03f));
+  }
+#pragma unroll
+  MPPI_DET_ALL
+  {
+    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(1.48572235717979e-05f));
+    r[k] = f32x2{ __builtin_amdgcn_rcpf(q[k].x), __builtin_amdgcn_rcpf(q[k].y) };
+  }
+#pragma unroll
+  MPPI_DET_ALL
+  {
+    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(6.37261928875436e-04f));
+    y[k] = MPPI_DET_PKFMA(-q[k], r[k], MPPI_DET_SPLAT(1.0f));  // e
+  }
+#pragma unroll
+  MPPI_DET_ALL
+  {
+    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(4.89352455891786e-03f));
+    r[k] = MPPI_DET_PKFMA(y[k], r[k], r[k]);
+  }
+#pragma unroll
+  MPPI_DET_ALL p[k] = xc[k] * p[k];
+#pragma unroll
+  MPPI_DET_ALL y[k] = p[k] * r[k];
+#pragma unroll
+  MPPI_DET_ALL x2[k] = MPPI_DET_PKFMA(-q[k], y[k], p[k]);  // x2 is free: the residual
+#pragma unroll
+  MPPI_DET_ALL y[k] = MPPI_DET_PKFMA(x2[k], r[k], y[k]);
+#pragma unroll
+  MPPI_DET_ALL x2[k] = MPPI_DET_PKFMA(-q[k], y[k], p[k]);
+#pragma unroll
+  MPPI_DET_ALL y[k] = MPPI_DET_PKFMA(x2[k], r[k], y[k]);
+#pragma unroll
+  MPPI_DET_ALL
+  {
+    v[2 * k] = (fabs(x[k].x) >= 1.220703125e-4f) ? y[k].x : x[k].x;
+    v[2 * k + 1] = (fabs(x[k].y) >= 1.220703125e-4f) ? y[k].y : x[k].y;
+  }
+#undef MPPI_DET_ALL
+#undef MPPI_DET_PKFMA
+#undef MPPI_DET_SPLAT
+}
+#endif
+
 /** tanh of N values in place, pairwise through tanh2() */
 template <int N>
 MPPI_HD static inline void tanh_n(float (&v)[N])
@@ -424,6 +512,32 @@ MPPI_HD static inline void tanh_n(float (&v)[N])
     tanh2(v[i], v[i + 1], &v[i], &v[i + 1]);
   if (N & 1)
     v[N - 1] = tanh(v[N - 1]);
+}
+
+/** tanh of N values in place with the packed pairs evaluated in lockstep on the device (tanh_pairs): the same bits as
+ *  tanh_n, more live registers (7 pair-registers per pair), no dependent back-to-back packed instructions */
+template <int N>
+MPPI_HD static inline void tanh_n_lockstep(float (&v)[N])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (N >= 4)
+  {
+    float w[2 * (N / 2)];
+#pragma unroll
+    for (int i = 0; i < 2 * (N / 2); i++)
+      w[i] = v[i];
+    tanh_pairs<N / 2>(w);
+#pragma unroll
+    for (int i = 0; i < 2 * (N / 2); i++)
+      v[i] = w[i];
+    if (N & 1)
+      v[N - 1] = tanh(v[N - 1]);
+  }
+  else
+    tanh_n<N>(v);
+#else
+  tanh_n<N>(v);
+#endif
 }
 
 /** Device flavour of the reference's sigmoid (utils/activation_functions.cuh:49-59): (1 + tanh(x/2))/2. */
@@ -440,6 +554,19 @@ MPPI_HD static inline void sigmoid_n(float (&v)[N])
   for (int i = 0; i < N; i++)
     v[i] = v[i] / 2.0f;
   tanh_n<N>(v);
+#pragma unroll
+  for (int i = 0; i < N; i++)
+    v[i] = (1.0f + v[i]) / 2.0f;
+}
+
+/** sigmoid_n with the tanh evaluated in lockstep (tanh_n_lockstep): the same bits */
+template <int N>
+MPPI_HD static inline void sigmoid_n_lockstep(float (&v)[N])
+{
+#pragma unroll
+  for (int i = 0; i < N; i++)
+    v[i] = v[i] / 2.0f;
+  tanh_n_lockstep<N>(v);
 #pragma unroll
   for (int i = 0; i < N; i++)
     v[i] = (1.0f + v[i]) / 2.0f;

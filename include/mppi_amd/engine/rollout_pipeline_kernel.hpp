@@ -91,6 +91,38 @@ __device__ inline void pipePublish(lds_counter_t ctr, const int value, const int
     *ctr = value;
 }
 
+/* ---- A/B instrumentation (tools/pipe_timing.py; never defined in a product build): where the role waves of
+ * rolloutPipelineRepKernel spend their time.  Every wave of the first PIPE_TIMING_BLOCKS blocks accumulates s_memtime ticks
+ * (constant 100 MHz on gfx950: 10 ns — coarse per event, unbiased over the hundreds of events of a launch) per category. */
+#if defined(MPPI_PIPE_TIMING)
+constexpr int PIPE_TIMING_BLOCKS = 8, PIPE_TIMING_WAVES = 16, PIPE_TIMING_SLOTS = 8;
+static __device__ unsigned long long g_pipe_timing[PIPE_TIMING_BLOCKS * PIPE_TIMING_WAVES * PIPE_TIMING_SLOTS];
+struct PipeTimer
+{
+  unsigned long long acc[PIPE_TIMING_SLOTS] = {};
+  unsigned long long t0 = 0;
+  __device__ inline void start()
+  {
+    t0 = __builtin_amdgcn_s_memtime();
+  }
+  __device__ inline void stop(const int slot)
+  {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    acc[slot] += t1 - t0;
+    t0 = t1;
+  }
+  __device__ inline void flush(const int block, const int wave, const int lane) const
+  {
+    if (block < PIPE_TIMING_BLOCKS && wave < PIPE_TIMING_WAVES && lane == 0)
+      for (int i = 0; i < PIPE_TIMING_SLOTS; i++)
+        g_pipe_timing[(block * PIPE_TIMING_WAVES + wave) * PIPE_TIMING_SLOTS + i] = acc[i];
+  }
+};
+#define PIPE_T(x) x
+#else
+#define PIPE_T(x)
+#endif
+
 /** sampler waves of blocks that hold ONE set of role waves (BZ == 1, or the folded Tube variant): the draw (Philox rounds
  *  + two Box-Muller pairs per quad, ~320 dependent instructions) is as long as the dynamics of four cart-pole steps, and a
  *  block of three waves leaves the CU's fourth SIMD idle — a second sampler wave taking alternate trips is free */
@@ -414,11 +446,14 @@ __host__ __device__ inline int samplerGrdBytes(const SAMPLING_T* smp)
   return ((smp->getGrdSharedSizeBytes() + 15) / 16) * 16;
 }
 
-/** helper waves of rolloutPipelineRepKernel: a block of REP dynamics waves puts one on each SIMD of the CU; two sampler
- *  waves (alternate trips) and two cost waves (alternate step pairs, see the kernel) give every SIMD one helper of about
- *  half a role instead of loading two SIMDs with a whole role each */
-constexpr int PIPE_REP_SAMPLERS = 2;
-constexpr int PIPE_REP_COSTS = 2;
+/** helper waves of rolloutPipelineRepKernel: a block of REP = 4 dynamics waves puts one on each SIMD of the CU and every SIMD
+ *  gets one helper wave next to it.  The SIMD is the unit that saturates (measured with the in-kernel timers of
+ *  tools/pipe_timing.py, round 3: fp32 MFMA and fp32 VALU share the SIMD's multipliers, their cycles ADD whichever wave
+ *  issues them), so the helper work is dealt so that the four SIMDs carry about the same: per step and block of 64 rollouts
+ *  the cost role is ~1550 issue cycles (ARStandardCost), the sampler role ~480 — ONE sampler wave and THREE cost waves
+ *  (~500 cycles per SIMD and step each) instead of two and two (240 / 775: the SIMDs hosting a cost wave set the pace). */
+constexpr int PIPE_REP_SAMPLERS = 1;
+constexpr int PIPE_REP_COSTS = 3;
 
 template <class DYN_T, class COST_T, class SAMPLING_T>
 __host__ inline size_t pipelineRepSharedBytes(const DYN_T& dyn, const COST_T& cost, const SAMPLING_T& smp, int ring)
@@ -466,10 +501,9 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
   static_assert(REP > 1 && 64 % REP == 0, "this variant is for replicated-lane dynamics");
   constexpr int DW = BX * REP / 64;  // dynamics waves
   constexpr int NS = PIPE_REP_SAMPLERS, NC = PIPE_REP_COSTS;
-  // wave order: dynamics 0 .. DW-1, then sampler 0, cost 0, sampler 1, cost 1: with the waves of a workgroup dealt to
-  // the CU's four SIMDs in turn, every SIMD gets one dynamics wave and one helper
+  // wave order: dynamics 0 .. DW-1, then the sampler(s), then the cost waves: with the waves of a workgroup dealt to the
+  // CU's four SIMDs in turn, every SIMD gets one dynamics wave and one helper
   constexpr int NWAVES = DW + NS + NC;
-  static_assert(NS == 2 && NC == 2, "helper wave order below");
   constexpr int NTHREADS = 64 * NWAVES;
   constexpr int PER_WAVE = 64 / REP;
   __builtin_assume(__builtin_amdgcn_workgroup_size_x() == NTHREADS);
@@ -490,8 +524,8 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
   const int wave = __builtin_amdgcn_readfirstlane(tid_x >> 6);  // wave-uniform
   const int lane = tid_x & 63;
   const bool is_dyn = wave < DW;
-  const bool is_sampler = !is_dyn && ((wave - DW) & 1) == 0;
-  const int helper_id = is_dyn ? 0 : (wave - DW) >> 1;  // which of the two samplers / cost waves
+  const bool is_sampler = !is_dyn && wave < DW + NS;
+  const int helper_id = is_dyn ? 0 : (is_sampler ? wave - DW : wave - DW - NS);  // which of the samplers / cost waves
   // rollout slot of this thread: dynamics waves carry PER_WAVE rollouts x REP lanes, the other two one lane per rollout
   const int thread_idx = is_dyn ? wave * PER_WAVE + (lane % PER_WAVE) : lane;
   const int rep_lane = is_dyn ? lane / PER_WAVE : 0;
@@ -557,6 +591,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
     // sampler s takes trips s, s + NS, ...
     constexpr int QUADS = STEPS * C / 4;
     lds_counter_t smp_prog = counters + 4 * (DW + helper_id);
+    PIPE_T(PipeTimer tm; tm.start();)
     for (int t = STEPS * helper_id; t < num_timesteps; t += STEPS * NS)
     {
       float zq[4 * QUADS];
@@ -582,6 +617,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
       }
       pipePublish(smp_prog, min(t + STEPS, num_timesteps), lane);
     }
+    PIPE_T(tm.stop(0); tm.flush(block_idx, wave, lane);)  // slot 0: the whole sampler loop (it never waits)
   }
   else if (is_dyn)
   {
@@ -616,19 +652,27 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
       seen_smp[q] = 0;
     // the pair (t, t + 1) lies inside one sampler trip (STEPS is even): wait for the sampler that owns the trip
     auto wait_samples = [&](const int t, const int need) {
-      const int owner = (t / STEPS) % NS;
-      if (owner == 0)
+      if constexpr (NS == 1)
         pipeWait(counters + 4 * DW, need, seen_smp[0]);
       else
-        pipeWait(counters + 4 * (DW + 1), need, seen_smp[1]);
+      {
+        const int owner = (t / STEPS) % NS;
+        if (owner == 0)
+          pipeWait(counters + 4 * DW, need, seen_smp[0]);
+        else
+          pipeWait(counters + 4 * (DW + 1), need, seen_smp[NS - 1]);
+      }
     };
     int t = 0;
     // full pairs of steps as one basic block (see rolloutPipelineKernel): lets the scheduler overlap the second step's
     // independent work with the first step's MFMA chains
+    PIPE_T(PipeTimer tm; tm.start();)
     for (; t + 1 < num_timesteps; t += 2)
     {
       wait_samples(t, t + 2);
+      PIPE_T(tm.stop(1);)  // slot 1: waiting for the sampler
       pipeWait(cost_prog, t + 2 - ring_steps, seen_cost);
+      PIPE_T(tm.stop(2);)  // slot 2: waiting for the cost waves (ring back-pressure)
       float ubuf[2 * C];
 #pragma unroll
       for (int j = 0; j < 2 * C; j++)
@@ -636,7 +680,9 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
       dyn_step(x, x_next, t, &ubuf[0]);
       dyn_step(x_next, x, t + 1, &ubuf[C]);
       pipePublish(my_prog, t + 2, lane);
+      PIPE_T(tm.stop(0);)  // slot 0: two steps of work
     }
+    PIPE_T(tm.flush(block_idx, wave, lane);)
     if (t < num_timesteps)
     {
       wait_samples(t, num_timesteps);
@@ -657,12 +703,16 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
     // A private copy whose words are pinned to VGPRs (which this wave has to spare) takes the parameters out of that
     // competition; every lane holds the same values, the arithmetic is unchanged.
     //
-    // Two cost waves take alternate PAIRS of steps.  The running cost is a sum in step order and the plugin's status
-    // word (crash flags) threads through the steps, so a pair can only be evaluated after the one before it: the waves
-    // do not run concurrently, they RELAY — each finishes its pair, leaves the running cost and the status of its 64
-    // rollouts in LDS and publishes cost_prog; the other picks them up.  The point is where the instructions issue: each
-    // of the two SIMDs hosting a cost wave carries half the cost role next to its dynamics wave (the block finishes
-    // with its slowest dynamics wave), and the outputs of a wave's next pair are fetched while it waits for its turn.
+    // NC cost waves take the PAIRS of steps in turn.  The running cost is a sum in step order and the plugin's status word
+    // (crash flags) threads through the steps, so a pair's result can only be FINAL after the pair before it — but almost
+    // all of a pair's work (map lookups, trigonometry, the terms of the sum) does not wait for that: the wave evaluates its
+    // pair AHEAD of its turn with the status it last saw (its own result NC pairs ago), the waves therefore work
+    // concurrently, and what is left for the turn itself — the RELAY: running cost and status of the 64 rollouts handed on
+    // in LDS — is two additions.  Only when the status some rollout arrives with differs from the guess (a crash flag
+    // raised during the NC - 1 pairs in between) is the pair evaluated again, now with the true status, for the whole wave:
+    // same plugin calls with the same inputs as the in-order evaluation, so the costs are the same bits.
+    // (Round 2 evaluated inside the relay: the in-kernel timers showed that chain — 2 x 3100 cycles per pair — busy for
+    // the whole launch, as long as the dynamics waves themselves.)
     COST_T costs_v = *costs;
     vgprResident(costs_v);
     COST_T* costs_w = &costs_v;
@@ -670,12 +720,15 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
 #pragma unroll
     for (int w = 0; w < DW; w++)
       seen_dyn[w] = 0;
+    int status_guess = 0;  // the status this wave expects its next pair to start from
+    PIPE_T(PipeTimer tm; tm.start();)
     for (int t = 2 * helper_id; t < num_timesteps; t += 2 * NC)
     {
       const int hi = min(t + 2, num_timesteps);
 #pragma unroll
       for (int w = 0; w < DW; w++)
         pipeWait(counters + 4 * w, hi, seen_dyn[w]);
+      PIPE_T(tm.stop(1);)  // slot 1: waiting for the dynamics waves
       float yb[2][O], ub[2][C];
 #pragma unroll
       for (int q = 0; q < 2; q++)
@@ -689,24 +742,43 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
         for (int i = 0; i < C; i++)
           ub[q][i] = row[tt * C + i];
       }
+      PIPE_T(tm.stop(3);)  // slot 3: fetching outputs / controls of the pair
+      float cq[2] = { 0.0f, 0.0f };
+      auto evaluate = [&](int status) {
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+        {
+          if (t + q < num_timesteps)
+            cq[q] = costs_w->computeRunningCost(yb[q], ub[q], t + q, theta_c_shared, &status) +
+                    sampling->computeLikelihoodRatioCost(ub[q], theta_d_shared, global_idx, t + q, 0, args.lambda, args.alpha);
+        }
+        return status;
+      };
+      int status_out = evaluate(status_guess);
+      PIPE_T(tm.stop(0);)  // slot 0: the pair's cost evaluation, ahead of the relay
       if (t > 0)
       {
         pipeWait(cost_prog, t, seen_cost);
         running_cost = relay_cost[lane];
         crash_status = relay_status[lane];
       }
-#pragma unroll
-      for (int q = 0; q < 2; q++)
-      {
-        if (t + q < num_timesteps)
-          running_cost += costs_w->computeRunningCost(yb[q], ub[q], t + q, theta_c_shared, &crash_status) +
-                          sampling->computeLikelihoodRatioCost(ub[q], theta_d_shared, global_idx, t + q, 0, args.lambda,
-                                                               args.alpha);
+      PIPE_T(tm.stop(2);)  // slot 2: waiting for the relay
+      if (__builtin_amdgcn_ballot_w64(crash_status != status_guess) != 0ull)
+      {  // wave-uniform: some rollout's status changed in between
+        status_out = evaluate(crash_status);
+        PIPE_T(tm.stop(4);)  // slot 4: re-evaluation inside the relay
       }
+      running_cost += cq[0];
+      if (t + 1 < num_timesteps)
+        running_cost += cq[1];
+      crash_status = status_out;
+      status_guess = status_out;
       relay_cost[lane] = running_cost;
       relay_status[lane] = crash_status;
       pipePublish(cost_prog, hi, lane);
+      PIPE_T(tm.stop(5);)  // slot 5: the relay itself
     }
+    PIPE_T(tm.flush(block_idx, wave, lane);)
   }
   __syncthreads();
 

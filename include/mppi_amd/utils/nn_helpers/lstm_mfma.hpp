@@ -153,8 +153,11 @@ struct LSTMMfma
       sg[8 + i] = acc[2][i] + bg[2][i];
       gc[i] = acc[3][i] + bg[3][i];
     }
-    mppi::det::sigmoid_n<12>(sg);
-    mppi::det::tanh_n<4>(gc);
+    // lockstep evaluation (det_math.h: tanh_pairs): no dependent back-to-back packed instructions, hence none of the
+    // s_nop 0 a lone wave pays an issue slot for (LSTM K=65536, T=200: 1653 -> 1531 us per launch, with the colored-noise
+    // sampler 2006 -> 1882 us; A/B in one session)
+    mppi::det::sigmoid_n_lockstep<12>(sg);
+    mppi::det::tanh_n_lockstep<4>(gc);
     float hn[4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -164,7 +167,7 @@ struct LSTMMfma
       c[i] = in_part + keep_part;
       hn[i] = c[i];
     }
-    mppi::det::tanh_n<4>(hn);
+    mppi::det::tanh_n_lockstep<4>(hn);
 #pragma unroll
     for (int i = 0; i < 4; i++)
       hn[i] = hn[i] * sg[8 + i];
@@ -195,7 +198,7 @@ struct LSTMMfma
 #pragma unroll
         for (int i = 0; i < 4; i++)
           v[4 * rb + i] = a[rb][i] + b1[rb][i];
-      mppi::det::tanh_n<RB_M * 4>(v);
+      mppi::det::tanh_n_lockstep<RB_M * 4>(v);
 #pragma unroll
       for (int rb = 0; rb < RB_M; rb++)
       {

@@ -164,7 +164,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB
+    """the library load_library() opens: the in-tree build, or the experimental build MPPI_AMD_LIB names (tools/ A/B runs)"""
+    return os.environ.get("MPPI_AMD_LIB") or _build.LIB
 
 
 def load_library(build_if_missing=True):

@@ -30,3 +30,18 @@ using ARModel = ModelT<ARModelDyn, ARStandardCost, ARSampler,
                        /*PIPELINE=*/false, /*RMPPI=*/true>;  // Robust MPPI runs on the MFMA forward too
 /* default (64, 4): MFMA variant, 64 rollouts x 4 lanes = 4 waves, one per SIMD of a CU */
 MPPI_REGISTER_MODEL("autorally_nn", MPPI_SAMPLER_GAUSSIAN, ARModel, 64, 4)
+
+#if defined(MPPI_PIPE_TIMING)
+/* A/B instrumentation read-back (tools/pipe_timing.py): ticks[blocks][waves][slots] of the last pipelined launch */
+extern "C" int mppi_debug_read_pipe_timing(unsigned long long* out, int capacity)
+{
+  constexpr int N = kernels::PIPE_TIMING_BLOCKS * kernels::PIPE_TIMING_WAVES * kernels::PIPE_TIMING_SLOTS;
+  if (!out || capacity < N)
+    return -N;
+  if (hipDeviceSynchronize() != hipSuccess)
+    return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(kernels::g_pipe_timing), sizeof(unsigned long long) * N) != hipSuccess)
+    return -2;
+  return N;
+}
+#endif

@@ -87,6 +87,8 @@ def _closed_loop(cfg, name, seed=42, steps=STEPS, inject=False):
         sync.slideControlSequence(1)
         x, _ = orc.model_step(x, u_o[0])
         orc.vanilla_slide(1)
+    sync.close()  # leave no stream behind: the multi-rank tests need the hardware queues
+    free.close()
     assert drift_u[0] <= U_TOL
     rep = {"steps": steps, "K": K, "T": T, "resynchronised_worst_u": worst_sync,
            "free_running_u_linf": {"step1": drift_u[0], "step10": drift_u[min(9, steps - 1)],

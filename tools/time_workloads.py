@@ -34,14 +34,15 @@ if "cartpole" in which:
     run("cartpole", cartpole_cfg(K=16384, T=100), [(64, 1, 1), (64, 1, 2), (32, 1)])
     run("cartpole", cartpole_cfg(K=2048, T=100), [(64, 1)])
 if "autorally" in which:
-    run("autorally", autorally_cfg(K=16384, T=150, lambda_=1.0), [(64, 4, 1), (64, 4, 2), (32, 4), (8, 16)], n=30)
+    # (0, 0, v): the model's default shape — (64, 4), or (64, 8) in the eight-lanes-per-rollout A/B build
+    run("autorally", autorally_cfg(K=16384, T=150, lambda_=1.0), [(0, 0, 1), (0, 0, 2), (32, 4), (32, 8)], n=30)
 if "di" in which:
     run("di-tube", di_cfg(K=8192, T=150, tube=True), [(64, 1, 1), (0, 0, 0), (32, 1, 2)])
 if "lstm" in which:
     cfg = bicycle_lstm_cfg(K=65536, T=200, lambda_=1.0)
-    run("lstm", cfg, [(64, 4, 1), (64, 4, 2), (32, 4)], n=10)
+    run("lstm", cfg, [(0, 0, 1), (0, 0, 2)], n=10)
     cfg["colored"] = ([1.0, 1.0], 0.97, 0.0)
-    run("lstm+colored", cfg, [(64, 4, 1), (64, 4, 2), (32, 4)], n=10)
+    run("lstm+colored", cfg, [(0, 0, 1), (0, 0, 2)], n=10)
     cfg = cartpole_cfg(K=16384, T=100)
     cfg["colored"] = ([1.0], 0.97, 0.0)
     run("cartpole+colored", cfg, [(64, 1, 1), (64, 1, 2)], n=50)
