@@ -1,0 +1,5 @@
+/* forwarding header: the reference's include path (include/mppi/dynamics/racer_dubins/racer_dubins.cuh) -> this engine's header.  Paths only. */
+#ifndef MPPI_FWD_DYNAMICS_RACER_DUBINS_RACER_DUBINS_CUH
+#define MPPI_FWD_DYNAMICS_RACER_DUBINS_RACER_DUBINS_CUH
+#include "mppi_amd/dynamics/racer_dubins/racer_dubins.hpp"
+#endif

@@ -63,4 +63,54 @@ public:
   }
 };
 }  // namespace mppi
+
+#include <vector>
+
+/**
+ * Host-side holder with the reference's name and constructor (feedback_controllers/DDP/ddp.cuh:62-140:
+ * DDPFeedback<DYN_T, NUM_TIMESTEPS>(model, dt)), so that a caller's `new DDPFeedback<Dyn, T>(model, dt)` and the FB_T
+ * template argument of the controller classes keep compiling.  The reference's class also OWNS the DDP / iLQR solver that
+ * produces the gains (ddp/ddp.h, host Eigen code, out of scope: SURVEY.md §2); here the gains are handed in —
+ * setFeedbackGains(K[T][S][C]) — and the controller uploads them (mppi_set_feedback_gains) before its next computeControl.
+ */
+template <class DYN_T, int NUM_TIMESTEPS>
+class DDPFeedback
+{
+public:
+  static const int FB_TIMESTEPS = NUM_TIMESTEPS;
+  typedef DYN_T DYN_TYPE;
+  DDPFeedback(DYN_T* model, float dt) : model_(model), dt_(dt)
+  {
+  }
+  /** gains [T][S][C]: the C x S gain matrix of every time step, column-major (DDPFeedbackState::fb_gain_traj_) */
+  void setFeedbackGains(const std::vector<float>& gains, bool accumulate_all_states = false)
+  {
+    gains_ = gains;
+    accumulate_all_states_ = accumulate_all_states;
+    version_++;
+  }
+  const std::vector<float>& getFeedbackGains() const
+  {
+    return gains_;
+  }
+  bool accumulateAllStates() const
+  {
+    return accumulate_all_states_;
+  }
+  unsigned version() const
+  {
+    return version_;
+  }
+  float getDt() const
+  {
+    return dt_;
+  }
+  DYN_T* model_ = nullptr;
+
+private:
+  float dt_ = 0.0f;
+  std::vector<float> gains_;
+  bool accumulate_all_states_ = false;
+  unsigned version_ = 0;
+};
 #endif

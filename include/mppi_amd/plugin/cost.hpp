@@ -71,7 +71,7 @@ public:
   void setParams(const PARAMS_T& params)
   {
     params_ = params;
-    paramsToDevice();
+    (void)paramsToDevice();
   }
   __host__ __device__ PARAMS_T getParams() const
   {

@@ -7,9 +7,13 @@
  *   initializeDynamics, enforceConstraints, computeStateDeriv, computeKinematics, updateState, step, stateToOutput
  * A model written for the reference keeps its device code (computeDynamics / computeKinematics / overrides) as is.
  *
- * Not mirrored: the Eigen host overloads.  The host never evaluates a model here — the nominal state trajectory is
- * re-rolled on the device by the same plugin code (mppi-generic_amd/csrc/finalize_kernel.hpp) — so a model only needs
- * its device methods.
+ * The Eigen host overloads of a model (computeDynamics / step on Eigen vectors) are not mirrored: the engine never
+ * evaluates a model on the host — the nominal state trajectory is re-rolled on the device by the same plugin code
+ * (include/mppi_amd/engine/finalize_kernel.hpp) — so a model only needs its device methods.  What a CALLER does with the
+ * model on the host — `model->enforceConstraints(x, u); model->step(x, x_next, xdot, u, y, t, dt);` in its simulation loop
+ * (examples/cartpole_example.cu:76-80) — is served by the two host overloads declared below and defined in
+ * plugin/dynamics_host.hpp: they run the model's DEVICE code for one rollout, so the caller's plant integrates with the
+ * arithmetic the rollouts use.
  */
 #ifndef MPPI_AMD_PLUGIN_DYNAMICS_HPP_
 #define MPPI_AMD_PLUGIN_DYNAMICS_HPP_
@@ -19,6 +23,7 @@
 #include "mppi_amd/plugin/managed.hpp"
 #include "mppi_amd/plugin/math_utils.hpp"
 #include "mppi_amd/plugin/parallel_utils.hpp"
+#include "mppi_amd/plugin/host_arrays.hpp"
 
 #ifndef E_INDEX
 #define E_INDEX(ENUM, enum_val) static_cast<int>(ENUM::enum_val)
@@ -67,6 +72,10 @@ public:
   static const int OUTPUT_DIM = O_IND_CLASS(PARAMS_T, NUM_OUTPUTS);
   typedef CLASS_T DYN_T;
   typedef PARAMS_T DYN_PARAMS_T;
+  /* host-side vector types (reference: Eigen columns, dynamics.cuh:80-90; here plugin/host_arrays.hpp) */
+  typedef mppi::host::Array<STATE_DIM> state_array;
+  typedef mppi::host::Array<CONTROL_DIM> control_array;
+  typedef mppi::host::Array<OUTPUT_DIM> output_array;
 
   Dynamics(hipStream_t stream = 0)
   {
@@ -124,7 +133,7 @@ public:
   void setParams(const PARAMS_T& params)
   {
     params_ = params;
-    paramsToDevice();
+    (void)paramsToDevice();
   }
   __host__ __device__ PARAMS_T getParams() const
   {
@@ -134,13 +143,29 @@ public:
   {
     for (int i = 0; i < CONTROL_DIM; i++)
       control_rngs_[i] = control_rngs[i];
-    paramsToDevice();
+    (void)paramsToDevice();
   }
   void setControlDeadbands(const float* control_deadband)
   {
     for (int i = 0; i < CONTROL_DIM; i++)
       control_deadband_[i] = control_deadband[i];
-    paramsToDevice();
+    (void)paramsToDevice();
+  }
+
+  /* ------------------------------ host side: a caller's simulation loop ------------------------------ */
+  /** Dynamics::enforceConstraints / step on host vectors (reference: dynamics.cuh:300-340 host overloads): evaluated by the
+   *  model's device code on one lane — include "mppi_amd/plugin/dynamics_host.hpp" (hipcc) in the translation unit that
+   *  calls them */
+  void enforceConstraints(state_array& state, control_array& control);
+  void step(state_array& state, state_array& next_state, state_array& state_der, control_array& control,
+            output_array& output, const float t, const float dt);
+  /** reference: dynamics.cuh printState */
+  void printState(const float* state) const
+  {
+    printf("State:");
+    for (int i = 0; i < STATE_DIM; i++)
+      printf(" %f", state[i]);
+    printf("\n");
   }
 
   /* ------------------------------ device side: what the kernels call ------------------------------ */

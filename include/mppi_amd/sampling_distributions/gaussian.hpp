@@ -151,6 +151,19 @@ public:
   {
     bindToStream(stream);
   }
+  /** reference: sampling_distribution.cuh:60-66 (construct from a parameter struct), :120-135 (setParams / getParams) */
+  GaussianDistribution(const SAMPLING_PARAMS_T& params, hipStream_t stream = 0) : params_(params)
+  {
+    bindToStream(stream);
+  }
+  void setParams(const SAMPLING_PARAMS_T& params)
+  {
+    params_ = params;
+  }
+  __host__ __device__ SAMPLING_PARAMS_T getParams() const
+  {
+    return params_;
+  }
 
   /** row stride in floats: T*C, +1 when even (bank-conflict-free column walk) */
   __host__ __device__ static inline int rowStride(int num_timesteps)

@@ -1211,11 +1211,66 @@ static mppi_status rocrandFill(mppi_handle h)
   return MPPI_OK;
 }
 
+/* ---------------------------------------------------------------- roctx ranges --------------------------------------- */
+/**
+ * Marker ranges around the enqueue of the rollout, merge and post-processing kernels (the reference has no
+ * profiler ranges; `rocprofv3 --marker-trace --kernel-trace` then attributes the kernels of an iteration).  Opt-in:
+ * MPPI_AMD_ROCTX=1 — libroctx64 is dlopen'ed on first use; when the variable is unset a range is one predictable branch.
+ */
+namespace
+{
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)();
+struct Roctx
+{
+  roctx_push_fn push = nullptr;
+  roctx_pop_fn pop = nullptr;
+  Roctx()
+  {
+    const char* on = getenv("MPPI_AMD_ROCTX");
+    if (!on || on[0] == '0' || on[0] == '\0')
+      return;
+    for (const char* name : { "librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4" })
+    {
+      void* lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!lib)
+        continue;
+      push = (roctx_push_fn)dlsym(lib, "roctxRangePushA");
+      pop = (roctx_pop_fn)dlsym(lib, "roctxRangePop");
+      if (push && pop)
+        return;
+      push = nullptr;
+      pop = nullptr;
+    }
+  }
+};
+static const Roctx& roctx()
+{
+  static const Roctx r;
+  return r;
+}
+struct RoctxRange
+{
+  bool active;
+  explicit RoctxRange(const char* name) : active(roctx().push != nullptr)
+  {
+    if (active)
+      roctx().push(name);
+  }
+  ~RoctxRange()
+  {
+    if (active)
+      roctx().pop();
+  }
+};
+}  // namespace
+
 /* ---------------------------------------------------------------- internals -------------------------------------- */
 static mppi_status launchCombine(mppi_handle h, const float* records, int num_records, int finalize, float* record_out,
                                  int k_total, bool world_major = false, const unsigned* wait_flags = nullptr,
                                  unsigned wait_seq = 0, const kernels::PostTargets* post = nullptr)
 {
+  RoctxRange range(finalize ? "mppi:merge" : "mppi:merge_local");
   kernels::CombineArgs a{};
   if (post)
     a.post = *post;
@@ -1244,6 +1299,7 @@ static mppi_status launchCombine(mppi_handle h, const float* records, int num_re
 
 static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
 {
+  RoctxRange range("mppi:rollout");
   kernels::RolloutArgs a{};
   a.dt = h->cfg.dt;
   a.num_timesteps = h->cfg.num_timesteps;
@@ -1420,6 +1476,7 @@ static bool allFinite(const std::vector<float>& v)
 static mppi_status finalize(mppi_handle h, const float* ctrl_in_d, int smooth_mask, int constrain_mask,
                             std::vector<float>* ctrl_out[2], std::vector<float>* state_out[2], int num_systems = 0)
 {
+  RoctxRange range("mppi:finalize");
   const int T = h->cfg.num_timesteps;
   kernels::FinalizeArgs a{};
   // the control history goes up through its slice of the pinned input block (one small asynchronous copy)
@@ -1924,6 +1981,7 @@ mppi_status mppi_compute_control(mppi_handle h, const float* x0, int stride)
   for (int i = 0; i < h->S; i++)  // base_plant.hpp:466-470 skips the iteration on a non-finite state; here the call says so
     if (!std::isfinite(x0[i]))
       return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite initial state");
+  RoctxRange range("mppi:compute_control");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   h->last_stride = stride;
   if (h->cfg.controller == MPPI_CONTROLLER_TUBE)
