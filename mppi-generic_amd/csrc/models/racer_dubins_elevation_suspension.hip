@@ -9,13 +9,17 @@
  *
  * Block shapes: (64, 4) — the default — runs a rollout on four replica lanes that share out the wheels of the suspension,
  * the hidden units and neurons of the steering network and the rows of the covariance update
- * (RacerDubinsElevationSuspensionQuad; default network shape only).  Two systems (Tube): (32, 4, 2).  A (64, 4, 2) block is 512
- * threads, i.e. 256 registers per lane.  While every lane kept its own copy of the steering weights (81 registers, ~200
- * values of the step spilled) that instantiation returned NaN costs for injected noise when compiled at -O3 — correct at
- * -O2, correct with the in-kernel draw, correct for every other model, and correct again since the weights moved into
- * DPP rows (lstm_quad.hpp) and the spills went away.  Not understood beyond that, so it stays un-instantiated; the
- * 256-thread block keeps the step in registers with room to spare.  BY == 1: one lane per rollout; fused rollout kernel
- * (the LDS fallback of the steering network needs a block barrier in initializeDynamics, see
+ * (RacerDubinsElevationSuspensionQuad; default network shape only).  Two systems (Tube): (64, 4, 2) or (32, 4, 2).
+ * History of the (64, 4, 2) block (512 threads, i.e. at most 256 registers per lane): while every lane kept its own copy of
+ * the steering weights (81 registers; 1032 B of scratch per lane, ~200 spilled values of the step) that instantiation
+ * returned NaN costs for injected noise at -O3 and correct ones at -O2; since the weights live in DPP rows (lstm_quad.hpp)
+ * the kernel has no scratch and is correct at -O3.  Round 3 looked for the cause in the OLD code objects (038afa8 rebuilt at
+ * -O3 and -O2): no wait-state violation around any DPP, ds_bpermute, v_readlane / v_writelane (tools/dpp_hazard_lint.py,
+ * extended for that, 25 418 cross-lane instructions), the two builds differ by four flat loads of spilled values — nothing
+ * that names an instruction, so the evidence for the current form is empirical: tools/soak_four_lane.py (every four-lane
+ * model x one and two systems x injected noise, 10^4 launches, 0 non-finite costs, results reproduced bit for bit) and the
+ * oracle comparison of the shape at full size (tests/test_full_size_parity.py).  BY == 1: one lane per rollout; fused
+ * rollout kernel (the LDS fallback of the steering network needs a block barrier in initializeDynamics, see
  * racer_dubins_elevation_lstm_steering.hip).
  * Robust MPPI (RMPPI = true): both of its kernels run the four-lanes-per-rollout form.
  */
@@ -34,7 +38,8 @@ using RacerSuspensionModel =
            sampling_distributions::GaussianDistribution<RacerDubinsElevationSuspensionParams>,
            Shapes<Shape<64, 1, 1>, Shape<32, 1, 1>, Shape<64, 1, 2>>, /*FIN_BY=*/2,
            /* four lanes per rollout: a wheel, a covariance row, a hidden unit and five MLP neurons each */
-           RacerDubinsElevationSuspensionQuad, Shapes<Shape<64, 4, 1>, Shape<32, 4, 2>>, /*PIPELINE=*/false, /*RMPPI=*/true>;
+           RacerDubinsElevationSuspensionQuad, Shapes<Shape<64, 4, 1>, Shape<64, 4, 2>, Shape<32, 4, 2>>, /*PIPELINE=*/false,
+           /*RMPPI=*/true>;
 using RacerSuspensionColoredModel =
     ModelT<RacerDubinsElevationSuspension, SuspensionCost,
            sampling_distributions::ColoredNoiseDistribution<RacerDubinsElevationSuspensionParams>, Shapes<Shape<64, 1, 1>>,

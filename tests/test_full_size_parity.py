@@ -237,3 +237,23 @@ def test_racer_elevation_16384x100_vs_oracle(gpu, model, block_y, variant):
     eng.computeControl(cfg["x0"], 1)
     orc.vanilla_compute_control(cfg["x0"], 1, eps)
     _check_vanilla(eng, orc)
+
+
+def test_suspension_two_systems_64x4x2_16384x100_vs_oracle(gpu):
+    """Tube-MPPI on the suspension model with the (64, 4, 2) block — 512 threads, the instantiation that returned NaN costs for
+    injected noise in round 2 while the steering weights sat in per-lane registers (csrc/models/
+    racer_dubins_elevation_suspension.hip) — at the full size, injected noise, against the oracle"""
+    from test_racer_dubins_suspension import suspension_cfg
+    cfg = suspension_cfg(K=16384, T=100, D=2)
+    eng, orc = make_engine(cfg, block_x=64, block_y=4), make_oracle(cfg)
+    eps = host_noise(1, cfg["K"], cfg["T"], 2, seed=11)
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    orc.tube_compute_control(cfg["x0"], 1, eps)
+    costs = eng.getSampledCostSeq()
+    assert np.isfinite(costs).all()
+    assert ulp_diff(costs, orc.costs()).max() == 0
+    assert np.abs(eng.getControlSeq() - orc.control()).max() <= U_TOL
+    assert np.abs(eng.getNominalControlSeq() - orc.nominal_control()).max() <= U_TOL
+    eng.close()
+

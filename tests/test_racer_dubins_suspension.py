@@ -223,8 +223,9 @@ def test_suspension_tube_and_colored_closed_loop(gpu):
     eps = host_noise(1, cfg["K"], cfg["T"], 2, seed=4)
     o = make_oracle(cfg)
     o.tube_compute_control(cfg["x0"], 1, eps)
-    # no shape: (32, 4, 2), the four-lane form for two systems; (64, 1, 2): one lane per rollout
-    for shape in ({}, dict(block_x=32, block_y=4), dict(block_x=64, block_y=1)):
+    # no shape: the default (64, 4) with two systems, 512 threads — the instantiation that once returned NaN (see the model's
+    # .hip); (32, 4, 2): 256 threads; (64, 1, 2): one lane per rollout
+    for shape in ({}, dict(block_x=64, block_y=4), dict(block_x=32, block_y=4), dict(block_x=64, block_y=1)):
         eng = make_engine(cfg, **shape)
         eng.injectNoise(eps)
         eng.computeControl(cfg["x0"], 1)
