@@ -1133,16 +1133,18 @@ struct ModelT : ModelBase
     if (st != MPPI_OK)
       return st;
     smp.params_.num_distributions = 1;
-    const size_t smem = calcClassSharedMemSize(&smp, 64);
+    SAMPLING_T dump_smp = smp;
+    dump_smp.rows_global_d_ = nullptr;  // the dump kernel reads the rows back from ITS LDS, whatever the rollouts use
+    const size_t smem = calcClassSharedMemSize(&dump_smp, 64);
     if (smem > MAX_LDS_BYTES)
     {
-      err = "noise dump kernel LDS overflow";
+      err = "noise dump kernel: the rows of 64 rollouts do not fit the LDS at this horizon";
       return MPPI_ERR_LDS_OVERFLOW;
     }
     auto kfn = kernels::noiseDumpKernel<SAMPLING_T>;
     if (smem > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(kfn, dim3((s.num_rollouts_local + 63) / 64), dim3(64, 1, 1), smem, stream, smp, out_d);
+    hipLaunchKernelGGL(kfn, dim3((s.num_rollouts_local + 63) / 64), dim3(64, 1, 1), smem, stream, dump_smp, out_d);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
     {

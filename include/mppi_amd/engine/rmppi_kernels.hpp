@@ -206,8 +206,11 @@ __global__ void __launch_bounds__(BX * 2 * replicated_lanes<DYN_T>::value)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* theta_s_shared = reinterpret_cast<float*>(smem_raw);
   float* theta_c_shared = theta_s_shared + calcClassSharedMemSize(dynamics, SLOTS) / (int)sizeof(float);
-  float* theta_d_shared = theta_c_shared + calcClassSharedMemSize(costs, SLOTS) / (int)sizeof(float);
-  float* cost_s = theta_d_shared + calcClassSharedMemSize(sampling, SLOTS) / (int)sizeof(float);
+  float* theta_d_lds = theta_c_shared + calcClassSharedMemSize(costs, SLOTS) / (int)sizeof(float);
+  float* cost_s = theta_d_lds + calcClassSharedMemSize(sampling, SLOTS) / (int)sizeof(float);
+  // the block's sample rows: in LDS, or — horizons whose rows do not fit — in the sampler's HBM buffer (see rolloutKernel)
+  float* theta_d_shared = sampling->blockRows(theta_d_lds, block_idx, SLOTS);
+  sampling->setStagingBase(theta_d_lds);
   float* w_s = cost_s + math::nearest_multiple_4(SLOTS);
   float* theta_fb = w_s + math::nearest_multiple_4(SLOTS);
   float* xnom_buf = theta_fb + calcClassSharedMemSize(fb_controller, SLOTS) / (int)sizeof(float);  // [2][BX][S]

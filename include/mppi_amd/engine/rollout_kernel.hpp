@@ -351,6 +351,7 @@ __global__ void __launch_bounds__(BX* BY* BZ* replicated_lanes<DYN_T>::value)
   float* next_shared = theta_d_lds + calcClassSharedMemSize(sampling, SLOTS) / (int)sizeof(float);
   // the block's sample rows: in LDS, or — horizons whose rows do not fit — in the sampler's HBM buffer (generic pointers)
   float* theta_d_shared = sampling->blockRows(theta_d_lds, block_idx, SLOTS);
+  sampling->setStagingBase(theta_d_lds);  // block-shared LDS of the sampler (colored noise: the table staging tiles)
 
   float x_priv[S], xn_priv[S], xdot_priv[S], u_priv[C], y_priv[O];
   int crash_priv = 0;

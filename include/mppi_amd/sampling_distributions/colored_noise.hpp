@@ -148,7 +148,9 @@ public:
   static const int CONTROL_DIM = PARENT::CONTROL_DIM;
   static constexpr bool IN_LOOP_DRAW = false;  ///< the rows are filled by the prologue GEMM
   static constexpr bool COLORED = true;
-  static constexpr bool SUPPORTS_GLOBAL_ROWS = false;  ///< the prologue GEMM writes the rows through the LDS
+  /** long horizons: the prologue GEMM writes its tiles straight into the HBM rows (the accumulators are registers; only the
+   *  table staging tiles need the LDS), the step loop reads them back through sampleRow() like the Gaussian sampler */
+  static constexpr bool SUPPORTS_GLOBAL_ROWS = true;
   static constexpr int MAX_TB = 16;            ///< time blocks (of 16 steps) accumulated per pass over the spectrum
 
   /* reference: ColoredNoiseParamsImpl, colored_noise/colored_noise.cuh:45-73 */
@@ -333,7 +335,9 @@ public:
     const int KS = coloredNumKSteps(T), NTB = coloredNumTBlocks(T), KK = coloredSpectrumFloats(T);
     const int NG = KS >> 2;  // tiles of 4 k-steps
     const bool from_buffer = this->noise_source_ == NOISE_EPS_BUFFER;
-    float* __restrict__ stage = theta_d + (((size_t)bx * nz * stride + 3) & ~(size_t)3);  // 16-byte aligned
+    // [slot rows][staging tiles] in LDS; with the rows in HBM (theta_d then points there) the staging tiles start the region
+    float* __restrict__ stage = this->rows_global_d_ ? this->staging_lds_
+                                                     : theta_d + (((size_t)bx * nz * stride + 3) & ~(size_t)3);  // 16-byte aligned
     for (int c = 0; c < CONTROL_DIM; c++)
     {
       const float* __restrict__ basis = basis_d_ + (size_t)c * KS * NTB * 64;

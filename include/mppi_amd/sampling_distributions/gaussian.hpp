@@ -117,6 +117,7 @@ public:
   int thread_slot_ = -1;             ///< rollout slot of this thread, -1: blockDim.x * threadIdx.z + threadIdx.x
   int block_rollouts_ = 0;           ///< rollouts per block, 0: blockDim.x
   int block_systems_ = 0;            ///< systems per block, 0: blockDim.z
+  float* staging_lds_ = nullptr;     ///< base of this sampler's LDS region (setStagingBase; thread-private register)
 
   __device__ inline void setThreadMapping(int slot, int block_rollouts, int block_systems = 0)
   {
@@ -184,6 +185,12 @@ public:
   __host__ __device__ inline int getGrdSharedSizeBytes() const
   {
     return 0;
+  }
+  /** the LDS region the kernel reserved for this sampler ([slot rows][block-shared part]); with the rows in HBM the
+   *  block-shared part is all that is left there — samplers that use it (colored noise) remember the base */
+  __device__ inline void setStagingBase(float* theta_d_lds)
+  {
+    staging_lds_ = theta_d_lds;
   }
 
   /** decay^iter by repeated multiplication (exact for decay == 1; the CPU oracle does the same) */

@@ -521,6 +521,19 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   }
   const char* force_hbm_rows = getenv("MPPI_AMD_ROWS_IN_HBM");  // test hook: the HBM-row variant at any horizon
   const bool want_hbm_rows = lds > MAX_LDS_BYTES || (force_hbm_rows && force_hbm_rows[0] == '1');
+  if (want_hbm_rows && cfg->controller == MPPI_CONTROLLER_ROBUST && h->model->globalRowsFloats(1, 1, cfg->num_timesteps) > 0)
+  {
+    // Robust MPPI at horizons whose rows of even 32 rollouts x 2 systems overflow the LDS (or on request): the (64, 1, 2)
+    // block with the rows in HBM — rolloutRMPPIKernel reaches them through the same pointer as the fused rollout kernel
+    if (lds > MAX_LDS_BYTES)
+      h->bx = cfg->block_x != 0 ? cfg->block_x : 64;
+    h->model->setGlobalRows(reinterpret_cast<float*>(16));  // placeholder until the buffer exists: sizes the LDS request
+    lds = h->model->rmppiSharedBytes(h->bx, cfg->num_timesteps);
+    if (lds <= MAX_LDS_BYTES)
+      h->rows_in_hbm = true;
+    else
+      h->model->setGlobalRows(nullptr);
+  }
   if (want_hbm_rows && cfg->controller != MPPI_CONTROLLER_ROBUST && cfg->kernel_variant != MPPI_KERNEL_PIPELINE &&
       h->model->globalRowsFloats(1, 1, cfg->num_timesteps) > 0)
   {

@@ -61,10 +61,60 @@ def test_cartpole_T5000_vs_oracle(gpu):
     assert np.abs(eng.getOptimalControlSeq()[0] - u).max() <= 1e-5
 
 
-def test_colored_sampler_still_reports_overflow(gpu):
-    """the colored-noise sampler writes its rows through the LDS (prologue GEMM): no HBM form, the error stays explicit"""
-    cfg = cartpole_cfg(K=256, T=5000)
+def test_colored_sampler_T1000_vs_oracle(gpu):
+    """the colored-noise sampler at a horizon whose rows do not fit the LDS (round 3: its prologue GEMM writes the tiles straight
+    into the HBM rows; only the table staging tiles stay in LDS) — the reference keeps its samples in global memory for every
+    sampler (sampling_distributions/sampling_distribution.cu:169-205) and has no horizon limit"""
+    from common import host_spectrum
+    cfg = cartpole_cfg(K=256, T=1000, soft=True)
     cfg["colored"] = ([1.0], 0.97, 0.0)
-    with pytest.raises(m.MPPIError) as e:
-        make_engine(cfg)
-    assert e.value.status == 6
+    eng, orc = make_engine(cfg), make_oracle(cfg)
+    z = host_spectrum(1, cfg["K"], cfg["T"], 1, seed=3)
+    eng.injectNoise(z)
+    eng.computeControl(cfg["x0"], 1)
+    orc.colored_compute_control(cfg["x0"], 1, z, *cfg["colored"])
+    assert ulp_diff(eng.getSampledCostSeq(), orc.costs()).max() == 0
+    assert np.abs(eng.getControlSeq() - orc.control()).max() <= 1e-5
+    eng.close()
+    # and the same kernel with the rows forced into HBM at a horizon that would fit: the same bits as with LDS rows
+    cfg = cartpole_cfg(K=300, T=64, soft=True)
+    cfg["colored"] = ([1.0], 0.97, 0.0)
+    a = make_engine(cfg, kernel_variant=1)
+    b = _engine_with_hbm_rows(cfg, kernel_variant=1)
+    for eng in (a, b):
+        eng.uploadState(cfg["x0"])
+        eng.optimize(2)
+    assert np.array_equal(a.getSampledCostSeq(), b.getSampledCostSeq())
+    assert np.array_equal(a.getOptimalControlSeq(), b.getOptimalControlSeq())
+
+
+def test_rmppi_T1000_vs_oracle(gpu):
+    """Robust MPPI at a horizon whose rows of even 32 rollouts x 2 systems overflow the LDS: (64, 1, 2) block, rows in HBM"""
+    cfg = di_cfg(K=320, T=1000, tube=True)
+    cfg["control_cost_coeff"] = [0.3, 0.2]
+    cfg["ranges"] = [[-3.0, 3.0], [-3.0, 3.0]]
+    eng = m.RobustMPPIController(cfg["model"], cfg["K"], cfg["T"], cfg["dt"], cfg["lambda_"], cfg["alpha"], 1, seed=42,
+                                 save_samples=True)
+    eng.setDynamicsParams(cfg["dyn"])
+    eng.setCostParams(cfg["cost"])
+    eng.setControlRanges(cfg["ranges"])
+    eng.setSamplingParams(cfg["std_dev"], cfg["control_cost_coeff"])
+    eng.setRMPPIParams(40.0, 9, 32)
+    orc = make_oracle(cfg)
+    rob = po.RobustOracle(orc, 40.0, 9, 32)
+    T, K = cfg["T"], cfg["K"]
+    g = np.random.default_rng(1).uniform(-0.4, 0.4, (T, 4, 2)).astype(np.float32)
+    eng.setFeedbackGains(g)
+    rob.set_gains(g)
+    mean = (0.3 * np.sin(np.arange(T * 2, dtype=np.float32) * 0.02)).reshape(T, 2)
+    eng.updateImportanceSampler(mean)
+    eps = host_noise(1, K, T, 2)[0]
+    eng.injectNoise(eps)
+    x0 = np.stack([cfg["x0"], cfg["x0"] + np.array([0.3, -0.2, 0.1, 0.05], np.float32)])
+    got = eng.rolloutCosts(x0, 1)
+    means = np.tile(mean, (2, 1, 1))
+    v = orc.set_gaussian_controls(means, eps, 1, 0)
+    want, v_fb = rob.rollout_costs(x0, means, v)
+    assert ulp_diff(got, want).max() == 0
+    assert ulp_diff(eng.getSampledControls(), v_fb).max() == 0
+    eng.close()
