@@ -343,12 +343,33 @@ MPPI_HD static inline void rcp_benign2(const float xa, const float xb, float* ra
 #endif
 }
 
+/* tanh's rational: Eigen's coefficients times 2^-8 / 4.89352518554385e-03, the constant terms of P and Q both 2^-8 */
+#define MPPI_DET_TANH_C0 0.00390625f
+#define MPPI_DET_TANH_P1 5.086935125291348e-04f
+#define MPPI_DET_TANH_P2 1.1859759069920983e-05f
+#define MPPI_DET_TANH_P3 4.088866845108896e-08f
+#define MPPI_DET_TANH_P4 -6.868667440373954e-11f
+#define MPPI_DET_TANH_P5 1.5966473477548038e-13f
+#define MPPI_DET_TANH_P6 -2.2037797495707987e-16f
+#define MPPI_DET_TANH_Q1 1.8107749056071043e-03f
+#define MPPI_DET_TANH_Q2 9.462016896577552e-05f
+#define MPPI_DET_TANH_Q3 9.565081882101367e-07f
+
 /**
- * tanh(x), branch-free: clamp to +-7.9053 (tanh rounds to +-1 in fp32 beyond), then the odd rational minimax
- * x * P6(x^2) / Q3(x^2) with the coefficient set of Eigen's generic_fast_tanh_float (MathFunctionsImpl.h, MPL2), one
- * correctly rounded division.  No divergent control flow — the NN dynamics evaluate 64 of these per rollout and step,
- * and a two-branch exp-based form costs both branches on a SIMD machine.
- * Accuracy: <= 7 ulp (4e-7 absolute) against float64 tanh; tanh(x) = x exactly for |x| < 2^-13; +-1 for |x| >= 7.9053.
+ * tanh(x), branch-free and select-free: clamp to +-7.9053 (tanh rounds to +-1 in fp32 beyond), then the odd rational minimax
+ * x * P6(x^2) / Q3(x^2) (coefficient set of Eigen's generic_fast_tanh_float, MathFunctionsImpl.h, MPL2, RESCALED so that
+ * P(0) = Q(0) = 2^-8 exactly), one correctly rounded division.  No divergent control flow — the NN dynamics evaluate 64 of
+ * these per rollout and step, and a two-branch exp-based form costs both branches on a SIMD machine.
+ *
+ * The common constant term makes tanh(x) = x EXACT for small arguments without a compare / select pair (round 3; the select
+ * was 2 of the 13 issue slots of a packed tanh): for |x| < 3.6e-4 both polynomials round to 2^-8, p = x * 2^-8 and the
+ * quotient p / 2^-8 are exact scalings — also for -0 and, up to the rounding of x * 2^-8, for subnormals, identically on
+ * the host and in div_benign's Newton-Raphson core (a ZERO result is +0 for either sign of x, see below).  Accuracy: <= 6 ulp (4e-7 absolute) against float64 tanh (was 5 with
+ * the original constants); +-1 for |x| >= 7.9053.
+ * NaN: the clamp is fminf(fmaxf(x, -c), c) / v_med3_f32, both of which return the non-NaN bound, so tanh(NaN) = tanh(-c)
+ * = -1 on host and device alike — a NaN pre-activation no longer propagates through the activation (it does through
+ * every other path of a step: the state that produced it stays NaN, and the costs of such a rollout are clamped by the
+ * cost plugins as before).  Callers that need tanhf's NaN can test their argument.
  */
 MPPI_HD static inline float tanh(float x)
 {
@@ -357,20 +378,24 @@ MPPI_HD static inline float tanh(float x)
 #endif
   const float xc = fminf(fmaxf(x, -7.90531110763549805f), 7.90531110763549805f);
   const float x2 = xc * xc;
-  float p = fma(x2, -2.76076847742355e-16f, 2.00018790482477e-13f);
-  p = fma(x2, p, -8.60467152213735e-11f);
-  p = fma(x2, p, 5.12229709037114e-08f);
-  p = fma(x2, p, 1.48572235717979e-05f);
-  p = fma(x2, p, 6.37261928875436e-04f);
-  p = fma(x2, p, 4.89352455891786e-03f);
+  float p = fma(x2, MPPI_DET_TANH_P6, MPPI_DET_TANH_P5);
+  p = fma(x2, p, MPPI_DET_TANH_P4);
+  p = fma(x2, p, MPPI_DET_TANH_P3);
+  p = fma(x2, p, MPPI_DET_TANH_P2);
+  p = fma(x2, p, MPPI_DET_TANH_P1);
+  p = fma(x2, p, MPPI_DET_TANH_C0);
   p = xc * p;
-  float q = fma(x2, 1.19825839466702e-06f, 1.18534705686654e-04f);
-  q = fma(x2, q, 2.26843463243900e-03f);
-  q = fma(x2, q, 4.89352518554385e-03f);
-  const float r = div_benign(p, q);
-  /* |x| < 2^-13: tanh(x) = x to the last bit (x^3/3 is below half an ulp) — also keeps -0, subnormals and NaN intact
-   * (the comparison is false for NaN) and keeps div_benign's numerator away from the subnormal range */
-  return (fabs(x) >= 1.220703125e-4f) ? r : x;
+  float q = fma(x2, MPPI_DET_TANH_Q3, MPPI_DET_TANH_Q2);
+  q = fma(x2, q, MPPI_DET_TANH_Q1);
+  q = fma(x2, q, MPPI_DET_TANH_C0);
+#if defined(__HIP_DEVICE_COMPILE__)
+  return div_benign(p, q);
+#else
+  /* a zero quotient (x = -0, or |x| < 2^-141 where x * 2^-8 underflows) comes out of the device's Newton-Raphson core as
+   * +0 whatever its sign: its exact residual fma(-q, y, p) is +0 and y + 0 * r rounds -0 + +0 to +0.  The host's IEEE quotient
+   * would keep the sign; adding +0 gives it the device's value (and changes no other result). */
+  return div_benign(p, q) + 0.0f;
+#endif
 }
 
 /**
@@ -382,23 +407,22 @@ MPPI_HD static inline void tanh2(const float xa, const float xb, float* ra, floa
 {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const f32x2 x = { xa, xb };
   f32x2 xc;
   xc.x = fminf(fmaxf(xa, -7.90531110763549805f), 7.90531110763549805f);
   xc.y = fminf(fmaxf(xb, -7.90531110763549805f), 7.90531110763549805f);
   const f32x2 x2 = xc * xc;
 #define MPPI_DET_PKFMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
 #define MPPI_DET_SPLAT(v) (f32x2{ (v), (v) })
-  f32x2 p = MPPI_DET_PKFMA(x2, MPPI_DET_SPLAT(-2.76076847742355e-16f), MPPI_DET_SPLAT(2.00018790482477e-13f));
-  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(-8.60467152213735e-11f));
-  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(5.12229709037114e-08f));
-  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(1.48572235717979e-05f));
-  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(6.37261928875436e-04f));
-  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(4.89352455891786e-03f));
+  f32x2 p = MPPI_DET_PKFMA(x2, MPPI_DET_SPLAT(MPPI_DET_TANH_P6), MPPI_DET_SPLAT(MPPI_DET_TANH_P5));
+  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(MPPI_DET_TANH_P4));
+  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(MPPI_DET_TANH_P3));
+  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(MPPI_DET_TANH_P2));
+  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(MPPI_DET_TANH_P1));
+  p = MPPI_DET_PKFMA(x2, p, MPPI_DET_SPLAT(MPPI_DET_TANH_C0));
   p = xc * p;
-  f32x2 q = MPPI_DET_PKFMA(x2, MPPI_DET_SPLAT(1.19825839466702e-06f), MPPI_DET_SPLAT(1.18534705686654e-04f));
-  q = MPPI_DET_PKFMA(x2, q, MPPI_DET_SPLAT(2.26843463243900e-03f));
-  q = MPPI_DET_PKFMA(x2, q, MPPI_DET_SPLAT(4.89352518554385e-03f));
+  f32x2 q = MPPI_DET_PKFMA(x2, MPPI_DET_SPLAT(MPPI_DET_TANH_Q3), MPPI_DET_SPLAT(MPPI_DET_TANH_Q2));
+  q = MPPI_DET_PKFMA(x2, q, MPPI_DET_SPLAT(MPPI_DET_TANH_Q1));
+  q = MPPI_DET_PKFMA(x2, q, MPPI_DET_SPLAT(MPPI_DET_TANH_C0));
   f32x2 r = { __builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y) };
   const f32x2 e = MPPI_DET_PKFMA(-q, r, MPPI_DET_SPLAT(1.0f));
   r = MPPI_DET_PKFMA(e, r, r);
@@ -407,8 +431,8 @@ MPPI_HD static inline void tanh2(const float xa, const float xb, float* ra, floa
   y = MPPI_DET_PKFMA(MPPI_DET_PKFMA(-q, y, p), r, y);
 #undef MPPI_DET_PKFMA
 #undef MPPI_DET_SPLAT
-  *ra = (fabs(x.x) >= 1.220703125e-4f) ? y.x : x.x;
-  *rb = (fabs(x.y) >= 1.220703125e-4f) ? y.y : x.y;
+  *ra = y.x;
+  *rb = y.y;
 #else
   *ra = tanh(xa);
   *rb = tanh(xb);
@@ -433,50 +457,49 @@ __device__ inline void tanh_pairs(float (&v)[2 * NP])
 #define MPPI_DET_PKFMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
 #define MPPI_DET_SPLAT(c) (f32x2{ (c), (c) })
 #define MPPI_DET_ALL for (int k = 0; k < NP; k++)
-  f32x2 x[NP], xc[NP], x2[NP], p[NP], q[NP], r[NP], y[NP];
+  f32x2 xc[NP], x2[NP], p[NP], q[NP], r[NP], y[NP];
 #pragma unroll
   MPPI_DET_ALL
   {
-    x[k] = f32x2{ v[2 * k], v[2 * k + 1] };
-    xc[k].x = fminf(fmaxf(x[k].x, -7.90531110763549805f), 7.90531110763549805f);
-    xc[k].y = fminf(fmaxf(x[k].y, -7.90531110763549805f), 7.90531110763549805f);
+    xc[k].x = fminf(fmaxf(v[2 * k], -7.90531110763549805f), 7.90531110763549805f);
+    xc[k].y = fminf(fmaxf(v[2 * k + 1], -7.90531110763549805f), 7.90531110763549805f);
   }
 #pragma unroll
   MPPI_DET_ALL x2[k] = xc[k] * xc[k];
 #pragma unroll
   MPPI_DET_ALL
   {
-    p[k] = MPPI_DET_PKFMA(x2[k], MPPI_DET_SPLAT(-2.76076847742355e-16f), MPPI_DET_SPLAT(2.00018790482477e-13f));
-    q[k] = MPPI_DET_PKFMA(x2[k], MPPI_DET_SPLAT(1.19825839466702e-06f), MPPI_DET_SPLAT(1.18534705686654e-04f));
+    p[k] = MPPI_DET_PKFMA(x2[k], MPPI_DET_SPLAT(MPPI_DET_TANH_P6), MPPI_DET_SPLAT(MPPI_DET_TANH_P5));
+    q[k] = MPPI_DET_PKFMA(x2[k], MPPI_DET_SPLAT(MPPI_DET_TANH_Q3), MPPI_DET_SPLAT(MPPI_DET_TANH_Q2));
   }
 #pragma unroll
   MPPI_DET_ALL
   {
-    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(-8.60467152213735e-11f));
-    q[k] = MPPI_DET_PKFMA(x2[k], q[k], MPPI_DET_SPLAT(2.26843463243900e-03f));
+    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(MPPI_DET_TANH_P4));
+    q[k] = MPPI_DET_PKFMA(x2[k], q[k], MPPI_DET_SPLAT(MPPI_DET_TANH_Q1));
   }
 #pragma unroll
   MPPI_DET_ALL
   {
-    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(5.12229709037114e-08f));
-    q[k] = MPPI_DET_PKFMA(x2[k], q[k], MPPI_DET_SPLAT(4.89352518554385e-03f));
+    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(MPPI_DET_TANH_P3));
+    q[k] = MPPI_DET_PKFMA(x2[k], q[k], MPPI_DET_SPLAT(MPPI_DET_TANH_C0));
   }
 #pragma unroll
   MPPI_DET_ALL
   {
-    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(1.48572235717979e-05f));
+    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(MPPI_DET_TANH_P2));
     r[k] = f32x2{ __builtin_amdgcn_rcpf(q[k].x), __builtin_amdgcn_rcpf(q[k].y) };
   }
 #pragma unroll
   MPPI_DET_ALL
   {
-    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(6.37261928875436e-04f));
+    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(MPPI_DET_TANH_P1));
     y[k] = MPPI_DET_PKFMA(-q[k], r[k], MPPI_DET_SPLAT(1.0f));  // e
   }
 #pragma unroll
   MPPI_DET_ALL
   {
-    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(4.89352455891786e-03f));
+    p[k] = MPPI_DET_PKFMA(x2[k], p[k], MPPI_DET_SPLAT(MPPI_DET_TANH_C0));
     r[k] = MPPI_DET_PKFMA(y[k], r[k], r[k]);
   }
 #pragma unroll
@@ -494,8 +517,8 @@ __device__ inline void tanh_pairs(float (&v)[2 * NP])
 #pragma unroll
   MPPI_DET_ALL
   {
-    v[2 * k] = (fabs(x[k].x) >= 1.220703125e-4f) ? y[k].x : x[k].x;
-    v[2 * k + 1] = (fabs(x[k].y) >= 1.220703125e-4f) ? y[k].y : x[k].y;
+    v[2 * k] = y[k].x;
+    v[2 * k + 1] = y[k].y;
   }
 #undef MPPI_DET_ALL
 #undef MPPI_DET_PKFMA
