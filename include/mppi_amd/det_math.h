@@ -582,10 +582,34 @@ MPPI_HD static inline void sigmoid_n(float (&v)[N])
     v[i] = (1.0f + v[i]) / 2.0f;
 }
 
-/** sigmoid_n with the tanh evaluated in lockstep (tanh_n_lockstep): the same bits */
+/** sigmoid_n with the tanh evaluated in lockstep (tanh_n_lockstep): the same bits.  (1 + t) / 2 is evaluated as
+ *  fma(t, 0.5, 0.5): halving is exact, so RN(1 + t) / 2 == RN((1 + t) / 2) == RN(0.5 t + 0.5) — one instruction instead of
+ *  two, and on the device two values per packed instruction like the halving of the argument. */
 template <int N>
 MPPI_HD static inline void sigmoid_n_lockstep(float (&v)[N])
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2)
+  {
+    const f32x2 h = f32x2{ v[i], v[i + 1] } * f32x2{ 0.5f, 0.5f };
+    v[i] = h.x;
+    v[i + 1] = h.y;
+  }
+  if (N & 1)
+    v[N - 1] = v[N - 1] * 0.5f;
+  tanh_n_lockstep<N>(v);
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2)
+  {
+    const f32x2 s2 = __builtin_elementwise_fma(f32x2{ v[i], v[i + 1] }, f32x2{ 0.5f, 0.5f }, f32x2{ 0.5f, 0.5f });
+    v[i] = s2.x;
+    v[i + 1] = s2.y;
+  }
+  if (N & 1)
+    v[N - 1] = fma(v[N - 1], 0.5f, 0.5f);
+#else
 #pragma unroll
   for (int i = 0; i < N; i++)
     v[i] = v[i] / 2.0f;
@@ -593,6 +617,7 @@ MPPI_HD static inline void sigmoid_n_lockstep(float (&v)[N])
 #pragma unroll
   for (int i = 0; i < N; i++)
     v[i] = (1.0f + v[i]) / 2.0f;
+#endif
 }
 
 /** atan(x), Cephes atanf structure. */

@@ -447,13 +447,19 @@ __host__ __device__ inline int samplerGrdBytes(const SAMPLING_T* smp)
 }
 
 /** helper waves of rolloutPipelineRepKernel: a block of REP = 4 dynamics waves puts one on each SIMD of the CU and every SIMD
- *  gets one helper wave next to it.  The SIMD is the unit that saturates (measured with the in-kernel timers of
- *  tools/pipe_timing.py, round 3: fp32 MFMA and fp32 VALU share the SIMD's multipliers, their cycles ADD whichever wave
- *  issues them), so the helper work is dealt so that the four SIMDs carry about the same: per step and block of 64 rollouts
- *  the cost role is ~1550 issue cycles (ARStandardCost), the sampler role ~480 — ONE sampler wave and THREE cost waves
- *  (~500 cycles per SIMD and step each) instead of two and two (240 / 775: the SIMDs hosting a cost wave set the pace). */
-constexpr int PIPE_REP_SAMPLERS = 1;
-constexpr int PIPE_REP_COSTS = 3;
+ *  gets one helper wave next to it.  The SIMD is the unit that saturates (in-kernel timers, tools/pipe_timing.py, round 3:
+ *  fp32 MFMA and fp32 VALU share the SIMD's multipliers — their cycles ADD whichever wave issues them), so no helper may
+ *  need the whole launch.  Measured for AutoRally-NN (K = 16384, T = 150; s_memtime ticks per launch, the dynamics waves
+ *  work 389 k of them): ONE sampler wave is busy for 417 k ticks — it sets the pace — and a cost wave of THREE for 217 k;
+ *  TWO samplers 205 k each, a cost wave of TWO 343 k.  Two and two it is (185.4 us per launch against 187.9 with one and
+ *  three); the cost waves evaluate ahead of their relay, so they work concurrently either way.  A/B builds:
+ *  -DMPPI_PIPE_REP_NS=.. -DMPPI_PIPE_REP_NC=.. */
+#if !defined(MPPI_PIPE_REP_NS)
+#define MPPI_PIPE_REP_NS 2
+#define MPPI_PIPE_REP_NC 2
+#endif
+constexpr int PIPE_REP_SAMPLERS = MPPI_PIPE_REP_NS;
+constexpr int PIPE_REP_COSTS = MPPI_PIPE_REP_NC;
 
 template <class DYN_T, class COST_T, class SAMPLING_T>
 __host__ inline size_t pipelineRepSharedBytes(const DYN_T& dyn, const COST_T& cost, const SAMPLING_T& smp, int ring)

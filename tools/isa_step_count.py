@@ -24,6 +24,8 @@ KERNELS = [
      4, "valu_pk"),
     ("autorally_mfma_pipeline_dynamics_wave", "autorally_nn.hip", ["rolloutPipelineRepKernel", "NeuralNetModelMFMA", "ELb1E"],
      None, "mfma"),
+    ("lstm_mfma_pipeline_dynamics_wave", "bicycle_slip_lstm.hip", ["rolloutPipelineRepKernel", "BicycleSlipLSTMMFMA", "ELb1E"],
+     None, "mfma"),
 ]
 
 
@@ -72,8 +74,9 @@ def main():
             res[key] = {"error": "no loop with %s instructions" % marker, "kernel": name[:160]}
             continue
         _, ops, c = best
-        if steps is None:  # MFMA network: 28 v_mfma per step and wave (7 + 16 + 4 tiles + 1)
-            steps = max(1, round(c["mfma"] / 28))
+        if steps is None:  # MFMA networks: 28 v_mfma per step and wave for the AutoRally MLP, 44 for the LSTM + MLP
+            per_step = 44 if "LSTM" in name else 28
+            steps = max(1, round(c["mfma"] / per_step))
         vec = sum(v for k, v in c.items() if k in ("valu", "valu_pk", "valu_cmpsel", "trans", "xlane", "mfma"))
         res[key] = {"kernel": name[:200], "loop_instructions": len(ops), "steps_per_trip": steps,
                     "instructions_per_step": round(len(ops) / steps, 2),

@@ -37,7 +37,9 @@ def main():
     assert n == len(buf), n
     t = np.frombuffer(buf, np.uint64).reshape(BLOCKS, WAVES, SLOTS).astype(np.float64)
     used = [w for w in range(WAVES) if t[:, w].sum() > 0]
-    ns, nc = 1, 3  # PIPE_REP_SAMPLERS / PIPE_REP_COSTS of rollout_pipeline_kernel.hpp: dynamics waves, then samplers, then cost waves
+    # PIPE_REP_SAMPLERS / PIPE_REP_COSTS of rollout_pipeline_kernel.hpp (A/B builds: PIPE_NS / PIPE_NC): dynamics waves, then
+    # samplers, then cost waves
+    ns, nc = int(os.environ.get("PIPE_NS", "2")), int(os.environ.get("PIPE_NC", "2"))
     dw = len(used) - ns - nc
     ticks_per_us = float(t[:, :dw, :3].sum(axis=2).mean()) / (roll / 50 * 1e3)  # a dynamics wave is busy for the whole launch
     out = {"workload": "AutoRally-NN K=16384 T=150, rolloutPipelineRepKernel, %d dynamics + %d sampler + %d cost waves per block"
