@@ -399,18 +399,37 @@ struct ModelT : ModelBase
     }
     return ModelBase::setFeedbackGains(gains, T, accumulate_all_states, stream, err);
   }
-  /** Robust MPPI runs a model with a replicated-lane form on that form only: networks of another shape rule it out */
-  bool rmppiFormUsable(std::string& err) const
+  /** Robust MPPI's two kernels run on the replicated-lane (FAST) form of a model when there is one — and when it is usable:
+   *  the four-lane forms of the RACER models are compiled for the reference's network shapes, a network of another shape
+   *  (`register_form_` false) runs the kernels on the model itself, one lane per rollout and system (round 3; it used to be
+   *  refused).  f(rm_dyn) is called with the object the kernels take. */
+  static constexpr bool RMPPI_HAS_FALLBACK = has_register_form<DYN_T>::value && !std::is_void<DYN_FAST_T>::value;
+  bool rmppiUseFast() const
   {
-    if constexpr (has_register_form<DYN_T>::value && !std::is_void<DYN_FAST_T>::value)
+    if constexpr (std::is_void<DYN_FAST_T>::value)
+      return false;
+    else if constexpr (has_register_form<DYN_T>::value)
+      return dyn.register_form_;
+    else
+      return true;
+  }
+  template <class F>
+  auto withRmppiDynamics(F&& f)
+  {
+    if constexpr (std::is_void<DYN_FAST_T>::value)
+      return f(dyn);
+    else if constexpr (RMPPI_HAS_FALLBACK)
     {
       if (!dyn.register_form_)
-      {
-        err = "Robust MPPI runs this model on its replicated-lane form, which exists for the default network shapes only";
-        return false;
-      }
+        return f(dyn);
+      DYN_FAST_T fast(dyn);
+      return f(fast);
     }
-    return true;
+    else
+    {
+      DYN_FAST_T fast(dyn);
+      return f(fast);
+    }
   }
   size_t rmppiSharedBytes(int bx, int T) override
   {
@@ -418,13 +437,7 @@ struct ModelT : ModelBase
     {
       smp.params_.num_timesteps = T;
       smp.params_.num_distributions = 2;
-      if constexpr (!std::is_void<DYN_FAST_T>::value)
-      {
-        DYN_FAST_T fast(dyn);
-        return kernels::rmppiSharedBytes(fast, cost, fb, smp, bx);
-      }
-      else
-        return kernels::rmppiSharedBytes(dyn, cost, fb, smp, bx);
+      return withRmppiDynamics([&](auto& rm_dyn) { return kernels::rmppiSharedBytes(rm_dyn, cost, fb, smp, bx); });
     }
     return 0;
   }
@@ -435,27 +448,26 @@ struct ModelT : ModelBase
     {
       if (!blobsReady(err))
         return MPPI_ERR_STATE;
-      if (!rmppiFormUsable(err))
-        return MPPI_ERR_LAUNCH_SHAPE;
       prepSampler(s);
       constexpr int BX = 64;
-      // models with replicated-lane (MFMA) dynamics run both Robust MPPI kernels on them
-      using RM_DYN_T = std::conditional_t<std::is_void<DYN_FAST_T>::value, DYN_T, DYN_FAST_T>;
-      constexpr int REP = kernels::replicated_lanes<RM_DYN_T>::value;
-      RM_DYN_T rm_dyn(dyn);
-      const size_t smem = kernels::initEvalSharedBytes<RM_DYN_T, COST_T, SAMPLING_T>(rm_dyn, cost, BX);
-      auto kfn = kernels::initEvalKernel<RM_DYN_T, COST_T, SAMPLING_T, BX>;
-      if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL(kfn, dim3((a.num_eval_rollouts + BX - 1) / BX), dim3(BX * REP, 1, 1), smem, stream, rm_dyn, cost,
-                         smp, a);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess)
-      {
-        err = std::string("initEvalKernel launch: ") + hipGetErrorString(e);
-        return MPPI_ERR_HIP;
-      }
-      return MPPI_OK;
+      // models with replicated-lane (MFMA / four-lane) dynamics run both Robust MPPI kernels on them (withRmppiDynamics)
+      return withRmppiDynamics([&](auto& rm_dyn) -> mppi_status {
+        using RM_DYN_T = std::decay_t<decltype(rm_dyn)>;
+        constexpr int REP = kernels::replicated_lanes<RM_DYN_T>::value;
+        const size_t smem = kernels::initEvalSharedBytes<RM_DYN_T, COST_T, SAMPLING_T>(rm_dyn, cost, BX);
+        auto kfn = kernels::initEvalKernel<RM_DYN_T, COST_T, SAMPLING_T, BX>;
+        if (smem > 48 * 1024)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kfn, dim3((a.num_eval_rollouts + BX - 1) / BX), dim3(BX * REP, 1, 1), smem, stream, rm_dyn, cost,
+                           smp, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+        {
+          err = std::string("initEvalKernel launch: ") + hipGetErrorString(e);
+          return MPPI_ERR_HIP;
+        }
+        return MPPI_OK;
+      });
     }
     return ModelBase::launchInitEval(a, s, stream, err);
   }
@@ -464,29 +476,30 @@ struct ModelT : ModelBase
   {
     if constexpr (RMPPI)
     {
-      using RM_DYN_T = std::conditional_t<std::is_void<DYN_FAST_T>::value, DYN_T, DYN_FAST_T>;
-      constexpr int REP = kernels::replicated_lanes<RM_DYN_T>::value;
-      RM_DYN_T rm_dyn(dyn);
-      const size_t smem = kernels::rmppiSharedBytes(rm_dyn, cost, fb, smp, BX);
-      if (smem > MAX_LDS_BYTES)
-      {
-        err = "RMPPI rollout kernel needs " + std::to_string(smem) + " B of LDS per block; gfx950 has 163840";
-        return MPPI_ERR_LDS_OVERFLOW;
-      }
-      const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
-      auto kfn = in_loop ? kernels::rolloutRMPPIKernel<RM_DYN_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, BX, SAMPLING_T::IN_LOOP_DRAW>
-                         : kernels::rolloutRMPPIKernel<RM_DYN_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, BX, false>;
-      if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL(kfn, dim3((a.base.num_rollouts + BX - 1) / BX), dim3(BX * REP, 1, 2), smem, stream, rm_dyn, cost, fb,
-                         smp, a);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess)
-      {
-        err = std::string("rolloutRMPPIKernel launch: ") + hipGetErrorString(e);
-        return MPPI_ERR_HIP;
-      }
-      return MPPI_OK;
+      return withRmppiDynamics([&](auto& rm_dyn) -> mppi_status {
+        using RM_DYN_T = std::decay_t<decltype(rm_dyn)>;
+        constexpr int REP = kernels::replicated_lanes<RM_DYN_T>::value;
+        const size_t smem = kernels::rmppiSharedBytes(rm_dyn, cost, fb, smp, BX);
+        if (smem > MAX_LDS_BYTES)
+        {
+          err = "RMPPI rollout kernel needs " + std::to_string(smem) + " B of LDS per block; gfx950 has 163840";
+          return MPPI_ERR_LDS_OVERFLOW;
+        }
+        const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
+        auto kfn = in_loop ? kernels::rolloutRMPPIKernel<RM_DYN_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, BX, SAMPLING_T::IN_LOOP_DRAW>
+                           : kernels::rolloutRMPPIKernel<RM_DYN_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, BX, false>;
+        if (smem > 48 * 1024)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kfn, dim3((a.base.num_rollouts + BX - 1) / BX), dim3(BX * REP, 1, 2), smem, stream, rm_dyn, cost, fb,
+                           smp, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+        {
+          err = std::string("rolloutRMPPIKernel launch: ") + hipGetErrorString(e);
+          return MPPI_ERR_HIP;
+        }
+        return MPPI_OK;
+      });
     }
     err = "model is not registered for Robust MPPI";
     return MPPI_ERR_UNSUPPORTED;
@@ -503,8 +516,6 @@ struct ModelT : ModelBase
         err = "Robust MPPI needs the DDP feedback gains [T][S][C] (mppi_set_feedback_gains) before it can run";
         return MPPI_ERR_STATE;
       }
-      if (!rmppiFormUsable(err))
-        return MPPI_ERR_LAUNCH_SHAPE;
       prepSampler(s);
       if (bx == 64)
         return launchRMPPIShape<64>(a, stream, err);

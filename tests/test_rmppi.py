@@ -298,9 +298,12 @@ def test_rmppi_error_paths(gpu):
 
 
 @pytest.mark.gpu
-def test_rmppi_refuses_networks_the_four_lane_form_is_not_compiled_for(gpu):
-    """Robust MPPI runs the elevation-map RACER models on their four-lanes-per-rollout form, which exists for the default
-    network shapes: another steering network ("lstm_structure") is an error, not a silent wrong answer"""
+@pytest.mark.parametrize("mode", ["injected", "philox"])
+def test_rmppi_runs_networks_of_other_shapes_on_the_one_lane_form(gpu, mode):
+    """Robust MPPI runs the elevation-map RACER models on their four-lanes-per-rollout form, which is compiled for the
+    reference's network shapes; a steering network of another shape ("lstm_structure") used to be refused — since round 3 both
+    Robust kernels then run on the model itself, one lane per rollout and system (ModelT::withRmppiDynamics): costs of both
+    systems and the written-back controls against the oracle, bit for bit"""
     cfg = _rm_cfg("lstm_steering", K=512, T=12)
     Hn = 6
     rng = np.random.default_rng(3)
@@ -309,8 +312,38 @@ def test_rmppi_refuses_networks_the_four_lane_form_is_not_compiled_for(gpu):
     blobs["lstm_weights"] = rng.uniform(-0.4, 0.4, 4 * Hn * Hn + 4 * Hn * 4 + 6 * Hn).astype(np.float32)
     blobs["lstm_output_weights"] = rng.uniform(-0.4, 0.4, (Hn + 4) * 12 + 12 + 12 + 1).astype(np.float32)
     cfg["blobs"] = dict(sorted(blobs.items(), key=lambda kv: 0 if kv[0] == "lstm_structure" else 1))
-    eng, _, _ = _make_pair(cfg)
-    eng.setFeedbackGains(_gains(cfg["T"], eng.STATE_DIM, eng.CONTROL_DIM), False)
-    with pytest.raises(m.MPPIError) as e:
-        eng.computeControl(cfg["x0"], 1)
-    assert "default network shapes" in str(e.value)
+    eng, orc, rob = _make_pair(cfg, thr=40.0, save_samples=True)
+    S, C, T, K = eng.STATE_DIM, eng.CONTROL_DIM, cfg["T"], cfg["K"]
+    g = _gains(T, S, C)
+    eng.setFeedbackGains(g, False)
+    rob.set_gains(g, False)
+    mean = (0.3 * np.sin(np.arange(T * C, dtype=np.float32) * 0.2)).reshape(T, C)
+    eng.updateImportanceSampler(mean)
+    if mode == "injected":
+        eps = host_noise(1, K, T, C)[0]
+        eng.injectNoise(eps)
+    else:
+        eps = po.philox_normal(42, 0, K, T, C)
+    dx = np.zeros(S, np.float32)
+    dx[:7] = [0.3, -0.2, 0.1, 0.05, 0.02, 0.01, 0.0]
+    x0 = np.stack([cfg["x0"], cfg["x0"] + dx])
+    got = eng.rolloutCosts(x0, 2)
+    means = np.tile(mean, (2, 1, 1))
+    v = orc.set_gaussian_controls(means, eps, 2, 0)
+    want, v_fb = rob.rollout_costs(x0, means, v)
+    assert np.isfinite(got).all()
+    assert ulp_diff(got, want).max() == 0
+    assert ulp_diff(eng.getSampledControls(), v_fb).max() == 0
+    # and a whole computeControl (candidate evaluation + rollout + post-processing) runs on that form
+    eng2, orc2, rob2 = _make_pair(cfg, thr=2000.0)
+    e3 = host_noise(2, K, T, C, seed=9)
+    eng2.injectNoise(e3[1:])
+    eng2.updateImportanceSamplingControl(cfg["x0"], 1)
+    rob2.update_importance_sampling(cfg["x0"], 1, e3[0])
+    eng2.setFeedbackGains(g, False)
+    rob2.set_gains(g, False)
+    eng2.computeControl(cfg["x0"], 1)
+    rob2.compute_control(cfg["x0"], 1, e3[1:])
+    assert np.abs(eng2.getControlSeq() - orc2.control()).max() <= U_TOL
+    eng.close()
+    eng2.close()
