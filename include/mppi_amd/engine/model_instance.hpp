@@ -22,6 +22,7 @@
 #include "finalize_kernel.hpp"
 #include "rollout_pipeline_kernel.hpp"
 #include "rmppi_kernels.hpp"
+#include "rmppi_pipeline_kernel.hpp"
 #include "mppi_amd/feedback_controllers/ddp_feedback.hpp"
 #include "mppi_amd/sampling_distributions/colored_noise.hpp"
 
@@ -125,13 +126,21 @@ struct ModelBase
     err = "model is not instantiated for Robust MPPI";
     return MPPI_ERR_UNSUPPORTED;
   }
-  virtual mppi_status launchRMPPI(int bx, const kernels::RMPPIArgs& a, const SamplerLaunchState& s, hipStream_t stream,
-                                  std::string& err)
+  /** pipeline: the role-pipelined kernel (rmppi_pipeline_kernel.hpp) when the model has one and its replicated-lane form is
+   *  usable with the loaded networks, else rolloutRMPPIKernel */
+  virtual mppi_status launchRMPPI(int bx, bool pipeline, const kernels::RMPPIArgs& a, const SamplerLaunchState& s,
+                                  hipStream_t stream, std::string& err)
   {
     err = "model is not instantiated for Robust MPPI";
     return MPPI_ERR_UNSUPPORTED;
   }
   virtual size_t rmppiSharedBytes(int bx, int T)
+  {
+    return 0;
+  }
+  /** LDS request of the role-pipelined Robust MPPI kernel (64 rollouts x 2 systems per block); 0: the model has none, its
+   *  replicated-lane form does not take the loaded networks, or not even the shortest rings fit */
+  virtual size_t rmppiPipelineSharedBytes(int T)
   {
     return 0;
   }
@@ -187,7 +196,7 @@ struct ModelBase
 /** bumped BY HAND whenever ModelBase's virtual methods are added, removed or reordered or a field of an argument struct is
  *  swapped at equal size — changes sizeof() cannot see (a stale plugin would dispatch to the wrong vtable slot).
  *  3: round 3 (rows-in-HBM / release-flag arguments). */
-#define MPPI_ENGINE_ABI_VERSION 3
+#define MPPI_ENGINE_ABI_VERSION 4
 
 constexpr int engineAbiFingerprint()
 {
@@ -441,6 +450,59 @@ struct ModelT : ModelBase
     }
     return 0;
   }
+  /** the role-pipelined Robust MPPI kernel exists for models with a replicated-lane form and a sampler whose rows may live
+   *  in HBM and need no block-wide prologue of their own (the Gaussian sampler) */
+  static constexpr bool rmppiHasPipeline()
+  {
+    if constexpr (RMPPI && !std::is_void<DYN_FAST_T>::value)
+      return kernels::replicated_lanes<DYN_FAST_T>::value > 1 && SAMPLING_T::SUPPORTS_GLOBAL_ROWS && !SAMPLING_T::COLORED;
+    else
+      return false;
+  }
+  size_t rmppiPipelineSharedBytes(int T) override
+  {
+    if constexpr (rmppiHasPipeline())
+    {
+      if (!rmppiUseFast())
+        return 0;
+      smp.params_.num_timesteps = T;
+      smp.params_.num_distributions = 2;
+      DYN_FAST_T fast(dyn);
+      const kernels::RMPPIPipeRings r = kernels::rmppiPipelineRings(fast, cost, fb, smp, MAX_LDS_BYTES);
+      return r.out_steps ? kernels::rmppiPipelineSharedBytes(fast, cost, fb, smp, r) : 0;
+    }
+    return 0;
+  }
+  mppi_status launchRMPPIPipeline(const kernels::RMPPIArgs& a, hipStream_t stream, std::string& err)
+  {
+    if constexpr (rmppiHasPipeline())
+    {
+      DYN_FAST_T fast(dyn);
+      const kernels::RMPPIPipeRings r = kernels::rmppiPipelineRings(fast, cost, fb, smp, MAX_LDS_BYTES);
+      if (r.out_steps == 0)
+      {
+        err = "pipelined RMPPI rollout kernel: the rings do not fit 160 KiB of LDS next to the sample rows";
+        return MPPI_ERR_LDS_OVERFLOW;
+      }
+      const size_t smem = kernels::rmppiPipelineSharedBytes(fast, cost, fb, smp, r);
+      const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
+      auto kfn = in_loop ? kernels::rolloutRMPPIPipelineKernel<DYN_FAST_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, SAMPLING_T::IN_LOOP_DRAW>
+                         : kernels::rolloutRMPPIPipelineKernel<DYN_FAST_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, false>;
+      if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(kfn, dim3((a.base.num_rollouts + 63) / 64), dim3(64 * kernels::rmppiPipelineWaves<DYN_FAST_T>(), 1, 1),
+                         smem, stream, fast, cost, fb, smp, a, r);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess)
+      {
+        err = std::string("rolloutRMPPIPipelineKernel launch: ") + hipGetErrorString(e);
+        return MPPI_ERR_HIP;
+      }
+      return MPPI_OK;
+    }
+    err = "model has no role-pipelined Robust MPPI kernel";
+    return MPPI_ERR_LAUNCH_SHAPE;
+  }
   mppi_status launchInitEval(const kernels::InitEvalArgs& a, const SamplerLaunchState& s, hipStream_t stream,
                              std::string& err) override
   {
@@ -504,7 +566,7 @@ struct ModelT : ModelBase
     err = "model is not registered for Robust MPPI";
     return MPPI_ERR_UNSUPPORTED;
   }
-  mppi_status launchRMPPI(int bx, const kernels::RMPPIArgs& a, const SamplerLaunchState& s, hipStream_t stream,
+  mppi_status launchRMPPI(int bx, bool pipeline, const kernels::RMPPIArgs& a, const SamplerLaunchState& s, hipStream_t stream,
                           std::string& err) override
   {
     if constexpr (RMPPI)
@@ -517,6 +579,11 @@ struct ModelT : ModelBase
         return MPPI_ERR_STATE;
       }
       prepSampler(s);
+      if constexpr (rmppiHasPipeline())
+      {
+        if (pipeline && bx == 64 && rmppiUseFast())
+          return launchRMPPIPipeline(a, stream, err);
+      }
       if (bx == 64)
         return launchRMPPIShape<64>(a, stream, err);
       if (bx == 32)  // horizons whose sample rows for 64 rollouts x 2 systems do not fit the LDS
@@ -524,7 +591,7 @@ struct ModelT : ModelBase
       err = "Robust MPPI rollout kernel is instantiated for 64 or 32 rollouts per block";
       return MPPI_ERR_LAUNCH_SHAPE;
     }
-    return ModelBase::launchRMPPI(bx, a, s, stream, err);
+    return ModelBase::launchRMPPI(bx, pipeline, a, s, stream, err);
   }
 
   bool supportsPipeline() const override

@@ -7,7 +7,7 @@ classes (same method names) on top of those entry points so tests read like the 
 from . import buildlib as _buildlib
 from .buildlib import build
 from .capi import (MppiTexture2dParams, MppiConfig, MppiGaussianParams, MppiStats, MppiSystemStats, SIGNATURES, library_path, load_library)
-from .controllers import (MPPI_CONTROLLER_TUBE, MPPI_CONTROLLER_VANILLA, MPPI_NOISE_INJECTED, MPPI_NOISE_PHILOX_FUSED,
+from .controllers import (MPPI_KERNEL_AUTO, MPPI_KERNEL_FUSED, MPPI_KERNEL_PIPELINE, MPPI_CONTROLLER_TUBE, MPPI_CONTROLLER_VANILLA, MPPI_NOISE_INJECTED, MPPI_NOISE_PHILOX_FUSED,
                           MPPIError, MPPIController, TubeMPPIController, VanillaMPPIController, ColoredMPPIController, RobustMPPIController,
                           MPPI_CONTROLLER_COLORED, CartpoleDynamicsParams,
                           CartpoleQuadraticCostParams, DoubleIntegratorParams, DoubleIntegratorCircleCostParams,

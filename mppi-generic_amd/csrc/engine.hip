@@ -97,6 +97,7 @@ struct mppi_handle_s
   float* eps_d = nullptr;          // [n_eps_iters][K_local][T][C]
   float* samples_d = nullptr;      // [D][K_local][T][C]
   float* rows_d = nullptr;         // [num_blocks][bx * bz][rowStride]: the sampler's rows when they do not fit the LDS
+  bool rm_pipeline = false;        // Robust MPPI: ask the model for its role-pipelined rollout kernel (rows in HBM, bx = 64)
   bool rows_in_hbm = false;
   /* ColoredMPPI options (controllers/ColoredMPPI/colored_mppi_controller.cuh:18-22, 159-193): Tsallis weights and state leash */
   float tsallis_gamma = 0.0f, tsallis_r = 0.0f;
@@ -467,6 +468,26 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     if (cfg->block_x == 0 && h->model->rmppiSharedBytes(64, cfg->num_timesteps) > MAX_LDS_BYTES)
       h->bx = 32;
   }
+  if (cfg->controller == MPPI_CONTROLLER_ROBUST && cfg->kernel_variant != MPPI_KERNEL_FUSED &&
+      (cfg->block_x == 0 || cfg->block_x == 64) && h->model->globalRowsFloats(1, 1, cfg->num_timesteps) > 0)
+  {
+    // replicated-lane (MFMA / four-lane) dynamics: the role-pipelined kernel (rmppi_pipeline_kernel.hpp), 64 rollouts x 2
+    // systems per block with the sample rows in HBM — the rings take their place in the LDS
+    h->model->setGlobalRows(reinterpret_cast<float*>(16));  // placeholder until the buffer exists: sizes the LDS request
+    const size_t need = h->model->rmppiPipelineSharedBytes(cfg->num_timesteps);
+    if (need > 0 && need <= MAX_LDS_BYTES)
+    {
+      h->rm_pipeline = true;
+      h->rows_in_hbm = true;
+      h->bx = 64;
+    }
+    else
+      h->model->setGlobalRows(nullptr);
+  }
+  if (cfg->controller == MPPI_CONTROLLER_ROBUST && cfg->kernel_variant == MPPI_KERNEL_PIPELINE && !h->rm_pipeline)
+    return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
+                "mppi_create: the pipelined Robust MPPI kernel needs a model with replicated-lane (MFMA / four-lane) dynamics, the "
+                "Gaussian sampler and block_x 0 or 64");
   // Tube with a pipeline-capable model and no explicit shape: fold the two systems into the lanes of a wave (32, 1, 2)
   if (h->D == 2 && cfg->controller == MPPI_CONTROLLER_TUBE && cfg->block_x == 0 && cfg->block_y == 0 &&
       cfg->kernel_variant != MPPI_KERNEL_FUSED && h->model->supportsPipelineFold(32, 1, 2) &&
@@ -506,7 +527,7 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
                        ((h->model->supportsPipeline() && h->bx == 64 && h->by == 1) ||
                         h->model->supportsPipelineFold(h->bx, h->by, h->bz) ||
                         h->model->supportsPipelineRep(h->bx, h->by, h->bz));
-  if (cfg->kernel_variant == MPPI_KERNEL_PIPELINE && !pipe_ok)
+  if (cfg->kernel_variant == MPPI_KERNEL_PIPELINE && !pipe_ok && !h->rm_pipeline)
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
                 "mppi_create: the pipeline variant needs a model registered for it and block shape (64, 1), or (64, REP, 1) "
                 "for replicated-lane (MFMA) dynamics");
@@ -520,7 +541,7 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, false);
   }
   const char* force_hbm_rows = getenv("MPPI_AMD_ROWS_IN_HBM");  // test hook: the HBM-row variant at any horizon
-  const bool want_hbm_rows = lds > MAX_LDS_BYTES || (force_hbm_rows && force_hbm_rows[0] == '1');
+  const bool want_hbm_rows = !h->rm_pipeline && (lds > MAX_LDS_BYTES || (force_hbm_rows && force_hbm_rows[0] == '1'));
   if (want_hbm_rows && cfg->controller == MPPI_CONTROLLER_ROBUST && h->model->globalRowsFloats(1, 1, cfg->num_timesteps) > 0)
   {
     // Robust MPPI at horizons whose rows of even 32 rollouts x 2 systems overflow the LDS (or on request): the (64, 1, 2)
@@ -1355,7 +1376,7 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
     kernels::RMPPIArgs ra{};
     ra.base = a;
     ra.value_function_threshold = h->value_function_threshold;
-    st = h->model->launchRMPPI(h->bx, ra, s, h->stream, err);
+    st = h->model->launchRMPPI(h->bx, h->rm_pipeline, ra, s, h->stream, err);
   }
   else
   {

@@ -141,8 +141,46 @@ def test_rmppi_rollout_zero_gains_identical_systems():
                                                 ("suspension", False, "injected"), ("suspension", True, "philox"),
                                                 ("complete", False, "injected"), ("complete", True, "philox")])
 def test_rmppi_rollout_costs_bit_exact(gpu, model, acc_all, mode):
-    cfg = _rm_cfg(model, K=1000, T=37)  # ragged last block, odd horizon
-    eng, orc, rob = _make_pair(cfg, thr=40.0, save_samples=True)
+    _rollout_costs_bit_exact(model, acc_all, mode)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,K,T,mode,variant", [("autorally", 1000, 37, "injected", m.MPPI_KERNEL_FUSED),
+                                                     ("autorally", 1000, 37, "philox", m.MPPI_KERNEL_FUSED),
+                                                     ("suspension", 1000, 37, "philox", m.MPPI_KERNEL_FUSED),
+                                                     ("autorally", 330, 150, "philox", m.MPPI_KERNEL_PIPELINE),
+                                                     ("autorally", 320, 3, "injected", m.MPPI_KERNEL_PIPELINE),
+                                                     ("autorally", 300, 1, "philox", m.MPPI_KERNEL_PIPELINE),
+                                                     ("lstm", 1000, 37, "philox", m.MPPI_KERNEL_PIPELINE)])
+def test_rmppi_rollout_costs_bit_exact_both_kernels(gpu, model, K, T, mode, variant):
+    """models with replicated-lane dynamics run the role-pipelined kernel (rmppi_pipeline_kernel.hpp) by default; the fused
+    rolloutRMPPIKernel stays available (kernel_variant) and both give the oracle's bits — also at the benchmark horizon, at
+    horizons shorter than a sampler trip and the rings, and with blocks of one partly filled wave"""
+    _rollout_costs_bit_exact(model, False, mode, K=K, T=T, kernel_variant=variant)
+
+
+@pytest.mark.gpu
+def test_rmppi_pipelined_kernel_independent_noise(gpu):
+    """use_same_noise_for_all_distributions off: the sampler waves draw one Philox stream per system; fused == pipelined"""
+    cfg = _rm_cfg("autorally", K=512, T=20)
+    got = []
+    for variant in (m.MPPI_KERNEL_FUSED, m.MPPI_KERNEL_PIPELINE):
+        eng, orc, rob = _make_pair(cfg, thr=40.0, save_samples=True, kernel_variant=variant)
+        g = _gains(cfg["T"], eng.STATE_DIM, eng.CONTROL_DIM)
+        eng.setFeedbackGains(g, False)
+        eng.setIndependentNoise(True)
+        x0 = np.stack([cfg["x0"], cfg["x0"] + np.float32(0.05)])
+        got.append((eng.rolloutCosts(x0, 2).copy(), eng.getSampledControls().copy()))
+        eng.close()
+    assert np.isfinite(got[0][0]).all()
+    assert ulp_diff(got[0][0], got[1][0]).max() == 0
+    assert ulp_diff(got[0][1], got[1][1]).max() == 0
+    assert np.abs(got[0][1][0] - got[0][1][1]).max() > 1e-3  # the two systems really drew different noise
+
+
+def _rollout_costs_bit_exact(model, acc_all, mode, K=1000, T=37, **kw):
+    cfg = _rm_cfg(model, K=K, T=T)  # default: ragged last block, odd horizon
+    eng, orc, rob = _make_pair(cfg, thr=40.0, save_samples=True, **kw)
     S, C, T, K = eng.STATE_DIM, eng.CONTROL_DIM, cfg["T"], cfg["K"]
     g = _gains(T, S, C)
     eng.setFeedbackGains(g, acc_all)
