@@ -37,12 +37,16 @@ namespace mppi
 {
 namespace kernels
 {
-/* helper waves per block; A/B builds: -DMPPI_RMPPI_PIPE_NS=.. -DMPPI_RMPPI_PIPE_NC=.. (cost waves PER SYSTEM) */
+/* helper waves per block; A/B builds: -DMPPI_RMPPI_PIPE_NS=.. -DMPPI_RMPPI_PIPE_NC=.. (cost waves PER SYSTEM).
+ * AutoRally-NN, K = 16384, T = 150, Robust computeControl (tools/robust_latency.py, one session): NS / NC = 2 / 2 690 us,
+ * 1 / 2 684, 2 / 1 736, 2 / 3 637; after the last-state feedback path 2 / 2 640, 1 / 3 622, 2 / 3 624.  The cost waves'
+ * chain (a pair of steps is evaluated by one wave) is what a third wave per system shortens; one sampler keeps up with both
+ * systems (one Philox draw per pair of steps serves both).  15 waves = 960 threads per block. */
 #if !defined(MPPI_RMPPI_PIPE_NS)
-#define MPPI_RMPPI_PIPE_NS 2
+#define MPPI_RMPPI_PIPE_NS 1
 #endif
 #if !defined(MPPI_RMPPI_PIPE_NC)
-#define MPPI_RMPPI_PIPE_NC 2
+#define MPPI_RMPPI_PIPE_NC 3
 #endif
 constexpr int RMPPI_PIPE_SAMPLERS = MPPI_RMPPI_PIPE_NS;
 constexpr int RMPPI_PIPE_COSTS = MPPI_RMPPI_PIPE_NC;
@@ -92,6 +96,36 @@ __host__ inline RMPPIPipeRings rmppiPipelineRings(const DYN_T& dyn, const COST_T
       return r;
   }
   return RMPPIPipeRings{ 0, 0, 0 };
+}
+
+/**
+ * The REP replica lanes of a rollout hold the same N values; replica r stores the fields r, r + REP, ... at
+ * base[field * 64] (fields past the end: field j * REP again, same value).  Every lane of the wave stays active and the
+ * stores of a replica group go to distinct addresses.  The dynamics waves of this kernel contain NO region that only the
+ * lanes of one replica execute (`if (rep_lane == 0) store`): the kernel runs at the register limit of a 1024-thread block and
+ * spills, and with the suspension / complete RACER models a register reloaded inside such a region — valid in the lanes
+ * active there only — was used again by all lanes after it: the covariance rows the replicas 1..3 computed in the next step
+ * came out a few ulp off in every rollout (round 3, found with tests/test_rmppi.py).
+ */
+template <int REP, int N>
+__device__ inline void stripedStore(float* base, const float (&vals)[N], const int rep_lane)
+{
+#pragma unroll
+  for (int j = 0; j < N; j += REP)
+  {
+    float v = vals[j];
+    int field = j;
+#pragma unroll
+    for (int q = 1; q < REP; q++)
+    {
+      if (j + q < N)
+      {
+        v = (rep_lane == q) ? vals[j + q] : v;
+        field = (rep_lane == q) ? j + q : field;
+      }
+    }
+    base[field * 64] = v;
+  }
 }
 
 template <class DYN_T, class COST_T, class FB_T, class SAMPLING_T, bool DRAW_IN_LOOP>
@@ -252,9 +286,9 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
           if (t + s2 < num_timesteps)
           {
             if (DRAW_IN_LOOP)
-              sampling->shapeControlSample(global_idx, t + s2, z, &zq[z][s2 * C], u);
+              sampling->template shapeControlSample<true>(global_idx, t + s2, z, &zq[z][s2 * C], u);
             else
-              sampling->readControlSample(global_idx, t + s2, z, u, theta_d_shared, 1, 0, y);
+              sampling->template readControlSample<true>(global_idx, t + s2, z, u, theta_d_shared, 1, 0, y);
             float* slot = smp_ring + ((size_t)(z * rings.sample_steps + ((t + s2) & smp_mask)) * C) * 64 + lane;
 #pragma unroll
             for (int i = 0; i < C; i++)
@@ -273,6 +307,7 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
     lds_counter_t peer_prog = counters + 4 * (is_nominal ? wave + DW : wave - DW);
     float* my_out = out_ring + (size_t)thread_idz * rings.out_steps * F * 64;
     const float* my_smp = smp_ring + (size_t)thread_idz * rings.sample_steps * C * 64;
+    const bool last_state_only = fb_controller->lastStateOnly();
     auto dyn_step = [&](float* xc, float* xn, int t, const float* u_in) {
 #pragma unroll
       for (int i = 0; i < C; i++)
@@ -280,15 +315,22 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
         u[i] = u_in[i];
         fb_control[i] = 0.0f;
       }
+      // (all stores of the dynamics waves are issued by every lane: see stripedStore)
       float* xs = xnom_ring + (size_t)(t & xnom_mask) * S * 64 + thread_idx;
-      if (is_nominal)
+      if (last_state_only)
+      {  // wave-uniform: the reference's gain product keeps the last state's term only (ddp_feedback.hpp)
+        if (is_nominal)
+          xs[(S - 1) * 64] = xc[S - 1];  // the replicas write the same value to the same word
+        else
+          fb_controller->kLastState(xc[S - 1], xs[(S - 1) * 64], t, fb_control);
+      }
+      else if (is_nominal)
       {  // wave-uniform
-        if (rep_lane == 0)
-        {
+        float xv[S];
 #pragma unroll
-          for (int i = 0; i < S; i++)
-            xs[i * 64] = xc[i];
-        }
+        for (int i = 0; i < S; i++)
+          xv[i] = xc[i];
+        stripedStore<REP>(xs, xv, rep_lane);
       }
       else
       {
@@ -303,22 +345,17 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
         u[i] += fb_control[i];
       dynamics->enforceConstraints(xc, u);
       dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
-      if (rep_lane == 0)
+      float rec[F];  // y | u | feedback term (zero on the nominal system)
+#pragma unroll
+      for (int i = 0; i < O; i++)
+        rec[i] = y[i];
+#pragma unroll
+      for (int i = 0; i < C; i++)
       {
-        float* slot = my_out + (size_t)(t & out_mask) * F * 64 + thread_idx;
-#pragma unroll
-        for (int i = 0; i < O; i++)
-          slot[i * 64] = y[i];
-#pragma unroll
-        for (int i = 0; i < C; i++)
-          slot[(O + i) * 64] = u[i];
-        if (!is_nominal)
-        {
-#pragma unroll
-          for (int i = 0; i < C; i++)
-            slot[(O + C + i) * 64] = fb_control[i];
-        }
+        rec[O + i] = u[i];
+        rec[O + C + i] = fb_control[i];
       }
+      stripedStore<REP>(my_out + (size_t)(t & out_mask) * F * 64 + thread_idx, rec, rep_lane);
     };
     int seen_smp[NS], seen_cost = 0, seen_peer = 0;
 #pragma unroll
@@ -405,7 +442,7 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
         for (int i = 0; i < C; i++)
         {
           ub[q][i] = slot[(O + i) * 64];
-          fbb[q][i] = is_nominal ? 0.0f : slot[(O + C + i) * 64];
+          fbb[q][i] = slot[(O + C + i) * 64];
         }
         // the feedback-filled, clamped control replaces the sample (rmppi_kernels.cu:780-781)
         if (t + q < num_timesteps)
@@ -423,7 +460,7 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
           if (t + q < num_timesteps)
           {
             const float curr_cost = costs_w->computeRunningCost(yb[q], ub[q], t + q, theta_c_shared, &status);
-            const float lr = sampling->computeLikelihoodRatioCost(ub[q], theta_d_shared, global_idx, t + q, thread_idz,
+            const float lr = sampling->template computeLikelihoodRatioCost<true>(ub[q], theta_d_shared, global_idx, t + q, thread_idz,
                                                                   args.lambda, args.alpha);
             if (is_nominal)
             {
@@ -434,7 +471,7 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
             {
               da[q] = curr_cost + lr;
               db[q] = curr_cost +
-                      sampling->computeFeedbackCost(fbb[q], theta_d_shared, t + q, thread_idz, args.lambda, args.alpha);
+                      sampling->template computeFeedbackCost<true>(fbb[q], theta_d_shared, t + q, thread_idz, args.lambda, args.alpha);
             }
           }
         }

@@ -43,6 +43,23 @@ public:
   {
   }
 
+  /** true when k() depends on the LAST state only (the reference's behaviour for an even CONTROL_DIM, see above): kernels
+   *  that hand the nominal state from wave to wave then move one float per step instead of STATE_DIM */
+  __device__ inline bool lastStateOnly() const
+  {
+    return (CONTROL_DIM % 2 == 0) && !accumulate_all_states_;
+  }
+  /** k() for lastStateOnly(): the assignment of the last state's term is the one that survives ddp.cu:27-37 */
+  __device__ inline void kLastState(const float x_act_last, const float x_goal_last, const int t,
+                                    float* __restrict__ control_output) const
+  {
+    const float* fb_gain_t = fb_gain_traj_d_ + (size_t)STATE_DIM * CONTROL_DIM * t + (STATE_DIM - 1) * CONTROL_DIM;
+    const float e = x_act_last - x_goal_last;
+#pragma unroll
+    for (int j = 0; j < CONTROL_DIM; j++)
+      control_output[j] = fb_gain_t[j] * e;
+  }
+
   /** reference: ddp.cu:11-45.  control_output must be zero-initialised by the caller (rmppi_kernels.cu:755-758). */
   __device__ inline void k(const float* __restrict__ x_act, const float* __restrict__ x_goal, const int t,
                            float* __restrict__ theta, float* __restrict__ control_output) const

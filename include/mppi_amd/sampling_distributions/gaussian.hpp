@@ -523,6 +523,7 @@ public:
   }
 
   /** reference: gaussian.cu:571-629 */
+  template <bool LANE_D = false>
   __device__ inline float computeFeedbackCost(const float* __restrict__ u_fb, float* __restrict__ theta_d, const int t,
                                               const int distribution_idx, const float lambda = 1.0f,
                                               const float alpha = 0.0f)
@@ -537,7 +538,7 @@ public:
       for (int l = 0; l < W; l++)
       {
         const int j = i * W + l;
-        const float sd = sigmaValue<false, false>(d, t, j);  // the per-step table when time_specific_std_dev (:579-583)
+        const float sd = sigmaValue<LANE_D, false>(d, t, j);  // the per-step table when time_specific_std_dev (:579-583)
         lane[l] += params_.control_cost_coeff[j] * (u_fb[j] * u_fb[j]) / (sd * sd);
       }
     for (int l = 0; l < W; l++)
