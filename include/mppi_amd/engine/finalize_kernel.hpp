@@ -40,10 +40,11 @@ struct FinalizeArgs
   int constrain_mode;         ///< 0: Dynamics::enforceConstraints (mppi_controller.cu:227-231);
                               ///< 1: ColoredMPPI — only control channel 1 is clamped to its range, no deadband
                               ///<    (controllers/ColoredMPPI/colored_mppi_controller.cu:232-237)
-  /* Low-latency hand-over (single-system controllers): the *_out_d pointers then are host memory mapped into the device,
-   * the kernel copies the merge statistics next to them and raises flags the host spins on — flags_d[0] <- seq as soon as
-   * the control sequence (and the statistics) are out, i.e. BEFORE the T-step re-rollout of the state trajectory, and
-   * flags_d[1] <- seq when the trajectories are complete.  nullptr: no flags (results fetched with a copy + synchronise). */
+  /* Low-latency hand-over: the *_out_d pointers then are host memory mapped into the device, the kernel copies the merge
+   * statistics next to them and raises flags the host spins on — system z (one block each): flags_d[2 z] <- seq as soon as
+   * its control sequence (and the statistics) are out, i.e. BEFORE the T-step re-rollout of the state trajectory, and
+   * flags_d[2 z + 1] <- seq when its trajectories are complete.  nullptr: no flags (results fetched with a copy +
+   * synchronise). */
   unsigned* flags_d;
   unsigned seq;
   const float* stats_in_d;    ///< [stats_floats] merge statistics (combineKernel), or nullptr
@@ -99,7 +100,7 @@ __device__ inline void finalizeEmitControl(DYN_T* dynamics, const FinalizeArgs& 
   if (a.stats_in_d && a.stats_out_d)
     for (int e = elem_lane; e < a.stats_floats; e += elem_stride)
       a.stats_out_d[e] = a.stats_in_d[e];
-  raiseHostFlag(a.flags_d, 0, a.seq, elem_lane == 0);
+  raiseHostFlag(a.flags_d, 2 * z + 0, a.seq, elem_lane == 0);
 }
 
 /** by > 1 (LDS + barrier contract): the state and output trajectories are collected in LDS and written out once at the end —
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
     for (int e = ty; e < T * O; e += BY)
       a.output_out_d[(size_t)z * T * O + e] = y_traj[e];
   }
-  raiseHostFlag(a.flags_d, 1, a.seq, ty == 0 && lx == 0);
+  raiseHostFlag(a.flags_d, 2 * z + 1, a.seq, ty == 0 && lx == 0);
 }
 
 /**
@@ -422,7 +423,7 @@ __global__ void __launch_bounds__(64) finalizeRepKernel(DYN_T dynamics_obj, cons
     for (int i = 0; i < S; i++)
       x[i] = xn[i];
   }
-  raiseHostFlag(a.flags_d, 1, a.seq, lane == 0);
+  raiseHostFlag(a.flags_d, 2 * z + 1, a.seq, lane == 0);
 }
 
 }  // namespace kernels

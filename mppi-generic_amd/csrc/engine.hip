@@ -1662,9 +1662,20 @@ static mppi_status ensureTrajectories(mppi_handle h)
   if (!h->traj_pending)
     return MPPI_OK;
   MPPI_TRY(waitHostFlag(h, 1, h->io_seq));
-  h->traj_pending = false;
   const int T = h->cfg.num_timesteps;
   const float* out = h->io_out_h;
+  if (h->cfg.controller == MPPI_CONTROLLER_ROBUST)
+  {  // system 0: the nominal trajectory (the next call's candidates start from it), system 1: the real one
+    MPPI_TRY(waitHostFlag(h, 3, h->io_seq));
+    h->traj_pending = false;
+    const float* xs = out + (h->state_out_d - h->out_block_d);
+    std::copy(xs, xs + (size_t)T * h->S, h->nominal_state_h.begin());
+    std::copy(xs + (size_t)T * h->S, xs + (size_t)2 * T * h->S, h->state_h.begin());
+    if (!allFinite(h->nominal_state_h))
+      return fail(h, MPPI_ERR_NAN, "non-finite value in the nominal state sequence of the last mppi_compute_control");
+    return MPPI_OK;
+  }
+  h->traj_pending = false;
   std::copy(out + (h->state_out_d - h->out_block_d), out + (h->state_out_d - h->out_block_d) + (size_t)T * h->S,
             h->state_h.begin());
   if (!allFinite(h->state_h))  // base_plant.hpp:515-528 checks the state trajectory as well as the control
@@ -1987,11 +1998,75 @@ static mppi_status computeControlRobust(mppi_handle h, const float* x0_real, int
   const int S = h->S;
   if (!h->gains_set)
     return fail(h, MPPI_ERR_STATE, "Robust MPPI: set the DDP feedback gains first (mppi_set_feedback_gains)");
-  HIP_TRY(h, hipMemcpyAsync(h->x0_d, h->rm_nominal_state.data(), sizeof(float) * S, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->x0_d + S, x0_real, sizeof(float) * S, hipMemcpyHostToDevice, h->stream));
-  // both importance samplers start from the nominal control (:655-656); later iterations continue from the NEW nominal
-  HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->nominal_control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice,
-                            h->stream));
+  if (!h->low_latency)
+  {
+    HIP_TRY(h, hipMemcpyAsync(h->x0_d, h->rm_nominal_state.data(), sizeof(float) * S, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->x0_d + S, x0_real, sizeof(float) * S, hipMemcpyHostToDevice, h->stream));
+    // both importance samplers start from the nominal control (:655-656); later iterations continue from the NEW nominal
+    HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->nominal_control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice,
+                              h->stream));
+  }
+  if (h->low_latency)
+  {
+    /* As computeControlVanilla: inputs and results through host memory mapped into the device, no copy command and no stream
+     * synchronisation; the call returns when both control sequences and the statistics are out, while the finalize kernel
+     * still re-rolls the two state trajectories (the nominal one is what the NEXT call's candidate states are built from:
+     * rmNominalStateAndStride and the trajectory getters wait for it).  AutoRally-NN, T = 150: 179 us of a 622 us call. */
+    if (h->traj_pending)
+      MPPI_TRY(ensureTrajectories(h));
+    float* in = h->io_in_h;
+    std::copy(h->rm_nominal_state.begin(), h->rm_nominal_state.begin() + S, in + (h->x0_d - h->in_block_d));
+    std::copy(x0_real, x0_real + S, in + (h->x0_d - h->in_block_d) + S);
+    float* mean = in + (h->mean_d - h->in_block_d);
+    std::copy(h->nominal_control_h.begin(), h->nominal_control_h.end(), mean);
+    std::copy(h->nominal_control_h.begin(), h->nominal_control_h.end(), mean + h->TC);
+    float* hist = in + (h->history_d - h->in_block_d);
+    std::copy(h->nominal_history_h.begin(), h->nominal_history_h.end(), hist);
+    std::copy(h->history_h.begin(), h->history_h.end(), hist + 2 * h->C);
+    hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+    HIP_TRY(h, hipGetLastError());
+    for (int it = 0; it < h->cfg.num_iters; it++)
+    {
+      if (it > 0)
+        HIP_TRY(h, hipMemcpyAsync(h->mean_d + h->TC, h->mean_d, sizeof(float) * h->TC, hipMemcpyDeviceToDevice, h->stream));
+      MPPI_TRY(iteration(h, it, stride));
+    }
+    const int T = h->cfg.num_timesteps;
+    kernels::FinalizeArgs a{};
+    a.control_in_d = h->mean_d;
+    a.history_d = h->history_d;
+    a.history_stride = 2 * h->C;
+    a.x0_d = h->x0_d;
+    a.dt = h->cfg.dt;
+    a.num_timesteps = T;
+    a.smooth_mask = 3;
+    a.constrain_mask = 0;
+    a.constrain_mode = 0;
+    a.control_out_d = h->io_out_dev + (h->ctrl_out_d - h->out_block_d);
+    a.state_out_d = h->io_out_dev + (h->state_out_d - h->out_block_d);
+    a.output_out_d = h->io_out_dev + (h->output_out_d - h->out_block_d);
+    a.stats_in_d = h->stats_d;
+    a.stats_out_d = h->io_out_dev + (h->stats_d - h->out_block_d);
+    a.stats_floats = 2 * kernels::STATS_STRIDE;
+    a.flags_d = h->io_flags_dev;
+    a.seq = ++h->io_seq;
+    std::string err;
+    const mppi_status st = h->model->launchFinalize(2, a, h->stream, err);
+    if (st != MPPI_OK)
+      return fail(h, st, err);
+    h->out_pin_fresh = false;
+    h->results_in_io = true;
+    h->traj_pending = true;  // set before the waits: a failing wait must not leave io_out unguarded for the next call
+    MPPI_TRY(waitHostFlag(h, 0, h->io_seq));
+    MPPI_TRY(waitHostFlag(h, 2, h->io_seq));
+    const float* out = h->io_out_h;
+    std::copy(out, out + (size_t)T * h->C, h->nominal_control_h.begin());
+    std::copy(out + (size_t)T * h->C, out + (size_t)2 * T * h->C, h->control_h.begin());
+    parseStats(h, out + (h->stats_d - h->out_block_d));
+    if (!allFinite(h->control_h) || !allFinite(h->nominal_control_h))
+      return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control sequence");
+    return MPPI_OK;
+  }
   for (int it = 0; it < h->cfg.num_iters; it++)
   {
     HIP_TRY(h, hipMemcpyAsync(h->mean_d + h->TC, h->mean_d, sizeof(float) * h->TC, hipMemcpyDeviceToDevice, h->stream));
@@ -2082,6 +2157,7 @@ mppi_status mppi_get_nominal_state_seq(mppi_handle h, float* x)
     return fail(h, MPPI_ERR_INVALID_ARG, "null");
   if (h->D != 2)
     return fail(h, MPPI_ERR_STATE, "no nominal system in this controller");
+  MPPI_TRY(ensureTrajectories(h));
   std::copy(h->nominal_state_h.begin(), h->nominal_state_h.end(), x);
   return MPPI_OK;
 }
@@ -2210,6 +2286,7 @@ mppi_status mppi_update_importance_sampling_control(mppi_handle h, const float* 
   if (h->cfg.controller != MPPI_CONTROLLER_ROBUST)
     return fail(h, MPPI_ERR_STATE, "mppi_update_importance_sampling_control: the handle is not a Robust MPPI controller");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  MPPI_TRY(ensureTrajectories(h));  // the nominal state trajectory of the last mppi_compute_control (low-latency hand-over)
   const int T = h->cfg.num_timesteps, C = h->C;
   h->real_stride = stride;
   MPPI_TRY(rmNominalStateAndStride(h, state, stride));
