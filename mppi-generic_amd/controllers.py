@@ -590,6 +590,11 @@ class RobustMPPIController(MPPIController):
         self._check(self._lib.mppi_get_nominal_control_seq(self._h, u))
         return u
 
+    def getNominalStateSeq(self):
+        x = np.empty((self.num_timesteps, self.STATE_DIM), np.float32)
+        self._check(self._lib.mppi_get_nominal_state_seq(self._h, x))
+        return x
+
 
 class TubeMPPIController(MPPIController):
     """reference: controllers/Tube-MPPI/tube_mppi_controller.cuh — TubeMPPIController"""
