@@ -127,10 +127,13 @@ __global__ void __launch_bounds__(BX* replicated_lanes<DYN_T>::value)
   float running_cost = 0.0f;
   float* x = xa;
   float* x_next = xb;
+  // the rollout walks ONE row of samples: a Philox quad is drawn when the walk enters it, not once per element
+  // (two-control models: one draw per two steps instead of two per step; none while candidate_t rests at T - 1)
+  typename SAMPLING_T::QuadCache quad_cache;
   for (int t = 0; t < num_timesteps; t++)
   {
     const int candidate_t = min(t + stride, num_timesteps - 1);
-    sampling->sampleAt(candidate_sample_idx, candidate_t, 0, u);
+    sampling->sampleAt(candidate_sample_idx, candidate_t, 0, u, &quad_cache);
     dynamics->enforceConstraints(x, u);
     dynamics->step(x, x_next, xdot, u, y, theta_s_shared, t, args.dt);
     // the likelihood-ratio term is taken at the UNSHIFTED time and the GLOBAL index (rmppi_kernels.cu:337-339)

@@ -398,13 +398,22 @@ public:
    * read sample `candidate_sample_idx` at the time-shifted index min(t + stride, T - 1)
    * (reference: core/rmppi_kernels.cu:309-312 readControlSample(candidate_sample_idx, candidate_t, ...)).
    */
+  /** the last Philox quad a lane drew through sampleAt(): consecutive elements of a row share a quad (a step of a
+   *  two-control model is half of one), so a caller that walks a row keeps one of these across its calls */
+  struct QuadCache
+  {
+    int quad = -1;
+    float z[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+  };
   __device__ inline void sampleAt(const int sample_index, const int t, const int distribution_index,
-                                  float* __restrict__ control) const
+                                  float* __restrict__ control, QuadCache* cache = nullptr) const
   {
     const int d = distribution_index >= params_.num_distributions ? 0 : distribution_index;
     const float* mean = control_means_d_ + (size_t)(params_.num_timesteps * d + t) * CONTROL_DIM;
     const bool use_mean = ((sample_index + rollout_offset_) == 0) || (t < optimization_stride_);
     const bool pure = isPureNoise(sample_index);
+    QuadCache local;
+    QuadCache& qc = cache ? *cache : local;
 #pragma unroll
     for (int i = 0; i < CONTROL_DIM; i++)
     {
@@ -417,10 +426,13 @@ public:
       }
       else
       {
-        float z[4];
-        mppi::rng::normal4(seed_, generation_, independentNoise() ? (uint32_t)d : 0u,
-                           (uint32_t)(sample_index + rollout_offset_), (uint32_t)(e >> 2), z);
-        eps = (e & 3) == 0 ? z[0] : ((e & 3) == 1 ? z[1] : ((e & 3) == 2 ? z[2] : z[3]));
+        if ((e >> 2) != qc.quad)
+        {  // (rows of one distribution and one rollout only: the cache is keyed by the quad index)
+          qc.quad = e >> 2;
+          mppi::rng::normal4(seed_, generation_, independentNoise() ? (uint32_t)d : 0u,
+                             (uint32_t)(sample_index + rollout_offset_), (uint32_t)(e >> 2), qc.z);
+        }
+        eps = (e & 3) == 0 ? qc.z[0] : ((e & 3) == 1 ? qc.z[1] : ((e & 3) == 2 ? qc.z[2] : qc.z[3]));
       }
       control[i] = shapeSample(mean[i], sigmaValue<false, true>(d, t, i), eps, use_mean, pure);
     }
