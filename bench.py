@@ -211,6 +211,53 @@ def compute_control_latency(device, x0):
                           "getControlSeq + slide back to back"}
 
 
+def robust_autorally_leg(device):
+    """Robust MPPI (two coupled systems per rollout, DDP feedback term) on the AutoRally NeuralNetModel, K=16384, T=150: what a
+    control loop sees per call.  The rollout runs as the role-pipelined kernel of engine/rmppi_pipeline_kernel.hpp."""
+    import numpy as np
+    import mppi_generic_amd as m
+    from common import autorally_cfg
+    K, Tn = 16384, 150
+    cfg = autorally_cfg(K=K, T=Tn, lambda_=1.0)
+    eng = m.RobustMPPIController(cfg["model"], K, Tn, cfg["dt"], cfg["lambda_"], 0.0, 1, seed=42, device=device)
+    eng.setCostParams(cfg["cost"])
+    for name, blob in cfg["blobs"].items():
+        eng.setModelBlob(name, blob)
+    eng.setControlRanges(cfg["ranges"])
+    eng.setSamplingParams(cfg["std_dev"], [0.2, 0.1])
+    eng.setRMPPIParams(500.0, 9, 32)
+    g = np.random.default_rng(5).uniform(-0.3, 0.3, (Tn, 7, 2)).astype(np.float32)
+    x = cfg["x0"].copy()
+
+    def cycle():
+        eng.updateImportanceSamplingControl(x, 1)
+        eng.setFeedbackGains(g)
+        eng.computeControl(x, 1)
+    for _ in range(10):
+        cycle()
+    n = 50
+    t_a = time.perf_counter()
+    for _ in range(n):
+        cycle()
+    period = (time.perf_counter() - t_a) / n
+    ready = 0.0
+    for _ in range(n):
+        eng.getTargetStateSeq()  # the previous call's trajectories have landed: the stream is idle
+        t_a = time.perf_counter()
+        eng.computeControl(x, 1)
+        ready += time.perf_counter() - t_a
+    u = eng.getControlSeq()
+    eng.close()
+    return {"workload": "RobustMPPI (nominal + real system, DDP gains [T][7][2], 9 x 32 candidate rollouts), AutoRally "
+                        "NeuralNetModel<7,2,3> + ARStandardCost, K=16384, T=150",
+            "control_ready_us": round(ready / n * 1e6, 2), "cycle_us": round(period * 1e6, 2), "finite": bool(np.isfinite(u).all()),
+            "kernel": "rolloutRMPPIPipelineKernel<NeuralNetModelMFMA<7,2,3>,ARStandardCost,DeviceDDP,Gaussian>: 8 dynamics + 1 sampler "
+                      "+ 6 cost waves per 64 rollouts x 2 systems (profiles/r03_b_robust_kernel_stats.csv)",
+            "definition": "control_ready: mppi_compute_control from an idle stream until both control sequences and the statistics "
+                          "are on the host; cycle: updateImportanceSamplingControl (candidate evaluation, slide, nominal "
+                          "trajectory) + setFeedbackGains + computeControl back to back"}
+
+
 def autorally_leg(device):
     """AutoRally NeuralNetModel (FNN 6-32-32-4, synthetic weights) + ARStandardCost, K=16384, T=150, one GPU:
     iterations/s and the MFMA roofline of the NN forward (F_alg = 2 * sum(MAC) * K * T)."""
@@ -706,7 +753,7 @@ def main():
         # secondary workloads of the north star (not the headline `value`)
         if not args.primary_only and world == 1 and args.workload == "cartpole":
             for key, leg_fn in (("autorally_nn", autorally_leg), ("lstm_colored", lstm_colored_leg), ("di_tube", di_tube_leg),
-                                ("racer_elevation", racer_elevation_leg)):
+                                ("racer_elevation", racer_elevation_leg), ("robust_autorally_nn", robust_autorally_leg)):
                 try:
                     out[key] = leg_fn(local_rank)
                 except Exception as e:  # noqa: BLE001

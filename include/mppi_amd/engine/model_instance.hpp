@@ -120,8 +120,8 @@ struct ModelBase
     err = "model is not instantiated for Robust MPPI";
     return MPPI_ERR_UNSUPPORTED;
   }
-  virtual mppi_status launchInitEval(const kernels::InitEvalArgs& a, const SamplerLaunchState& s, hipStream_t stream,
-                                     std::string& err)
+  virtual mppi_status launchInitEval(bool pipeline, const kernels::InitEvalArgs& a, const SamplerLaunchState& s,
+                                     hipStream_t stream, std::string& err)
   {
     err = "model is not instantiated for Robust MPPI";
     return MPPI_ERR_UNSUPPORTED;
@@ -503,7 +503,7 @@ struct ModelT : ModelBase
     err = "model has no role-pipelined Robust MPPI kernel";
     return MPPI_ERR_LAUNCH_SHAPE;
   }
-  mppi_status launchInitEval(const kernels::InitEvalArgs& a, const SamplerLaunchState& s, hipStream_t stream,
+  mppi_status launchInitEval(bool pipeline, const kernels::InitEvalArgs& a, const SamplerLaunchState& s, hipStream_t stream,
                              std::string& err) override
   {
     if constexpr (RMPPI)
@@ -512,6 +512,34 @@ struct ModelT : ModelBase
         return MPPI_ERR_STATE;
       prepSampler(s);
       constexpr int BX = 64;
+      if constexpr (rmppiHasPipeline())
+      {
+        // the candidate rollouts as blocks of role waves (rmppi_pipeline_kernel.hpp) when the rows of 64 rollouts and a ring
+        // fit the LDS; else the fused kernel below
+        if (pipeline && rmppiUseFast())
+        {
+          DYN_FAST_T fast(dyn);
+          const int ring = kernels::initEvalPipelineRing(fast, cost, a.num_timesteps, MAX_LDS_BYTES);
+          if (ring > 0)
+          {
+            constexpr int REP = kernels::replicated_lanes<DYN_FAST_T>::value;
+            const size_t smem = kernels::initEvalPipelineSharedBytes(fast, cost, a.num_timesteps, ring);
+            auto kfn = kernels::initEvalPipelineKernel<DYN_FAST_T, COST_T, SAMPLING_T>;
+            if (smem > 48 * 1024)
+              (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            constexpr int WAVES = REP + kernels::INIT_EVAL_PIPE_SAMPLERS + kernels::INIT_EVAL_PIPE_COSTS;
+            hipLaunchKernelGGL(kfn, dim3((a.num_eval_rollouts + BX - 1) / BX), dim3(64 * WAVES, 1, 1), smem, stream, fast, cost, smp,
+                               a, ring);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess)
+            {
+              err = std::string("initEvalPipelineKernel launch: ") + hipGetErrorString(e);
+              return MPPI_ERR_HIP;
+            }
+            return MPPI_OK;
+          }
+        }
+      }
       // models with replicated-lane (MFMA / four-lane) dynamics run both Robust MPPI kernels on them (withRmppiDynamics)
       return withRmppiDynamics([&](auto& rm_dyn) -> mppi_status {
         using RM_DYN_T = std::decay_t<decltype(rm_dyn)>;
@@ -531,7 +559,7 @@ struct ModelT : ModelBase
         return MPPI_OK;
       });
     }
-    return ModelBase::launchInitEval(a, s, stream, err);
+    return ModelBase::launchInitEval(pipeline, a, s, stream, err);
   }
   template <int BX>
   mppi_status launchRMPPIShape(const kernels::RMPPIArgs& a, hipStream_t stream, std::string& err)

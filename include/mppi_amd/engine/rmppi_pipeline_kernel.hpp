@@ -539,6 +539,259 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
                                                              thread_idz, tid_x, block_idx, nrows, theta_d_shared, cost_s, w_s);
 }
 
+/* =====================================================================================================================
+ * Candidate evaluation (reference: rmppi_kernels.cu:231-356, initEvalKernel) as role waves.  9 x 32 rollouts are five blocks:
+ * the fused kernel is ONE wave per 16 rollouts doing draw, step and cost in turn — a chain of T x ~1100 instructions,
+ * 382 us for AutoRally-NN at T = 150 whatever the machine's width.  Here a block of 64 evaluation rollouts runs like
+ * rolloutPipelineRepKernel: REP dynamics waves, two sampler waves (sampleAt: sample `rollout % samples_per_candidate` at the
+ * time index shifted by the candidate's stride), two cost waves evaluating ahead of their relay.  The whole shaped row of a
+ * rollout (T x C floats, 64 rollouts: 77 KB at T = 150) sits in LDS — the samplers run ahead as far as they like — next to
+ * the output ring.  Same plugin calls in the same order per rollout: the candidate costs are the fused kernel's bits.
+ * ===================================================================================================================== */
+constexpr int INIT_EVAL_PIPE_SAMPLERS = 2, INIT_EVAL_PIPE_COSTS = 2;
+
+template <class DYN_T, class COST_T>
+__host__ inline size_t initEvalPipelineSharedBytes(const DYN_T& dyn, const COST_T& cost, int num_timesteps, int ring)
+{
+  constexpr int C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
+  size_t n = calcClassSharedMemSize(&dyn, 64) + calcClassSharedMemSize(&cost, 64);
+  n += sizeof(float) * (size_t)math::nearest_multiple_4(num_timesteps * C) * 64;  // shaped samples [t][c][rollout]
+  n += sizeof(float) * (size_t)ring * O * 64;                                      // output ring [slot][i][rollout]
+  n += sizeof(float) * 2 * 64;                                                     // relay: running cost, status
+  n += sizeof(int) * 4 * (replicated_lanes<DYN_T>::value + INIT_EVAL_PIPE_SAMPLERS + 1);
+  return n;
+}
+template <class DYN_T, class COST_T>
+__host__ inline int initEvalPipelineRing(const DYN_T& dyn, const COST_T& cost, int num_timesteps, size_t max_lds)
+{
+  for (int ring = 32; ring >= 4; ring >>= 1)
+    if (initEvalPipelineSharedBytes(dyn, cost, num_timesteps, ring) <= max_lds)
+      return ring;
+  return 0;
+}
+
+template <class DYN_T, class COST_T, class SAMPLING_T>
+__global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + INIT_EVAL_PIPE_SAMPLERS + INIT_EVAL_PIPE_COSTS))
+    initEvalPipelineKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const InitEvalArgs args,
+                           const int ring_steps)
+{
+  constexpr int BX = 64;
+  constexpr int REP = replicated_lanes<DYN_T>::value;
+  static_assert(REP > 1 && 64 % REP == 0, "this variant is for replicated-lane dynamics");
+  constexpr int DW = BX * REP / 64;
+  constexpr int NS = INIT_EVAL_PIPE_SAMPLERS, NC = INIT_EVAL_PIPE_COSTS;
+  constexpr int NTHREADS = 64 * (DW + NS + NC);
+  constexpr int PER_WAVE = 64 / REP;
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == NTHREADS);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_y() == 1);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_z() == 1);
+  __builtin_assume(__builtin_amdgcn_workitem_id_x() < NTHREADS);
+  __builtin_assume(__builtin_amdgcn_workitem_id_y() == 0);
+  __builtin_assume(__builtin_amdgcn_workitem_id_z() == 0);
+  DYN_T* dynamics = &dynamics_obj;
+  COST_T* costs = &costs_obj;
+  SAMPLING_T* sampling = &sampling_obj;
+  constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
+
+  const int tid_x = (int)__builtin_amdgcn_workitem_id_x();
+  const int wave = __builtin_amdgcn_readfirstlane(tid_x >> 6);
+  const int lane = tid_x & 63;
+  const bool is_dyn = wave < DW;
+  const bool is_sampler = !is_dyn && wave < DW + NS;
+  const int helper_id = is_dyn ? 0 : (is_sampler ? wave - DW : wave - DW - NS);
+  const int thread_idx = is_dyn ? wave * PER_WAVE + (lane % PER_WAVE) : lane;
+  const int global_idx = BX * (int)blockIdx.x + thread_idx;
+  const bool valid = global_idx < args.num_eval_rollouts;
+  const int gi = valid ? global_idx : 0;
+  const int candidate_idx = gi / args.samples_per_candidate;
+  const int candidate_sample_idx = gi % args.samples_per_candidate;
+  const int num_timesteps = args.num_timesteps;
+  const int ring_mask = ring_steps - 1;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* theta_s_shared = reinterpret_cast<float*>(smem_raw);
+  float* theta_c_shared = theta_s_shared + calcClassSharedMemSize(dynamics, BX) / (int)sizeof(float);
+  float* samples = theta_c_shared + calcClassSharedMemSize(costs, BX) / (int)sizeof(float);  // [t][c][rollout]
+  float* ring = samples + (size_t)math::nearest_multiple_4(num_timesteps * C) * 64;           // [slot][i][rollout]
+  float* relay_cost = ring + (size_t)ring_steps * O * 64;
+  int* relay_status = reinterpret_cast<int*>(relay_cost + 64);
+  lds_counter_t counters = (lds_counter_t)(relay_status + 64);
+  // counters + 4 w: steps dynamics wave w has put into the ring; + 4 (DW + s): sampler s; + 4 (DW + NS): the cost waves
+  lds_counter_t cost_prog = counters + 4 * (DW + NS);
+
+  float x[S], x_next[S], xdot[S], u[C], y[O];
+  int crash_status = 0;
+#pragma unroll
+  for (int i = 0; i < S; i++)
+  {
+    x[i] = args.states_d[candidate_idx * S + i];
+    x_next[i] = 0.0f;
+    xdot[i] = 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    u[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < O; i++)
+    y[i] = 0.0f;
+  const int stride = args.strides_d[candidate_idx];
+  if (tid_x < DW + NS + 1)
+    counters[4 * tid_x] = 0;
+  __syncthreads();
+  dynamics->initializeDynamics(x, u, y, theta_s_shared, 0.0f, args.dt);
+  costs->initializeCosts(y, u, theta_c_shared, 0.0f, args.dt);
+  __syncthreads();
+
+  float running_cost = 0.0f;
+  constexpr int TRIP = 2;  // steps per sampler trip and per cost-wave turn
+
+  if (is_sampler)
+  {
+    lds_counter_t smp_prog = counters + 4 * (DW + helper_id);
+    typename SAMPLING_T::QuadCache quad_cache;
+    for (int t = TRIP * helper_id; t < num_timesteps; t += TRIP * NS)
+    {
+#pragma unroll
+      for (int q = 0; q < TRIP; q++)
+      {
+        if (t + q < num_timesteps)
+        {
+          const int candidate_t = min(t + q + stride, num_timesteps - 1);
+          sampling->sampleAt(candidate_sample_idx, candidate_t, 0, u, &quad_cache);
+#pragma unroll
+          for (int i = 0; i < C; i++)
+            samples[((t + q) * C + i) * 64 + lane] = u[i];
+        }
+      }
+      pipePublish(smp_prog, min(t + TRIP, num_timesteps), lane);
+    }
+  }
+  else if (is_dyn)
+  {
+    lds_counter_t my_prog = counters + 4 * wave;
+    const int rep_lane = lane / PER_WAVE;
+    int seen_smp[NS], seen_cost = 0;
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+      seen_smp[q] = 0;
+    auto dyn_step = [&](float* xc, float* xn, int t) {
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        u[i] = samples[(t * C + i) * 64 + thread_idx];
+      dynamics->enforceConstraints(xc, u);
+      dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, args.dt);
+      // the clamped control goes back next to the outputs: the cost waves read both (every lane stores: stripedStore)
+      float rec[O];
+#pragma unroll
+      for (int i = 0; i < O; i++)
+        rec[i] = y[i];
+      stripedStore<REP>(ring + (size_t)(t & ring_mask) * O * 64 + thread_idx, rec, rep_lane);
+      float uc[C];
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        uc[i] = u[i];
+      stripedStore<REP>(samples + (size_t)t * C * 64 + thread_idx, uc, rep_lane);
+    };
+    int t = 0;
+    for (; t + 1 < num_timesteps; t += 2)
+    {
+      const int owner = (t / TRIP) % NS;
+#pragma unroll
+      for (int q = 0; q < NS; q++)
+        if (owner == q)
+          pipeWait(counters + 4 * (DW + q), t + 2, seen_smp[q]);
+      pipeWait(cost_prog, t + 2 - ring_steps, seen_cost);
+      dyn_step(x, x_next, t);
+      dyn_step(x_next, x, t + 1);
+      pipePublish(my_prog, t + 2, lane);
+    }
+    if (t < num_timesteps)
+    {
+      const int owner = (t / TRIP) % NS;
+#pragma unroll
+      for (int q = 0; q < NS; q++)
+        if (owner == q)
+          pipeWait(counters + 4 * (DW + q), num_timesteps, seen_smp[q]);
+      pipeWait(cost_prog, num_timesteps - ring_steps, seen_cost);
+      dyn_step(x, x_next, t);
+      pipePublish(my_prog, num_timesteps, lane);
+    }
+  }
+  else
+  {
+    COST_T costs_v = *costs;
+    vgprResident(costs_v);
+    COST_T* costs_w = &costs_v;
+    int seen_dyn[DW], seen_cost = 0;
+#pragma unroll
+    for (int w = 0; w < DW; w++)
+      seen_dyn[w] = 0;
+    int status_guess = 0;
+    for (int t = 2 * helper_id; t < num_timesteps; t += 2 * NC)
+    {
+      const int hi = min(t + 2, num_timesteps);
+#pragma unroll
+      for (int w = 0; w < DW; w++)
+        pipeWait(counters + 4 * w, hi, seen_dyn[w]);
+      float yb[2][O], ub[2][C];
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+      {
+        const int tt = min(t + q, num_timesteps - 1);
+        const float* slot = ring + (size_t)(tt & ring_mask) * O * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < O; i++)
+          yb[q][i] = slot[i * 64];
+#pragma unroll
+        for (int i = 0; i < C; i++)
+          ub[q][i] = samples[(tt * C + i) * 64 + lane];
+      }
+      float cq[2] = { 0.0f, 0.0f };
+      auto evaluate = [&](int status) {
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+        {
+          // the likelihood-ratio term is taken at the UNSHIFTED time and the GLOBAL index (rmppi_kernels.cu:337-339)
+          if (t + q < num_timesteps)
+            cq[q] = costs_w->computeRunningCost(yb[q], ub[q], t + q, theta_c_shared, &status) +
+                    sampling->computeLikelihoodRatioCost(ub[q], nullptr, global_idx, t + q, 0, args.lambda, args.alpha);
+        }
+        return status;
+      };
+      int status_out = evaluate(status_guess);
+      if (t > 0)
+      {
+        pipeWait(cost_prog, t, seen_cost);
+        running_cost = relay_cost[lane];
+        crash_status = relay_status[lane];
+      }
+      if (__builtin_amdgcn_ballot_w64(crash_status != status_guess) != 0ull)
+        status_out = evaluate(crash_status);
+      running_cost += cq[0];
+      if (t + 1 < num_timesteps)
+        running_cost += cq[1];
+      crash_status = status_out;
+      status_guess = status_out;
+      relay_cost[lane] = running_cost;
+      relay_status[lane] = crash_status;
+      pipePublish(cost_prog, hi, lane);
+    }
+  }
+  __syncthreads();
+  // computeAndSaveCost (mppi_common.cu:843-853) with running / T passed in; cost wave 0 publishes
+  if (!is_dyn && !is_sampler && helper_id == 0)
+  {
+    running_cost = relay_cost[lane];
+    const float* slot = ring + (size_t)((num_timesteps - 1) & ring_mask) * O * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < O; i++)
+      y[i] = slot[i * 64];
+    if (valid)
+      args.trajectory_costs_d[global_idx] =
+          running_cost / (float)num_timesteps + costs->terminalCost(y, theta_c_shared) / (float)num_timesteps;
+  }
+}
+
 }  // namespace kernels
 }  // namespace mppi
 #endif

@@ -1976,7 +1976,7 @@ static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, in
   s.optimization_stride = stride;
   s.independent_noise = h->independent_noise ? 1 : 0;
   std::string err;
-  mppi_status st = h->model->launchInitEval(a, s, h->stream, err);
+  mppi_status st = h->model->launchInitEval(h->rm_pipeline, a, s, h->stream, err);
   if (st != MPPI_OK)
     return fail(h, st, err);
   h->generation++;

@@ -178,6 +178,33 @@ def test_rmppi_pipelined_kernel_independent_noise(gpu):
     assert np.abs(got[0][1][0] - got[0][1][1]).max() > 1e-3  # the two systems really drew different noise
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,T", [("autorally", 37), ("autorally", 150), ("lstm", 20), ("suspension", 21), ("complete", 12)])
+def test_rmppi_candidate_evaluation_both_kernels(gpu, model, T):
+    """updateImportanceSamplingControl's candidate rollouts (9 x 32, time-shifted samples) on the fused init-eval kernel and
+    as blocks of role waves: the same candidate free energies, best index and nominal state, bit for bit"""
+    cfg = _rm_cfg(model, K=1024, T=T)
+    got = []
+    for variant in (m.MPPI_KERNEL_FUSED, m.MPPI_KERNEL_PIPELINE):
+        eng, orc, rob = _make_pair(cfg, thr={"autorally": 500.0}.get(model, 2000.0), kernel_variant=variant)
+        S, C = eng.STATE_DIM, eng.CONTROL_DIM
+        x = cfg["x0"].copy()
+        rec = []
+        for i in range(3):
+            eng.updateImportanceSamplingControl(x, 1 + i)  # strides 1, 2, 3: odd and even shifts of the sample rows
+            ns_, best, stride, fe = eng.getRMPPIState()
+            rec.append((ns_.copy(), np.array([best, stride]), fe.copy()))
+            eng.setFeedbackGains(_gains(T, S, C, seed=3 + i, scale=0.3))
+            eng.computeControl(x, 1 + i)
+            x = x + np.float32(0.02)
+        got.append(rec)
+        eng.close()
+    for a, b in zip(*got):
+        for p, q in zip(a, b):
+            assert np.array_equal(p, q)
+    assert np.isfinite(got[0][-1][2]).all() and np.abs(got[0][-1][2]).max() > 0
+
+
 def _rollout_costs_bit_exact(model, acc_all, mode, K=1000, T=37, **kw):
     cfg = _rm_cfg(model, K=K, T=T)  # default: ragged last block, odd horizon
     eng, orc, rob = _make_pair(cfg, thr=40.0, save_samples=True, **kw)
