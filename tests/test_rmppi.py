@@ -412,3 +412,48 @@ def test_rmppi_runs_networks_of_other_shapes_on_the_one_lane_form(gpu, mode):
     assert np.abs(eng2.getControlSeq() - orc2.control()).max() <= U_TOL
     eng.close()
     eng2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["di", "autorally"])
+def test_rmppi_two_ranks_match_unsharded(gpu, model):
+    """Robust MPPI with the rollouts sharded over two ranks (two handles on this GPU, P2P mailbox exchange; every rank
+    evaluates the candidates itself): the same nominal / real control sequences as one handle, rank for rank the same bits.
+    AutoRally runs the role-pipelined kernels.  computeControl blocks until the merged result is there, so each rank is
+    driven from its own thread — as one process per GPU would."""
+    import threading
+    cfg = _rm_cfg(model, K=2048, T=40, num_iters=2)
+    thr = {"di": 25.0}.get(model, 500.0)
+    S = C = None
+
+    def drive(eng, out, barrier=None):
+        x = cfg["x0"].copy()
+        for i in range(3):
+            eng.updateImportanceSamplingControl(x, 1)
+            eng.setFeedbackGains(_gains(cfg["T"], eng.STATE_DIM, eng.CONTROL_DIM, seed=20 + i, scale=0.3))
+            if barrier is not None:
+                barrier.wait()
+            eng.computeControl(x, 1)
+            out.append((eng.getControlSeq().copy(), eng.getNominalControlSeq().copy(), eng.getRMPPIState()[1]))
+            x = x + np.float32(0.01)
+
+    full, _, _ = _make_pair(cfg, thr=thr)
+    ref = []
+    drive(full, ref)
+    full.close()
+    ranks = [_make_pair(cfg, thr=thr, rank=r, world_size=2)[0] for r in range(2)]
+    m.MPPIController.p2pConnectLocal(ranks)
+    outs = [[], []]
+    barrier = threading.Barrier(2)
+    ts = [threading.Thread(target=drive, args=(ranks[r], outs[r], barrier)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not any(t.is_alive() for t in ts)
+    for c in ranks:
+        c.close()
+    assert len(outs[0]) == 3 and len(outs[1]) == 3
+    for a, b, r in zip(outs[0], outs[1], ref):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] == r[2]
+        assert np.abs(a[0] - r[0]).max() <= 5e-6 and np.abs(a[1] - r[1]).max() <= 5e-6
