@@ -80,7 +80,9 @@ typedef enum mppi_kernel_variant
 {
   MPPI_KERNEL_AUTO = 0,     /* pipeline where the model is registered for it and the block shape is (64, 1), else fused */
   MPPI_KERNEL_FUSED = 1,    /* one wave carries sampling, dynamics and cost of its rollouts (engine/rollout_kernel.hpp) */
-  MPPI_KERNEL_PIPELINE = 2  /* sampler / dynamics / cost waves decoupled through LDS (engine/rollout_pipeline_kernel.hpp) */
+  MPPI_KERNEL_PIPELINE = 2  /* sampler / dynamics / cost waves decoupled through LDS (engine/rollout_pipeline_kernel.hpp);
+                             * Robust MPPI: engine/rmppi_pipeline_kernel.hpp (rollout and candidate evaluation), for models
+                             * with replicated-lane dynamics and the Gaussian sampler — what AUTO picks there as well */
 } mppi_kernel_variant;
 
 /**
