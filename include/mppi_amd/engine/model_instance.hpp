@@ -656,6 +656,12 @@ struct ModelT : ModelBase
       const size_t smem = kernels::pipelineRepSharedBytes(fast, cost, smp, ring);
       auto kfn = in_loop ? kernels::rolloutPipelineRepKernel<FAST, COST_T, SAMPLING_T, SAMPLING_T::IN_LOOP_DRAW>
                          : kernels::rolloutPipelineRepKernel<FAST, COST_T, SAMPLING_T, false>;
+      if constexpr (SAMPLING_T::SUPPORTS_GLOBAL_ROWS)
+      {
+        if (smp.rows_global_d_)  // long horizons: the sample rows in HBM
+          kfn = in_loop ? kernels::rolloutPipelineRepKernel<FAST, COST_T, SAMPLING_T, SAMPLING_T::IN_LOOP_DRAW, true>
+                        : kernels::rolloutPipelineRepKernel<FAST, COST_T, SAMPLING_T, false, true>;
+      }
       if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem);
@@ -691,6 +697,12 @@ struct ModelT : ModelBase
       const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
       auto kfn = in_loop ? kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, SAMPLING_T::IN_LOOP_DRAW, FOLD>
                          : kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, false, FOLD>;
+      if constexpr (SAMPLING_T::SUPPORTS_GLOBAL_ROWS)
+      {
+        if (smp.rows_global_d_)  // long horizons: the sample rows in HBM
+          kfn = in_loop ? kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, SAMPLING_T::IN_LOOP_DRAW, FOLD, true>
+                        : kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, false, FOLD, true>;
+      }
       if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem);

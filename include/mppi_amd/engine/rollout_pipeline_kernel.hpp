@@ -59,7 +59,9 @@ __host__ inline size_t pipelineSharedBytes(const DYN_T& dyn, const COST_T& cost,
   n += calcClassSharedMemSize(&cost, slots);
   n += calcClassSharedMemSize(&smp, slots);
   n += sizeof(float) * 2 * math::nearest_multiple_4(slots);                     // cost_s, w_s
-  n += sizeof(float) * (size_t)rings * pipeRingSteps(DYN_T::OUTPUT_DIM) * DYN_T::OUTPUT_DIM * 64;  // output ring [z][slot][i][lane]
+  // output ring [z][slot][i][lane]; with the rows in HBM the clamped control travels through it as well
+  n += sizeof(float) * (size_t)rings * pipeRingSteps(DYN_T::OUTPUT_DIM) *
+       (DYN_T::OUTPUT_DIM + (smp.rows_global_d_ ? DYN_T::CONTROL_DIM : 0)) * 64;
   n += sizeof(int) * 4 * 4 * rings;                                              // progress counters (padded)
   return n;
 }
@@ -133,7 +135,10 @@ __host__ __device__ constexpr int pipelineBlockX(int bz, bool fold_z)
   return (bz == 1 || fold_z) ? 64 * (2 + PIPE_SAMPLERS) : 64 * PIPE_ROLES;
 }
 
-template <class DYN_T, class COST_T, class SAMPLING_T, int BZ, bool DRAW_IN_LOOP, bool FOLD_Z = false>
+/** ROWS_HBM: the sample rows of the block in the sampler's HBM buffer (long horizons) — see rolloutPipelineRepKernel: the
+ *  dynamics wave fetches the next trip's samples while it computes the current one, the clamped control reaches the cost
+ *  wave through the output ring */
+template <class DYN_T, class COST_T, class SAMPLING_T, int BZ, bool DRAW_IN_LOOP, bool FOLD_Z = false, bool ROWS_HBM = false>
 __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ))
     rolloutPipelineKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args)
 {
@@ -192,13 +197,20 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* theta_s_shared = reinterpret_cast<float*>(smem_raw);
   float* theta_c_shared = theta_s_shared + calcClassSharedMemSize(dynamics, SLOTS) / (int)sizeof(float);
-  float* theta_d_shared = theta_c_shared + calcClassSharedMemSize(costs, SLOTS) / (int)sizeof(float);
-  float* cost_s = theta_d_shared + calcClassSharedMemSize(sampling, SLOTS) / (int)sizeof(float);
+  float* theta_d_lds = theta_c_shared + calcClassSharedMemSize(costs, SLOTS) / (int)sizeof(float);
+  float* theta_d_shared = theta_d_lds;
+  if constexpr (ROWS_HBM)
+  {
+    theta_d_shared = sampling->blockRows(theta_d_lds, (int)blockIdx.x, SLOTS);
+    sampling->setStagingBase(theta_d_lds);
+  }
+  constexpr int F = O + (ROWS_HBM ? C : 0);  // floats per step and rollout in the output ring
+  float* cost_s = theta_d_lds + calcClassSharedMemSize(sampling, SLOTS) / (int)sizeof(float);
   float* w_s = cost_s + math::nearest_multiple_4(SLOTS);
   float* ring_all = w_s + math::nearest_multiple_4(SLOTS);
-  float* ring = ring_all + (size_t)ring_z * PIPE_RING * O * 64;  // [slot][i][lane]
+  float* ring = ring_all + (size_t)ring_z * PIPE_RING * F * 64;  // [slot][i][lane]
   lds_counter_t counters =
-      (lds_counter_t)(reinterpret_cast<int*>(ring_all + (size_t)WZ * PIPE_RING * O * 64) + 16 * ring_z);
+      (lds_counter_t)(reinterpret_cast<int*>(ring_all + (size_t)WZ * PIPE_RING * F * 64) + 16 * ring_z);
   lds_counter_t smp_prog = counters + 0;   // steps whose shaped sample is in the row
   lds_counter_t dyn_prog = counters + 4;   // steps whose output is in the ring
   lds_counter_t cost_prog = counters + 8;  // steps the cost wave has consumed
@@ -327,13 +339,37 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
           row[t * C + i] = u[i];
       }
       dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
-      float* slot = ring + (size_t)(t % PIPE_RING) * O * 64 + lane;
+      float* slot = ring + (size_t)(t % PIPE_RING) * F * 64 + lane;
 #pragma unroll
       for (int i = 0; i < O; i++)
         slot[i * 64] = y[i];
+      if constexpr (ROWS_HBM)
+      {
+#pragma unroll
+        for (int i = 0; i < C; i++)
+          slot[(O + i) * 64] = u[i];
+      }
     };
     int seen_smp = 0, seen_smp1 = 0, seen_cost = 0;
     int t = 0;
+    auto wait_trip = [&](const int tp, const int need) {  // the samples of the trip that starts at step tp are in the rows
+      if (NS == 2 && (tp & 4))
+        pipeWait(smp_prog1, need, seen_smp1);
+      else
+        pipeWait(smp_prog, need, seen_smp);
+    };
+    float unext[4 * C];  // ROWS_HBM: the next trip's samples, in flight while the current trip runs
+    auto prefetch = [&](const int tp) {
+      if (tp < num_timesteps)
+      {
+        wait_trip(tp, min(tp + 4, num_timesteps));
+#pragma unroll
+        for (int j = 0; j < 4 * C; j++)
+          unext[j] = (tp * C + j < num_timesteps * C) ? row[tp * C + j] : 0.0f;
+      }
+    };
+    if constexpr (ROWS_HBM)
+      prefetch(0);
     // Full groups of 4 steps form ONE basic block (no tail test between the steps): the recurrence is skewed — the angle
     // of step t + 1 depends only on the state at t, not on step t's derivative — so the scheduler can start the next
     // step's argument reduction / sincos underneath the current step's division chain.  A single wave issues in order,
@@ -341,15 +377,23 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
     // the critical path.
     for (; t + 3 < num_timesteps; t += 4)
     {
-      if (NS == 2 && (t & 4))                            // samples for steps t .. t+3 are in the rows
-        pipeWait(smp_prog1, t + 4, seen_smp1);
-      else
-        pipeWait(smp_prog, t + 4, seen_smp);
+      if constexpr (!ROWS_HBM)
+        wait_trip(t, t + 4);                             // samples for steps t .. t+3 are in the rows
       pipeWait(cost_prog, t + 4 - PIPE_RING, seen_cost); // their ring slots have been consumed
       float ubuf[4 * C];
+      if constexpr (ROWS_HBM)
+      {
 #pragma unroll
-      for (int j = 0; j < 4 * C; j++)
-        ubuf[j] = row[t * C + j];
+        for (int j = 0; j < 4 * C; j++)
+          ubuf[j] = unext[j];
+        prefetch(t + 4);
+      }
+      else
+      {
+#pragma unroll
+        for (int j = 0; j < 4 * C; j++)
+          ubuf[j] = row[t * C + j];
+      }
       dyn_step(x, x_next, t, &ubuf[0]);
       dyn_step(x_next, x, t + 1, &ubuf[C]);
       dyn_step(x, x_next, t + 2, &ubuf[2 * C]);
@@ -359,15 +403,13 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
     if (t < num_timesteps)
     {  // tail of 1..3 steps
       const int hi = num_timesteps;
-      if (NS == 2 && (t & 4))
-        pipeWait(smp_prog1, hi, seen_smp1);
-      else
-        pipeWait(smp_prog, hi, seen_smp);
+      if constexpr (!ROWS_HBM)
+        wait_trip(t, hi);
       pipeWait(cost_prog, hi - PIPE_RING, seen_cost);
       float ubuf[4 * C];
 #pragma unroll
       for (int j = 0; j < 4 * C; j++)
-        ubuf[j] = (t * C + j < num_timesteps * C) ? row[t * C + j] : 0.0f;
+        ubuf[j] = ROWS_HBM ? unext[j] : ((t * C + j < num_timesteps * C) ? row[t * C + j] : 0.0f);
       dyn_step(x, x_next, t, &ubuf[0]);
       if (t + 1 < num_timesteps)
         dyn_step(x_next, x, t + 1, &ubuf[C]);
@@ -381,13 +423,13 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
     /* ------------------------------------------------ cost wave --------------------------------------------------- */
     int seen_dyn = 0;
     auto cost_step = [&](const int tt) {
-      const float* slot = ring + (size_t)(tt % PIPE_RING) * O * 64 + lane;
+      const float* slot = ring + (size_t)(tt % PIPE_RING) * F * 64 + lane;
 #pragma unroll
       for (int i = 0; i < O; i++)
         y[i] = slot[i * 64];
 #pragma unroll
       for (int i = 0; i < C; i++)
-        u[i] = row[tt * C + i];
+        u[i] = ROWS_HBM ? slot[(O + i) * 64] : row[tt * C + i];
       running_cost += costs->computeRunningCost(y, u, tt, theta_c_shared, &crash_status) +
                       sampling->template computeLikelihoodRatioCost<FOLD_Z>(u, theta_d_shared, global_idx, tt,
                                                                             distribution_idx, args.lambda, args.alpha);
@@ -468,8 +510,9 @@ __host__ inline size_t pipelineRepSharedBytes(const DYN_T& dyn, const COST_T& co
   size_t n = 0;
   n += calcClassSharedMemSize(&dyn, slots);
   n += calcClassSharedMemSize(&cost, slots);
-  n += calcClassSharedMemSize(&smp, slots) - samplerGrdBytes(&smp);       // the sample rows
-  const size_t ring_bytes = sizeof(float) * (size_t)ring * DYN_T::OUTPUT_DIM * 64;  // output ring [slot][i][rollout]
+  n += calcClassSharedMemSize(&smp, slots) - samplerGrdBytes(&smp);       // the sample rows (none when they live in HBM)
+  // output ring [slot][i][rollout]; with the rows in HBM the clamped control travels through it as well
+  const size_t ring_bytes = sizeof(float) * (size_t)ring * (DYN_T::OUTPUT_DIM + (smp.rows_global_d_ ? DYN_T::CONTROL_DIM : 0)) * 64;
   n += ring_bytes > (size_t)samplerGrdBytes(&smp) ? ring_bytes : (size_t)samplerGrdBytes(&smp);
   n += sizeof(float) * 4 * math::nearest_multiple_4(slots);              // cost_s, w_s, relay_cost, relay_status
   n += sizeof(int) * 4 * (replicated_lanes<DYN_T>::value + PIPE_REP_SAMPLERS + 1);  // progress counters (padded)
@@ -497,7 +540,14 @@ __device__ inline void vgprResident(T& obj)
     asm volatile("" : "+v"(w[i]));
 }
 
-template <class DYN_T, class COST_T, class SAMPLING_T, bool DRAW_IN_LOOP>
+/**
+ * ROWS_HBM (long horizons: T * C floats per rollout do not fit the LDS next to the ring): the block's sample rows live in the
+ * sampler's HBM buffer (blockRows).  The sampler waves write them there (write-through stores, nobody waits for them), the
+ * dynamics waves fetch the samples of the NEXT pair of steps while they compute the current one (the rows are complete far
+ * ahead of them), and the clamped control travels to the cost waves through the output ring next to the outputs — so no wave
+ * waits on a global load inside its step loop.  Same arithmetic, same bits.
+ */
+template <class DYN_T, class COST_T, class SAMPLING_T, bool DRAW_IN_LOOP, bool ROWS_HBM = false>
 __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_REP_SAMPLERS + PIPE_REP_COSTS))
     rolloutPipelineRepKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args,
                              const int ring_steps)
@@ -548,10 +598,17 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* theta_s_shared = reinterpret_cast<float*>(smem_raw);
   float* theta_c_shared = theta_s_shared + calcClassSharedMemSize(dynamics, SLOTS) / (int)sizeof(float);
-  float* theta_d_shared = theta_c_shared + calcClassSharedMemSize(costs, SLOTS) / (int)sizeof(float);
+  float* theta_d_lds = theta_c_shared + calcClassSharedMemSize(costs, SLOTS) / (int)sizeof(float);
+  float* theta_d_shared = theta_d_lds;
+  if constexpr (ROWS_HBM)
+  {
+    theta_d_shared = sampling->blockRows(theta_d_lds, block_idx, SLOTS);
+    sampling->setStagingBase(theta_d_lds);
+  }
+  constexpr int F = O + (ROWS_HBM ? C : 0);  // floats per step and rollout in the output ring
   // [sample rows][sampler Grd (prologue only)  U  output ring (step loop only)][cost_s][w_s][counters]
-  float* ring = theta_d_shared + (calcClassSharedMemSize(sampling, SLOTS) - samplerGrdBytes(sampling)) / (int)sizeof(float);
-  const int overlay_floats = max(ring_steps * O * 64, samplerGrdBytes(sampling) / (int)sizeof(float));
+  float* ring = theta_d_lds + (calcClassSharedMemSize(sampling, SLOTS) - samplerGrdBytes(sampling)) / (int)sizeof(float);
+  const int overlay_floats = max(ring_steps * F * 64, samplerGrdBytes(sampling) / (int)sizeof(float));
   float* cost_s = ring + overlay_floats;
   float* w_s = cost_s + math::nearest_multiple_4(SLOTS);
   float* relay_cost = w_s + math::nearest_multiple_4(SLOTS);  // running cost / status handed from cost wave to cost wave
@@ -646,10 +703,16 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
       dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
       if (rep_lane == 0)
       {
-        float* slot = ring + (size_t)(t & ring_mask) * O * 64 + thread_idx;
+        float* slot = ring + (size_t)(t & ring_mask) * F * 64 + thread_idx;
 #pragma unroll
         for (int i = 0; i < O; i++)
           slot[i * 64] = y[i];
+        if constexpr (ROWS_HBM)
+        {
+#pragma unroll
+          for (int i = 0; i < C; i++)
+            slot[(O + i) * 64] = u[i];
+        }
       }
     };
     int seen_smp[NS], seen_cost = 0;
@@ -673,16 +736,39 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
     // full pairs of steps as one basic block (see rolloutPipelineKernel): lets the scheduler overlap the second step's
     // independent work with the first step's MFMA chains
     PIPE_T(PipeTimer tm; tm.start();)
+    float unext[2 * C];  // ROWS_HBM: the samples of the pair after the current one, in flight while the current one runs
+    auto prefetch = [&](const int tp) {
+      if (tp < num_timesteps)
+      {
+        wait_samples(tp, min(tp + 2, num_timesteps));
+#pragma unroll
+        for (int j = 0; j < 2 * C; j++)
+          unext[j] = (tp * C + j < num_timesteps * C) ? row[tp * C + j] : 0.0f;
+      }
+    };
+    if constexpr (ROWS_HBM)
+      prefetch(0);
     for (; t + 1 < num_timesteps; t += 2)
     {
-      wait_samples(t, t + 2);
+      if constexpr (!ROWS_HBM)
+        wait_samples(t, t + 2);
       PIPE_T(tm.stop(1);)  // slot 1: waiting for the sampler
       pipeWait(cost_prog, t + 2 - ring_steps, seen_cost);
       PIPE_T(tm.stop(2);)  // slot 2: waiting for the cost waves (ring back-pressure)
       float ubuf[2 * C];
+      if constexpr (ROWS_HBM)
+      {
 #pragma unroll
-      for (int j = 0; j < 2 * C; j++)
-        ubuf[j] = row[t * C + j];
+        for (int j = 0; j < 2 * C; j++)
+          ubuf[j] = unext[j];
+        prefetch(t + 2);
+      }
+      else
+      {
+#pragma unroll
+        for (int j = 0; j < 2 * C; j++)
+          ubuf[j] = row[t * C + j];
+      }
       dyn_step(x, x_next, t, &ubuf[0]);
       dyn_step(x_next, x, t + 1, &ubuf[C]);
       pipePublish(my_prog, t + 2, lane);
@@ -691,12 +777,13 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
     PIPE_T(tm.flush(block_idx, wave, lane);)
     if (t < num_timesteps)
     {
-      wait_samples(t, num_timesteps);
+      if constexpr (!ROWS_HBM)
+        wait_samples(t, num_timesteps);
       pipeWait(cost_prog, num_timesteps - ring_steps, seen_cost);
       float ubuf[C];
 #pragma unroll
       for (int j = 0; j < C; j++)
-        ubuf[j] = row[t * C + j];
+        ubuf[j] = ROWS_HBM ? unext[j] : row[t * C + j];
       dyn_step(x, x_next, t, &ubuf[0]);
       pipePublish(my_prog, num_timesteps, lane);
     }
@@ -740,13 +827,13 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
       for (int q = 0; q < 2; q++)
       {
         const int tt = min(t + q, num_timesteps - 1);
-        const float* slot = ring + (size_t)(tt & ring_mask) * O * 64 + lane;
+        const float* slot = ring + (size_t)(tt & ring_mask) * F * 64 + lane;
 #pragma unroll
         for (int i = 0; i < O; i++)
           yb[q][i] = slot[i * 64];
 #pragma unroll
         for (int i = 0; i < C; i++)
-          ub[q][i] = row[tt * C + i];
+          ub[q][i] = ROWS_HBM ? slot[(O + i) * 64] : row[tt * C + i];
       }
       PIPE_T(tm.stop(3);)  // slot 3: fetching outputs / controls of the pair
       float cq[2] = { 0.0f, 0.0f };
@@ -794,7 +881,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
   if (writer)
   {
     running_cost = relay_cost[lane];
-    const float* slot = ring + (size_t)((num_timesteps - 1) & ring_mask) * O * 64 + lane;
+    const float* slot = ring + (size_t)((num_timesteps - 1) & ring_mask) * F * 64 + lane;
 #pragma unroll
     for (int i = 0; i < O; i++)
       y[i] = slot[i * 64];

@@ -535,13 +535,28 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   size_t lds = cfg->controller == MPPI_CONTROLLER_ROBUST ?
                    h->model->rmppiSharedBytes(h->bx, cfg->num_timesteps) :
                    h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, h->pipeline);
+  const char* force_hbm_rows = getenv("MPPI_AMD_ROWS_IN_HBM");  // test hook: the HBM-row variant at any horizon
+  const bool hbm_forced = force_hbm_rows && force_hbm_rows[0] == '1';
+  if (h->pipeline && (lds > MAX_LDS_BYTES || hbm_forced) && h->model->globalRowsFloats(1, 1, cfg->num_timesteps) > 0)
+  {
+    // the role-pipelined kernels at horizons whose rows do not fit the LDS next to the output ring: rows in HBM (round 3:
+    // the dynamics waves fetch a trip ahead, the clamped control reaches the cost waves through the ring)
+    h->model->setGlobalRows(reinterpret_cast<float*>(16));  // placeholder until the buffer exists: sizes the LDS request
+    const size_t need = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, true);
+    if (need <= MAX_LDS_BYTES)
+    {
+      h->rows_in_hbm = true;
+      lds = need;
+    }
+    else
+      h->model->setGlobalRows(nullptr);
+  }
   if (lds > MAX_LDS_BYTES && h->pipeline && cfg->kernel_variant == MPPI_KERNEL_AUTO)
   {  // the output ring does not fit next to the sample rows: fall back to the fused variant
     h->pipeline = false;
     lds = h->model->rolloutSharedBytes(h->bx, h->by, h->bz, cfg->num_timesteps, h->D, false);
   }
-  const char* force_hbm_rows = getenv("MPPI_AMD_ROWS_IN_HBM");  // test hook: the HBM-row variant at any horizon
-  const bool want_hbm_rows = !h->rm_pipeline && (lds > MAX_LDS_BYTES || (force_hbm_rows && force_hbm_rows[0] == '1'));
+  const bool want_hbm_rows = !h->rm_pipeline && !h->rows_in_hbm && (lds > MAX_LDS_BYTES || hbm_forced);
   if (want_hbm_rows && cfg->controller == MPPI_CONTROLLER_ROBUST && h->model->globalRowsFloats(1, 1, cfg->num_timesteps) > 0)
   {
     // Robust MPPI at horizons whose rows of even 32 rollouts x 2 systems overflow the LDS (or on request): the (64, 1, 2)
@@ -2493,7 +2508,7 @@ mppi_status mppi_choose_kernel(mppi_handle h, int num_evaluations, int* chosen_v
   if (num_evaluations <= 0)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_choose_kernel: num_evaluations must be > 0");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-  const bool pipe_ok = h->cfg.controller != MPPI_CONTROLLER_ROBUST && !h->rows_in_hbm &&
+  const bool pipe_ok = h->cfg.controller != MPPI_CONTROLLER_ROBUST &&
                        ((h->model->supportsPipeline() && h->bx == 64 && h->by == 1) ||
                         h->model->supportsPipelineFold(h->bx, h->by, h->bz) || h->model->supportsPipelineRep(h->bx, h->by, h->bz)) &&
                        h->model->rolloutSharedBytes(h->bx, h->by, h->bz, h->cfg.num_timesteps, h->D, true) <= MAX_LDS_BYTES;

@@ -40,6 +40,57 @@ def test_hbm_rows_bit_identical_to_lds_rows(gpu, mk, noise):
     assert np.array_equal(a.getOptimalControlSeq(), b.getOptimalControlSeq())
 
 
+@pytest.mark.parametrize("mk", [lambda: cartpole_cfg_lr(K=1000, T=50), lambda: cartpole_cfg(K=333, T=7, soft=True),
+                                lambda: di_cfg(K=512, T=33, tube=True), lambda: autorally_cfg(K=200, T=37),
+                                lambda: autorally_cfg(K=130, T=2)],
+                         ids=["cartpole", "cartpole-T7", "di-tube", "autorally-mfma", "autorally-T2"])
+@pytest.mark.parametrize("noise", ["injected", "philox"])
+def test_pipelined_kernels_hbm_rows_bit_identical_to_lds_rows(gpu, mk, noise):
+    """the role-pipelined kernels with the rows in HBM (round 3: the dynamics waves fetch a trip ahead, the clamped control
+    reaches the cost waves through the output ring): costs, samples and u* are the bits of the LDS-row kernels — one lane per
+    rollout (two samplers), two systems per block, replicated-lane dynamics, horizons shorter than a trip"""
+    cfg = mk()
+    a = make_engine(cfg, kernel_variant=2, save_samples=True)
+    b = _engine_with_hbm_rows(cfg, kernel_variant=2, save_samples=True)
+    x0 = np.tile(cfg["x0"], (cfg["D"], 1))
+    for eng in (a, b):
+        if noise == "injected":
+            eng.injectNoise(host_noise(1, cfg["K"], cfg["T"], eng.CONTROL_DIM))
+        eng.uploadState(x0)
+        eng.optimize(2)
+    assert np.array_equal(a.getSampledCostSeq(), b.getSampledCostSeq())
+    assert np.array_equal(a.getSampledControls(), b.getSampledControls())
+    assert np.array_equal(a.getOptimalControlSeq(), b.getOptimalControlSeq())
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("mk,T", [(cartpole_cfg, 2000), (autorally_cfg, 1000)], ids=["cartpole-T2000", "autorally-T1000"])
+def test_pipelined_kernels_long_horizon_vs_oracle(gpu, mk, T):
+    """horizons whose rows do not fit the LDS stay on the role-pipelined kernels (the default; rows in HBM) and agree with
+    the oracle; the fused kernel on the same rows gives the same bits"""
+    cfg = mk(K=256, T=T, soft=True) if mk is cartpole_cfg else mk(K=256, T=T)
+    eng, orc = make_engine(cfg, kernel_variant=2), make_oracle(cfg)
+    C = eng.CONTROL_DIM
+    eps = host_noise(1, cfg["K"], cfg["T"], C)
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    orc.vanilla_compute_control(cfg["x0"], 1, eps)
+    assert ulp_diff(eng.getSampledCostSeq(), orc.costs()).max() == 0
+    assert np.abs(eng.getControlSeq() - orc.control()).max() <= 1e-5
+    costs = eng.getSampledCostSeq().copy()
+    eng.close()
+    auto = make_engine(cfg)  # no request: the pipelined kernel as well
+    fused = make_engine(cfg, kernel_variant=1)
+    for e in (auto, fused):
+        e.injectNoise(eps)
+        e.computeControl(cfg["x0"], 1)
+    assert np.array_equal(auto.getSampledCostSeq(), costs) and np.array_equal(fused.getSampledCostSeq(), costs)
+    assert np.array_equal(auto.getControlSeq(), fused.getControlSeq())
+    auto.close()
+    fused.close()
+
+
 def test_cartpole_T5000_vs_oracle(gpu):
     """T = 5000: 20 KB of samples per rollout — no block shape fits the LDS; mppi_create moves the rows to HBM by itself"""
     cfg = cartpole_cfg(K=2048, T=5000, soft=True)
@@ -76,16 +127,19 @@ def test_colored_sampler_T1000_vs_oracle(gpu):
     assert ulp_diff(eng.getSampledCostSeq(), orc.costs()).max() == 0
     assert np.abs(eng.getControlSeq() - orc.control()).max() <= 1e-5
     eng.close()
-    # and the same kernel with the rows forced into HBM at a horizon that would fit: the same bits as with LDS rows
+    # and the same kernels with the rows forced into HBM at a horizon that would fit: the same bits as with LDS rows
     cfg = cartpole_cfg(K=300, T=64, soft=True)
     cfg["colored"] = ([1.0], 0.97, 0.0)
-    a = make_engine(cfg, kernel_variant=1)
-    b = _engine_with_hbm_rows(cfg, kernel_variant=1)
-    for eng in (a, b):
-        eng.uploadState(cfg["x0"])
-        eng.optimize(2)
-    assert np.array_equal(a.getSampledCostSeq(), b.getSampledCostSeq())
-    assert np.array_equal(a.getOptimalControlSeq(), b.getOptimalControlSeq())
+    for variant in (1, 2):  # fused, role-pipelined
+        a = make_engine(cfg, kernel_variant=variant)
+        b = _engine_with_hbm_rows(cfg, kernel_variant=variant)
+        for eng in (a, b):
+            eng.uploadState(cfg["x0"])
+            eng.optimize(2)
+        assert np.array_equal(a.getSampledCostSeq(), b.getSampledCostSeq())
+        assert np.array_equal(a.getOptimalControlSeq(), b.getOptimalControlSeq())
+        a.close()
+        b.close()
 
 
 def test_rmppi_T1000_vs_oracle(gpu):
