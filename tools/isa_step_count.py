@@ -20,12 +20,13 @@ import isa_tu  # noqa: E402
 
 # (key, translation unit, kernel-name substrings, steps per trip of the dynamics loop, marker class)
 KERNELS = [
-    ("cartpole_pipeline_dynamics_wave", "cartpole.hip", ["rolloutPipelineKernel", "Cartpole", "GaussianDistribution", "ELi1E"],
-     4, "valu_pk"),
-    ("autorally_mfma_pipeline_dynamics_wave", "autorally_nn.hip", ["rolloutPipelineRepKernel", "NeuralNetModelMFMA", "ELb1E"],
-     None, "mfma"),
-    ("lstm_mfma_pipeline_dynamics_wave", "bicycle_slip_lstm.hip", ["rolloutPipelineRepKernel", "BicycleSlipLSTMMFMA", "ELb1E"],
-     None, "mfma"),
+    # (template tails: <.., BZ = 1, DRAW_IN_LOOP, FOLD_Z = false, ROWS_HBM = false> / <.., DRAW_IN_LOOP, ROWS_HBM = false>)
+    ("cartpole_pipeline_dynamics_wave", "cartpole.hip",
+     ["rolloutPipelineKernel", "Cartpole", "GaussianDistribution", "ELi1ELb1ELb0ELb0EE"], 4, "valu_pk"),
+    ("autorally_mfma_pipeline_dynamics_wave", "autorally_nn.hip",
+     ["rolloutPipelineRepKernel", "NeuralNetModelMFMA", "GaussianDistribution", "ELb1ELb0EE"], None, "mfma"),
+    ("lstm_mfma_pipeline_dynamics_wave", "bicycle_slip_lstm.hip",
+     ["rolloutPipelineRepKernel", "BicycleSlipLSTMMFMA", "GaussianDistribution", "ELb1ELb0EE"], None, "mfma"),
 ]
 
 
