@@ -11,6 +11,7 @@
 #include "mppi_amd/plugin/dynamics.hpp"
 #include "mppi_amd/utils/nn_helpers/fnn_helper.hpp"
 #include "mppi_amd/utils/nn_helpers/fnn_mfma.hpp"
+#include "mppi_amd/utils/nn_helpers/fnn_wave.hpp"
 
 struct NNDynamicsParams : public DynamicsParams
 {
@@ -116,6 +117,9 @@ public:
  * (REPLICATED_LANES, see csrc/rollout_kernel.hpp), so no LDS slot and no barrier is involved.
  */
 template <int S_DIM, int C_DIM, int K_DIM>
+class NeuralNetModelWave;
+
+template <int S_DIM, int C_DIM, int K_DIM>
 class NeuralNetModelMFMA : public Dynamics<NeuralNetModelMFMA<S_DIM, C_DIM, K_DIM>, NNDynamicsParams>
 {
 public:
@@ -123,6 +127,8 @@ public:
   static const int DYNAMICS_DIM = S_DIM - K_DIM;
   static constexpr int REPLICATED_LANES = 4;
   using NET = mppi::FNNMfma<DYNAMICS_DIM + C_DIM, 32, 4>;
+  /** the form the single-trajectory re-rollout runs on (engine: finalizeRepKernel): one rollout per wave, lane = neuron */
+  using FINALIZE_FORM = NeuralNetModelWave<S_DIM, C_DIM, K_DIM>;
 
   /** shares parameters, control ranges and the weight blob with the plain model */
   NeuralNetModelMFMA(const NeuralNetModel<S_DIM, C_DIM, K_DIM>& other) : PARENT_CLASS(other.stream_)
@@ -180,6 +186,74 @@ public:
 
   const float* theta_d_ = nullptr;
   NET net_;  ///< per-thread weight fragments: the object is passed to the kernel by value, so this lives in VGPRs
+};
+
+/**
+ * The same model for ONE rollout on a whole wave (utils/nn_helpers/fnn_wave.hpp: lane j is neuron j of a layer, the
+ * activations travel by v_readlane).  All 64 lanes carry the rollout's state (REPLICATED_LANES = 64); same fma chains as the
+ * other forms, so the trajectories are the same bits.  Used for the re-rollout of the optimised control sequence, a chain of
+ * T dependent steps: 0.5 us per step against 1.2 us on the MFMA form, whose 18 dependent MFMAs per step only pay for 16
+ * rollouts at a time.
+ */
+template <int S_DIM, int C_DIM, int K_DIM>
+class NeuralNetModelWave : public Dynamics<NeuralNetModelWave<S_DIM, C_DIM, K_DIM>, NNDynamicsParams>
+{
+public:
+  using PARENT_CLASS = Dynamics<NeuralNetModelWave<S_DIM, C_DIM, K_DIM>, NNDynamicsParams>;
+  static const int DYNAMICS_DIM = S_DIM - K_DIM;
+  static constexpr int REPLICATED_LANES = 64;
+  using NET = mppi::FNNWave<DYNAMICS_DIM + C_DIM, 32, 4>;
+
+  NeuralNetModelWave(const NeuralNetModel<S_DIM, C_DIM, K_DIM>& other) : PARENT_CLASS(other.stream_)
+  {
+    this->params_ = other.params_;
+    for (int i = 0; i < C_DIM; i++)
+    {
+      this->control_rngs_[i] = other.control_rngs_[i];
+      this->control_deadband_[i] = other.control_deadband_[i];
+      this->zero_control_[i] = other.zero_control_[i];
+    }
+    theta_d_ = other.helper_.theta_d_;
+  }
+  __host__ __device__ int getGrdSharedSizeBytes() const
+  {
+    return 0;
+  }
+  __host__ __device__ int getBlkSharedSizeBytes() const
+  {
+    return 0;
+  }
+  __device__ inline void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
+                                            float dt)
+  {
+    PARENT_CLASS::initializeDynamics(state, control, output, theta_s, t_0, dt);
+    net_.load(theta_d_, (int)(threadIdx.x & 63));
+  }
+  __device__ inline void computeKinematics(float* state, float* state_der)
+  {
+    float s, c;
+    mppi::det::sincos(state[2], &s, &c);
+    state_der[0] = c * state[4] - s * state[5];
+    state_der[1] = s * state[4] + c * state[5];
+    state_der[2] = -state[6];
+  }
+  __device__ inline void computeDynamics(float* state, float* control, float* state_der, float* theta_s = nullptr)
+  {
+    float in[DYNAMICS_DIM + C_DIM], out[4];
+#pragma unroll
+    for (int i = 0; i < DYNAMICS_DIM; i++)
+      in[i] = state[i + (S_DIM - DYNAMICS_DIM)];
+#pragma unroll
+    for (int i = 0; i < C_DIM; i++)
+      in[DYNAMICS_DIM + i] = control[i];
+    net_.forward(in, out);
+#pragma unroll
+    for (int i = 0; i < DYNAMICS_DIM; i++)
+      state_der[i + (S_DIM - DYNAMICS_DIM)] = out[i];
+  }
+
+  const float* theta_d_ = nullptr;
+  NET net_;
 };
 
 #endif

@@ -312,6 +312,15 @@ template <class T>
 struct has_lstm_structure<T, std::void_t<decltype(std::declval<T&>().setLSTMStructure((const int*)nullptr, 0))>> : std::true_type
 {
 };
+/** a replicated-lane form that names a sibling made for ONE rollout per wave (`using FINALIZE_FORM = ...`) */
+template <class T, class = void>
+struct has_finalize_form : std::false_type
+{
+};
+template <class T>
+struct has_finalize_form<T, std::void_t<typename T::FINALIZE_FORM>> : std::true_type
+{
+};
 template <class T, class = void>
 struct has_register_form : std::false_type
 {
@@ -1491,6 +1500,33 @@ struct ModelT : ModelBase
   {
     if (!blobsReady(err))
       return MPPI_ERR_STATE;
+    if constexpr (has_finalize_form<DYN_FAST_T>::value)
+    {
+      // a form of the model made for ONE rollout on a wave (NN models: lane = neuron, utils/nn_helpers/fnn_wave.hpp): the
+      // re-rollout is a chain of T dependent steps, what counts is the length of a step's dependent chain
+      // (MPPI_AMD_FINALIZE_FORM=rep: the replicated-lane form instead — tests compare the two)
+      const char* form = getenv("MPPI_AMD_FINALIZE_FORM");
+      if (!(form && form[0] == 'r'))
+      {
+        using WAVE_T = typename DYN_FAST_T::FINALIZE_FORM;
+        WAVE_T wave_form(dyn);
+        const size_t smem_w = kernels::finalizeRepSharedBytes(wave_form, a.num_timesteps);
+        if (smem_w <= MAX_LDS_BYTES)
+        {
+          auto kw = kernels::finalizeRepKernel<WAVE_T>;
+          if (smem_w > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w);
+          hipLaunchKernelGGL(kw, dim3(D), dim3(64, 1, 1), smem_w, stream, wave_form, a);
+          hipError_t e = hipGetLastError();
+          if (e != hipSuccess)
+          {
+            err = std::string("finalizeRepKernel (wave form) launch: ") + hipGetErrorString(e);
+            return MPPI_ERR_HIP;
+          }
+          return MPPI_OK;
+        }
+      }
+    }
     if constexpr (!std::is_void<DYN_FAST_T>::value)
     {  // replicated-lane (MFMA) dynamics: the register-resident single-wave variant
       DYN_FAST_T fast(dyn);

@@ -297,3 +297,30 @@ def test_autorally_requires_blobs(gpu):
     with pytest.raises(m.MPPIError) as e:
         c.setModelBlob("dynamics_weights", np.zeros(10, np.float32))
     assert e.value.status == 1
+
+
+@pytest.mark.gpu
+def test_trajectory_rerollout_wave_form_equals_mfma_form(gpu):
+    """the re-rollout of u* (state / output trajectories of computeControl) runs on the one-rollout-per-wave form of the NN
+    model (lane = neuron, fnn_wave.hpp); the replicated-lane MFMA form gives the same bits — Vanilla and Tube"""
+    import os
+    from common import autorally_cfg, make_engine
+    for tube in (False, True):
+        cfg = autorally_cfg(K=512, T=150)
+        if tube:
+            cfg["D"] = 2
+        got = []
+        for form in (None, "rep"):
+            if form:
+                os.environ["MPPI_AMD_FINALIZE_FORM"] = form
+            try:
+                eng = make_engine(cfg, tube=tube)
+                x = cfg["x0"].copy()
+                eng.computeControl(x, 1)
+                got.append((eng.getControlSeq().copy(), eng.getTargetStateSeq().copy(), eng.getTargetOutputSeq().copy()))
+                eng.close()
+            finally:
+                os.environ.pop("MPPI_AMD_FINALIZE_FORM", None)
+        for a, b in zip(*got):
+            assert np.array_equal(a, b)
+        assert np.isfinite(got[0][1]).all() and np.abs(got[0][1][-1] - got[0][1][0]).max() > 1e-3
