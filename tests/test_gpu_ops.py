@@ -75,10 +75,15 @@ def test_error_codes(gpu):
     with pytest.raises(m.MPPIError) as e:  # launch shape not instantiated (reference: exit(), mppi_common.cu:1266-1277)
         m.VanillaMPPIController("cartpole", 128, 10, 0.02, 1.0, block_x=48, block_y=3)
     assert e.value.status == 5
-    with pytest.raises(m.MPPIError) as e:  # LDS overflow (reference: runtime_error, mppi_controller.cu:64-76)
-        # (the fused kernel would move the rows to HBM; the pipeline variant keeps them in LDS and says so)
-        m.VanillaMPPIController("cartpole", 128, 2000, 0.02, 1.0, block_x=64, block_y=1, kernel_variant=2)
+    # LDS overflow (reference: runtime_error, mppi_controller.cu:64-76).  Every rollout kernel moves its sample rows to HBM
+    # when they do not fit (T = 2000 on the pipeline variant runs); what is left is the post-processing kernel, which keeps
+    # the control sequence in LDS: T * C beyond ~19 000
+    m.VanillaMPPIController("cartpole", 128, 2000, 0.02, 1.0, block_x=64, block_y=1, kernel_variant=2).close()
+    big = m.VanillaMPPIController("cartpole", 128, 25000, 0.02, 1.0)
+    with pytest.raises(m.MPPIError) as e:
+        big.computeControl(np.zeros(4, np.float32), 1)
     assert e.value.status == 6
+    big.close()
     with pytest.raises(m.MPPIError) as e:
         m.VanillaMPPIController("cartpole", 0, 10, 0.02, 1.0)
     assert e.value.status == 1
