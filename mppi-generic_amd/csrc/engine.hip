@@ -1690,6 +1690,17 @@ static mppi_status ensureTrajectories(mppi_handle h)
       return fail(h, MPPI_ERR_NAN, "non-finite value in the nominal state sequence of the last mppi_compute_control");
     return MPPI_OK;
   }
+  if (h->cfg.controller == MPPI_CONTROLLER_TUBE)
+  {  // system 0: the actual system, system 1: the nominal one (its first state is where the next call starts from)
+    MPPI_TRY(waitHostFlag(h, 3, h->io_seq));
+    h->traj_pending = false;
+    const float* xs = out + (h->state_out_d - h->out_block_d);
+    std::copy(xs, xs + (size_t)T * h->S, h->state_h.begin());
+    std::copy(xs + (size_t)T * h->S, xs + (size_t)2 * T * h->S, h->nominal_state_h.begin());
+    if (!allFinite(h->state_h) || !allFinite(h->nominal_state_h))
+      return fail(h, MPPI_ERR_NAN, "non-finite value in the state sequences of the last mppi_compute_control");
+    return MPPI_OK;
+  }
   h->traj_pending = false;
   std::copy(out + (h->state_out_d - h->out_block_d), out + (h->state_out_d - h->out_block_d) + (size_t)T * h->S,
             h->state_h.begin());
@@ -1801,6 +1812,84 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
   {
     std::copy(x0, x0 + S, h->nominal_state_h.begin());
     h->nominal_state_init = true;
+  }
+  if (h->low_latency)
+  {
+    /* Inputs and results through host memory mapped into the device, flags instead of copies + synchronisations (see
+     * computeControlVanilla).  Every optimisation pass needs both trajectories on the host (the nominal system is replaced by
+     * the actual one when that is the better of the two, :264-277), so the loop waits for all four flags; the final smoothing
+     * pass returns with the control sequences and leaves its two trajectories to ensureTrajectories(). */
+    MPPI_TRY(ensureTrajectories(h));
+    const int T = h->cfg.num_timesteps;
+    auto stage_inputs = [&]() -> mppi_status {
+      float* in = h->io_in_h;
+      std::copy(x0, x0 + S, in + (h->x0_d - h->in_block_d));
+      std::copy(h->nominal_state_h.begin(), h->nominal_state_h.begin() + S, in + (h->x0_d - h->in_block_d) + S);
+      float* mean = in + (h->mean_d - h->in_block_d);
+      std::copy(h->control_h.begin(), h->control_h.end(), mean);
+      std::copy(h->nominal_control_h.begin(), h->nominal_control_h.end(), mean + h->TC);
+      std::copy(h->history_h.begin(), h->history_h.end(), in + (h->history_d - h->in_block_d));
+      hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+      HIP_TRY(h, hipGetLastError());
+      return MPPI_OK;
+    };
+    auto finalize_flagged = [&](const int smooth_mask) -> mppi_status {
+      kernels::FinalizeArgs a{};
+      a.control_in_d = h->mean_d;
+      a.history_d = h->history_d;
+      a.history_stride = 0;
+      a.x0_d = h->x0_d;
+      a.dt = h->cfg.dt;
+      a.num_timesteps = T;
+      a.smooth_mask = smooth_mask;
+      a.constrain_mask = 0;
+      a.constrain_mode = 0;
+      a.control_out_d = h->io_out_dev + (h->ctrl_out_d - h->out_block_d);
+      a.state_out_d = h->io_out_dev + (h->state_out_d - h->out_block_d);
+      a.output_out_d = h->io_out_dev + (h->output_out_d - h->out_block_d);
+      a.stats_in_d = h->stats_d;
+      a.stats_out_d = h->io_out_dev + (h->stats_d - h->out_block_d);
+      a.stats_floats = 2 * kernels::STATS_STRIDE;
+      a.flags_d = h->io_flags_dev;
+      a.seq = ++h->io_seq;
+      std::string err;
+      const mppi_status st = h->model->launchFinalize(2, a, h->stream, err);
+      if (st != MPPI_OK)
+        return fail(h, st, err);
+      h->out_pin_fresh = false;
+      h->results_in_io = true;
+      h->traj_pending = true;  // set before the waits: a failing wait must not leave io_out unguarded for the next call
+      MPPI_TRY(waitHostFlag(h, 0, h->io_seq));
+      MPPI_TRY(waitHostFlag(h, 2, h->io_seq));
+      const float* out = h->io_out_h;
+      std::copy(out, out + (size_t)T * h->C, h->control_h.begin());
+      std::copy(out + (size_t)T * h->C, out + (size_t)2 * T * h->C, h->nominal_control_h.begin());
+      parseStats(h, out + (h->stats_d - h->out_block_d));
+      return MPPI_OK;
+    };
+    for (int it = 0; it < h->cfg.num_iters; it++)
+    {
+      MPPI_TRY(stage_inputs());
+      MPPI_TRY(iteration(h, it, stride));
+      MPPI_TRY(finalize_flagged(0));
+      MPPI_TRY(ensureTrajectories(h));
+      if (h->stats_h.real_sys.baseline < h->stats_h.nominal_sys.baseline + h->nominal_threshold)
+      {
+        h->stats_h.nominal_state_used = 0;
+        h->nominal_state_h = h->state_h;
+        h->nominal_control_h = h->control_h;
+      }
+      else
+      {
+        h->stats_h.nominal_state_used = 1;
+      }
+    }
+    // smoothControlTrajectory() smooths the nominal control (:281, :325-329), then computeStateTrajectory(state)
+    MPPI_TRY(stage_inputs());
+    MPPI_TRY(finalize_flagged(/*smooth nominal*/ 2));
+    if (!allFinite(h->control_h) || !allFinite(h->nominal_control_h))
+      return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control sequence");
+    return MPPI_OK;
   }
   std::vector<float>* co[2] = { &h->control_h, &h->nominal_control_h };
   std::vector<float>* so[2] = { &h->state_h, &h->nominal_state_h };
@@ -2232,6 +2321,7 @@ mppi_status mppi_slide(mppi_handle h, int steps)
   {
     // tube_mppi_controller.cu:312-323: updateNominalState(nominal_control.col(0)) — one in-place model step, no clamp
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    MPPI_TRY(ensureTrajectories(h));  // the nominal trajectory of the last mppi_compute_control (low-latency hand-over)
     HIP_TRY(h, hipMemcpyAsync(h->step_x_d, h->nominal_state_h.data(), sizeof(float) * h->S, hipMemcpyHostToDevice,
                               h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->step_u_d, h->nominal_control_h.data(), sizeof(float) * C, hipMemcpyHostToDevice,

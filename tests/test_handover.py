@@ -50,6 +50,37 @@ def test_vanilla_handovers_agree(gpu):
             assert np.array_equal(p, q)
 
 
+@pytest.mark.parametrize("num_iters", [1, 3])
+def test_tube_handovers_agree(gpu, num_iters):
+    """Tube MPPI: every optimisation pass needs both trajectories on the host (nominal <- actual when the actual system is the
+    better one), the final smoothing pass hands the control sequences over first"""
+    from common import di_cfg
+    cfg = di_cfg(K=1024, T=60, tube=True, num_iters=num_iters)
+    out = []
+    for env in (None, "1"):
+        eng = _with_env(env, lambda: make_engine(cfg))
+        x = cfg["x0"].copy()
+        rec = []
+        for i in range(5):
+            eng.computeControl(x, 1)
+            st = eng.getStats()
+            r = [eng.getControlSeq().copy(), eng.getNominalControlSeq().copy(),
+                 np.array([st.real_sys.baseline, st.nominal_sys.baseline, st.nominal_state_used], np.float32)]
+            if i % 2 == 0:
+                r += [eng.getTargetStateSeq().copy(), eng.getNominalStateSeq().copy()]
+            rec.append(r)
+            eng.slideControlSequence(1)
+            x = x + np.float32(0.05 * (i + 1))  # push the actual system away from the nominal one
+        out.append(rec)
+        eng.close()
+    for a, b in zip(*out):
+        assert len(a) == len(b)
+        for p, q in zip(a, b):
+            assert np.array_equal(p, q)
+    used = {int(r[2][2]) for r in out[0]}
+    assert np.isfinite(out[0][-1][0]).all() and len(used) >= 1
+
+
 @pytest.mark.parametrize("model", ["di", "autorally"])
 def test_robust_handovers_agree(gpu, model):
     """Robust MPPI: both control sequences and the statistics come back with the first flag of each system; the nominal
