@@ -131,7 +131,9 @@ struct mppi_handle_s
   bool results_in_io = false;      // the last finalize pass wrote to io_out_h (low-latency path), not to out_block_d
   bool traj_pending = false;       // state_h / output of the last call are still being written by the finalize kernel
   bool low_latency = true;         // MPPI_AMD_NO_SPIN=1 in the environment: copy + hipStreamSynchronize hand-over instead
-  float* step_pin_h = nullptr;     // [S + C] pinned mirror of step_x_d | step_u_d (one block too)
+  float* step_pin_h = nullptr;     // [S + C] host memory mapped into the device: [x | u] of a single model step
+  float* step_pin_dev = nullptr;   // its device address
+  unsigned step_seq = 0;           // hand-over counter of the model-step flag (io_flags[8])
   size_t in_floats = 0, out_floats = 0;
   bool out_pin_fresh = false;      // out_pin_h holds the results (incl. stats) of the last finalize pass; reset by launches
   float* step_x_d = nullptr;       // [S]
@@ -706,10 +708,13 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   ALLOC_OR_FAIL(h->ctrl_in_d, (size_t)D * T * C);
   ALLOC_OR_FAIL(h->step_x_d, (size_t)S + C);  // [x | u] of mppi_model_step
   h->step_u_d = h->step_x_d + S;
-  if (hipHostMalloc((void**)&h->step_pin_h, ((size_t)S + C) * sizeof(float), hipHostMallocDefault) != hipSuccess)
+  // [x | u] of a single model step, mapped into the device: the kernel reads and writes it in place, the host waits on a flag
+  if (hipHostMalloc((void**)&h->step_pin_h, ((size_t)S + C) * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent) !=
+          hipSuccess ||
+      hipHostGetDevicePointer((void**)&h->step_pin_dev, h->step_pin_h, 0) != hipSuccess)
   {
     freeAll(hp);
-    return fail(nullptr, MPPI_ERR_HIP, "hipHostMalloc of the pinned model-step buffer failed");
+    return fail(nullptr, MPPI_ERR_HIP, "hipHostMalloc of the device-mapped model-step buffer failed");
   }
   if (cfg->save_samples)
     ALLOC_OR_FAIL(h->samples_d, (size_t)D * K * T * C);
@@ -2306,6 +2311,32 @@ static void slideSequence(std::vector<float>& u, int T, int C, int steps, const 
   }
 }
 
+/** x <- one model step under u (u <- the clamped control when `enforce`), in host memory mapped into the device: no copy
+ *  command; the host spins on a flag raised behind the kernel (MPPI_AMD_NO_SPIN=1: a stream synchronisation instead) */
+static mppi_status modelStepInPlace(mppi_handle h, float* x, float* u, float dt, int enforce)
+{
+  std::copy(x, x + h->S, h->step_pin_h);
+  std::copy(u, u + h->C, h->step_pin_h + h->S);
+  std::string err;
+  mppi_status st = h->model->launchModelStep(h->step_pin_dev, h->step_pin_dev + h->S, dt, enforce, h->stream, err);
+  if (st != MPPI_OK)
+    return fail(h, st, err);
+  if (h->low_latency)
+  {
+    const unsigned seq = ++h->step_seq;
+    hipLaunchKernelGGL(kernels::raiseFlagKernel, dim3(1), dim3(64), 0, h->stream, h->io_flags_dev + 8, seq);
+    HIP_TRY(h, hipGetLastError());
+    MPPI_TRY(waitHostFlag(h, 8, seq));
+  }
+  else
+  {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  std::copy(h->step_pin_h, h->step_pin_h + h->S, x);
+  std::copy(h->step_pin_h + h->S, h->step_pin_h + h->S + h->C, u);
+  return MPPI_OK;
+}
+
 mppi_status mppi_slide(mppi_handle h, int steps)
 {
   CHECK_HANDLE(h);
@@ -2322,17 +2353,8 @@ mppi_status mppi_slide(mppi_handle h, int steps)
     // tube_mppi_controller.cu:312-323: updateNominalState(nominal_control.col(0)) — one in-place model step, no clamp
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     MPPI_TRY(ensureTrajectories(h));  // the nominal trajectory of the last mppi_compute_control (low-latency hand-over)
-    HIP_TRY(h, hipMemcpyAsync(h->step_x_d, h->nominal_state_h.data(), sizeof(float) * h->S, hipMemcpyHostToDevice,
-                              h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->step_u_d, h->nominal_control_h.data(), sizeof(float) * C, hipMemcpyHostToDevice,
-                              h->stream));
-    std::string err;
-    mppi_status st = h->model->launchModelStep(h->step_x_d, h->step_u_d, h->cfg.dt, 0, h->stream, err);
-    if (st != MPPI_OK)
-      return fail(h, st, err);
-    HIP_TRY(h, hipMemcpyAsync(h->nominal_state_h.data(), h->step_x_d, sizeof(float) * h->S, hipMemcpyDeviceToHost,
-                              h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<float> u0(h->nominal_control_h.begin(), h->nominal_control_h.begin() + C);
+    MPPI_TRY(modelStepInPlace(h, h->nominal_state_h.data(), u0.data(), h->cfg.dt, 0));
     saveControlHistory(steps, h->nominal_control_h, h->history_h, C);
     slideSequence(h->nominal_control_h, T, C, steps, zero.data(), h->slide_scale_h.data());
     slideSequence(h->control_h, T, C, steps, zero.data(), h->slide_scale_h.data());
@@ -2976,19 +2998,7 @@ mppi_status mppi_model_step(mppi_handle h, float* x, float* u, float dt, int enf
   if (!x || !u)
     return fail(h, MPPI_ERR_INVALID_ARG, "null");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-  // [x | u] through pinned memory: one copy up, one copy back, one synchronisation
-  std::copy(x, x + h->S, h->step_pin_h);
-  std::copy(u, u + h->C, h->step_pin_h + h->S);
-  const size_t bytes = sizeof(float) * (size_t)(h->S + h->C);
-  HIP_TRY(h, hipMemcpyAsync(h->step_x_d, h->step_pin_h, bytes, hipMemcpyHostToDevice, h->stream));
-  std::string err;
-  mppi_status st = h->model->launchModelStep(h->step_x_d, h->step_u_d, dt, enforce, h->stream, err);
-  if (st != MPPI_OK)
-    return fail(h, st, err);
-  HIP_TRY(h, hipMemcpyAsync(h->step_pin_h, h->step_x_d, bytes, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  std::copy(h->step_pin_h, h->step_pin_h + h->S, x);
-  std::copy(h->step_pin_h + h->S, h->step_pin_h + h->S + h->C, u);
+  MPPI_TRY(modelStepInPlace(h, x, u, dt, enforce));
   return MPPI_OK;
 }
 

@@ -318,6 +318,17 @@ __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineAr
   }
 }
 
+/** every store of the kernels in front of it on the stream is out: publish `seq` where the host spins (device-mapped host
+ *  memory, system scope) — the hand-over of a small kernel whose signature has no flag argument (model step) */
+__global__ void __launch_bounds__(64) raiseFlagKernel(unsigned* flag, unsigned seq)
+{
+  if (threadIdx.x == 0)
+  {
+    __threadfence_system();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 /**
  * First kernel of a low-latency mppi_compute_control: the inputs of the call (x0 | nominal control | control history, the
  * handle's input block) are read straight from host memory mapped into the device and written to the device-resident
