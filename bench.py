@@ -344,9 +344,28 @@ def di_tube_leg(device):
     t0 = time.perf_counter()
     eng.optimize(n, True)
     wall = time.perf_counter() - t0
+    # what a control loop sees: computeControl (optimisation pass, nominal / actual choice, smoothing pass) and the loop period
+    x = cfg["x0"].copy()
+    for _ in range(30):
+        eng.computeControl(x, 1)
+    m_ = 200
+    ready = 0.0
+    for _ in range(m_):
+        eng.getTargetStateSeq()  # the previous call's trajectories have landed: the stream is idle
+        t_a = time.perf_counter()
+        eng.computeControl(x, 1)
+        ready += time.perf_counter() - t_a
+    t_a = time.perf_counter()
+    for _ in range(m_):
+        eng.computeControl(x, 1)
+        eng.getControlSeq()
+        eng.slideControlSequence(1)
+    loop = (time.perf_counter() - t_a) / m_
+    eng.close()
     return {"workload": "DoubleIntegrator + DoubleIntegratorCircleCost, Tube-MPPI iteration (actual + nominal system in one "
                         "launch), K=8192, T=150", "value": round(n / wall, 3), "unit": "MPPI iters/s",
-            "ms_per_step": round(wall / n * 1e3, 6)}
+            "ms_per_step": round(wall / n * 1e3, 6), "compute_control_ready_us": round(ready / m_ * 1e6, 2),
+            "closed_loop_period_us": round(loop * 1e6, 2)}
 
 
 def racer_elevation_leg(device):
