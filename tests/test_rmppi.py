@@ -233,7 +233,7 @@ def _rollout_costs_bit_exact(model, acc_all, mode, K=1000, T=37, **kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["di", "cartpole"])
+@pytest.mark.parametrize("model", ["di", "cartpole", "autorally"])  # autorally: the role-pipelined kernel
 def test_rmppi_time_specific_std_dev(gpu, model):
     """time_specific_std_dev on a Robust handle: setGaussianControls, the likelihood-ratio cost AND the feedback cost read
     sigma[d][t][c] (gaussian.cu:21-43, :488-493, :579-583) — the feedback cost once kept the scalar sigma (round-2 advice)"""
@@ -250,7 +250,9 @@ def test_rmppi_time_specific_std_dev(gpu, model):
     eng.updateImportanceSampler(mean)
     eps = host_noise(1, K, T, C)[0]
     eng.injectNoise(eps)
-    x0 = np.stack([cfg["x0"], cfg["x0"] + np.array([0.3, -0.2, 0.1, 0.05], np.float32)[:S]])
+    dx = np.zeros(S, np.float32)
+    dx[:4] = [0.3, -0.2, 0.1, 0.05]
+    x0 = np.stack([cfg["x0"], cfg["x0"] + dx])
     got = eng.rolloutCosts(x0, 1)
     means = np.tile(mean, (2, 1, 1))
     v = orc.set_gaussian_controls(means, eps, 1, 0)
