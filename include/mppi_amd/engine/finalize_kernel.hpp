@@ -50,7 +50,17 @@ struct FinalizeArgs
   const float* stats_in_d;    ///< [stats_floats] merge statistics (combineKernel), or nullptr
   float* stats_out_d;
   int stats_floats;
+  /** horizons whose control sequence does not fit the LDS twice (T * C beyond ~19 000): [D][(2 T + 4) * C] floats of HBM for
+   *  the smoothing buffer and the smoothed sequence; nullptr: both in LDS.  (One lane per rollout and replicated-lane
+   *  kernels; the LDS + barrier variant keeps its trajectories in LDS as well and stays limited.) */
+  float* scratch_d;
 };
+
+/** floats of FinalizeArgs::scratch_d per system */
+__host__ __device__ inline size_t finalizeScratchFloats(int num_timesteps, int control_dim)
+{
+  return (size_t)math::nearest_multiple_4((num_timesteps + 4) * control_dim) + math::nearest_multiple_4(num_timesteps * control_dim);
+}
 
 /** all stores of the block are out (barrier), then one lane publishes `seq` at system scope: the host sees the data it guards */
 __device__ inline void raiseHostFlag(unsigned* flags_d, const int idx, const unsigned seq, const bool one_lane)
@@ -107,12 +117,13 @@ __device__ inline void finalizeEmitControl(DYN_T* dynamics, const FinalizeArgs& 
  *  a block barrier waits for the wave's outstanding global stores, so storing every step put a memory round trip on
  *  each of the ~5 barriers of a step */
 template <class DYN_T>
-__host__ inline size_t finalizeSharedBytes(const DYN_T& dyn, int num_timesteps, int by = 1)
+__host__ inline size_t finalizeSharedBytes(const DYN_T& dyn, int num_timesteps, int by = 1, bool scratch = false)
 {
   constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
   size_t n = calcClassSharedMemSize(&dyn, 1);
-  n += sizeof(float) * (math::nearest_multiple_4((num_timesteps + 4) * C) + math::nearest_multiple_4(num_timesteps * C) +
-                        4 * math::nearest_multiple_4(S) + math::nearest_multiple_4(C) + math::nearest_multiple_4(O));
+  if (!scratch)
+    n += sizeof(float) * finalizeScratchFloats(num_timesteps, C);
+  n += sizeof(float) * (4 * math::nearest_multiple_4(S) + math::nearest_multiple_4(C) + math::nearest_multiple_4(O));
   if (by > 1)
     n += sizeof(float) * (math::nearest_multiple_4(num_timesteps * S) + math::nearest_multiple_4(num_timesteps * O));
   return n;
@@ -147,9 +158,14 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* theta_s = reinterpret_cast<float*>(smem_raw);
-  float* buf = theta_s + calcClassSharedMemSize(dynamics, 1) / (int)sizeof(float);  // [(T+4)][C]
-  float* ctrl = buf + math::nearest_multiple_4((T + 4) * C);                         // [T][C]
-  float* x = ctrl + math::nearest_multiple_4(T * C);
+  float* lds_next = theta_s + calcClassSharedMemSize(dynamics, 1) / (int)sizeof(float);
+  float* buf = lds_next;  // [(T+4)][C]
+  if (a.scratch_d)
+    buf = a.scratch_d + (size_t)z * finalizeScratchFloats(T, C);  // long horizons: smoothing buffer and sequence in HBM
+  else
+    lds_next += finalizeScratchFloats(T, C);
+  float* ctrl = buf + math::nearest_multiple_4((T + 4) * C);  // [T][C]
+  float* x = lds_next;
   float* xn = x + math::nearest_multiple_4(S);
   float* xdot = xn + math::nearest_multiple_4(S);
   float* zero_state = xdot + math::nearest_multiple_4(S);
@@ -224,11 +240,18 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
       for (int i = 0; i < O; i++)
         a.output_out_d[((size_t)z * T + 0) * O + i] = yr[i];
     }
+    float un[C];  // the next step's control is fetched a step ahead (it may live in HBM: FinalizeArgs::scratch_d)
+#pragma unroll
+    for (int i = 0; i < C; i++)
+      un[i] = ctrl[i];
     for (int t = 0; t < T - 1; t++)
     {
 #pragma unroll
       for (int i = 0; i < C; i++)
-        ur[i] = ctrl[t * C + i];
+      {
+        ur[i] = un[i];
+        un[i] = ctrl[(t + 1) * C + i];
+      }
       dynamics->enforceConstraints(xr, ur);
       dynamics->step(xr, xnr, xdr, ur, yr, theta_s, t, a.dt);
 #pragma unroll
@@ -301,12 +324,11 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
  * rollouts use, so the trajectory is bit-identical to what they integrated.  Launch: grid = D, block = (64, 1, 1).
  */
 template <class DYN_T>
-__host__ inline size_t finalizeRepSharedBytes(const DYN_T& dyn, int num_timesteps)
+__host__ inline size_t finalizeRepSharedBytes(const DYN_T& dyn, int num_timesteps, bool scratch = false)
 {
   constexpr int C = DYN_T::CONTROL_DIM;
   constexpr int ROLLOUTS = 64 / replicated_lanes<DYN_T>::value;
-  return calcClassSharedMemSize(&dyn, ROLLOUTS) +
-         sizeof(float) * (math::nearest_multiple_4((num_timesteps + 4) * C) + math::nearest_multiple_4(num_timesteps * C));
+  return calcClassSharedMemSize(&dyn, ROLLOUTS) + (scratch ? 0 : sizeof(float) * finalizeScratchFloats(num_timesteps, C));
 }
 
 template <class DYN_T>
@@ -329,6 +351,8 @@ __global__ void __launch_bounds__(64) finalizeRepKernel(DYN_T dynamics_obj, cons
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* theta_s = reinterpret_cast<float*>(smem_raw);
   float* buf = theta_s + calcClassSharedMemSize(dynamics, ROLLOUTS) / (int)sizeof(float);  // [(T+4)][C]
+  if (a.scratch_d)
+    buf = a.scratch_d + (size_t)z * finalizeScratchFloats(T, C);  // long horizons: smoothing buffer and sequence in HBM
   float* ctrl = buf + math::nearest_multiple_4((T + 4) * C);                                // [T][C]
   const float* uin = a.control_in_d + (size_t)z * T * C;
 
@@ -400,11 +424,18 @@ __global__ void __launch_bounds__(64) finalizeRepKernel(DYN_T dynamics_obj, cons
     for (int i = 0; i < O; i++)
       a.output_out_d[((size_t)z * T + 0) * O + i] = y[i];
   }
+  float un[C];  // the next step's control, fetched a step ahead (it may live in HBM: FinalizeArgs::scratch_d)
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    un[i] = ctrl[i];
   for (int t = 0; t < T - 1; t++)
   {
 #pragma unroll
     for (int i = 0; i < C; i++)
-      u[i] = ctrl[t * C + i];
+    {
+      u[i] = un[i];
+      un[i] = ctrl[(t + 1) * C + i];
+    }
     dynamics->enforceConstraints(x, u);
     dynamics->step(x, xn, xdot, u, y, theta_s, t, a.dt);
     if (writer)

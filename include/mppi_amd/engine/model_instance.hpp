@@ -1510,7 +1510,7 @@ struct ModelT : ModelBase
       {
         using WAVE_T = typename DYN_FAST_T::FINALIZE_FORM;
         WAVE_T wave_form(dyn);
-        const size_t smem_w = kernels::finalizeRepSharedBytes(wave_form, a.num_timesteps);
+        const size_t smem_w = kernels::finalizeRepSharedBytes(wave_form, a.num_timesteps, a.scratch_d != nullptr);
         if (smem_w <= MAX_LDS_BYTES)
         {
           auto kw = kernels::finalizeRepKernel<WAVE_T>;
@@ -1530,7 +1530,7 @@ struct ModelT : ModelBase
     if constexpr (!std::is_void<DYN_FAST_T>::value)
     {  // replicated-lane (MFMA) dynamics: the register-resident single-wave variant
       DYN_FAST_T fast(dyn);
-      const size_t smem_rep = kernels::finalizeRepSharedBytes(fast, a.num_timesteps);
+      const size_t smem_rep = kernels::finalizeRepSharedBytes(fast, a.num_timesteps, a.scratch_d != nullptr);
       bool usable = smem_rep <= MAX_LDS_BYTES;
       if constexpr (has_register_form<DYN_T>::value)
         usable = usable && dyn.register_form_;
@@ -1550,7 +1550,7 @@ struct ModelT : ModelBase
         return MPPI_OK;
       }
     }
-    const size_t smem = kernels::finalizeSharedBytes(dyn, a.num_timesteps, FIN_BY);
+    const size_t smem = kernels::finalizeSharedBytes(dyn, a.num_timesteps, FIN_BY, a.scratch_d != nullptr);
     if (smem > MAX_LDS_BYTES)
     {
       err = "finalize kernel LDS overflow";

@@ -97,6 +97,7 @@ struct mppi_handle_s
   float* eps_d = nullptr;          // [n_eps_iters][K_local][T][C]
   float* samples_d = nullptr;      // [D][K_local][T][C]
   float* rows_d = nullptr;         // [num_blocks][bx * bz][rowStride]: the sampler's rows when they do not fit the LDS
+  float* fin_scratch_d = nullptr;  // [D][(2 T + 4) C]: smoothing buffer + sequence of the finalize kernels at long horizons
   bool rm_pipeline = false;        // Robust MPPI: ask the model for its role-pipelined rollout kernel (rows in HBM, bx = 64)
   bool rows_in_hbm = false;
   /* ColoredMPPI options (controllers/ColoredMPPI/colored_mppi_controller.cuh:18-22, 159-193): Tsallis weights and state leash */
@@ -387,7 +388,7 @@ static void freeAll(mppi_handle h)
   h->in_pin_h = h->out_pin_h = h->step_pin_h = nullptr;
   h->step_u_d = nullptr;  // slice of the step_x_d block
   float** bufs[] = { &h->in_block_d, &h->out_block_d, &h->costs_d,   &h->partials_d,  &h->send_d,     &h->recv_d,
-                     &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->gather_tmp_d, &h->rows_d,
+                     &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->gather_tmp_d, &h->rows_d, &h->fin_scratch_d,
                      &h->tsallis_weights_d, &h->rocrand_eps_d, &h->std_dev_time_d };
   for (float** b : bufs)
   {
@@ -722,6 +723,14 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   {
     ALLOC_OR_FAIL(h->rows_d, h->model->globalRowsFloats(h->num_blocks, h->bx * h->bz, T));
     h->model->setGlobalRows(h->rows_d);
+  }
+  {
+    // the finalize kernels keep the control sequence twice in LDS (smoothing buffer + result) while that is a minor share of
+    // it; beyond 64 KiB per system (T * C > ~8 000) — or on request (test hook) — both live in HBM
+    const char* force = getenv("MPPI_AMD_FINALIZE_SCRATCH");
+    const size_t per_sys = kernels::finalizeScratchFloats(T, C);
+    if (per_sys * sizeof(float) > 64 * 1024 || (force && force[0] == '1'))
+      ALLOC_OR_FAIL(h->fin_scratch_d, (size_t)D * per_sys);
   }
 #undef ALLOC_OR_FAIL
   {
@@ -1533,6 +1542,7 @@ static mppi_status finalize(mppi_handle h, const float* ctrl_in_d, int smooth_ma
   RoctxRange range("mppi:finalize");
   const int T = h->cfg.num_timesteps;
   kernels::FinalizeArgs a{};
+  a.scratch_d = h->fin_scratch_d;
   // the control history goes up through its slice of the pinned input block (one small asynchronous copy)
   float* hist_pin = h->in_pin_h + (h->history_d - h->in_block_d);
   if (h->cfg.controller == MPPI_CONTROLLER_ROBUST)
@@ -1729,6 +1739,7 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     x0 = leashed.data();
   }
   kernels::FinalizeArgs a{};
+  a.scratch_d = h->fin_scratch_d;
   a.control_in_d = h->mean_d;
   a.history_d = h->history_d;
   a.history_stride = 0;
@@ -1840,6 +1851,7 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
     };
     auto finalize_flagged = [&](const int smooth_mask) -> mppi_status {
       kernels::FinalizeArgs a{};
+  a.scratch_d = h->fin_scratch_d;
       a.control_in_d = h->mean_d;
       a.history_d = h->history_d;
       a.history_stride = 0;
@@ -2142,6 +2154,7 @@ static mppi_status computeControlRobust(mppi_handle h, const float* x0_real, int
     }
     const int T = h->cfg.num_timesteps;
     kernels::FinalizeArgs a{};
+  a.scratch_d = h->fin_scratch_d;
     a.control_in_d = h->mean_d;
     a.history_d = h->history_d;
     a.history_stride = 2 * h->C;

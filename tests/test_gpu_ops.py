@@ -76,12 +76,23 @@ def test_error_codes(gpu):
         m.VanillaMPPIController("cartpole", 128, 10, 0.02, 1.0, block_x=48, block_y=3)
     assert e.value.status == 5
     # LDS overflow (reference: runtime_error, mppi_controller.cu:64-76).  Every rollout kernel moves its sample rows to HBM
-    # when they do not fit (T = 2000 on the pipeline variant runs); what is left is the post-processing kernel, which keeps
-    # the control sequence in LDS: T * C beyond ~19 000
+    # when they do not fit (T = 2000 on the pipeline variant runs) and the post-processing kernels their control sequence
+    # (tests/test_long_horizon.py: T = 25 000); what is left is the LDS + barrier variant of the post-processing kernel, which
+    # collects its trajectories in LDS — a RACER model with a network of another shape than its four-lane form at T = 4000
     m.VanillaMPPIController("cartpole", 128, 2000, 0.02, 1.0, block_x=64, block_y=1, kernel_variant=2).close()
-    big = m.VanillaMPPIController("cartpole", 128, 25000, 0.02, 1.0)
+    from test_racer_dubins_lstm_steering import steering_cfg
+    from common import make_engine
+    rng = np.random.default_rng(2)
+    cfg = steering_cfg(K=128, T=4000)
+    Hn = 6
+    blobs = {"lstm_structure": np.array([Hn, Hn + 4, 12, 1], np.float32),
+             "lstm_weights": rng.uniform(-0.4, 0.4, 4 * Hn * Hn + 4 * Hn * 4 + 6 * Hn).astype(np.float32),
+             "lstm_output_weights": rng.uniform(-0.4, 0.4, (Hn + 4) * 12 + 12 + 12 + 1).astype(np.float32)}
+    maps = {k: v for k, v in cfg["blobs"].items() if k.startswith("elevation")}
+    cfg["blobs"] = {**blobs, **maps}  # the structure first, then the weights
+    big = make_engine(cfg)
     with pytest.raises(m.MPPIError) as e:
-        big.computeControl(np.zeros(4, np.float32), 1)
+        big.computeControl(cfg["x0"], 1)
     assert e.value.status == 6
     big.close()
     with pytest.raises(m.MPPIError) as e:

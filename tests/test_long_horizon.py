@@ -172,3 +172,46 @@ def test_rmppi_T1000_vs_oracle(gpu):
     assert ulp_diff(got, want).max() == 0
     assert ulp_diff(eng.getSampledControls(), v_fb).max() == 0
     eng.close()
+
+
+def _engine_with_finalize_scratch(cfg, **kw):
+    os.environ["MPPI_AMD_FINALIZE_SCRATCH"] = "1"
+    try:
+        return make_engine(cfg, **kw)
+    finally:
+        del os.environ["MPPI_AMD_FINALIZE_SCRATCH"]
+
+
+@pytest.mark.parametrize("mk", [lambda: cartpole_cfg(K=512, T=60, soft=True), lambda: di_cfg(K=512, T=33, tube=True),
+                                lambda: autorally_cfg(K=256, T=37)], ids=["cartpole", "di-tube", "autorally-wave-form"])
+def test_postprocessing_with_the_sequence_in_hbm_is_bit_identical(gpu, mk):
+    """smoothing buffer and control sequence of the post-processing kernels in HBM (long horizons) instead of LDS: controls and
+    trajectories are the same bits (one lane per rollout, two systems, the NN model's one-rollout-per-wave form)"""
+    cfg = mk()
+    got = []
+    for make in (make_engine, _engine_with_finalize_scratch):
+        eng = make(cfg)
+        x = cfg["x0"].copy()
+        eng.computeControl(x, 1)
+        eng.slideControlSequence(1)
+        eng.computeControl(x, 1)
+        got.append((eng.getControlSeq().copy(), eng.getTargetStateSeq().copy(), eng.getTargetOutputSeq().copy()))
+        eng.close()
+    for a, b in zip(*got):
+        assert np.array_equal(a, b)
+
+
+def test_cartpole_T25000_postprocessing_vs_oracle(gpu):
+    """T * C = 25 000: neither the sample rows nor the control sequence fit the LDS — rows and post-processing buffers in HBM;
+    control sequence and state trajectory against the oracle"""
+    cfg = cartpole_cfg(K=128, T=25000, soft=True)
+    eng, orc = make_engine(cfg), make_oracle(cfg)
+    eps = host_noise(1, cfg["K"], cfg["T"], 1)
+    eng.injectNoise(eps)
+    eng.computeControl(cfg["x0"], 1)
+    orc.vanilla_compute_control(cfg["x0"], 1, eps)
+    assert ulp_diff(eng.getSampledCostSeq(), orc.costs()).max() == 0
+    assert np.abs(eng.getControlSeq() - orc.control()).max() <= 1e-5
+    # (a 25 000-step open-loop trajectory of the cart-pole amplifies the 1e-5 of the controls: compare its first thousand steps)
+    assert np.abs(eng.getTargetStateSeq()[:1000] - orc.state_traj()[:1000]).max() <= 1e-3
+    eng.close()
