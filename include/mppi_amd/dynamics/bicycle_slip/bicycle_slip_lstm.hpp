@@ -20,6 +20,7 @@
 #include "mppi_amd/plugin/dynamics.hpp"
 #include "mppi_amd/utils/nn_helpers/lstm_helper.hpp"
 #include "mppi_amd/utils/nn_helpers/lstm_mfma.hpp"
+#include "mppi_amd/utils/nn_helpers/lstm_wave.hpp"
 
 struct BicycleSlipLSTMParams : public DynamicsParams
 {
@@ -124,12 +125,16 @@ public:
  * BX rollouts x 4 replicated lanes (REPLICATED_LANES, csrc/rollout_kernel.hpp); kinematics, Euler step and constraints
  * are evaluated redundantly by the four lanes on private register copies; the LSTM state lives in registers.
  */
+class BicycleSlipLSTMWave;
+
 class BicycleSlipLSTMMFMA : public MPPI_internal::Dynamics<BicycleSlipLSTMMFMA, BicycleSlipLSTMParams>
 {
 public:
   using PARENT_CLASS = MPPI_internal::Dynamics<BicycleSlipLSTMMFMA, BicycleSlipLSTMParams>;
   static const int DYNAMICS_DIM = 4;
   static constexpr int REPLICATED_LANES = 4;
+  /** the form the single-trajectory re-rollout runs on (engine: finalizeRepKernel): one rollout per wave */
+  using FINALIZE_FORM = BicycleSlipLSTMWave;
   using NET = mppi::LSTMMfma<bicycle_slip_lstm::LSTM_INPUT, bicycle_slip_lstm::LSTM_HIDDEN,
                              bicycle_slip_lstm::MLP_HIDDEN, bicycle_slip_lstm::NET_OUTPUT>;
 
@@ -188,6 +193,74 @@ public:
   const float* lstm_d_ = nullptr;
   const float* fnn_d_ = nullptr;
   NET net_;  ///< weight fragments + recurrent state: per-thread registers (the object is a by-value kernel argument)
+};
+
+/**
+ * The same model for ONE rollout on a whole wave (utils/nn_helpers/lstm_wave.hpp: lane = gate row of the LSTM / neuron of the
+ * output network, activations by v_readlane); REPLICATED_LANES = 64, same fma chains and activations as the other forms — the
+ * trajectories are the same bits.  Used for the re-rollout of the optimised control sequence (T dependent steps).
+ */
+class BicycleSlipLSTMWave : public MPPI_internal::Dynamics<BicycleSlipLSTMWave, BicycleSlipLSTMParams>
+{
+public:
+  using PARENT_CLASS = MPPI_internal::Dynamics<BicycleSlipLSTMWave, BicycleSlipLSTMParams>;
+  static const int DYNAMICS_DIM = 4;
+  static constexpr int REPLICATED_LANES = 64;
+  using NET = mppi::LSTMWave<bicycle_slip_lstm::LSTM_INPUT, bicycle_slip_lstm::LSTM_HIDDEN,
+                             bicycle_slip_lstm::MLP_HIDDEN, bicycle_slip_lstm::NET_OUTPUT>;
+
+  BicycleSlipLSTMWave(const BicycleSlipLSTM& other) : PARENT_CLASS(other.stream_)
+  {
+    this->params_ = other.params_;
+    for (int i = 0; i < CONTROL_DIM; i++)
+    {
+      this->control_rngs_[i] = other.control_rngs_[i];
+      this->control_deadband_[i] = other.control_deadband_[i];
+      this->zero_control_[i] = other.zero_control_[i];
+    }
+    lstm_d_ = other.lstm_.weights_d_;
+    fnn_d_ = other.lstm_.output_nn_.theta_d_;
+  }
+  __host__ __device__ int getGrdSharedSizeBytes() const
+  {
+    return 0;
+  }
+  __host__ __device__ int getBlkSharedSizeBytes() const
+  {
+    return 0;
+  }
+  __device__ inline void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
+                                            float dt)
+  {
+    PARENT_CLASS::initializeDynamics(state, control, output, theta_s, t_0, dt);
+    net_.load(lstm_d_, fnn_d_, (int)(threadIdx.x & 63));
+  }
+  __device__ inline void computeKinematics(float* state, float* state_der)
+  {
+    float s, c;
+    mppi::det::sincos(state[2], &s, &c);
+    state_der[0] = c * state[4] - s * state[5];
+    state_der[1] = s * state[4] + c * state[5];
+    state_der[2] = -state[6];
+  }
+  __device__ inline void computeDynamics(float* state, float* control, float* state_der, float* theta_s = nullptr)
+  {
+    float in[bicycle_slip_lstm::LSTM_INPUT], out[bicycle_slip_lstm::NET_OUTPUT];
+#pragma unroll
+    for (int i = 0; i < DYNAMICS_DIM; i++)
+      in[i] = state[i + (STATE_DIM - DYNAMICS_DIM)];
+#pragma unroll
+    for (int i = 0; i < CONTROL_DIM; i++)
+      in[DYNAMICS_DIM + i] = control[i];
+    net_.forward(in, out, (int)(threadIdx.x & 63));
+#pragma unroll
+    for (int i = 0; i < DYNAMICS_DIM; i++)
+      state_der[i + (STATE_DIM - DYNAMICS_DIM)] = out[i];
+  }
+
+  const float* lstm_d_ = nullptr;
+  const float* fnn_d_ = nullptr;
+  NET net_;
 };
 
 #endif

@@ -129,3 +129,29 @@ def test_bicycle_lstm_requires_blobs(gpu):
     with pytest.raises(m.MPPIError) as e:
         c.setModelBlob("lstm_weights", np.zeros(10, np.float32))
     assert e.value.status == 1
+
+
+@pytest.mark.gpu
+def test_trajectory_rerollout_wave_form_equals_mfma_form(gpu):
+    """the re-rollout of u* runs on the one-rollout-per-wave form of the LSTM model (lane = gate row / neuron, lstm_wave.hpp);
+    the replicated-lane MFMA form gives the same bits, and both agree with the oracle's state trajectory"""
+    import os
+    cfg = bicycle_lstm_cfg(K=512, T=120)
+    eps = host_noise(1, cfg["K"], cfg["T"], 2)
+    got = []
+    for form in (None, "rep"):
+        if form:
+            os.environ["MPPI_AMD_FINALIZE_FORM"] = form
+        try:
+            eng = make_engine(cfg)
+            eng.injectNoise(eps)
+            eng.computeControl(cfg["x0"], 1)
+            got.append((eng.getControlSeq().copy(), eng.getTargetStateSeq().copy(), eng.getTargetOutputSeq().copy()))
+            eng.close()
+        finally:
+            os.environ.pop("MPPI_AMD_FINALIZE_FORM", None)
+    for a, b in zip(*got):
+        assert np.array_equal(a, b)
+    orc = make_oracle(cfg)
+    orc.vanilla_compute_control(cfg["x0"], 1, eps)
+    assert np.abs(got[0][1] - orc.state_traj()).max() <= 1e-4
