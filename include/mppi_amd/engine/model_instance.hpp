@@ -1513,7 +1513,7 @@ struct ModelT : ModelBase
         const size_t smem_w = kernels::finalizeRepSharedBytes(wave_form, a.num_timesteps, a.scratch_d != nullptr);
         if (smem_w <= MAX_LDS_BYTES)
         {
-          auto kw = kernels::finalizeRepKernel<WAVE_T>;
+          auto kw = a.scratch_d ? kernels::finalizeRepKernel<WAVE_T, true> : kernels::finalizeRepKernel<WAVE_T, false>;
           if (smem_w > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w);
           hipLaunchKernelGGL(kw, dim3(D), dim3(64, 1, 1), smem_w, stream, wave_form, a);
@@ -1536,7 +1536,7 @@ struct ModelT : ModelBase
         usable = usable && dyn.register_form_;
       if (usable)
       {
-        auto krep = kernels::finalizeRepKernel<DYN_FAST_T>;
+        auto krep = a.scratch_d ? kernels::finalizeRepKernel<DYN_FAST_T, true> : kernels::finalizeRepKernel<DYN_FAST_T, false>;
         if (smem_rep > 48 * 1024)
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(krep), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)smem_rep);
@@ -1556,7 +1556,7 @@ struct ModelT : ModelBase
       err = "finalize kernel LDS overflow";
       return MPPI_ERR_LDS_OVERFLOW;
     }
-    auto kfn = kernels::finalizeKernel<DYN_T, FIN_BY>;
+    auto kfn = a.scratch_d ? kernels::finalizeKernel<DYN_T, FIN_BY, true> : kernels::finalizeKernel<DYN_T, FIN_BY, false>;
     if (smem > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem);
