@@ -103,9 +103,9 @@ __host__ inline RMPPIPipeRings rmppiPipelineRings(const DYN_T& dyn, const COST_T
  * base[field * 64] (fields past the end: field j * REP again, same value).  Every lane of the wave stays active and the
  * stores of a replica group go to distinct addresses.  The dynamics waves of this kernel contain NO region that only the
  * lanes of one replica execute (`if (rep_lane == 0) store`): the kernel runs at the register limit of a 1024-thread block and
- * spills, and with the suspension / complete RACER models a register reloaded inside such a region — valid in the lanes
- * active there only — was used again by all lanes after it: the covariance rows the replicas 1..3 computed in the next step
- * came out a few ulp off in every rollout (round 3, found with tests/test_rmppi.py).
+ * spills, and builds WITH such regions gave the suspension / complete RACER models covariance outputs a few ulp off in every
+ * rollout from the second step on (deterministic per build; builds without them are exact).  The instruction at fault was
+ * not identified — see DESIGN.md §5 for what was tried — so the pattern is avoided here.
  */
 template <int REP, int N>
 __device__ inline void stripedStore(float* base, const float (&vals)[N], const int rep_lane)
