@@ -459,26 +459,52 @@ struct ModelT : ModelBase
     }
     return 0;
   }
-  /** the role-pipelined Robust MPPI kernel exists for models with a replicated-lane form and a sampler whose rows may live
-   *  in HBM and need no block-wide prologue of their own (the Gaussian sampler) */
+  /** the role-pipelined Robust MPPI kernels (rmppi_pipeline_kernel.hpp) exist for models with a replicated-lane form, and for
+   *  models registered for the role-pipelined rollout (PIPELINE: one lane per rollout, no block barrier inside the per-step
+   *  methods) — with a sampler whose rows may live in HBM and need no block-wide prologue of their own (the Gaussian one) */
   static constexpr bool rmppiHasPipeline()
   {
-    if constexpr (RMPPI && !std::is_void<DYN_FAST_T>::value)
-      return kernels::replicated_lanes<DYN_FAST_T>::value > 1 && SAMPLING_T::SUPPORTS_GLOBAL_ROWS && !SAMPLING_T::COLORED;
-    else
+    if constexpr (!RMPPI || !SAMPLING_T::SUPPORTS_GLOBAL_ROWS || SAMPLING_T::COLORED)
       return false;
+    else if constexpr (!std::is_void<DYN_FAST_T>::value)
+      return kernels::replicated_lanes<DYN_FAST_T>::value > 1;
+    else
+      return PIPELINE;
+  }
+  /** can the pipelined kernels run with the networks loaded right now (replicated-lane forms exist for one shape only) */
+  bool rmppiPipelineUsable() const
+  {
+    if constexpr (!rmppiHasPipeline())
+      return false;
+    else if constexpr (std::is_void<DYN_FAST_T>::value)
+      return true;
+    else
+      return rmppiUseFast();
+  }
+  /** f(pipe_dyn): the dynamics object the pipelined kernels take — the replicated-lane form, or the model itself */
+  template <class F>
+  auto withRmppiPipelineDynamics(F&& f)
+  {
+    if constexpr (std::is_void<DYN_FAST_T>::value)
+      return f(dyn);
+    else
+    {
+      DYN_FAST_T fast(dyn);
+      return f(fast);
+    }
   }
   size_t rmppiPipelineSharedBytes(int T) override
   {
     if constexpr (rmppiHasPipeline())
     {
-      if (!rmppiUseFast())
+      if (!rmppiPipelineUsable())
         return 0;
       smp.params_.num_timesteps = T;
       smp.params_.num_distributions = 2;
-      DYN_FAST_T fast(dyn);
-      const kernels::RMPPIPipeRings r = kernels::rmppiPipelineRings(fast, cost, fb, smp, MAX_LDS_BYTES);
-      return r.out_steps ? kernels::rmppiPipelineSharedBytes(fast, cost, fb, smp, r) : 0;
+      return withRmppiPipelineDynamics([&](auto& pd) -> size_t {
+        const kernels::RMPPIPipeRings r = kernels::rmppiPipelineRings(pd, cost, fb, smp, MAX_LDS_BYTES);
+        return r.out_steps ? kernels::rmppiPipelineSharedBytes(pd, cost, fb, smp, r) : 0;
+      });
     }
     return 0;
   }
@@ -486,28 +512,30 @@ struct ModelT : ModelBase
   {
     if constexpr (rmppiHasPipeline())
     {
-      DYN_FAST_T fast(dyn);
-      const kernels::RMPPIPipeRings r = kernels::rmppiPipelineRings(fast, cost, fb, smp, MAX_LDS_BYTES);
-      if (r.out_steps == 0)
-      {
-        err = "pipelined RMPPI rollout kernel: the rings do not fit 160 KiB of LDS next to the sample rows";
-        return MPPI_ERR_LDS_OVERFLOW;
-      }
-      const size_t smem = kernels::rmppiPipelineSharedBytes(fast, cost, fb, smp, r);
-      const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
-      auto kfn = in_loop ? kernels::rolloutRMPPIPipelineKernel<DYN_FAST_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, SAMPLING_T::IN_LOOP_DRAW>
-                         : kernels::rolloutRMPPIPipelineKernel<DYN_FAST_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, false>;
-      if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL(kfn, dim3((a.base.num_rollouts + 63) / 64), dim3(64 * kernels::rmppiPipelineWaves<DYN_FAST_T>(), 1, 1),
-                         smem, stream, fast, cost, fb, smp, a, r);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess)
-      {
-        err = std::string("rolloutRMPPIPipelineKernel launch: ") + hipGetErrorString(e);
-        return MPPI_ERR_HIP;
-      }
-      return MPPI_OK;
+      return withRmppiPipelineDynamics([&](auto& pd) -> mppi_status {
+        using PD_T = std::decay_t<decltype(pd)>;
+        const kernels::RMPPIPipeRings r = kernels::rmppiPipelineRings(pd, cost, fb, smp, MAX_LDS_BYTES);
+        if (r.out_steps == 0)
+        {
+          err = "pipelined RMPPI rollout kernel: the rings do not fit 160 KiB of LDS next to the sample rows";
+          return MPPI_ERR_LDS_OVERFLOW;
+        }
+        const size_t smem = kernels::rmppiPipelineSharedBytes(pd, cost, fb, smp, r);
+        const bool in_loop = SAMPLING_T::IN_LOOP_DRAW && smp.noise_source_ == 0;
+        auto kfn = in_loop ? kernels::rolloutRMPPIPipelineKernel<PD_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, SAMPLING_T::IN_LOOP_DRAW>
+                           : kernels::rolloutRMPPIPipelineKernel<PD_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, false>;
+        if (smem > 48 * 1024)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kfn, dim3((a.base.num_rollouts + 63) / 64), dim3(64 * kernels::rmppiPipelineWaves<PD_T>(), 1, 1), smem,
+                           stream, pd, cost, fb, smp, a, r);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+        {
+          err = std::string("rolloutRMPPIPipelineKernel launch: ") + hipGetErrorString(e);
+          return MPPI_ERR_HIP;
+        }
+        return MPPI_OK;
+      });
     }
     err = "model has no role-pipelined Robust MPPI kernel";
     return MPPI_ERR_LAUNCH_SHAPE;
@@ -525,20 +553,23 @@ struct ModelT : ModelBase
       {
         // the candidate rollouts as blocks of role waves (rmppi_pipeline_kernel.hpp) when the rows of 64 rollouts and a ring
         // fit the LDS; else the fused kernel below
-        if (pipeline && rmppiUseFast())
+        if (pipeline && rmppiPipelineUsable())
         {
-          DYN_FAST_T fast(dyn);
-          const int ring = kernels::initEvalPipelineRing(fast, cost, a.num_timesteps, MAX_LDS_BYTES);
-          if (ring > 0)
-          {
-            constexpr int REP = kernels::replicated_lanes<DYN_FAST_T>::value;
-            const size_t smem = kernels::initEvalPipelineSharedBytes(fast, cost, a.num_timesteps, ring);
-            auto kfn = kernels::initEvalPipelineKernel<DYN_FAST_T, COST_T, SAMPLING_T>;
+          bool launched = false;
+          const mppi_status st = withRmppiPipelineDynamics([&](auto& pd) -> mppi_status {
+            using PD_T = std::decay_t<decltype(pd)>;
+            const int ring = kernels::initEvalPipelineRing(pd, cost, a.num_timesteps, MAX_LDS_BYTES);
+            if (ring == 0)
+              return MPPI_OK;  // rows + ring do not fit: the fused kernel below
+            launched = true;
+            constexpr int REP = kernels::replicated_lanes<PD_T>::value;
+            const size_t smem = kernels::initEvalPipelineSharedBytes(pd, cost, a.num_timesteps, ring);
+            auto kfn = kernels::initEvalPipelineKernel<PD_T, COST_T, SAMPLING_T>;
             if (smem > 48 * 1024)
               (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             constexpr int WAVES = REP + kernels::INIT_EVAL_PIPE_SAMPLERS + kernels::INIT_EVAL_PIPE_COSTS;
-            hipLaunchKernelGGL(kfn, dim3((a.num_eval_rollouts + BX - 1) / BX), dim3(64 * WAVES, 1, 1), smem, stream, fast, cost, smp,
-                               a, ring);
+            hipLaunchKernelGGL(kfn, dim3((a.num_eval_rollouts + BX - 1) / BX), dim3(64 * WAVES, 1, 1), smem, stream, pd, cost, smp, a,
+                               ring);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess)
             {
@@ -546,7 +577,9 @@ struct ModelT : ModelBase
               return MPPI_ERR_HIP;
             }
             return MPPI_OK;
-          }
+          });
+          if (launched || st != MPPI_OK)
+            return st;
         }
       }
       // models with replicated-lane (MFMA / four-lane) dynamics run both Robust MPPI kernels on them (withRmppiDynamics)
@@ -618,7 +651,7 @@ struct ModelT : ModelBase
       prepSampler(s);
       if constexpr (rmppiHasPipeline())
       {
-        if (pipeline && bx == 64 && rmppiUseFast())
+        if (pipeline && bx == 64 && rmppiPipelineUsable())
           return launchRMPPIPipeline(a, stream, err);
       }
       if (bx == 64)

@@ -48,8 +48,19 @@ namespace kernels
 #if !defined(MPPI_RMPPI_PIPE_NC)
 #define MPPI_RMPPI_PIPE_NC 3
 #endif
-constexpr int RMPPI_PIPE_SAMPLERS = MPPI_RMPPI_PIPE_NS;
-constexpr int RMPPI_PIPE_COSTS = MPPI_RMPPI_PIPE_NC;
+/** replicated-lane dynamics: the tuned counts above.  One lane per rollout (analytic models: a dynamics wave carries 64
+ *  rollouts and a step is ~40 instructions): the Philox draw sets the pace — two samplers taking alternate trips — and one
+ *  cost wave per system keeps up */
+template <class DYN_T>
+__host__ __device__ constexpr int rmppiPipeSamplers()
+{
+  return replicated_lanes<DYN_T>::value > 1 ? MPPI_RMPPI_PIPE_NS : 2;
+}
+template <class DYN_T>
+__host__ __device__ constexpr int rmppiPipeCosts()
+{
+  return replicated_lanes<DYN_T>::value > 1 ? MPPI_RMPPI_PIPE_NC : 1;
+}
 
 /** ring depths in steps, powers of two: outputs (dynamics -> cost), shaped samples (sampler -> dynamics), nominal states */
 struct RMPPIPipeRings
@@ -62,7 +73,7 @@ struct RMPPIPipeRings
 template <class DYN_T>
 __host__ __device__ constexpr int rmppiPipelineWaves()
 {
-  return 2 * replicated_lanes<DYN_T>::value + RMPPI_PIPE_SAMPLERS + 2 * RMPPI_PIPE_COSTS;
+  return 2 * replicated_lanes<DYN_T>::value + rmppiPipeSamplers<DYN_T>() + 2 * rmppiPipeCosts<DYN_T>();
 }
 
 template <class DYN_T, class COST_T, class FB_T, class SAMPLING_T>
@@ -80,7 +91,7 @@ __host__ inline size_t rmppiPipelineSharedBytes(const DYN_T& dyn, const COST_T& 
   n += sizeof(float) * 2 * (size_t)r.sample_steps * C * 64;          // [z][slot][c][rollout]
   n += sizeof(float) * (size_t)r.xnom_steps * S * 64;                // [slot][s][rollout]
   n += sizeof(float) * 7 * math::nearest_multiple_4(slots);          // cost_s, w_s, acc_a_s, acc_b_s, relay a / b / status
-  n += sizeof(int) * 4 * (2 * replicated_lanes<DYN_T>::value + RMPPI_PIPE_SAMPLERS + 2);  // progress counters (padded)
+  n += sizeof(int) * 4 * (2 * replicated_lanes<DYN_T>::value + rmppiPipeSamplers<DYN_T>() + 2);  // progress counters (padded)
   return n;
 }
 
@@ -135,9 +146,9 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
 {
   constexpr int BX = 64, BZ = 2;
   constexpr int REP = replicated_lanes<DYN_T>::value;
-  static_assert(REP > 1 && 64 % REP == 0, "this variant is for replicated-lane dynamics");
-  constexpr int DW = BX * REP / 64;  // dynamics waves per system
-  constexpr int NS = RMPPI_PIPE_SAMPLERS, NC = RMPPI_PIPE_COSTS;
+  static_assert(REP >= 1 && 64 % REP == 0, "whole waves of replica groups");
+  constexpr int DW = BX * REP / 64;  // dynamics waves per system (one lane per rollout: 1)
+  constexpr int NS = rmppiPipeSamplers<DYN_T>(), NC = rmppiPipeCosts<DYN_T>();
   // wave order: nominal dynamics 0 .. DW-1, real dynamics DW .. 2 DW-1 (the CU deals a workgroup's waves to its four SIMDs
   // in turn: with DW = 4 the two systems of a group of rollouts share a SIMD), then the samplers, then the cost waves
   constexpr int NWAVES = rmppiPipelineWaves<DYN_T>();
@@ -577,7 +588,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + INIT_EV
 {
   constexpr int BX = 64;
   constexpr int REP = replicated_lanes<DYN_T>::value;
-  static_assert(REP > 1 && 64 % REP == 0, "this variant is for replicated-lane dynamics");
+  static_assert(REP >= 1 && 64 % REP == 0, "whole waves of replica groups");
   constexpr int DW = BX * REP / 64;
   constexpr int NS = INIT_EVAL_PIPE_SAMPLERS, NC = INIT_EVAL_PIPE_COSTS;
   constexpr int NTHREADS = 64 * (DW + NS + NC);

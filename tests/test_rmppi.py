@@ -148,6 +148,10 @@ def test_rmppi_rollout_costs_bit_exact(gpu, model, acc_all, mode):
 @pytest.mark.parametrize("model,K,T,mode,variant", [("autorally", 1000, 37, "injected", m.MPPI_KERNEL_FUSED),
                                                      ("autorally", 1000, 37, "philox", m.MPPI_KERNEL_FUSED),
                                                      ("suspension", 1000, 37, "philox", m.MPPI_KERNEL_FUSED),
+                                                     ("di", 1000, 37, "injected", m.MPPI_KERNEL_FUSED),
+                                                     ("cartpole", 1000, 37, "philox", m.MPPI_KERNEL_FUSED),
+                                                     ("di", 333, 150, "philox", m.MPPI_KERNEL_PIPELINE),
+                                                     ("cartpole", 300, 3, "injected", m.MPPI_KERNEL_PIPELINE),
                                                      ("autorally", 330, 150, "philox", m.MPPI_KERNEL_PIPELINE),
                                                      ("autorally", 320, 3, "injected", m.MPPI_KERNEL_PIPELINE),
                                                      ("autorally", 300, 1, "philox", m.MPPI_KERNEL_PIPELINE),
@@ -179,7 +183,8 @@ def test_rmppi_pipelined_kernel_independent_noise(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model,T", [("autorally", 37), ("autorally", 150), ("lstm", 20), ("suspension", 21), ("complete", 12)])
+@pytest.mark.parametrize("model,T", [("autorally", 37), ("autorally", 150), ("lstm", 20), ("suspension", 21), ("complete", 12),
+                                     ("di", 150), ("cartpole", 41)])
 def test_rmppi_candidate_evaluation_both_kernels(gpu, model, T):
     """updateImportanceSamplingControl's candidate rollouts (9 x 32, time-shifted samples) on the fused init-eval kernel and
     as blocks of role waves: the same candidate free energies, best index and nominal state, bit for bit"""
