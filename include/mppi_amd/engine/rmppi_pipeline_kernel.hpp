@@ -49,17 +49,24 @@ namespace kernels
 #define MPPI_RMPPI_PIPE_NC 3
 #endif
 /** replicated-lane dynamics: the tuned counts above.  One lane per rollout (analytic models: a dynamics wave carries 64
- *  rollouts and a step is ~40 instructions): the Philox draw sets the pace — two samplers taking alternate trips — and one
- *  cost wave per system keeps up */
+ *  rollouts and a step is ~40 instructions): what sets the pace there is the cost waves' chain again — double integrator,
+ *  K = 8192, T = 150, Robust computeControl with NS1 / NC1 = 2 / 1 144 us, 3 / 1 144, 2 / 2 99, 4 / 2 98, 2 / 3 89, 2 / 4 88
+ *  (the fused kernel: 253 us).  A/B builds: -DMPPI_RMPPI_PIPE_NS1=.. -DMPPI_RMPPI_PIPE_NC1=.. */
+#if !defined(MPPI_RMPPI_PIPE_NS1)
+#define MPPI_RMPPI_PIPE_NS1 2
+#endif
+#if !defined(MPPI_RMPPI_PIPE_NC1)
+#define MPPI_RMPPI_PIPE_NC1 3
+#endif
 template <class DYN_T>
 __host__ __device__ constexpr int rmppiPipeSamplers()
 {
-  return replicated_lanes<DYN_T>::value > 1 ? MPPI_RMPPI_PIPE_NS : 2;
+  return replicated_lanes<DYN_T>::value > 1 ? MPPI_RMPPI_PIPE_NS : MPPI_RMPPI_PIPE_NS1;
 }
 template <class DYN_T>
 __host__ __device__ constexpr int rmppiPipeCosts()
 {
-  return replicated_lanes<DYN_T>::value > 1 ? MPPI_RMPPI_PIPE_NC : 1;
+  return replicated_lanes<DYN_T>::value > 1 ? MPPI_RMPPI_PIPE_NC : MPPI_RMPPI_PIPE_NC1;
 }
 
 /** ring depths in steps, powers of two: outputs (dynamics -> cost), shaped samples (sampler -> dynamics), nominal states */
