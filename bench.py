@@ -258,6 +258,45 @@ def robust_autorally_leg(device):
                           "trajectory) + setFeedbackGains + computeControl back to back"}
 
 
+def robust_di_leg(device):
+    """Robust MPPI on the double integrator (the reference's example: examples/double_integrator_CORL2020.cu), K=8192, T=150"""
+    import numpy as np
+    import mppi_generic_amd as m
+    from common import di_cfg
+    cfg = di_cfg(K=8192, T=150, tube=True, num_iters=1)
+    eng = m.RobustMPPIController(cfg["model"], cfg["K"], cfg["T"], cfg["dt"], cfg["lambda_"], 0.0, 1, seed=42, device=device)
+    eng.setDynamicsParams(cfg["dyn"])
+    eng.setCostParams(cfg["cost"])
+    eng.setSamplingParams(cfg["std_dev"], [0.3, 0.2])
+    eng.setRMPPIParams(25.0, 9, 32)
+    g = np.random.default_rng(5).uniform(-0.3, 0.3, (cfg["T"], 4, 2)).astype(np.float32)
+    x = cfg["x0"].copy()
+
+    def cycle():
+        eng.updateImportanceSamplingControl(x, 1)
+        eng.setFeedbackGains(g)
+        eng.computeControl(x, 1)
+    for _ in range(20):
+        cycle()
+    n = 200
+    t_a = time.perf_counter()
+    for _ in range(n):
+        cycle()
+    period = (time.perf_counter() - t_a) / n
+    ready = 0.0
+    for _ in range(n):
+        eng.getTargetStateSeq()
+        t_a = time.perf_counter()
+        eng.computeControl(x, 1)
+        ready += time.perf_counter() - t_a
+    u = eng.getControlSeq()
+    eng.close()
+    return {"workload": "RobustMPPI, DoubleIntegrator + DoubleIntegratorCircleCost, K=8192, T=150, 9 x 32 candidate rollouts",
+            "control_ready_us": round(ready / n * 1e6, 2), "cycle_us": round(period * 1e6, 2), "finite": bool(np.isfinite(u).all()),
+            "kernel": "rolloutRMPPIPipelineKernel<DoubleIntegratorDynamics,...>: 2 dynamics + 2 sampler + 6 cost waves per 64 rollouts "
+                      "x 2 systems"}
+
+
 def autorally_leg(device):
     """AutoRally NeuralNetModel (FNN 6-32-32-4, synthetic weights) + ARStandardCost, K=16384, T=150, one GPU:
     iterations/s and the MFMA roofline of the NN forward (F_alg = 2 * sum(MAC) * K * T)."""
@@ -772,7 +811,8 @@ def main():
         # secondary workloads of the north star (not the headline `value`)
         if not args.primary_only and world == 1 and args.workload == "cartpole":
             for key, leg_fn in (("autorally_nn", autorally_leg), ("lstm_colored", lstm_colored_leg), ("di_tube", di_tube_leg),
-                                ("racer_elevation", racer_elevation_leg), ("robust_autorally_nn", robust_autorally_leg)):
+                                ("racer_elevation", racer_elevation_leg), ("robust_autorally_nn", robust_autorally_leg),
+                                ("robust_double_integrator", robust_di_leg)):
                 try:
                     out[key] = leg_fn(local_rank)
                 except Exception as e:  # noqa: BLE001
