@@ -168,7 +168,13 @@ struct mppi_handle_s
   float* cand_states_d = nullptr;
   float* cand_costs_d = nullptr;
   int* cand_strides_d = nullptr;
-  int cand_capacity = 0;
+  int cand_capacity = 0;     // candidates * samples the cost buffers hold
+  int cand_capacity_nc = 0;  // candidates the state / stride buffers hold
+  /* the same three in host memory mapped into the device (low-latency hand-over: the candidate kernel reads its inputs and
+   * writes its costs in place, the host waits on io_flags[9]): [states (nc * S) | strides (nc ints) | costs (nc * ns)] */
+  float* cand_io_h = nullptr;
+  float* cand_io_dev = nullptr;
+  unsigned cand_seq = 0;
 
   /* rocRAND host API (MPPI_NOISE_ROCRAND_HOST; librocrand.so loaded lazily): the reference's structure — a library
    * generator fills an eps buffer in HBM (curandGenerateNormal, sampling_distributions/gaussian/gaussian.cu:380-394) */
@@ -402,6 +408,8 @@ static void freeAll(mppi_handle h)
     (void)hipFree(h->cand_costs_d);
   if (h->cand_strides_d)
     (void)hipFree(h->cand_strides_d);
+  if (h->cand_io_h)
+    (void)hipHostFree(h->cand_io_h);
   if (h->ev_a)
     (void)hipEventDestroy(h->ev_a);
   if (h->ev_b)
@@ -1999,7 +2007,7 @@ static void rmBestIndex(mppi_handle h)
 static mppi_status rmEnsureCandidateBuffers(mppi_handle h)
 {
   const int n = h->num_candidates * h->samples_per_candidate;
-  if (n <= h->cand_capacity)
+  if (n <= h->cand_capacity && h->num_candidates <= h->cand_capacity_nc)
     return MPPI_OK;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (h->cand_states_d)
@@ -2008,18 +2016,61 @@ static mppi_status rmEnsureCandidateBuffers(mppi_handle h)
     (void)hipFree(h->cand_costs_d);
   if (h->cand_strides_d)
     (void)hipFree(h->cand_strides_d);
+  if (h->cand_io_h)
+    (void)hipHostFree(h->cand_io_h);
   h->cand_states_d = h->cand_costs_d = nullptr;
   h->cand_strides_d = nullptr;
+  h->cand_io_h = h->cand_io_dev = nullptr;
+  HIP_TRY(h, hipHostMalloc((void**)&h->cand_io_h, sizeof(float) * ((size_t)h->num_candidates * (h->S + 1) + n),
+                           hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_TRY(h, hipHostGetDevicePointer((void**)&h->cand_io_dev, h->cand_io_h, 0));
   HIP_TRY(h, hipMalloc((void**)&h->cand_states_d, sizeof(float) * h->num_candidates * h->S));
   HIP_TRY(h, hipMalloc((void**)&h->cand_costs_d, sizeof(float) * n));
   HIP_TRY(h, hipMalloc((void**)&h->cand_strides_d, sizeof(int) * h->num_candidates));
   h->cand_capacity = n;
+  h->cand_capacity_nc = h->num_candidates;
   return MPPI_OK;
 }
 
 /** the nominal state trajectory from rm_nominal_state under nominal_control_h (computeStateTrajectoryHelper) */
 static mppi_status rmNominalStateTrajectory(mppi_handle h)
 {
+  if (h->low_latency)
+  {
+    // inputs with the input block, the trajectory back through the device-mapped output block + flag (system 0 only)
+    const int T = h->cfg.num_timesteps;
+    float* in = h->io_in_h;
+    std::copy(h->rm_nominal_state.begin(), h->rm_nominal_state.begin() + h->S, in + (h->x0_d - h->in_block_d));
+    std::copy(h->nominal_control_h.begin(), h->nominal_control_h.end(), in + (h->mean_d - h->in_block_d));
+    hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+    HIP_TRY(h, hipGetLastError());
+    kernels::FinalizeArgs a{};
+    a.scratch_d = h->fin_scratch_d;
+    a.control_in_d = h->mean_d;
+    a.history_d = h->history_d;
+    a.history_stride = 0;
+    a.x0_d = h->x0_d;
+    a.dt = h->cfg.dt;
+    a.num_timesteps = T;
+    a.smooth_mask = 0;
+    a.constrain_mask = 0;
+    a.constrain_mode = 0;
+    a.control_out_d = h->io_out_dev + (h->ctrl_out_d - h->out_block_d);
+    a.state_out_d = h->io_out_dev + (h->state_out_d - h->out_block_d);
+    a.output_out_d = h->io_out_dev + (h->output_out_d - h->out_block_d);
+    a.flags_d = h->io_flags_dev;
+    a.seq = ++h->io_seq;
+    std::string err;
+    const mppi_status st = h->model->launchFinalize(1, a, h->stream, err);
+    if (st != MPPI_OK)
+      return fail(h, st, err);
+    h->out_pin_fresh = false;
+    h->results_in_io = true;
+    MPPI_TRY(waitHostFlag(h, 1, h->io_seq));
+    const float* xs = h->io_out_h + (h->state_out_d - h->out_block_d);
+    std::copy(xs, xs + (size_t)T * h->S, h->nominal_state_h.begin());
+    return MPPI_OK;
+  }
   HIP_TRY(h, hipMemcpyAsync(h->x0_d, h->rm_nominal_state.data(), sizeof(float) * h->S, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->ctrl_in_d, h->nominal_control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice,
                             h->stream));
@@ -2056,13 +2107,28 @@ static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, in
     }
   rmImportanceSamplerStrides(stride, nc, h->rm_line_weights, h->rm_cand_strides);
   MPPI_TRY(rmEnsureCandidateBuffers(h));
-  HIP_TRY(h, hipMemcpyAsync(h->cand_states_d, h->rm_cand_states.data(), sizeof(float) * nc * S, hipMemcpyHostToDevice,
-                            h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->cand_strides_d, h->rm_cand_strides.data(), sizeof(int) * nc, hipMemcpyHostToDevice,
-                            h->stream));
-  // copyNominalControlToDevice: distribution 0 <- nominal control (:409-412)
-  HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->nominal_control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice,
-                            h->stream));
+  float* cand_costs_dev = h->cand_costs_d;
+  if (h->low_latency)
+  {
+    // candidate states and strides stay in host memory mapped into the device (the kernel reads them once, in place), the
+    // nominal control goes up with the input block: no copy command
+    std::copy(h->rm_cand_states.begin(), h->rm_cand_states.end(), h->cand_io_h);
+    std::memcpy(h->cand_io_h + (size_t)nc * S, h->rm_cand_strides.data(), sizeof(int) * nc);
+    std::copy(h->nominal_control_h.begin(), h->nominal_control_h.end(), h->io_in_h + (h->mean_d - h->in_block_d));
+    hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+    HIP_TRY(h, hipGetLastError());
+    cand_costs_dev = h->cand_io_dev + (size_t)nc * (S + 1);
+  }
+  else
+  {
+    HIP_TRY(h, hipMemcpyAsync(h->cand_states_d, h->rm_cand_states.data(), sizeof(float) * nc * S, hipMemcpyHostToDevice,
+                              h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->cand_strides_d, h->rm_cand_strides.data(), sizeof(int) * nc, hipMemcpyHostToDevice,
+                              h->stream));
+    // copyNominalControlToDevice: distribution 0 <- nominal control (:409-412)
+    HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->nominal_control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice,
+                              h->stream));
+  }
   kernels::InitEvalArgs a{};
   a.dt = h->cfg.dt;
   a.num_timesteps = h->cfg.num_timesteps;
@@ -2070,9 +2136,9 @@ static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, in
   a.samples_per_candidate = ns;
   a.lambda = h->cfg.lambda;
   a.alpha = h->cfg.alpha;
-  a.strides_d = h->cand_strides_d;
-  a.states_d = h->cand_states_d;
-  a.trajectory_costs_d = h->cand_costs_d;
+  a.strides_d = h->low_latency ? reinterpret_cast<const int*>(h->cand_io_dev + (size_t)nc * S) : h->cand_strides_d;
+  a.states_d = h->low_latency ? h->cand_io_dev : h->cand_states_d;
+  a.trajectory_costs_d = cand_costs_dev;
   SamplerLaunchState s{};
   s.num_rollouts_local = h->K_local;
   s.num_rollouts_global = h->cfg.num_rollouts;
@@ -2102,9 +2168,21 @@ static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, in
     return fail(h, st, err);
   h->generation++;
   h->rm_cand_costs.resize((size_t)nc * ns);
-  HIP_TRY(h, hipMemcpyAsync(h->rm_cand_costs.data(), h->cand_costs_d, sizeof(float) * nc * ns, hipMemcpyDeviceToHost,
-                            h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->low_latency)
+  {
+    const unsigned seq = ++h->cand_seq;
+    hipLaunchKernelGGL(kernels::raiseFlagKernel, dim3(1), dim3(64), 0, h->stream, h->io_flags_dev + 9, seq);
+    HIP_TRY(h, hipGetLastError());
+    MPPI_TRY(waitHostFlag(h, 9, seq));
+    const float* costs = h->cand_io_h + (size_t)nc * (S + 1);
+    std::copy(costs, costs + (size_t)nc * ns, h->rm_cand_costs.begin());
+  }
+  else
+  {
+    HIP_TRY(h, hipMemcpyAsync(h->rm_cand_costs.data(), h->cand_costs_d, sizeof(float) * nc * ns, hipMemcpyDeviceToHost,
+                              h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
   rmBestIndex(h);
   h->stats_h.nominal_state_used = h->best_index;
   h->nominal_stride = h->rm_cand_strides[h->best_index];
