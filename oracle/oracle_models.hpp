@@ -1337,7 +1337,10 @@ struct RacerDubinsElevationSuspension : RacerDubinsElevationLSTMSteering
  * :607-618 (initializeDynamics); parameters and the 26-entry state layout: racer_dubins_elevation_lstm_unc.cuh:5-48.
  * Network inputs the step does not fill are zero (the reference's host path: getZeroInputVector).  The reference's tests
  * for this class compare GPU and CPU paths on random data or need a network file that is an LFS stub here
- * (TestMatchesPython): no known answer to pin on — see tests/test_racer_dubins_lstm_unc.py.
+ * (TestMatchesPython): no known answer to pin on — see tests/test_racer_dubins_lstm_unc.py; the whole step is checked against
+ * an independent float64 restatement written from the reference's source (tests/test_racer_complete_step_f64.py, round 3).
+ * In reverse gear the reference's computeQ calls the parent's and then — without a return — overwrites every entry with the
+ * network's (:305-309): the network's process noise applies in both gears, as here.
  */
 struct RacerDubinsElevationLSTMUncertainty : RacerDubinsElevationSuspension
 {

@@ -5,7 +5,8 @@ Pinning.  The reference's tests for this class compare its GPU and CPU paths on 
 numbers (TestMatchesPython) reads a network file that is a git-LFS stub in this snapshot.  No known answer exists, so:
 hand checks of what the class adds (quadratic brake lag, mean correction, network process noise, static settling states),
 the property that with silent networks and no braking the vehicle states move exactly as the suspension model's, and HIP
-against the oracle bit for bit.  DESIGN.md lists the class as "parity by restatement, unpinned"."""
+against the oracle bit for bit.  DESIGN.md lists the class as "parity by restatement, unpinned"; round 3 added an independent
+float64 restatement of the WHOLE step written from the reference's source (tests/test_racer_complete_step_f64.py)."""
 import math
 
 import numpy as np
