@@ -49,18 +49,29 @@ def lstm_step_f64(lstm, out, I, H, layers, x):
     return W2 @ np.tanh(W1 @ act + b1) + b2
 
 
-def complete_step_f64(p, blobs, x, u, dt, height_of, normal_of):
-    """(next_state[26], state_der[26], {output index: value}) of the reference's device step(), in float64"""
-    b, e, s = p.base, p.suspension.elevation, p.suspension
+def complete_step_f64(p, blobs, x, u, dt, height_of, normal_of, complete=True):
+    """(next_state, state_der, {output index: value}) of the reference's device step(), in float64.
+    complete: RacerDubinsElevationLSTMUncertainty (26 states); else its parent RacerDubinsElevationSuspension (24 states:
+    linear brake lag, no mean network, the parametric process noise, no static-settling states —
+    racer_dubins_elevation_suspension_lstm.cu:343-392)"""
+    if complete:
+        b, e, s = p.base, p.suspension.elevation, p.suspension
+        unc0 = UNC
+    else:
+        b, e, s = p.base, p.elevation, p
+        unc0 = 13
     x = x.astype(np.float64)
     u0, u1 = float(u[0]), float(u[1])
-    xd, xn = np.zeros(NS), x.copy()
+    xd, xn = np.zeros(len(x)), x.copy()
     v = x[S_VEL]
-    # quadratic brake lag (:510-520)
     err = (-u0 if u0 < 0 else 0.0) - x[S_BRAKE]
-    xd[S_BRAKE] = min(max((err > 0) * (err * p.pos_quad_brake_c[0] + err * abs(err) * p.pos_quad_brake_c[1]) +
-                          (err < 0) * (err * p.neg_quad_brake_c[0] + err * abs(err) * p.neg_quad_brake_c[1]),
-                          -b.max_brake_rate_neg), b.max_brake_rate_pos)
+    if complete:  # quadratic brake lag (racer_dubins_elevation_lstm_unc.cu:510-520)
+        xd[S_BRAKE] = min(max((err > 0) * (err * p.pos_quad_brake_c[0] + err * abs(err) * p.pos_quad_brake_c[1]) +
+                              (err < 0) * (err * p.neg_quad_brake_c[0] + err * abs(err) * p.neg_quad_brake_c[1]),
+                              -b.max_brake_rate_neg), b.max_brake_rate_pos)
+    else:  # computeParametricDelayDeriv (racer_dubins.cu:281-293)
+        xd[S_BRAKE] = min(max((err > 0) * err * b.brake_delay_constant + (err < 0) * err * b.brake_delay_constant_neg,
+                              -b.max_brake_rate_neg), b.max_brake_rate_pos)
     # computeParametricAccelDeriv (racer_dubins_elevation.cu:759-798)
     idx = int(0.2 < abs(v) <= 3.0) + 2 * int(abs(v) > 3.0)
     bs = min(max(x[S_BRAKE], 0.0), 0.25)
@@ -91,13 +102,14 @@ def complete_step_f64(p, blobs, x, u, dt, height_of, normal_of):
     xd[S_ROLL], xd[S_PITCH], xd[S_CGZ] = x[S_ROLL_RATE], x[S_PITCH_RATE], x[S_CGVZ]
     # mean network, forward gear only (:526-585): corrects dv/dt and dyaw/dt
     thr, brk = (u0 if u0 >= 0 else 0.0), (-u0 if u0 <= 0 else 0.0)
-    if b.gear_sign == 1:
+    if complete and b.gear_sign == 1:
         mo = lstm_step_f64(blobs["mean_lstm_weights"], blobs["mean_lstm_output_weights"], 12, 4, (16, 20, 2),
                            [v, x[S_OMEGA], x[S_BRAKE], x[S_STEER], x[S_STEER_RATE], thr, brk, u1, math.sin(x[S_STATIC_PITCH]),
                             xd[S_VEL], xd[S_YAW]])
         xd[S_VEL] += mo[0]
         xd[S_YAW] += mo[1]
-    xn[S_OMEGA] = xd[S_YAW]
+    if complete:
+        xn[S_OMEGA] = xd[S_YAW]
     # updateState (racer_dubins_elevation_suspension_lstm.cu:394-418): Euler over everything in front of the steering rate
     for i in range(S_STEER_RATE):
         xn[i] = x[i] + xd[i] * dt
@@ -117,20 +129,32 @@ def complete_step_f64(p, blobs, x, u, dt, height_of, normal_of):
     Q = np.zeros((4, 4))
     # (in reverse the reference first calls the parent's computeQ and then — there is no return — overwrites all sixteen
     # entries with the network's, :305-309: the network's process noise applies in both gears)
-    uo = lstm_step_f64(blobs["unc_lstm_weights"], blobs["unc_lstm_output_weights"], 13, 4, (17, 20, 5),
-                       [v, x[S_OMEGA], x[S_BRAKE], x[S_STEER], x[S_STEER_RATE], thr, brk, u1, math.sin(x[S_STATIC_ROLL]),
-                        math.sin(x[S_STATIC_PITCH]), xd[S_VEL], xd[S_YAW]])
-    uo = np.abs(1 / (1 + np.exp(-uo)) * np.array(p.unc_scale[:5], np.float64))
-    Q[0, 0] = uo[0] + (b.c_b[idx] * (v if idx == 0 else 1.0)) ** 2 * uo[4]
-    Q[1, 1] = uo[1] + ((v / b.wheel_base) / (math.cos(delta) ** 2 * b.steer_angle_scale)) ** 2 * uo[3]
-    Q[2, 2], Q[3, 3] = uo[2] * sy * sy, uo[2] * cy * cy
-    Q[2, 3] = Q[3, 2] = -uo[2] * sy * cy
-    un = x[UNC:UNC + 10]  # POS_X, POS_Y, YAW, VEL_X, POS_X_Y, POS_X_YAW, POS_X_VEL_X, POS_Y_YAW, POS_Y_VEL_X, YAW_VEL_X
+    if complete:
+        uo = lstm_step_f64(blobs["unc_lstm_weights"], blobs["unc_lstm_output_weights"], 13, 4, (17, 20, 5),
+                           [v, x[S_OMEGA], x[S_BRAKE], x[S_STEER], x[S_STEER_RATE], thr, brk, u1, math.sin(x[S_STATIC_ROLL]),
+                            math.sin(x[S_STATIC_PITCH]), xd[S_VEL], xd[S_YAW]])
+        uo = np.abs(1 / (1 + np.exp(-uo)) * np.array(p.unc_scale[:5], np.float64))
+        Q[0, 0] = uo[0] + (b.c_b[idx] * (v if idx == 0 else 1.0)) ** 2 * uo[4]
+        Q[1, 1] = uo[1] + ((v / b.wheel_base) / (math.cos(delta) ** 2 * b.steer_angle_scale)) ** 2 * uo[3]
+        Q[2, 2], Q[3, 3] = uo[2] * sy * sy, uo[2] * cy * cy
+        Q[2, 3] = Q[3, 2] = -uo[2] * sy * cy
+    else:  # the parametric process noise (racer_dubins_elevation.cu:421-506, device branch)
+        side = v * v * t / b.wheel_base + b.gravity * math.sin(x[S_ROLL])
+        q11 = abs(e.Q_y_f * abs(side) * max(abs(v) - 2, 0.0))
+        Q[0, 0] = e.Q_x_acc * abs(xd[S_VEL]) + e.Q_x_v[idx] * abs(v)
+        Q[1, 1] = abs(v) * (e.Q_omega_steering * abs(delta) + e.Q_omega_v)
+        Q[2, 2], Q[3, 3] = q11 * sy * sy, q11 * cy * cy
+        Q[2, 3] = Q[3, 2] = -q11 * sy * cy
+    un = x[unc0:unc0 + 10]  # POS_X, POS_Y, YAW, VEL_X, POS_X_Y, POS_X_YAW, POS_X_VEL_X, POS_Y_YAW, POS_Y_VEL_X, YAW_VEL_X
     S = np.array([[un[3], un[9], un[6], un[8]], [un[9], un[2], un[5], un[7]], [un[6], un[5], un[0], un[4]],
                   [un[8], un[7], un[4], un[1]]])  # matrix order (v, yaw, x, y)
     F = np.eye(4) + A * dt
     Sn = F @ S @ F.T + Q * dt
-    xn[UNC:UNC + 10] = [Sn[2, 2], Sn[3, 3], Sn[1, 1], Sn[0, 0], Sn[3, 2], Sn[2, 1], Sn[2, 0], Sn[3, 1], Sn[3, 0], Sn[1, 0]]
+    xn[unc0:unc0 + 10] = [Sn[2, 2], Sn[3, 3], Sn[1, 1], Sn[0, 0], Sn[3, 2], Sn[2, 1], Sn[2, 0], Sn[3, 1], Sn[3, 0], Sn[1, 0]]
+    y = {0: xn[S_VEL], 2: xn[S_X], 3: xn[S_Y], O_POS_Z: xn[S_CGZ] - xn[S_PITCH] * (-s.c_g[0]), O_F_UP: f_up, O_F_FWD: f_fwd,
+         O_F_SIDE: f_side}  # setOutputs (racer_dubins_elevation_suspension_lstm.cu:438-): the entries the cost reads
+    if not complete:
+        return xn, xd, y
     # static settling at the NEXT pose with the current static angles as the body attitude (racer_dubins.cu:359-433)
     roll, pitch, yaw = x[S_STATIC_ROLL], x[S_STATIC_PITCH], xn[S_YAW]
     cr, sr_, cp, sp_, cyw, syw = math.cos(roll), math.sin(roll), math.cos(pitch), math.sin(pitch), math.cos(yaw), math.sin(yaw)
@@ -145,9 +169,6 @@ def complete_step_f64(p, blobs, x, u, dt, height_of, normal_of):
     xn[S_STATIC_ROLL] = (math.asin(front / (0.737 * 2)) + math.asin(rear / (0.737 * 2))) / 2
     left, right = clamp(hh["rl"] - hh["fl"], 2.98), clamp(hh["rr"] - hh["fr"], 2.98)
     xn[S_STATIC_PITCH] = (math.asin(left / 2.981) + math.asin(right / 2.981)) / 2
-    # setOutputs (racer_dubins_elevation_suspension_lstm.cu:438-): the entries the cost of the benchmark reads
-    y = {0: xn[S_VEL], 2: xn[S_X], 3: xn[S_Y], O_POS_Z: xn[S_CGZ] - xn[S_PITCH] * (-s.c_g[0]), O_F_UP: f_up, O_F_FWD: f_fwd,
-         O_F_SIDE: f_side}
     return xn, xd, y
 
 
@@ -195,3 +216,46 @@ def test_oracle_whole_step_against_float64():
                 tol = (2e-3 + 3e-4 * abs(wv)) if k in (O_F_UP, O_F_FWD, O_F_SIDE) else (3e-6 + 3e-6 * abs(wv))
                 assert abs(y[k] - wv) <= tol, (gear, trial, "y", k, y[k], wv)
     assert worst < 1e-4
+
+
+def test_oracle_suspension_whole_step_against_float64():
+    """the parent class, RacerDubinsElevationSuspension (24 states), the same way — also listed as unpinned in DESIGN.md"""
+    from test_racer_dubins_suspension import suspension_cfg
+    from test_racer_dubins_suspension import st as st24
+    rng = np.random.default_rng(78)
+    sx, sy = -0.04, 0.06
+    centres = (np.arange(240) + 0.5) * 0.25 - 30.0
+    X, Y = np.meshgrid(centres, centres)
+    z = (sx * X + sy * Y).astype(np.float32)
+    nvec = np.array([-sx, -sy, 1.0]) / math.sqrt(sx * sx + sy * sy + 1)
+    n32 = np.append(nvec, 0.0).astype(np.float32).astype(np.float64)
+    for gear in (1, -1):
+        cfg = suspension_cfg(K=64, T=4, maps="both")
+        cfg["blobs"]["elevation_map"] = z
+        cfg["blobs"]["normals_map"] = np.broadcast_to(np.append(nvec, 0.0).astype(np.float32), (240, 240, 4)).copy()
+        p = cfg["dyn"]
+        p.base.gear_sign = gear
+        o = make_oracle(cfg)
+        for trial in range(60):
+            x = st24(rng.uniform(-4, 5), rng.uniform(-3, 3), rng.uniform(-12, 12), rng.uniform(-12, 12), rng.uniform(-0.4, 0.4),
+                     rng.uniform(0, 0.6), rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), 0.0, rng.uniform(-0.4, 0.4),
+                     rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(-0.5, 0.5))
+            x[S_CGZ] = sx * x[S_X] + sy * x[S_Y] + 0.32 + rng.uniform(-0.03, 0.03)
+            cov = rng.uniform(-0.05, 0.05, (4, 4))
+            cov = cov @ cov.T + 0.01 * np.eye(4)
+            x[13:23] = [cov[2, 2], cov[3, 3], cov[1, 1], cov[0, 0], cov[3, 2], cov[2, 1], cov[2, 0], cov[3, 1], cov[3, 0], cov[1, 0]]
+            u = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1)], np.float32)
+            xn, xd, y = o.model_step_full(x, u, 0.02)
+            wn, wd, wy = complete_step_f64(p, cfg["blobs"], x, u, 0.02, lambda w: sx * w[0] + sy * w[1], lambda w: n32,
+                                           complete=False)
+            for i in range(23):  # (entry 23 is the filler the model carries along)
+                loose = i in (S_CGVZ, S_ROLL_RATE, S_PITCH_RATE)
+                tol = (2e-3 + 3e-4 * abs(wd[i])) if loose else (2e-5 + 2e-5 * abs(wd[i]))
+                assert abs(xd[i] - wd[i]) <= tol, (gear, trial, "xd", i, xd[i], wd[i])
+                tol = (1e-4 + 1e-5 * abs(wn[i])) if loose else (3e-6 + 3e-6 * abs(wn[i]))
+                if i == S_YAW and abs(abs(wn[i]) - PI) < 1e-4:
+                    continue
+                assert abs(xn[i] - wn[i]) <= tol, (gear, trial, "xn", i, xn[i], wn[i])
+            for k, wv in wy.items():
+                tol = (2e-3 + 3e-4 * abs(wv)) if k in (O_F_UP, O_F_FWD, O_F_SIDE) else (3e-6 + 3e-6 * abs(wv))
+                assert abs(y[k] - wv) <= tol, (gear, trial, "y", k, y[k], wv)
