@@ -86,6 +86,23 @@ typedef enum mppi_kernel_variant
 } mppi_kernel_variant;
 
 /**
+ * Arithmetic of the last stage of an iteration (baseline -> weights -> normaliser -> weighted mean).  Every mode is far inside
+ * the 1e-5 parity bar for ONE iteration; the reference-order modes exist so that a free-running closed loop — which amplifies
+ * any difference — can be compared with the reference bit for bit (tests/test_closed_loop_parity.py).
+ */
+typedef enum mppi_reduction_mode
+{
+  MPPI_REDUCTION_FUSED = 0,               /* default: block-local softmin records in the rollout kernel's epilogue + one merge
+                                             kernel (rescale-merge: exact in real arithmetic, ~6e-8 from the reference's order) */
+  MPPI_REDUCTION_REFERENCE_ORDER = 1,     /* the reference's own order, operation for operation: global first-minimum baseline,
+                                             w_k against it, eta = float(sum of double(w_k)) in index order, weight = w_k / eta per
+                                             rollout, sum_strides consecutive rollouts serially, then the cells serially
+                                             (core/mppi_common.cu:885-900, 958-966, 1055-1063, 1115-1160).  Samples go through HBM */
+  MPPI_REDUCTION_REFERENCE_ORDER_FMA = 2  /* the same with inter = fma(weight, v, inter): what nvcc's default -fmad=true makes of
+                                             `inter += weight * v` on the reference's GPU path */
+} mppi_reduction_mode;
+
+/**
  * Construction parameters == the template arguments + ControllerParams of the reference
  * (controllers/controller.cuh:46-68; template <DYN, COST, FB, SAMPLING, MAX_TIMESTEPS, NUM_ROLLOUTS>, :70-75).
  */
@@ -118,7 +135,8 @@ typedef struct mppi_gaussian_params
   const float* control_cost_coeff; /* [C] */
   float pure_noise_trajectories_percentage;
   float std_dev_decay;
-  int sum_strides; /* accepted for compatibility; the block-local reduction does not need it */
+  int sum_strides; /* rollouts per cell of the weighted reduction (gaussian.cuh:30, default 32): only the reference-order
+                      reduction modes use it; the block-local reduction does not need it */
 } mppi_gaussian_params;
 
 /** per-system statistics (reference: MPPIFreeEnergyStatistics controllers/controller.cuh:22-38, getBaselineCost/getNormalizerCost) */
@@ -222,6 +240,9 @@ mppi_status mppi_set_control_deadband(mppi_handle h, const float* deadband);
 /** setLambda / setAlpha / setNumIters (controllers/controller.cuh:700-760) */
 mppi_status mppi_set_lambda_alpha(mppi_handle h, float lambda, float alpha);
 mppi_status mppi_set_num_iters(mppi_handle h, int num_iters);
+/** mppi_reduction_mode; MPPI_ERR_UNSUPPORTED on a K-sharded handle (the reference order runs over all rollouts).  The
+ *  environment variable MPPI_AMD_REDUCTION=reference | reference_fma selects the mode for every handle created afterwards. */
+mppi_status mppi_set_reduction_mode(mppi_handle h, int mode);
 /** slide_control_scale_ (controller.cuh:67) [C]; Tube: nominal_threshold_ (Tube-MPPI/tube_mppi_controller.cuh:20) */
 mppi_status mppi_set_slide_control_scale(mppi_handle h, const float* scale);
 mppi_status mppi_set_nominal_threshold(mppi_handle h, float threshold);
@@ -445,6 +466,16 @@ mppi_status mppi_compute_weights(float* costs, int num_rollouts, float lambda_in
 /** launchWeightedReductionKernel (core/mppi_common.cu:1366-1388): u_out[T][C] = sum_k (w_k/normalizer) v[k][t][c] */
 mppi_status mppi_weighted_reduction(const float* weights, const float* v, float normalizer, int num_rollouts,
                                     int num_timesteps, int control_dim, float* u_out, int device);
+/** the reference-order forms of the two (exact_reduce_kernels.hpp; what MPPI_REDUCTION_REFERENCE_ORDER runs): costs[K] ->
+ *  w_k = exp(-(S_k - rho)/lambda) in place with the GLOBAL first-minimum rho; stats8 = {rho, eta = float(sum of double(w)) in
+ *  index order, free energy mean, variance, modified variance (computeFreeEnergy's serial fp32 sums), sum w^2, 0, 0} */
+mppi_status mppi_compute_weights_reference_order(float* costs, int num_rollouts, float lambda, float* stats8, int device);
+/** weightedReductionKernel in the reference's summation order (core/mppi_common.cu:1115-1160): cells of sum_stride
+ *  consecutive rollouts summed serially with weight = w_k / normalizer, then the cells serially; fma != 0 contracts
+ *  inter += weight * v into one fma as nvcc's default does */
+mppi_status mppi_weighted_reduction_reference_order(const float* weights, const float* v, float normalizer, int num_rollouts,
+                                                    int num_timesteps, int control_dim, int sum_stride, int fma, float* u_out,
+                                                    int device);
 /** eps[k_begin..k_end)[T][C] exactly as the fused generator draws it (for generator parity tests) */
 mppi_status mppi_philox_normal(uint64_t seed, uint32_t generation, int num_rollouts, int num_timesteps,
                                int control_dim, int k_begin, int k_end, float* eps_out, int device);

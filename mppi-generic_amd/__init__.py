@@ -12,7 +12,9 @@ from .controllers import (MPPI_KERNEL_AUTO, MPPI_KERNEL_FUSED, MPPI_KERNEL_PIPEL
                           MPPI_CONTROLLER_COLORED, CartpoleDynamicsParams,
                           CartpoleQuadraticCostParams, DoubleIntegratorParams, DoubleIntegratorCircleCostParams,
                           ARStandardCostParams, RacerDubinsParams, RacerDubinsElevationParams, RacerDubinsSuspensionParams, RacerDubinsUncertaintyParams, QuadraticCostParams28, fnn_blob_from_npz_dict, lstm_blob_from_npz_dict,
-                          det_eval, LSTMLSTMHelper, texture2d_query, npz_read_array, philox_normal, launch_boundary_us, issue_interval_ns, norm_exp, compute_weights, weighted_reduction)
+                          det_eval, LSTMLSTMHelper, texture2d_query, npz_read_array, philox_normal, launch_boundary_us, issue_interval_ns, norm_exp, compute_weights, weighted_reduction,
+                          compute_weights_reference_order, weighted_reduction_reference_order,
+                          MPPI_REDUCTION_FUSED, MPPI_REDUCTION_REFERENCE_ORDER, MPPI_REDUCTION_REFERENCE_ORDER_FMA)
 from .plant import BasePlant, SimulatedPlant, interpolateControls, interpolateFeedback, interpolateState
 
 __all__ = [

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mppi_set_control_deadband": (C.c_int, [H, _f32p]),
     "mppi_set_lambda_alpha": (C.c_int, [H, C.c_float, C.c_float]),
     "mppi_set_num_iters": (C.c_int, [H, C.c_int]),
+    "mppi_set_reduction_mode": (C.c_int, [H, C.c_int]),
     "mppi_set_slide_control_scale": (C.c_int, [H, _f32p]),
     "mppi_set_nominal_threshold": (C.c_int, [H, C.c_float]),
     "mppi_set_model_blob": (C.c_int, [H, C.c_char_p, _f32p, C.c_size_t, C.POINTER(C.c_int), C.c_int]),
@@ -137,6 +138,9 @@ SIGNATURES = {
     "mppi_norm_exp": (C.c_int, [_f32p, C.c_int, C.c_float, C.c_float, C.c_int]),
     "mppi_compute_weights": (C.c_int, [_f32p, C.c_int, C.c_float, _f32p, C.c_int]),
     "mppi_weighted_reduction": (C.c_int, [_f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
+    "mppi_compute_weights_reference_order": (C.c_int, [_f32p, C.c_int, C.c_float, _f32p, C.c_int]),
+    "mppi_weighted_reduction_reference_order": (C.c_int, [_f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                           C.c_int, _f32p, C.c_int]),
     "mppi_philox_normal": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
     "mppi_measure_launch_boundary": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "mppi_measure_issue_interval": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),

@@ -19,6 +19,7 @@ MPPI_NOISE_PHILOX_FUSED = 0
 MPPI_NOISE_INJECTED = 1
 MPPI_NOISE_ROCRAND_HOST = 2
 MPPI_KERNEL_AUTO, MPPI_KERNEL_FUSED, MPPI_KERNEL_PIPELINE = 0, 1, 2
+MPPI_REDUCTION_FUSED, MPPI_REDUCTION_REFERENCE_ORDER, MPPI_REDUCTION_REFERENCE_ORDER_FMA = 0, 1, 2
 
 
 class MPPIError(RuntimeError):
@@ -359,6 +360,11 @@ class MPPIController:
 
     def setNumIters(self, n):
         self._check(self._lib.mppi_set_num_iters(self._h, n))
+
+    def setReductionMode(self, mode):
+        """MPPI_REDUCTION_FUSED (default) | MPPI_REDUCTION_REFERENCE_ORDER | MPPI_REDUCTION_REFERENCE_ORDER_FMA:
+        mppi_set_reduction_mode — the last stage of an iteration in the reference's own arithmetic order"""
+        self._check(self._lib.mppi_set_reduction_mode(self._h, int(mode)))
 
     def setSlideControlScale(self, scale):
         self._check(self._lib.mppi_set_slide_control_scale(self._h, _f32(scale).reshape(-1)))
@@ -732,6 +738,25 @@ def compute_weights(costs, lambda_inv, device=0):
     out = np.zeros(2, np.float32)
     _op_check(lib, lib.mppi_compute_weights(w, w.size, lambda_inv, out, device))
     return w, float(out[0]), float(out[1])
+
+
+def compute_weights_reference_order(costs, lambda_, device=0):
+    """weights, stats8 = {rho, eta, free energy mean / variance / modified variance, sum w^2, 0, 0} in the reference's order"""
+    lib = load_library()
+    w = _f32(costs).reshape(-1).copy()
+    st = np.zeros(8, np.float32)
+    _op_check(lib, lib.mppi_compute_weights_reference_order(w, w.size, lambda_, st, device))
+    return w, st
+
+
+def weighted_reduction_reference_order(weights, v, normalizer, sum_stride=32, fma=False, device=0):
+    lib = load_library()
+    v = _f32(v)
+    K, T, Cd = v.shape
+    u = np.empty((T, Cd), np.float32)
+    _op_check(lib, lib.mppi_weighted_reduction_reference_order(_f32(weights).reshape(-1), v, normalizer, K, T, Cd,
+                                                               sum_stride, 1 if fma else 0, u, device))
+    return u
 
 
 def weighted_reduction(weights, v, normalizer, device=0):

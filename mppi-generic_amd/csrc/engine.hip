@@ -27,6 +27,7 @@
 #include "npz_reader.hpp"
 #include "mppi_amd/engine/model_instance.hpp"
 #include "reduce_kernels.hpp"
+#include "exact_reduce_kernels.hpp"
 #include "mppi_amd/utils/texture_helpers/two_d_texture_helper.hpp"
 #include "mppi_amd/utils/nn_helpers/lstm_lstm_helper.hpp"
 
@@ -103,6 +104,12 @@ struct mppi_handle_s
   /* ColoredMPPI options (controllers/ColoredMPPI/colored_mppi_controller.cuh:18-22, 159-193): Tsallis weights and state leash */
   float tsallis_gamma = 0.0f, tsallis_r = 0.0f;
   float* tsallis_weights_d = nullptr;  // [K_local]
+  /* reference-order reduction (mppi_set_reduction_mode, exact_reduce_kernels.hpp) */
+  int reduction_mode = MPPI_REDUCTION_FUSED;
+  int sum_strides = 32;                // GaussianParams::sum_strides (sampling_distributions/gaussian/gaussian.cuh:30)
+  float* exact_weights_d = nullptr;    // [D][K_local]
+  float* exact_inter_d = nullptr;      // [D][ceil(K_local / sum_strides)][T*C]
+  int exact_inter_cells = 0;
   float* std_dev_time_d = nullptr;     // [D][T][C] time_specific_std_dev table
   bool leash_active = false;
   int leash_jump = 1;
@@ -256,6 +263,34 @@ static mppi_status fail(mppi_handle h, mppi_status s, const std::string& msg)
     return MPPI_ERR_INVALID_ARG;      \
   std::lock_guard<std::recursive_mutex> handle_lock__((h)->mu)
 
+/** buffers of the reference-order reduction: samples in HBM (what cfg.save_samples allocates), weights, cell partials */
+static mppi_status ensureExactBuffers(mppi_handle h)
+{
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (!h->samples_d)
+    HIP_TRY(h, hipMalloc((void**)&h->samples_d, sizeof(float) * (size_t)h->D * h->K_local * h->TC));
+  if (!h->exact_weights_d)
+    HIP_TRY(h, hipMalloc((void**)&h->exact_weights_d, sizeof(float) * (size_t)h->D * h->K_local));
+  const int cells = (h->K_local - 1) / h->sum_strides + 1;
+  if (!h->exact_inter_d || cells > h->exact_inter_cells)
+  {
+    if (h->exact_inter_d)
+      (void)hipFree(h->exact_inter_d);
+    h->exact_inter_d = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&h->exact_inter_d, sizeof(float) * (size_t)h->D * cells * h->TC));
+    h->exact_inter_cells = cells;
+  }
+  static bool attr_set = false;
+  if (!attr_set)
+  {
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernels::exactWeightsKernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kernels::EXACT_WEIGHTS_LDS_BYTES));
+    attr_set = true;
+  }
+  return MPPI_OK;
+}
+
 /* ------------------------------------------------------------------------------------------------------------------ */
 extern "C" {
 
@@ -395,7 +430,7 @@ static void freeAll(mppi_handle h)
   h->step_u_d = nullptr;  // slice of the step_x_d block
   float** bufs[] = { &h->in_block_d, &h->out_block_d, &h->costs_d,   &h->partials_d,  &h->send_d,     &h->recv_d,
                      &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->gather_tmp_d, &h->rows_d, &h->fin_scratch_d,
-                     &h->tsallis_weights_d, &h->rocrand_eps_d, &h->std_dev_time_d };
+                     &h->tsallis_weights_d, &h->rocrand_eps_d, &h->std_dev_time_d, &h->exact_weights_d, &h->exact_inter_d };
   for (float** b : bufs)
   {
     if (*b)
@@ -762,6 +797,25 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   h->slide_scale_h.assign(C, 0.0f);  // controller.cuh:67 slide_control_scale_ = Zero()
   h->nominal_history_h.assign((size_t)2 * C, 0.0f);
   h->rm_nominal_state.assign(S, 0.0f);
+  {
+    // MPPI_AMD_REDUCTION=reference | reference_fma: every handle of the process starts in the reference-order reduction
+    const char* red = getenv("MPPI_AMD_REDUCTION");
+    if (red && red[0] && !exchangeActive(hp))
+    {
+      const int mode = !strcmp(red, "reference") ? MPPI_REDUCTION_REFERENCE_ORDER :
+                       !strcmp(red, "reference_fma") ? MPPI_REDUCTION_REFERENCE_ORDER_FMA : MPPI_REDUCTION_FUSED;
+      if (mode != MPPI_REDUCTION_FUSED)
+      {
+        hp->reduction_mode = mode;
+        if (ensureExactBuffers(hp) != MPPI_OK)
+        {
+          g_create_error = hp->last_error;
+          freeAll(hp);
+          return MPPI_ERR_HIP;
+        }
+      }
+    }
+  }
   *out = h.release();
   return MPPI_OK;
 }
@@ -835,6 +889,26 @@ mppi_status mppi_set_sampler_params(mppi_handle h, const mppi_gaussian_params* p
     if (!(p->std_dev[i] > 0.0f))
       return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_sampler_params: std_dev must be > 0");
   h->model->setSamplerParams(p, h->D);
+  if (p->sum_strides > 0 && p->sum_strides != h->sum_strides)
+  {
+    h->sum_strides = p->sum_strides;
+    if (h->reduction_mode != MPPI_REDUCTION_FUSED)
+      MPPI_TRY(ensureExactBuffers(h));
+  }
+  return MPPI_OK;
+}
+
+mppi_status mppi_set_reduction_mode(mppi_handle h, int mode)
+{
+  CHECK_HANDLE(h);
+  if (mode != MPPI_REDUCTION_FUSED && mode != MPPI_REDUCTION_REFERENCE_ORDER && mode != MPPI_REDUCTION_REFERENCE_ORDER_FMA)
+    return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_reduction_mode: unknown mode");
+  if (mode != MPPI_REDUCTION_FUSED && exchangeActive(h))
+    return fail(h, MPPI_ERR_UNSUPPORTED,
+                "the reference-order reduction sums over ALL rollouts in index order: not available on a K-sharded handle");
+  h->reduction_mode = mode;
+  if (mode != MPPI_REDUCTION_FUSED)
+    MPPI_TRY(ensureExactBuffers(h));
   return MPPI_OK;
 }
 mppi_status mppi_set_independent_noise(mppi_handle h, int independent)
@@ -1454,9 +1528,43 @@ static inline bool tsallisActive(const mppi_handle_s* h)
   return h->cfg.controller == MPPI_CONTROLLER_COLORED && h->tsallis_gamma != 0.0f && h->tsallis_r != 0.0f;
 }
 
+/** the reference's own last stage, operation for operation (exact_reduce_kernels.hpp): global rho -> weights -> eta in
+ *  double, index order -> per-rollout weight / eta, cells of sum_strides rollouts, cells in order */
+static mppi_status launchExactReduction(mppi_handle h)
+{
+  RoctxRange range("mppi:reduce_reference_order");
+  kernels::ExactWeightsArgs a{};
+  a.num_rollouts = h->K_local;
+  a.costs_d = h->costs_d;
+  a.weights_d = h->exact_weights_d;
+  a.stats_out_d = h->stats_d;
+  a.lambda = h->cfg.lambda;
+  a.lambda_inv = (float)(1.0 / (double)h->cfg.lambda);
+  a.tsallis_gamma = tsallisActive(h) ? h->tsallis_gamma : 0.0f;
+  a.tsallis_r = tsallisActive(h) ? h->tsallis_r : 0.0f;
+  hipLaunchKernelGGL(kernels::exactWeightsKernel, dim3(h->D), dim3(kernels::COMBINE_THREADS),
+                     kernels::EXACT_WEIGHTS_LDS_BYTES, h->stream, a);
+  const int cells = (h->K_local - 1) / h->sum_strides + 1;
+  const dim3 grid((h->TC + 63) / 64, (cells + kernels::COMBINE_THREADS / 64 - 1) / (kernels::COMBINE_THREADS / 64), h->D);
+  if (h->reduction_mode == MPPI_REDUCTION_REFERENCE_ORDER_FMA)
+    hipLaunchKernelGGL(kernels::exactReductionCellsKernel<1>, grid, dim3(kernels::COMBINE_THREADS), 0, h->stream,
+                       h->exact_weights_d, h->samples_d, h->stats_d, h->TC, h->K_local, h->sum_strides, cells,
+                       h->exact_inter_d);
+  else
+    hipLaunchKernelGGL(kernels::exactReductionCellsKernel<0>, grid, dim3(kernels::COMBINE_THREADS), 0, h->stream,
+                       h->exact_weights_d, h->samples_d, h->stats_d, h->TC, h->K_local, h->sum_strides, cells,
+                       h->exact_inter_d);
+  hipLaunchKernelGGL(kernels::exactReductionFinalKernel, dim3((h->TC + 63) / 64, h->D), dim3(64), 0, h->stream,
+                     h->exact_inter_d, h->TC, cells, h->mean_d);
+  HIP_TRY(h, hipGetLastError());
+  return MPPI_OK;
+}
+
 static mppi_status iterationLocal(mppi_handle h, int iteration, int stride)
 {
   MPPI_TRY(launchRollout(h, iteration, stride));
+  if (h->reduction_mode != MPPI_REDUCTION_FUSED)
+    return launchExactReduction(h);
   if (tsallisActive(h))
   {  // global baseline -> Tsallis weights -> weighted mean of the dumped samples (reduce_kernels.hpp)
     hipLaunchKernelGGL(kernels::tsallisWeightsKernel, dim3(1), dim3(kernels::COMBINE_THREADS), 0, h->stream, h->K_local,
@@ -3185,6 +3293,64 @@ mppi_status mppi_weighted_reduction(const float* weights, const float* v, float 
   const int per_block = 32;
   hipLaunchKernelGGL(kernels::weightedReductionKernel, dim3((K + per_block - 1) / per_block), dim3(256), 0, 0, w.p,
                      vd.p, u.p, normalizer, (int)TC, K, per_block);
+  OP_TRY(hipGetLastError());
+  OP_TRY(hipMemcpy(u_out, u.p, sizeof(float) * TC, hipMemcpyDeviceToHost));
+  return MPPI_OK;
+}
+
+mppi_status mppi_compute_weights_reference_order(float* costs, int K, float lambda, float* stats8, int device)
+{
+  if (!costs || !stats8 || K <= 0 || !(lambda > 0.0f))
+    return MPPI_ERR_INVALID_ARG;
+  MPPI_TRY(opDevice(device));
+  DevBuf c, w, st;
+  OP_TRY(c.alloc(K));
+  OP_TRY(w.alloc(K));
+  OP_TRY(st.alloc(kernels::STATS_STRIDE));
+  OP_TRY(hipMemcpy(c.p, costs, sizeof(float) * K, hipMemcpyHostToDevice));
+  OP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernels::exactWeightsKernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kernels::EXACT_WEIGHTS_LDS_BYTES));
+  kernels::ExactWeightsArgs a{};
+  a.num_rollouts = K;
+  a.costs_d = c.p;
+  a.weights_d = w.p;
+  a.stats_out_d = st.p;
+  a.lambda = lambda;
+  a.lambda_inv = (float)(1.0 / (double)lambda);
+  hipLaunchKernelGGL(kernels::exactWeightsKernel, dim3(1), dim3(kernels::COMBINE_THREADS), kernels::EXACT_WEIGHTS_LDS_BYTES,
+                     0, a);
+  OP_TRY(hipGetLastError());
+  OP_TRY(hipMemcpy(costs, w.p, sizeof(float) * K, hipMemcpyDeviceToHost));
+  OP_TRY(hipMemcpy(stats8, st.p, sizeof(float) * kernels::STATS_STRIDE, hipMemcpyDeviceToHost));
+  return MPPI_OK;
+}
+
+mppi_status mppi_weighted_reduction_reference_order(const float* weights, const float* v, float normalizer, int K, int T,
+                                                    int C, int sum_stride, int fma, float* u_out, int device)
+{
+  if (!weights || !v || !u_out || K <= 0 || T <= 0 || C <= 0 || sum_stride <= 0)
+    return MPPI_ERR_INVALID_ARG;
+  MPPI_TRY(opDevice(device));
+  DevBuf w, vd, u, st, inter;
+  const int TC = T * C;
+  const int cells = (K - 1) / sum_stride + 1;
+  OP_TRY(w.alloc(K));
+  OP_TRY(vd.alloc((size_t)K * TC));
+  OP_TRY(u.alloc(TC));
+  OP_TRY(st.alloc(kernels::STATS_STRIDE));
+  OP_TRY(inter.alloc((size_t)cells * TC));
+  float sth[kernels::STATS_STRIDE] = { 0.0f, normalizer };
+  OP_TRY(hipMemcpy(w.p, weights, sizeof(float) * K, hipMemcpyHostToDevice));
+  OP_TRY(hipMemcpy(vd.p, v, sizeof(float) * (size_t)K * TC, hipMemcpyHostToDevice));
+  OP_TRY(hipMemcpy(st.p, sth, sizeof(sth), hipMemcpyHostToDevice));
+  const dim3 grid((TC + 63) / 64, (cells + kernels::COMBINE_THREADS / 64 - 1) / (kernels::COMBINE_THREADS / 64), 1);
+  if (fma)
+    hipLaunchKernelGGL(kernels::exactReductionCellsKernel<1>, grid, dim3(kernels::COMBINE_THREADS), 0, 0, w.p, vd.p, st.p, TC,
+                       K, sum_stride, cells, inter.p);
+  else
+    hipLaunchKernelGGL(kernels::exactReductionCellsKernel<0>, grid, dim3(kernels::COMBINE_THREADS), 0, 0, w.p, vd.p, st.p, TC,
+                       K, sum_stride, cells, inter.p);
+  hipLaunchKernelGGL(kernels::exactReductionFinalKernel, dim3((TC + 63) / 64, 1), dim3(64), 0, 0, inter.p, TC, cells, u.p);
   OP_TRY(hipGetLastError());
   OP_TRY(hipMemcpy(u_out, u.p, sizeof(float) * TC, hipMemcpyDeviceToHost));
   return MPPI_OK;

@@ -310,6 +310,11 @@ void oracle_weighted_reduction(const float* w, const float* v, float normalizer,
 {
   weightedReduction(w, v, normalizer, K, T, C, sum_stride, u_out);
 }
+/** process-wide flavour of `inter += weight * v` in every weightedReduction: 0 = multiply, then add (default); 1 = one fma */
+void oracle_set_reduction_fma(int fma)
+{
+  weightedReductionFma() = fma != 0;
+}
 void oracle_smooth(float* u, const float* history, int T, int C)
 {
   smoothControlTrajectory(u, history, T, C);
@@ -386,6 +391,10 @@ void oracle_tube_compute_control(void* h, const float* x0, int stride, const flo
 void oracle_vanilla_slide(void* h, int steps)
 {
   ((Controller*)h)->vanillaSlide(steps);
+}
+void oracle_tube_slide(void* h, int steps)
+{
+  ((Controller*)h)->tubeSlide(steps);
 }
 void oracle_get_control(void* h, float* u)
 {

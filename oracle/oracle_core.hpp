@@ -376,9 +376,18 @@ inline void computeFreeEnergy(float& fe, float& fe_var, float& fe_mod, const flo
  * weight = w/eta computed per rollout, then thread 0 sums the ceil(K/sum_stride) partials serially.
  * v: [K][T][C] (one distribution), u_out: [T][C].
  */
+/** `inter += weight * v` is two roundings here by default (this file is compiled with -ffp-contract=off; it is also what
+ *  the reference's own CPU statement of the kernel computes); nvcc's default -fmad=true contracts it to one fma on the
+ *  reference's GPU path — g_weighted_reduction_fma selects that flavour (oracle_set_reduction_fma) */
+inline bool& weightedReductionFma()
+{
+  static bool fma_flavour = false;
+  return fma_flavour;
+}
 inline void weightedReduction(const float* w, const float* v, float normalizer, int K, int T, int C, int sum_stride,
                               float* u_out)
 {
+  const bool use_fma = weightedReductionFma();
   const int cells = (K - 1) / sum_stride + 1;
   std::vector<float> inter((size_t)cells * C);
   for (int t = 0; t < T; t++)
@@ -392,7 +401,14 @@ inline void weightedReduction(const float* w, const float* v, float normalizer, 
         {
           const float weight = w[k] / normalizer;
           for (int c = 0; c < C; c++)
-            inter[(size_t)j * C + c] += weight * v[((size_t)k * T + t) * C + c];
+          {
+            float& cell = inter[(size_t)j * C + c];
+            const float s = v[((size_t)k * T + t) * C + c];
+            if (use_fma)
+              cell = det::fma(weight, s, cell);
+            else
+              cell += weight * s;
+          }
         }
       }
     for (int c = 0; c < C; c++)
@@ -694,6 +710,21 @@ struct Controller
     std::vector<float> x0n(nominal_state.begin(), nominal_state.begin() + dyn->S);
     computeStateTrajectory(*dyn, dt, x0n.data(), nominal_control.data(), T, nominal_state.data());
     computeStateTrajectory(*dyn, dt, x0_actual, control.data(), T, state_traj.data());
+  }
+
+  /** reference: controllers/Tube-MPPI/tube_mppi_controller.cu:312-350 — updateNominalState(nominal control column 0): one
+   *  in-place model step of nominal_state_trajectory.col(0) without constraints; the control history is taken from the NOMINAL
+   *  control; both sequences slide */
+  void tubeSlide(int steps)
+  {
+    const int S = dyn->S, C = dyn->C, O = dyn->O;
+    std::vector<float> x(nominal_state.begin(), nominal_state.begin() + S), xn(S), xdot(S, 0.0f), y(O, 0.0f),
+        u(nominal_control.begin(), nominal_control.begin() + C), theta(std::max(1, dyn->scratchFloats()), 0.0f);
+    dyn->step(x.data(), xn.data(), xdot.data(), u.data(), y.data(), theta.data(), 0, dt);
+    std::copy(xn.begin(), xn.end(), nominal_state.begin());
+    saveControlHistory(steps, nominal_control.data(), control_history.data(), C);
+    slideControlSequence(nominal_control.data(), T, C, steps, dyn->zero_control.data(), slide_scale.data());
+    slideControlSequence(control.data(), T, C, steps, dyn->zero_control.data(), slide_scale.data());
   }
 
   /** reference: controllers/controller.cuh:351-356 (vanilla slide) */

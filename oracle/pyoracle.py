@@ -85,6 +85,7 @@ def lib():
         L.oracle_vanilla_compute_control.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p]
         L.oracle_tube_compute_control.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p]
         L.oracle_vanilla_slide.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_tube_slide.argtypes = [C.c_void_p, C.c_int]
         for n in ("control", "nominal_control", "state_traj", "nominal_state_traj", "costs", "weights", "samples",
                   "stats"):
             getattr(L, "oracle_get_" + n).argtypes = [C.c_void_p, _f32p]
@@ -275,6 +276,9 @@ class Oracle:
 
     def vanilla_slide(self, steps):
         self.L.oracle_vanilla_slide(self.h, steps)
+
+    def tube_slide(self, steps):
+        self.L.oracle_tube_slide(self.h, steps)
 
     def _get(self, name, shape):
         out = np.empty(shape, np.float32)
@@ -494,6 +498,12 @@ def weighted_reduction(w, v, eta, sum_stride=32):
     u = np.empty((T, Cd), np.float32)
     lib().oracle_weighted_reduction(_f32(w).reshape(-1), v, eta, K, T, Cd, sum_stride, u)
     return u
+
+
+def set_reduction_fma(fma):
+    """process-wide: `inter += weight * v` of every weighted reduction as ONE fma (what nvcc's default -fmad=true makes of it on
+    the reference's GPU path) instead of a rounded product followed by an addition (the default: the reference's CPU statement)"""
+    lib().oracle_set_reduction_fma(1 if fma else 0)
 
 
 def smooth(u, history):
