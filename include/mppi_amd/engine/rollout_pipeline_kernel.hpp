@@ -68,6 +68,8 @@ __host__ inline size_t pipelineSharedBytes(const DYN_T& dyn, const COST_T& cost,
 
 /** progress counters live in LDS: address-space-3 pointers keep the polls on ds_read instead of flat loads */
 typedef volatile __attribute__((address_space(3))) int* lds_counter_t;
+typedef int pipe_int4 __attribute__((ext_vector_type(4)));
+typedef volatile __attribute__((address_space(3))) pipe_int4* lds_counter4_t;
 
 /**
  * Blocks until *ctr >= need.  `cached` is the consumer's last observed value: the producer usually runs ahead, so most
@@ -92,12 +94,25 @@ __device__ inline void pipePublish(lds_counter_t ctr, const int value, const int
   if (lane == 0)
     *ctr = value;
 }
-
+/**
+ * pipePublish for a producer whose data went to LDS ONLY (ring slots, LDS sample rows).  The LDS unit executes the DS
+ * instructions of a wave in issue order (that order is what lgkmcnt counts), so the counter store below cannot become visible
+ * before the data stores in front of it: no s_waitcnt is needed, only the compiler must keep the order.  The release fence of
+ * pipePublish cost the dynamics wave of rolloutPipelineKernel an exposed LDS write round trip per trip (in-kernel timers,
+ * profiles/r04_cartpole_pipe_timing*.json).  NOT for data stored to global memory (the HBM-row variants' sampler waves).
+ */
+__device__ inline void pipePublishLds(lds_counter_t ctr, const int value, const int lane)
+{
+  asm volatile("" ::: "memory");
+  if (lane == 0)
+    *ctr = value;
+  asm volatile("" ::: "memory");
+}
 /* ---- A/B instrumentation (tools/pipe_timing.py; never defined in a product build): where the role waves of
  * rolloutPipelineRepKernel spend their time.  Every wave of the first PIPE_TIMING_BLOCKS blocks accumulates s_memtime ticks
  * (constant 100 MHz on gfx950: 10 ns — coarse per event, unbiased over the hundreds of events of a launch) per category. */
 #if defined(MPPI_PIPE_TIMING)
-constexpr int PIPE_TIMING_BLOCKS = 8, PIPE_TIMING_WAVES = 16, PIPE_TIMING_SLOTS = 8;
+constexpr int PIPE_TIMING_BLOCKS = 256, PIPE_TIMING_WAVES = 24, PIPE_TIMING_SLOTS = 8;
 static __device__ unsigned long long g_pipe_timing[PIPE_TIMING_BLOCKS * PIPE_TIMING_WAVES * PIPE_TIMING_SLOTS];
 struct PipeTimer
 {
@@ -112,6 +127,12 @@ struct PipeTimer
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     acc[slot] += t1 - t0;
     t0 = t1;
+  }
+  /** per-trip record of one wave (the dynamics wave of rolloutPipelineKernel): row 4 + kind of the block's table, entry trip */
+  __device__ inline void trip(const int block, const int kind, const int trip_idx, const int lane, const unsigned long long v) const
+  {
+    if (block < PIPE_TIMING_BLOCKS && lane == 0 && trip_idx < 4 * PIPE_TIMING_SLOTS && kind < 5)
+      g_pipe_timing[(block * PIPE_TIMING_WAVES + 4 + 4 * kind) * PIPE_TIMING_SLOTS + trip_idx] = v;
   }
   __device__ inline void flush(const int block, const int wave, const int lane) const
   {
@@ -163,6 +184,7 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
   __builtin_assume(__builtin_amdgcn_workitem_id_y() == 0);
   __builtin_assume(__builtin_amdgcn_workitem_id_z() < WZ);
 
+  PIPE_T(PipeTimer tm; tm.start(); const unsigned long long t_entry = wall_clock64();)
   DYN_T* dynamics = &dynamics_obj;
   COST_T* costs = &costs_obj;
   SAMPLING_T* sampling = &sampling_obj;
@@ -211,10 +233,11 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
   float* ring = ring_all + (size_t)ring_z * PIPE_RING * F * 64;  // [slot][i][lane]
   lds_counter_t counters =
       (lds_counter_t)(reinterpret_cast<int*>(ring_all + (size_t)WZ * PIPE_RING * F * 64) + 16 * ring_z);
+  // the three counters the dynamics wave consumes sit in one 16-byte word group: it reads them with a single ds_read_b128
   lds_counter_t smp_prog = counters + 0;   // steps whose shaped sample is in the row
+  lds_counter_t smp_prog1 = counters + 1;  // second sampler wave (trips 1, 3, 5, ...)
+  lds_counter_t cost_prog = counters + 2;  // steps the cost wave has consumed
   lds_counter_t dyn_prog = counters + 4;   // steps whose output is in the ring
-  lds_counter_t cost_prog = counters + 8;  // steps the cost wave has consumed
-  lds_counter_t smp_prog1 = counters + 12; // second sampler wave (trips 1, 3, 5, ...)
   static_assert(NS <= 2, "one spare counter");
 
   sampling->setThreadMapping(shared_idx, BX, BZ);
@@ -234,6 +257,40 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
 #pragma unroll
   for (int i = 0; i < O; i++)
     y[i] = 0.0f;
+  /* One trip of a sampler wave (plain draw): four steps = C Philox quads, shaped by the setGaussianControls rule, clamped when
+   * the constraints do not depend on the state, stored in the rollout's row.  The FIRST trip of every sampler wave runs here,
+   * in front of the block's barriers: it needs nothing but kernel arguments, and the dynamics wave — which can do nothing
+   * until steps 0..3 exist — would otherwise sit through prologue + draw in sequence (0.76 + 1.0 us of a 26 us launch,
+   * in-kernel timers of round 4); now the other waves' prologue and the first draw overlap. */
+  constexpr int SMP_STEPS = 4;
+  auto sampler_trip = [&](const int t) {
+    constexpr int QUADS = C;  // SMP_STEPS * C / 4
+    float zq[4 * QUADS];
+    if (DRAW_IN_LOOP)
+    {
+#pragma unroll
+      for (int q = 0; q < QUADS; q++)
+        sampling->drawQuad(global_idx, t * C / 4 + q, &zq[4 * q]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < SMP_STEPS; s2++)
+    {
+      if (t + s2 < num_timesteps)
+      {
+        if (DRAW_IN_LOOP)
+          sampling->template shapeControlSample<FOLD_Z>(global_idx, t + s2, distribution_idx, &zq[s2 * C], u);
+        else
+          sampling->template readControlSample<FOLD_Z>(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
+        if (SMP_CONSTRAINS)
+          dynamics->enforceConstraints(x, u);
+        sampling->writeControlSample(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
+      }
+    }
+  };
+  constexpr bool EARLY_FIRST_TRIP = DRAW_IN_LOOP && !PAIR_DRAW;
+  if (EARLY_FIRST_TRIP && role == 0 && SMP_STEPS * smp_id < num_timesteps)
+    sampler_trip(SMP_STEPS * smp_id);
+
   if (lane == 0 && wave_x == 0)
   {
     *smp_prog = 0;
@@ -251,6 +308,7 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
 
   float running_cost = 0.0f;
   float* row = sampling->sampleRow(theta_d_shared, shared_idx);
+  PIPE_T(tm.stop(3);)  // slot 3: kernel entry -> role loops (argument loads, counter reset, initialisers, two barriers)
 
   if (role == 0 && PAIR_DRAW)
   {
@@ -294,34 +352,27 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
   else if (role == 0)
   {
     /* ------------------------------------------------ sampler wave ------------------------------------------------ */
-    constexpr int STEPS = 4;
-    constexpr int QUADS = C;  // STEPS * C / 4
+    constexpr int STEPS = SMP_STEPS;
     lds_counter_t my_prog = smp_id == 0 ? smp_prog : smp_prog1;
-    for (int t = STEPS * smp_id; t < num_timesteps; t += STEPS * NS)
-    {
-      float zq[4 * QUADS];
-      if (DRAW_IN_LOOP)
-      {
-#pragma unroll
-        for (int q = 0; q < QUADS; q++)
-          sampling->drawQuad(global_idx, t * C / 4 + q, &zq[4 * q]);
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < STEPS; s2++)
-      {
-        if (t + s2 < num_timesteps)
-        {
-          if (DRAW_IN_LOOP)
-            sampling->template shapeControlSample<FOLD_Z>(global_idx, t + s2, distribution_idx, &zq[s2 * C], u);
-          else
-            sampling->template readControlSample<FOLD_Z>(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
-          if (SMP_CONSTRAINS)
-            dynamics->enforceConstraints(x, u);
-          sampling->writeControlSample(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
-        }
-      }
-      pipePublish(my_prog, min(t + STEPS, num_timesteps), lane);
+    auto publish = [&](const int value) {
+      if constexpr (ROWS_HBM)
+        pipePublish(my_prog, value, lane);  // the rows are in global memory: a real release fence
+      else
+        pipePublishLds(my_prog, value, lane);
+    };
+    int t = STEPS * smp_id;
+    if (EARLY_FIRST_TRIP && t < num_timesteps)
+    {  // drawn, shaped and stored in front of the barriers
+      publish(min(t + STEPS, num_timesteps));
+      t += STEPS * NS;
     }
+    for (; t < num_timesteps; t += STEPS * NS)
+    {
+      sampler_trip(t);
+      publish(min(t + STEPS, num_timesteps));
+      PIPE_T(if (smp_id == 0) { const unsigned long long ts0 = tm.t0; tm.stop(0); tm.trip(block_idx, 3, t / (STEPS * NS), lane, tm.t0 - ts0); })
+    }
+    PIPE_T(tm.stop(0);)  // slot 0: the whole sampler loop (it never waits)
   }
   else if (role == 1)
   {
@@ -352,12 +403,27 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
     };
     int seen_smp = 0, seen_smp1 = 0, seen_cost = 0;
     int t = 0;
-    auto wait_trip = [&](const int tp, const int need) {  // the samples of the trip that starts at step tp are in the rows
-      if (NS == 2 && (tp & 4))
-        pipeWait(smp_prog1, need, seen_smp1);
+    // The three counters this wave consumes, read with ONE ds_read_b128 inside the previous trip's arithmetic (`ahead`): the
+    // poll's LDS round trip is off the critical path, and only when even that (slightly stale, hence conservative — counters
+    // only grow) value does not cover a request does the wave really poll.
+    pipe_int4 ahead = { 0, 0, 0, 0 };
+    auto look_ahead = [&]() { ahead = *(lds_counter4_t)counters; };
+    auto need = [&](lds_counter_t ctr, int& cached, const int ahead_value, const int n) {
+      if (cached >= n)
+        return;
+      cached = max(cached, __builtin_amdgcn_readfirstlane(ahead_value));
+      if (cached >= n)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       else
-        pipeWait(smp_prog, need, seen_smp);
+        pipeWait(ctr, n, cached);
     };
+    auto wait_trip = [&](const int tp, const int n) {  // the samples of the trip that starts at step tp are in the rows
+      if (NS == 2 && (tp & 4))
+        need(smp_prog1, seen_smp1, ahead.y, n);
+      else
+        need(smp_prog, seen_smp, ahead.x, n);
+    };
+    auto wait_ring = [&](const int n) { need(cost_prog, seen_cost, ahead.z, n); };
     float unext[4 * C];  // ROWS_HBM: the next trip's samples, in flight while the current trip runs
     auto prefetch = [&](const int tp) {
       if (tp < num_timesteps)
@@ -370,16 +436,46 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
     };
     if constexpr (ROWS_HBM)
       prefetch(0);
-    // Full groups of 4 steps form ONE basic block (no tail test between the steps): the recurrence is skewed — the angle
+    // Full groups of steps form ONE basic block (no tail test between the steps): the recurrence is skewed — the angle
     // of step t + 1 depends only on the state at t, not on step t's derivative — so the scheduler can start the next
-    // step's argument reduction / sincos underneath the current step's division chain.  A single wave issues in order,
-    // and most instructions of a step wait ~8 cycles on their predecessor; overlapping the two chains is what shortens
-    // the critical path.
+    // step's argument reduction / sincos underneath the current step's division chain.
+    //
+    // Blocks with two sampler waves and the rows in LDS take EIGHT steps per trip (one trip of each sampler wave): the
+    // in-kernel timers of round 4 put ~60 ns of a 4-step trip's ~750 ns into what surrounds the steps — counter checks, the
+    // release fence's exposed LDS round trip before every publish, the loop's scalar bookkeeping — and that part halves.
+    if constexpr (!ROWS_HBM && NS == 2)
+    {
+      for (; t + 7 < num_timesteps; t += 8)
+      {
+        need(smp_prog, seen_smp, ahead.x, t + 4);        // sampler wave 0: steps t .. t+3
+        need(smp_prog1, seen_smp1, ahead.y, t + 8);      // sampler wave 1: steps t+4 .. t+7
+        PIPE_T(const unsigned long long tw0 = tm.t0; tm.stop(1); tm.trip(block_idx, 0, t / 8, lane, tm.t0 - tw0);)  // slot 1: waiting for the samplers
+        wait_ring(t + 8 - PIPE_RING);                    // their ring slots have been consumed
+        PIPE_T(const unsigned long long tw1 = tm.t0; tm.stop(2); tm.trip(block_idx, 1, t / 8, lane, tm.t0 - tw1);)  // slot 2: waiting for the cost wave
+        float ubuf[8 * C];
+#pragma unroll
+        for (int j = 0; j < 8 * C; j++)
+          ubuf[j] = row[t * C + j];
+        dyn_step(x, x_next, t, &ubuf[0]);
+        dyn_step(x_next, x, t + 1, &ubuf[C]);
+        dyn_step(x, x_next, t + 2, &ubuf[2 * C]);
+        dyn_step(x_next, x, t + 3, &ubuf[3 * C]);
+        dyn_step(x, x_next, t + 4, &ubuf[4 * C]);
+        dyn_step(x_next, x, t + 5, &ubuf[5 * C]);
+        dyn_step(x, x_next, t + 6, &ubuf[6 * C]);
+        look_ahead();                                    // lands during the last step; consumed by the next trip's checks
+        dyn_step(x_next, x, t + 7, &ubuf[7 * C]);
+        pipePublishLds(dyn_prog, t + 8, lane);
+        PIPE_T(const unsigned long long tw2 = tm.t0; tm.stop(0); tm.trip(block_idx, 2, t / 8, lane, tm.t0 - tw2);)  // slot 0: eight steps of work
+      }
+    }
     for (; t + 3 < num_timesteps; t += 4)
     {
       if constexpr (!ROWS_HBM)
         wait_trip(t, t + 4);                             // samples for steps t .. t+3 are in the rows
-      pipeWait(cost_prog, t + 4 - PIPE_RING, seen_cost); // their ring slots have been consumed
+      PIPE_T(tm.stop(1);)                                // slot 1: waiting for the sampler
+      wait_ring(t + 4 - PIPE_RING);                      // their ring slots have been consumed
+      PIPE_T(tm.stop(2);)                                // slot 2: waiting for the cost wave (ring back-pressure)
       float ubuf[4 * C];
       if constexpr (ROWS_HBM)
       {
@@ -397,15 +493,17 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
       dyn_step(x, x_next, t, &ubuf[0]);
       dyn_step(x_next, x, t + 1, &ubuf[C]);
       dyn_step(x, x_next, t + 2, &ubuf[2 * C]);
+      look_ahead();
       dyn_step(x_next, x, t + 3, &ubuf[3 * C]);
-      pipePublish(dyn_prog, t + 4, lane);
+      pipePublishLds(dyn_prog, t + 4, lane);             // ring (and LDS rows) only: no fence needed, see pipePublishLds
+      PIPE_T(tm.stop(0);)                                // slot 0: four steps of work
     }
     if (t < num_timesteps)
     {  // tail of 1..3 steps
       const int hi = num_timesteps;
       if constexpr (!ROWS_HBM)
         wait_trip(t, hi);
-      pipeWait(cost_prog, hi - PIPE_RING, seen_cost);
+      wait_ring(hi - PIPE_RING);
       float ubuf[4 * C];
 #pragma unroll
       for (int j = 0; j < 4 * C; j++)
@@ -415,7 +513,8 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
         dyn_step(x_next, x, t + 1, &ubuf[C]);
       if (t + 2 < num_timesteps)
         dyn_step(x, x_next, t + 2, &ubuf[2 * C]);
-      pipePublish(dyn_prog, hi, lane);
+      pipePublishLds(dyn_prog, hi, lane);
+      PIPE_T(tm.stop(0);)
     }
   }
   else if (role == 2)
@@ -439,21 +538,26 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
     for (; t + 3 < num_timesteps; t += 4)
     {
       pipeWait(dyn_prog, t + 4, seen_dyn);
+      PIPE_T(tm.stop(1);)  // slot 1: waiting for the dynamics wave
       cost_step(t);
       cost_step(t + 1);
       cost_step(t + 2);
       cost_step(t + 3);
-      pipePublish(cost_prog, t + 4, lane);
+      pipePublishLds(cost_prog, t + 4, lane);  // the ring reads above are DS instructions: ordered before this store
+      PIPE_T(tm.stop(0);)  // slot 0: four steps of cost
     }
     if (t < num_timesteps)
     {
       pipeWait(dyn_prog, num_timesteps, seen_dyn);
+      PIPE_T(tm.stop(1);)
       for (int tt = t; tt < num_timesteps; tt++)
         cost_step(tt);
-      pipePublish(cost_prog, num_timesteps, lane);
+      pipePublishLds(cost_prog, num_timesteps, lane);
+      PIPE_T(tm.stop(0);)
     }
   }
   __syncthreads();
+  PIPE_T(tm.stop(4);)  // slot 4: role loop done -> every wave of the block done
 
   // the cost wave holds the running cost and the last output: it publishes the rollout's result
   const bool writer = (role == 2);
@@ -461,6 +565,8 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
   blockSoftminEpilogue<SAMPLING_T, C, BX, BZ, NTHREADS>(sampling, args, terminal, running_cost, writer, valid, global_idx,
                                                         shared_idx, thread_idz, tid_flat, block_idx, nrows,
                                                         theta_d_shared, cost_s, w_s);
+  PIPE_T(tm.stop(5); tm.acc[6] = t_entry; tm.acc[7] = wall_clock64(); tm.flush(block_idx, wave_x + 4 * ring_z, lane);)
+  // slot 5: block softmin epilogue; slots 6 / 7: s_memrealtime (100 MHz, chip-wide) at entry / exit: launch ramp and tail across blocks
 }
 
 

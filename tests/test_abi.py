@@ -76,7 +76,7 @@ def test_hand_written_dpp_instructions_have_no_hazard(lib):
 def test_committed_isa_step_counts_match_the_sources(lib):
     """bench.py's issue floor multiplies a STATIC instruction count (profiles/r*_isa_step_counts.json) with issue intervals it
     measures live: the committed counts must be what the current sources compile to (regenerate with
-    `python tools/isa_step_count.py profiles/r03_isa_step_counts.json` after touching a step loop)"""
+    `python tools/isa_step_count.py profiles/r04_isa_step_counts.json` after touching a step loop)"""
     import glob
     import json
     import subprocess

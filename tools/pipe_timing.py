@@ -20,7 +20,7 @@ import numpy as np  # noqa: E402
 import mppi_generic_amd as m  # noqa: E402
 from common import autorally_cfg, make_engine  # noqa: E402
 
-BLOCKS, WAVES, SLOTS = 8, 16, 8
+BLOCKS, WAVES, SLOTS = 256, 24, 8  # PIPE_TIMING_BLOCKS / _WAVES / _SLOTS of rollout_pipeline_kernel.hpp
 
 
 def main():
