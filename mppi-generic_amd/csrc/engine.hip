@@ -1435,9 +1435,8 @@ static mppi_status launchCombine(mppi_handle h, const float* records, int num_re
   a.wait_flags_d = wait_flags;
   a.wait_seq = wait_seq;
   a.wait_limit_ticks = 200000000ull;  // 2 s of the 100 MHz wall clock
-  const size_t smem = sizeof(float) * 4 * (size_t)num_records;
-  hipLaunchKernelGGL(kernels::combineKernel, dim3(h->D, (h->TC + kernels::COMBINE_COLS - 1) / kernels::COMBINE_COLS),
-                     dim3(kernels::COMBINE_THREADS), smem, h->stream, a);
+  hipLaunchKernelGGL(kernels::combineKernel, dim3(h->D, kernels::combineGridY(h->TC)), dim3(kernels::MERGE_THREADS), 0,
+                     h->stream, a);
   HIP_TRY(h, hipGetLastError());
   return MPPI_OK;
 }
@@ -3355,6 +3354,19 @@ mppi_status mppi_weighted_reduction_reference_order(const float* weights, const 
   OP_TRY(hipMemcpy(u_out, u.p, sizeof(float) * TC, hipMemcpyDeviceToHost));
   return MPPI_OK;
 }
+
+#if defined(MPPI_COMBINE_TIMING)
+extern "C" int mppi_debug_read_combine_timing(unsigned long long* out, int capacity)
+{
+  if (!out || capacity < 32)
+    return -32;
+  if (hipDeviceSynchronize() != hipSuccess)
+    return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(kernels::g_combine_timing), sizeof(unsigned long long) * 32) != hipSuccess)
+    return -2;
+  return 32;
+}
+#endif
 
 __global__ void philoxNormalKernel(uint64_t seed, uint32_t generation, int TC, int k_begin, int k_end, float* out)
 {

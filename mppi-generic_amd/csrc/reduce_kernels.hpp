@@ -12,11 +12,9 @@
  * finalize == 0 writes the merged record (per-GPU partial, layout identical to the input records) instead of u*.
  * Also produces the reference's free-energy statistics (mppi_common.cu:1065-1081) from eta and sum w^2.
  *
- * Launch: grid = (D systems, ceil(T*C / 64) column blocks), block = COMBINE_THREADS (16 waves), dynamic LDS =
- * 4 * num_records floats.  The kernel is a chain of memory round trips (the records were just written by other CUs), so
- * it is organised to need only TWO of them: every block fetches the record tails once (rho / eta / sum w^2 -> LDS) and,
- * before reducing them, already has its first 16 column loads per lane in flight; wave w then sums records w, w+16, ...
- * for the block's 64 columns and the sixteen wave partials are added in a fixed order.
+ * Launch: grid = (D systems, combineGridY(T*C)), block = MERGE_THREADS (4 waves), no LDS.  The kernel is a chain of
+ * latencies (the records were just written by other CUs), so it is organised as ONE memory round trip per wave and nothing
+ * else that waits: a wave owns MERGE_COLS columns, a lane the records l, l + 64, ... — see combineWave().
  */
 #ifndef MPPI_AMD_REDUCE_KERNELS_HPP_
 #define MPPI_AMD_REDUCE_KERNELS_HPP_
@@ -109,161 +107,235 @@ __device__ inline double blockSum(double v, double* red_s)
   return r;
 }
 
-constexpr int COMBINE_COLS = 64;
+constexpr int COMBINE_COLS = 64;  ///< columns per block of the Tsallis mean kernel below
 
-__global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineArgs a)
+#if defined(MPPI_COMBINE_TIMING)
+/* A/B instrumentation (tools/combine_timing.py; never defined in a product build): s_memtime at the phases of combineKernel,
+ * [wave][8] for the first waves of the grid */
+static __device__ unsigned long long g_combine_timing[4 * 8];
+#define COMBINE_T(i)                                                                                                    \
+  if ((threadIdx.x & 63) == 0 && wave_global < 4)                                                                      \
+  g_combine_timing[wave_global * 8 + (i)] = __builtin_amdgcn_s_memtime()
+#else
+#define COMBINE_T(i)
+#endif
+
+/* ---- wave64 all-reduce without LDS: four DPP steps inside the rows of 16 lanes (xor 1, xor 2, half-row mirror, row mirror:
+ * a butterfly — both lanes of a pair form the same commutative sum, so all 16 lanes of a row end with identical bits), then
+ * the four row results through v_readlane in a fixed order.  ~20 issue slots against six dependent ds_bpermute round trips
+ * (~0.3 us) for a __shfl_xor tree: the merge kernel is a chain of latencies, and its three reductions were 1.5 us of it
+ * (in-kernel timers, round 4: profiles/r04_combine_timing_before.json). */
+template <int CTRL>
+__device__ inline float dppMoveF(const float v)
 {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* rho_s = reinterpret_cast<float*>(smem_raw);  // [num_records] record tails, fetched from memory ONCE
-  float* eta_s = rho_s + a.num_records;
-  float* eta2_s = eta_s + a.num_records;
-  __shared__ float part_s[COMBINE_THREADS / 64][COMBINE_COLS];
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ inline double dppMoveD(const double v)
+{
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;  // quad_perm [1,0,3,2] / [2,3,0,1]
 
-  const int z = blockIdx.x;
-  const int col0 = blockIdx.y * COMBINE_COLS;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  constexpr int NW = COMBINE_THREADS / 64;
+__device__ inline float readLaneF(const float v, const int l)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ inline double readLaneD(const double v, const int l)
+{
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ inline float waveAllMin(float v)
+{
+  v = fminf(v, dppMoveF<DPP_XOR1>(v));
+  v = fminf(v, dppMoveF<DPP_XOR2>(v));
+  v = fminf(v, dppMoveF<DPP_HALF_MIRROR>(v));
+  v = fminf(v, dppMoveF<DPP_MIRROR>(v));
+  return fminf(fminf(readLaneF(v, 0), readLaneF(v, 16)), fminf(readLaneF(v, 32), readLaneF(v, 48)));
+}
+__device__ inline float waveAllSum(float v)
+{
+  v += dppMoveF<DPP_XOR1>(v);
+  v += dppMoveF<DPP_XOR2>(v);
+  v += dppMoveF<DPP_HALF_MIRROR>(v);
+  v += dppMoveF<DPP_MIRROR>(v);
+  return (readLaneF(v, 0) + readLaneF(v, 16)) + (readLaneF(v, 32) + readLaneF(v, 48));
+}
+__device__ inline double waveAllSum(double v)
+{
+  v += dppMoveD<DPP_XOR1>(v);
+  v += dppMoveD<DPP_XOR2>(v);
+  v += dppMoveD<DPP_HALF_MIRROR>(v);
+  v += dppMoveD<DPP_MIRROR>(v);
+  return (readLaneD(v, 0) + readLaneD(v, 16)) + (readLaneD(v, 32) + readLaneD(v, 48));
+}
+
+constexpr int MERGE_COLS = 4;       ///< columns of u* per wave
+constexpr int MERGE_WAVES = 1;      ///< waves per block: ONE — a wave's loads touch 64 cache lines per instruction (lane = record, rows
+                                    ///< 416 B apart), and four waves queueing on one CU's address unit took 3.3 us to get their loads out
+constexpr int MERGE_THREADS = 64 * MERGE_WAVES;
+constexpr int MERGE_LANE_RECORDS = 4;  ///< records a lane keeps in registers: up to 256 records without a second pass
+/** y extent of combineKernel's grid: ceil(T C / MERGE_COLS) column waves + one wave for the record tail / the statistics */
+__host__ __device__ inline int combineGridY(const int TC)
+{
+  return ((TC + MERGE_COLS - 1) / MERGE_COLS + 1 + MERGE_WAVES - 1) / MERGE_WAVES;
+}
+
+/**
+ * The merge, one WAVE per MERGE_COLS columns of u* and no data exchanged between waves: lane l owns records l, l + 64, ...
+ * (their tails and their MERGE_COLS column values in registers), every wave forms rho, the scale factors, eta and sum w^2 for
+ * itself — the same instructions on the same data in every wave, block and rank, hence the same bits — then its columns'
+ * sums over the lanes.  One memory round trip (all loads of a wave are issued before anything is waited for), no LDS, no
+ * barrier.  Round 4 replaced the block-cooperative form (2 blocks x 16 waves, record tails through LDS, __shfl_xor trees, a
+ * barrier pair) whose body took 5.1-5.5 us of a ~29 us Cartpole iteration.
+ * One extra wave (the last one of the grid's y extent) writes the statistics (finalize) or the merged record's tail.
+ */
+template <bool MAILBOX>
+__device__ inline float mergeLoad(const float* p)
+{
+  return MAILBOX ? loadPeerWritten(p) : *p;
+}
+
+template <bool MAILBOX>
+__device__ inline void combineWave(const CombineArgs& a, const int z, const int wave_global, const int lane)
+{
+  const int col_waves = (a.TC + MERGE_COLS - 1) / MERGE_COLS;
+  const bool stats_wave = wave_global == col_waves;
+  if (wave_global > col_waves)
+    return;
   const float* rec = a.records_d + (size_t)z * a.z_stride;
   const float lambda_inv = (float)(1.0 / (double)a.lambda);
-
-  __shared__ int wait_failed_s;
-  const bool mailbox = a.wait_flags_d != nullptr;
-  if (mailbox)
-  {
-    // one lane per peer spins on that peer's flag (bounded: a peer that never posts must not wedge the GPU)
-    if (tid == 0)
-      wait_failed_s = 0;
-    __syncthreads();
-    if (tid < a.num_records)
-    {
-      const unsigned long long t0 = wall_clock64();
-      while (__hip_atomic_load(a.wait_flags_d + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.wait_seq)
-      {
-        __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - t0 > a.wait_limit_ticks)
-        {
-          wait_failed_s = 1;
-          break;
-        }
-      }
-    }
-    __syncthreads();
-    if (wait_failed_s)
-    {  // leave a mark the host checks (mppi_synchronize / result getters) and no result: the mean is left untouched
-      if (tid == 0 && blockIdx.y == 0 && a.stats_out_d)
-        a.stats_out_d[(size_t)z * STATS_STRIDE + 6] = 1.0f;
-      return;
-    }
-  }
-  // the column loads do not depend on the scale factors: issue the first batch before the reductions so that its
-  // memory round trip overlaps theirs
-  const int j = col0 + lane;
-  const bool col_ok = j < a.TC;
-  const float* col = rec + (col_ok ? j : 0);
-  constexpr int BATCH = 16;
-  float v0[BATCH];
-#pragma unroll
-  for (int i = 0; i < BATCH; i++)
-  {
-    const int b = wave + i * NW;
-    v0[i] = (col_ok && b < a.num_records) ? (mailbox ? loadPeerWritten(col + (size_t)b * a.rec_stride) : col[(size_t)b * a.rec_stride]) : 0.0f;
-  }
-
-  for (int b = tid; b < a.num_records; b += COMBINE_THREADS)
-  {
-    const float* r = rec + (size_t)b * a.rec_stride + a.TC;
-    rho_s[b] = mailbox ? loadPeerWritten(r) : r[0];
-    eta_s[b] = mailbox ? loadPeerWritten(r + 1) : r[1];
-    eta2_s[b] = mailbox ? loadPeerWritten(r + 2) : r[2];
-  }
-  __syncthreads();  // the only barrier before the partial sums
-
-  // rho, eta, sum w^2 over ALL records, redundantly in every wave — lane-strided partials joined by shuffle trees in a fixed
-  // order, so every wave (and every block, and every rank merging the same records) gets the same bits.  A block-wide
-  // reduction would cost three barrier pairs on a kernel that is nothing but latency; this costs num_records / 64 exps a lane.
-  float rho = INFINITY;
-  for (int b = lane; b < a.num_records; b += 64)
-    rho = fminf(rho, rho_s[b]);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
-    rho = fminf(rho, __shfl_xor(rho, off, 64));
+  const int n = a.num_records;
+  const int col0 = wave_global * MERGE_COLS;
   // a record whose rollouts all cost +inf has rho_b = inf and U_b = eta_b = 0: scale 0 (inf - inf would be NaN when the
   // global minimum is inf as well — then nothing has weight, as with the reference's global baseline)
-  auto scale = [&](const int b) {
-    const float dist = rho_s[b] - rho;
+  auto scale = [&](const float rho_b, const float rho) {
+    const float dist = rho_b - rho;
     return (dist == dist) ? mppi::det::exp(-lambda_inv * dist) : 0.0f;
   };
+  float rho, tot[MERGE_COLS];
   double eta = 0.0, eta2 = 0.0;
-  for (int b = lane; b < a.num_records; b += 64)
+  if (n <= 64 * MERGE_LANE_RECORDS)
   {
-    const float s = scale(b);
-    eta += (double)s * (double)eta_s[b];
-    eta2 += (double)s * (double)s * (double)eta2_s[b];
-  }
+    // everything this wave needs, requested at once: one round trip to records other CUs (or other GPUs) have just written
+    float rho_b[MERGE_LANE_RECORDS], eta_b[MERGE_LANE_RECORDS], eta2_b[MERGE_LANE_RECORDS], v[MERGE_LANE_RECORDS][MERGE_COLS];
+    typedef float merge_f4 __attribute__((ext_vector_type(4)));
+    // 16-byte loads where the records allow it (T C a multiple of 4: tail and column group are aligned quads): two load
+    // instructions per record instead of seven
+    const bool quads = !MAILBOX && MERGE_COLS == 4 && (a.TC & 3) == 0 && (a.rec_stride & 3) == 0 && (a.z_stride & 3) == 0;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
+    for (int i = 0; i < MERGE_LANE_RECORDS; i++)
+    {
+      const int b = lane + 64 * i;
+      const bool ok = b < n;
+      const float* r = rec + (size_t)(ok ? b : 0) * a.rec_stride;
+      if (quads)
+      {
+        const merge_f4 tail = *reinterpret_cast<const merge_f4*>(r + a.TC);
+        const merge_f4 cols = *reinterpret_cast<const merge_f4*>(r + (stats_wave ? 0 : col0));
+        rho_b[i] = ok ? tail.x : INFINITY;
+        eta_b[i] = ok ? tail.y : 0.0f;
+        eta2_b[i] = ok ? tail.z : 0.0f;
+        const bool okc = ok && !stats_wave;
+        v[i][0] = okc ? cols.x : 0.0f;
+        v[i][1] = okc ? cols.y : 0.0f;
+        v[i][2] = okc ? cols.z : 0.0f;
+        v[i][3] = okc ? cols.w : 0.0f;
+        continue;
+      }
+      rho_b[i] = ok ? mergeLoad<MAILBOX>(r + a.TC) : INFINITY;
+      eta_b[i] = ok ? mergeLoad<MAILBOX>(r + a.TC + 1) : 0.0f;
+      eta2_b[i] = ok ? mergeLoad<MAILBOX>(r + a.TC + 2) : 0.0f;
+#pragma unroll
+      for (int c = 0; c < MERGE_COLS; c++)
+        v[i][c] = (ok && !stats_wave && col0 + c < a.TC) ? mergeLoad<MAILBOX>(r + col0 + c) : 0.0f;
+    }
+    COMBINE_T(1);
+    float m = rho_b[0];
+#pragma unroll
+    for (int i = 1; i < MERGE_LANE_RECORDS; i++)
+      m = fminf(m, rho_b[i]);
+    COMBINE_T(2);  // the loads have arrived
+    rho = waveAllMin(m);
+    COMBINE_T(3);
+    float acc[MERGE_COLS];
+#pragma unroll
+    for (int c = 0; c < MERGE_COLS; c++)
+      acc[c] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MERGE_LANE_RECORDS; i++)
+    {
+      const float s = scale(rho_b[i], rho);  // 0 for the padding records (rho_b = inf unless everything is inf: then eta_b = 0)
+      eta += (double)s * (double)eta_b[i];
+      eta2 += (double)s * (double)s * (double)eta2_b[i];
+#pragma unroll
+      for (int c = 0; c < MERGE_COLS; c++)
+        acc[c] += s * v[i][c];
+    }
+    COMBINE_T(4);
+    eta = waveAllSum(eta);
+    eta2 = waveAllSum(eta2);
+#pragma unroll
+    for (int c = 0; c < MERGE_COLS; c++)
+      tot[c] = waveAllSum(acc[c]);
+    COMBINE_T(5);
+  }
+  else
   {
-    eta += __shfl_xor(eta, off, 64);
-    eta2 += __shfl_xor(eta2, off, 64);
+    // many records (K / 64 > 256): two passes over the tails, lane-strided in ascending order (the second one hits the L2)
+    float m = INFINITY;
+    for (int b = lane; b < n; b += 64)
+      m = fminf(m, mergeLoad<MAILBOX>(rec + (size_t)b * a.rec_stride + a.TC));
+    rho = waveAllMin(m);
+    float acc[MERGE_COLS];
+#pragma unroll
+    for (int c = 0; c < MERGE_COLS; c++)
+      acc[c] = 0.0f;
+    for (int b = lane; b < n; b += 64)
+    {
+      const float* r = rec + (size_t)b * a.rec_stride;
+      const float s = scale(mergeLoad<MAILBOX>(r + a.TC), rho);
+      eta += (double)s * (double)mergeLoad<MAILBOX>(r + a.TC + 1);
+      eta2 += (double)s * (double)s * (double)mergeLoad<MAILBOX>(r + a.TC + 2);
+#pragma unroll
+      for (int c = 0; c < MERGE_COLS; c++)
+        acc[c] += s * ((!stats_wave && col0 + c < a.TC) ? mergeLoad<MAILBOX>(r + col0 + c) : 0.0f);
+    }
+    eta = waveAllSum(eta);
+    eta2 = waveAllSum(eta2);
+#pragma unroll
+    for (int c = 0; c < MERGE_COLS; c++)
+      tot[c] = waveAllSum(acc[c]);
   }
   const float eta_f = (float)eta;
 
-  // wave w sums records w, w + NW, ... in ascending order (fixed order => run-to-run reproducible).  The scale factors of a
-  // batch of 16 records are computed by lanes 0..15 of the wave — one exp each, side by side — and read back lane by lane
-  // (v_readlane: a scalar operand), instead of travelling through LDS behind a barrier.
-  float acc = 0.0f;
+  if (!stats_wave)
   {
-    const int bl = wave + (lane & (BATCH - 1)) * NW;
-    const float s_mine = bl < a.num_records ? scale(bl) : 0.0f;
-#pragma unroll
-    for (int i = 0; i < BATCH; i++)
+    if (lane < MERGE_COLS && col0 + lane < a.TC)
     {
-      const float s_i = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s_mine), i));
-      acc += s_i * v0[i];  // v0[i] is 0 beyond the last record
-    }
-  }
-  if (a.num_records > BATCH * NW)
-  {
-    for (int b = wave + BATCH * NW; b < a.num_records; b += BATCH * NW)
-    {
-      float v[BATCH];
+      // lane c takes column c (the sums are wave-uniform)
+      float mine = tot[0];
 #pragma unroll
-      for (int i = 0; i < BATCH; i++)
+      for (int c = 1; c < MERGE_COLS; c++)
+        mine = lane == c ? tot[c] : mine;
+      const int j = col0 + lane;
+      if (a.finalize)
+        a.mean_out_d[(size_t)z * a.TC + j] = mine / eta_f;
+      else
       {
-        const int bi = b + i * NW;
-        v[i] = (col_ok && bi < a.num_records) ?
-                   (mailbox ? loadPeerWritten(col + (size_t)bi * a.rec_stride) : col[(size_t)bi * a.rec_stride]) :
-                   0.0f;
-      }
-      const int bl = b + (lane & (BATCH - 1)) * NW;
-      const float s_mine = bl < a.num_records ? scale(bl) : 0.0f;
-#pragma unroll
-      for (int i = 0; i < BATCH; i++)
-      {
-        const float s_i = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s_mine), i));
-        acc += s_i * v[i];
+        a.record_out_d[(size_t)z * a.PS + j] = mine;
+        for (int p = 0; p < a.post.world; p++)
+          __hip_atomic_store(a.post.peer_slot[p] + (size_t)z * a.PS + j, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
-  part_s[wave][lane] = acc;
-  __syncthreads();
-  if (wave == 0 && j < a.TC)
-  {
-    float tot = part_s[0][lane];
-#pragma unroll
-    for (int w = 1; w < NW; w++)
-      tot += part_s[w][lane];
-    if (a.finalize)
-      a.mean_out_d[(size_t)z * a.TC + j] = tot / eta_f;
-    else
-    {
-      a.record_out_d[(size_t)z * a.PS + j] = tot;
-      for (int p = 0; p < a.post.world; p++)
-        __hip_atomic_store(a.post.peer_slot[p] + (size_t)z * a.PS + j, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  if (tid == 0 && blockIdx.y == 0)
+  else if (lane == 0)
   {
     if (a.finalize)
     {
@@ -296,6 +368,50 @@ __global__ void __launch_bounds__(COMBINE_THREADS) combineKernel(const CombineAr
           __hip_atomic_store(a.post.peer_slot[p] + (size_t)z * a.PS + a.TC + i, tail[i], __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_SYSTEM);
     }
+  }
+  COMBINE_T(6);
+}
+
+__global__ void __launch_bounds__(MERGE_THREADS) combineKernel(const CombineArgs a)
+{
+  const int z = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_global = __builtin_amdgcn_readfirstlane((int)blockIdx.y * MERGE_WAVES + (tid >> 6));
+  COMBINE_T(0);
+  const bool mailbox = a.wait_flags_d != nullptr;
+  if (mailbox)
+  {
+    // one lane per peer spins on that peer's flag (bounded: a peer that never posts must not wedge the GPU)
+    __shared__ int wait_failed_s;
+    if (tid == 0)
+      wait_failed_s = 0;
+    __syncthreads();
+    if (tid < a.num_records)
+    {
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load(a.wait_flags_d + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.wait_seq)
+      {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > a.wait_limit_ticks)
+        {
+          wait_failed_s = 1;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (wait_failed_s)
+    {  // leave a mark the host checks (mppi_synchronize / result getters) and no result: the mean is left untouched
+      if (tid == 0 && blockIdx.y == 0 && a.stats_out_d)
+        a.stats_out_d[(size_t)z * STATS_STRIDE + 6] = 1.0f;
+      return;
+    }
+    combineWave<true>(a, z, wave_global, lane);
+  }
+  else
+  {
+    combineWave<false>(a, z, wave_global, lane);
   }
   if (!a.finalize && a.post.world > 0)
   {
