@@ -720,9 +720,11 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
   float* relay_cost = w_s + math::nearest_multiple_4(SLOTS);  // running cost / status handed from cost wave to cost wave
   int* relay_status = reinterpret_cast<int*>(relay_cost + math::nearest_multiple_4(SLOTS));
   lds_counter_t counters = (lds_counter_t)(relay_status + math::nearest_multiple_4(SLOTS));
-  // counters + 4 * w, w < DW: steps whose output dynamics wave w has put into the ring
-  // counters + 4 * (DW + s): sampler s — steps (of ITS trips) whose shaped sample is in the row
-  lds_counter_t cost_prog = counters + 4 * (DW + NS);  // steps the cost waves have consumed
+  // counters + s, s < NS (<= 2): sampler s — steps (of ITS trips) whose shaped sample is in the row
+  // counters + 2: steps the cost waves have consumed          } one 16-byte group: a dynamics wave reads all it waits for
+  // counters + 4 + w, w < DW: steps whose output dynamics wave w has put into the ring   (the cost waves' group)
+  static_assert(NS <= 2, "the sampler counters share a 16-byte group with the cost counter");
+  lds_counter_t cost_prog = counters + 2;
 
   sampling->setThreadMapping(shared_idx, BX);
 
@@ -741,8 +743,8 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
 #pragma unroll
   for (int i = 0; i < O; i++)
     y[i] = 0.0f;
-  if (tid_x < DW + NS + 1)
-    counters[4 * tid_x] = 0;
+  if (tid_x < 4 + DW)
+    counters[tid_x] = 0;
   __syncthreads();
 
   dynamics->initializeDynamics(x, u, y, theta_s_shared, 0.0f, dt);
@@ -759,7 +761,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
     /* ------------------------------------------------ sampler waves ----------------------------------------------- */
     // sampler s takes trips s, s + NS, ...
     constexpr int QUADS = STEPS * C / 4;
-    lds_counter_t smp_prog = counters + 4 * (DW + helper_id);
+    lds_counter_t smp_prog = counters + helper_id;
     PIPE_T(PipeTimer tm; tm.start();)
     for (int t = STEPS * helper_id; t < num_timesteps; t += STEPS * NS)
     {
@@ -784,14 +786,17 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
           sampling->writeControlSample(global_idx, t + s2, 0, u, theta_d_shared, 1, 0, y);
         }
       }
-      pipePublish(smp_prog, min(t + STEPS, num_timesteps), lane);
+      if constexpr (ROWS_HBM)
+        pipePublish(smp_prog, min(t + STEPS, num_timesteps), lane);  // rows in global memory: a real release fence
+      else
+        pipePublishLds(smp_prog, min(t + STEPS, num_timesteps), lane);
     }
     PIPE_T(tm.stop(0); tm.flush(block_idx, wave, lane);)  // slot 0: the whole sampler loop (it never waits)
   }
   else if (is_dyn)
   {
     /* ------------------------------------------------ dynamics waves ---------------------------------------------- */
-    lds_counter_t my_prog = counters + 4 * wave;
+    lds_counter_t my_prog = counters + 4 + wave;
     auto dyn_step = [&](float* xc, float* xn, int t, const float* u_in) {
 #pragma unroll
       for (int i = 0; i < C; i++)
@@ -825,17 +830,30 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
 #pragma unroll
     for (int q = 0; q < NS; q++)
       seen_smp[q] = 0;
+    // the counters this wave waits for (samplers, cost waves) in ONE 16-byte read issued inside the previous pair's
+    // arithmetic: see rolloutPipelineKernel
+    pipe_int4 ahead = { 0, 0, 0, 0 };
+    auto look_ahead = [&]() { ahead = *(lds_counter4_t)counters; };
+    auto need = [&](lds_counter_t ctr, int& cached, const int ahead_value, const int n) {
+      if (cached >= n)
+        return;
+      cached = max(cached, __builtin_amdgcn_readfirstlane(ahead_value));
+      if (cached >= n)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      else
+        pipeWait(ctr, n, cached);
+    };
     // the pair (t, t + 1) lies inside one sampler trip (STEPS is even): wait for the sampler that owns the trip
-    auto wait_samples = [&](const int t, const int need) {
+    auto wait_samples = [&](const int t, const int n) {
       if constexpr (NS == 1)
-        pipeWait(counters + 4 * DW, need, seen_smp[0]);
+        need(counters, seen_smp[0], ahead.x, n);
       else
       {
         const int owner = (t / STEPS) % NS;
         if (owner == 0)
-          pipeWait(counters + 4 * DW, need, seen_smp[0]);
+          need(counters, seen_smp[0], ahead.x, n);
         else
-          pipeWait(counters + 4 * (DW + 1), need, seen_smp[NS - 1]);
+          need(counters + 1, seen_smp[NS - 1], ahead.y, n);
       }
     };
     int t = 0;
@@ -859,7 +877,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
       if constexpr (!ROWS_HBM)
         wait_samples(t, t + 2);
       PIPE_T(tm.stop(1);)  // slot 1: waiting for the sampler
-      pipeWait(cost_prog, t + 2 - ring_steps, seen_cost);
+      need(cost_prog, seen_cost, ahead.z, t + 2 - ring_steps);
       PIPE_T(tm.stop(2);)  // slot 2: waiting for the cost waves (ring back-pressure)
       float ubuf[2 * C];
       if constexpr (ROWS_HBM)
@@ -876,8 +894,9 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
           ubuf[j] = row[t * C + j];
       }
       dyn_step(x, x_next, t, &ubuf[0]);
+      look_ahead();  // lands during the second step; consumed by the next pair's checks
       dyn_step(x_next, x, t + 1, &ubuf[C]);
-      pipePublish(my_prog, t + 2, lane);
+      pipePublishLds(my_prog, t + 2, lane);  // ring (and LDS rows) only: no fence needed, see pipePublishLds
       PIPE_T(tm.stop(0);)  // slot 0: two steps of work
     }
     PIPE_T(tm.flush(block_idx, wave, lane);)
@@ -885,13 +904,13 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
     {
       if constexpr (!ROWS_HBM)
         wait_samples(t, num_timesteps);
-      pipeWait(cost_prog, num_timesteps - ring_steps, seen_cost);
+      need(cost_prog, seen_cost, ahead.z, num_timesteps - ring_steps);
       float ubuf[C];
 #pragma unroll
       for (int j = 0; j < C; j++)
         ubuf[j] = ROWS_HBM ? unext[j] : row[t * C + j];
       dyn_step(x, x_next, t, &ubuf[0]);
-      pipePublish(my_prog, num_timesteps, lane);
+      pipePublishLds(my_prog, num_timesteps, lane);
     }
   }
   else
@@ -926,7 +945,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
       const int hi = min(t + 2, num_timesteps);
 #pragma unroll
       for (int w = 0; w < DW; w++)
-        pipeWait(counters + 4 * w, hi, seen_dyn[w]);
+        pipeWait(counters + 4 + w, hi, seen_dyn[w]);
       PIPE_T(tm.stop(1);)  // slot 1: waiting for the dynamics waves
       float yb[2][O], ub[2][C];
 #pragma unroll
@@ -974,7 +993,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
       status_guess = status_out;
       relay_cost[lane] = running_cost;
       relay_status[lane] = crash_status;
-      pipePublish(cost_prog, hi, lane);
+      pipePublishLds(cost_prog, hi, lane);  // relay slots and ring reads are DS instructions: ordered before this store
       PIPE_T(tm.stop(5);)  // slot 5: the relay itself
     }
     PIPE_T(tm.flush(block_idx, wave, lane);)
