@@ -28,19 +28,23 @@ class PendulumCostParams(C.Structure):
                 ("velocity_coeff", C.c_float), ("terminal_coeff", C.c_float), ("goal_angle", C.c_float)]
 
 
-def build_plugin():
-    newest = os.path.getmtime(SRC)
+SRC_REF_STYLE = os.path.join(REPO, "examples", "my_model", "pendulum_model_reference_style.hip")
+PLUGIN_REF_STYLE = os.path.join(OUT_DIR, "libpendulum_model_reference_style.so")
+
+
+def build_plugin(src=SRC, out=PLUGIN):
+    newest = os.path.getmtime(src)
     for d, _, files in os.walk(os.path.join(REPO, "include")):
         for f in files:
             newest = max(newest, os.path.getmtime(os.path.join(d, f)))
-    if os.path.exists(PLUGIN) and os.path.getmtime(PLUGIN) >= newest:
-        return PLUGIN
+    if os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
     os.makedirs(OUT_DIR, exist_ok=True)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-I" + os.path.join(REPO, "include"), SRC, "-o", PLUGIN]
+           "-I" + os.path.join(REPO, "include"), src, "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    return PLUGIN
+    return out
 
 
 @pytest.fixture(scope="module")
@@ -132,3 +136,57 @@ def test_user_model_swings_up_in_closed_loop(gpu, plugin):
         eng.slideControlSequence(1)
     err = np.arctan2(np.sin(x[0] - np.pi), np.cos(x[0] - np.pi))
     assert abs(err) < 0.4 and abs(x[1]) < 2.0, x
+
+
+# ------------------------------------------------------------------ a model file as a MPPI-Generic user has it ----------------
+@pytest.fixture(scope="module")
+def plugin_reference_style(plugin):
+    assert plugin.mppi_load_plugin(build_plugin(SRC_REF_STYLE, PLUGIN_REF_STYLE).encode()) == 0, plugin.mppi_last_error(None)
+    return plugin
+
+
+def test_reference_style_model_source_is_what_integration_md_says(plugin_reference_style):
+    """INTEGRATION.md §1 as an executable statement: a model written with the reference's include paths, its own step() with
+    __syncthreads(), threadIdx.y-strided loops and the platform's sinf / cosf builds ALONE against include/ — the only edit
+    against a CUDA source is cudaStream_t -> hipStream_t"""
+    src = open(SRC_REF_STYLE).read()
+    code = src[src.index("#include"):]  # below the header comment
+    assert "<mppi/dynamics/dynamics.cuh>" in code and "<mppi/cost_functions/cost.cuh>" in code
+    assert "__syncthreads()" in code and "sinf(" in code and "cosf(" in code and "threadIdx.y" in code and "blockDim.y" in code
+    assert "mppi::det::" not in code and "lane_sync" not in code and "cuda" not in code.replace("cudaStream_t stream = nullptr", "")
+    assert "user_pendulum_reference_style" in plugin_reference_style.mppi_list_models().decode().split("\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 1), (16, 4)], ids=["64x1", "16x4-reference-shape"])
+def test_reference_style_model_meets_the_references_cost_tolerance(gpu, plugin_reference_style, shape):
+    """the unmodified device code against a float64 rollout at the reference's own GPU-vs-CPU bar (1e-4 relative,
+    tests/mppi_core/rollout_kernel_tests.cu:200-261) — on one lane per rollout and on the reference's (x = rollout,
+    y = intra-rollout lane) block shape, where the model's own __syncthreads() separate the phases of a step as upstream —
+    and against the mppi::det:: version of the same model (what changes is the last bits, not the controller)"""
+    K, T, dt = 2048, 60, 0.02
+    x0 = np.array([0.3, 0.0], np.float32)
+    eps = host_noise(1, K, T, 1)
+
+    def run(model, **kw):
+        eng = m.VanillaMPPIController(model, K, T, dt, 1.0, 0.0, 1, seed=SEED, save_samples=True, **kw)
+        p = PendulumParams(1.0, 1.0, 0.1, 9.81)
+        c = PendulumCostParams((C.c_float * 1)(0.0), 1.0, 10.0, 0.1, 0.0, np.pi)
+        eng.setDynamicsParams(p)
+        eng.setCostParams(c)
+        eng.setControlRanges([[-4.0, 4.0]])
+        eng.setSamplingParams([2.0], [0.0])
+        eng.injectNoise(eps)
+        eng.uploadState(x0)
+        eng.optimize(1)
+        out = eng.getSampledCostSeq()[0].copy(), eng.getSampledControls()[0].copy(), eng.getOptimalControlSeq()[0].copy()
+        eng.close()
+        return out + (p, c)
+
+    costs, v, u, p, c = run("user_pendulum_reference_style", block_x=shape[0], block_y=shape[1])
+    want = _numpy_rollout_costs(v, x0, dt, p, c)
+    np.testing.assert_allclose(costs, want, rtol=1e-4)
+    costs_det, v_det, u_det, _, _ = run("user_pendulum")
+    assert np.array_equal(v, v_det)                      # same sampler, same clamp: same samples
+    np.testing.assert_allclose(costs, costs_det, rtol=2e-5)
+    assert np.abs(u - u_det).max() <= 1e-4               # lambda = 1: a few 1e-6 of cost move the weights by as much
