@@ -82,7 +82,8 @@ typedef enum mppi_kernel_variant
   MPPI_KERNEL_FUSED = 1,    /* one wave carries sampling, dynamics and cost of its rollouts (engine/rollout_kernel.hpp) */
   MPPI_KERNEL_PIPELINE = 2  /* sampler / dynamics / cost waves decoupled through LDS (engine/rollout_pipeline_kernel.hpp);
                              * Robust MPPI: engine/rmppi_pipeline_kernel.hpp (rollout and candidate evaluation), for models
-                             * with replicated-lane dynamics and the Gaussian sampler — what AUTO picks there as well */
+                             * registered for it (replicated-lane or one-lane PIPELINE dynamics) with the Gaussian sampler —
+                             * what AUTO picks there as well */
 } mppi_kernel_variant;
 
 /**
@@ -429,11 +430,13 @@ mppi_status mppi_iteration_merge(mppi_handle h);
  * more devices) call mppi_p2p_connect_local(peers[world]) instead — hipIpc does not open a handle of its own process.
  * From then on mppi_optimize / mppi_compute_control use the mailbox; RCCL (mppi_comm_init_rccl) stays the fallback.
  * A merge kernel gives up after 2 s without a peer's record; mppi_get_stats then returns MPPI_ERR_COMM.
- * Reconnecting: a session begins with mppi_p2p_mailbox_handle (or mppi_p2p_connect_local), which clear the flags and records
- * of the previous session — sequence numbers restart at 1 — and mppi_p2p_connect closes the mappings it opened before; every
- * rank of the new session exports / connects before any of them runs its first exchange.
+ * Reconnecting: every rank of the new session calls mppi_p2p_reset (ends the session: flags and records cleared, sequence
+ * numbers restart at 1), then exports / connects again before any of them runs its first exchange; mppi_p2p_connect closes the
+ * mappings it opened before.  mppi_p2p_mailbox_handle itself has NO side effect on a connected session — it may be called
+ * again (a peer that maps late, a caller that simply asks twice) without disturbing records in flight.
  */
 mppi_status mppi_p2p_mailbox_handle(mppi_handle h, void* out_bytes, size_t capacity, size_t* nbytes);
+mppi_status mppi_p2p_reset(mppi_handle h);
 mppi_status mppi_p2p_connect(mppi_handle h, const void* handles, size_t stride_bytes);
 mppi_status mppi_p2p_connect_local(mppi_handle h, const mppi_handle* peers);
 /** native RCCL path: unique id created on rank 0 and shipped by the caller to every rank (ncclGetUniqueId / ncclCommInitRank) */

@@ -67,7 +67,9 @@ inline const std::string& registeredModelName()
   using MODEL = ModelT<DYN_T, COST_T, SAMPLING_T, Shapes<Shape<64, 1, 1>, Shape<64, 1, 2>, Shape<32, 1, 1>, Shape<32, 1, 2>>,
                        /*FIN_BY=*/1, void, Shapes<>, /*PIPELINE=*/true, /*RMPPI=*/!SAMPLING_T::COLORED>;
   static const std::string name = [] {
-    std::string n = std::string("tpl:") + typeid(DYN_T).name() + ":" + typeid(COST_T).name();
+    // the sampler type is part of the instantiation (two controllers that differ only in their Gaussian sampler class must
+    // not share a registration: the parameter layouts differ)
+    std::string n = std::string("tpl:") + typeid(DYN_T).name() + ":" + typeid(COST_T).name() + ":" + typeid(SAMPLING_T).name();
     const mppi_status s = mppi_register_model(n.c_str(), SAMPLING_T::COLORED ? MPPI_SAMPLER_COLORED : MPPI_SAMPLER_GAUSSIAN,
                                               &modelFactory<MODEL, 64, 1>, engineAbiFingerprint());
     if (s != MPPI_OK)
@@ -246,8 +248,11 @@ public:
   control_array getCurrentControl(const state_array& state, double rel_time) const
   {
     const control_trajectory u = getControlSeq();
-    const int lower = (int)(rel_time / params_.dt_);
-    const double a = (rel_time - lower * (double)params_.dt_) / params_.dt_;
+    // a relative time before the sequence or at / beyond its end holds the first / last control (no read outside it)
+    int lower = (int)(rel_time / params_.dt_);
+    lower = lower < 0 ? 0 : (lower > params_.num_timesteps_ - 1 ? params_.num_timesteps_ - 1 : lower);
+    double a = (rel_time - lower * (double)params_.dt_) / params_.dt_;
+    a = a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a);
     control_array out;
     for (int i = 0; i < CONTROL_DIM; i++)
       out[i] = (float)((1.0 - a) * u(i, lower) + a * u(i, lower + 1 < params_.num_timesteps_ ? lower + 1 : lower));
@@ -365,9 +370,11 @@ protected:
     if (!pushed_ || std::memcmp(&sp, &smp_params_, sizeof(sp)) != 0)
     {
       float sd[2 * CONTROL_DIM], cc[CONTROL_DIM];
+      // the sampler's own table may hold ONE distribution (MAX_DISTRIBUTIONS of its parameter type): never read past it
+      constexpr int SD_HELD = (int)(sizeof(sp.std_dev) / sizeof(sp.std_dev[0]));
       for (int i = 0; i < 2 * CONTROL_DIM; i++)
-        sd[i] = sp.std_dev[i];
-      if (sp.num_distributions <= 1)  // one set of standard deviations serves both systems of Tube / Robust MPPI
+        sd[i] = sp.std_dev[i < SD_HELD ? i : i % CONTROL_DIM];
+      if (sp.num_distributions <= 1 || SD_HELD < 2 * CONTROL_DIM)  // one set of standard deviations serves both systems of Tube / Robust MPPI
         for (int i = 0; i < CONTROL_DIM; i++)
           sd[CONTROL_DIM + i] = sd[i];
       for (int i = 0; i < CONTROL_DIM; i++)

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -195,7 +196,7 @@ struct ModelBase
  *  plugin built against other headers: its kernels would read the argument blocks with the wrong layout) */
 /** bumped BY HAND whenever ModelBase's virtual methods are added, removed or reordered or a field of an argument struct is
  *  swapped at equal size — changes sizeof() cannot see (a stale plugin would dispatch to the wrong vtable slot).
- *  3: round 3 (rows-in-HBM / release-flag arguments). */
+ *  3: rows-in-HBM arguments; 4: release-flag arguments of the finalize kernels (both round 3). */
 #define MPPI_ENGINE_ABI_VERSION 4
 
 constexpr int engineAbiFingerprint()
@@ -1082,6 +1083,12 @@ struct ModelT : ModelBase
         return MPPI_ERR_STATE;
       }
       const int H = dyn.lstm_.HIDDEN_DIM;
+      for (int i = 0; i < H; i++)
+        if (!std::isfinite(hidden[i]) || !std::isfinite(cell[i]))
+        {  // det::tanh(NaN) = -1: a NaN recurrent state would be masked, not propagated (see mppi_set_model_blob)
+          err = "non-finite hidden / cell state";
+          return MPPI_ERR_NAN;
+        }
       float* tail = weights_d + dyn.lstm_.LSTM_NUM_PARAMS;
       hipError_t e = hipMemcpyAsync(tail, hidden, H * sizeof(float), hipMemcpyHostToDevice, stream);
       if (e == hipSuccess)

@@ -278,8 +278,8 @@ __global__ void __launch_bounds__(BX * 2 * replicated_lanes<DYN_T>::value)
       u[i] += fb_control[i];
     dynamics->enforceConstraints(xc, u);
     // the feedback-filled, clamped control replaces the sample (rmppi_kernels.cu:780-781)
-    if (rep_lane == 0)
-      sampling->writeControlSample(global_idx, t, distribution_idx, u, theta_d_shared, 1, 0, y);
+    // (all replicas of a rollout write — same word, same value: no replica-divergent region in the step loop)
+    sampling->writeControlSample(global_idx, t, distribution_idx, u, theta_d_shared, 1, 0, y);
     dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
   };
   // what step tt adds to the two accumulators of this lane's system (rmppi_kernels.cu:797-812)

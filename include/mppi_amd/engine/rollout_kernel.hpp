@@ -423,8 +423,9 @@ __global__ void __launch_bounds__(BX* BY* BZ* replicated_lanes<DYN_T>::value)
     lane_sync();
     dynamics->enforceConstraints(xc, u);
     lane_sync();
-    if (rep_lane == 0)
-      sampling->writeControlSample(global_idx, t, distribution_idx, u, theta_d_shared, BY, thread_idy, y);
+    // every replica of a rollout writes (same word, same value): no region that narrows EXEC to one replica in the step loop
+    // (see rolloutPipelineRepKernel)
+    sampling->writeControlSample(global_idx, t, distribution_idx, u, theta_d_shared, BY, thread_idy, y);
     dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
     lane_sync();
     running_cost += costs->computeRunningCost(y, u, t, theta_c_shared, crash_status) +
@@ -493,12 +494,9 @@ __global__ void __launch_bounds__(BX* BY* BZ* replicated_lanes<DYN_T>::value)
       if (!SMP_CONSTRAINS)
       {
         dynamics->enforceConstraints(xc, u);
-        if (rep_lane == 0)
-        {
 #pragma unroll
-          for (int i = 0; i < C; i++)
-            row[tt * C + i] = u[i];
-        }
+        for (int i = 0; i < C; i++)
+          row[tt * C + i] = u[i];  // all replicas: same word, same value
       }
       dynamics->step(xc, xn, xdot, u, y, theta_s_shared, tt, dt);
     };

@@ -801,18 +801,20 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_RE
 #pragma unroll
       for (int i = 0; i < C; i++)
         u[i] = u_in[i];
+      // The REP replicas of a rollout hold identical copies of u and y: ALL of them store (same word, same value) instead
+      // of `if (rep_lane == 0) { ... }`.  A region that narrows EXEC to one replica inside a spilling four-lane kernel gave
+      // wrong covariance outputs in one round-3 build (the register allocator works on the wave-level control
+      // flow and may place spill code of a live-through value inside such a region, where it only covers the active
+      // lanes); with no replica-divergent region in the step loop there is no place for that to happen — and the
+      // s_and_saveexec / s_or pair around the stores is gone as well.
       if (!SMP_CONSTRAINS)
       {
         dynamics->enforceConstraints(xc, u);
-        if (rep_lane == 0)
-        {
 #pragma unroll
-          for (int i = 0; i < C; i++)
-            row[t * C + i] = u[i];
-        }
+        for (int i = 0; i < C; i++)
+          row[t * C + i] = u[i];
       }
       dynamics->step(xc, xn, xdot, u, y, theta_s_shared, t, dt);
-      if (rep_lane == 0)
       {
         float* slot = ring + (size_t)(t & ring_mask) * F * 64 + thread_idx;
 #pragma unroll

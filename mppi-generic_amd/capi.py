@@ -128,6 +128,7 @@ SIGNATURES = {
     "mppi_iteration_local": (C.c_int, [H]),
     "mppi_iteration_merge": (C.c_int, [H]),
     "mppi_p2p_mailbox_handle": (C.c_int, [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mppi_p2p_reset": (C.c_int, [H]),
     "mppi_p2p_connect": (C.c_int, [H, C.c_void_p, C.c_size_t]),
     "mppi_p2p_connect_local": (C.c_int, [H, C.POINTER(C.c_void_p)]),
     "mppi_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

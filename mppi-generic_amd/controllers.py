@@ -523,6 +523,10 @@ class MPPIController:
         self._check(self._lib.mppi_p2p_mailbox_handle(self._h, buf, 64, C.byref(n)))
         return bytes(buf.raw[:n.value])
 
+    def p2pReset(self):
+        """ends this rank's mailbox session (mppi_p2p_reset): every rank calls it before a NEW session exports / connects"""
+        self._check(self._lib.mppi_p2p_reset(self._h))
+
     def p2pConnect(self, handles):
         """handles: list of world byte strings (rank order) from p2pMailboxHandle of every rank"""
         blob = b"".join(h.ljust(64, b"\0") for h in handles)

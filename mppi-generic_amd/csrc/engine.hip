@@ -361,7 +361,13 @@ mppi_status mppi_register_model(const char* name, int sampler_kind, mppi_model_f
                 std::to_string(engineAbiFingerprint()) + "): rebuild the plugin");
   ModelRegistry& r = registry();
   std::lock_guard<std::mutex> lock(r.mu);
-  r.factories[{ name, sampler_kind }] = factory;  // a later registration of the same name replaces the earlier one
+  // the same factory again (a plugin loaded twice, a second controller of the same template instantiation) is fine; ANOTHER
+  // factory under a name that is already taken would silently switch the kernels of handles created later: refused
+  auto it = r.factories.find({ name, sampler_kind });
+  if (it != r.factories.end() && it->second != factory)
+    return fail(nullptr, MPPI_ERR_STATE, std::string("mppi_register_model('") + name + "'): the name is already registered "
+                                         "with a different factory");
+  r.factories[{ name, sampler_kind }] = factory;
   return MPPI_OK;
 }
 
@@ -532,8 +538,8 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   }
   if (cfg->controller == MPPI_CONTROLLER_ROBUST && cfg->kernel_variant == MPPI_KERNEL_PIPELINE && !h->rm_pipeline)
     return fail(nullptr, MPPI_ERR_LAUNCH_SHAPE,
-                "mppi_create: the pipelined Robust MPPI kernel needs a model with replicated-lane (MFMA / four-lane) dynamics, the "
-                "Gaussian sampler and block_x 0 or 64");
+                "mppi_create: the pipelined Robust MPPI kernel needs a model registered for it (replicated-lane MFMA / four-lane "
+                "dynamics, or a one-lane model registered with PIPELINE), the Gaussian sampler and block_x 0 or 64");
   // Tube with a pipeline-capable model and no explicit shape: fold the two systems into the lanes of a wave (32, 1, 2)
   if (h->D == 2 && cfg->controller == MPPI_CONTROLLER_TUBE && cfg->block_x == 0 && cfg->block_y == 0 &&
       cfg->kernel_variant != MPPI_KERNEL_FUSED && h->model->supportsPipelineFold(32, 1, 2) &&
@@ -1058,6 +1064,16 @@ mppi_status mppi_set_model_blob(mppi_handle h, const char* name, const float* da
   CHECK_HANDLE(h);
   if (!name || !data || count == 0)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_model_blob: null or empty");
+  // Network parameters and recurrent states must be finite.  det::tanh / det::sigmoid clamp their argument with min / max,
+  // which return the non-NaN bound: tanh(NaN) = -1 (det_math.h) — a NaN can NOT travel through an activation the way it
+  // does through tanhf().  With finite parameters a network's output is bounded by its last layer's |W| and |b| whatever its
+  // input, so the states it drives stay finite from a finite initial state (mppi_compute_control refuses a non-finite one);
+  // the one way a NaN could enter a network and be masked is a corrupt parameter file, which is refused here.
+  if (strstr(name, "weights") || strstr(name, "lstm_state"))
+    for (size_t i = 0; i < count; i++)
+      if (!std::isfinite(data[i]))
+        return fail(h, MPPI_ERR_NAN, "mppi_set_model_blob: '" + std::string(name) + "' holds a non-finite value at index " +
+                                         std::to_string(i));
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   std::string err;
@@ -1115,6 +1131,7 @@ mppi_status mppi_set_lstm_initial_state(mppi_handle h, const float* hidden, cons
   CHECK_HANDLE(h);
   if (!hidden || !cell)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_lstm_initial_state: null");
+
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   std::string err;
   mppi_status st = h->model->setLSTMInitialState(hidden, cell, h->stream, err);
@@ -3009,7 +3026,10 @@ mppi_status mppi_p2p_mailbox_handle(mppi_handle h, void* out_bytes, size_t capac
   if (!out_bytes || capacity < sizeof(hipIpcMemHandle_t))
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_p2p_mailbox_handle: buffer too small (needs 64 bytes)");
   MPPI_TRY(ensureMailbox(h));
-  MPPI_TRY(resetMailboxSession(h));
+  // Exporting the handle has no side effect on a LIVE session (a caller that asks twice, a peer that maps late): the mailbox
+  // is only cleared when no session is connected — a new one starts with mppi_p2p_reset (or on a handle that never ran)
+  if (!h->p2p_ready)
+    MPPI_TRY(resetMailboxSession(h));
   hipIpcMemHandle_t ipc;
   hipError_t e = hipIpcGetMemHandle(&ipc, h->mbox_d);
   if (e != hipSuccess && h->mbox_uncached)
@@ -3030,6 +3050,14 @@ mppi_status mppi_p2p_mailbox_handle(mppi_handle h, void* out_bytes, size_t capac
   if (nbytes)
     *nbytes = sizeof(ipc);
   return MPPI_OK;
+}
+
+mppi_status mppi_p2p_reset(mppi_handle h)
+{
+  CHECK_HANDLE(h);
+  h->p2p_ready = false;
+  h->exchange_failed = false;
+  return resetMailboxSession(h);
 }
 
 mppi_status mppi_p2p_connect(mppi_handle h, const void* handles, size_t stride_bytes)
