@@ -104,6 +104,7 @@ struct mppi_handle_s
   /* ColoredMPPI options (controllers/ColoredMPPI/colored_mppi_controller.cuh:18-22, 159-193): Tsallis weights and state leash */
   float tsallis_gamma = 0.0f, tsallis_r = 0.0f;
   float* tsallis_weights_d = nullptr;  // [K_local]
+  float* tsallis_record_d = nullptr;   // [PS] K-sharded Tsallis: {sum w v | rho, sum w, sum w^2, 0} of this rank
   /* reference-order reduction (mppi_set_reduction_mode, exact_reduce_kernels.hpp) */
   int reduction_mode = MPPI_REDUCTION_FUSED;
   int sum_strides = 32;                // GaussianParams::sum_strides (sampling_distributions/gaussian/gaussian.cuh:30)
@@ -200,7 +201,6 @@ struct mppi_handle_s
   float* peer_mbox[16] = { nullptr };
   bool peer_opened[16] = { false };  // hipIpcOpenMemHandle'd (to be closed)
   bool p2p_ready = false;
-  bool p2p_auto = false;         // set around library-driven iterations (mppi_iteration_local keeps the caller-driven exchange)
   bool exchange_failed = false;  // a merge kernel gave up waiting for a peer (stats[6] mark), sticky until mppi_p2p_connect
   unsigned xseq = 0;  // exchange sequence number: flags carry it, its parity selects the mailbox half
 };
@@ -436,7 +436,7 @@ static void freeAll(mppi_handle h)
   h->step_u_d = nullptr;  // slice of the step_x_d block
   float** bufs[] = { &h->in_block_d, &h->out_block_d, &h->costs_d,   &h->partials_d,  &h->send_d,     &h->recv_d,
                      &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->gather_tmp_d, &h->rows_d, &h->fin_scratch_d,
-                     &h->tsallis_weights_d, &h->rocrand_eps_d, &h->std_dev_time_d, &h->exact_weights_d, &h->exact_inter_d };
+                     &h->tsallis_weights_d, &h->tsallis_record_d, &h->rocrand_eps_d, &h->std_dev_time_d, &h->exact_weights_d, &h->exact_inter_d };
   for (float** b : bufs)
   {
     if (*b)
@@ -987,15 +987,14 @@ mppi_status mppi_set_colored_mppi_params(mppi_handle h, float gamma, float r_exp
   {
     if (r_exp == 1.0f || !(gamma > 0.0f))
       return fail(h, MPPI_ERR_INVALID_ARG, "mppi_set_colored_mppi_params: Tsallis weights need gamma > 0 and r != 1");
-    if (exchangeActive(h))
-      return fail(h, MPPI_ERR_UNSUPPORTED, "Tsallis weights need the global baseline before any weight: not available on a "
-                                           "K-sharded handle");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (!h->samples_d)  // the weighted mean is formed from the samples in HBM (control_samples_d_ of the reference)
       HIP_TRY(h, hipMalloc((void**)&h->samples_d, sizeof(float) * (size_t)h->D * h->K_local * h->TC));
     if (!h->tsallis_weights_d)
       HIP_TRY(h, hipMalloc((void**)&h->tsallis_weights_d, sizeof(float) * (size_t)h->K_local));
+    if (exchangeActive(h) && !h->tsallis_record_d)  // K-sharded: this rank's record of the second exchange (iterationShardedTsallis)
+      HIP_TRY(h, hipMalloc((void**)&h->tsallis_record_d, sizeof(float) * (size_t)h->D * h->PS));
   }
   h->tsallis_gamma = gamma;
   h->tsallis_r = r_exp;
@@ -1428,11 +1427,10 @@ struct RoctxRange
 }  // namespace
 
 /* ---------------------------------------------------------------- internals -------------------------------------- */
-static mppi_status launchCombine(mppi_handle h, const float* records, int num_records, int finalize, float* record_out,
-                                 int k_total, bool world_major = false, const unsigned* wait_flags = nullptr,
-                                 unsigned wait_seq = 0, const kernels::PostTargets* post = nullptr)
+static kernels::CombineArgs combineArgs(mppi_handle h, const float* records, int num_records, int finalize, float* record_out,
+                                        int k_total, bool world_major = false, const unsigned* wait_flags = nullptr,
+                                        unsigned wait_seq = 0, const kernels::PostTargets* post = nullptr)
 {
-  RoctxRange range(finalize ? "mppi:merge" : "mppi:merge_local");
   kernels::CombineArgs a{};
   if (post)
     a.post = *post;
@@ -1452,6 +1450,16 @@ static mppi_status launchCombine(mppi_handle h, const float* records, int num_re
   a.wait_flags_d = wait_flags;
   a.wait_seq = wait_seq;
   a.wait_limit_ticks = 200000000ull;  // 2 s of the 100 MHz wall clock
+  return a;
+}
+
+static mppi_status launchCombine(mppi_handle h, const float* records, int num_records, int finalize, float* record_out,
+                                 int k_total, bool world_major = false, const unsigned* wait_flags = nullptr,
+                                 unsigned wait_seq = 0, const kernels::PostTargets* post = nullptr)
+{
+  RoctxRange range(finalize ? "mppi:merge" : "mppi:merge_local");
+  const kernels::CombineArgs a =
+      combineArgs(h, records, num_records, finalize, record_out, k_total, world_major, wait_flags, wait_seq, post);
   hipLaunchKernelGGL(kernels::combineKernel, dim3(h->D, kernels::combineGridY(h->TC)), dim3(kernels::MERGE_THREADS), 0,
                      h->stream, a);
   HIP_TRY(h, hipGetLastError());
@@ -1581,6 +1589,10 @@ static mppi_status iterationLocal(mppi_handle h, int iteration, int stride)
   MPPI_TRY(launchRollout(h, iteration, stride));
   if (h->reduction_mode != MPPI_REDUCTION_FUSED)
     return launchExactReduction(h);
+  if (tsallisActive(h) && exchangeActive(h))
+    return fail(h, MPPI_ERR_UNSUPPORTED, "Tsallis weights need two exchanges per iteration: on a K-sharded handle use "
+                                         "mppi_optimize / mppi_compute_control over the P2P mailbox or RCCL, not the caller-driven "
+                                         "mppi_iteration_local / mppi_iteration_merge pair");
   if (tsallisActive(h))
   {  // global baseline -> Tsallis weights -> weighted mean of the dumped samples (reduce_kernels.hpp)
     hipLaunchKernelGGL(kernels::tsallisWeightsKernel, dim3(1), dim3(kernels::COMBINE_THREADS), 0, h->stream, h->K_local,
@@ -1593,11 +1605,6 @@ static mppi_status iterationLocal(mppi_handle h, int iteration, int stride)
   }
   if (!exchangeActive(h))
     return launchCombine(h, h->partials_d, h->num_blocks, 1, nullptr, h->cfg.num_rollouts);
-  if (h->p2p_ready && h->p2p_auto)
-  {  // the local merge delivers its record to the peers itself
-    const kernels::PostTargets t = p2pTargets(h, ++h->xseq);
-    return launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local, false, nullptr, 0, &t);
-  }
   return launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local);
 }
 
@@ -1609,35 +1616,120 @@ static mppi_status iterationMerge(mppi_handle h)
   return launchCombine(h, h->recv_d, h->cfg.world_size, 1, nullptr, h->cfg.num_rollouts, true);
 }
 
-/** P2P exchange: the local merge has posted this rank's record (iterationLocal); the global merge waits for the peers' flags */
-static mppi_status iterationMergeP2P(mppi_handle h)
+/** this rank's mailbox half of exchange `seq`: the world's records and the flags the peers raise */
+static inline void p2pInbox(mppi_handle h, unsigned seq, const float** records, const unsigned** flags)
 {
   const int world = h->cfg.world_size;
   const size_t dps = (size_t)h->D * h->PS;
-  const unsigned seq = h->xseq;
   const unsigned parity = seq & 1u;
-  const float* records = h->mbox_d + (size_t)parity * world * dps;
-  const unsigned* flags = reinterpret_cast<const unsigned*>(h->mbox_d + (size_t)2 * world * dps) + parity * world;
-  return launchCombine(h, records, world, 1, nullptr, h->cfg.num_rollouts, true, flags, seq);
+  *records = h->mbox_d + (size_t)parity * world * dps;
+  *flags = reinterpret_cast<const unsigned*>(h->mbox_d + (size_t)2 * world * dps) + parity * world;
+}
+
+/** P2P exchange: the local merge has posted this rank's record (iterationLocal); the global merge waits for the peers' flags */
+static mppi_status iterationMergeP2P(mppi_handle h)
+{
+  const float* records;
+  const unsigned* flags;
+  p2pInbox(h, h->xseq, &records, &flags);
+  return launchCombine(h, records, h->cfg.world_size, 1, nullptr, h->cfg.num_rollouts, true, flags, h->xseq);
+}
+
+/** rollout kernel done: local merge + post + wait + global merge in ONE launch (combineShardedKernel) */
+static mppi_status launchCombineSharded(mppi_handle h)
+{
+  RoctxRange range("mppi:merge_sharded");
+  const unsigned seq = ++h->xseq;
+  const kernels::PostTargets t = p2pTargets(h, seq);
+  const float* records;
+  const unsigned* flags;
+  p2pInbox(h, seq, &records, &flags);
+  const kernels::CombineArgs loc = combineArgs(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local, false, nullptr, 0, &t);
+  const kernels::CombineArgs glob = combineArgs(h, records, h->cfg.world_size, 1, nullptr, h->cfg.num_rollouts, true, flags, seq);
+  hipLaunchKernelGGL(kernels::combineShardedKernel, dim3(h->D, kernels::combineGridY(h->TC)), dim3(kernels::MERGE_THREADS), 0,
+                     h->stream, loc, glob);
+  HIP_TRY(h, hipGetLastError());
+  return MPPI_OK;
+}
+
+static mppi_status exchangeAllGather(mppi_handle h)
+{
+  if (!h->comm || !g_ncclAllGather)
+    return fail(h, MPPI_ERR_STATE,
+                "world_size > 1: call mppi_p2p_connect / mppi_comm_init_rccl first, or drive the exchange yourself with "
+                "mppi_iteration_local / mppi_get_exchange_buffers / mppi_iteration_merge");
+  const int rc = g_ncclAllGather(h->send_d, h->recv_d, (size_t)h->D * h->PS, /*ncclFloat32*/ 7, h->comm, h->stream);
+  if (rc != 0)
+    return fail(h, MPPI_ERR_COMM, "ncclAllGather failed with code " + std::to_string(rc));
+  return MPPI_OK;
+}
+
+/**
+ * ColoredMPPI's Tsallis weights on a K-sharded handle (reference: core/mppi_common.cu:968-985 on all K rollouts).  The weights
+ * are not shift-invariant, so the GLOBAL baseline has to exist before any of them: two exchanges per iteration —
+ *   1. the ranks' minima (the local merge's record; only its tail is used),
+ *   2. {sum w v | rho, sum w, sum w^2} of every rank under that common baseline; the merge then rescales by exp(0) = 1.
+ * Over the P2P mailbox (two sequence numbers per iteration) or RCCL; the caller-driven exchange has one hop per iteration and
+ * does not offer it.
+ */
+static mppi_status iterationShardedTsallis(mppi_handle h, int iteration, int stride)
+{
+  const int world = h->cfg.world_size;
+  MPPI_TRY(launchRollout(h, iteration, stride));
+  const float* peer_records = nullptr;
+  const unsigned* flags = nullptr;
+  unsigned seq1 = 0;
+  if (h->p2p_ready)
+  {
+    seq1 = ++h->xseq;
+    const kernels::PostTargets t = p2pTargets(h, seq1);
+    MPPI_TRY(launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local, false, nullptr, 0, &t));
+    p2pInbox(h, seq1, &peer_records, &flags);
+  }
+  else
+  {
+    MPPI_TRY(launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local));
+    MPPI_TRY(exchangeAllGather(h));
+    peer_records = h->recv_d;
+  }
+  float* rec = h->tsallis_record_d;
+  hipLaunchKernelGGL(kernels::tsallisWeightsKernel, dim3(1), dim3(kernels::COMBINE_THREADS), 0, h->stream, h->K_local,
+                     h->costs_d, h->tsallis_gamma, h->tsallis_r, h->cfg.lambda, h->tsallis_weights_d, h->stats_d, peer_records,
+                     world, h->D * h->PS, h->TC, flags, seq1, 200000000ull, rec + h->TC);
+  hipLaunchKernelGGL(kernels::tsallisMeanKernel, dim3((h->TC + kernels::COMBINE_COLS - 1) / kernels::COMBINE_COLS),
+                     dim3(kernels::COMBINE_THREADS), 0, h->stream, h->tsallis_weights_d, h->samples_d, h->stats_d, h->TC,
+                     h->K_local, rec, 0);
+  HIP_TRY(h, hipGetLastError());
+  if (h->p2p_ready)
+  {
+    const unsigned seq2 = ++h->xseq;
+    const kernels::PostTargets t = p2pTargets(h, seq2);
+    MPPI_TRY(launchCombine(h, rec, 1, 0, h->send_d, h->K_local, false, nullptr, 0, &t));
+    return iterationMergeP2P(h);
+  }
+  MPPI_TRY(launchCombine(h, rec, 1, 0, h->send_d, h->K_local));
+  MPPI_TRY(exchangeAllGather(h));
+  return iterationMerge(h);
 }
 
 static mppi_status iteration(mppi_handle h, int it, int stride)
 {
-  h->p2p_auto = true;  // iterations driven by the library use the mailbox when it is connected
-  const mppi_status st_local = iterationLocal(h, it, stride);
-  h->p2p_auto = false;
-  MPPI_TRY(st_local);
+  if (exchangeActive(h) && tsallisActive(h))
+  {
+    if (!h->p2p_ready && !h->comm)
+      return fail(h, MPPI_ERR_STATE, "Tsallis weights on a K-sharded handle need the P2P mailbox or the RCCL communicator "
+                                     "(two exchanges per iteration): mppi_p2p_connect / mppi_comm_init_rccl");
+    return iterationShardedTsallis(h, it, stride);
+  }
+  if (exchangeActive(h) && h->p2p_ready)
+  {  // two launches, as un-sharded: rollout, then merge + post + wait + merge in one kernel
+    MPPI_TRY(launchRollout(h, it, stride));
+    return launchCombineSharded(h);
+  }
+  MPPI_TRY(iterationLocal(h, it, stride));
   if (exchangeActive(h))
   {
-    if (h->p2p_ready)
-      return iterationMergeP2P(h);
-    if (!h->comm || !g_ncclAllGather)
-      return fail(h, MPPI_ERR_STATE,
-                  "world_size > 1: call mppi_p2p_connect / mppi_comm_init_rccl first, or drive the exchange yourself with "
-                  "mppi_iteration_local / mppi_get_exchange_buffers / mppi_iteration_merge");
-    const int rc = g_ncclAllGather(h->send_d, h->recv_d, (size_t)h->D * h->PS, /*ncclFloat32*/ 7, h->comm, h->stream);
-    if (rc != 0)
-      return fail(h, MPPI_ERR_COMM, "ncclAllGather failed with code " + std::to_string(rc));
+    MPPI_TRY(exchangeAllGather(h));
     MPPI_TRY(iterationMerge(h));
   }
   return MPPI_OK;

@@ -434,6 +434,63 @@ __global__ void __launch_bounds__(MERGE_THREADS) combineKernel(const CombineArgs
   }
 }
 
+/**
+ * The merge of a K-SHARDED iteration in ONE launch (P2P mailbox exchange): every wave
+ *   1. merges this rank's block records for its columns (combineWave, finalize = 0) and writes the result into slot [rank] of
+ *      EVERY peer's mailbox (system-scope stores over xGMI; this rank's own mailbox included),
+ *   2. takes a ticket; the wave that takes the last one raises this exchange's flag at every peer,
+ *   3. waits (bounded) until every peer's flag shows this exchange, and
+ *   4. merges the world's records from its own mailbox into u* (combineWave, finalize = 1).
+ * A sharded iteration is then the two launches of an un-sharded one — rollout, merge — plus one hop.  Round 3 ran steps 1-2
+ * and 3-4 as two launches (5.6 us apart on a ~32 us iteration).  No wave waits for another wave of this launch (the ticket is
+ * taken, not awaited; what is awaited comes from other GPUs), so the grid needs no co-residency guarantee.
+ */
+__global__ void __launch_bounds__(MERGE_THREADS) combineShardedKernel(const CombineArgs loc, const CombineArgs glob)
+{
+  const int z = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_global = __builtin_amdgcn_readfirstlane((int)blockIdx.y * MERGE_WAVES + (tid >> 6));
+  combineWave<false>(loc, z, wave_global, lane);
+  if (MERGE_WAVES > 1)
+    __syncthreads();
+  if (tid == 0)
+  {
+    __threadfence_system();  // this block's slice of the record is visible to every peer before its ticket counts
+    const unsigned nblocks = gridDim.x * gridDim.y;
+    const unsigned t = __hip_atomic_fetch_add(loc.post.ticket_d, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == nblocks - 1)
+    {
+      __hip_atomic_store(loc.post.ticket_d, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      for (int p = 0; p < loc.post.world; p++)
+        __hip_atomic_store(loc.post.peer_flag[p], loc.post.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  // one lane per peer spins on that peer's flag (bounded: a peer that never posts must not wedge the GPU)
+  bool failed = false;
+  if (lane < glob.num_records)
+  {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(glob.wait_flags_d + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != glob.wait_seq)
+    {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > glob.wait_limit_ticks)
+      {
+        failed = true;
+        break;
+      }
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(failed) != 0ull)
+  {  // leave a mark the host checks (mppi_synchronize / result getters) and no result: the mean is left untouched
+    if (tid == 0 && blockIdx.y == 0 && glob.stats_out_d)
+      glob.stats_out_d[(size_t)z * STATS_STRIDE + 6] = 1.0f;
+    return;
+  }
+  combineWave<true>(glob, z, wave_global, lane);
+}
+
 /** every store of the kernels in front of it on the stream is out: publish `seq` where the host spins (device-mapped host
  *  memory, system scope) — the hand-over of a small kernel whose signature has no flag argument (model step) */
 __global__ void __launch_bounds__(64) raiseFlagKernel(unsigned* flag, unsigned seq)
@@ -510,16 +567,60 @@ __global__ void __launch_bounds__(COMBINE_THREADS)
  * this path takes the GLOBAL baseline first (one block over the K costs), writes the weights, the normaliser (double) and the
  * free-energy statistics, and tsallisMeanKernel then forms the weighted mean from the samples the rollout kernel dumped to HBM.
  */
+/**
+ * K-sharded handles: the baseline must be the GLOBAL one before any weight exists (the weights are not shift-invariant), so
+ * the ranks exchange their minima first — `peer_records_d` are the world's merged records of that first exchange ([world][PS]
+ * rows of system 0, tail[0] = the rank's own minimum; nullptr: un-sharded) — and `record_tail_out_d` receives {rho, eta_local,
+ * sum w^2 local, 0}: the tail of the record of the SECOND exchange, whose merge then needs no rescaling (all rho equal).
+ */
 __global__ void __launch_bounds__(COMBINE_THREADS)
     tsallisWeightsKernel(int num_rollouts, const float* __restrict__ costs_d, float gamma, float r, float lambda,
-                         float* __restrict__ weights_d, float* __restrict__ stats_out_d)
+                         float* __restrict__ weights_d, float* __restrict__ stats_out_d,
+                         const float* __restrict__ peer_records_d = nullptr, int world = 0, int peer_stride = 0, int TC = 0,
+                         const unsigned* __restrict__ wait_flags_d = nullptr, unsigned wait_seq = 0,
+                         unsigned long long wait_limit_ticks = 0, float* __restrict__ record_tail_out_d = nullptr)
 {
   __shared__ double red_d[COMBINE_THREADS / 64];
   __shared__ float red_f[COMBINE_THREADS / 64];
+  __shared__ int wait_failed_s;
   const int tid = threadIdx.x;
   float m = INFINITY;
-  for (int i = tid; i < num_rollouts; i += COMBINE_THREADS)
-    m = fminf(m, costs_d[i]);
+  if (peer_records_d)
+  {
+    if (wait_flags_d)
+    {  // P2P mailbox: the peers' records of the first exchange must have arrived (bounded wait, as in combineKernel)
+      if (tid == 0)
+        wait_failed_s = 0;
+      __syncthreads();
+      if (tid < world)
+      {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(wait_flags_d + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != wait_seq)
+        {
+          __builtin_amdgcn_s_sleep(2);
+          if (wall_clock64() - t0 > wait_limit_ticks)
+          {
+            wait_failed_s = 1;
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      if (wait_failed_s)
+      {
+        if (tid == 0)
+          stats_out_d[6] = 1.0f;
+        return;
+      }
+    }
+    for (int p = tid; p < world; p += COMBINE_THREADS)
+      m = fminf(m, loadPeerWritten(peer_records_d + (size_t)p * peer_stride + TC));
+  }
+  else
+  {
+    for (int i = tid; i < num_rollouts; i += COMBINE_THREADS)
+      m = fminf(m, costs_d[i]);
+  }
   m = blockMin(m, red_f);
   double s = 0.0, s2 = 0.0;
   const float inv = 1.0f / (r - 1.0f);
@@ -535,6 +636,13 @@ __global__ void __launch_bounds__(COMBINE_THREADS)
   }
   s = blockSum(s, red_d);
   s2 = blockSum(s2, red_d);
+  if (tid == 0 && record_tail_out_d)
+  {
+    record_tail_out_d[0] = m;
+    record_tail_out_d[1] = (float)s;
+    record_tail_out_d[2] = (float)s2;
+    record_tail_out_d[3] = 0.0f;
+  }
   if (tid == 0)
   {
     // the statistics of combineKernel (mppi_common.cu:1065-1081 computeFreeEnergy) on these weights
@@ -556,7 +664,7 @@ __global__ void __launch_bounds__(COMBINE_THREADS)
  *  w, w + 16, ... in ascending order and the sixteen partials are added in a fixed order (reproducible run to run) */
 __global__ void __launch_bounds__(COMBINE_THREADS)
     tsallisMeanKernel(const float* __restrict__ weights_d, const float* __restrict__ v_d, const float* __restrict__ stats_d,
-                      int TC, int num_rollouts, float* __restrict__ mean_out_d)
+                      int TC, int num_rollouts, float* __restrict__ mean_out_d, int normalize = 1)
 {
   __shared__ float part_s[COMBINE_THREADS / 64][COMBINE_COLS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -574,7 +682,7 @@ __global__ void __launch_bounds__(COMBINE_THREADS)
 #pragma unroll
     for (int w = 1; w < NW; w++)
       tot += part_s[w][lane];
-    mean_out_d[j] = tot / stats_d[1];
+    mean_out_d[j] = normalize ? tot / stats_d[1] : tot;  // !normalize: this rank's part of a K-sharded sum (a record's columns)
   }
 }
 

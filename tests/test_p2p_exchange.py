@@ -59,6 +59,72 @@ def test_p2p_local_matches_unsharded(gpu, world):
     assert np.abs(u0 - u_orc).max() <= 1e-5
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_tsallis_weights_on_sharded_handles(gpu, world):
+    """ColoredMPPI's Tsallis weights (core/mppi_common.cu:968-985) need the GLOBAL baseline before any weight: on K-sharded
+    handles the ranks exchange their minima first, then {sum w v | rho, sum w, sum w^2} under the common baseline (two mailbox
+    exchanges per iteration, engine.hip: iterationShardedTsallis) — against the un-sharded engine on the same noise and
+    against the oracle's un-sharded iteration"""
+    from common import host_spectrum
+    from test_colored_noise import _colored_cartpole
+    import gc
+    cfg = _colored_cartpole(K=2048, T=60)
+    K, T = cfg["K"], cfg["T"]
+    exps, decay, fmin = cfg["colored"]
+    kw = dict(gamma=400.0, r_exp=1.7)
+    z = host_spectrum(2, K, T, 1, seed=40)
+    full = make_engine(cfg)
+    full.setColoredMPPIParams(**kw)
+    full.injectNoise(z)
+    full.uploadState(cfg["x0"])
+    full.optimize(2)
+    u_full = full.getOptimalControlSeq()[0].copy()
+    st_full = full.getStats().real_sys
+    rho_full, eta_full = st_full.baseline, st_full.normalizer
+    full.close()
+    gc.collect()
+    ranks = [make_engine(cfg, rank=r, world_size=world) for r in range(world)]
+    m.MPPIController.p2pConnectLocal(ranks)
+    kl = K // world
+    for r, c in enumerate(ranks):
+        c.setColoredMPPIParams(**kw)
+        c.injectNoise(np.ascontiguousarray(z[:, r * kl:(r + 1) * kl]))
+        c.uploadState(cfg["x0"])
+    for c in ranks:
+        c.optimize(2, synchronize=False)
+    for c in ranks:
+        c.synchronize()
+    us = [c.getOptimalControlSeq()[0] for c in ranks]
+    sts = [c.getStats().real_sys for c in ranks]
+    for c in ranks:
+        c.close()
+    for u, st in zip(us, sts):
+        assert np.isfinite(u).all()
+        assert np.array_equal(u, us[0])  # every rank merges the same records in the same order
+        assert np.abs(u - u_full).max() <= 5e-6, np.abs(u - u_full).max()
+        assert st.baseline == rho_full
+        assert abs(st.normalizer - eta_full) <= 1e-6 * eta_full
+    # the oracle's un-sharded first iteration (time-domain noise from its own colored-noise pipeline)
+    orc = make_oracle(cfg)
+    orc.set_colored_mppi_params(kw["gamma"], kw["r_exp"], None, False, 1)
+    eps = po.colored_noise(z[0], exps, decay, fmin)
+    u_orc = orc.iterate(cfg["x0"], np.zeros((T, 1), np.float32), eps)[0]
+    ranks = [make_engine(cfg, rank=r, world_size=world) for r in range(world)]
+    m.MPPIController.p2pConnectLocal(ranks)
+    for r, c in enumerate(ranks):
+        c.setColoredMPPIParams(**kw)
+        c.injectNoise(np.ascontiguousarray(z[:1, r * kl:(r + 1) * kl]))
+        c.uploadState(cfg["x0"])
+    for c in ranks:
+        c.optimize(1, synchronize=False)
+    for c in ranks:
+        c.synchronize()
+    u1 = ranks[0].getOptimalControlSeq()[0]
+    for c in ranks:
+        c.close()
+    assert np.abs(u1 - u_orc).max() <= 1e-5, np.abs(u1 - u_orc).max()
+
+
 def test_p2p_local_two_systems(gpu):
     """Tube-MPPI (two systems per record): the gathered records are [world][D][PS], merged with world-major strides"""
     cfg = di_cfg(K=2048, T=60, tube=True)
