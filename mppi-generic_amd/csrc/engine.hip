@@ -203,6 +203,8 @@ struct mppi_handle_s
   bool p2p_ready = false;
   bool exchange_failed = false;  // a merge kernel gave up waiting for a peer (stats[6] mark), sticky until mppi_p2p_connect
   unsigned xseq = 0;  // exchange sequence number: flags carry it, its parity selects the mailbox half
+  size_t mbox_aux_off = 0;  // aux channel of the mailbox (Robust MPPI candidate costs), in 4-byte words from mbox_d
+  unsigned aseq = 0;        // its own sequence number
 };
 
 namespace
@@ -2306,8 +2308,8 @@ static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, in
     h->nominal_stride = 0;
     return MPPI_OK;
   }
-  if (h->cfg.world_size > 1 && h->noise_source == MPPI_NOISE_INJECTED)
-    return fail(h, MPPI_ERR_UNSUPPORTED, "Robust MPPI init-eval with injected noise needs world_size == 1");
+  // (injected noise on a K-sharded handle: the slab this call consumes must hold the GLOBAL rollouts' rows 0 .. ns-1 on
+  //  every rank — the evaluation samples are the same rows for every candidate and every rank, robust_mppi_controller.cu:596)
   if (ns > h->K_local && h->noise_source == MPPI_NOISE_INJECTED)
     return fail(h, MPPI_ERR_INVALID_ARG, "samples_per_candidate exceeds the injected noise rows");
   // candidates = [nominal_x_k, nominal_x_k+1, real_x_k+1] * line search weights (:350-362)
@@ -2345,16 +2347,33 @@ static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, in
     HIP_TRY(h, hipMemcpyAsync(h->mean_d, h->nominal_control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice,
                               h->stream));
   }
+  /* K-sharded handles connected over the P2P mailbox evaluate the candidates SHARDED BY CANDIDATE ("RMPPI
+   * init-eval shards over candidates x samples the same way"): rank r takes candidates [r * ceil(nc / world), ...), writes
+   * their costs at their position of the array in every peer's aux mailbox (postAuxKernel) and every rank assembles all
+   * nc x ns costs from its own (gatherAuxKernel) — same kernel, same bits as the replicated evaluation, 1 / world of the work.
+   * Other exchanges (RCCL, caller-driven) keep evaluating all candidates on every rank: the costs are needed on the HOST of
+   * every rank, and a block's T-step chain takes as long for one candidate as for nine. */
+  const int world = h->cfg.world_size;
+  const bool shard_eval = world > 1 && h->p2p_ready && nc * ns <= kernels::MAILBOX_AUX_FLOATS;
+  int c_lo = 0, c_hi = nc;
+  if (shard_eval)
+  {
+    const int chunk = (nc + world - 1) / world;
+    c_lo = std::min(nc, h->cfg.rank * chunk);
+    c_hi = std::min(nc, c_lo + chunk);
+  }
   kernels::InitEvalArgs a{};
   a.dt = h->cfg.dt;
   a.num_timesteps = h->cfg.num_timesteps;
-  a.num_eval_rollouts = nc * ns;
+  a.num_eval_rollouts = (c_hi - c_lo) * ns;
   a.samples_per_candidate = ns;
   a.lambda = h->cfg.lambda;
   a.alpha = h->cfg.alpha;
-  a.strides_d = h->low_latency ? reinterpret_cast<const int*>(h->cand_io_dev + (size_t)nc * S) : h->cand_strides_d;
-  a.states_d = h->low_latency ? h->cand_io_dev : h->cand_states_d;
-  a.trajectory_costs_d = cand_costs_dev;
+  a.strides_d = (h->low_latency ? reinterpret_cast<const int*>(h->cand_io_dev + (size_t)nc * S) : h->cand_strides_d) + c_lo;
+  a.states_d = (h->low_latency ? h->cand_io_dev : h->cand_states_d) + (size_t)c_lo * S;
+  // sharded: the slice goes to the device buffer (posted from there), the assembled array to where the host reads it
+  float* slice_dev = (shard_eval ? h->cand_costs_d : cand_costs_dev) + (size_t)c_lo * ns;
+  a.trajectory_costs_d = slice_dev;
   SamplerLaunchState s{};
   s.num_rollouts_local = h->K_local;
   s.num_rollouts_global = h->cfg.num_rollouts;
@@ -2379,10 +2398,34 @@ static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, in
   s.optimization_stride = stride;
   s.independent_noise = h->independent_noise ? 1 : 0;
   std::string err;
-  mppi_status st = h->model->launchInitEval(h->rm_pipeline, a, s, h->stream, err);
-  if (st != MPPI_OK)
-    return fail(h, st, err);
+  if (c_hi > c_lo)
+  {
+    mppi_status st = h->model->launchInitEval(h->rm_pipeline, a, s, h->stream, err);
+    if (st != MPPI_OK)
+      return fail(h, st, err);
+  }
   h->generation++;
+  if (shard_eval)
+  {
+    const unsigned seq = ++h->aseq;
+    const unsigned parity = seq & 1u;
+    kernels::AuxTargets t{};
+    t.world = world;
+    t.seq = seq;
+    for (int p = 0; p < world; p++)
+    {
+      float* aux = h->peer_mbox[p] + h->mbox_aux_off;
+      t.peer_aux[p] = aux + (size_t)parity * kernels::MAILBOX_AUX_FLOATS;
+      t.peer_flag[p] = reinterpret_cast<unsigned*>(aux + 2 * (size_t)kernels::MAILBOX_AUX_FLOATS) + parity * world + h->cfg.rank;
+    }
+    hipLaunchKernelGGL(kernels::postAuxKernel, dim3(1), dim3(256), 0, h->stream, slice_dev, c_lo * ns, (c_hi - c_lo) * ns, t);
+    const float* my_aux = h->mbox_d + h->mbox_aux_off;
+    hipLaunchKernelGGL(kernels::gatherAuxKernel, dim3(1), dim3(256), 0, h->stream,
+                       my_aux + (size_t)parity * kernels::MAILBOX_AUX_FLOATS,
+                       reinterpret_cast<const unsigned*>(my_aux + 2 * (size_t)kernels::MAILBOX_AUX_FLOATS) + parity * world, world,
+                       seq, 200000000ull, nc * ns, cand_costs_dev);
+    HIP_TRY(h, hipGetLastError());
+  }
   h->rm_cand_costs.resize((size_t)nc * ns);
   if (h->low_latency)
   {
@@ -2399,6 +2442,10 @@ static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, in
                               h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
+  if (shard_eval)
+    for (float c : h->rm_cand_costs)
+      if (c != c)  // gatherAuxKernel's mark: a peer never delivered its slice (a trajectory cost itself is clamped, never NaN)
+        return fail(h, MPPI_ERR_COMM, "Robust MPPI candidate evaluation: a peer's slice of the candidate costs did not arrive");
   rmBestIndex(h);
   h->stats_h.nominal_state_used = h->best_index;
   h->nominal_stride = h->rm_cand_strides[h->best_index];
@@ -3076,7 +3123,10 @@ static mppi_status ensureMailbox(mppi_handle h)
   if (world > 16)
     return fail(h, MPPI_ERR_UNSUPPORTED, "P2P mailbox exchange supports up to 16 ranks");
   const size_t dps = (size_t)h->D * h->PS;
-  h->mbox_bytes = sizeof(float) * 2 * world * dps + sizeof(unsigned) * (2 * world + 4);  // records, flags, ticket counter
+  // records | flags [2][world], ticket counter (+ 3 words of padding) | aux arrays [2][MAILBOX_AUX_FLOATS] | aux flags [2][world]
+  h->mbox_aux_off = 2 * world * dps + (size_t)(2 * world + 4);  // in 4-byte words from the base
+  h->mbox_aux_off = (h->mbox_aux_off + 3) & ~(size_t)3;
+  h->mbox_bytes = sizeof(float) * (h->mbox_aux_off + 2 * (size_t)kernels::MAILBOX_AUX_FLOATS + 2 * (size_t)world);
   h->mbox_bytes = (h->mbox_bytes + 4095) & ~(size_t)4095;
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   // uncached device memory where the runtime offers it (the mailbox is written by other agents); every access to it is a
@@ -3102,13 +3152,14 @@ static mppi_status ensureMailbox(mppi_handle h)
  */
 static mppi_status resetMailboxSession(mppi_handle h)
 {
-  if (!h->mbox_d || h->xseq == 0)
+  if (!h->mbox_d || (h->xseq == 0 && h->aseq == 0))
     return MPPI_OK;  // fresh (zeroed at allocation) or never used since the last reset
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemsetAsync(h->mbox_d, 0, h->mbox_bytes, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->xseq = 0;
+  h->aseq = 0;
   return MPPI_OK;
 }
 
@@ -3183,6 +3234,7 @@ mppi_status mppi_p2p_connect(mppi_handle h, const void* handles, size_t stride_b
     h->peer_opened[p] = true;
   }
   h->xseq = 0;
+  h->aseq = 0;
   h->exchange_failed = false;
   h->p2p_ready = true;
   return MPPI_OK;
@@ -3223,6 +3275,7 @@ mppi_status mppi_p2p_connect_local(mppi_handle h, const mppi_handle* peers)
     h->peer_mbox[p] = q->mbox_d;
   }
   h->xseq = 0;
+  h->aseq = 0;
   h->exchange_failed = false;
   h->p2p_ready = true;
   return MPPI_OK;

@@ -491,6 +491,58 @@ __global__ void __launch_bounds__(MERGE_THREADS) combineShardedKernel(const Comb
   combineWave<true>(glob, z, wave_global, lane);
 }
 
+/* ---- a second, small mailbox channel for values every rank needs IN FULL on its host (Robust MPPI: the costs of the
+ * candidate evaluation, sharded over the ranks by candidates — SURVEY.md §8e "RMPPI init-eval shards the same way"): every rank
+ * writes its slice at its position of the array in every peer's aux region, raises its flag there; gatherAuxKernel waits for
+ * all flags of its own region and hands the assembled array on. */
+constexpr int MAILBOX_AUX_FLOATS = 4096;  ///< per parity; candidates x samples_per_candidate must fit (else: replicated evaluation)
+struct AuxTargets
+{
+  float* peer_aux[16];      ///< peer p's aux array of this exchange's parity (this rank's own mailbox included)
+  unsigned* peer_flag[16];  ///< peer p's aux flag word for this rank
+  int world;
+  unsigned seq;
+};
+__global__ void __launch_bounds__(256) postAuxKernel(const float* __restrict__ src, const int offset, const int count, const AuxTargets t)
+{
+  for (int p = 0; p < t.world; p++)
+    for (int i = (int)threadIdx.x; i < count; i += 256)
+      __hip_atomic_store(t.peer_aux[p] + offset + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    __threadfence_system();
+    for (int p = 0; p < t.world; p++)
+      __hip_atomic_store(t.peer_flag[p], t.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+/** dst[0..n) <- the assembled array; a peer that never posts: dst is filled with NaN (the host reports MPPI_ERR_COMM) */
+__global__ void __launch_bounds__(256)
+    gatherAuxKernel(const float* __restrict__ aux, const unsigned* __restrict__ flags, const int world, const unsigned seq,
+                    const unsigned long long wait_limit_ticks, const int n, float* __restrict__ dst)
+{
+  __shared__ int failed_s;
+  if (threadIdx.x == 0)
+    failed_s = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < world)
+  {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq)
+    {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > wait_limit_ticks)
+      {
+        failed_s = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = (int)threadIdx.x; i < n; i += 256)
+    dst[i] = failed_s ? __builtin_nanf("") : loadPeerWritten(aux + i);
+}
+
 /** every store of the kernels in front of it on the stream is out: publish `seq` where the host spins (device-mapped host
  *  memory, system scope) — the hand-over of a small kernel whose signature has no flag argument (model step) */
 __global__ void __launch_bounds__(64) raiseFlagKernel(unsigned* flag, unsigned seq)

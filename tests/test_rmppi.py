@@ -422,13 +422,17 @@ def test_rmppi_runs_networks_of_other_shapes_on_the_one_lane_form(gpu, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["di", "autorally"])
-def test_rmppi_two_ranks_match_unsharded(gpu, model):
-    """Robust MPPI with the rollouts sharded over two ranks (two handles on this GPU, P2P mailbox exchange; every rank
-    evaluates the candidates itself): the same nominal / real control sequences as one handle, rank for rank the same bits.
-    AutoRally runs the role-pipelined kernels.  computeControl blocks until the merged result is there, so each rank is
-    driven from its own thread — as one process per GPU would."""
+@pytest.mark.parametrize("model,world", [("di", 2), ("autorally", 2), ("di", 4)])
+def test_rmppi_ranks_match_unsharded(gpu, model, world):
+    """Robust MPPI with the rollouts sharded over 2 / 4 ranks (handles on this GPU, P2P mailbox exchange) AND the candidate
+    evaluation sharded by candidate over the same ranks (9 candidates: 5 + 4, or 3 + 3 + 3 + 0; the costs travel through the
+    mailbox's aux channel and every rank picks the best candidate from all 9 x 32 of them): the same nominal / real control
+    sequences and the same best candidate as one handle, rank for rank the same bits.  AutoRally runs the role-pipelined
+    kernels.  The calls block until the merged result is there, so each rank is driven from its own thread — as one process
+    per GPU would."""
     import threading
+    import gc
+    gc.collect()  # every in-process rank needs a hardware queue of its own: no stream of an earlier test may stay alive
     cfg = _rm_cfg(model, K=2048, T=40, num_iters=2)
     thr = {"di": 25.0}.get(model, 500.0)
     S = C = None
@@ -448,11 +452,11 @@ def test_rmppi_two_ranks_match_unsharded(gpu, model):
     ref = []
     drive(full, ref)
     full.close()
-    ranks = [_make_pair(cfg, thr=thr, rank=r, world_size=2)[0] for r in range(2)]
+    ranks = [_make_pair(cfg, thr=thr, rank=r, world_size=world)[0] for r in range(world)]
     m.MPPIController.p2pConnectLocal(ranks)
-    outs = [[], []]
-    barrier = threading.Barrier(2)
-    ts = [threading.Thread(target=drive, args=(ranks[r], outs[r], barrier)) for r in range(2)]
+    outs = [[] for _ in range(world)]
+    barrier = threading.Barrier(world)
+    ts = [threading.Thread(target=drive, args=(ranks[r], outs[r], barrier)) for r in range(world)]
     for t in ts:
         t.start()
     for t in ts:
@@ -460,7 +464,8 @@ def test_rmppi_two_ranks_match_unsharded(gpu, model):
     assert not any(t.is_alive() for t in ts)
     for c in ranks:
         c.close()
-    assert len(outs[0]) == 3 and len(outs[1]) == 3
-    for a, b, r in zip(outs[0], outs[1], ref):
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] == r[2]
-        assert np.abs(a[0] - r[0]).max() <= 5e-6 and np.abs(a[1] - r[1]).max() <= 5e-6
+    assert all(len(o) == 3 for o in outs)
+    for q in range(1, world):
+        for a, b, r in zip(outs[0], outs[q], ref):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] == r[2]
+            assert np.abs(a[0] - r[0]).max() <= 5e-6 and np.abs(a[1] - r[1]).max() <= 5e-6
