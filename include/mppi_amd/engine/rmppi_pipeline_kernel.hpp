@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
           }
         }
       }
-      pipePublish(smp_prog, hi, lane);
+      pipePublishLds(smp_prog, hi, lane);
     }
   }
   else if (is_dyn)
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
       fetch(t + 1, &ubuf[C]);
       dyn_step(x, x_next, t, &ubuf[0]);
       dyn_step(x_next, x, t + 1, &ubuf[C]);
-      pipePublish(my_prog, t + 2, lane);
+      pipePublishLds(my_prog, t + 2, lane);
     }
     if (t < num_timesteps)
     {
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
       float ubuf[C];
       fetch(t, &ubuf[0]);
       dyn_step(x, x_next, t, &ubuf[0]);
-      pipePublish(my_prog, num_timesteps, lane);
+      pipePublishLds(my_prog, num_timesteps, lane);
     }
   }
   else
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
       rl_a[lane] = acc_a;
       rl_b[lane] = acc_b;
       rl_s[lane] = crash_status;
-      pipePublish(cost_prog, hi, lane);
+      pipePublishLds(cost_prog, hi, lane);
     }
   }
   __syncthreads();
@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + INIT_EV
             samples[((t + q) * C + i) * 64 + lane] = u[i];
         }
       }
-      pipePublish(smp_prog, min(t + TRIP, num_timesteps), lane);
+      pipePublishLds(smp_prog, min(t + TRIP, num_timesteps), lane);
     }
   }
   else if (is_dyn)
@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + INIT_EV
       pipeWait(cost_prog, t + 2 - ring_steps, seen_cost);
       dyn_step(x, x_next, t);
       dyn_step(x_next, x, t + 1);
-      pipePublish(my_prog, t + 2, lane);
+      pipePublishLds(my_prog, t + 2, lane);
     }
     if (t < num_timesteps)
     {
@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + INIT_EV
           pipeWait(counters + 4 * (DW + q), num_timesteps, seen_smp[q]);
       pipeWait(cost_prog, num_timesteps - ring_steps, seen_cost);
       dyn_step(x, x_next, t);
-      pipePublish(my_prog, num_timesteps, lane);
+      pipePublishLds(my_prog, num_timesteps, lane);
     }
   }
   else
@@ -792,7 +792,7 @@ __global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + INIT_EV
       status_guess = status_out;
       relay_cost[lane] = running_cost;
       relay_status[lane] = crash_status;
-      pipePublish(cost_prog, hi, lane);
+      pipePublishLds(cost_prog, hi, lane);
     }
   }
   __syncthreads();

@@ -34,6 +34,8 @@
 #include "mppi_amd/plugin/math_utils.hpp"
 #include "mppi_amd/plugin/parallel_utils.hpp"
 
+#include "mppi_amd/utils/wave_ops.hpp"
+
 namespace mppi
 {
 namespace kernels
@@ -145,10 +147,7 @@ __device__ inline void blockSoftminEpilogueCost(SAMPLING_T* sampling, const Roll
 #pragma unroll
     for (int z = 0; z < BZ; z++)
     {
-      float v = (lane < BX) ? cost_s[BX * z + lane] : INFINITY;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1)
-        v = fminf(v, __shfl_xor(v, off, 64));
+      const float v = mppi::wave::waveAllMin((lane < BX) ? cost_s[BX * z + lane] : INFINITY);  // DPP, no LDS round trips
       rho_mine = (z == thread_idz) ? v : rho_mine;
     }
   }
@@ -226,16 +225,12 @@ __device__ inline void blockSoftminEpilogueCost(SAMPLING_T* sampling, const Roll
 #pragma unroll
       for (int z = 0; z < BZ; z++)
       {
-        float rho_b = (lane < BX) ? cost_s[BX * z + lane] : INFINITY;
+        const float rho_b = mppi::wave::waveAllMin((lane < BX) ? cost_s[BX * z + lane] : INFINITY);
         const double w = (lane < BX) ? (double)w_s[BX * z + lane] : 0.0;
-        double eta = w, eta2 = w * w;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-        {
-          rho_b = fminf(rho_b, __shfl_xor(rho_b, off, 64));
-          eta += __shfl_xor(eta, off, 64);
-          eta2 += __shfl_xor(eta2, off, 64);
-        }
+        // (three six-level __shfl_xor trees — 24 dependent ds_bpermute round trips for the two doubles — were ~0.5 us of the
+        //  kernel's fixed part)
+        const double eta = mppi::wave::waveAllSum(w);
+        const double eta2 = mppi::wave::waveAllSum(w * w);
         if (lane == 0)
         {
           float* rec = args.partials_d + ((size_t)z * num_blocks + block_idx) * PS + TC;

@@ -43,6 +43,63 @@ __device__ inline void transpose4x4(float (&v)[4])
   v[2] = __uint_as_float(r23[0]);
   v[3] = __uint_as_float(r23[1]);
 }
+/* ---- wave64 all-reduce without LDS: four DPP steps inside the rows of 16 lanes (xor 1, xor 2, half-row mirror, row mirror:
+ * a butterfly — both lanes of a pair form the same commutative sum, so all 16 lanes of a row end with identical bits), then
+ * the four row results through v_readlane in a fixed order.  ~20 issue slots against six dependent ds_bpermute round trips
+ * (~0.3 us) for a __shfl_xor tree: the merge kernel is a chain of latencies, and its three reductions were 1.5 us of it
+ * (in-kernel timers, round 4: profiles/r04_combine_timing_before.json); the block-softmin epilogue of the rollout kernels uses
+ * them as well. */
+template <int CTRL>
+__device__ inline float dppMoveF(const float v)
+{
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ inline double dppMoveD(const double v)
+{
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;  // quad_perm [1,0,3,2] / [2,3,0,1]
+
+__device__ inline float readLaneF(const float v, const int l)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ inline double readLaneD(const double v, const int l)
+{
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ inline float waveAllMin(float v)
+{
+  v = fminf(v, dppMoveF<DPP_XOR1>(v));
+  v = fminf(v, dppMoveF<DPP_XOR2>(v));
+  v = fminf(v, dppMoveF<DPP_HALF_MIRROR>(v));
+  v = fminf(v, dppMoveF<DPP_MIRROR>(v));
+  return fminf(fminf(readLaneF(v, 0), readLaneF(v, 16)), fminf(readLaneF(v, 32), readLaneF(v, 48)));
+}
+__device__ inline float waveAllSum(float v)
+{
+  v += dppMoveF<DPP_XOR1>(v);
+  v += dppMoveF<DPP_XOR2>(v);
+  v += dppMoveF<DPP_HALF_MIRROR>(v);
+  v += dppMoveF<DPP_MIRROR>(v);
+  return (readLaneF(v, 0) + readLaneF(v, 16)) + (readLaneF(v, 32) + readLaneF(v, 48));
+}
+__device__ inline double waveAllSum(double v)
+{
+  v += dppMoveD<DPP_XOR1>(v);
+  v += dppMoveD<DPP_XOR2>(v);
+  v += dppMoveD<DPP_HALF_MIRROR>(v);
+  v += dppMoveD<DPP_MIRROR>(v);
+  return (readLaneD(v, 0) + readLaneD(v, 16)) + (readLaneD(v, 32) + readLaneD(v, 48));
+}
+
 }  // namespace wave
 }  // namespace mppi
 

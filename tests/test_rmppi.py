@@ -455,8 +455,10 @@ def test_rmppi_ranks_match_unsharded(gpu, model, world):
     ranks = [_make_pair(cfg, thr=thr, rank=r, world_size=world)[0] for r in range(world)]
     m.MPPIController.p2pConnectLocal(ranks)
     outs = [[] for _ in range(world)]
-    barrier = threading.Barrier(world)
-    ts = [threading.Thread(target=drive, args=(ranks[r], outs[r], barrier)) for r in range(world)]
+    # a rank that fails must not leave the others waiting for ever (a blocked non-daemon thread would keep the whole pytest
+    # process from exiting): the barrier times out, the threads are daemons
+    barrier = threading.Barrier(world, timeout=60)
+    ts = [threading.Thread(target=drive, args=(ranks[r], outs[r], barrier), daemon=True) for r in range(world)]
     for t in ts:
         t.start()
     for t in ts:
