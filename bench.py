@@ -463,6 +463,29 @@ def racer_elevation_leg(device):
     return out
 
 
+def reference_order_leg(device):
+    """What the opt-in reference-order reduction (mppi_set_reduction_mode: global rho, eta in double in index order, per-rollout
+    weight / eta, cells of 32 rollouts — the mode in which a free-running closed loop is bit-identical to the oracle) costs per
+    iteration next to the default fused reduction: samples through HBM + three K-long serial sums."""
+    import mppi_generic_amd as m
+    from common import autorally_cfg, cartpole_cfg, make_engine
+    out = {}
+    for key, cfg, n in (("cartpole_16384x100", cartpole_cfg(K=K_PER_GPU, T=T), 400),
+                        ("autorally_nn_16384x150", autorally_cfg(K=16384, T=150, lambda_=1.0), 100)):
+        eng = make_engine(cfg, device=device)
+        eng.setReductionMode(m.MPPI_REDUCTION_REFERENCE_ORDER)
+        eng.uploadState(cfg["x0"])
+        eng.optimize(20, True)
+        t0 = time.perf_counter()
+        eng.optimize(n, True)
+        wall = time.perf_counter() - t0
+        out[key] = {"ms_per_step": round(wall / n * 1e3, 6), "value": round(n / wall, 3), "unit": "MPPI iters/s"}
+        eng.close()
+    out["definition"] = ("one optimisation iteration with MPPI_REDUCTION_REFERENCE_ORDER: rollout kernel (samples dumped to HBM) + "
+                         "exactWeightsKernel + exactReductionCellsKernel + exactReductionFinalKernel; parity mode, not the headline")
+    return out
+
+
 def np_tile(x, d):
     import numpy as np
     return np.tile(x, (d, 1))
@@ -839,7 +862,7 @@ def main():
         if not args.primary_only and world == 1 and args.workload == "cartpole":
             for key, leg_fn in (("autorally_nn", autorally_leg), ("lstm_colored", lstm_colored_leg), ("di_tube", di_tube_leg),
                                 ("racer_elevation", racer_elevation_leg), ("robust_autorally_nn", robust_autorally_leg),
-                                ("robust_double_integrator", robust_di_leg)):
+                                ("robust_double_integrator", robust_di_leg), ("reference_order_reduction", reference_order_leg)):
                 try:
                     if key in ("autorally_nn", "di_tube"):
                         out[key] = leg_fn(local_rank, with_cpu_baseline=not args.no_cpu_baseline)
