@@ -128,6 +128,12 @@ public:
   {
     check(mppi_set_num_iters(h_, n));
   }
+  /** mppi_reduction_mode: MPPI_REDUCTION_REFERENCE_ORDER runs the last stage of every iteration in the reference's own
+   *  summation order (bit-equal closed loops against the reference's arithmetic; costs the samples a round trip through HBM) */
+  void setReductionMode(int mode)
+  {
+    check(mppi_set_reduction_mode(h_, mode));
+  }
   void setSeed(unsigned long long seed)
   {
     check(mppi_set_seed(h_, seed));

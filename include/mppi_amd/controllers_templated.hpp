@@ -157,6 +157,12 @@ public:
     if (h_)
       pushControllerParams();
   }
+  /** mppi_reduction_mode (mppi_amd.h): the reference's own summation order for the last stage of an iteration, for parity runs */
+  void setReductionMode(int mode)
+  {
+    ensureHandle();
+    check(mppi_set_reduction_mode(h_, mode));
+  }
   float getLambda() const
   {
     return params_.lambda_;

@@ -148,6 +148,35 @@ def test_mode_switch_and_sum_strides(gpu):
     sh.close()
 
 
+@pytest.mark.parametrize("tsallis", [False, True], ids=["exponential", "tsallis"])
+def test_colored_mppi_reference_order(gpu, tsallis):
+    """ColoredMPPI (colored-noise sampler; with and without Tsallis weights, core/mppi_common.cu:968-985) in the reference-order
+    mode: four closed-loop steps, control sequence and state trajectory bit for bit"""
+    from common import host_spectrum
+    from test_colored_noise import _colored_cartpole
+    cfg = _colored_cartpole(K=2048, T=60)
+    eng, orc = make_engine(cfg), make_oracle(cfg)
+    eng.setReductionMode(m.MPPI_REDUCTION_REFERENCE_ORDER)
+    exps, decay, fmin = cfg["colored"]
+    if tsallis:
+        eng.setColoredMPPIParams(gamma=400.0, r_exp=1.7)
+        orc.set_colored_mppi_params(400.0, 1.7, None, False, 1)
+    x = cfg["x0"].copy()
+    for i in range(4):
+        z = host_spectrum(1, cfg["K"], cfg["T"], 1, seed=60 + i)
+        eng.injectNoise(z)
+        eng.computeControl(x, 1)
+        orc.colored_compute_control(x, 1, z, exps, decay, fmin)
+        assert np.array_equal(_bits(eng.getControlSeq()), _bits(orc.control())), i
+        assert np.array_equal(_bits(eng.getTargetStateSeq()), _bits(orc.state_traj())), i
+        st, so = eng.getStats().real_sys, orc.stats()
+        assert st.baseline == so["baseline"][0] and st.normalizer == so["normalizer"][0], i
+        x, _ = orc.model_step(x, orc.control()[0])
+        eng.slideControlSequence(1)
+        orc.vanilla_slide(1)
+    eng.close()
+
+
 def test_tube_free_running_closed_loop_100_steps(gpu):
     """config 3 (double integrator, Tube-MPPI, K = 8192, T = 150): 100 control iterations with Tube's slide
     (tube_mppi_controller.cu:312-323: the nominal state takes a model step), the actual state disturbed every step, NEVER
