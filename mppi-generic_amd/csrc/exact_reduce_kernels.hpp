@@ -18,8 +18,10 @@
  *
  * The serial sums are what they are — K dependent additions; they run as three waves of one block side by side (eta in
  * double, norm and var in float), each walking the weights through LDS with 16-byte broadcast reads (every lane of the wave
- * performs the same additions).  Cost at K = 16384: ~45 us per system on top of the rollout kernel; the samples' round trip
- * through HBM (2 x K T C x 4 B) is a few microseconds.  This mode buys bit-equality with the reference's order, not speed.
+ * performs the same additions).  Measured at K = 16384: ~145 us for this kernel (a dependent v_add_f64 every ~20 cycles: the
+ * chain's latency, not its issue rate), 196 us per Cartpole iteration against 27 us with the fused reduction, 369 against
+ * 197 us for AutoRally-NN (bench.py: reference_order_reduction); the samples' round trip through HBM (2 x K T C x 4 B) is a few
+ * microseconds of that.  This mode buys bit-equality with the reference's order, not speed.
  */
 #ifndef MPPI_AMD_EXACT_REDUCE_KERNELS_HPP_
 #define MPPI_AMD_EXACT_REDUCE_KERNELS_HPP_
@@ -33,8 +35,9 @@ namespace mppi
 {
 namespace kernels
 {
-constexpr int EXACT_TILE = 8192;  ///< weights per LDS tile: 8192 x (8 + 4 + 4) B = 128 KiB
-constexpr size_t EXACT_WEIGHTS_LDS_BYTES = (size_t)EXACT_TILE * (sizeof(double) + 2 * sizeof(float));
+constexpr int EXACT_TILE = 8192;  ///< weights per LDS tile: (8192 + 16) x (8 + 4 + 4) B = 128.25 KiB
+constexpr int EXACT_PAD = 16;     ///< zeros behind a tile: the serial waves fetch one trip ahead without a bounds test
+constexpr size_t EXACT_WEIGHTS_LDS_BYTES = (size_t)(EXACT_TILE + EXACT_PAD) * (sizeof(double) + 2 * sizeof(float));
 
 /** how the weights come about */
 struct ExactWeightsArgs
@@ -56,9 +59,9 @@ struct ExactWeightsArgs
 __global__ void __launch_bounds__(COMBINE_THREADS) exactWeightsKernel(const ExactWeightsArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char exact_smem_raw[];
-  double* wd_s = reinterpret_cast<double*>(exact_smem_raw);        // [EXACT_TILE]
-  float* wf_s = reinterpret_cast<float*>(wd_s + EXACT_TILE);       // [EXACT_TILE]
-  float* w2_s = wf_s + EXACT_TILE;                                 // [EXACT_TILE]
+  double* wd_s = reinterpret_cast<double*>(exact_smem_raw);              // [EXACT_TILE + EXACT_PAD]
+  float* wf_s = reinterpret_cast<float*>(wd_s + EXACT_TILE + EXACT_PAD); // [EXACT_TILE + EXACT_PAD]
+  float* w2_s = wf_s + EXACT_TILE + EXACT_PAD;                           // [EXACT_TILE + EXACT_PAD]
   __shared__ float red_f[COMBINE_THREADS / 64];
   __shared__ double eta_s;
   __shared__ float norm_s, var_s;
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(COMBINE_THREADS) exactWeightsKernel(const Exac
   {
     const int n = min(EXACT_TILE, K - base);
     const int n_pad = (n + 15) & ~15;  // the serial waves walk 16 weights per trip; +0 leaves every sum unchanged
-    for (int i = tid; i < n_pad; i += COMBINE_THREADS)
+    for (int i = tid; i < n_pad + EXACT_PAD; i += COMBINE_THREADS)
     {
       float w = 0.0f;
       if (i < n)
@@ -113,10 +116,10 @@ __global__ void __launch_bounds__(COMBINE_THREADS) exactWeightsKernel(const Exac
         cur[i] = p[i];
       for (int b = 0; b < n_pad; b += 16)
       {
-        const bool more = b + 16 < n_pad;
+        // the next trip's sixteen weights are on their way while this trip's are added (zeros behind the tile: no bounds test)
 #pragma unroll
         for (int i = 0; i < 8; i++)
-          nxt[i] = more ? p[(b + 16) / 2 + i] : make_double2(0.0, 0.0);
+          nxt[i] = p[(b + 16) / 2 + i];
 #pragma unroll
         for (int i = 0; i < 8; i++)
         {
@@ -138,10 +141,9 @@ __global__ void __launch_bounds__(COMBINE_THREADS) exactWeightsKernel(const Exac
         cur[i] = p[i];
       for (int b = 0; b < n_pad; b += 16)
       {
-        const bool more = b + 16 < n_pad;
 #pragma unroll
         for (int i = 0; i < 4; i++)
-          nxt[i] = more ? p[(b + 16) / 4 + i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          nxt[i] = p[(b + 16) / 4 + i];
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
