@@ -199,6 +199,14 @@ const char* mppi_last_error(mppi_handle h);
 mppi_status mppi_get_dims(mppi_handle h, int* state_dim, int* control_dim, int* output_dim, int* num_systems);
 /** rollouts owned by this handle (K / world_size) */
 mppi_status mppi_get_local_rollouts(mppi_handle h, int* k_local, int* k_offset);
+/**
+ * Kernel launches this handle has made since mppi_create: rollout launches (rolloutKernel and its pipelined forms — the
+ * reference's launchRolloutKernel / launchFastRolloutKernel, core/mppi_common.cu:520-630) and launches of the reduction stage
+ * (the merge of the per-block records, or the reference-order kernels counted as one).  A Vanilla handle whose rollout kernel
+ * merges the previous iteration's records in its sampler waves makes n rollout launches and ONE merge launch for n iterations.
+ * Either pointer may be NULL.
+ */
+mppi_status mppi_get_launch_counts(mppi_handle h, unsigned long long* rollout_launches, unsigned long long* merge_launches);
 
 /* ---------------------------------------------------------------- parameters ------------------------------------- */
 /** Dynamics::setParams + paramsToDevice (dynamics/dynamics.cu:3-17); pod = the model's *_dynamics_params (mppi_amd/model_params.h) */

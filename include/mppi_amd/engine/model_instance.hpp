@@ -156,6 +156,11 @@ struct ModelBase
   {
     return false;
   }
+  /** rolloutPipelineKernel's STREAM_MERGE form exists: one system, Gaussian sampler drawing in the loop */
+  virtual bool supportsStreamedMerge() const
+  {
+    return false;
+  }
   /** role-pipelined variant with the two systems of Tube-MPPI folded into the lanes of a wave, shape (32, 1, 2) */
   virtual bool supportsPipelineFold(int bx, int by, int bz) const
   {
@@ -196,8 +201,8 @@ struct ModelBase
  *  plugin built against other headers: its kernels would read the argument blocks with the wrong layout) */
 /** bumped BY HAND whenever ModelBase's virtual methods are added, removed or reordered or a field of an argument struct is
  *  swapped at equal size — changes sizeof() cannot see (a stale plugin would dispatch to the wrong vtable slot).
- *  3: rows-in-HBM arguments; 4: release-flag arguments of the finalize kernels (both round 3). */
-#define MPPI_ENGINE_ABI_VERSION 4
+ *  3: rows-in-HBM arguments; 4: release-flag arguments of the finalize kernels (both round 3); 5: supportsStreamedMerge (round 4). */
+#define MPPI_ENGINE_ABI_VERSION 5
 
 constexpr int engineAbiFingerprint()
 {
@@ -669,6 +674,10 @@ struct ModelT : ModelBase
   {
     return PIPELINE;
   }
+  bool supportsStreamedMerge() const override
+  {
+    return PIPELINE && SAMPLING_T::IN_LOOP_DRAW && !SAMPLING_T::COLORED;
+  }
   bool supportsPipelineRep(int bx, int by, int bz) const override
   {
     if constexpr (!std::is_void<DYN_FAST_T>::value)
@@ -745,6 +754,22 @@ struct ModelT : ModelBase
         if (smp.rows_global_d_)  // long horizons: the sample rows in HBM
           kfn = in_loop ? kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, SAMPLING_T::IN_LOOP_DRAW, FOLD, true>
                         : kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, Z, false, FOLD, true>;
+      }
+      if constexpr (Z == 1 && !FOLD && SAMPLING_T::IN_LOOP_DRAW && !SAMPLING_T::COLORED)
+      {
+        // the previous iteration's block records merged by this launch's sampler waves (RolloutArgs::prev_records_d)
+        if (args.prev_records_d && in_loop && !smp.rows_global_d_)
+          kfn = kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, 1, SAMPLING_T::IN_LOOP_DRAW, false, false, true>;
+        else if (args.prev_records_d)
+        {
+          err = "prev_records_d: this launch cannot merge the previous records itself (noise source / rows in HBM)";
+          return MPPI_ERR_STATE;
+        }
+      }
+      else if (args.prev_records_d)
+      {
+        err = "prev_records_d: the streamed merge exists for one-system Gaussian pipeline launches only";
+        return MPPI_ERR_STATE;
       }
       if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,

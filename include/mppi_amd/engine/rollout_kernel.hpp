@@ -85,6 +85,11 @@ struct RolloutArgs
   float* trajectory_costs_d;    ///< [D][K_local]
   float* partials_d;            ///< [D][num_blocks][partialStride]
   int save_samples;             ///< != 0: also write the clamped samples to sampler.control_samples_d_
+  /* STREAM_MERGE (rolloutPipelineKernel, round 4): the block records of the PREVIOUS iteration (one system, at most 256 of
+   * them, T*C a multiple of 4) — this launch's sampler waves merge them into the control mean they shape with, four columns per
+   * trip, instead of a merge launch in between; nullptr: the mean is in sampler.control_means_d_ */
+  const float* prev_records_d;  ///< [prev_num_records][partialStride]
+  int prev_num_records;
 };
 
 template <class DYN_T, class COST_T, class SAMPLING_T>

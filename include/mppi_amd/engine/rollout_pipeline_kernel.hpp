@@ -32,7 +32,9 @@
 #ifndef MPPI_AMD_ROLLOUT_PIPELINE_KERNEL_HPP_
 #define MPPI_AMD_ROLLOUT_PIPELINE_KERNEL_HPP_
 
+#include <type_traits>
 #include "rollout_kernel.hpp"
+#include "merge_wave.hpp"
 
 namespace mppi
 {
@@ -63,6 +65,8 @@ __host__ inline size_t pipelineSharedBytes(const DYN_T& dyn, const COST_T& cost,
   n += sizeof(float) * (size_t)rings * pipeRingSteps(DYN_T::OUTPUT_DIM) *
        (DYN_T::OUTPUT_DIM + (smp.rows_global_d_ ? DYN_T::CONTROL_DIM : 0)) * 64;
   n += sizeof(int) * 4 * 4 * rings;                                              // progress counters (padded)
+  // STREAM_MERGE: the control mean the sampler waves merge for themselves, [T][C], for the cost wave's likelihood-ratio term
+  n += sizeof(float) * math::nearest_multiple_4(smp.params_.num_timesteps * DYN_T::CONTROL_DIM);
   return n;
 }
 
@@ -159,10 +163,22 @@ __host__ __device__ constexpr int pipelineBlockX(int bz, bool fold_z)
 /** ROWS_HBM: the sample rows of the block in the sampler's HBM buffer (long horizons) — see rolloutPipelineRepKernel: the
  *  dynamics wave fetches the next trip's samples while it computes the current one, the clamped control reaches the cost
  *  wave through the output ring */
-template <class DYN_T, class COST_T, class SAMPLING_T, int BZ, bool DRAW_IN_LOOP, bool FOLD_Z = false, bool ROWS_HBM = false>
+/**
+ * STREAM_MERGE (round 4; one system, plain draw, rows in LDS): the sampler waves merge the PREVIOUS iteration's block records
+ * (args.prev_records_d) into the control mean themselves, four columns — the steps of one trip — at a time, with the arithmetic
+ * of the merge kernel (merge_wave.hpp: the same functions, the same bits): each sampler wave loads the 256 record tails once
+ * (rho, the scale factors and eta stay in its registers) and, one of its own trips ahead, the four 16-byte column quads a lane
+ * owns; a trip then costs four DPP all-reduces and four divisions on top of its draw.  The merge launch between two
+ * iterations (3.3 us of body + a 1.6 us boundary on a 27 us Cartpole iteration) disappears; what remains of it is that the
+ * first trip waits for the records' memory round trip instead of only for its own draw.  The last iteration of a sequence is
+ * merged by combineKernel as before (the engine flushes before anything reads the mean or the statistics).
+ */
+template <class DYN_T, class COST_T, class SAMPLING_T, int BZ, bool DRAW_IN_LOOP, bool FOLD_Z = false, bool ROWS_HBM = false,
+          bool STREAM_MERGE = false>
 __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ))
     rolloutPipelineKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args)
 {
+  static_assert(!STREAM_MERGE || (BZ == 1 && !FOLD_Z && !ROWS_HBM && DRAW_IN_LOOP), "STREAM_MERGE: one system, plain draw, LDS rows");
   // FOLD_Z (Tube: BZ == 2): a wave carries 32 rollouts x 2 systems in its 64 lanes.  Half the sample rows per block
   // (two systems with T*C floats per rollout each are what overflows the LDS at 64 rollouts), twice the blocks — at
   // K = 8192 exactly one block per CU — and the two systems of a rollout advance in the same instruction stream.
@@ -233,6 +249,7 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
   float* ring = ring_all + (size_t)ring_z * PIPE_RING * F * 64;  // [slot][i][lane]
   lds_counter_t counters =
       (lds_counter_t)(reinterpret_cast<int*>(ring_all + (size_t)WZ * PIPE_RING * F * 64) + 16 * ring_z);
+  float* mean_row_s = ring_all + (size_t)WZ * PIPE_RING * F * 64 + 16 * WZ;  // [T][C] (STREAM_MERGE), behind the counters
   // the three counters the dynamics wave consumes sit in one 16-byte word group: it reads them with a single ds_read_b128
   lds_counter_t smp_prog = counters + 0;   // steps whose shaped sample is in the row
   lds_counter_t smp_prog1 = counters + 1;  // second sampler wave (trips 1, 3, 5, ...)
@@ -263,7 +280,37 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
    * until steps 0..3 exist — would otherwise sit through prologue + draw in sequence (0.76 + 1.0 us of a 26 us launch,
    * in-kernel timers of round 4); now the other waves' prologue and the first draw overlap. */
   constexpr int SMP_STEPS = 4;
-  auto sampler_trip = [&](const int t) {
+  constexpr int TRIP_COLS = SMP_STEPS * C;                 // columns of the mean a trip shapes with
+  constexpr int TRIP_GROUPS = TRIP_COLS / MERGE_COLS;      // = C quads of four columns
+  // STREAM_MERGE state of a sampler wave: what the record tails gave (once) and the column quads of its NEXT trip (in flight)
+  MergeTails mt;
+  float vq[STREAM_MERGE ? TRIP_GROUPS : 1][MERGE_LANE_RECORDS][MERGE_COLS];
+  const int TC_all = num_timesteps * C;
+  auto load_trip_columns = [&](const int t) {
+    if constexpr (STREAM_MERGE)
+    {
+      typedef float merge_f4 __attribute__((ext_vector_type(4)));
+      const int PS = partialStride(num_timesteps, C);
+#pragma unroll
+      for (int g = 0; g < TRIP_GROUPS; g++)
+      {
+        const int col0 = t * C + MERGE_COLS * g;  // T*C is a multiple of 4 (engine): a quad lies inside the record or behind it
+#pragma unroll
+        for (int i = 0; i < MERGE_LANE_RECORDS; i++)
+        {
+          const int b = lane + 64 * i;
+          const bool ok = b < args.prev_num_records && col0 < TC_all;
+          const merge_f4 q = *reinterpret_cast<const merge_f4*>(args.prev_records_d + (size_t)(ok ? b : 0) * PS + (ok ? col0 : 0));
+          vq[g][i][0] = ok ? q.x : 0.0f;
+          vq[g][i][1] = ok ? q.y : 0.0f;
+          vq[g][i][2] = ok ? q.z : 0.0f;
+          vq[g][i][3] = ok ? q.w : 0.0f;
+        }
+      }
+    }
+  };
+  float rho_b[MERGE_LANE_RECORDS], eta_b[MERGE_LANE_RECORDS], eta2_b[MERGE_LANE_RECORDS];  // record tails (STREAM_MERGE), in flight
+  auto sampler_trip = [&](const int t, auto first_trip) {
     constexpr int QUADS = C;  // SMP_STEPS * C / 4
     float zq[4 * QUADS];
     if (DRAW_IN_LOOP)
@@ -272,12 +319,40 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
       for (int q = 0; q < QUADS; q++)
         sampling->drawQuad(global_idx, t * C / 4 + q, &zq[4 * q]);
     }
+    PIPE_T(if (decltype(first_trip)::value && smp_id == 0) tm.trip(block_idx, 4, 1, lane, __builtin_amdgcn_s_memtime() - tm.t0);)  // stage stamps of the first trip: ticks since kernel entry
+    float mu[TRIP_COLS];
+    if constexpr (STREAM_MERGE)
+    {
+      // first trip: the tails' loads were issued at kernel entry and are first touched here, BEHIND the draw — the Philox
+      // rounds run under the memory round trip instead of after it
+      if constexpr (decltype(first_trip)::value)
+        mergeTails(rho_b, eta_b, eta2_b, (float)(1.0 / (double)args.lambda), mt);
+      PIPE_T(if (decltype(first_trip)::value && smp_id == 0) tm.trip(block_idx, 4, 2, lane, __builtin_amdgcn_s_memtime() - tm.t0);)
+      // this trip's part of u* of the previous iteration: the merge kernel's arithmetic on the quads loaded a trip ago
+#pragma unroll
+      for (int g = 0; g < TRIP_GROUPS; g++)
+      {
+        float tot[MERGE_COLS];
+        mergeColumns(mt.s, vq[g], tot);
+#pragma unroll
+        for (int c = 0; c < MERGE_COLS; c++)
+        {
+          mu[MERGE_COLS * g + c] = tot[c] / mt.eta_f;
+          if (t * C + MERGE_COLS * g + c < TC_all)
+            mean_row_s[t * C + MERGE_COLS * g + c] = mu[MERGE_COLS * g + c];  // every lane: same word, same value
+        }
+      }
+      PIPE_T(if (decltype(first_trip)::value && smp_id == 0) tm.trip(block_idx, 4, 3, lane, __builtin_amdgcn_s_memtime() - tm.t0);)
+      load_trip_columns(t + SMP_STEPS * NS);  // the quads of this wave's next trip: in flight until then
+    }
 #pragma unroll
     for (int s2 = 0; s2 < SMP_STEPS; s2++)
     {
       if (t + s2 < num_timesteps)
       {
-        if (DRAW_IN_LOOP)
+        if constexpr (STREAM_MERGE)
+          sampling->template shapeControlSampleMean<FOLD_Z>(global_idx, t + s2, distribution_idx, &zq[s2 * C], &mu[s2 * C], u);
+        else if (DRAW_IN_LOOP)
           sampling->template shapeControlSample<FOLD_Z>(global_idx, t + s2, distribution_idx, &zq[s2 * C], u);
         else
           sampling->template readControlSample<FOLD_Z>(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
@@ -286,10 +361,34 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
         sampling->writeControlSample(global_idx, t + s2, distribution_idx, u, theta_d_shared, 1, 0, y);
       }
     }
+    PIPE_T(if (decltype(first_trip)::value && smp_id == 0) tm.trip(block_idx, 4, 4, lane, __builtin_amdgcn_s_memtime() - tm.t0);)
   };
   constexpr bool EARLY_FIRST_TRIP = DRAW_IN_LOOP && !PAIR_DRAW;
+  static_assert(!STREAM_MERGE || EARLY_FIRST_TRIP, "STREAM_MERGE: the record tails are merged inside the early first trip");
+  if constexpr (STREAM_MERGE)
+  {
+    if (role == 0)
+    {
+      // the record tails (one 16-byte load per record and lane) and the first trip's quads: one memory round trip, under which
+      // the first draw runs (the loads' results are first touched by mergeTails inside the first trip)
+      typedef float merge_f4 __attribute__((ext_vector_type(4)));
+      const int PS = partialStride(num_timesteps, C);
+#pragma unroll
+      for (int i = 0; i < MERGE_LANE_RECORDS; i++)
+      {
+        const int b = lane + 64 * i;
+        const bool ok = b < args.prev_num_records;
+        const merge_f4 tail = *reinterpret_cast<const merge_f4*>(args.prev_records_d + (size_t)(ok ? b : 0) * PS + TC_all);
+        rho_b[i] = ok ? tail.x : INFINITY;
+        eta_b[i] = ok ? tail.y : 0.0f;
+        eta2_b[i] = ok ? tail.z : 0.0f;
+      }
+      load_trip_columns(SMP_STEPS * smp_id);
+      PIPE_T(if (smp_id == 0) tm.trip(block_idx, 4, 0, lane, __builtin_amdgcn_s_memtime() - tm.t0);)
+    }
+  }
   if (EARLY_FIRST_TRIP && role == 0 && SMP_STEPS * smp_id < num_timesteps)
-    sampler_trip(SMP_STEPS * smp_id);
+    sampler_trip(SMP_STEPS * smp_id, std::true_type{});
 
   if (lane == 0 && wave_x == 0)
   {
@@ -368,7 +467,7 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
     }
     for (; t < num_timesteps; t += STEPS * NS)
     {
-      sampler_trip(t);
+      sampler_trip(t, std::false_type{});
       publish(min(t + STEPS, num_timesteps));
       PIPE_T(if (smp_id == 0) { const unsigned long long ts0 = tm.t0; tm.stop(0); tm.trip(block_idx, 3, t / (STEPS * NS), lane, tm.t0 - ts0); })
     }
@@ -530,8 +629,9 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
       for (int i = 0; i < C; i++)
         u[i] = ROWS_HBM ? slot[(O + i) * 64] : row[tt * C + i];
       running_cost += costs->computeRunningCost(y, u, tt, theta_c_shared, &crash_status) +
-                      sampling->template computeLikelihoodRatioCost<FOLD_Z>(u, theta_d_shared, global_idx, tt,
-                                                                            distribution_idx, args.lambda, args.alpha);
+                      sampling->template computeLikelihoodRatioCost<FOLD_Z, STREAM_MERGE>(u, theta_d_shared, global_idx, tt,
+                                                                                          distribution_idx, args.lambda,
+                                                                                          args.alpha, mean_row_s);
     };
     int t = 0;
     // full groups as one basic block: the four steps' ring / row reads and mean loads issue ahead of the arithmetic

@@ -392,6 +392,20 @@ public:
                                pure);
   }
 
+  /** the same with the means handed in (a kernel that has just merged them itself: rolloutPipelineKernel, STREAM_MERGE) */
+  template <bool LANE_D = false>
+  __device__ inline void shapeControlSampleMean(const int sample_index, const int t, const int distribution_index,
+                                                const float* __restrict__ eps, const float* __restrict__ mean_vals,
+                                                float* __restrict__ control) const
+  {
+    const int d = distribution_index >= params_.num_distributions ? 0 : distribution_index;
+    const bool use_mean = ((sample_index + rollout_offset_) == 0) || (t < optimization_stride_);
+    const bool pure = isPureNoise(sample_index);
+#pragma unroll
+    for (int i = 0; i < CONTROL_DIM; i++)
+      control[i] = shapeSample(mean_vals[i], sigmaValue<LANE_D, true>(d, t, i), eps[i], use_mean, pure);
+  }
+
   /**
    * Random access to one shaped sample v[d][sample_index][t][:] without the block's LDS rows: eps comes from the eps
    * buffer or from the Philox quad that holds the element.  Used by the Robust-MPPI init-eval kernel, whose rollouts
@@ -478,11 +492,12 @@ public:
    * reference: gaussian.cu:480-569, device flavour: 0.5*lambda*(1-alpha) * sum_i coeff_i*mu_i*(mu_i - 2u_i)/sigma_i^2
    * with mu := 0 on pure-noise rollouts; vector-lane accumulation order of the CONTROL_DIM % 4 / % 2 / scalar branches.
    */
-  template <bool LANE_D = false>
+  template <bool LANE_D = false, bool MEAN_ROW = false>
   __device__ inline float computeLikelihoodRatioCost(const float* __restrict__ u, float* __restrict__ theta_d,
                                                      const int sample_index, const int t, const int distribution_idx,
-                                                     const float lambda = 1.0f, const float alpha = 0.0f)
-  {
+                                                     const float lambda = 1.0f, const float alpha = 0.0f,
+                                                     const float* __restrict__ mean_row = nullptr)
+  {  // MEAN_ROW: the means of distribution 0 from `mean_row` ([T][C], LDS) instead of control_means_d_ (STREAM_MERGE kernels)
     const int d = distribution_idx >= params_.num_distributions ? 0 : distribution_idx;
     const float* control_cost_coeff = params_.control_cost_coeff;
     const bool pure = isPureNoise(sample_index);
@@ -510,7 +525,7 @@ public:
         for (int l = 0; l < W; l++)
         {
           const int j = i * W + l;
-          const float mu = meanValue<LANE_D>(d, t, j);  // unconditional: a wave-uniform (scalar) load
+          const float mu = MEAN_ROW ? mean_row[t * CONTROL_DIM + j] : meanValue<LANE_D>(d, t, j);  // unconditional: a wave-uniform load
           const float mean_i = pure ? 0.0f : mu;
           const float sd = sigmaValue<LANE_D, false>(d, t, j);
           lane[l] += control_cost_coeff[j] * mean_i * (mean_i - 2.0f * u[j]) / (sd * sd);
@@ -525,7 +540,7 @@ public:
     {
       for (; i < CONTROL_DIM; i += step)
       {
-        const float mu = meanValue<LANE_D>(d, t, i);  // unconditional: a wave-uniform (scalar) load
+        const float mu = MEAN_ROW ? mean_row[t * CONTROL_DIM + i] : meanValue<LANE_D>(d, t, i);  // unconditional: a wave-uniform load
         const float mean_i = pure ? 0.0f : mu;
         const float sd = sigmaValue<LANE_D, false>(d, t, i);
         cost += control_cost_coeff[i] * mean_i * (mean_i - 2.0f * u[i]) / (sd * sd);

@@ -284,6 +284,12 @@ class MPPIController:
         self.num_rollouts, self.num_timesteps = num_rollouts, num_timesteps
         self.dt, self.lambda_, self.alpha = dt, lambda_, alpha
 
+    def launchCounts(self):
+        """(rollout launches, reduction-stage launches) of this handle since creation (mppi_get_launch_counts)"""
+        r, g = C.c_ulonglong(), C.c_ulonglong()
+        self._check(self._lib.mppi_get_launch_counts(self._h, C.byref(r), C.byref(g)))
+        return r.value, g.value
+
     # -- plumbing --
     def _check(self, st):
         if st != 0:

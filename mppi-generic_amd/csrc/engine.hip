@@ -90,7 +90,14 @@ struct mppi_handle_s
   float* x0_d = nullptr;           // [D][S]
   float* mean_d = nullptr;         // [D][T][C]
   float* costs_d = nullptr;        // [D][K_local]
-  float* partials_d = nullptr;     // [D][num_blocks][PS]
+  float* partials_d = nullptr;     // [D][num_blocks][PS]: the records the NEXT rollout launch writes
+  /* Streamed merge (rolloutPipelineKernel, STREAM_MERGE): the records of the last rollout launch stay un-merged in
+   * pending_records_d until the next rollout launch merges them in its sampler waves — or flushMerge() runs combineKernel on
+   * them, which everything that reads mean_d / stats_d does first.  Two record buffers alternate. */
+  float* partials_alt_d = nullptr;
+  const float* pending_records_d = nullptr;
+  unsigned long long n_rollout_launches = 0, n_merge_launches = 0;  // mppi_get_launch_counts
+  bool stream_merge_enabled = true;  // MPPI_AMD_NO_STREAM_MERGE=1 switches it off (A/B)
   float* send_d = nullptr;         // [D][PS]
   float* recv_d = nullptr;         // [world][D][PS]
   float* gather_tmp_d = nullptr;   // [D][world][PS] (records regrouped per system)
@@ -436,7 +443,7 @@ static void freeAll(mppi_handle h)
     (void)hipHostFree(h->step_pin_h);
   h->in_pin_h = h->out_pin_h = h->step_pin_h = nullptr;
   h->step_u_d = nullptr;  // slice of the step_x_d block
-  float** bufs[] = { &h->in_block_d, &h->out_block_d, &h->costs_d,   &h->partials_d,  &h->send_d,     &h->recv_d,
+  float** bufs[] = { &h->in_block_d, &h->out_block_d, &h->costs_d,   &h->partials_d,  &h->partials_alt_d, &h->send_d,     &h->recv_d,
                      &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->gather_tmp_d, &h->rows_d, &h->fin_scratch_d,
                      &h->tsallis_weights_d, &h->tsallis_record_d, &h->rocrand_eps_d, &h->std_dev_time_d, &h->exact_weights_d, &h->exact_inter_d };
   for (float** b : bufs)
@@ -754,6 +761,11 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   }
   ALLOC_OR_FAIL(h->costs_d, (size_t)D * K);
   ALLOC_OR_FAIL(h->partials_d, (size_t)D * h->num_blocks * h->PS);
+  ALLOC_OR_FAIL(h->partials_alt_d, (size_t)D * h->num_blocks * h->PS);
+  {
+    const char* no_stream = getenv("MPPI_AMD_NO_STREAM_MERGE");
+    h->stream_merge_enabled = !(no_stream && no_stream[0] == '1');
+  }
   ALLOC_OR_FAIL(h->send_d, (size_t)D * h->PS);
   ALLOC_OR_FAIL(h->recv_d, (size_t)world * D * h->PS);
   ALLOC_OR_FAIL(h->gather_tmp_d, (size_t)world * D * h->PS);
@@ -868,6 +880,16 @@ mppi_status mppi_get_local_rollouts(mppi_handle h, int* k_local, int* k_offset)
     *k_local = h->K_local;
   if (k_offset)
     *k_offset = h->K_offset;
+  return MPPI_OK;
+}
+
+mppi_status mppi_get_launch_counts(mppi_handle h, unsigned long long* rollout_launches, unsigned long long* merge_launches)
+{
+  CHECK_HANDLE(h);
+  if (rollout_launches)
+    *rollout_launches = h->n_rollout_launches;
+  if (merge_launches)
+    *merge_launches = h->n_merge_launches;
   return MPPI_OK;
 }
 
@@ -1460,6 +1482,7 @@ static mppi_status launchCombine(mppi_handle h, const float* records, int num_re
                                  unsigned wait_seq = 0, const kernels::PostTargets* post = nullptr)
 {
   RoctxRange range(finalize ? "mppi:merge" : "mppi:merge_local");
+  h->n_merge_launches++;
   const kernels::CombineArgs a =
       combineArgs(h, records, num_records, finalize, record_out, k_total, world_major, wait_flags, wait_seq, post);
   hipLaunchKernelGGL(kernels::combineKernel, dim3(h->D, kernels::combineGridY(h->TC)), dim3(kernels::MERGE_THREADS), 0,
@@ -1468,9 +1491,32 @@ static mppi_status launchCombine(mppi_handle h, const float* records, int num_re
   return MPPI_OK;
 }
 
+static inline bool tsallisActive(const mppi_handle_s* h);
+/** may the NEXT rollout launch merge the previous launch's records itself (rolloutPipelineKernel STREAM_MERGE)? */
+static bool streamMergeApplies(const mppi_handle_s* h)
+{
+  return h->stream_merge_enabled && h->pipeline && h->bz == 1 && h->D == 1 && h->by == 1 && h->bx == 64 && !h->rows_in_hbm &&
+         !exchangeActive(h) && h->noise_source == MPPI_NOISE_PHILOX_FUSED && h->reduction_mode == MPPI_REDUCTION_FUSED &&
+         !tsallisActive(h) && h->cfg.controller != MPPI_CONTROLLER_ROBUST && (h->TC & 3) == 0 && h->num_blocks <= 256 &&
+         h->model->supportsStreamedMerge();
+}
+static mppi_status launchCombine(mppi_handle h, const float* records, int num_records, int finalize, float* record_out,
+                                 int k_total, bool world_major, const unsigned* wait_flags, unsigned wait_seq,
+                                 const kernels::PostTargets* post);
+/** the records of the last rollout launch are still un-merged: merge them now (combineKernel -> mean_d, stats_d) */
+static mppi_status flushMerge(mppi_handle h)
+{
+  if (!h->pending_records_d)
+    return MPPI_OK;
+  const float* rec = h->pending_records_d;
+  h->pending_records_d = nullptr;
+  return launchCombine(h, rec, h->num_blocks, 1, nullptr, h->cfg.num_rollouts, false, nullptr, 0, nullptr);
+}
+
 static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
 {
   RoctxRange range("mppi:rollout");
+  h->n_rollout_launches++;
   kernels::RolloutArgs a{};
   a.dt = h->cfg.dt;
   a.num_timesteps = h->cfg.num_timesteps;
@@ -1481,6 +1527,19 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   a.trajectory_costs_d = h->costs_d;
   a.partials_d = h->partials_d;
   a.save_samples = h->samples_d ? 1 : 0;
+  a.prev_records_d = nullptr;
+  a.prev_num_records = 0;
+  if (h->pending_records_d)
+  {
+    if (!streamMergeApplies(h))
+      MPPI_TRY(flushMerge(h));  // (a setting changed between two launches: merge the pending records the ordinary way)
+    else
+    {
+      a.prev_records_d = h->pending_records_d;
+      a.prev_num_records = h->num_blocks;
+      h->pending_records_d = nullptr;
+    }
+  }
   SamplerLaunchState s{};
   s.num_rollouts_local = h->K_local;
   s.num_rollouts_global = h->cfg.num_rollouts;
@@ -1559,6 +1618,7 @@ static inline bool tsallisActive(const mppi_handle_s* h)
 static mppi_status launchExactReduction(mppi_handle h)
 {
   RoctxRange range("mppi:reduce_reference_order");
+  h->n_merge_launches++;
   kernels::ExactWeightsArgs a{};
   a.num_rollouts = h->K_local;
   a.costs_d = h->costs_d;
@@ -1606,7 +1666,15 @@ static mppi_status iterationLocal(mppi_handle h, int iteration, int stride)
     return MPPI_OK;
   }
   if (!exchangeActive(h))
+  {
+    if (streamMergeApplies(h))
+    {  // leave the records to the next rollout launch (or to flushMerge) and write the next ones into the other buffer
+      h->pending_records_d = h->partials_d;
+      std::swap(h->partials_d, h->partials_alt_d);
+      return MPPI_OK;
+    }
     return launchCombine(h, h->partials_d, h->num_blocks, 1, nullptr, h->cfg.num_rollouts);
+  }
   return launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local);
 }
 
@@ -1641,6 +1709,7 @@ static mppi_status iterationMergeP2P(mppi_handle h)
 static mppi_status launchCombineSharded(mppi_handle h)
 {
   RoctxRange range("mppi:merge_sharded");
+  h->n_merge_launches++;
   const unsigned seq = ++h->xseq;
   const kernels::PostTargets t = p2pTargets(h, seq);
   const float* records;
@@ -1994,6 +2063,7 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     HIP_TRY(h, hipGetLastError());
     for (int it = 0; it < h->cfg.num_iters; it++)
       MPPI_TRY(iteration(h, it, stride));
+    MPPI_TRY(flushMerge(h));  // the last iteration's records (streamed merge): everything below reads mean_d / stats_d
     a.control_out_d = h->io_out_dev + (h->ctrl_out_d - h->out_block_d);
     a.state_out_d = h->io_out_dev + (h->state_out_d - h->out_block_d);
     a.output_out_d = h->io_out_dev + (h->output_out_d - h->out_block_d);
@@ -2025,6 +2095,7 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
   HIP_TRY(h, hipMemcpyAsync(h->in_block_d, in, sizeof(float) * h->in_floats, hipMemcpyHostToDevice, h->stream));
   for (int it = 0; it < h->cfg.num_iters; it++)
     MPPI_TRY(iteration(h, it, stride));
+  MPPI_TRY(flushMerge(h));  // the last iteration's records (streamed merge): everything below reads mean_d / stats_d
   a.control_out_d = h->ctrl_out_d;
   a.state_out_d = h->state_out_d;
   a.output_out_d = h->output_out_d;
@@ -2920,6 +2991,7 @@ mppi_status mppi_optimize(mppi_handle h, int n, int synchronize)
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   for (int i = 0; i < n; i++)  // opt_iter of mppi_controller.cu:160: std_dev_decay^i shapes iteration i of this call
     MPPI_TRY(iteration(h, i, h->last_stride));
+  MPPI_TRY(flushMerge(h));  // streamed merge: the last iteration's records become mean_d / stats_d here
   if (synchronize)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPPI_OK;
@@ -2940,6 +3012,7 @@ mppi_status mppi_time_iterations(mppi_handle h, int n, float* ms_total, float* m
     HIP_TRY(h, hipEventRecord(h->ev_a, h->stream));
     for (int i = 0; i < n; i++)
       MPPI_TRY(iteration(h, 0, h->last_stride));
+    MPPI_TRY(flushMerge(h));  // the n-th iteration's merge belongs to the n timed iterations
     HIP_TRY(h, hipEventRecord(h->ev_b, h->stream));
     HIP_TRY(h, hipEventSynchronize(h->ev_b));
     HIP_TRY(h, hipEventElapsedTime(ms_total, h->ev_a, h->ev_b));
@@ -2952,13 +3025,22 @@ mppi_status mppi_time_iterations(mppi_handle h, int n, float* ms_total, float* m
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipEventRecord(h->ev_a, h->stream));
     for (int i = 0; i < n; i++)
+    {
       MPPI_TRY(launchRollout(h, 0, h->last_stride));
+      if (streamMergeApplies(h))
+      {  // the kernel that is timed is the one iterations run: it merges the previous launch's records in its sampler waves
+        h->pending_records_d = h->partials_d;
+        std::swap(h->partials_d, h->partials_alt_d);
+      }
+    }
     HIP_TRY(h, hipEventRecord(h->ev_b, h->stream));
     HIP_TRY(h, hipEventSynchronize(h->ev_b));
     float sum = 0.0f;
     HIP_TRY(h, hipEventElapsedTime(&sum, h->ev_a, h->ev_b));
     // leave the handle as an iteration would: merged records, updated mean
-    if (!exchangeActive(h))
+    if (h->pending_records_d)
+      MPPI_TRY(flushMerge(h));
+    else if (!exchangeActive(h))
       MPPI_TRY(launchCombine(h, h->partials_d, h->num_blocks, 1, nullptr, h->cfg.num_rollouts));
     else
       MPPI_TRY(launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local));
@@ -3069,7 +3151,8 @@ mppi_status mppi_iteration_local(mppi_handle h)
   CHECK_HANDLE(h);
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   // the caller drives the optimisation loop: its iteration index (std_dev_decay) restarts with mppi_upload_state
-  return iterationLocal(h, h->external_iteration++, h->last_stride);
+  MPPI_TRY(iterationLocal(h, h->external_iteration++, h->last_stride));
+  return flushMerge(h);  // (a caller-driven loop sees every iteration's mean: no streamed merge across its calls)
 }
 mppi_status mppi_iteration_merge(mppi_handle h)
 {

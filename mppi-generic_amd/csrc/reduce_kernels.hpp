@@ -23,6 +23,7 @@
 #include <math.h>
 #include "mppi_amd/det_math.h"
 #include "mppi_amd/utils/wave_ops.hpp"
+#include "mppi_amd/engine/merge_wave.hpp"
 
 namespace mppi
 {
@@ -124,11 +125,9 @@ static __device__ unsigned long long g_combine_timing[4 * 8];
 using mppi::wave::waveAllMin;  // wave64 all-reduces on DPP + v_readlane (include/mppi_amd/utils/wave_ops.hpp)
 using mppi::wave::waveAllSum;
 
-constexpr int MERGE_COLS = 4;       ///< columns of u* per wave
 constexpr int MERGE_WAVES = 1;      ///< waves per block: ONE — a wave's loads touch 64 cache lines per instruction (lane = record, rows
                                     ///< 416 B apart), and four waves queueing on one CU's address unit took 3.3 us to get their loads out
 constexpr int MERGE_THREADS = 64 * MERGE_WAVES;
-constexpr int MERGE_LANE_RECORDS = 4;  ///< records a lane keeps in registers: up to 256 records without a second pass
 /** y extent of combineKernel's grid: ceil(T C / MERGE_COLS) column waves + one wave for the record tail / the statistics */
 __host__ __device__ inline int combineGridY(const int TC)
 {
@@ -161,12 +160,7 @@ __device__ inline void combineWave(const CombineArgs& a, const int z, const int 
   const float lambda_inv = (float)(1.0 / (double)a.lambda);
   const int n = a.num_records;
   const int col0 = wave_global * MERGE_COLS;
-  // a record whose rollouts all cost +inf has rho_b = inf and U_b = eta_b = 0: scale 0 (inf - inf would be NaN when the
-  // global minimum is inf as well — then nothing has weight, as with the reference's global baseline)
-  auto scale = [&](const float rho_b, const float rho) {
-    const float dist = rho_b - rho;
-    return (dist == dist) ? mppi::det::exp(-lambda_inv * dist) : 0.0f;
-  };
+  auto scale = [&](const float rho_b, const float rho_) { return mergeScale(rho_b, rho_, lambda_inv); };
   float rho, tot[MERGE_COLS];
   double eta = 0.0, eta2 = 0.0;
   if (n <= 64 * MERGE_LANE_RECORDS)
@@ -205,33 +199,14 @@ __device__ inline void combineWave(const CombineArgs& a, const int z, const int 
         v[i][c] = (ok && !stats_wave && col0 + c < a.TC) ? mergeLoad<MAILBOX>(r + col0 + c) : 0.0f;
     }
     COMBINE_T(1);
-    float m = rho_b[0];
-#pragma unroll
-    for (int i = 1; i < MERGE_LANE_RECORDS; i++)
-      m = fminf(m, rho_b[i]);
-    COMBINE_T(2);  // the loads have arrived
-    rho = waveAllMin(m);
+    MergeTails mt;
+    mergeTails(rho_b, eta_b, eta2_b, lambda_inv, mt);  // (the first use of a loaded value waits for the round trip)
     COMBINE_T(3);
-    float acc[MERGE_COLS];
-#pragma unroll
-    for (int c = 0; c < MERGE_COLS; c++)
-      acc[c] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < MERGE_LANE_RECORDS; i++)
-    {
-      const float s = scale(rho_b[i], rho);  // 0 for the padding records (rho_b = inf unless everything is inf: then eta_b = 0)
-      eta += (double)s * (double)eta_b[i];
-      eta2 += (double)s * (double)s * (double)eta2_b[i];
-#pragma unroll
-      for (int c = 0; c < MERGE_COLS; c++)
-        acc[c] += s * v[i][c];
-    }
+    rho = mt.rho;
+    eta = mt.eta;
+    eta2 = mt.eta2;
     COMBINE_T(4);
-    eta = waveAllSum(eta);
-    eta2 = waveAllSum(eta2);
-#pragma unroll
-    for (int c = 0; c < MERGE_COLS; c++)
-      tot[c] = waveAllSum(acc[c]);
+    mergeColumns(mt.s, v, tot);
     COMBINE_T(5);
   }
   else

@@ -20,9 +20,10 @@ import isa_tu  # noqa: E402
 
 # (key, translation unit, kernel-name substrings, steps per trip of the dynamics loop, marker class)
 KERNELS = [
-    # (template tails: <.., BZ = 1, DRAW_IN_LOOP, FOLD_Z = false, ROWS_HBM = false> / <.., DRAW_IN_LOOP, ROWS_HBM = false>)
+    # (template tails: <.., BZ = 1, DRAW_IN_LOOP, FOLD_Z = false, ROWS_HBM = false, STREAM_MERGE = true> — the instantiation the
+    #  iterations of the headline run — / <.., DRAW_IN_LOOP, ROWS_HBM = false>)
     ("cartpole_pipeline_dynamics_wave", "cartpole.hip",
-     ["rolloutPipelineKernel", "Cartpole", "GaussianDistribution", "ELi1ELb1ELb0ELb0EE"], 8, "valu_pk"),  # round 4: eight steps per trip
+     ["rolloutPipelineKernel", "Cartpole", "GaussianDistribution", "ELi1ELb1ELb0ELb0ELb1EE"], 8, "valu_pk"),  # round 4: eight steps per trip
     ("autorally_mfma_pipeline_dynamics_wave", "autorally_nn.hip",
      ["rolloutPipelineRepKernel", "NeuralNetModelMFMA", "GaussianDistribution", "ELb1ELb0EE"], None, "mfma"),
     ("lstm_mfma_pipeline_dynamics_wave", "bicycle_slip_lstm.hip",

@@ -32,7 +32,7 @@ def main():
     eng.optimize(50)
     n_it = 200
     tot, roll = eng.timeIterations(n_it)
-    eng.optimize(1)
+    eng.optimize(2)  # the stamps of the LAST launch: the second one merges the first one's records in its sampler waves
     buf = (C.c_ulonglong * (BLOCKS * WAVES * SLOTS))()
     n = lib.mppi_debug_read_pipe_timing_cartpole(buf, len(buf))
     assert n == len(buf), n
@@ -80,6 +80,11 @@ def main():
         "work_4_steps": [us(v) for v in per(2).mean(axis=0)],
         "sampler_wave_0_its_trips": [us(v) for v in per(3).mean(axis=0)[:13]],
     }
+    # streamed merge: the stages of sampler wave 0's first trip, microseconds since kernel entry (zero when the launch did not stream)
+    st = per(4).mean(axis=0)
+    out["sampler_wave_0_first_trip_since_entry_us"] = {
+        "record loads issued": us(st[0]), "draw done": us(st[1]), "tails merged (rho, scales, eta)": us(st[2]),
+        "first four columns of the mean merged": us(st[3]), "samples shaped and stored": us(st[4])}
     d = out["dynamics_wave"]
     out["dynamics_work_share_of_block_life"] = round(d["work_100_steps"] / out["across_blocks_real_time_us"]["block_life_mean"], 3)
     out["dynamics_work_share_of_launch"] = round(d["work_100_steps"] / kernel_us, 3)
