@@ -283,13 +283,21 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
   constexpr int TRIP_COLS = SMP_STEPS * C;                 // columns of the mean a trip shapes with
   constexpr int TRIP_GROUPS = TRIP_COLS / MERGE_COLS;      // = C quads of four columns
   // STREAM_MERGE state of a sampler wave: what the record tails gave (once) and the column quads of its NEXT trip (in flight)
+  // The loaded quads stay RAW until the trip that consumes them: a select on a padding record next to the load is a use, and
+  // the compiler waits for the load right there — the tails, the first quads and every trip's "prefetch" each cost their own
+  // exposed memory round trip that way (ISA of round 4: three back-to-back vmcnt(0) in front of the first draw).
+  typedef float merge_f4 __attribute__((ext_vector_type(4)));
   MergeTails mt;
-  float vq[STREAM_MERGE ? TRIP_GROUPS : 1][MERGE_LANE_RECORDS][MERGE_COLS];
+  merge_f4 vq[STREAM_MERGE ? TRIP_GROUPS : 1][MERGE_LANE_RECORDS];
+  // the records' tails (rho_b, eta_b; the sum of w^2 behind them is the statistics' business): loaded at kernel entry.  Eight
+  // bytes, not the whole 16-byte tail: the register allocator hands the dead half of a wider load's destination to the next
+  // load while the first is still in flight, and the hazard costs a wait in between (ISA of round 4)
+  typedef float merge_f2 __attribute__((ext_vector_type(2)));
+  merge_f2 tailq[MERGE_LANE_RECORDS];
   const int TC_all = num_timesteps * C;
   auto load_trip_columns = [&](const int t) {
     if constexpr (STREAM_MERGE)
     {
-      typedef float merge_f4 __attribute__((ext_vector_type(4)));
       const int PS = partialStride(num_timesteps, C);
 #pragma unroll
       for (int g = 0; g < TRIP_GROUPS; g++)
@@ -299,17 +307,12 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
         for (int i = 0; i < MERGE_LANE_RECORDS; i++)
         {
           const int b = lane + 64 * i;
-          const bool ok = b < args.prev_num_records && col0 < TC_all;
-          const merge_f4 q = *reinterpret_cast<const merge_f4*>(args.prev_records_d + (size_t)(ok ? b : 0) * PS + (ok ? col0 : 0));
-          vq[g][i][0] = ok ? q.x : 0.0f;
-          vq[g][i][1] = ok ? q.y : 0.0f;
-          vq[g][i][2] = ok ? q.z : 0.0f;
-          vq[g][i][3] = ok ? q.w : 0.0f;
+          const bool ok = b < args.prev_num_records && col0 < TC_all;  // (else: any valid address; the value is not used)
+          vq[g][i] = *reinterpret_cast<const merge_f4*>(args.prev_records_d + (size_t)(ok ? b : 0) * PS + (ok ? col0 : 0));
         }
       }
     }
   };
-  float rho_b[MERGE_LANE_RECORDS], eta_b[MERGE_LANE_RECORDS], eta2_b[MERGE_LANE_RECORDS];  // record tails (STREAM_MERGE), in flight
   auto sampler_trip = [&](const int t, auto first_trip) {
     constexpr int QUADS = C;  // SMP_STEPS * C / 4
     float zq[4 * QUADS];
@@ -326,14 +329,42 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
       // first trip: the tails' loads were issued at kernel entry and are first touched here, BEHIND the draw — the Philox
       // rounds run under the memory round trip instead of after it
       if constexpr (decltype(first_trip)::value)
+      {
+        // The draw stays HERE, between the loads' issue and their first use: left alone the compiler sinks the whole draw below
+        // the merge (its results are only needed by the shaping at the end) and consumes the loads at once — the wave then sits
+        // out the memory round trip and draws afterwards instead of drawing under it.  The empty asm uses the normals, so they
+        // exist at this point; the scheduling barrier keeps the merge's arithmetic below it.
+#pragma unroll
+        for (int q = 0; q < 4 * QUADS; q++)
+          asm volatile("" : "+v"(zq[q]));
+        __builtin_amdgcn_sched_barrier(0);
+        float rho_b[MERGE_LANE_RECORDS], eta_b[MERGE_LANE_RECORDS], eta2_b[MERGE_LANE_RECORDS];
+#pragma unroll
+        for (int i = 0; i < MERGE_LANE_RECORDS; i++)
+        {
+          const bool ok = lane + 64 * i < args.prev_num_records;
+          rho_b[i] = ok ? tailq[i].x : INFINITY;
+          eta_b[i] = ok ? tailq[i].y : 0.0f;
+          eta2_b[i] = 0.0f;  // (MergeTails::eta2 is not used here)
+        }
         mergeTails(rho_b, eta_b, eta2_b, (float)(1.0 / (double)args.lambda), mt);
+      }
       PIPE_T(if (decltype(first_trip)::value && smp_id == 0) tm.trip(block_idx, 4, 2, lane, __builtin_amdgcn_s_memtime() - tm.t0);)
       // this trip's part of u* of the previous iteration: the merge kernel's arithmetic on the quads loaded a trip ago
 #pragma unroll
       for (int g = 0; g < TRIP_GROUPS; g++)
       {
-        float tot[MERGE_COLS];
-        mergeColumns(mt.s, vq[g], tot);
+        float v[MERGE_LANE_RECORDS][MERGE_COLS], tot[MERGE_COLS];
+#pragma unroll
+        for (int i = 0; i < MERGE_LANE_RECORDS; i++)
+        {
+          const bool ok = lane + 64 * i < args.prev_num_records;  // a padding record counts as zeros (combineWave's rule)
+          v[i][0] = ok ? vq[g][i].x : 0.0f;
+          v[i][1] = ok ? vq[g][i].y : 0.0f;
+          v[i][2] = ok ? vq[g][i].z : 0.0f;
+          v[i][3] = ok ? vq[g][i].w : 0.0f;
+        }
+        mergeColumns(mt.s, v, tot);
 #pragma unroll
         for (int c = 0; c < MERGE_COLS; c++)
         {
@@ -371,19 +402,15 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
     {
       // the record tails (one 16-byte load per record and lane) and the first trip's quads: one memory round trip, under which
       // the first draw runs (the loads' results are first touched by mergeTails inside the first trip)
-      typedef float merge_f4 __attribute__((ext_vector_type(4)));
       const int PS = partialStride(num_timesteps, C);
 #pragma unroll
       for (int i = 0; i < MERGE_LANE_RECORDS; i++)
       {
         const int b = lane + 64 * i;
-        const bool ok = b < args.prev_num_records;
-        const merge_f4 tail = *reinterpret_cast<const merge_f4*>(args.prev_records_d + (size_t)(ok ? b : 0) * PS + TC_all);
-        rho_b[i] = ok ? tail.x : INFINITY;
-        eta_b[i] = ok ? tail.y : 0.0f;
-        eta2_b[i] = ok ? tail.z : 0.0f;
+        tailq[i] = *reinterpret_cast<const merge_f2*>(args.prev_records_d + (size_t)(b < args.prev_num_records ? b : 0) * PS + TC_all);
       }
       load_trip_columns(SMP_STEPS * smp_id);
+      asm volatile("" ::: "memory");  // the loads are issued here, not sunk to their first use behind the draw
       PIPE_T(if (smp_id == 0) tm.trip(block_idx, 4, 0, lane, __builtin_amdgcn_s_memtime() - tm.t0);)
     }
   }
