@@ -55,20 +55,21 @@ def _latest_pmc_file():
 PMC_FILE = _latest_pmc_file()
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the kernel whose (shortened) name starts with kernel_prefix, from the committed PMC passes
-    (tools/profile_bench.sh + tools/pmc_summary.py -> profiles/), or None"""
+def pmc_traffic(kernel_prefix, suffix=""):
+    """HBM bytes per launch of the kernel whose (shortened) name starts with kernel_prefix (and ends with suffix: the tail of the
+    template arguments tells instantiations of one kernel apart), from the committed PMC passes (tools/profile_bench.sh +
+    tools/pmc_summary.py -> profiles/), or None"""
     try:
         d = json.load(open(os.path.join(REPO, PMC_FILE)))
         for name, e in d["kernels"].items():
-            if name.startswith(kernel_prefix) and e.get("hbm_traffic_bytes_per_launch"):
+            if name.startswith(kernel_prefix) and name.endswith(suffix) and e.get("hbm_traffic_bytes_per_launch"):
                 return round(e["hbm_traffic_bytes_per_launch"], 1)
     except Exception:  # noqa: BLE001
         pass
     return None
 
 
-def pmc_pipe_util(kernel_prefix):
+def pmc_pipe_util(kernel_prefix, suffix=""):
     """{"mfma_util_percent", "valu_busy_percent"} of the kernel from the committed SQ counter pass
     (tools/profile_bench.sh + tools/pmc_mfma_summary.py -> profiles/r*_pmc_mfma_valu.json), or None"""
     import glob
@@ -76,7 +77,7 @@ def pmc_pipe_util(kernel_prefix):
         files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_mfma_valu.json")))
         d = json.load(open(files[-1]))
         for name, e in d["kernels"].items():
-            if name.startswith(kernel_prefix):
+            if name.startswith(kernel_prefix) and name.endswith(suffix):
                 return {"mfma_util_percent": round(e.get("MfmaUtil_percent", 0.0), 2),
                         "valu_busy_percent": round(e.get("VALUBusy_percent", 0.0), 2),
                         "source": os.path.relpath(files[-1], REPO) + " (SQ_VALU_MFMA_BUSY_CYCLES, SQ_ACTIVE_INST_VALU, "
@@ -117,7 +118,16 @@ def cpu_baseline(cfg, budget_s=12.0, label=None):
     }
 
 
-def latency_model(device, iteration_us):
+def launches_per_iteration(eng, n=100):
+    """kernel launches one optimisation iteration costs on this handle, counted by the library (mppi_get_launch_counts): 2
+    (rollout + merge) or — where the rollout kernel merges the previous records in its sampler waves — 1"""
+    r0, g0 = eng.launchCounts()
+    eng.optimize(n, True)
+    r1, g1 = eng.launchCounts()
+    return int(round((r1 - r0 + g1 - g0) / float(n)))
+
+
+def latency_model(device, iteration_us, n_launch=2):
     """What bounds an iteration of this design at K=16384 (t_floor ~ T * t_step + n_launch * t_launch), measured
     live: the rollout kernel against T (slope = time of one dependent rollout step on the dynamics wave, intercept = launch
     ramp + prologue + block softmin epilogue + one launch boundary, since the launches are timed back to back), and the
@@ -129,7 +139,7 @@ def latency_model(device, iteration_us):
     # trace's row for rolloutPipelineKernel<Cartpole> holds nothing but the headline configuration
     if os.environ.get("MPPI_BENCH_NO_TSCAN"):
         return {"skipped": "MPPI_BENCH_NO_TSCAN set (traced run: the T scan shares the headline kernel's name)"}
-    ts, us = [25, 50, 100, 200], []
+    ts, us = [24, 52, 100, 200], []  # multiples of 4: every T runs the kernel form the headline runs (streamed merge)
     for tt in ts:
         e = make_engine(cartpole_cfg(K=K_PER_GPU, T=tt), device=device)
         e.uploadState(np.zeros(4, np.float32))
@@ -139,13 +149,16 @@ def latency_model(device, iteration_us):
         e.close()
     slope, intercept = np.polyfit(np.asarray(ts, np.float64), np.asarray(us, np.float64), 1)
     boundary = m.launch_boundary_us(device, 400)
-    floor = slope * T + intercept + boundary  # rollout kernel (its boundary is in the intercept) + the merge launch's boundary
+    # rollout kernel (its own boundary is in the intercept) + the boundary of every further launch of an iteration
+    floor = slope * T + intercept + (n_launch - 1) * boundary
     return {"t_scan_T": ts, "t_scan_kernel_us": [round(u, 2) for u in us], "step_ns": round(slope * 1e3, 1),
-            "fixed_us": round(intercept, 2), "launch_boundary_us": round(boundary, 2), "n_launch": 2,
+            "fixed_us": round(intercept, 2), "launch_boundary_us": round(boundary, 2), "n_launch": n_launch,
             "latency_floor_us": round(floor, 2), "iteration_us": round(iteration_us, 2),
             "frac_of_floor": round(floor / iteration_us, 4),
-            "definition": "latency_floor_us = step_ns * T + fixed_us + launch_boundary_us: the rollout kernel as it is plus the "
-                          "bare boundary of the merge launch; iteration - floor = the merge kernel's own two memory round trips"}
+            "definition": "latency_floor_us = step_ns * T + fixed_us + (n_launch - 1) * launch_boundary_us: the rollout kernel as "
+                          "it is (n_launch = 1: it merges the previous iteration's records in its sampler waves, and the one "
+                          "merge launch at the end of a loop is spread over its iterations) plus the bare boundary of a "
+                          "separate merge launch where there is one"}
 
 
 def isa_step_counts():
@@ -783,13 +796,17 @@ def main():
     else:
         b_alg = 4.0 * (2.0 * k_local * t_steps * C_dim + 2.0 * k_local + 2.0 * t_steps * C_dim)
         achieved = b_alg / (roll_us * 1e-6) / 1e9
+        # one GPU: the instantiation that merges the previous iteration's records in its sampler waves (STREAM_MERGE = true);
+        # K-sharded: the plain one, the merge is combineShardedKernel
+        tail = "false, false, true>" if world == 1 else "false, false, false>"
         roofline = {
-            "bound": "hbm", "kernel": "rolloutPipelineKernel<CartpoleDynamics,CartpoleQuadraticCost,Gaussian,1,true>",
+            "bound": "hbm", "kernel": "rolloutPipelineKernel<CartpoleDynamics, CartpoleQuadraticCost, GaussianDistribution<"
+                                      "CartpoleDynamicsParams>, 1, true, " + tail,
             "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": pmc_traffic("rolloutPipelineKernel<CartpoleDynamics") if k_local == K_PER_GPU else None,
+            "traffic": pmc_traffic("rolloutPipelineKernel<CartpoleDynamics", tail) if k_local == K_PER_GPU else None,
             "traffic_static_from_profiles": PMC_FILE,
-            "pipe_utilisation_static_from_profiles": pmc_pipe_util("rolloutPipelineKernel<CartpoleDynamics"),
+            "pipe_utilisation_static_from_profiles": pmc_pipe_util("rolloutPipelineKernel<CartpoleDynamics", tail),
             "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, " + PMC_FILE + " "
                               "(2*FETCH_SIZE + WRITE_SIZE), collected by the builder, NOT in this run: the sample tensor never "
                               "reaches HBM, so traffic << algorithmic bytes",
@@ -800,12 +817,14 @@ def main():
                     "~17 % more time, DESIGN.md §5); see issue_floor for a floor that does not depend on the kernel's own timing",
         }
         if world == 1:
+            n_launch = launches_per_iteration(sr.eng)
+            roofline["launches_per_iteration"] = n_launch
             try:
-                roofline["issue_floor"] = issue_floor(local_rank, iter_us, roll_us)
+                roofline["issue_floor"] = issue_floor(local_rank, iter_us, roll_us, n_launch=n_launch)
             except Exception as e:  # noqa: BLE001
                 roofline["issue_floor"] = {"error": str(e)}
             try:
-                roofline["latency_model"] = latency_model(local_rank, iter_us)
+                roofline["latency_model"] = latency_model(local_rank, iter_us, n_launch)
             except Exception as e:  # noqa: BLE001
                 roofline["latency_model"] = {"error": str(e)}
     exchange_info = dict(sr.exchange)
