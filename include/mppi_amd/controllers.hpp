@@ -134,6 +134,11 @@ public:
   {
     check(mppi_set_reduction_mode(h_, mode));
   }
+  /** kernel launches since construction: rollout launches, launches of the reduction stage (mppi_get_launch_counts) */
+  void getLaunchCounts(unsigned long long& rollout_launches, unsigned long long& merge_launches) const
+  {
+    check(mppi_get_launch_counts(h_, &rollout_launches, &merge_launches));
+  }
   void setSeed(unsigned long long seed)
   {
     check(mppi_set_seed(h_, seed));
