@@ -326,10 +326,14 @@ def autorally_leg(device, with_cpu_baseline=True):
     eng = make_engine(cfg, device=device)
     eng.uploadState(cfg["x0"])
     eng.optimize(20, True)
-    n = 100
-    t0 = time.perf_counter()
-    eng.optimize(n, True)
-    wall = time.perf_counter() - t0
+    # 400 iterations per timed call, best of three: a call's fixed part (first enqueue, the wake-up after the synchronisation —
+    # ~0.6 ms here) was 3 % of a 100-iteration call
+    n = 400
+    wall = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        eng.optimize(n, True)
+        wall = min(wall, time.perf_counter() - t0)
     ms_total, ms_roll = eng.timeIterations(50)
     roll_us = ms_roll / 50 * 1e3
     f_alg = 2.0 * (6 * 32 + 32 * 32 + 32 * 4) * K * Tn
@@ -373,10 +377,12 @@ def lstm_colored_leg(device):
     eng = make_engine(cfg, device=device)
     eng.uploadState(cfg["x0"])
     eng.optimize(5, True)
-    n = 30
-    t0 = time.perf_counter()
-    eng.optimize(n, True)
-    wall = time.perf_counter() - t0
+    n = 60
+    wall = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        eng.optimize(n, True)
+        wall = min(wall, time.perf_counter() - t0)
     ms_total, ms_roll = eng.timeIterations(20)
     roll_us = ms_roll / 20 * 1e3
     f_net = 2.0 * (4 * 16 * (6 + 16) + (16 + 6) * 32 + 32 * 4) * K * Tn
