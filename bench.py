@@ -823,6 +823,11 @@ def main():
                     "~17 % more time, DESIGN.md §5); see issue_floor for a floor that does not depend on the kernel's own timing",
         }
         if world == 1:
+            roofline["note"] += ("; on one GPU this kernel also does the softmin merge of the previous iteration's block records "
+                                 "(in its sampler waves — until round 4 a second launch of 3.3 us + a 1.55 us boundary), so its "
+                                 "duration is the whole iteration: compare frac with (rollout + merge) of earlier rounds, "
+                                 "13.24 MB / 27.0 us = 0.061, not with the rollout kernel alone")
+        if world == 1:
             n_launch = launches_per_iteration(sr.eng)
             roofline["launches_per_iteration"] = n_launch
             try:
