@@ -26,14 +26,30 @@ INCLUDE = os.path.join(REPO, "include")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
+# Flags of single translation units (file name -> extra flags), decided by A/B measurement on the MI355X, never by guess.
+#   cartpole.hip: the GCN scheduler's max-ILP strategy (same instructions, another order — results bit-identical, the parity
+#   suite runs on it): Cartpole K=16384, T=100 iteration 24.27 -> 23.79 us in one session (round 4; `buildlib.py --variant
+#   maxilp all -mllvm -amdgpu-sched-strategy=max-ilp` is the experiment).  The same flag on every unit: AutoRally-NN +-0 although
+#   its dynamics wave loses 14 % of its instructions (83 of 83 s_nop per two steps are gone — they were not what bounds it),
+#   LSTM + colored -1.3 %, DI Tube -1.5 %, Robust MPPI 3-12 % slower, the elevation models -1.3 .. +3.2 %: not applied there.
+UNIT_FLAGS = {
+    "cartpole.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+}
+
 
 def _hipcc():
     return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-def _flags():
+def _flags(tu=None):
     extra = os.environ.get("MPPI_HIPCC_EXTRA", "")
-    return FLAGS + (extra.split() if extra else []) + ["-I" + INCLUDE, "-I" + CSRC]
+    unit = UNIT_FLAGS.get(os.path.basename(tu), []) if tu else []
+    return FLAGS + unit + (extra.split() if extra else []) + ["-I" + INCLUDE, "-I" + CSRC]
+
+
+def unit_flags(tu):
+    """the per-unit flags of a translation unit (tools/isa_tu.py compiles with them too)"""
+    return list(UNIT_FLAGS.get(os.path.basename(tu), []))
 
 
 def translation_units():
@@ -58,6 +74,7 @@ def source_hash():
     """sha256 over (relative path, contents) of every source the library is built from + the compiler flags"""
     h = hashlib.sha256()
     h.update(" ".join(_flags()[:len(FLAGS)] + os.environ.get("MPPI_HIPCC_EXTRA", "").split()).encode())
+    h.update(repr(sorted(UNIT_FLAGS.items())).encode())
     for s in _sources():
         h.update(os.path.relpath(s, REPO).encode())
         with open(s, "rb") as f:
@@ -102,12 +119,12 @@ def _obj_stale(tu, obj, flag_sig):
 
 def _compile(tu, verbose):
     obj = _obj_path(tu)
-    flag_sig = " ".join(_flags())
+    flag_sig = " ".join(_flags(tu))
     if not _obj_stale(tu, obj, flag_sig):
         return obj, 0.0
     import time
     t0 = time.time()
-    cmd = [_hipcc()] + _flags() + ["-MD", "-MF", obj + ".d", "-c", tu, "-o", obj]
+    cmd = [_hipcc()] + _flags(tu) + ["-MD", "-MF", obj + ".d", "-c", tu, "-o", obj]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -137,7 +154,7 @@ def build_variant(tag, extra_flags, only=None, verbose=False):
 
     def one(job):
         tu, obj = job
-        cmd = [_hipcc()] + _flags() + list(extra_flags) + ["-c", tu, "-o", obj]
+        cmd = [_hipcc()] + _flags(tu) + list(extra_flags) + ["-c", tu, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -32,6 +32,9 @@ def disassemble(tu):
     co, s = os.path.join(WORK, name + ".co"), os.path.join(WORK, name + ".s")
     if not os.path.exists(s) or os.path.getmtime(s) < newest_source_mtime():
         extra = os.environ.get("MPPI_HIPCC_EXTRA", "").split()
+        sys.path.insert(0, os.path.join(REPO, "mppi-generic_amd"))
+        import buildlib  # the unit's own flags (buildlib.UNIT_FLAGS): the ISA that is counted is the ISA that ships
+        extra = buildlib.unit_flags(tu) + extra
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"] + extra +
                        ["-I" + os.path.join(REPO, "include"), "-I" + os.path.join(REPO, "mppi-generic_amd", "csrc"),
                         "--cuda-device-only", "--no-gpu-bundle-output", "-c", tu, "-o", co], check=True)
