@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
 #pragma unroll
   for (int i = 0; i < S; i++)
   {
-    x[i] = args.init_x_d[S * thread_idz + i];
+    x[i] = 0.0f;  // the initial state is fetched behind the samplers' first trip (below): nothing in front of it reads the state
     xdot[i] = 0.0f;
     x_next[i] = 0.0f;
   }
@@ -416,6 +416,12 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
   }
   if (EARLY_FIRST_TRIP && role == 0 && SMP_STEPS * smp_id < num_timesteps)
     sampler_trip(SMP_STEPS * smp_id, std::true_type{});
+  // The initial state: a scalar load through a pointer out of the kernel arguments, i.e. a second dependent round trip after
+  // the arguments' own.  Up here it stood between kernel entry and the sampler waves' first loads (STREAM_MERGE: the record
+  // tails, the critical path of the launch); the waves that need the state wait at the barrier below anyway.
+#pragma unroll
+  for (int i = 0; i < S; i++)
+    x[i] = args.init_x_d[S * thread_idz + i];
 
   if (lane == 0 && wave_x == 0)
   {
