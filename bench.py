@@ -818,6 +818,8 @@ def main():
                               "reaches HBM, so traffic << algorithmic bytes",
             "algorithmic_bytes_per_launch": b_alg, "avg_kernel_us": round(roll_us, 3),
             "avg_iteration_us_event_timed": round(iter_us, 3),
+            # SURVEY.md §8d prices the roofline on the whole iteration (t_iter), the contract on the dominant kernel: both
+            "frac_on_iteration": round(b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
             "note": "the HBM roofline is the ceiling SURVEY.md §8d assigns, not the one that binds: the kernel is issue-bound on "
                     "the dynamics wave (T dependent Euler steps per rollout, one wave per CU at K=16384 — K=32768 costs only "
                     "~17 % more time, DESIGN.md §5); see issue_floor for a floor that does not depend on the kernel's own timing",
