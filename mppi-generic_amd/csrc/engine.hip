@@ -1793,7 +1793,7 @@ static mppi_status iteration(mppi_handle h, int it, int stride)
     return iterationShardedTsallis(h, it, stride);
   }
   if (exchangeActive(h) && h->p2p_ready)
-  {  // two launches, as un-sharded: rollout, then merge + post + wait + merge in one kernel
+  {  // two launches: rollout, then merge + post + wait + merge in one kernel
     MPPI_TRY(launchRollout(h, it, stride));
     return launchCombineSharded(h);
   }

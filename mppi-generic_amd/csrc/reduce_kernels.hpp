@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(MERGE_THREADS) combineKernel(const CombineArgs
  *   2. takes a ticket; the wave that takes the last one raises this exchange's flag at every peer,
  *   3. waits (bounded) until every peer's flag shows this exchange, and
  *   4. merges the world's records from its own mailbox into u* (combineWave, finalize = 1).
- * A sharded iteration is then the two launches of an un-sharded one — rollout, merge — plus one hop.  Round 3 ran steps 1-2
+ * A sharded iteration is then two launches — rollout, merge — plus one hop.  Round 3 ran steps 1-2
  * and 3-4 as two launches (5.6 us apart on a ~32 us iteration).  No wave waits for another wave of this launch (the ticket is
  * taken, not awaited; what is awaited comes from other GPUs), so the grid needs no co-residency guarantee.
  */
