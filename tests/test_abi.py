@@ -93,3 +93,42 @@ def test_committed_isa_step_counts_match_the_sources(lib):
         for f in ("loop_instructions", "steps_per_trip", "instructions_per_step", "vector_instructions_per_step"):
             assert got[key][f] == e[f], "%s.%s: committed %s, sources compile to %s" % (key, f, e[f], got[key][f])
     assert "double_integrator_robust" in lib.mppi_list_models().decode().split("\n")
+
+
+def test_streamed_merge_first_trip_keeps_its_shape_in_the_isa(lib):
+    """The streamed merge (rolloutPipelineKernel, STREAM_MERGE) is only worth its launch if the record loads of a sampler wave's
+    first trip FLY UNDER its first draw — which the compiler undoes when left alone (round 4: selects next to the loads, the
+    dead half of wider loads reused as another load's destination, the draw sunk below the merge: three exposed round trips,
+    4.6 instead of 3.4 us to the first sample).  Checked on the ISA of the built unit, in program order of the sampler wave's
+    entry path: tail loads and column-quad loads issued -> Philox rounds (v_mul_hi_u32) -> the first wait for a load.  And the
+    kernel keeps everything in registers (no scratch)."""
+    import re
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import isa_tu
+    path, _ = isa_tu.disassemble(os.path.join(REPO, "mppi-generic_amd", "csrc", "models", "cartpole.hip"))
+    lines = open(path).read().split("\n")
+    heads = [i for i, l in enumerate(lines) if re.match(r"^[0-9a-f]{16} <", l)] + [len(lines)]
+    body = None
+    for a, b in zip(heads, heads[1:]):
+        if "rolloutPipelineKernel" in lines[a] and "ELi1ELb1ELb0ELb0ELb1EE" in lines[a]:
+            body = [l.split("//")[0].strip() for l in lines[a + 1:b]]
+    assert body, "the STREAM_MERGE instantiation of rolloutPipelineKernel<Cartpole> is not in cartpole.hip's code object"
+    first = lambda pat: next(i for i, l in enumerate(body) if re.search(pat, l))  # noqa: E731
+    tails, quads = first(r"^global_load_dwordx2 "), first(r"^global_load_dwordx4 ")
+    draw, wait = first(r"^v_mul_hi_u32 "), first(r"^s_waitcnt vmcnt")
+    assert tails < draw and quads < draw, (tails, quads, draw)   # the loads are issued in front of the draw ...
+    assert draw < wait, (draw, wait)                             # ... and nothing waits for them before the draw has started
+    n_mul = sum(1 for l in body[draw:wait] if l.startswith(("v_mul_hi_u32", "s_mul_hi_u32")))
+    assert n_mul >= 16, n_mul                                    # (the ten Philox rounds' high multiplies: the whole draw is in between)
+    co = os.path.splitext(path)[0] + ".co"
+    notes = subprocess.run([isa_tu.LLVM + "llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+    for blk in notes.split("  - .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "rolloutPipelineKernel" in name and "ELi1ELb1ELb0ELb0ELb1EE" in name:
+            assert int(re.search(r"private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0
+            assert int(re.search(r"vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0
+            break
+    else:
+        raise AssertionError("kernel metadata not found")
