@@ -441,7 +441,10 @@ mppi_status mppi_iteration_merge(mppi_handle h);
  * Reconnecting: every rank of the new session calls mppi_p2p_reset (ends the session: flags and records cleared, sequence
  * numbers restart at 1), then exports / connects again before any of them runs its first exchange; mppi_p2p_connect closes the
  * mappings it opened before.  mppi_p2p_mailbox_handle itself has NO side effect on a connected session — it may be called
- * again (a peer that maps late, a caller that simply asks twice) without disturbing records in flight.
+ * again (a peer that maps late, a caller that simply asks twice) without disturbing records in flight.  The rule is ENFORCED:
+ * mppi_p2p_connect on a handle whose session is live or used (sequence numbers != 0) returns MPPI_ERR_STATE instead of
+ * restarting the sequence numbers over the old session's flags (the mailbox cannot be cleared at connect time — a peer that
+ * connected first may already have posted).  The exchange-failure mark is sticky on the device until a session starts.
  */
 mppi_status mppi_p2p_mailbox_handle(mppi_handle h, void* out_bytes, size_t capacity, size_t* nbytes);
 mppi_status mppi_p2p_reset(mppi_handle h);

@@ -290,13 +290,9 @@ static mppi_status ensureExactBuffers(mppi_handle h)
     HIP_TRY(h, hipMalloc((void**)&h->exact_inter_d, sizeof(float) * (size_t)h->D * cells * h->TC));
     h->exact_inter_cells = cells;
   }
-  static bool attr_set = false;
-  if (!attr_set)
-  {
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernels::exactWeightsKernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kernels::EXACT_WEIGHTS_LDS_BYTES));
-    attr_set = true;
-  }
+  // the attribute belongs to (function, device): set per call — it is cheap — rather than once per process
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernels::exactWeightsKernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kernels::EXACT_WEIGHTS_LDS_BYTES));
   return MPPI_OK;
 }
 
@@ -1503,6 +1499,16 @@ static bool streamMergeApplies(const mppi_handle_s* h)
 static mppi_status launchCombine(mppi_handle h, const float* records, int num_records, int finalize, float* record_out,
                                  int k_total, bool world_major, const unsigned* wait_flags, unsigned wait_seq,
                                  const kernels::PostTargets* post);
+/** An iteration loop that leaves through an error must not leave pending_records_d behind: the next call would upload a fresh
+ *  mean and its first launch would merge the stale records over it.  (After a successful flushMerge the pointer is null.) */
+struct PendingRecordsGuard
+{
+  mppi_handle h;
+  ~PendingRecordsGuard()
+  {
+    h->pending_records_d = nullptr;
+  }
+};
 /** the records of the last rollout launch are still un-merged: merge them now (combineKernel -> mean_d, stats_d) */
 static mppi_status flushMerge(mppi_handle h)
 {
@@ -1709,9 +1715,14 @@ static mppi_status iterationMergeP2P(mppi_handle h)
 static mppi_status launchCombineSharded(mppi_handle h)
 {
   RoctxRange range("mppi:merge_sharded");
-  h->n_merge_launches++;
   const unsigned seq = ++h->xseq;
   const kernels::PostTargets t = p2pTargets(h, seq);
+  if (h->D * kernels::combineGridY(h->TC) > kernels::COMBINE_SHARDED_MAX_BLOCKS)
+  {  // the fused form's waves wait for the launch's own last ticket: a grid that cannot be resident at once takes two launches
+    MPPI_TRY(launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local, false, nullptr, 0, &t));
+    return iterationMergeP2P(h);
+  }
+  h->n_merge_launches++;
   const float* records;
   const unsigned* flags;
   p2pInbox(h, seq, &records, &flags);
@@ -2022,6 +2033,8 @@ static mppi_status ensureTrajectories(mppi_handle h)
 static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, int stride)
 {
   const int T = h->cfg.num_timesteps;
+  h->pending_records_d = nullptr;  // this call uploads its own mean: nothing of an earlier (failed) call may be merged over it
+  PendingRecordsGuard guard{ h };
   // ColoredMPPI state leash (colored_mppi_controller.cu:150-156): the optimisation starts from the state of the previous
   // solution at index leash_jump, pulled towards the measured state by at most the leash per dimension
   std::vector<float> leashed;
@@ -2989,6 +3002,7 @@ mppi_status mppi_optimize(mppi_handle h, int n, int synchronize)
   if (n < 0)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_optimize: negative iteration count");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  PendingRecordsGuard guard{ h };
   for (int i = 0; i < n; i++)  // opt_iter of mppi_controller.cu:160: std_dev_decay^i shapes iteration i of this call
     MPPI_TRY(iteration(h, i, h->last_stride));
   MPPI_TRY(flushMerge(h));  // streamed merge: the last iteration's records become mean_d / stats_d here
@@ -3003,6 +3017,7 @@ mppi_status mppi_time_iterations(mppi_handle h, int n, float* ms_total, float* m
   if (n <= 0 || !ms_total)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_time_iterations: bad arguments");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  PendingRecordsGuard guard{ h };
   // pass 1: whole iterations between two events.  Sharded handle whose exchange is driven by the caller (no library
   // communicator): the iteration is not the library's to time — *ms_total = 0 and only the kernel pass below runs.
   *ms_total = 0.0f;
@@ -3066,18 +3081,47 @@ mppi_status mppi_choose_kernel(mppi_handle h, int num_evaluations, int* chosen_v
   float t_ms[2] = { INFINITY, INFINITY };  // [0] fused, [1] pipeline
   const bool was = h->pipeline;
   const uint32_t generation = h->generation;
+  /* What is compared is what an iteration costs with either structure: on a handle that merges on its own (no exchange) the
+   * fused kernel needs a merge launch behind every rollout launch, the pipelined one may merge the previous records in its
+   * sampler waves (one launch per iteration) — timing the bare rollout kernels would hold ~3-5 us per iteration against the
+   * pipeline on small problems.  The trial iterations overwrite mean_d / stats_d: both are saved and put back.  A K-sharded
+   * handle's merge needs its peers and is the same launch for both structures: there the rollout kernels alone are timed. */
+  const bool whole_iterations = !exchangeActive(h) && !tsallisActive(h);
+  PendingRecordsGuard guard{ h };
+  float* saved_d = nullptr;
+  const size_t mean_floats = (size_t)h->D * h->TC, stats_floats = (size_t)h->D * kernels::STATS_STRIDE;
+  if (whole_iterations)
+  {
+    HIP_TRY(h, hipMalloc((void**)&saved_d, sizeof(float) * (mean_floats + stats_floats)));
+    (void)hipMemcpyAsync(saved_d, h->mean_d, sizeof(float) * mean_floats, hipMemcpyDeviceToDevice, h->stream);
+    (void)hipMemcpyAsync(saved_d + mean_floats, h->stats_d, sizeof(float) * stats_floats, hipMemcpyDeviceToDevice, h->stream);
+  }
+  auto trial = [&]() -> mppi_status { return whole_iterations ? iteration(h, 0, h->last_stride) : launchRollout(h, 0, h->last_stride); };
+  auto restore = [&]() {
+    if (!saved_d)
+      return;
+    (void)hipMemcpyAsync(h->mean_d, saved_d, sizeof(float) * mean_floats, hipMemcpyDeviceToDevice, h->stream);
+    (void)hipMemcpyAsync(h->stats_d, saved_d + mean_floats, sizeof(float) * stats_floats, hipMemcpyDeviceToDevice, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(saved_d);
+    saved_d = nullptr;
+  };
   for (int v = 0; v < 2; v++)
   {
     if ((v == 0 && !fused_ok) || (v == 1 && !pipe_ok))
       continue;
     h->pipeline = v == 1;
-    mppi_status st = launchRollout(h, 0, h->last_stride);  // warm-up (code object load, LDS attribute)
+    mppi_status st = trial();  // warm-up (code object load, LDS attribute)
+    if (st == MPPI_OK && whole_iterations)
+      st = flushMerge(h);
     if (st == MPPI_OK)
       st = hipStreamSynchronize(h->stream) == hipSuccess ? MPPI_OK : MPPI_ERR_HIP;
     if (st == MPPI_OK && hipEventRecord(h->ev_a, h->stream) != hipSuccess)
       st = MPPI_ERR_HIP;
     for (int i = 0; st == MPPI_OK && i < num_evaluations; i++)
-      st = launchRollout(h, 0, h->last_stride);
+      st = trial();
+    if (st == MPPI_OK && whole_iterations)
+      st = flushMerge(h);  // the last iteration's merge belongs to the timed iterations
     if (st == MPPI_OK && (hipEventRecord(h->ev_b, h->stream) != hipSuccess || hipEventSynchronize(h->ev_b) != hipSuccess ||
                           hipEventElapsedTime(&t_ms[v], h->ev_a, h->ev_b) != hipSuccess))
       st = MPPI_ERR_HIP;
@@ -3085,10 +3129,12 @@ mppi_status mppi_choose_kernel(mppi_handle h, int num_evaluations, int* chosen_v
     {
       h->pipeline = was;
       h->generation = generation;
+      restore();
       return st == MPPI_ERR_HIP ? fail(h, st, "mppi_choose_kernel: HIP error while timing the rollout kernels") : st;
     }
     t_ms[v] /= (float)num_evaluations;
   }
+  restore();
   h->generation = generation;  // the trial launches do not advance the noise stream
   if (!fused_ok && !pipe_ok)
   {
@@ -3278,11 +3324,25 @@ mppi_status mppi_p2p_mailbox_handle(mppi_handle h, void* out_bytes, size_t capac
   return MPPI_OK;
 }
 
+/** the exchange-failure mark stats_d[z][6] is sticky on the device (no kernel clears it, reduce_kernels.hpp: combineWave): a new
+ *  session starts without it */
+static mppi_status clearExchangeFailure(mppi_handle h)
+{
+  h->exchange_failed = false;
+  if (!h->stats_d)
+    return MPPI_OK;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  for (int z = 0; z < h->D; z++)
+    HIP_TRY(h, hipMemsetAsync(h->stats_d + (size_t)z * kernels::STATS_STRIDE + 6, 0, sizeof(float), h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
 mppi_status mppi_p2p_reset(mppi_handle h)
 {
   CHECK_HANDLE(h);
   h->p2p_ready = false;
-  h->exchange_failed = false;
+  MPPI_TRY(clearExchangeFailure(h));
   return resetMailboxSession(h);
 }
 
@@ -3293,6 +3353,14 @@ mppi_status mppi_p2p_connect(mppi_handle h, const void* handles, size_t stride_b
   if (!handles || stride_bytes < sizeof(hipIpcMemHandle_t))
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_p2p_connect: handles[world] with a stride of at least 64 bytes expected");
   MPPI_TRY(ensureMailbox(h));
+  /* A session's sequence numbers start at 1 and the merge waits for flag == sequence number, so a mailbox that still holds the
+   * flags and records of an earlier session would let this one pass its waits early (stale or half-written peer records merged
+   * silently).  The mailbox cannot be cleared HERE — a peer of the new session that connected first may already have posted
+   * into it — only before its handle is exported, which mppi_p2p_mailbox_handle does on a handle without a live session.  A
+   * live or used session therefore has to be ended explicitly first: mppi_p2p_reset, then export, then connect. */
+  if (h->p2p_ready || h->xseq != 0 || h->aseq != 0)
+    return fail(h, MPPI_ERR_STATE, "mppi_p2p_connect: this handle has a live (or used) exchange session; call mppi_p2p_reset on "
+                                   "every rank, export the mailbox handles again (mppi_p2p_mailbox_handle) and then connect");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   for (int p = 0; p < world; p++)
   {
@@ -3318,7 +3386,7 @@ mppi_status mppi_p2p_connect(mppi_handle h, const void* handles, size_t stride_b
   }
   h->xseq = 0;
   h->aseq = 0;
-  h->exchange_failed = false;
+  MPPI_TRY(clearExchangeFailure(h));
   h->p2p_ready = true;
   return MPPI_OK;
 }
@@ -3359,7 +3427,7 @@ mppi_status mppi_p2p_connect_local(mppi_handle h, const mppi_handle* peers)
   }
   h->xseq = 0;
   h->aseq = 0;
-  h->exchange_failed = false;
+  MPPI_TRY(clearExchangeFailure(h));
   h->p2p_ready = true;
   return MPPI_OK;
 }

@@ -277,7 +277,8 @@ __device__ inline void combineWave(const CombineArgs& a, const int z, const int 
       st[3] = fe_var;
       st[4] = lambda * (weird + 0.5f * (weird * weird));
       st[5] = var;
-      st[6] = 0.0f;
+      // st[6] is the exchange-failure mark (a bounded wait that ran out): STICKY — no kernel clears it, so that a later
+      // successful merge cannot erase it before the host has looked; the host resets it where a session starts
       st[7] = 0.0f;
     }
     else
@@ -365,9 +366,13 @@ __global__ void __launch_bounds__(MERGE_THREADS) combineKernel(const CombineArgs
  *   3. waits (bounded) until every peer's flag shows this exchange, and
  *   4. merges the world's records from its own mailbox into u* (combineWave, finalize = 1).
  * A sharded iteration is then two launches — rollout, merge — plus one hop.  Round 3 ran steps 1-2
- * and 3-4 as two launches (5.6 us apart on a ~32 us iteration).  No wave waits for another wave of this launch (the ticket is
- * taken, not awaited; what is awaited comes from other GPUs), so the grid needs no co-residency guarantee.
+ * and 3-4 as two launches (5.6 us apart on a ~32 us iteration).  Step 3 includes this rank's OWN flag, which the launch's last
+ * ticket raises: every wave therefore waits until all one-wave blocks of this launch have taken their tickets, i.e. the grid
+ * must be CO-RESIDENT (a block that cannot start while the resident ones spin would run them into the 2 s limit).  The grid is
+ * D x combineGridY(T*C) blocks of one wave without LDS — 101 at Cartpole's T*C = 100 — and the host refuses the fused form
+ * above COMBINE_SHARDED_MAX_BLOCKS (engine.hip: launchCombineSharded falls back to the two-launch form there).
  */
+constexpr int COMBINE_SHARDED_MAX_BLOCKS = 2048;  ///< 256 CUs x 8 one-wave blocks: resident at once with a wide margin
 __global__ void __launch_bounds__(MERGE_THREADS) combineShardedKernel(const CombineArgs loc, const CombineArgs glob)
 {
   const int z = blockIdx.x;
@@ -630,8 +635,7 @@ __global__ void __launch_bounds__(COMBINE_THREADS)
     stats_out_d[3] = fe_var;
     stats_out_d[4] = lambda * (weird + 0.5f * (weird * weird));
     stats_out_d[5] = var;
-    stats_out_d[6] = 0.0f;
-    stats_out_d[7] = 0.0f;
+    stats_out_d[7] = 0.0f;  // ([6], the exchange-failure mark, is sticky: see combineWave)
   }
 }
 

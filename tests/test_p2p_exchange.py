@@ -172,6 +172,23 @@ def _ipc_worker(rank, world, conn, repo):
     eng.optimize(3, synchronize=True)
     conn.send(eng.getOptimalControlSeq()[0].tobytes())
     conn.recv()
+    # ---- a second session on the same handles (round-4 advisor finding): the mailbox still holds the flags 1..3 and the
+    # records of the first one.  Connecting again without ending it is refused; reset -> export -> connect starts clean.
+    import mppi_generic_amd as m  # noqa: F811
+    try:
+        eng.p2pConnect(handles)
+        refused = "not refused"
+    except m.MPPIError as e:
+        refused = e.status
+    eng.p2pReset()
+    conn.send((refused, eng.p2pMailboxHandle()))
+    handles2 = conn.recv()
+    eng.p2pConnect(handles2)
+    conn.send("connected")
+    conn.recv()
+    eng.optimize(2, synchronize=True)
+    conn.send(eng.getOptimalControlSeq()[0].tobytes())
+    conn.recv()
     eng.close()
 
 
@@ -204,6 +221,24 @@ def test_p2p_two_processes_share_the_gpu_through_hipipc(gpu):
             assert a.poll(120), "worker did not finish"
             us.append(np.frombuffer(a.recv(), np.float32))
         for a in pipes:
+            a.send("next")
+        handles2 = []
+        for a in pipes:
+            assert a.poll(120), "worker did not reach the second session"
+            refused, hnd = a.recv()
+            assert refused == 7, refused  # MPPI_ERR_STATE: a live session must be ended with mppi_p2p_reset first
+            handles2.append(hnd)
+        for a in pipes:
+            a.send(handles2)
+        for a in pipes:
+            assert a.poll(120) and a.recv() == "connected"
+        for a in pipes:
+            a.send("go")
+        us2 = []
+        for a in pipes:
+            assert a.poll(120), "worker did not finish the second session"
+            us2.append(np.frombuffer(a.recv(), np.float32))
+        for a in pipes:
             a.send("bye")
     finally:
         for p in procs:
@@ -217,6 +252,11 @@ def test_p2p_two_processes_share_the_gpu_through_hipipc(gpu):
     u_full = full.getOptimalControlSeq()[0].reshape(-1)
     assert np.array_equal(us[0], us[1])
     assert np.abs(us[0] - u_full).max() <= 5e-6
+    full.optimize(2)  # the second session continues from the first one's mean (generations 3, 4)
+    u_full2 = full.getOptimalControlSeq()[0].reshape(-1)
+    full.close()
+    assert np.array_equal(us2[0], us2[1])
+    assert np.abs(us2[0] - u_full2).max() <= 1e-5
 
 
 def test_bench_self_launches_two_ranks_from_plain_python(gpu):
