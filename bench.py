@@ -87,34 +87,38 @@ def pmc_pipe_util(kernel_prefix, suffix=""):
     return None
 
 
-def cpu_baseline(cfg, budget_s=12.0, label=None):
+def cpu_baseline(cfg, budget_s=12.0, label=None, min_iters=1, one_core_k=None, noise_note=""):
     """oracle iterations/s on the host cores, bounded sample (never the thing shipped or measured as `value`); any of the
-    Vanilla / Tube configurations (cfg["D"] systems per iteration)"""
+    Vanilla / Tube configurations (cfg["D"] systems per iteration).  one_core_k: the single-thread figure is taken on a slice
+    of that many rollouts (rollouts are independent: the time is proportional) and scaled to the full K."""
     import numpy as np
     import pyoracle as po
     from common import make_oracle
-    o = make_oracle(cfg)
-    K, Tn, C, D = cfg["K"], cfg["T"], o.C, cfg["D"]
-    eps = po.philox_normal(42, 0, K, Tn, C)
-    mean = np.zeros((D, Tn, C), np.float32)
-    x0 = np.tile(np.asarray(cfg["x0"], np.float32), (D, 1))
+    K, Tn, D = cfg["K"], cfg["T"], cfg["D"]
     threads = max(1, min(po.max_threads(), usable_cores()))
     out = {}
-    for key, th in (("all", threads), ("one", 1)):
-        o.time_iterations(x0, mean, eps, 1, th)  # warm-up
-        t1 = o.time_iterations(x0, mean, eps, 1, th)
-        n = max(1, int(budget_s / 2 / max(t1, 1e-4)))
+    for key, th, k_used in (("all", threads, K), ("one", 1, one_core_k or K)):
+        c = dict(cfg, K=k_used)
+        o = make_oracle(c)
+        eps = po.philox_normal(42, 0, k_used, Tn, o.C)
+        mean = np.zeros((D, Tn, o.C), np.float32)
+        x0 = np.tile(np.asarray(cfg["x0"], np.float32), (D, 1))
+        t1 = o.time_iterations(x0, mean, eps, 1, th)  # warm-up (and the estimate the sample size comes from)
+        n = max(min_iters if key == "all" else 1, int(budget_s / 2 / max(t1, 1e-4)))
         n = min(n, 400)
         tt = o.time_iterations(x0, mean, eps, n, th)
-        out[key] = (n / tt, n, th)
-    v, n, th = out["all"]
+        out[key] = (n / tt * (k_used / float(K)), n, th, k_used)
+        del o
+    v, n, th, _ = out["all"]
     what = label or ("Cartpole K=%d T=%d" % (K, Tn))
+    one = out["one"]
     return {
         "value": round(v, 3), "unit": "MPPI iters/s", "cores": th, "kind": "port",
         "sample": "%d iterations of the same workload (%s, one optimisation-loop body each) with the "
-                  "rollouts spread over %d OpenMP threads" % (n, what, th),
-        "value_1core": round(out["one"][0], 3),
-        "sample_1core": "%d iterations, single thread (the reference's CPU path is single-threaded)" % out["one"][1],
+                  "rollouts spread over %d OpenMP threads%s" % (n, what, th, noise_note),
+        "value_1core": round(one[0], 4),
+        "sample_1core": "%d iteration(s), single thread (the reference's CPU path is single-threaded)%s" % (
+            one[1], "" if one[3] == K else ", on a slice of %d of the %d rollouts, scaled by %d" % (one[3], K, K // one[3])),
     }
 
 
@@ -154,11 +158,14 @@ def latency_model(device, iteration_us, n_launch=2):
     return {"t_scan_T": ts, "t_scan_kernel_us": [round(u, 2) for u in us], "step_ns": round(slope * 1e3, 1),
             "fixed_us": round(intercept, 2), "launch_boundary_us": round(boundary, 2), "n_launch": n_launch,
             "latency_floor_us": round(floor, 2), "iteration_us": round(iteration_us, 2),
-            "frac_of_floor": round(floor / iteration_us, 4),
+            "fit_residual": round(1.0 - floor / iteration_us, 4),
             "definition": "latency_floor_us = step_ns * T + fixed_us + (n_launch - 1) * launch_boundary_us: the rollout kernel as "
                           "it is (n_launch = 1: it merges the previous iteration's records in its sampler waves, and the one "
                           "merge launch at the end of a loop is spread over its iterations) plus the bare boundary of a "
-                          "separate merge launch where there is one"}
+                          "separate merge launch where there is one.  fit_residual = 1 - latency_floor_us / iteration_us: how "
+                          "well a line through the kernel's OWN timings reproduces the iteration — a consistency check of the "
+                          "measurement, not a distance to any bound (issue_floor is the floor that does not depend on the "
+                          "kernel's timing)"}
 
 
 def isa_step_counts():
@@ -231,6 +238,59 @@ def compute_control_latency(device, x0):
                           "getControlSeq + slide back to back"}
 
 
+def kernel_stats_us(kernel_prefix):
+    """average duration (us) of the kernel whose name starts with kernel_prefix in the latest committed rocprofv3 --stats summary
+    (profiles/r*_kernel_stats.csv), with the file it came from — the static stand-in where a leg cannot time its kernel live"""
+    import csv
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*kernel_stats.csv")), reverse=True):
+        try:
+            for row in csv.DictReader(open(f)):
+                name = row.get("Name") or row.get("name") or row.get("KernelName") or ""
+                if name.startswith(kernel_prefix):
+                    ns = float(row.get("AverageNs") or row.get("Average") or row.get("avg_ns") or 0.0)
+                    if ns > 0:
+                        return ns * 1e-3, os.path.relpath(f, REPO)
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None
+
+
+def rollout_kernel_us(eng, n, kernel_prefix):
+    """(us per launch of the handle's rollout kernel, how it was obtained): HIP events on the engine's own stream around n
+    back-to-back launches (mppi_time_iterations), or the committed kernel-trace average when the handle cannot be timed so"""
+    try:
+        _, ms_roll = eng.timeIterations(n)
+        if ms_roll > 0:
+            return ms_roll / n * 1e3, "HIP events around %d back-to-back launches on the engine's stream (mppi_time_iterations)" % n
+    except Exception as e:  # noqa: BLE001
+        why = str(e)[:120]
+    else:
+        why = "no rollout pass"
+    us, src = kernel_stats_us(kernel_prefix)
+    return us, "static: rocprofv3 --kernel-trace --stats average from %s (live timing unavailable: %s)" % (src, why)
+
+
+def robust_roofline(eng, n, kernel_prefix, flops_per_launch, b_alg, peak_note):
+    """MFMA (NN model) or HBM (analytic model) roofline of a Robust MPPI rollout launch: two systems per rollout"""
+    us, how = rollout_kernel_us(eng, n, kernel_prefix)
+    traffic = pmc_traffic(kernel_prefix)
+    if us is None:
+        return {"error": "kernel could not be timed", "how": how}
+    if flops_per_launch:
+        ach = flops_per_launch / (us * 1e-6) / 1e12
+        r = {"bound": "mfma", "achieved": round(ach, 4), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 5),
+             "algorithmic_flops_per_launch": flops_per_launch}
+    else:
+        ach = b_alg / (us * 1e-6) / 1e9
+        r = {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
+    r.update({"kernel": kernel_prefix + "...>", "traffic": traffic, "traffic_static_from_profiles": PMC_FILE,
+              "algorithmic_bytes_per_launch": b_alg,
+              "traffic_over_algorithmic_bytes": round(traffic / b_alg, 3) if traffic else None,
+              "avg_kernel_us": round(us, 3), "avg_kernel_us_source": how, "note": peak_note})
+    return r
+
+
 def robust_autorally_leg(device):
     """Robust MPPI (two coupled systems per rollout, DDP feedback term) on the AutoRally NeuralNetModel, K=16384, T=150: what a
     control loop sees per call.  The rollout runs as the role-pipelined kernel of engine/rmppi_pipeline_kernel.hpp."""
@@ -267,9 +327,15 @@ def robust_autorally_leg(device):
         eng.computeControl(x, 1)
         ready += time.perf_counter() - t_a
     u = eng.getControlSeq()
+    # two systems per rollout: twice the Vanilla row's flops; B_alg with D = 2
+    roof = robust_roofline(eng, 20, "rolloutRMPPIPipelineKernel<NeuralNetModelMFMA", 2 * 2.0 * (6 * 32 + 32 * 32 + 32 * 4) * K * Tn,
+                           4.0 * 2 * (2.0 * K * Tn * 2 + 2.0 * K + 2.0 * Tn * 2),
+                           "the one hot kernel whose sample rows leave the CU: `traffic` above the algorithmic bytes is write "
+                           "amplification of the per-lane clamped-control write-back (DESIGN.md §5)")
     eng.close()
     return {"workload": "RobustMPPI (nominal + real system, DDP gains [T][7][2], 9 x 32 candidate rollouts), AutoRally "
                         "NeuralNetModel<7,2,3> + ARStandardCost, K=16384, T=150",
+            "roofline": roof,
             "control_ready_us": round(ready / n * 1e6, 2), "cycle_us": round(period * 1e6, 2), "finite": bool(np.isfinite(u).all()),
             "kernel": "rolloutRMPPIPipelineKernel<NeuralNetModelMFMA<7,2,3>,ARStandardCost,DeviceDDP,Gaussian>: 8 dynamics + 1 sampler "
                       "+ 6 cost waves per 64 rollouts x 2 systems (profiles/r03_b_robust_kernel_stats.csv)",
@@ -310,8 +376,12 @@ def robust_di_leg(device):
         eng.computeControl(x, 1)
         ready += time.perf_counter() - t_a
     u = eng.getControlSeq()
+    roof = robust_roofline(eng, 50, "rolloutRMPPIPipelineKernel<DoubleIntegratorDynamics", 0.0,
+                           4.0 * 2 * (2.0 * cfg["K"] * cfg["T"] * 2 + 2.0 * cfg["K"] + 2.0 * cfg["T"] * 2),
+                           "HBM is the ceiling SURVEY.md §8d assigns; the kernel is bound by the issue rate of its dynamics waves")
     eng.close()
     return {"workload": "RobustMPPI, DoubleIntegrator + DoubleIntegratorCircleCost, K=8192, T=150, 9 x 32 candidate rollouts",
+            "roofline": roof,
             "control_ready_us": round(ready / n * 1e6, 2), "cycle_us": round(period * 1e6, 2), "finite": bool(np.isfinite(u).all()),
             "kernel": "rolloutRMPPIPipelineKernel<DoubleIntegratorDynamics,...>: 2 dynamics + 2 sampler + 6 cost waves per 64 rollouts "
                       "x 2 systems"}
@@ -366,7 +436,7 @@ def autorally_leg(device, with_cpu_baseline=True):
     }
 
 
-def lstm_colored_leg(device):
+def lstm_colored_leg(device, with_cpu_baseline=True):
     """BASELINE config 5: LSTM bicycle-slip dynamics (LSTM(6,16) + MLP {22,32,4}, synthetic weights) + ARStandardCost +
     ColoredNoise sampler (exponents 1, offset decay 0.97), ColoredMPPI iteration, K=65536, T=200, one GPU.
     MFMA roofline: F_alg = 2*(4H(I+H) + (H+I)*M + M*OUT)*K*T for the network + 2*(2T+2)*T*C*K for the colored-noise GEMM."""
@@ -389,7 +459,19 @@ def lstm_colored_leg(device):
     f_noise = 2.0 * (2 * Tn + 2) * Tn * 2 * K
     achieved = f_net / (roll_us * 1e-6) / 1e12              # the MFMA roofline is for the NN forward only
     achieved_with_gemm = (f_net + f_noise) / (roll_us * 1e-6) / 1e12
+    eng.close()
+    cpu = None
+    if with_cpu_baseline:  # at least 3 CPU iterations of config 5
+        try:
+            cpu = cpu_baseline(dict(cfg, colored=None), budget_s=6.0, label="LSTM bicycle-slip K=%d T=%d" % (K, Tn), min_iters=3,
+                               one_core_k=K // 16,
+                               noise_note=("; time-domain noise given — the reference's CPU rollout takes its noise from the "
+                                           "device sampler (rollout_kernel_test.cu:516-517), so the colored-noise transform is "
+                                           "not part of the CPU path"))
+        except Exception as e:  # noqa: BLE001
+            cpu = {"error": str(e)}
     return {
+        "cpu_baseline": cpu,
         "workload": "LSTM bicycle-slip dynamics (LSTM(6,16) + MLP {22,32,4}, synthetic weights) + ARStandardCost + ColoredNoise "
                     "sampler (exponents [1,1], offset_decay_rate 0.97), ColoredMPPI iteration, K=65536, T=200, block (64 "
                     "rollouts x 4 MFMA lanes)",
@@ -439,6 +521,17 @@ def di_tube_leg(device, with_cpu_baseline=True):
         eng.getControlSeq()
         eng.slideControlSequence(1)
     loop = (time.perf_counter() - t_a) / m_
+    roll_us, how = rollout_kernel_us(eng, 100, "rolloutPipelineKernel<DoubleIntegratorDynamics")
+    b_alg = 4.0 * 2 * (2.0 * cfg["K"] * cfg["T"] * 2 + 2.0 * cfg["K"] + 2.0 * cfg["T"] * 2)  # SURVEY.md §8d with D = 2 systems
+    achieved = b_alg / (roll_us * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "kernel": "rolloutPipelineKernel<DoubleIntegratorDynamics, DoubleIntegratorCircleCost, Gaussian, 2 "
+                                          "systems folded into the lanes of a wave>",
+                "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": pmc_traffic("rolloutPipelineKernel<DoubleIntegratorDynamics"), "traffic_static_from_profiles": PMC_FILE,
+                "algorithmic_bytes_per_launch": b_alg, "avg_kernel_us": round(roll_us, 3), "avg_kernel_us_source": how,
+                "frac_on_iteration": round(b_alg / (wall / n) / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "HBM is the ceiling SURVEY.md §8d assigns; the samples of both systems stay in LDS, the kernel is bound by "
+                        "the issue rate of its dynamics wave (T dependent steps, 32 rollouts x 2 systems per wave)"}
     eng.close()
     cpu = None
     if with_cpu_baseline:
@@ -448,6 +541,7 @@ def di_tube_leg(device, with_cpu_baseline=True):
             cpu = {"error": str(e)}
     return {"workload": "DoubleIntegrator + DoubleIntegratorCircleCost, Tube-MPPI iteration (actual + nominal system in one "
                         "launch), K=8192, T=150", "value": round(n / wall, 3), "unit": "MPPI iters/s", "cpu_baseline": cpu,
+            "roofline": roofline,
             "ms_per_step": round(wall / n * 1e3, 6), "compute_control_ready_us": round(ready / m_ * 1e6, 2),
             "closed_loop_period_us": round(loop * 1e6, 2)}
 
@@ -716,11 +810,40 @@ WORKLOAD_TEXT = {
 }
 
 
+K_BASE = {"cartpole": K_PER_GPU, "autorally": K_PER_GPU, "lstm_colored": 65536}  # the BASELINE problem of every workload
+
+
 def workload_cfg(workload, k_total):
-    from common import autorally_cfg, cartpole_cfg
+    from common import autorally_cfg, bicycle_lstm_cfg, cartpole_cfg
     if workload == "autorally":
         return autorally_cfg(K=k_total, T=150, lambda_=1.0), 150
+    if workload == "lstm_colored":  # BASELINE config 5: "K=65536 T=200, 8xMI355X"
+        cfg = bicycle_lstm_cfg(K=k_total, T=200, lambda_=1.0)
+        cfg["colored"] = ([1.0, 1.0], 0.97, 0.0)
+        return cfg, 200
     return cartpole_cfg(K=k_total, T=T), T
+
+
+# What a first multi-GPU run should show, written down BEFORE one exists (no 8-GPU node was ever available to the builder) so
+# that the driver's curve can falsify it.  Inputs are one-GPU measurements (profiles/r04_d_*, tools/kscan.py) and two
+# estimates that have never been measured across devices: the sharded merge (combineShardedKernel: local merge + post + ticket +
+# wait + global merge, ~3.5 us of body behind a 1.55 us boundary) and the xGMI hop of a ~0.4-1.6 KB record + flag (2-3 us).
+#   * the rollout kernels do NOT get faster below one block per CU: K = 16384 is 256 blocks of 64 rollouts on 256 CUs, and a
+#     block's time is T dependent steps of its dynamics wave whatever the other CUs do (kscan: Cartpole K = 2048 / 4096 / 16384
+#     within 3 %) -> strong scaling of the two K = 16384 problems is < 1x at every N;
+#   * config 5 (K = 65536: 1024 blocks, one per CU at a time = 4 rounds) is the problem that shards: N = 2 -> 2 rounds,
+#     N = 4 -> 1 round, N = 8 -> 1 round on half the CUs (no further gain).
+PREDICTED_MS_PER_STEP = {
+    "inputs": {"cartpole_rollout_kernel_us": 22.7, "autorally_rollout_kernel_us": 184.0, "lstm_colored_round_us": 460.0,
+               "sharded_merge_us": 5.0, "xgmi_hop_us": 2.5,
+               "source": "one-GPU measurements (profiles/r04_d_kernel_stats.csv: plain Cartpole instantiation 22.5-22.9 us, "
+                         "AutoRally-NN 183-186 us, config 5 1.84 ms = 4 rounds); merge + hop estimated, never measured across devices"},
+    "cartpole_strong": {2: 0.0302, 4: 0.0302, 8: 0.0302},       # 22.7 + 5.0 + 2.5 us, against 0.0250 on one GPU (one launch)
+    "cartpole_weak": {2: 0.0302, 4: 0.0302, 8: 0.0302},         # same step, N x the rollouts
+    "autorally_strong": {2: 0.1915, 4: 0.1915, 8: 0.1915},      # 184 + 7.5 us, against 0.189 on one GPU
+    "autorally_weak": {2: 0.1915, 4: 0.1915, 8: 0.1915},
+    "lstm_colored_strong": {2: 0.9275, 4: 0.4675, 8: 0.4675},   # rounds x 460 us + 7.5 us, against 1.84 on one GPU
+}
 
 
 def main():
@@ -768,7 +891,7 @@ def main():
     scaling_reported = scaling if world > 1 else "none"  # one GPU: nothing scales
 
     def leg(workload, strong_, hint, steps, warmup, min_time):
-        k_total = K_PER_GPU if strong_ else K_PER_GPU * world
+        k_total = K_BASE[workload] if strong_ else K_BASE[workload] * world
         cfg, t_steps = workload_cfg(workload, k_total)
         sr = ShardedRun(cfg, rank, world, local_rank, dist, hint)
         elapsed, reps = sr.measure(steps, warmup, min_time)
@@ -777,8 +900,49 @@ def main():
                "rollouts_per_gpu": k_total // world, "global_rollouts": k_total, "num_timesteps": t_steps,
                "repetitions": len(reps), "ms_per_step_min": round(min(reps) / steps * 1e3, 6),
                "ms_per_step_max": round(max(reps) / steps * 1e3, 6), "exchange": sr.exchange["text"],
+               "exchange_mode": sr.exchange["mode"],
                "finite": bool(np.isfinite(sr.eng.getOptimalControlSeq()).all())}
+        pred = PREDICTED_MS_PER_STEP.get("%s_%s" % (workload, "strong" if strong_ else "weak"), {}).get(world)
+        if world > 1 and pred is not None:
+            res["predicted_ms_per_step"] = pred
         return sr, cfg, res, elapsed, reps
+
+    def exchange_paths(workload, steps, warmup, negotiated, head_iter_us, head_roll_us):
+        """BOTH data paths of the K-sharded iteration on the strong-scaling problem, each forced in turn (the headline reports
+        only the one that won the negotiation): event-timed iteration minus event-timed rollout kernel = what merge + exchange
+        cost on that path.  A path that cannot run here says why (e.g. RCCL refuses two ranks on one device)."""
+        out = {}
+        for mode in ("p2p", "rccl"):
+            key = "exchange_%s_us" % mode
+            try:
+                if mode == negotiated:
+                    it_us, ro_us, ms_step, ok, why, ranks = head_iter_us, head_roll_us, None, True, "", world
+                else:
+                    cfg2, _ = workload_cfg(workload, K_BASE[workload])
+                    sr2 = ShardedRun(cfg2, rank, world, local_rank, dist, mode)
+                    ok = sr2.exchange["mode"] == mode
+                    why = "; ".join(t["why"] for t in sr2.exchange["tried"] if t["mode"] == mode and not t["ok"])
+                    it_us = ro_us = ms_step = None
+                    ranks = sr2.exchange.get("rccl_ranks") if mode == "rccl" else world
+                    if ok:
+                        elapsed2, _ = sr2.measure(steps, warmup, 0.05)
+                        ms_step = round(elapsed2 / steps * 1e3, 6)
+                        it_us, ro_us = sr2.kernel_times_us(min(200, max(20, steps)), elapsed2 / steps * 1e6)
+                    sr2.close()
+                if ok:
+                    out[key] = round(it_us - ro_us, 3)
+                    out[mode] = {"ok": True, "iteration_us_event_timed": round(it_us, 3), "rollout_kernel_us": round(ro_us, 3),
+                                 "ms_per_step": ms_step, "ranks": ranks, "negotiated": mode == negotiated}
+                else:
+                    out[key] = None
+                    out[mode] = {"ok": False, "refused": (why or "path not available")[:300], "negotiated": False}
+            except Exception as e:  # noqa: BLE001
+                out[key] = None
+                out[mode] = {"ok": False, "refused": str(e)[:300], "negotiated": False}
+        out["rccl_ranks"] = out["rccl"].get("ranks") if out["rccl"]["ok"] else None
+        out["definition"] = ("exchange_<path>_us = event-timed iteration - event-timed rollout kernel on the strong-scaling headline "
+                             "problem with that path forced: local merge + post/all-gather + wait + global merge")
+        return out
 
     # ------------------------------------------------------------------ the headline leg
     sr, cfg, head, elapsed, reps = leg(args.workload, strong, None, args.steps, args.warmup, args.min_time)
@@ -842,19 +1006,37 @@ def main():
                 roofline["latency_model"] = {"error": str(e)}
     exchange_info = dict(sr.exchange)
     sr.close()
+    if world > 1:
+        pred = PREDICTED_MS_PER_STEP.get("%s_%s" % (args.workload, scaling), {}).get(world)
+        if pred is not None:
+            head["predicted_ms_per_step"] = pred
 
     # ------------------------------------------------------------------ N > 1: the other scaling mode and the other workload
     extra = {}
     if world > 1 and not args.primary_only:
         other = "autorally" if args.workload == "cartpole" else "cartpole"
+        try:
+            extra["exchange_paths"] = exchange_paths(args.workload, max(20, min(args.steps, 200)), max(5, min(args.warmup, 50)),
+                                                     exchange_info["mode"], iter_us, roll_us)
+            extra["exchange_p2p_us"] = extra["exchange_paths"]["exchange_p2p_us"]
+            extra["exchange_rccl_us"] = extra["exchange_paths"]["exchange_rccl_us"]
+            extra["rccl_ranks"] = extra["exchange_paths"]["rccl_ranks"]
+        except Exception as e:  # noqa: BLE001
+            extra["exchange_paths"] = {"error": str(e)}
+        WORKLOAD_TEXT.setdefault("lstm_colored", "LSTM bicycle-slip dynamics (LSTM(6,16) + MLP {22,32,4}, synthetic weights) + "
+                                 "ARStandardCost + ColoredNoise sampler (exponents [1,1], offset decay 0.97), ColoredMPPI "
+                                 "iteration, T=200 (BASELINE config 5)")
         for key, wl, st_ in (("weak" if strong else "strong", args.workload, not strong),
-                             (other + "_strong", other, True), (other + "_weak", other, False)):
+                             (other + "_strong", other, True), (other + "_weak", other, False),
+                             ("lstm_colored_strong", "lstm_colored", True)):
             steps = args.steps if wl == "cartpole" else max(20, min(args.steps, 200))
+            if wl == "lstm_colored":
+                steps = max(5, min(args.steps, 40))
             try:
                 sr2, _, res, _, _ = leg(wl, st_, hint, steps, max(5, min(args.warmup, steps)), args.min_time)
                 res["steps"] = steps
                 res["workload"] = WORKLOAD_TEXT[wl] + ", K=%d rollouts %s" % (
-                    K_PER_GPU, "in total, split over the GPUs" if st_ else "per GPU")
+                    K_BASE[wl], "in total, split over the GPUs" if st_ else "per GPU")
                 res["scaling"] = "strong" if st_ else "weak"
                 sr2.close()
             except Exception as e:  # noqa: BLE001
@@ -867,7 +1049,8 @@ def main():
         out = {
             "metric": "MPPI iters/sec (KxT rollouts)", "value": head["value"], "unit": "MPPI iters/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": scaling_reported,
+            "ms_per_step": head["ms_per_step"], "predicted_ms_per_step": head.get("predicted_ms_per_step"),
+            "higher_is_better": True, "scaling": scaling_reported,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": wl,
@@ -887,6 +1070,7 @@ def main():
         }
         out.update(extra)
         if world > 1:
+            out["predicted_ms_per_step_model"] = PREDICTED_MS_PER_STEP["inputs"]
             out["multi_gpu_note"] = ("headline = strong scaling of the BASELINE problem; DESIGN.md §6 predicts < 1.0x for it (the "
                                      "rollout kernel is T dependent steps of one wave per CU whatever K is; sharding adds one merge "
                                      "launch and the hop) and ~N x for the weak line beside it")
@@ -896,7 +1080,7 @@ def main():
                                 ("racer_elevation", racer_elevation_leg), ("robust_autorally_nn", robust_autorally_leg),
                                 ("robust_double_integrator", robust_di_leg), ("reference_order_reduction", reference_order_leg)):
                 try:
-                    if key in ("autorally_nn", "di_tube"):
+                    if key in ("autorally_nn", "di_tube", "lstm_colored"):
                         out[key] = leg_fn(local_rank, with_cpu_baseline=not args.no_cpu_baseline)
                     else:
                         out[key] = leg_fn(local_rank)

@@ -11,6 +11,9 @@
  *                                                            updateImportanceSamplingControl + slideControlSequence;
  *                                                            computeControl; feedback; timing averages
  *   runControlLoop(is_alive)        :566-603                 iterate, pacing on the state time stamps
+ *   checkRequiresBuffer / updateFromBuffer(getSmoothedBuffer(t))   :266, :477-482   the per-cycle hook through which a model with
+ *                                   an LSTM in its rollouts gets its initial (hidden, cell) from the recent history — BufferedPlant
+ *                                   below (core/buffered_plant.hpp, core/buffer.hpp) keeps that history and runs the initialiser
  * Pure virtual hooks as in the reference (:148-174): pubControl, pubNominalState, pubFreeEnergyStatistics, checkStatus,
  * getCurrentTime, getPoseTime.
  *
@@ -31,9 +34,12 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <deque>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -74,6 +80,24 @@ public:
   virtual double getStateTime()
   {
     return state_time_;
+  }
+  /** time series of named values, one sample every buffer_dt over the last buffer_tau seconds, oldest first
+   *  (base_plant.hpp:31 buffer_trajectory = std::map<std::string, Eigen::VectorXf>) */
+  using buffer_trajectory = std::map<std::string, std::vector<float>>;
+  /** base_plant.hpp:266: a plant without a buffer returns an empty one */
+  virtual buffer_trajectory getSmoothedBuffer(double time)
+  {
+    return buffer_trajectory();
+  }
+  /** Dynamics::checkRequiresBuffer() of the reference's model (dynamics.cuh:366-369): does the model want its history every cycle? */
+  virtual bool checkRequiresBuffer()
+  {
+    return false;
+  }
+  /** Dynamics::updateFromBuffer (dynamics.cuh:371-374; racer_dubins_elevation_lstm_steering.cu:216-233): false = keys missing */
+  virtual bool updateFromBuffer(const buffer_trajectory& buffer)
+  {
+    return false;
   }
   /** where a derived plant runs its feedback solver and calls setFeedbackGains() */
   virtual void computeFeedback(const s_array& state, const s_traj& state_traj, const c_traj& control_traj)
@@ -245,6 +269,11 @@ public:
       sum += v;
     if (!std::isfinite(sum))
       return;
+    if (checkRequiresBuffer())
+    {  // base_plant.hpp:477-482 — before the optimisation: the rollouts of this cycle start from the history's (h0, c0)
+      std::lock_guard<std::mutex> lck(params_guard_);
+      updateFromBuffer(getSmoothedBuffer(state_time));
+    }
     const int status = checkStatus();
     // robot time decides how far the previous solution is slid
     if (last == -1)
@@ -323,6 +352,194 @@ protected:
   double avg_loop_time_ms_ = 0, avg_optimize_time_ms_ = 0, avg_feedback_time_ms_ = 0, avg_sleep_time_ms_ = 0;
   int num_iter_ = 0;
   int status_ = 1;
+};
+
+/**
+ * BufferedPlant — a plant that keeps the recent history of named signals and, every control cycle, turns it into the initial
+ * recurrent state of the model's prediction LSTM.
+ *
+ * reference: core/buffered_plant.hpp (the plant), core/buffer.hpp (time-stamped lists, getInterpState :180-207,
+ * getSmoothedBuffer :209-250: tau / dt + 1 samples ending at the newest state's time, linear interpolation, empty while the
+ * history is shorter than tau, cleanBuffers :252-264), and the consumer
+ * dynamics/racer_dubins/racer_dubins_elevation_lstm_steering.cu:216-233 (updateFromBuffer: rows STEER_ANGLE * 0.2,
+ * STEER_ANGLE_RATE * 0.2, CAN_STEER_CMD of the initialiser's input, LSTMLSTMHelper::initializeLSTM).
+ * Here the model lives behind the C ABI, so the model-side half of that hook is a description the plant owns
+ * (LSTMBufferInit: which buffer keys, scaled by what, feed which initialiser network) and its effect is
+ * mppi_lstm_lstm_initialize (host, as in the reference) + controller.setLSTMInitialState (mppi_set_lstm_initial_state).
+ */
+struct LSTMBufferInit
+{
+  std::vector<std::string> keys;  ///< one buffer key per input of the initialiser LSTM, in input order
+  std::vector<float> scales;      ///< factor applied to that key's samples (the steering model: 0.2, 0.2, 1)
+  int init_input_dim = 0, init_hidden_dim = 0;
+  std::vector<int> init_output_layers;  ///< {init_hidden_dim + init_input_dim, ..., 2 * hidden_dim}
+  std::vector<float> init_lstm_blob, init_output_blob;  ///< the device helpers' blob layouts (lstm_blob_from_npz "init_")
+  int hidden_dim = 0;  ///< of the prediction LSTM inside the rollouts
+  int init_len = 0;    ///< samples the initialiser reads (the newest init_len of the buffer)
+};
+
+template <class CONTROLLER_T>
+class BufferedPlant : public BasePlant<CONTROLLER_T>
+{
+public:
+  using Base = BasePlant<CONTROLLER_T>;
+  using buffer_trajectory = typename Base::buffer_trajectory;
+  BufferedPlant(std::shared_ptr<CONTROLLER_T> controller, int hz, int optimization_stride)
+    : Base(std::move(controller), hz, optimization_stride)
+  {
+  }
+
+  /** buffer.hpp updateExtraValue / updateControls / updateOdometry: every signal is a named, time-stamped list here */
+  void updateExtraValue(const std::string& name, float value, double time)
+  {
+    std::lock_guard<std::mutex> lck(buffer_guard_);
+    std::deque<Sample>& q = lists_[name];
+    if (!q.empty() && time < q.back().time)
+      return;  // insertIntoBuffer drops samples older than the newest (buffer.hpp:120-133)
+    q.push_back(Sample{ time, value });
+  }
+  void updateValues(const std::vector<std::string>& names, const std::vector<float>& values, double time)
+  {
+    for (size_t i = 0; i < names.size() && i < values.size(); i++)
+      updateExtraValue(names[i], values[i], time);
+  }
+  /** linear interpolation of every list at `time`, clamped to the list's ends */
+  std::map<std::string, float> getInterpState(double time)
+  {
+    std::lock_guard<std::mutex> lck(buffer_guard_);
+    std::map<std::string, float> out;
+    for (const auto& kv : lists_)
+      if (!kv.second.empty())
+        out[kv.first] = interp(kv.second, time);
+    return out;
+  }
+  buffer_trajectory getSmoothedBuffer(double latest_time) override
+  {
+    buffer_trajectory result;
+    {
+      std::lock_guard<std::mutex> lck(buffer_guard_);
+      if (lists_.empty())
+        return result;
+      for (const auto& kv : lists_)  // not enough history yet: empty, the model keeps its previous initial state
+        if (kv.second.empty() || kv.second.back().time - kv.second.front().time < buffer_tau_ - 1e-9)
+          return result;
+    }
+    const int steps = (int)(buffer_tau_ / buffer_dt_ + 1e-9) + 1;
+    for (int t = 0; t < steps; t++)
+    {
+      const double query = latest_time - (steps - 1 - t) * buffer_dt_;
+      for (const auto& kv : getInterpState(query))
+      {
+        std::vector<float>& row = result[kv.first];
+        row.resize(steps);
+        row[t] = kv.second;
+      }
+    }
+    return result;
+  }
+  void cleanBuffers(double time)
+  {
+    std::lock_guard<std::mutex> lck(buffer_guard_);
+    for (auto& kv : lists_)
+      while (kv.second.size() > 1 && kv.second.front().time < time - buffer_time_horizon_)
+        kv.second.pop_front();
+  }
+  void clearBuffers()
+  {
+    std::lock_guard<std::mutex> lck(buffer_guard_);
+    lists_.clear();
+  }
+  void setBufferParams(double time_horizon, double tau, double dt)
+  {
+    buffer_time_horizon_ = time_horizon;
+    buffer_tau_ = tau;
+    buffer_dt_ = dt;
+  }
+
+  /** the model-side description of updateFromBuffer; with it the plant "requires the buffer" */
+  void setLSTMBufferInit(const LSTMBufferInit& init)
+  {
+    lstm_init_ = init;
+    has_lstm_init_ = true;
+  }
+  bool checkRequiresBuffer() override
+  {
+    return has_lstm_init_;
+  }
+  bool updateFromBuffer(const buffer_trajectory& buffer) override
+  {
+    if (!has_lstm_init_)
+      return false;
+    const LSTMBufferInit& li = lstm_init_;
+    size_t cols = 0;
+    for (const std::string& k : li.keys)
+    {  // checkIfKeysInBuffer: a missing key leaves the model as it is
+      auto it = buffer.find(k);
+      if (it == buffer.end() || (int)it->second.size() < li.init_len)
+        return false;
+      cols = it->second.size();
+    }
+    std::vector<float> samples(cols * li.init_input_dim);  // [cols][init_input_dim], oldest first
+    for (int i = 0; i < li.init_input_dim; i++)
+    {
+      const std::vector<float>& row = buffer.at(li.keys[i]);
+      for (size_t c = 0; c < cols; c++)
+        samples[c * li.init_input_dim + i] = row[c] * li.scales[i];
+    }
+    std::vector<float> hc(2 * (size_t)li.hidden_dim);
+    const mppi_status st = mppi_lstm_lstm_initialize(li.init_input_dim, li.init_hidden_dim, li.init_output_layers.data(),
+                                                     (int)li.init_output_layers.size(), li.init_lstm_blob.data(),
+                                                     li.init_output_blob.data(), li.hidden_dim, li.init_len, samples.data(),
+                                                     (int)cols, hc.data());
+    if (st != MPPI_OK)
+      throw Error(st, "BufferedPlant::updateFromBuffer: mppi_lstm_lstm_initialize failed");
+    last_hidden_.assign(hc.begin(), hc.begin() + li.hidden_dim);
+    last_cell_.assign(hc.begin() + li.hidden_dim, hc.end());
+    this->controller_->setLSTMInitialState(last_hidden_, last_cell_);
+    num_buffer_updates_++;
+    return true;
+  }
+  int numBufferUpdates() const
+  {
+    return num_buffer_updates_;
+  }
+  const std::vector<float>& lastHidden() const
+  {
+    return last_hidden_;
+  }
+  const std::vector<float>& lastCell() const
+  {
+    return last_cell_;
+  }
+
+protected:
+  struct Sample
+  {
+    double time;
+    float value;
+  };
+  static float interp(const std::deque<Sample>& q, double time)
+  {
+    if (time <= q.front().time)
+      return q.front().value;
+    if (time >= q.back().time)
+      return q.back().value;
+    size_t hi = 1;
+    while (q[hi].time < time)
+      hi++;
+    const Sample &a = q[hi - 1], &b = q[hi];
+    const double w = b.time > a.time ? (time - a.time) / (b.time - a.time) : 0.0;
+    return (float)((1.0 - w) * a.value + w * b.value);
+  }
+  std::mutex buffer_guard_;
+  std::map<std::string, std::deque<Sample>> lists_;
+  double buffer_time_horizon_ = 2.0;  ///< how long values are kept           (buffered_plant.hpp:81-83)
+  double buffer_tau_ = 1.0;           ///< how far back the well-sampled history reaches
+  double buffer_dt_ = 0.02;           ///< spacing of the well-sampled history
+  LSTMBufferInit lstm_init_;
+  bool has_lstm_init_ = false;
+  std::vector<float> last_hidden_, last_cell_;
+  int num_buffer_updates_ = 0;
 };
 
 /**

@@ -15,7 +15,7 @@ from .controllers import (MPPI_KERNEL_AUTO, MPPI_KERNEL_FUSED, MPPI_KERNEL_PIPEL
                           det_eval, LSTMLSTMHelper, texture2d_query, npz_read_array, philox_normal, launch_boundary_us, issue_interval_ns, norm_exp, compute_weights, weighted_reduction,
                           compute_weights_reference_order, weighted_reduction_reference_order,
                           MPPI_REDUCTION_FUSED, MPPI_REDUCTION_REFERENCE_ORDER, MPPI_REDUCTION_REFERENCE_ORDER_FMA)
-from .plant import BasePlant, SimulatedPlant, interpolateControls, interpolateFeedback, interpolateState
+from .plant import BasePlant, BufferedPlantMixin, SimulatedPlant, interpolateControls, interpolateFeedback, interpolateState
 
 __all__ = [
     "build", "load_library", "library_path", "MPPIError", "MPPIController", "VanillaMPPIController",

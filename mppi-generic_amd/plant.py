@@ -248,6 +248,9 @@ class BasePlant:
             state_time = self.state_time_
         if not np.isfinite(state.sum()):
             return
+        if self.checkRequiresBuffer():  # base_plant.hpp:477-482: this cycle's rollouts start from the history's (h0, c0)
+            with self.params_guard_ if hasattr(self, "params_guard_") else self.access_guard_:
+                self.updateFromBuffer(self.getSmoothedBuffer(state_time))
         status = self.checkStatus()
         # robot time decides how far the previous solution is slid
         ctl = self.controller_
@@ -280,6 +283,16 @@ class BasePlant:
         self.optimize_loop_duration_ = (_time.monotonic() - loop_start) * 1e3
         self.avg_loop_time_ms_ = prev * self.avg_loop_time_ms_ + self.optimize_loop_duration_ / n
 
+    # ---- the history hook (base_plant.hpp:266, :477-482; Dynamics::checkRequiresBuffer / updateFromBuffer) ----
+    def getSmoothedBuffer(self, time):
+        return {}
+
+    def checkRequiresBuffer(self):
+        return False
+
+    def updateFromBuffer(self, buffer):
+        return False
+
     def computeFeedback(self, state, state_traj, control_traj):
         """hook: the reference runs its DDP solver here (controller.cuh computeFeedback); gains enter this framework from
         the caller (setFeedbackGains), so the default does nothing"""
@@ -301,6 +314,85 @@ class BasePlant:
             if self.num_iter_ > 0:
                 prev = (self.num_iter_ - 1.0) / self.num_iter_
                 self.avg_sleep_time_ms_ = prev * self.avg_sleep_time_ms_ + self.sleep_duration_ / self.num_iter_
+
+
+class BufferedPlantMixin:
+    """core/buffered_plant.hpp + core/buffer.hpp of the reference (C++: mppi_amd::BufferedPlant in include/mppi_amd/plant.hpp):
+    named, time-stamped signal lists; getSmoothedBuffer(t) = tau / dt + 1 linearly interpolated samples ending at t (empty
+    while the history is shorter than tau); and the model-side half of Dynamics::updateFromBuffer for a model with an LSTM in
+    its rollouts (racer_dubins_elevation_lstm_steering.cu:216-233: rows STEER_ANGLE * 0.2, STEER_ANGLE_RATE * 0.2,
+    CAN_STEER_CMD -> LSTMLSTMHelper::initializeLSTM) as a description the plant owns: setLSTMBufferInit(helper, keys, scales).
+    Mix in FRONT of a BasePlant subclass."""
+
+    def _buffer_init(self):
+        if not hasattr(self, "lists_"):
+            self.lists_ = {}
+            self.buffer_time_horizon_, self.buffer_tau_, self.buffer_dt_ = 2.0, 1.0, 0.02
+            self.lstm_helper_ = None
+            self.num_buffer_updates_ = 0
+            self.last_hidden_cell_ = None
+
+    def updateExtraValue(self, name, value, time):
+        self._buffer_init()
+        q = self.lists_.setdefault(name, [])
+        if q and time < q[-1][0]:
+            return
+        q.append((float(time), float(value)))
+
+    def getInterpState(self, time):
+        self._buffer_init()
+        out = {}
+        for k, q in self.lists_.items():
+            if q:
+                ts = np.array([a for a, _ in q])
+                vs = np.array([b for _, b in q])
+                out[k] = np.float32(np.interp(time, ts, vs))
+        return out
+
+    def getSmoothedBuffer(self, latest_time):
+        self._buffer_init()
+        if not self.lists_ or any((not q) or q[-1][0] - q[0][0] < self.buffer_tau_ - 1e-9 for q in self.lists_.values()):
+            return {}
+        steps = int(self.buffer_tau_ / self.buffer_dt_ + 1e-9) + 1
+        times = latest_time - (steps - 1 - np.arange(steps)) * self.buffer_dt_
+        out = {}
+        for k, q in self.lists_.items():
+            ts = np.array([a for a, _ in q])
+            vs = np.array([b for _, b in q])
+            out[k] = np.interp(times, ts, vs).astype(np.float32)
+        return out
+
+    def cleanBuffers(self, time):
+        self._buffer_init()
+        for k, q in self.lists_.items():
+            while len(q) > 1 and q[0][0] < time - self.buffer_time_horizon_:
+                q.pop(0)
+
+    def clearBuffers(self):
+        self.lists_ = {}
+
+    def setLSTMBufferInit(self, helper, keys, scales):
+        """helper: controllers.LSTMLSTMHelper with its initialiser parameters set; keys / scales: one buffer key and factor per
+        input of the initialiser LSTM"""
+        self._buffer_init()
+        assert len(keys) == len(scales) == helper.init_input_dim
+        self.lstm_helper_, self.lstm_keys_, self.lstm_scales_ = helper, list(keys), [float(v) for v in scales]
+
+    def checkRequiresBuffer(self):
+        self._buffer_init()
+        return self.lstm_helper_ is not None
+
+    def updateFromBuffer(self, buffer):
+        self._buffer_init()
+        h = self.lstm_helper_
+        if h is None or any(k not in buffer or len(buffer[k]) < h.init_len for k in self.lstm_keys_):
+            return False  # checkIfKeysInBuffer: the model keeps its previous initial state
+        rows = np.stack([np.asarray(buffer[k], np.float32) * np.float32(sc) for k, sc in zip(self.lstm_keys_, self.lstm_scales_)])
+        hidden, cell = h.initializeLSTM(rows)
+        self.controller_.setLSTMInitialState(hidden, cell)
+        self.last_hidden_cell_ = (hidden, cell)
+        self.num_buffer_updates_ += 1
+        return True
 
 
 class SimulatedPlant(BasePlant):

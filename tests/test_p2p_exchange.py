@@ -285,3 +285,14 @@ def test_bench_self_launches_two_ranks_from_plain_python(gpu):
         assert "error" not in out[key], out[key]
         assert out[key]["value"] > 0 and out[key]["finite"]
     assert out["autorally_strong"]["global_rollouts"] == 16384
+    # round 5: BASELINE config 5 (K = 65536 in total, the one problem with more than one round of blocks per CU) as a strong leg
+    c5 = out["lstm_colored_strong"]
+    assert "error" not in c5, c5
+    assert c5["global_rollouts"] == 65536 and c5["rollouts_per_gpu"] == 32768 and c5["value"] > 0 and c5["finite"]
+    assert c5["predicted_ms_per_step"] > 0 and out["predicted_ms_per_step"] > 0
+    # ... and BOTH exchange paths timed (or the reason a path cannot run here, as a string — never silence)
+    xp = out["exchange_paths"]
+    assert xp["p2p"]["ok"] and out["exchange_p2p_us"] > 0, xp
+    assert xp["rccl"]["ok"] or (isinstance(xp["rccl"]["refused"], str) and len(xp["rccl"]["refused"]) > 0), xp
+    if xp["rccl"]["ok"]:
+        assert out["exchange_rccl_us"] > 0 and out["rccl_ranks"] == 2

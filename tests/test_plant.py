@@ -194,3 +194,123 @@ def test_simulated_plant_drives_cartpole_to_goal(gpu):
     plant2 = m.SimulatedPlant(eng2, hz=50, optimization_stride=2, init_state=cfg["x0"])
     plant2.runSimulation(100)
     assert plant2.num_iter_ == 51 and plant2.getLastOptimizationStride() == 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BufferedPlant: the per-cycle history hook (core/base_plant.hpp:477-482, core/buffered_plant.hpp, core/buffer.hpp:180-264)
+# ---------------------------------------------------------------------------------------------------------------------
+class BufferedRecordingPlant(m.BufferedPlantMixin, RecordingPlant):
+    pass
+
+
+def test_buffered_plant_history_and_lstm_hook():
+    """irregular samples -> tau / dt + 1 interpolated ones ending at the state's time; empty while the history is shorter than
+    tau; the initialiser's known answer (lstm_lstm_helper_test.cu:161-180: all ones -> 101) reaches the controller BEFORE the
+    optimisation of the same cycle; a missing key leaves the model alone"""
+    ctl = MockController()
+    sets = []
+    ctl.setLSTMInitialState = lambda h, c: sets.append((len(ctl.calls), np.array(h), np.array(c)))
+    plant = BufferedRecordingPlant(ctl)
+    assert not plant.checkRequiresBuffer()
+    for t in (0.0, 0.03, 0.11, 0.2, 0.45, 0.46, 0.8, 0.95):
+        plant.updateExtraValue("RAMP", 2.0 * t, t)
+    assert plant.getSmoothedBuffer(0.95) == {}
+    plant.updateExtraValue("RAMP", 2.4, 1.2)
+    plant.updateExtraValue("RAMP", 0.0, 0.5)  # older than the newest sample: dropped
+    buf = plant.getSmoothedBuffer(1.2)
+    assert buf["RAMP"].shape == (51,)
+    assert np.allclose(buf["RAMP"], 2.0 * (1.2 - (50 - np.arange(51)) * 0.02), atol=1e-5)
+    plant.cleanBuffers(2.9)
+    assert plant.getInterpState(0.0)["RAMP"] == np.float32(1.9)
+    plant.clearBuffers()
+
+    helper = m.LSTMLSTMHelper(8, 60, [68, 100, 20], 8, 10, [18, 2], 6)
+    helper.setInitParams(np.ones_like(helper.init_lstm), np.ones_like(helper.init_output))
+    keys = ["K%d" % i for i in range(8)]
+    plant.setLSTMBufferInit(helper, keys, [0.5, 0.5] + [1.0] * 6)
+    assert plant.checkRequiresBuffer()
+    alive = threading.Event()
+    alive.set()
+    plant.updateState(np.zeros(2, np.float32), 0.0)
+    plant.runControlIteration(alive)  # no history yet: the optimisation runs, the model keeps its state
+    assert [c[0] for c in ctl.calls].count("compute") == 1 and not sets
+    for k in range(61):
+        for i, key in enumerate(keys):
+            plant.updateExtraValue(key, 2.0 if i < 2 else 1.0, 0.02 * k)
+    plant.updateState(np.zeros(2, np.float32), 1.2)
+    plant.runControlIteration(alive)
+    assert len(sets) == 1 and plant.num_buffer_updates_ == 1
+    at, hidden, cell = sets[0]
+    assert np.all(hidden == 101.0) and np.all(cell == 101.0) and hidden.shape == (10,)
+    assert ctl.calls[at][0] in ("is", "slide", "compute") and [c[0] for c in ctl.calls[:at]].count("compute") == 1  # before compute #2
+    plant.setLSTMBufferInit(helper, ["NOT_THERE"] + keys[1:], [1.0] * 8)
+    plant.updateState(np.zeros(2, np.float32), 1.3)
+    plant.runControlIteration(alive)
+    assert len(sets) == 1
+
+
+def test_cpp_buffered_plant_probe(lib):
+    """the same on the C++ class (include/mppi_amd/plant.hpp: mppi_amd::BufferedPlant) with a stub controller: g++ only, no device"""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "examples", "_build", "buffered_plant_probe")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    lib_dir = os.path.dirname(m.library_path())
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(repo, "include"),
+                        os.path.join(repo, "tests", "probes", "buffered_plant_probe.cpp"), "-L" + lib_dir, "-lmppi_amd",
+                        "-Wl,-rpath," + lib_dir, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "BUFFERED PLANT OK" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_buffered_plant_closed_loop_lstm_steering(gpu):
+    """racer_dubins_elevation_lstm_steering in a plant-driven closed loop: every cycle the plant turns the last second of
+    (STEER_ANGLE, STEER_ANGLE_RATE, CAN_STEER_CMD) into (h0, c0) with the initialiser LSTM and hands it to the engine before
+    computeControl (racer_dubins_elevation_lstm_steering.cu:216-233 through base_plant.hpp:477-482).  Checked: the hook fires on
+    every cycle once a second of history exists; what it set is initializeLSTM of exactly that history; and the engine's
+    rollouts really start from it — an oracle whose blob carries the same (h0, c0) gives the same trajectory costs, 0 ulp."""
+    from common import host_noise, make_oracle, ulp_diff
+    from test_racer_dubins_lstm_steering import H, LSTM_PARAMS, OUT_LAYERS, S_STEER, S_STEER_RATE, S_VEL, steering_cfg
+    cfg = steering_cfg(K=1024, T=64)
+    eng = make_engine(cfg)
+    rng = np.random.default_rng(4)
+    helper = m.LSTMLSTMHelper(3, 20, [23, 100, 8], 4, 4, OUT_LAYERS, 11)  # the shape of the reference's tests (:26-32)
+    helper.setInitParams(rng.uniform(-0.2, 0.2, helper.init_lstm.size), rng.uniform(-0.2, 0.2, helper.init_output.size))
+
+    class Plant(m.BufferedPlantMixin, m.SimulatedPlant):
+        def stepSimulation(self):
+            super().stepSimulation()
+            x, u = self.sim_state_, self.current_control_
+            for key, v in (("STEER_ANGLE", x[S_STEER]), ("STEER_ANGLE_RATE", x[S_STEER_RATE]), ("CAN_STEER_CMD", u[1])):
+                self.updateExtraValue(key, v, self.sim_time_)
+            self.cleanBuffers(self.sim_time_)
+
+    plant = Plant(eng, int(round(1.0 / cfg["dt"])), 1, init_state=cfg["x0"])
+    plant.setLSTMBufferInit(helper, ["STEER_ANGLE", "STEER_ANGLE_RATE", "CAN_STEER_CMD"], [0.2, 0.2, 1.0])
+    x = plant.runSimulation(80)
+    assert np.isfinite(x).all() and x[S_VEL] > 1.5
+    # 50 ticks fill one second of history; from then on every cycle initialises the LSTM
+    assert 25 <= plant.num_buffer_updates_ <= 31, plant.num_buffer_updates_
+    buf = plant.getSmoothedBuffer(plant.last_used_state_update_time_)
+    rows = np.stack([buf["STEER_ANGLE"] * np.float32(0.2), buf["STEER_ANGLE_RATE"] * np.float32(0.2), buf["CAN_STEER_CMD"]])
+    hidden, cell = helper.initializeLSTM(rows)
+    assert np.array_equal(hidden, plant.last_hidden_cell_[0]) and np.array_equal(cell, plant.last_hidden_cell_[1])
+    assert np.abs(hidden).max() > 1e-3  # a non-trivial initial state
+    # the engine's rollouts start from it
+    eps = host_noise(1, cfg["K"], cfg["T"], 2)
+    eng.injectNoise(eps)
+    mean = eng.getControlSeq()
+    eng.updateImportanceSampler(mean)
+    eng.computeControl(x, 1)
+    cfg["blobs"]["lstm_weights"] = cfg["blobs"]["lstm_weights"].copy()
+    cfg["blobs"]["lstm_weights"][LSTM_PARAMS:LSTM_PARAMS + H] = hidden
+    cfg["blobs"]["lstm_weights"][LSTM_PARAMS + H:LSTM_PARAMS + 2 * H] = cell
+    orc = make_oracle(cfg)
+    orc.set_nominal_control(mean)
+    orc.vanilla_compute_control(x, 1, eps)
+    assert int(ulp_diff(eng.getSampledCostSeq(), orc.costs()).max()) == 0
+    assert np.abs(eng.getControlSeq() - orc.control()).max() <= 1e-5
+    eng.close()
