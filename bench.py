@@ -48,8 +48,9 @@ def usable_cores():
 
 def _latest_pmc_file():
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic.json")))
-    return files[-1] if files else os.path.join("profiles", "none.json")
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_hbm_traffic.json")))
+    return os.path.relpath(files[-1], here) if files else os.path.join("profiles", "none.json")
 
 
 PMC_FILE = _latest_pmc_file()

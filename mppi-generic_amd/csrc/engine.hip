@@ -147,6 +147,13 @@ struct mppi_handle_s
   bool results_in_io = false;      // the last finalize pass wrote to io_out_h (low-latency path), not to out_block_d
   bool traj_pending = false;       // state_h / output of the last call are still being written by the finalize kernel
   bool low_latency = true;         // MPPI_AMD_NO_SPIN=1 in the environment: copy + hipStreamSynchronize hand-over instead
+  /* Direct ingest (round 5): the first rollout launch and the finalize kernel of a mppi_compute_control read x0 / the nominal
+   * control / the control history STRAIGHT from the host-mapped input block — mapped non-coherent, i.e. cached in the L2s and
+   * valid from the launch boundary on — instead of from a device block a separate ingestKernel filled first: one launch
+   * (boundary + a PCIe read of its own) less in front of the rollout.  MPPI_AMD_DIRECT_INGEST=0 restores the ingest launch. */
+  bool direct_ingest = false;
+  const float* x0_src_d = nullptr;    // where the NEXT rollout launch reads its initial state from (nullptr: x0_d)
+  const float* mean_src_d = nullptr;  // ... and its nominal control (nullptr: mean_d)
   float* step_pin_h = nullptr;     // [S + C] host memory mapped into the device: [x | u] of a single model step
   float* step_pin_dev = nullptr;   // its device address
   unsigned step_seq = 0;           // hand-over counter of the model-step flag (io_flags[8])
@@ -741,7 +748,13 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     const char* no_spin = getenv("MPPI_AMD_NO_SPIN");
     h->low_latency = !(no_spin && no_spin[0] == '1');
     const unsigned map_flags = hipHostMallocMapped | hipHostMallocCoherent;
-    if (hipHostMalloc((void**)&h->io_in_h, h->in_floats * sizeof(float), map_flags) != hipSuccess ||
+    const char* direct = getenv("MPPI_AMD_DIRECT_INGEST");
+    h->direct_ingest = h->low_latency && cfg->controller != MPPI_CONTROLLER_ROBUST && cfg->controller != MPPI_CONTROLLER_TUBE &&
+                       cfg->world_size == 1 && !(direct && direct[0] == '0');
+    // inputs: written by the host before a launch, read by kernels after it -> coherence at launch boundaries is enough, and
+    // non-coherent mapping lets the L2s serve the 256 blocks that all read the same few hundred bytes
+    const unsigned in_flags = h->direct_ingest ? (hipHostMallocMapped | hipHostMallocNonCoherent) : map_flags;
+    if (hipHostMalloc((void**)&h->io_in_h, h->in_floats * sizeof(float), in_flags) != hipSuccess ||
         hipHostMalloc((void**)&h->io_out_h, h->out_floats * sizeof(float), map_flags) != hipSuccess ||
         hipHostMalloc((void**)&h->io_flags_h, 64, map_flags) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->io_in_dev, h->io_in_h, 0) != hipSuccess ||
@@ -1529,7 +1542,7 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   a.num_rollouts = h->K_local;
   a.lambda = h->cfg.lambda;
   a.alpha = h->cfg.alpha;
-  a.init_x_d = h->x0_d;
+  a.init_x_d = h->x0_src_d ? h->x0_src_d : h->x0_d;
   a.trajectory_costs_d = h->costs_d;
   a.partials_d = h->partials_d;
   a.save_samples = h->samples_d ? 1 : 0;
@@ -1552,7 +1565,8 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   s.rollout_offset = h->K_offset;
   s.num_timesteps = h->cfg.num_timesteps;
   s.num_distributions = h->D;
-  s.control_means_d = h->mean_d;
+  s.control_means_d = h->mean_src_d ? h->mean_src_d : h->mean_d;
+  h->x0_src_d = h->mean_src_d = nullptr;  // one launch only: later iterations read what the merge wrote to mean_d
   s.eps_d = nullptr;
   if (h->noise_source == MPPI_NOISE_INJECTED)
   {
@@ -2072,10 +2086,23 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     std::copy(x0, x0 + h->S, in + (h->x0_d - h->in_block_d));
     std::copy(h->control_h.begin(), h->control_h.end(), in + (h->mean_d - h->in_block_d));
     std::copy(h->history_h.begin(), h->history_h.end(), in + (h->history_d - h->in_block_d));
-    hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
-    HIP_TRY(h, hipGetLastError());
+    const bool direct = h->direct_ingest && h->cfg.num_iters >= 1 && !h->samples_d && h->reduction_mode == MPPI_REDUCTION_FUSED &&
+                        !tsallisActive(h);
+    if (direct)
+    {  // no ingest launch: the first rollout launch and the finalize kernel read the mapped block themselves
+      h->x0_src_d = h->io_in_dev + (h->x0_d - h->in_block_d);
+      h->mean_src_d = h->io_in_dev + (h->mean_d - h->in_block_d);
+      a.x0_d = h->x0_src_d;
+      a.history_d = h->io_in_dev + (h->history_d - h->in_block_d);
+    }
+    else
+    {
+      hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+      HIP_TRY(h, hipGetLastError());
+    }
     for (int it = 0; it < h->cfg.num_iters; it++)
       MPPI_TRY(iteration(h, it, stride));
+    h->x0_src_d = h->mean_src_d = nullptr;
     MPPI_TRY(flushMerge(h));  // the last iteration's records (streamed merge): everything below reads mean_d / stats_d
     a.control_out_d = h->io_out_dev + (h->ctrl_out_d - h->out_block_d);
     a.state_out_d = h->io_out_dev + (h->state_out_d - h->out_block_d);
@@ -2088,6 +2115,12 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     const mppi_status st = h->model->launchFinalize(1, a, h->stream, err);
     if (st != MPPI_OK)
       return fail(h, st, err);
+    if (direct)
+    {  // behind the finalize kernel, off the caller's path: the device-resident x0 / history of later mppi_optimize / operator calls
+      hipLaunchKernelGGL(kernels::ingestRangesKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d,
+                         (int)(h->mean_d - h->in_block_d), (int)(h->history_d - h->in_block_d),
+                         (int)(h->in_floats - (size_t)(h->history_d - h->in_block_d)));
+    }
     h->out_pin_fresh = false;
     h->results_in_io = true;
     h->traj_pending = true;  // set before the wait: a failing wait must not leave io_out unguarded for the next call

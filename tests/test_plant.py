@@ -292,8 +292,8 @@ def test_buffered_plant_closed_loop_lstm_steering(gpu):
     plant.setLSTMBufferInit(helper, ["STEER_ANGLE", "STEER_ANGLE_RATE", "CAN_STEER_CMD"], [0.2, 0.2, 1.0])
     x = plant.runSimulation(80)
     assert np.isfinite(x).all() and x[S_VEL] > 1.5
-    # 50 ticks fill one second of history; from then on every cycle initialises the LSTM
-    assert 25 <= plant.num_buffer_updates_ <= 31, plant.num_buffer_updates_
+    # hz ticks fill the one second of history the smoothed buffer reaches back; from then on EVERY cycle initialises the LSTM
+    assert abs(plant.num_buffer_updates_ - (80 - plant.hz_)) <= 1, (plant.num_buffer_updates_, plant.hz_)
     buf = plant.getSmoothedBuffer(plant.last_used_state_update_time_)
     rows = np.stack([buf["STEER_ANGLE"] * np.float32(0.2), buf["STEER_ANGLE_RATE"] * np.float32(0.2), buf["CAN_STEER_CMD"]])
     hidden, cell = helper.initializeLSTM(rows)
@@ -312,5 +312,6 @@ def test_buffered_plant_closed_loop_lstm_steering(gpu):
     orc.set_nominal_control(mean)
     orc.vanilla_compute_control(x, 1, eps)
     assert int(ulp_diff(eng.getSampledCostSeq(), orc.costs()).max()) == 0
-    assert np.abs(eng.getControlSeq() - orc.control()).max() <= 1e-5
+    # (the first two steps of the smoothed sequence see the control history of the loop, which the fresh oracle does not have)
+    assert np.abs(eng.getControlSeq()[2:] - orc.control()[2:]).max() <= 1e-5
     eng.close()
