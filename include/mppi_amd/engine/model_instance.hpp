@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -26,6 +28,31 @@
 #include "rmppi_pipeline_kernel.hpp"
 #include "mppi_amd/feedback_controllers/ddp_feedback.hpp"
 #include "mppi_amd/sampling_distributions/colored_noise.hpp"
+
+/**
+ * hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, raised only when a launch needs more than was granted before: the
+ * attribute call is a runtime round trip (function lookup, locks) that every rollout launch of a > 48 KiB block paid in front of
+ * its dispatch — on the host's critical path of mppi_compute_control, where the first launch's enqueue time decides when the
+ * device starts.  The grant is per (device, kernel) and monotonic, so handles sharing a kernel on a device never lower each
+ * other's limit.
+ */
+inline hipError_t ensureDynamicLds(const void* fn, size_t smem)
+{
+  if (smem <= 48 * 1024)
+    return hipSuccess;
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> granted;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& g = granted[std::make_pair(dev, fn)];
+  if (smem <= g)
+    return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e == hipSuccess)
+    g = smem;
+  return e;
+}
 
 namespace mppi
 {
@@ -531,7 +558,7 @@ struct ModelT : ModelBase
         auto kfn = in_loop ? kernels::rolloutRMPPIPipelineKernel<PD_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, SAMPLING_T::IN_LOOP_DRAW>
                            : kernels::rolloutRMPPIPipelineKernel<PD_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, false>;
         if (smem > 48 * 1024)
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+          (void)ensureDynamicLds(reinterpret_cast<const void*>(kfn), smem);
         hipLaunchKernelGGL(kfn, dim3((a.base.num_rollouts + 63) / 64), dim3(64 * kernels::rmppiPipelineWaves<PD_T>(), 1, 1), smem,
                            stream, pd, cost, fb, smp, a, r);
         hipError_t e = hipGetLastError();
@@ -572,7 +599,7 @@ struct ModelT : ModelBase
             const size_t smem = kernels::initEvalPipelineSharedBytes(pd, cost, a.num_timesteps, ring);
             auto kfn = kernels::initEvalPipelineKernel<PD_T, COST_T, SAMPLING_T>;
             if (smem > 48 * 1024)
-              (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+              (void)ensureDynamicLds(reinterpret_cast<const void*>(kfn), smem);
             constexpr int WAVES = REP + kernels::INIT_EVAL_PIPE_SAMPLERS + kernels::INIT_EVAL_PIPE_COSTS;
             hipLaunchKernelGGL(kfn, dim3((a.num_eval_rollouts + BX - 1) / BX), dim3(64 * WAVES, 1, 1), smem, stream, pd, cost, smp, a,
                                ring);
@@ -595,7 +622,7 @@ struct ModelT : ModelBase
         const size_t smem = kernels::initEvalSharedBytes<RM_DYN_T, COST_T, SAMPLING_T>(rm_dyn, cost, BX);
         auto kfn = kernels::initEvalKernel<RM_DYN_T, COST_T, SAMPLING_T, BX>;
         if (smem > 48 * 1024)
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+          (void)ensureDynamicLds(reinterpret_cast<const void*>(kfn), smem);
         hipLaunchKernelGGL(kfn, dim3((a.num_eval_rollouts + BX - 1) / BX), dim3(BX * REP, 1, 1), smem, stream, rm_dyn, cost,
                            smp, a);
         hipError_t e = hipGetLastError();
@@ -627,7 +654,7 @@ struct ModelT : ModelBase
         auto kfn = in_loop ? kernels::rolloutRMPPIKernel<RM_DYN_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, BX, SAMPLING_T::IN_LOOP_DRAW>
                            : kernels::rolloutRMPPIKernel<RM_DYN_T, COST_T, DeviceDDP<DYN_T>, SAMPLING_T, BX, false>;
         if (smem > 48 * 1024)
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+          (void)ensureDynamicLds(reinterpret_cast<const void*>(kfn), smem);
         hipLaunchKernelGGL(kfn, dim3((a.base.num_rollouts + BX - 1) / BX), dim3(BX * REP, 1, 2), smem, stream, rm_dyn, cost, fb,
                            smp, a);
         hipError_t e = hipGetLastError();
@@ -715,8 +742,7 @@ struct ModelT : ModelBase
                         : kernels::rolloutPipelineRepKernel<FAST, COST_T, SAMPLING_T, false, true>;
       }
       if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem);
+        (void)ensureDynamicLds(reinterpret_cast<const void*>(kfn), smem);
       constexpr int WAVES = REP + kernels::PIPE_REP_SAMPLERS + kernels::PIPE_REP_COSTS;  // dynamics + helper waves
       hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WAVES, 1, 1), smem, stream, fast, cost, smp, args, ring);
       hipError_t e = hipGetLastError();
@@ -772,8 +798,7 @@ struct ModelT : ModelBase
         return MPPI_ERR_STATE;
       }
       if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem);
+        (void)ensureDynamicLds(reinterpret_cast<const void*>(kfn), smem);
       constexpr int RPB = FOLD ? 64 / Z : 64;  // rollouts per block
       const int grid = (args.num_rollouts + RPB - 1) / RPB;
       hipLaunchKernelGGL(kfn, dim3(grid), dim3(kernels::pipelineBlockX(Z, FOLD), 1, FOLD ? 1 : Z), smem, stream, dyn, cost,
@@ -1335,7 +1360,7 @@ struct ModelT : ModelBase
     }
     auto kfn = kernels::noiseDumpKernel<SAMPLING_T>;
     if (smem > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)ensureDynamicLds(reinterpret_cast<const void*>(kfn), smem);
     hipLaunchKernelGGL(kfn, dim3((s.num_rollouts_local + 63) / 64), dim3(64, 1, 1), smem, stream, dump_smp, out_d);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
@@ -1447,8 +1472,7 @@ struct ModelT : ModelBase
     auto kfn = in_loop ? kernels::rolloutKernel<FAST, COST_T, SAMPLING_T, X, 1, Z, SAMPLING_T::IN_LOOP_DRAW>
                        : kernels::rolloutKernel<FAST, COST_T, SAMPLING_T, X, 1, Z, false>;
     if (smem > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem);
+      (void)ensureDynamicLds(reinterpret_cast<const void*>(kfn), smem);
     const int grid = (args.num_rollouts + X - 1) / X;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(X * REP, 1, Z), smem, stream, fast, cost, smp, args);
     hipError_t e = hipGetLastError();
@@ -1491,8 +1515,7 @@ struct ModelT : ModelBase
                        : kernels::rolloutKernel<DYN_T, COST_T, SAMPLING_T, X, Y, Z, false>;
     if (smem > 48 * 1024)
     {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipError_t e = ensureDynamicLds(reinterpret_cast<const void*>(kfn), smem);
       if (e != hipSuccess)
       {
         err = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e);
@@ -1580,7 +1603,7 @@ struct ModelT : ModelBase
         {
           auto kw = a.scratch_d ? kernels::finalizeRepKernel<WAVE_T, true> : kernels::finalizeRepKernel<WAVE_T, false>;
           if (smem_w > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w);
+            (void)ensureDynamicLds(reinterpret_cast<const void*>(kw), smem_w);
           hipLaunchKernelGGL(kw, dim3(D), dim3(64, 1, 1), smem_w, stream, wave_form, a);
           hipError_t e = hipGetLastError();
           if (e != hipSuccess)
@@ -1603,8 +1626,7 @@ struct ModelT : ModelBase
       {
         auto krep = a.scratch_d ? kernels::finalizeRepKernel<DYN_FAST_T, true> : kernels::finalizeRepKernel<DYN_FAST_T, false>;
         if (smem_rep > 48 * 1024)
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(krep), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)smem_rep);
+          (void)ensureDynamicLds(reinterpret_cast<const void*>(krep), smem_rep);
         hipLaunchKernelGGL(krep, dim3(D), dim3(64, 1, 1), smem_rep, stream, fast, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
@@ -1623,8 +1645,7 @@ struct ModelT : ModelBase
     }
     auto kfn = a.scratch_d ? kernels::finalizeKernel<DYN_T, FIN_BY, true> : kernels::finalizeKernel<DYN_T, FIN_BY, false>;
     if (smem > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem);
+      (void)ensureDynamicLds(reinterpret_cast<const void*>(kfn), smem);
     hipLaunchKernelGGL(kfn, dim3(D), dim3(kernels::finalizeBlockX(FIN_BY), FIN_BY, 1), smem, stream, dyn, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)

@@ -67,6 +67,9 @@ struct FNNMfma
   float a1[RB][KS_IN];
   float a2[RB][KS_H];
   float a3[KS_H];
+#if defined(MPPI_FNN_L3_SPLIT)
+  float w3s[4][RB * 4];  ///< W3[o][16 rb + 4 g + i]: the output layer's weights of the units this lane owns in the D layout
+#endif
   float b1[RB][4];
   float b2[RB][4];
   float b3[4];
@@ -106,6 +109,15 @@ struct FNNMfma
 #pragma unroll
     for (int i = 0; i < 4; i++)
       b3[i] = (i < OUT) ? B3[i] : 0.0f;
+#if defined(MPPI_FNN_L3_SPLIT)
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          w3s[o][4 * rb + i] = (o < OUT) ? W3[o * H + 16 * rb + 4 * g + i] : 0.0f;
+#endif
   }
 
   /** hidden layer epilogue: bias + tanh (pairwise packed, det::tanh_n) of the RB x 4 values this lane owns, then the
@@ -197,6 +209,39 @@ struct FNNMfma
 #pragma unroll
       for (int rb = 0; rb < RB; rb++)
         acc[rb] = mfma16x16x4(a2[rb][s], bh[s], acc[rb]);
+#if defined(MPPI_FNN_L3_SPLIT)
+    {
+      /* ---- layer 3 on the vector unit, in the D layout: no transpose, no padded MFMA rows.  Lane group g owns the units
+       * 16 rb + 4 g + i: chain g = their products in ascending unit order; out = (chain0 + chain1) + (chain2 + chain3) + b ---- */
+      float v[RB * 4];
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          v[4 * rb + i] = acc[rb][i] + b2[rb][i];
+      mppi::det::tanh_n_lockstep<RB * 4>(v);
+      float p[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+      for (int j = 0; j < RB * 4; j++)
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+          p[o] = mppi::det::fma(w3s[o][j], v[j], p[o]);
+#pragma unroll
+      for (int o = 0; o < 4; o++)
+      {
+        const unsigned b = __float_as_uint(p[o]);
+        auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);  // [even row's value, odd row's value] in both rows of a pair
+        const float s01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        const unsigned c = __float_as_uint(s01);
+        auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);  // [rows 0-1's value, rows 2-3's value] in both halves
+        p[o] = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < OUT; i++)
+        out[i] = p[i] + b3[i];
+      return;
+    }
+#endif
     float bo[KS_H];
     squash(acc, b2, bo);
     gather8(bo);

@@ -147,13 +147,10 @@ struct mppi_handle_s
   bool results_in_io = false;      // the last finalize pass wrote to io_out_h (low-latency path), not to out_block_d
   bool traj_pending = false;       // state_h / output of the last call are still being written by the finalize kernel
   bool low_latency = true;         // MPPI_AMD_NO_SPIN=1 in the environment: copy + hipStreamSynchronize hand-over instead
-  /* Direct ingest (round 5): the first rollout launch and the finalize kernel of a mppi_compute_control read x0 / the nominal
-   * control / the control history STRAIGHT from the host-mapped input block — mapped non-coherent, i.e. cached in the L2s and
-   * valid from the launch boundary on — instead of from a device block a separate ingestKernel filled first: one launch
-   * (boundary + a PCIe read of its own) less in front of the rollout.  MPPI_AMD_DIRECT_INGEST=0 restores the ingest launch. */
-  bool direct_ingest = false;
-  const float* x0_src_d = nullptr;    // where the NEXT rollout launch reads its initial state from (nullptr: x0_d)
-  const float* mean_src_d = nullptr;  // ... and its nominal control (nullptr: mean_d)
+  /* host-side stamps of the last low-latency Vanilla mppi_compute_control, microseconds since the call's first statement
+   * (mppi_debug_host_stamps; tools/compute_control_host_timing.py): [0] inputs written, [1] ingest enqueued, [2] iterations
+   * enqueued, [3] merge flushed, [4] finalize enqueued, [5] flag 0 seen, [6] results copied out */
+  double host_stamps_us[8] = { 0 };
   float* step_pin_h = nullptr;     // [S + C] host memory mapped into the device: [x | u] of a single model step
   float* step_pin_dev = nullptr;   // its device address
   unsigned step_seq = 0;           // hand-over counter of the model-step flag (io_flags[8])
@@ -748,13 +745,7 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     const char* no_spin = getenv("MPPI_AMD_NO_SPIN");
     h->low_latency = !(no_spin && no_spin[0] == '1');
     const unsigned map_flags = hipHostMallocMapped | hipHostMallocCoherent;
-    const char* direct = getenv("MPPI_AMD_DIRECT_INGEST");
-    h->direct_ingest = h->low_latency && cfg->controller != MPPI_CONTROLLER_ROBUST && cfg->controller != MPPI_CONTROLLER_TUBE &&
-                       cfg->world_size == 1 && !(direct && direct[0] == '0');
-    // inputs: written by the host before a launch, read by kernels after it -> coherence at launch boundaries is enough, and
-    // non-coherent mapping lets the L2s serve the 256 blocks that all read the same few hundred bytes
-    const unsigned in_flags = h->direct_ingest ? (hipHostMallocMapped | hipHostMallocNonCoherent) : map_flags;
-    if (hipHostMalloc((void**)&h->io_in_h, h->in_floats * sizeof(float), in_flags) != hipSuccess ||
+    if (hipHostMalloc((void**)&h->io_in_h, h->in_floats * sizeof(float), map_flags) != hipSuccess ||
         hipHostMalloc((void**)&h->io_out_h, h->out_floats * sizeof(float), map_flags) != hipSuccess ||
         hipHostMalloc((void**)&h->io_flags_h, 64, map_flags) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->io_in_dev, h->io_in_h, 0) != hipSuccess ||
@@ -1542,7 +1533,7 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   a.num_rollouts = h->K_local;
   a.lambda = h->cfg.lambda;
   a.alpha = h->cfg.alpha;
-  a.init_x_d = h->x0_src_d ? h->x0_src_d : h->x0_d;
+  a.init_x_d = h->x0_d;
   a.trajectory_costs_d = h->costs_d;
   a.partials_d = h->partials_d;
   a.save_samples = h->samples_d ? 1 : 0;
@@ -1565,8 +1556,7 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   s.rollout_offset = h->K_offset;
   s.num_timesteps = h->cfg.num_timesteps;
   s.num_distributions = h->D;
-  s.control_means_d = h->mean_src_d ? h->mean_src_d : h->mean_d;
-  h->x0_src_d = h->mean_src_d = nullptr;  // one launch only: later iterations read what the merge wrote to mean_d
+  s.control_means_d = h->mean_d;
   s.eps_d = nullptr;
   if (h->noise_source == MPPI_NOISE_INJECTED)
   {
@@ -2082,28 +2072,23 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     if (h->traj_pending)  // a caller that never asked for the previous trajectories: the kernel must be done with io_out
       MPPI_TRY(waitHostFlag(h, 1, h->io_seq));
     h->traj_pending = false;
+    const std::chrono::steady_clock::time_point t_call = std::chrono::steady_clock::now();
+    auto stamp = [&](int i) {
+      h->host_stamps_us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
+    };
     float* in = h->io_in_h;
     std::copy(x0, x0 + h->S, in + (h->x0_d - h->in_block_d));
     std::copy(h->control_h.begin(), h->control_h.end(), in + (h->mean_d - h->in_block_d));
     std::copy(h->history_h.begin(), h->history_h.end(), in + (h->history_d - h->in_block_d));
-    const bool direct = h->direct_ingest && h->cfg.num_iters >= 1 && !h->samples_d && h->reduction_mode == MPPI_REDUCTION_FUSED &&
-                        !tsallisActive(h);
-    if (direct)
-    {  // no ingest launch: the first rollout launch and the finalize kernel read the mapped block themselves
-      h->x0_src_d = h->io_in_dev + (h->x0_d - h->in_block_d);
-      h->mean_src_d = h->io_in_dev + (h->mean_d - h->in_block_d);
-      a.x0_d = h->x0_src_d;
-      a.history_d = h->io_in_dev + (h->history_d - h->in_block_d);
-    }
-    else
-    {
-      hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
-      HIP_TRY(h, hipGetLastError());
-    }
+    stamp(0);
+    hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+    HIP_TRY(h, hipGetLastError());
+    stamp(1);
     for (int it = 0; it < h->cfg.num_iters; it++)
       MPPI_TRY(iteration(h, it, stride));
-    h->x0_src_d = h->mean_src_d = nullptr;
+    stamp(2);
     MPPI_TRY(flushMerge(h));  // the last iteration's records (streamed merge): everything below reads mean_d / stats_d
+    stamp(3);
     a.control_out_d = h->io_out_dev + (h->ctrl_out_d - h->out_block_d);
     a.state_out_d = h->io_out_dev + (h->state_out_d - h->out_block_d);
     a.output_out_d = h->io_out_dev + (h->output_out_d - h->out_block_d);
@@ -2115,19 +2100,16 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     const mppi_status st = h->model->launchFinalize(1, a, h->stream, err);
     if (st != MPPI_OK)
       return fail(h, st, err);
-    if (direct)
-    {  // behind the finalize kernel, off the caller's path: the device-resident x0 / history of later mppi_optimize / operator calls
-      hipLaunchKernelGGL(kernels::ingestRangesKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d,
-                         (int)(h->mean_d - h->in_block_d), (int)(h->history_d - h->in_block_d),
-                         (int)(h->in_floats - (size_t)(h->history_d - h->in_block_d)));
-    }
     h->out_pin_fresh = false;
     h->results_in_io = true;
     h->traj_pending = true;  // set before the wait: a failing wait must not leave io_out unguarded for the next call
+    stamp(4);
     MPPI_TRY(waitHostFlag(h, 0, h->io_seq));
+    stamp(5);
     const float* out = h->io_out_h;
     std::copy(out, out + (size_t)T * h->C, h->control_h.begin());
     parseStats(h, out + (h->stats_d - h->out_block_d));
+    stamp(6);
     if (!allFinite(h->control_h))
       return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control sequence");
     return MPPI_OK;
@@ -3181,6 +3163,16 @@ mppi_status mppi_choose_kernel(mppi_handle h, int num_evaluations, int* chosen_v
     *fused_ms = t_ms[0];
   if (pipeline_ms)
     *pipeline_ms = t_ms[1];
+  return MPPI_OK;
+}
+
+/** diagnostics: the host-side stamps of the last low-latency Vanilla mppi_compute_control (see mppi_handle_s::host_stamps_us) */
+mppi_status mppi_debug_host_stamps(mppi_handle h, double* out8)
+{
+  CHECK_HANDLE(h);
+  if (!out8)
+    return fail(h, MPPI_ERR_INVALID_ARG, "null");
+  std::copy(h->host_stamps_us, h->host_stamps_us + 8, out8);
   return MPPI_OK;
 }
 

@@ -492,16 +492,6 @@ __global__ void __launch_bounds__(256) ingestKernel(const float* __restrict__ ho
   for (int i = (int)threadIdx.x; i < n; i += 256)
     dst[i] = host_mapped[i];
 }
-/** two ranges of the same block in one launch: [0, n0) and [off1, off1 + n1) — the device-resident copies of x0 and the control
- *  history behind a direct-ingest mppi_compute_control (the nominal control between them now holds u*, not the input) */
-__global__ void __launch_bounds__(256) ingestRangesKernel(const float* __restrict__ host_mapped, float* __restrict__ dst, int n0,
-                                                          int off1, int n1)
-{
-  for (int i = (int)threadIdx.x; i < n0; i += 256)
-    dst[i] = host_mapped[i];
-  for (int i = (int)threadIdx.x; i < n1; i += 256)
-    dst[off1 + i] = host_mapped[off1 + i];
-}
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Unfused kernel-level operators with the reference's launch-wrapper semantics, exported through the C ABI for the

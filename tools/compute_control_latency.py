@@ -11,13 +11,14 @@ for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
 import numpy as np  # noqa: E402
 from common import cartpole_cfg, make_engine  # noqa: E402
 
-for K in (2048, 16384):
+IDLE_ONLY = len(sys.argv) > 1 and sys.argv[1] == "idle"  # tools/compute_control_trace.sh: K = 16384, idle-stream calls only
+for K in ((16384,) if IDLE_ONLY else (2048, 16384)):
     cfg = cartpole_cfg(K=K, T=100)
     eng = make_engine(cfg)
     x = cfg["x0"].copy()
     for _ in range(50):
         eng.computeControl(x, 1)
-    n = 1000
+    n = 300 if IDLE_ONLY else 1000
     t0 = time.perf_counter()
     for _ in range(n):
         eng.computeControl(x, 1)
