@@ -245,13 +245,11 @@ def kernel_stats_us(kernel_prefix):
     import csv
     import glob
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*kernel_stats.csv")), reverse=True):
-        try:
-            for row in csv.DictReader(open(f)):
-                name = row.get("Name") or row.get("name") or row.get("KernelName") or ""
-                if name.startswith(kernel_prefix):
-                    ns = float(row.get("AverageNs") or row.get("Average") or row.get("avg_ns") or 0.0)
-                    if ns > 0:
-                        return ns * 1e-3, os.path.relpath(f, REPO)
+        try:  # tools/stats_summary.py's format: comment lines, then calls,total_us,avg_us,...,kernel
+            lines = [ln for ln in open(f) if not ln.startswith("#")]
+            for row in csv.DictReader(lines):
+                if kernel_prefix in (row.get("kernel") or "") and float(row.get("avg_us") or 0.0) > 0:
+                    return float(row["avg_us"]), os.path.relpath(f, REPO)
         except Exception:  # noqa: BLE001
             continue
     return None, None

@@ -59,6 +59,7 @@ public:
   {
     const int layers[4] = { 6, 32, 32, 4 };  // ar_nn_model.cu:7, :17
     helper_.setStructure(layers, 4);
+    helper_.split_output_sum_ = true;  // this network's output layer in every form and in the oracle (fnn_helper.hpp)
   }
   static const char* getDynamicsModelName()
   {

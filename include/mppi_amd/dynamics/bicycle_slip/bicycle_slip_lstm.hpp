@@ -71,6 +71,7 @@ public:
     using namespace bicycle_slip_lstm;
     const int out_layers[3] = { LSTM_HIDDEN + LSTM_INPUT, MLP_HIDDEN, NET_OUTPUT };
     lstm_.setStructure(LSTM_INPUT, LSTM_HIDDEN, out_layers, 3);
+    lstm_.output_nn_.split_output_sum_ = true;  // this network's output layer in every form and in the oracle (fnn_helper.hpp)
   }
   static const char* getDynamicsModelName()
   {

@@ -74,6 +74,19 @@ public:
     return true;
   }
 
+  /**
+   * Summation order of the OUTPUT layer's dot products.  false: the reference's single chain, k ascending
+   * (fnn_helper.cu:458-462).  true — set by the two networks whose rollout forward runs on the matrix cores (AutoRally
+   * 6-32-32-4: NeuralNetModel; the bicycle LSTM's output net {22, 32, 4}) so that EVERY form of those models (this LDS form,
+   * FNNMfma / LSTMMfma, FNNWave / LSTMWave) and the CPU oracle evaluate the same bits: four interleaved chains, chain g =
+   * the inputs k with (k >> 2) & 3 == g in ascending k, out = (c0 + c1) + (c2 + c3) + b.  In the MFMA forms that is the
+   * layer evaluated where the previous layer's outputs already are (lane group g of the D layout owns exactly chain g's
+   * inputs) — 16 packed fmas and two swap-and-add steps instead of 8 MFMAs that use 4 of their 16 rows, behind two 4x4
+   * transposes (AutoRally-NN K=16384, T=150: 188.4 / 182.5 -> 179.0 / 174.2 us per launch, A/B in one session, round 5).
+   * Only the ORDER of the additions differs from the reference; tests/test_fnn_output_order.py bounds the effect.
+   */
+  bool split_output_sum_ = false;
+
   /** block-shared LDS bytes: the parameter blob, padded to 16 B (reference: SHARED_MEM_REQUEST_GRD_BYTES) */
   __host__ __device__ int getGrdSharedSizeBytes() const
   {
@@ -126,11 +139,22 @@ public:
       const float* W = theta_s + stride_idcs_[2 * i];
       const float* b = theta_s + stride_idcs_[2 * i + 1];
       const int n_in = net_structure_[i], n_out = net_structure_[i + 1];
+      const bool split = split_output_sum_ && i == NUM_LAYERS - 2;
       for (int j = tdy; j < n_out; j += bdy)
       {
         float tmp = 0.0f;
-        for (int k = 0; k < n_in; k++)
-          tmp = mppi::det::fma(W[j * n_in + k], curr_act[k], tmp);
+        if (split)
+        {  // the matrix-core networks' output layer: four interleaved chains (see split_output_sum_)
+          float c[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+          for (int k = 0; k < n_in; k++)
+            c[(k >> 2) & 3] = mppi::det::fma(W[j * n_in + k], curr_act[k], c[(k >> 2) & 3]);
+          tmp = (c[0] + c[1]) + (c[2] + c[3]);
+        }
+        else
+        {
+          for (int k = 0; k < n_in; k++)
+            tmp = mppi::det::fma(W[j * n_in + k], curr_act[k], tmp);
+        }
         tmp += b[j];
         if (i < NUM_LAYERS - 2)
           tmp = mppi::nn::tanh(tmp);

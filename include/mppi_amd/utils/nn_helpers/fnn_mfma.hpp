@@ -18,12 +18,15 @@
  *    layer x 16 rollouts are spread evenly over the 64 lanes, evaluated pairwise as packed fp32 (det::tanh2) — and
  *    re-laid out as the next layer's B fragments with the cross-lane 4x4 transpose of wave_ops.hpp (v_permlane32_swap +
  *    v_permlane16_swap): no LDS traffic and no barrier anywhere in the forward pass.
- *  - The last layer's rows are replicated (row m computes output m & 3), so every lane of a rollout ends up holding all
- *    OUT outputs and no broadcast is needed.
+ *  - The last (linear) layer does not go through the matrix core: 4 outputs would use 4 of an MFMA's 16 rows.  Every lane
+ *    multiplies the 8 hidden values it owns in the D layout with its slices of W3 (16 packed fmas for the 4 outputs) and the
+ *    four lane groups' partial chains meet in two swap-and-add steps (wave_ops.hpp: sumOverLaneGroups) — the summation
+ *    order FNNHelper::split_output_sum_ defines for this network in every form and in the oracle.
  *
  * Numerics: a chain of MFMAs over the k-steps is bit-for-bit the k-ordered fp32 fma chain
  *     acc = fma(W[j][k], act[k], acc), k ascending, acc0 = 0;  then acc += b[j]
  * that FNNHelper::forward (fnn_helper.hpp) and the CPU oracle evaluate; zero padding of k adds fma(0, 0, acc) = acc.
+ * Output layer: four interleaved chains + (c0 + c1) + (c2 + c3), the same in all of them (split_output_sum_).
  *
  * Restrictions: layers {IN, H, H, OUT} with IN <= 8, H a multiple of 16, OUT <= 4 (the AutoRally 6-32-32-4 network).
  */
@@ -66,10 +69,7 @@ struct FNNMfma
   /* per-lane constants: weight fragments (A operands) and the biases of the rows this lane owns in the D layout */
   float a1[RB][KS_IN];
   float a2[RB][KS_H];
-  float a3[KS_H];
-#if defined(MPPI_FNN_L3_SPLIT)
   float w3s[4][RB * 4];  ///< W3[o][16 rb + 4 g + i]: the output layer's weights of the units this lane owns in the D layout
-#endif
   float b1[RB][4];
   float b2[RB][4];
   float b3[4];
@@ -104,12 +104,8 @@ struct FNNMfma
       }
     }
 #pragma unroll
-    for (int s = 0; s < KS_H; s++)
-      a3[s] = ((m & 3) < OUT) ? W3[(m & 3) * H + 4 * s + g] : 0.0f;
-#pragma unroll
     for (int i = 0; i < 4; i++)
       b3[i] = (i < OUT) ? B3[i] : 0.0f;
-#if defined(MPPI_FNN_L3_SPLIT)
 #pragma unroll
     for (int o = 0; o < 4; o++)
 #pragma unroll
@@ -117,7 +113,6 @@ struct FNNMfma
 #pragma unroll
         for (int i = 0; i < 4; i++)
           w3s[o][4 * rb + i] = (o < OUT) ? W3[o * H + 16 * rb + 4 * g + i] : 0.0f;
-#endif
   }
 
   /** hidden layer epilogue: bias + tanh (pairwise packed, det::tanh_n) of the RB x 4 values this lane owns, then the
@@ -209,50 +204,31 @@ struct FNNMfma
 #pragma unroll
       for (int rb = 0; rb < RB; rb++)
         acc[rb] = mfma16x16x4(a2[rb][s], bh[s], acc[rb]);
-#if defined(MPPI_FNN_L3_SPLIT)
-    {
-      /* ---- layer 3 on the vector unit, in the D layout: no transpose, no padded MFMA rows.  Lane group g owns the units
-       * 16 rb + 4 g + i: chain g = their products in ascending unit order; out = (chain0 + chain1) + (chain2 + chain3) + b ---- */
-      float v[RB * 4];
+    /* ---- layer 3 (linear) on the vector unit, in the D layout: no transpose, no matrix-core rows that compute nothing.
+     * Lane group g owns the units 16 rb + 4 g + i — exactly the inputs of chain g of FNNHelper::split_output_sum_, in ascending
+     * order; the chains of the four lane groups meet through v_permlane16_swap (rows 0|1, 2|3) and v_permlane32_swap (halves):
+     * both lanes of a pair add the same two values in the same order, so all four lanes of a rollout hold the same bits. ---- */
+    float v[RB * 4];
 #pragma unroll
-      for (int rb = 0; rb < RB; rb++)
+    for (int rb = 0; rb < RB; rb++)
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          v[4 * rb + i] = acc[rb][i] + b2[rb][i];
-      mppi::det::tanh_n_lockstep<RB * 4>(v);
-      float p[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+      for (int i = 0; i < 4; i++)
+        v[4 * rb + i] = acc[rb][i] + b2[rb][i];
+#if !defined(MPPI_KNOCKOUT_TANH)
+    mppi::det::tanh_n_lockstep<RB * 4>(v);
+#endif
+    float p[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
-      for (int j = 0; j < RB * 4; j++)
-#pragma unroll
-        for (int o = 0; o < 4; o++)
-          p[o] = mppi::det::fma(w3s[o][j], v[j], p[o]);
+    for (int j = 0; j < RB * 4; j++)
 #pragma unroll
       for (int o = 0; o < 4; o++)
-      {
-        const unsigned b = __float_as_uint(p[o]);
-        auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);  // [even row's value, odd row's value] in both rows of a pair
-        const float s01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-        const unsigned c = __float_as_uint(s01);
-        auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);  // [rows 0-1's value, rows 2-3's value] in both halves
-        p[o] = __uint_as_float(q[0]) + __uint_as_float(q[1]);
-      }
+        p[o] = mppi::det::fma(w3s[o][j], v[j], p[o]);
 #pragma unroll
-      for (int i = 0; i < OUT; i++)
-        out[i] = p[i] + b3[i];
-      return;
-    }
-#endif
-    float bo[KS_H];
-    squash(acc, b2, bo);
-    gather8(bo);
-    /* ---- layer 3 (linear): rows replicated, every lane of the rollout receives all outputs ---- */
-    mfma_f32x4 o = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-    for (int s = 0; s < KS_H; s++)
-      o = mfma16x16x4(a3[s], bo[s], o);
+    for (int o = 0; o < 4; o++)
+      p[o] = mppi::wave::sumOverLaneGroups(p[o]);
 #pragma unroll
     for (int i = 0; i < OUT; i++)
-      out[i] = o[i] + b3[i];
+      out[i] = p[i] + b3[i];
   }
 };
 }  // namespace mppi

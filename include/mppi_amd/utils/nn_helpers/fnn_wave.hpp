@@ -7,7 +7,8 @@
  * v_mfma_f32_16x16x4_f32 of 8 passes each, the packed tanh of 8 values per lane, two cross-lane transposes — 1.2 us per
  * AutoRally step.  Here every lane owns one neuron of a layer and walks its row of the weight matrix,
  *     acc = fma(W[j][k], act[k], acc),  k ascending, acc0 = 0;  then acc += b[j]
- * — literally the chain FNNHelper::forward and the CPU oracle evaluate, so the result is the same bits as the MFMA form's —
+ * — literally the chain FNNHelper::forward and the CPU oracle evaluate (the output layer: their four interleaved chains,
+ * FNNHelper::split_output_sum_), so the result is the same bits as the MFMA form's —
  * with act[k] read from lane k of the previous layer's register (v_readlane: a scalar operand of the fma).  One tanh per
  * lane and layer.  32 + 32 + 6 dependent fmas a step instead of 18 MFMAs: 0.5 us per AutoRally step.
  *
@@ -72,10 +73,12 @@ struct FNNWave
     for (int k = 0; k < H; k++)
       acc = mppi::det::fma(w2[k], lane_value(h1, k), acc);
     const float h2 = mppi::det::tanh(acc + b2);
-    acc = 0.0f;
+    // output layer: the four interleaved chains of FNNHelper::split_output_sum_ (what every form of this network evaluates)
+    float c4[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
     for (int k = 0; k < H; k++)
-      acc = mppi::det::fma(w3[k], lane_value(h2, k), acc);
+      c4[(k >> 2) & 3] = mppi::det::fma(w3[k], lane_value(h2, k), c4[(k >> 2) & 3]);
+    acc = (c4[0] + c4[1]) + (c4[2] + c4[3]);
     acc = acc + b3;
 #pragma unroll
     for (int i = 0; i < OUT; i++)

@@ -48,7 +48,7 @@ struct LSTMMfma
   float ah[4][KS_H];   ///< gate weights, recurrent part
   float bg[4][4];      ///< gate biases of the units this lane owns in the D layout
   float a1h[RB_M][KS_H], a1x[RB_M][KS_X], b1[RB_M][4];  ///< MLP layer 1 ([h ; x] -> M)
-  float a2[KS_M], b2[4];                                 ///< MLP layer 2 (M -> OUT), rows replicated
+  float w2s[4][RB_M * 4], b2[4];                         ///< MLP layer 2 (M -> OUT): W2[o][16 rb + 4 g + i], this lane's units
   /* recurrent state */
   float hb[KS_H];  ///< hidden state as B fragments: unit 4s + g
   float c[4];      ///< cell state of units 4g + i
@@ -99,8 +99,12 @@ struct LSTMMfma
         b1[rb][i] = B1[16 * rb + 4 * g + i];
     }
 #pragma unroll
-    for (int s = 0; s < KS_M; s++)
-      a2[s] = ((m & 3) < OUT) ? W2[(m & 3) * M + 4 * s + g] : 0.0f;
+    for (int o = 0; o < 4; o++)
+#pragma unroll
+      for (int rb = 0; rb < RB_M; rb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          w2s[o][4 * rb + i] = (o < OUT) ? W2[o * M + 16 * rb + 4 * g + i] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; i++)
       b2[i] = (i < OUT) ? B2[i] : 0.0f;
@@ -201,23 +205,26 @@ struct LSTMMfma
       mppi::det::tanh_n_lockstep<RB_M * 4>(v);
 #pragma unroll
       for (int rb = 0; rb < RB_M; rb++)
-      {
 #pragma unroll
         for (int i = 0; i < 4; i++)
-          act[rb][i] = v[4 * rb + i];
-        mppi::wave::transpose4x4(act[rb]);  // units 16 rb + 4 s + g, s = 0..3
-      }
+          act[rb][i] = v[4 * rb + i];  // stays in the D layout: units 16 rb + 4 g + i
     }
-    /* ---- layer 2 (linear), rows replicated so that every lane of the rollout receives all outputs ---- */
-    mfma_f32x4 o = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    /* ---- layer 2 (linear) on the vector unit, in the D layout (fnn_mfma.hpp, layer 3: the same step): lane group g owns
+     * the inputs of chain g of FNNHelper::split_output_sum_; the four chains meet in two swap-and-add steps ---- */
+    float p[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
     for (int rb = 0; rb < RB_M; rb++)
 #pragma unroll
-      for (int s = 0; s < 4; s++)
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[4 * rb + s], act[rb][s], o, 0, 0, 0);
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+          p[o] = mppi::det::fma(w2s[o][4 * rb + i], act[rb][i], p[o]);
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+      p[o] = mppi::wave::sumOverLaneGroups(p[o]);
 #pragma unroll
     for (int i = 0; i < OUT; i++)
-      out[i] = o[i] + b2[i];
+      out[i] = p[i] + b2[i];
   }
 };
 }  // namespace mppi

@@ -105,10 +105,12 @@ struct LSTMWave
       acc = mppi::det::fma(w1x[k], in[k], acc);
     const float a1 = mppi::det::tanh(acc + b1);
     /* ---- layer 2 (linear) ---- */
-    acc = 0.0f;
+    // the four interleaved chains of FNNHelper::split_output_sum_ (what every form of this network evaluates)
+    float c4[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
     for (int k = 0; k < M; k++)
-      acc = mppi::det::fma(w2[k], lane_value(a1, k), acc);
+      c4[(k >> 2) & 3] = mppi::det::fma(w2[k], lane_value(a1, k), c4[(k >> 2) & 3]);
+    acc = (c4[0] + c4[1]) + (c4[2] + c4[3]);
     acc = acc + b2;
 #pragma unroll
     for (int i = 0; i < OUT; i++)

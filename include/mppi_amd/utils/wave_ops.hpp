@@ -43,6 +43,20 @@ __device__ inline void transpose4x4(float (&v)[4])
   v[2] = __uint_as_float(r23[0]);
   v[3] = __uint_as_float(r23[1]);
 }
+/**
+ * v, one value per lane group g = lane >> 4 (per column lane & 15): returns (v_0 + v_1) + (v_2 + v_3) in all four groups.
+ * v_permlane16_swap(a, a) leaves [row-pair's even value, row-pair's odd value] in both rows of a pair, v_permlane32_swap(c, c)
+ * [lower half's value, upper half's value] in both halves: the two lanes of a pair add the same operands in the same order.
+ */
+__device__ inline float sumOverLaneGroups(const float v)
+{
+  const unsigned b = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+  const float s01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const unsigned c = __float_as_uint(s01);
+  auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
 /* ---- wave64 all-reduce without LDS: four DPP steps inside the rows of 16 lanes (xor 1, xor 2, half-row mirror, row mirror:
  * a butterfly — both lanes of a pair form the same commutative sum, so all 16 lanes of a row end with identical bits), then
  * the four row results through v_readlane in a fixed order.  ~20 issue slots against six dependent ds_bpermute round trips

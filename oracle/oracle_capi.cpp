@@ -130,20 +130,50 @@ int oracle_set_blob(void* h, const char* name, const float* data, size_t count, 
   return -1;
 }
 /** one FNN forward on the host: layers[nl], theta blob, in -> out (known-answer tests) */
-void oracle_fnn_forward(const int* layers, int nl, const float* theta, const float* in, float* out)
+void oracle_fnn_forward2(const int* layers, int nl, const float* theta, const float* in, float* out, int split_output_sum)
 {
   FNN net;
   net.setStructure(std::vector<int>(layers, layers + nl));
+  net.split_output_sum = split_output_sum != 0;
   std::copy(theta, theta + net.numParams(), net.theta.begin());
   net.forward(in, out);
 }
+void oracle_fnn_forward(const int* layers, int nl, const float* theta, const float* in, float* out)
+{
+  oracle_fnn_forward2(layers, nl, theta, in, out, 0);  // the reference's order (fnn_helper.cu:458-462)
+}
+/** the output layer's summation order of the handle's network model (FNN::split_output_sum): 1 = what the AutoRally and
+ *  bicycle-LSTM models evaluate (default for them), 0 = the reference's single chain — for the test that bounds the difference */
+int oracle_set_split_output_sum(void* h, int on)
+{
+  auto* c = (Controller*)h;
+  if (auto* m = dynamic_cast<ARNeuralNetModel*>(c->dyn.get()))
+  {
+    m->net.split_output_sum = on != 0;
+    return 0;
+  }
+  if (auto* m = dynamic_cast<BicycleSlipLSTM*>(c->dyn.get()))
+  {
+    m->net.out_net.split_output_sum = on != 0;
+    return 0;
+  }
+  return -1;
+}
 /** `steps` LSTM forwards on the host from (h0, c0) of the blob with a constant input (known-answer tests):
  *  out [steps][output dim] */
+void oracle_lstm_forward2(int input_dim, int hidden_dim, const int* out_layers, int nl, const float* lstm_blob,
+                          const float* fnn_blob, const float* in, int steps, float* out, int split_output_sum);
 void oracle_lstm_forward(int input_dim, int hidden_dim, const int* out_layers, int nl, const float* lstm_blob,
                          const float* fnn_blob, const float* in, int steps, float* out)
 {
+  oracle_lstm_forward2(input_dim, hidden_dim, out_layers, nl, lstm_blob, fnn_blob, in, steps, out, 0);
+}
+void oracle_lstm_forward2(int input_dim, int hidden_dim, const int* out_layers, int nl, const float* lstm_blob,
+                          const float* fnn_blob, const float* in, int steps, float* out, int split_output_sum)
+{
   LSTM net;
   net.setStructure(input_dim, hidden_dim, std::vector<int>(out_layers, out_layers + nl));
+  net.out_net.split_output_sum = split_output_sum != 0;
   std::copy(lstm_blob, lstm_blob + net.numParams(), net.w.begin());
   std::copy(fnn_blob, fnn_blob + net.out_net.numParams(), net.out_net.theta.begin());
   std::vector<float> h(net.h0(), net.h0() + hidden_dim), c(net.c0(), net.c0() + hidden_dim);

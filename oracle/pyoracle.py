@@ -43,6 +43,10 @@ def lib():
         L.oracle_set_cost_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_set_blob.argtypes = [C.c_void_p, C.c_char_p, _f32p, C.c_size_t, C.POINTER(C.c_int), C.c_int]
         L.oracle_fnn_forward.argtypes = [C.POINTER(C.c_int), C.c_int, _f32p, _f32p, _f32p]
+        L.oracle_fnn_forward2.argtypes = [C.POINTER(C.c_int), C.c_int, _f32p, _f32p, _f32p, C.c_int]
+        L.oracle_lstm_forward2.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _f32p, _f32p, _f32p, C.c_int,
+                                           _f32p, C.c_int]
+        L.oracle_set_split_output_sum.argtypes = [C.c_void_p, C.c_int]
         L.oracle_lstm_forward.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _f32p, _f32p, _f32p, C.c_int,
                                           _f32p]
         L.oracle_state_deriv.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
@@ -148,6 +152,10 @@ class Oracle:
 
     def set_cost_params(self, pod):
         assert self.L.oracle_set_cost_params(self.h, C.byref(pod), C.sizeof(pod)) == 0
+
+    def set_split_output_sum(self, on):
+        """AutoRally-NN / bicycle-LSTM models: the output layer's summation order (default: split, what the engine evaluates)"""
+        assert self.L.oracle_set_split_output_sum(self.h, int(on)) == 0
 
     def set_blob(self, name, array):
         a = _f32(array)
@@ -330,22 +338,23 @@ def philox_normal(seed, generation, K, T, Cdim, k_begin=0, k_end=None, stream=0)
     return out
 
 
-def fnn_forward(layers, theta, x):
+def fnn_forward(layers, theta, x, split_output_sum=False):
+    """split_output_sum: the output layer's summation order of the matrix-core networks (oracle_models.hpp: FNN)"""
     layers = list(layers)
     arr = (C.c_int * len(layers))(*layers)
     out = np.zeros(layers[-1], np.float32)
-    lib().oracle_fnn_forward(arr, len(layers), _f32(theta).reshape(-1), _f32(x).reshape(-1), out)
+    lib().oracle_fnn_forward2(arr, len(layers), _f32(theta).reshape(-1), _f32(x).reshape(-1), out, int(split_output_sum))
     return out
 
 
-def lstm_forward(input_dim, hidden_dim, out_layers, lstm_blob, fnn_blob, inputs):
+def lstm_forward(input_dim, hidden_dim, out_layers, lstm_blob, fnn_blob, inputs, split_output_sum=False):
     """inputs [steps][input_dim] -> outputs [steps][out_layers[-1]], state carried from the blob's (h0, c0)"""
     out_layers = list(out_layers)
     arr = (C.c_int * len(out_layers))(*out_layers)
     x = _f32(inputs).reshape(-1, input_dim)
     out = np.zeros((x.shape[0], out_layers[-1]), np.float32)
-    lib().oracle_lstm_forward(input_dim, hidden_dim, arr, len(out_layers), _f32(lstm_blob).reshape(-1),
-                              _f32(fnn_blob).reshape(-1), x, x.shape[0], out)
+    lib().oracle_lstm_forward2(input_dim, hidden_dim, arr, len(out_layers), _f32(lstm_blob).reshape(-1),
+                               _f32(fnn_blob).reshape(-1), x, x.shape[0], out, int(split_output_sum))
     return out
 
 

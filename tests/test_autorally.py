@@ -43,7 +43,9 @@ def test_ar_dynamics_known_answers():
     xd = o.state_deriv([0, 0, np.pi / 2, 0, 3, 5, 1], [0, 0])
     np.testing.assert_allclose(xd[:3], [-5, 3, -1], rtol=4e-7)
     xd = o.state_deriv(np.ones(7), np.ones(2))
-    assert np.array_equal(xd[3:], np.full(4, 33.0, np.float32))
+    # EXPECT_FLOAT_EQ (4 ulp) in the reference; the reference's own summation order gives 33 exactly (test_fnn_output_order.py),
+    # the matrix-core networks' order (the model's, FNN::split_output_sum) lands 1 ulp below: 32 x tanh(7) is not 32
+    assert ulp_diff(xd[3:], np.full(4, 33.0, np.float32)).max() <= 4
 
 
 def test_ar_standard_cost_pieces():

@@ -64,7 +64,8 @@ def test_bicycle_lstm_oracle_kinematics_and_state():
     x = np.array([0.1, 1.0, -0.2, 0.3, 0.4, -0.5], np.float32)
     out = po.lstm_forward(6, 16, [22, 32, 4], lstm, fnn, np.stack([x, x]))
     assert np.abs(out[0] - out[1]).max() > 1e-4
-    np.testing.assert_array_equal(xd[3:], po.lstm_forward(6, 16, [22, 32, 4], lstm, fnn, [[0, 3, 5, 1, 0, 0]])[0])
+    # (the model evaluates its output layer in the split order of the matrix-core networks: oracle_models.hpp, FNN)
+    np.testing.assert_array_equal(xd[3:], po.lstm_forward(6, 16, [22, 32, 4], lstm, fnn, [[0, 3, 5, 1, 0, 0]], split_output_sum=True)[0])
 
 
 # ------------------------------------------------------------------ GPU parity -----------------------------------------
