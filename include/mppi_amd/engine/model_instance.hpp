@@ -821,6 +821,7 @@ struct ModelT : ModelBase
   /* colored noise: basis table cache */
   float* basis_d = nullptr;
   int basis_T = -1, basis_stride = -1;
+  size_t basis_floats = 0;
   bool basis_dirty = true;
   float* weights_d = nullptr;
   float* weights2_d = nullptr;
@@ -1310,10 +1311,15 @@ struct ModelT : ModelBase
       if (basis_dirty || basis_T != s.num_timesteps || basis_stride != s.optimization_stride)
       {
         std::vector<float> frag;
-        sampling_distributions::buildColoredNoiseBasis(s.num_timesteps, DYN_T::CONTROL_DIM, smp.exponents_,
-                                                       smp.offset_decay_rate_, smp.fmin_, s.optimization_stride, frag);
+        const bool radix4 = sampling_distributions::coloredUseRadix4(s.num_timesteps, s.optimization_stride);
+        if (radix4)  // T a multiple of 4: two FFT decimation steps in front of a GEMM a quarter the size (colored_noise.hpp)
+          sampling_distributions::buildColoredNoiseBasisRadix4(s.num_timesteps, DYN_T::CONTROL_DIM, smp.exponents_,
+                                                               smp.offset_decay_rate_, smp.fmin_, frag);
+        else
+          sampling_distributions::buildColoredNoiseBasis(s.num_timesteps, DYN_T::CONTROL_DIM, smp.exponents_,
+                                                         smp.offset_decay_rate_, smp.fmin_, s.optimization_stride, frag);
         hipError_t e = hipStreamSynchronize(stream);  // earlier launches may still read the old table
-        if (e == hipSuccess && basis_d && basis_T != s.num_timesteps)
+        if (e == hipSuccess && basis_d && (basis_T != s.num_timesteps || basis_floats != frag.size()))
         {
           e = hipFree(basis_d);
           basis_d = nullptr;
@@ -1330,6 +1336,7 @@ struct ModelT : ModelBase
           return MPPI_ERR_HIP;
         }
         basis_T = s.num_timesteps;
+        basis_floats = frag.size();
         basis_stride = s.optimization_stride;
         basis_dirty = false;
       }

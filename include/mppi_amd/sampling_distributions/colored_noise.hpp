@@ -140,6 +140,157 @@ inline void buildColoredNoiseBasis(int T, int C, const float* exponents, float o
   }
 }
 
+/* ====================================================================================================================
+ * Radix-4 form (round 5), used whenever T is a multiple of 4 — every BASELINE horizon is.
+ *
+ * The dense table above spends 2 (2T+2) T multiply-adds per (rollout, control): an O(T^2) stand-in for the reference's FFT.
+ * Two decimation steps of that FFT are applied in front of the GEMM: with T = 4P, N = 8P, w = exp(2 pi i / N) and the
+ * weighted spectrum c_f = W_f (zr_f + i zi_f),
+ *     x[4u + r] = Re sum_{f'=0}^{P}  D_r[f'] Omega^{f' u},     Omega = w^4 = exp(2 pi i / 2P),
+ *     D_r[f'] = w^{f' r} ( c_f' + (-i)^r conj(c_{2P-f'}) + i^r c_{2P+f'} + (-1)^r conj(c_{4P-f'}) ),
+ * i.e. the four time-residue classes r = t mod 4 are four inverse real DFTs of length 2P over the SAME basis: one table
+ * A'[u][f'] = (cos, -sin)(pi f' u / P) for every class AND every control (the frequency weights now travel with the spectrum
+ * operand), P x 2(P+1) entries instead of T x 2(T+1) per control — 26 KB instead of 2 x 321 KB at T = 200 — and a quarter of
+ * the multiply-adds.  Per (f', rollout, control) a lane draws the eight spectrum entries of the four partner frequencies
+ * (two Philox quads), forms the radix-4 butterfly and the three twiddle products in registers (~40 flops) and holds the
+ * B operands of all four classes for two k-steps; the classes share every A fragment it fetches.  The offset term
+ * -decay^t x[s] of rearrangeNoise is linear in ONE time sample and is applied to the finished rows (coloredOffsetPass).
+ *
+ * Table blob (one allocation, basis_d_): [A' fragments KS4 x NTB4 x 64][slot weights C x P1 x 8][twiddles P1 x 8][decay T],
+ * P1 = P + 1 padded to a multiple of 8.
+ *   A' fragment order: frag[(ks * NTB4 + tb) * 64 + lane] = A'[u = 16 tb + (lane & 15)][f' = 4 (ks >> 1) + (lane >> 4)],
+ *                      part ks & 1 (0: cos, 1: -sin): lane group g owns frequency 4 q + g of k-step pair q — real and
+ *                      imaginary part of one D_r[f'] land in the SAME lane, so no spectrum entry is drawn twice
+ *   slot weights:      w[f'][2 slot + part] for the slots A = f', B = 2P - f', C = 2P + f', D = 4P - f': m_f w_c[f] / (sigma_c N)
+ *                      with the conjugations of B and D folded into the sign of their imaginary weight, zero for the imaginary
+ *                      parts at f = 0 and f = T, and zero for a slot that repeats a frequency another slot of the same f'
+ *                      already carries (f' = 0: C = B = 2P;  f' = P: B = A = P and D = C = 3P)
+ *   twiddles:          (cos, sin)(2 pi f' r / N) for r = 1, 2, 3
+ * Philox spectrum of this form: quad 2 f' of stream 1 + c = (zr, zi) of slots A, B; quad 2 f' + 1 = slots C, D.
+ * ==================================================================================================================== */
+__host__ __device__ inline bool coloredRadix4(int num_timesteps)
+{
+  return (num_timesteps & 3) == 0 && num_timesteps >= 16;
+}
+/** the radix-4 form reads x[s] from the finished rows: the offset sample must be one of the T kept ones */
+__host__ __device__ inline bool coloredUseRadix4(int num_timesteps, int optimization_stride)
+{
+  return coloredRadix4(num_timesteps) && optimization_stride >= 0 && optimization_stride < num_timesteps;
+}
+__host__ __device__ inline int coloredR4P1(int num_timesteps)
+{
+  return ((num_timesteps >> 2) + 1 + 7) & ~7;
+}
+/** k-steps: two per frequency quadruple 4 q + g, q = 0 .. ceil((P + 1) / 4) - 1, rounded up to whole tiles of 4 */
+__host__ __device__ inline int coloredR4KSteps(int num_timesteps)
+{
+  const int pairs = ((num_timesteps >> 2) + 1 + 3) >> 2;
+  return (2 * pairs + 3) & ~3;
+}
+__host__ __device__ inline int coloredR4TBlocks(int num_timesteps)
+{
+  return ((num_timesteps >> 2) + 15) >> 4;
+}
+__host__ __device__ inline size_t coloredR4FragFloats(int T)
+{
+  return (size_t)coloredR4KSteps(T) * coloredR4TBlocks(T) * 64;
+}
+__host__ __device__ inline size_t coloredR4BlobFloats(int T, int C)
+{
+  return coloredR4FragFloats(T) + (size_t)C * coloredR4P1(T) * 8 + (size_t)coloredR4P1(T) * 8 + (size_t)((T + 3) & ~3);
+}
+
+/** Host: the radix-4 table blob (layout above); every entry is evaluated in double and rounded to float once */
+inline void buildColoredNoiseBasisRadix4(int T, int C, const float* exponents, float offset_decay_rate, float fmin,
+                                         std::vector<float>& blob)
+{
+  const int N = 2 * T, F = T + 1, P = T / 4, P1 = coloredR4P1(T);
+  const int KS = coloredR4KSteps(T), NTB = coloredR4TBlocks(T);
+  std::vector<float> coeff, sigma;
+  coloredNoiseWeights(T, C, exponents, fmin, coeff, sigma);
+  blob.assign(coloredR4BlobFloats(T, C), 0.0f);
+  const double pi = 3.14159265358979323846264338327950288;
+  float* frag = blob.data();
+  for (int ks = 0; ks < KS; ks++)
+    for (int g = 0; g < 4; g++)
+    {
+      const int fp = 4 * (ks >> 1) + g;
+      if (fp > P)
+        continue;
+      for (int u = 0; u < P; u++)
+      {
+        const double a = pi * (double)(((long long)fp * u) % (2 * P)) / (double)P;
+        frag[((size_t)ks * NTB + (u >> 4)) * 64 + 16 * g + (u & 15)] = (float)((ks & 1) ? -sin(a) : cos(a));
+      }
+    }
+  float* wslot = frag + coloredR4FragFloats(T);
+  for (int c = 0; c < C; c++)
+  {
+    const double denom = (double)(sigma[c] * 2 * T);
+    for (int fp = 0; fp <= P; fp++)
+    {
+      const int f_of_slot[4] = { fp, 2 * P - fp, 2 * P + fp, 4 * P - fp };
+      for (int slot = 0; slot < 4; slot++)
+      {
+        const int f = f_of_slot[slot];
+        bool repeated = false;  // a frequency an earlier slot of this f' carries already
+        for (int e = 0; e < slot; e++)
+          repeated = repeated || f_of_slot[e] == f;
+        const double m_f = (f == 0 || f == T) ? 1.0 : 2.0;
+        const double w = repeated ? 0.0 : (double)coeff[(size_t)c * F + f] * m_f / denom;
+        const double conj_sign = (slot == 1 || slot == 3) ? -1.0 : 1.0;
+        float* dst = wslot + ((size_t)c * P1 + fp) * 8 + 2 * slot;
+        dst[0] = (float)w;
+        dst[1] = (f == 0 || f == T) ? 0.0f : (float)(conj_sign * w);
+      }
+    }
+  }
+  float* twid = wslot + (size_t)C * P1 * 8;
+  for (int fp = 0; fp <= P; fp++)
+    for (int r = 1; r < 4; r++)
+    {
+      const double a = 2.0 * pi * (double)(((long long)fp * r) % N) / (double)N;
+      twid[(size_t)fp * 8 + 2 * (r - 1)] = (float)cos(a);
+      twid[(size_t)fp * 8 + 2 * (r - 1) + 1] = (float)sin(a);
+    }
+  float* decay = twid + (size_t)P1 * 8;
+  for (int t = 0; t < T; t++)
+    decay[t] = offset_decay_rate == 0.0f ? 0.0f : powf(offset_decay_rate, (float)t);
+}
+
+/**
+ * The butterfly of one frequency quadruple: n[8] = (re, im) of the spectrum at the slots A, B, C, D, w[8] their weights,
+ * tw[6] = (cos, sin) of the twiddles r = 1, 2, 3  ->  d[r][2] = (Re, Im) D_r.  Every operation is a single rounded fp32
+ * add / multiply or an explicit fma; the CPU oracle performs the same sequence (oracle_colored.hpp: coloredButterfly).
+ */
+__host__ __device__ inline void coloredButterflyRadix4(const float (&n)[8], const float* __restrict__ w,
+                                                       const float* __restrict__ tw, float (&d)[4][2])
+{
+  float p[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    p[i] = w[i] * n[i];
+  // A = p0 + i p1, B = p2 + i p3, C = p4 + i p5, D = p6 + i p7
+  const float s0r = p[0] + p[6], s0i = p[1] + p[7];  // A + D
+  const float s1r = p[0] - p[6], s1i = p[1] - p[7];  // A - D
+  const float s2r = p[2] + p[4], s2i = p[3] + p[5];  // B + C
+  const float s3r = p[3] - p[5], s3i = p[4] - p[2];  // i (C - B)
+  const float c0r = s0r + s2r, c0i = s0i + s2i;
+  const float c2r = s0r - s2r, c2i = s0i - s2i;
+  const float c1r = s1r + s3r, c1i = s1i + s3i;
+  const float c3r = s1r - s3r, c3i = s1i - s3i;
+  d[0][0] = c0r;
+  d[0][1] = c0i;
+  const float cr[3] = { c1r, c2r, c3r }, ci[3] = { c1i, c2i, c3i };
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+  {
+    const float tr = tw[2 * r], ti = tw[2 * r + 1];
+    d[r + 1][0] = mppi::det::fma(cr[r], tr, -(ci[r] * ti));
+    d[r + 1][1] = mppi::det::fma(cr[r], ti, ci[r] * tr);
+  }
+}
+
 template <class DYN_PARAMS_T>
 class ColoredNoiseDistribution : public GaussianDistribution<DYN_PARAMS_T>
 {
@@ -170,8 +321,11 @@ public:
   __host__ __device__ inline int getGrdSharedSizeBytes() const
   {
     const int ntb = coloredNumTBlocks(this->params_.num_timesteps);  // even
-    return 2 * 4 * (ntb < MAX_TB ? ntb : MAX_TB) * 64 * (int)sizeof(float);
+    const int dense = 2 * 4 * (ntb < MAX_TB ? ntb : MAX_TB) * 64 * (int)sizeof(float);
+    const int radix4 = 2 * 4 * MAX_TB4 * 64 * (int)sizeof(float);
+    return dense > radix4 ? dense : radix4;
   }
+  static constexpr int MAX_TB4 = 4;  ///< radix-4 form: time blocks (of 16 samples of ONE residue class) per pass
 
   /**
    * One (control, row-group pass, time-block chunk) of the prologue GEMM with a COMPILE-TIME number of time blocks NTBP
@@ -307,6 +461,178 @@ public:
   }
 
   /**
+   * Radix-4 form of coloredTiles (see the block comment above buildColoredNoiseBasisRadix4): one (control, row group, chunk of
+   * NTBP time blocks) with the accumulators of all four residue classes in registers — 4 x NTBP MFMA tiles share every A
+   * fragment.  Tile j = k-steps 4j .. 4j+3 = the frequencies f' = 8j + g and 8j + 4 + g of lane group g, real and imaginary part.
+   */
+  template <int NTBP>
+  __device__ __forceinline__ void coloredTilesRadix4(const float* __restrict__ basis, const float* __restrict__ wslot,
+                                                     const float* __restrict__ twid, float* __restrict__ stage,
+                                                     float* __restrict__ theta_d, const float* __restrict__ zbuf, const int c,
+                                                     const int tb0, const int NTB, const int NG, const int T, const int stride,
+                                                     const int bx, const int nz, const int row, const uint32_t rollout,
+                                                     const bool active, const bool valid, const bool from_buffer,
+                                                     const int tid_flat, const int nthreads, const int lane)
+  {
+    const int g = lane >> 4;
+    const int P = T >> 2;
+    constexpr int TILE4 = NTBP * 16;
+    colored_f32x4 acc[4][NTBP];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int tb = 0; tb < NTBP; tb++)
+        acc[r][tb] = colored_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid_flat >> 6);
+    const int nwaves = nthreads >> 6;
+    auto stage_tile = [&](const int j) {
+      float* dst_tile = stage + (size_t)(j & 1) * 4 * NTBP * 64;
+      for (int chunk = wave_u; chunk < NTBP; chunk += nwaves)
+      {
+        const int i = chunk * 64 + lane;  // float4 index inside the tile
+        const int e = i / TILE4, r = i - e * TILE4;
+        const float* src = basis + ((size_t)(4 * j + e) * NTB + tb0) * 64 + 4 * r;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst_tile + chunk * 256), 16, 0, 0);
+      }
+    };
+    // the B operands of tile j: zq[class][e], e = 2 h + part for the lane's two frequencies f' = 8 j + 4 h + g
+    auto draw = [&](const int j, float (&zq)[4][4]) {
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+      {
+        const int fp = 8 * j + 4 * h + g;
+        float d[4][2];
+        if (fp <= P)
+        {
+          float n[8];
+          if (from_buffer)
+          {
+            const int fs[4] = { fp, 2 * P - fp, 2 * P + fp, 4 * P - fp };
+#pragma unroll
+            for (int slot = 0; slot < 4; slot++)
+            {
+              n[2 * slot] = zbuf[2 * fs[slot]];
+              n[2 * slot + 1] = zbuf[2 * fs[slot] + 1];
+            }
+          }
+          else
+          {
+            float q0[4], q1[4];
+            mppi::rng::normal4(this->seed_, this->generation_, (uint32_t)(1 + c), rollout, (uint32_t)(2 * fp), q0);
+            mppi::rng::normal4(this->seed_, this->generation_, (uint32_t)(1 + c), rollout, (uint32_t)(2 * fp + 1), q1);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+              n[i] = q0[i];
+              n[4 + i] = q1[i];
+            }
+          }
+          coloredButterflyRadix4(n, wslot + (size_t)fp * 8, twid + (size_t)fp * 8, d);
+        }
+        else
+        {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            d[r][0] = d[r][1] = 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+          zq[r][2 * h] = d[r][0];
+          zq[r][2 * h + 1] = d[r][1];
+        }
+      }
+    };
+    __syncthreads();  // the staging buffers may still be read by a slower wave of the previous pass
+    stage_tile(0);
+    float zq[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        zq[r][e] = 0.0f;
+    if (active)
+      draw(0, zq);
+    __syncthreads();
+    for (int j = 0; j < NG; j++)
+    {
+      if (j + 1 < NG)
+        stage_tile(j + 1);
+      if (active)
+      {
+        const float* __restrict__ a_tile = stage + (size_t)(j & 1) * 4 * NTBP * 64 + lane;
+        float a_cur[NTBP], a_nxt[NTBP];
+#pragma unroll
+        for (int tb = 0; tb < NTBP; tb++)
+          a_cur[tb] = a_tile[tb * 64];
+#pragma unroll
+        for (int tb = 0; tb < NTBP; tb++)
+          asm volatile("" : "+v"(a_cur[tb]));
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+          if (e < 3)
+          {
+#pragma unroll
+            for (int tb = 0; tb < NTBP; tb++)
+              a_nxt[tb] = a_tile[((e + 1) * NTBP + tb) * 64];
+            asm volatile("" : "+v"(acc[0][0]) : : "memory");
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int tb = 0; tb < NTBP; tb++)
+              acc[r][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[tb], zq[r][e], acc[r][tb], 0, 0, 0);
+          if (e < 3)
+          {
+#pragma unroll
+            for (int tb = 0; tb < NTBP; tb++)
+            {
+              asm volatile("" : "+v"(a_nxt[tb]));
+              a_cur[tb] = a_nxt[tb];
+            }
+          }
+        }
+        if (j + 1 < NG)
+          draw(j + 1, zq);
+      }
+      __syncthreads();
+    }
+    if (valid)
+    {
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int tb = 0; tb < NTBP; tb++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+          {
+            const int u = 16 * (tb0 + tb) + 4 * g + i;
+            if (u < P)
+              for (int z = 0; z < nz; z++)
+                theta_d[(z * bx + row) * stride + (4 * u + r) * CONTROL_DIM + c] = acc[r][tb][i];
+          }
+    }
+  }
+
+  /** rearrangeNoise's offset (colored_noise.cu:39-56) on the finished rows: eps[t] = x[t] - decay^t x[s], one thread per
+   *  (row, control); x[s] is read before the thread rewrites it */
+  __device__ __forceinline__ void coloredOffsetPass(float* __restrict__ theta_d, const float* __restrict__ decay, const int T,
+                                                    const int stride, const int rows, const int tid_flat, const int nthreads)
+  {
+    const int s = this->optimization_stride_;
+    for (int job = tid_flat; job < rows * CONTROL_DIM; job += nthreads)
+    {
+      const int row = job / CONTROL_DIM, c = job - row * CONTROL_DIM;
+      float* r = theta_d + (size_t)row * stride + c;
+      const float xs = r[s * CONTROL_DIM];
+      for (int t = 0; t < T; t++)
+        r[t * CONTROL_DIM] = mppi::det::fma(-decay[t], xs, r[t * CONTROL_DIM]);
+    }
+  }
+
+  /**
    * Fills the block's sample rows with colored noise.  All waves of the block walk the table in lockstep — control by
    * control, 4 k-steps (one Philox quad per lane) at a time — so that every A fragment is fetched from L2 ONCE per
    * block: the threads stage the next tile global -> LDS (float4, coalesced) while the matrix cores work on the
@@ -338,6 +664,53 @@ public:
     // [slot rows][staging tiles] in LDS; with the rows in HBM (theta_d then points there) the staging tiles start the region
     float* __restrict__ stage = this->rows_global_d_ ? this->staging_lds_
                                                      : theta_d + (((size_t)bx * nz * stride + 3) & ~(size_t)3);  // 16-byte aligned
+    if (coloredUseRadix4(T, this->optimization_stride_))
+    {
+      const int KS4 = coloredR4KSteps(T), NTB4 = coloredR4TBlocks(T), P1 = coloredR4P1(T);
+      const float* __restrict__ wslot_all = basis_d_ + coloredR4FragFloats(T);
+      const float* __restrict__ twid = wslot_all + (size_t)CONTROL_DIM * P1 * 8;
+      const float* __restrict__ decay = twid + (size_t)P1 * 8;
+      for (int c = 0; c < CONTROL_DIM; c++)
+        for (int rg0 = 0; rg0 < RG; rg0 += nwaves)
+        {
+          const int rg = rg0 + wave;
+          const bool active = rg < RG;  // wave-uniform
+          const int row = 16 * rg + n;
+          const bool valid = active && row < nrows;
+          const uint32_t rollout = (uint32_t)(row0 + row + this->rollout_offset_);
+          const float* __restrict__ zbuf =
+              from_buffer ? this->eps_d_ + ((size_t)(row0 + (valid ? row : 0)) * CONTROL_DIM + c) * KK : nullptr;
+          for (int tb0 = 0; tb0 < NTB4; tb0 += MAX_TB4)
+          {
+#define MPPI_COLORED_R4_CASE(Q)                                                                                         \
+  case Q:                                                                                                               \
+    coloredTilesRadix4<Q>(basis_d_, wslot_all + (size_t)c * P1 * 8, twid, stage, theta_d, zbuf, c, tb0, NTB4, KS4 >> 2, T, \
+                          stride, bx, nz, row, rollout, active, valid, from_buffer, tid_flat, nthreads, lane);          \
+    break;
+            switch (min(MAX_TB4, NTB4 - tb0))  // block-uniform
+            {
+              MPPI_COLORED_R4_CASE(1)
+              MPPI_COLORED_R4_CASE(2)
+              MPPI_COLORED_R4_CASE(3)
+              default:
+                coloredTilesRadix4<4>(basis_d_, wslot_all + (size_t)c * P1 * 8, twid, stage, theta_d, zbuf, c, tb0, NTB4,
+                                      KS4 >> 2, T, stride, bx, nz, row, rollout, active, valid, from_buffer, tid_flat, nthreads,
+                                      lane);
+            }
+#undef MPPI_COLORED_R4_CASE
+          }
+        }
+      __syncthreads();  // every row is complete (rows in HBM: the barrier also waits for the block's stores)
+      if (this->rows_global_d_)
+        __threadfence_block();
+      coloredOffsetPass(theta_d, decay, T, stride, nrows == bx ? bx * nz : 0, tid_flat, nthreads);
+      if (nrows != bx)
+      {  // a partial last block: only its valid rows of every system
+        for (int z = 0; z < nz; z++)
+          coloredOffsetPass(theta_d + (size_t)z * bx * stride, decay, T, stride, nrows, tid_flat, nthreads);
+      }
+      return;
+    }
     for (int c = 0; c < CONTROL_DIM; c++)
     {
       const float* __restrict__ basis = basis_d_ + (size_t)c * KS * NTB * 64;

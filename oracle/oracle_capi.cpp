@@ -485,15 +485,18 @@ static ColoredNoiseParams coloredParams(int C, const float* exponents, float dec
   p.fmin = fmin;
   return p;
 }
-/** flavour 0: definition (double inverse DFT), 1: folded table + fp32 fma chains (the engine's arithmetic) */
+/** flavour 0: definition (double inverse DFT), 1: the engine's arithmetic for this (T, offset) — radix-4 butterfly + quarter-size
+ *  GEMM where T is a multiple of 4, else the dense folded table —, 2: the dense folded table + fp32 fma chains for any T */
 void oracle_colored_noise(int flavour, int K, int T, int C, const float* exponents, float decay, float fmin, int offset_t,
                           const float* z, float* eps)
 {
   const ColoredNoiseParams p = coloredParams(C, exponents, decay, fmin);
   if (flavour == 0)
     coloredNoiseDefinition(K, T, C, p, offset_t, z, eps);
-  else
+  else if (flavour == 2)
     coloredNoiseGemm(K, T, C, p, offset_t, z, eps);
+  else
+    coloredNoiseEngine(K, T, C, p, offset_t, z, eps);
 }
 void oracle_colored_weights(int T, int C, const float* exponents, float fmin, float* w /*[C][T+1]*/, float* sigma /*[C]*/)
 {
@@ -515,7 +518,7 @@ void oracle_colored_compute_control(void* h, const float* x0, int stride, const 
   const ColoredNoiseParams p = coloredParams(C, exponents, decay, fmin);
   std::vector<float> eps((size_t)c->num_iters * K * T * C);
   for (int it = 0; it < c->num_iters; it++)
-    coloredNoiseGemm(K, T, C, p, stride, z + (size_t)it * K * C * 2 * (T + 1), &eps[(size_t)it * K * T * C]);
+    coloredNoiseEngine(K, T, C, p, stride, z + (size_t)it * K * C * 2 * (T + 1), &eps[(size_t)it * K * T * C]);
   c->coloredComputeControl(x0, stride, eps.data());
 }
 

@@ -425,12 +425,13 @@ class RobustOracle:
 
 def colored_noise(z, exponents, offset_decay_rate=0.97, fmin=0.0, offset_t=1, flavour="gemm"):
     """z [K][C][T+1][2] Gaussian spectrum -> eps [K][T][C]; flavour "definition" (double inverse DFT, the reference's
-    pipeline step by step) or "gemm" (folded table + fp32 fma chains: the engine's arithmetic)"""
+    pipeline step by step), "gemm" / "engine" (the engine's arithmetic: radix-4 butterfly + quarter-size GEMM where T is a
+    multiple of 4, the dense folded table otherwise) or "dense" (the dense folded table + fp32 fma chains for any T)"""
     z = _f32(z)
     K, Cd, F, _ = z.shape
     T = F - 1
     eps = np.zeros((K, T, Cd), np.float32)
-    lib().oracle_colored_noise(0 if flavour == "definition" else 1, K, T, Cd, _f32(exponents).reshape(-1),
+    lib().oracle_colored_noise({"definition": 0, "gemm": 1, "engine": 1, "dense": 2}[flavour], K, T, Cd, _f32(exponents).reshape(-1),
                                offset_decay_rate, fmin, offset_t, z.reshape(-1), eps)
     return eps
 
