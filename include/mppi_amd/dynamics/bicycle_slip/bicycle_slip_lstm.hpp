@@ -151,9 +151,10 @@ public:
     lstm_d_ = other.lstm_.weights_d_;
     fnn_d_ = other.lstm_.output_nn_.theta_d_;
   }
+  /** block-shared LDS: the output layer's weights per lane group (lstm_mfma.hpp: w2_lds), 512 B */
   __host__ __device__ int getGrdSharedSizeBytes() const
   {
-    return 0;
+    return NET::W2_LDS_FLOATS * (int)sizeof(float);
   }
   __host__ __device__ int getBlkSharedSizeBytes() const
   {
@@ -164,7 +165,7 @@ public:
                                             float dt)
   {
     PARENT_CLASS::initializeDynamics(state, control, output, theta_s, t_0, dt);
-    net_.load(lstm_d_, fnn_d_, (int)(threadIdx.x & 63));
+    net_.load(lstm_d_, fnn_d_, (int)(threadIdx.x & 63), theta_s);
   }
 
   __device__ inline void computeKinematics(float* state, float* state_der)

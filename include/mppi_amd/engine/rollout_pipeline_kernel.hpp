@@ -787,7 +787,19 @@ __device__ inline void vgprResident(T& obj)
  * waits on a global load inside its step loop.  Same arithmetic, same bits.
  */
 template <class DYN_T, class COST_T, class SAMPLING_T, bool DRAW_IN_LOOP, bool ROWS_HBM = false>
-__global__ void __launch_bounds__(64 * (replicated_lanes<DYN_T>::value + PIPE_REP_SAMPLERS + PIPE_REP_COSTS))
+/* A block of this kernel is 512 threads = two waves per SIMD, and its LDS request (sample rows + ring) leaves room for one
+ * block per CU: the second __launch_bounds__ argument tells the register allocator that two waves per SIMD is all there will
+ * ever be, i.e. that 256 VGPRs per wave are there to be used (without it it aims at four and spills at 128).
+ * A/B: -DMPPI_PIPE_REP_MIN_WAVES=0 restores the default. */
+#if !defined(MPPI_PIPE_REP_MIN_WAVES)
+#define MPPI_PIPE_REP_MIN_WAVES 2
+#endif
+#if MPPI_PIPE_REP_MIN_WAVES > 0
+#define MPPI_PIPE_REP_BOUNDS(n) __launch_bounds__(n, MPPI_PIPE_REP_MIN_WAVES)
+#else
+#define MPPI_PIPE_REP_BOUNDS(n) __launch_bounds__(n)
+#endif
+__global__ void MPPI_PIPE_REP_BOUNDS(64 * (replicated_lanes<DYN_T>::value + PIPE_REP_SAMPLERS + PIPE_REP_COSTS))
     rolloutPipelineRepKernel(DYN_T dynamics_obj, COST_T costs_obj, SAMPLING_T sampling_obj, const RolloutArgs args,
                              const int ring_steps)
 {

@@ -70,6 +70,12 @@ struct FNNMfma
   float a1[RB][KS_IN];
   float a2[RB][KS_H];
   float w3s[4][RB * 4];  ///< W3[o][16 rb + 4 g + i]: the output layer's weights of the units this lane owns in the D layout
+  /** the same layer as ONE chain of MFMAs for kernels that cannot afford w3s' 32 registers (blocks of more than 512 threads:
+   *  128 VGPRs per wave — the Robust MPPI pipeline spilled inside its step loop with them, 388 -> 551 us per launch): row
+   *  m = 4 chain + output, and A[m][k] is W3[output][k] only where input k belongs to that chain, else 0 — fma(0, x, acc) = acc,
+   *  so row m accumulates exactly chain (m >> 2) of output (m & 3) in ascending k, all 16 rows busy; the D layout then hands
+   *  lane group g the chains g of the four outputs, and the same two swap-and-add steps join them.  Same bits, 8 registers. */
+  float a3m[KS_H];
   float b1[RB][4];
   float b2[RB][4];
   float b3[4];
@@ -113,6 +119,15 @@ struct FNNMfma
 #pragma unroll
         for (int i = 0; i < 4; i++)
           w3s[o][4 * rb + i] = (o < OUT) ? W3[o * H + 16 * rb + 4 * g + i] : 0.0f;
+    // k-step s of the next layer's B fragments carries unit 16 (s >> 2) + 4 (s & 3) + g, which belongs to chain s & 3
+#pragma unroll
+    for (int s = 0; s < KS_H; s++)
+      a3m[s] = ((s & 3) == (m >> 2) && (m & 3) < OUT) ? W3[(m & 3) * H + 16 * (s >> 2) + 4 * (s & 3) + g] : 0.0f;
+  }
+  /** which form of the output layer this kernel runs (folds at compile time: every kernel asserts its block shape) */
+  __device__ static inline bool outputLayerOnMatrixCore()
+  {
+    return __builtin_amdgcn_workgroup_size_x() > 512;
   }
 
   /** hidden layer epilogue: bias + tanh (pairwise packed, det::tanh_n) of the RB x 4 values this lane owns, then the
@@ -204,6 +219,20 @@ struct FNNMfma
 #pragma unroll
       for (int rb = 0; rb < RB; rb++)
         acc[rb] = mfma16x16x4(a2[rb][s], bh[s], acc[rb]);
+    if (outputLayerOnMatrixCore())
+    {
+      float bo[KS_H];
+      squash(acc, b2, bo);
+      gather8(bo);
+      mfma_f32x4 o = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+      for (int s = 0; s < KS_H; s++)
+        o = mfma16x16x4(a3m[s], bo[s], o);
+#pragma unroll
+      for (int i = 0; i < OUT; i++)
+        out[i] = mppi::wave::sumOverLaneGroups(o[i]) + b3[i];
+      return;
+    }
     /* ---- layer 3 (linear) on the vector unit, in the D layout: no transpose, no matrix-core rows that compute nothing.
      * Lane group g owns the units 16 rb + 4 g + i — exactly the inputs of chain g of FNNHelper::split_output_sum_, in ascending
      * order; the chains of the four lane groups meet through v_permlane16_swap (rows 0|1, 2|3) and v_permlane32_swap (halves):

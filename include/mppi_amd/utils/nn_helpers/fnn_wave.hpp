@@ -76,8 +76,13 @@ struct FNNWave
     // output layer: the four interleaved chains of FNNHelper::split_output_sum_ (what every form of this network evaluates)
     float c4[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
-    for (int k = 0; k < H; k++)
-      c4[(k >> 2) & 3] = mppi::det::fma(w3[k], lane_value(h2, k), c4[(k >> 2) & 3]);
+    for (int kb = 0; kb < H; kb += 16)  // (written so that every index is a constant after unrolling)
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (kb + 4 * g + i < H)
+            c4[g] = mppi::det::fma(w3[kb + 4 * g + i], lane_value(h2, kb + 4 * g + i), c4[g]);
     acc = (c4[0] + c4[1]) + (c4[2] + c4[3]);
     acc = acc + b3;
 #pragma unroll

@@ -48,14 +48,23 @@ struct LSTMMfma
   float ah[4][KS_H];   ///< gate weights, recurrent part
   float bg[4][4];      ///< gate biases of the units this lane owns in the D layout
   float a1h[RB_M][KS_H], a1x[RB_M][KS_X], b1[RB_M][4];  ///< MLP layer 1 ([h ; x] -> M)
-  float w2s[4][RB_M * 4], b2[4];                         ///< MLP layer 2 (M -> OUT): W2[o][16 rb + 4 g + i], this lane's units
+  float b2[4];
+  /** MLP layer 2 (M -> OUT) on the vector unit: W2[o][16 rb + 4 g + i] of the units lane group g owns, at
+   *  w2_lds[(4 g + o) * RB_M * 4 + 4 rb + i] in block-shared LDS and read back with 16-byte broadcast loads.  Measured, one
+   *  session (K = 65536, T = 200): weights in 32 VGPRs per lane 1437 us per launch, in LDS 1359 us — the opposite of the AutoRally
+   *  MLP (fnn_mfma.hpp: registers 179 us, LDS 188 us), so each network keeps the form that is faster for it. */
+  const float* w2_lds = nullptr;
+  static constexpr int W2_LDS_FLOATS = 4 * 4 * RB_M * 4;
+  float a2m[KS_M];  ///< the same layer as chain-masked MFMA rows for register-starved kernels (fnn_mfma.hpp: a3m)
   /* recurrent state */
   float hb[KS_H];  ///< hidden state as B fragments: unit 4s + g
   float c[4];      ///< cell state of units 4g + i
 
   /** lstm: [W_im W_fm W_om W_cm | W_ii W_fi W_oi W_ci | b_i b_f b_o b_c | h0 | c0];  fnn: [W1 | b1 | W2 | b2] */
-  __device__ inline void load(const float* __restrict__ lstm, const float* __restrict__ fnn, const int lane)
+  __device__ inline void load(const float* __restrict__ lstm, const float* __restrict__ fnn, const int lane,
+                              float* __restrict__ w2_table_lds)
   {
+    w2_lds = w2_table_lds;
     const int m = lane & 15, g = lane >> 4;
     const float* Wm = lstm;
     const float* Wi = lstm + 4 * H * H;
@@ -104,7 +113,11 @@ struct LSTMMfma
       for (int rb = 0; rb < RB_M; rb++)
 #pragma unroll
         for (int i = 0; i < 4; i++)
-          w2s[o][4 * rb + i] = (o < OUT) ? W2[o * M + 16 * rb + 4 * g + i] : 0.0f;
+          w2_table_lds[(4 * g + o) * RB_M * 4 + 4 * rb + i] = (o < OUT) ? W2[o * M + 16 * rb + 4 * g + i] : 0.0f;  // (every lane
+          // of group g and every wave of the block: same words, same values; visible after the block barrier behind initializeDynamics)
+#pragma unroll
+    for (int s = 0; s < KS_M; s++)
+      a2m[s] = ((s & 3) == (m >> 2) && (m & 3) < OUT) ? W2[(m & 3) * M + 16 * (s >> 2) + 4 * (s & 3) + g] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; i++)
       b2[i] = (i < OUT) ? B2[i] : 0.0f;
@@ -209,16 +222,36 @@ struct LSTMMfma
         for (int i = 0; i < 4; i++)
           act[rb][i] = v[4 * rb + i];  // stays in the D layout: units 16 rb + 4 g + i
     }
+    if (__builtin_amdgcn_workgroup_size_x() > 512)
+    {  // blocks of more than 512 threads (128 VGPRs per wave): the chain-masked MFMA form, same bits (fnn_mfma.hpp: a3m)
+      mfma_f32x4 o = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+      for (int rb = 0; rb < RB_M; rb++)
+      {
+        mppi::wave::transpose4x4(act[rb]);  // units 16 rb + 4 s + g, s = 0..3
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(a2m[4 * rb + s], act[rb][s], o, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < OUT; i++)
+        out[i] = mppi::wave::sumOverLaneGroups(o[i]) + b2[i];
+      return;
+    }
     /* ---- layer 2 (linear) on the vector unit, in the D layout (fnn_mfma.hpp, layer 3: the same step): lane group g owns
      * the inputs of chain g of FNNHelper::split_output_sum_; the four chains meet in two swap-and-add steps ---- */
     float p[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    const mfma_f32x4* __restrict__ w2q = reinterpret_cast<const mfma_f32x4*>(w2_lds + 4 * g * RB_M * 4);
 #pragma unroll
-    for (int rb = 0; rb < RB_M; rb++)
+    for (int o = 0; o < 4; o++)
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int rb = 0; rb < RB_M; rb++)
+      {
+        const mfma_f32x4 w = w2q[o * RB_M + rb];  // one 16-byte LDS broadcast per lane group
 #pragma unroll
-        for (int o = 0; o < 4; o++)
-          p[o] = mppi::det::fma(w2s[o][4 * rb + i], act[rb][i], p[o]);
+        for (int i = 0; i < 4; i++)
+          p[o] = mppi::det::fma(w[i], act[rb][i], p[o]);
+      }
 #pragma unroll
     for (int o = 0; o < 4; o++)
       p[o] = mppi::wave::sumOverLaneGroups(p[o]);

@@ -108,8 +108,13 @@ struct LSTMWave
     // the four interleaved chains of FNNHelper::split_output_sum_ (what every form of this network evaluates)
     float c4[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
-    for (int k = 0; k < M; k++)
-      c4[(k >> 2) & 3] = mppi::det::fma(w2[k], lane_value(a1, k), c4[(k >> 2) & 3]);
+    for (int kb = 0; kb < M; kb += 16)  // (written so that every index is a constant after unrolling)
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (kb + 4 * g + i < M)
+            c4[g] = mppi::det::fma(w2[kb + 4 * g + i], lane_value(a1, kb + 4 * g + i), c4[g]);
     acc = (c4[0] + c4[1]) + (c4[2] + c4[3]);
     acc = acc + b2;
 #pragma unroll
