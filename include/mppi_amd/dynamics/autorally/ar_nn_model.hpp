@@ -144,10 +144,11 @@ public:
     theta_d_ = other.helper_.theta_d_;
   }
 
-  /** weights and activations live in registers: no LDS at all */
+  /** weights and activations live in registers; block-shared LDS holds a copy of the hidden layers' biases per lane group
+   *  (256 B) that register-starved kernels read instead (fnn_mfma.hpp: bias_lds) */
   __host__ __device__ int getGrdSharedSizeBytes() const
   {
-    return 0;
+    return NET::BIAS_LDS_FLOATS * (int)sizeof(float);
   }
   __host__ __device__ int getBlkSharedSizeBytes() const
   {
@@ -158,7 +159,7 @@ public:
                                             float dt)
   {
     PARENT_CLASS::initializeDynamics(state, control, output, theta_s, t_0, dt);
-    net_.load(theta_d_, (int)(threadIdx.x & 63));
+    net_.load(theta_d_, (int)(threadIdx.x & 63), theta_s);
   }
 
   __device__ inline void computeKinematics(float* state, float* state_der)

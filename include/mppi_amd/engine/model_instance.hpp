@@ -1428,7 +1428,7 @@ struct ModelT : ModelBase
   size_t globalRowsFloats(int blocks, int slots, int T) const override
   {
     if constexpr (SAMPLING_T::SUPPORTS_GLOBAL_ROWS)
-      return (size_t)blocks * slots * SAMPLING_T::rowStride(T);
+      return (size_t)blocks * slots * SAMPLING_T::rowStrideGlobal(T);
     return 0;
   }
   void setGlobalRows(float* rows_d) override

@@ -436,6 +436,7 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
     float* rl_b = relay_b + BX * thread_idz;
     int* rl_s = relay_status + BX * thread_idz;
     float* row = sampling->sampleRow(theta_d_shared, shared_idx);
+    const bool pair_store = C == 2 && sampling->rows_global_d_ != nullptr;  // block-uniform
     int seen_dyn[DW], seen_cost = 0;
 #pragma unroll
     for (int w = 0; w < DW; w++)
@@ -463,11 +464,21 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
           fbb[q][i] = slot[(O + C + i) * 64];
         }
         // the feedback-filled, clamped control replaces the sample (rmppi_kernels.cu:780-781)
-        if (t + q < num_timesteps)
+        if (!(pair_store && t + 1 < num_timesteps) && t + q < num_timesteps)
         {
 #pragma unroll
           for (int i = 0; i < C; i++)
             row[(t + q) * C + i] = ub[q][i];
+        }
+      }
+      if constexpr (C == 2)
+      {
+        // rows in HBM start on 128-byte lines (rowStrideGlobal) and t is even: the pair's four floats are ONE aligned 16-byte
+        // store per lane — a quarter of the store instructions, and lines that fill front to back
+        if (pair_store && t + 1 < num_timesteps)
+        {
+          typedef float pair_f32x4 __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<pair_f32x4*>(row + t * C) = pair_f32x4{ ub[0][0], ub[0][1], ub[1][0], ub[1][1] };
         }
       }
       float da[2] = { 0.0f, 0.0f }, db[2] = { 0.0f, 0.0f };

@@ -175,7 +175,7 @@ __device__ inline void blockSoftminEpilogueCost(SAMPLING_T* sampling, const Roll
   const int TC = num_timesteps * C;
   const int PS = partialStride(num_timesteps, C);
   const int num_blocks = (int)gridDim.x;
-  const int row_stride = SAMPLING_T::rowStride(num_timesteps);
+  const int row_stride = sampling->rowStrideNow();
   if constexpr (WAVE_REDUCE && (BX % 2 == 0))
   {
     // U_b[z][j] = sum_i w_i v_i[j].  A column's BX rows are split between the two half-waves (lane l and l ^ 32 take the same

@@ -646,7 +646,7 @@ public:
                                                           const float dt, float* __restrict__ theta_d)
   {
     const int T = this->params_.num_timesteps;
-    const int stride = PARENT::rowStride(T);
+    const int stride = this->rowStrideNow();
     const int bx = this->rolloutsPerBlock();
     const int nthreads = (int)(blockDim.x * blockDim.y * blockDim.z);
     const int tid_flat = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));

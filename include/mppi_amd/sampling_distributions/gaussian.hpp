@@ -172,6 +172,17 @@ public:
     const int n = num_timesteps * CONTROL_DIM;
     return (n & 1) ? n : n + 1;
   }
+  /** rows in HBM (rows_global_d_): every row starts on a 128-byte line — a lane that fills its row a few steps at a time then
+   *  completes whole lines instead of straddling two (round 5: the Robust MPPI kernel's write-back) */
+  __host__ __device__ static inline int rowStrideGlobal(int num_timesteps)
+  {
+    return (num_timesteps * CONTROL_DIM + 31) & ~31;
+  }
+  /** the stride of THIS launch's rows: LDS rows or HBM rows */
+  __host__ __device__ inline int rowStrideNow() const
+  {
+    return rows_global_d_ ? rowStrideGlobal(params_.num_timesteps) : rowStride(params_.num_timesteps);
+  }
   /** LDS request per rollout slot: one sample row (reference: managed.cuh:104-111 Blk request) */
   __host__ __device__ inline int getBlkSharedSizeBytes() const
   {
@@ -180,7 +191,7 @@ public:
   /** where the rows of block `block_idx` (slots_per_block rows) live: the LDS region the kernel reserved, or the HBM buffer */
   __device__ inline float* blockRows(float* theta_d_lds, const int block_idx, const int slots_per_block) const
   {
-    return rows_global_d_ ? rows_global_d_ + (size_t)block_idx * slots_per_block * rowStride(params_.num_timesteps) : theta_d_lds;
+    return rows_global_d_ ? rows_global_d_ + (size_t)block_idx * slots_per_block * rowStrideGlobal(params_.num_timesteps) : theta_d_lds;
   }
   __host__ __device__ inline int getGrdSharedSizeBytes() const
   {
@@ -207,7 +218,7 @@ public:
 
   __device__ inline float* sampleRow(float* theta_d, int slot) const
   {
-    return theta_d + slot * rowStride(params_.num_timesteps);
+    return theta_d + slot * rowStrideNow();
   }
 
   __device__ inline bool isPureNoise(int sample_index) const
@@ -234,7 +245,7 @@ public:
     if (drawsInLoop())
       return;
     const int TC = params_.num_timesteps * CONTROL_DIM;
-    const int stride = rowStride(params_.num_timesteps);
+    const int stride = rowStrideNow();
     const int bx = rolloutsPerBlock();
     const int tid_flat = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
     const int nthreads = (int)(blockDim.x * blockDim.y * blockDim.z);

@@ -76,14 +76,21 @@ struct FNNMfma
    *  so row m accumulates exactly chain (m >> 2) of output (m & 3) in ascending k, all 16 rows busy; the D layout then hands
    *  lane group g the chains g of the four outputs, and the same two swap-and-add steps join them.  Same bits, 8 registers. */
   float a3m[KS_H];
+  /** register-starved kernels (outputLayerOnMatrixCore()) also fetch the hidden layers' biases — 16 values that depend on the
+   *  lane group only — from block-shared LDS at the point of use instead of holding them in VGPRs: bias_lds[((layer * 4 + g) *
+   *  RB + rb) * 4 + i]; with them in registers the Robust MPPI pipeline kernel spilled 6 VGPRs inside its step loop, and the
+   *  scratch stores were most of the "write amplification" its HBM counters showed (74 MB written for 39 MB of rows) */
+  const float* bias_lds = nullptr;
+  static constexpr int BIAS_LDS_FLOATS = 2 * 4 * RB * 4;
   float b1[RB][4];
   float b2[RB][4];
   float b3[4];
 
   /** theta: parameter blob [W1 (H x IN) | b1 | W2 (H x H) | b2 | W3 (OUT x H) | b3] (fnn_helper.cu:176-183) */
-  __device__ inline void load(const float* __restrict__ theta, const int lane)
+  __device__ inline void load(const float* __restrict__ theta, const int lane, float* __restrict__ bias_table_lds)
   {
     const int m = lane & 15, g = lane >> 4;
+    bias_lds = bias_table_lds;
     const float* W1 = theta;
     const float* B1 = W1 + IN * H;
     const float* W2 = B1 + H;
@@ -107,6 +114,9 @@ struct FNNMfma
       {
         b1[rb][i] = B1[16 * rb + 4 * g + i];
         b2[rb][i] = B2[16 * rb + 4 * g + i];
+        // (every lane of group g, every wave: same words, same values; visible after the barrier behind initializeDynamics)
+        bias_table_lds[((0 * 4 + g) * RB + rb) * 4 + i] = b1[rb][i];
+        bias_table_lds[((1 * 4 + g) * RB + rb) * 4 + i] = b2[rb][i];
       }
     }
 #pragma unroll
@@ -133,14 +143,30 @@ struct FNNMfma
   /** hidden layer epilogue: bias + tanh (pairwise packed, det::tanh_n) of the RB x 4 values this lane owns, then the
    *  4x4 cross-lane transpose that turns each row block's D layout (units 16 rb + 4 g + i) into the next layer's B
    *  fragments (unit 16 rb + 4 s + g in k-step 4 rb + s) */
-  __device__ inline void squash(const mfma_f32x4 (&acc)[RB], const float (&bias)[RB][4], float (&b_next)[KS_H]) const
+  __device__ inline void squash(const mfma_f32x4 (&acc)[RB], const float (&bias)[RB][4], float (&b_next)[KS_H],
+                                const int layer, const int g) const
   {
     float v[RB * 4];
+    if (outputLayerOnMatrixCore())
+    {
+      const mfma_f32x4* __restrict__ bq = reinterpret_cast<const mfma_f32x4*>(bias_lds + (layer * 4 + g) * RB * 4);
 #pragma unroll
-    for (int rb = 0; rb < RB; rb++)
+      for (int rb = 0; rb < RB; rb++)
+      {
+        const mfma_f32x4 b = bq[rb];
 #pragma unroll
-      for (int i = 0; i < 4; i++)
-        v[4 * rb + i] = acc[rb][i] + bias[rb][i];
+        for (int i = 0; i < 4; i++)
+          v[4 * rb + i] = acc[rb][i] + b[i];
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          v[4 * rb + i] = acc[rb][i] + bias[rb][i];
+    }
 #if !defined(MPPI_KNOCKOUT_TANH)
     // lockstep over the four pairs: no packed instruction reads its predecessor's result, i.e. none of the s_nop 0 the
     // compiler puts behind dependent packed fp32 instructions — a lone wave pays an issue slot for each
@@ -208,7 +234,7 @@ struct FNNMfma
       for (int rb = 0; rb < RB; rb++)
         acc[rb] = mfma16x16x4(a1[rb][s], bin[s], acc[rb]);
     float bh[KS_H];
-    squash(acc, b1, bh);
+    squash(acc, b1, bh, 0, g);
     gather8(bh);
     /* ---- layer 2 ---- */
 #pragma unroll
@@ -222,7 +248,7 @@ struct FNNMfma
     if (outputLayerOnMatrixCore())
     {
       float bo[KS_H];
-      squash(acc, b2, bo);
+      squash(acc, b2, bo, 1, g);
       gather8(bo);
       mfma_f32x4 o = mfma_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
