@@ -833,15 +833,15 @@ def workload_cfg(workload, k_total):
 #   * config 5 (K = 65536: 1024 blocks, one per CU at a time = 4 rounds) is the problem that shards: N = 2 -> 2 rounds,
 #     N = 4 -> 1 round, N = 8 -> 1 round on half the CUs (no further gain).
 PREDICTED_MS_PER_STEP = {
-    "inputs": {"cartpole_rollout_kernel_us": 22.7, "autorally_rollout_kernel_us": 184.0, "lstm_colored_round_us": 460.0,
+    "inputs": {"cartpole_rollout_kernel_us": 22.7, "autorally_rollout_kernel_us": 176.0, "lstm_colored_round_us": 410.0,
                "sharded_merge_us": 5.0, "xgmi_hop_us": 2.5,
-               "source": "one-GPU measurements (profiles/r04_d_kernel_stats.csv: plain Cartpole instantiation 22.5-22.9 us, "
-                         "AutoRally-NN 183-186 us, config 5 1.84 ms = 4 rounds); merge + hop estimated, never measured across devices"},
+               "source": "one-GPU measurements (profiles/r05_a_kernel_stats.csv: plain Cartpole instantiation 22.5-22.9 us, "
+                         "AutoRally-NN 176-179 us, config 5 1.62-1.64 ms = 4 rounds); merge + hop estimated, never measured across devices"},
     "cartpole_strong": {2: 0.0302, 4: 0.0302, 8: 0.0302},       # 22.7 + 5.0 + 2.5 us, against 0.0250 on one GPU (one launch)
     "cartpole_weak": {2: 0.0302, 4: 0.0302, 8: 0.0302},         # same step, N x the rollouts
-    "autorally_strong": {2: 0.1915, 4: 0.1915, 8: 0.1915},      # 184 + 7.5 us, against 0.189 on one GPU
-    "autorally_weak": {2: 0.1915, 4: 0.1915, 8: 0.1915},
-    "lstm_colored_strong": {2: 0.9275, 4: 0.4675, 8: 0.4675},   # rounds x 460 us + 7.5 us, against 1.84 on one GPU
+    "autorally_strong": {2: 0.1835, 4: 0.1835, 8: 0.1835},      # 176 + 7.5 us, against 0.181 on one GPU
+    "autorally_weak": {2: 0.1835, 4: 0.1835, 8: 0.1835},
+    "lstm_colored_strong": {2: 0.8275, 4: 0.4175, 8: 0.4175},   # rounds x 410 us + 7.5 us, against 1.64 on one GPU
 }
 
 
