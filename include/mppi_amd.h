@@ -454,6 +454,11 @@ mppi_status mppi_p2p_connect_local(mppi_handle h, const mppi_handle* peers);
 mppi_status mppi_rccl_unique_id(void* out_bytes, size_t capacity, size_t* nbytes);
 mppi_status mppi_comm_init_rccl(mppi_handle h, const void* unique_id, size_t nbytes);
 
+/** diagnostics: microseconds since the first statement of the last low-latency Vanilla mppi_compute_control at which the host had
+ *  [0] written the inputs, [1] enqueued the ingest, [2] the iterations, [3] the merge, [4] the finalize kernel, [5] seen the
+ *  control-ready flag, [6] copied the results out; out8[7] is unused (tools/compute_control_host_timing.py) */
+mppi_status mppi_debug_host_stamps(mppi_handle h, double* out8);
+
 /* ---------------------------------------------------------------- kernel-level operators ------------------------- */
 /* Host-buffer wrappers around single kernels, mirroring the reference's launch wrappers; used by the kernel-level
  * parity tests the way the reference's tests/include/kernel_tests/core harnesses use theirs. */

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mppi_get_dims": (C.c_int, [H] + [C.POINTER(C.c_int)] * 4),
     "mppi_get_local_rollouts": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mppi_get_launch_counts": (C.c_int, [H, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "mppi_debug_host_stamps": (C.c_int, [H, C.POINTER(C.c_double)]),
     "mppi_set_dynamics_params": (C.c_int, [H, C.c_void_p, C.c_size_t]),
     "mppi_set_cost_params": (C.c_int, [H, C.c_void_p, C.c_size_t]),
     "mppi_set_sampler_params": (C.c_int, [H, C.POINTER(MppiGaussianParams)]),

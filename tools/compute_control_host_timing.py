@@ -16,7 +16,6 @@ import mppi_generic_amd as m  # noqa: E402
 from common import cartpole_cfg, make_engine  # noqa: E402
 
 lib = m.load_library()
-lib.mppi_debug_host_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 cfg = cartpole_cfg(K=16384, T=100)
 eng = make_engine(cfg)
 x = cfg["x0"].copy()
