@@ -2209,26 +2209,30 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
       parseStats(h, out + (h->stats_d - h->out_block_d));
       return MPPI_OK;
     };
+    /* Round 5: ONE hand-over per call.  Between two optimisation passes the reference decides on the host whether the nominal
+     * system restarts from the actual one (:264-277) — after computing both state trajectories, of which the decision needs
+     * nothing and the next pass only row 0, the initial state.  Rounds 2-4 mirrored that: finalize pass, wait for both
+     * trajectories, decide, stage, second finalize pass (control on the host after 86 us at config 3).  The decision is two
+     * baselines the merge has just written: tubeSelectKernel takes it on the device (nominal mean and initial state
+     * overwritten where the actual system wins), the passes chain without the host, and a single finalize pass — smoothing the
+     * nominal control, re-rolling both trajectories — hands everything over.  Same values in every host-visible field. */
+    MPPI_TRY(stage_inputs());
     for (int it = 0; it < h->cfg.num_iters; it++)
     {
-      MPPI_TRY(stage_inputs());
       MPPI_TRY(iteration(h, it, stride));
-      MPPI_TRY(finalize_flagged(0));
-      MPPI_TRY(ensureTrajectories(h));
-      if (h->stats_h.real_sys.baseline < h->stats_h.nominal_sys.baseline + h->nominal_threshold)
-      {
-        h->stats_h.nominal_state_used = 0;
-        h->nominal_state_h = h->state_h;
-        h->nominal_control_h = h->control_h;
-      }
-      else
-      {
-        h->stats_h.nominal_state_used = 1;
-      }
+      hipLaunchKernelGGL(kernels::tubeSelectKernel, dim3(1), dim3(256), 0, h->stream, h->stats_d, h->mean_d, h->x0_d, h->TC, S,
+                         h->nominal_threshold);
+      HIP_TRY(h, hipGetLastError());
     }
     // smoothControlTrajectory() smooths the nominal control (:281, :325-329), then computeStateTrajectory(state)
-    MPPI_TRY(stage_inputs());
     MPPI_TRY(finalize_flagged(/*smooth nominal*/ 2));
+    if (h->cfg.num_iters > 0)
+    {
+      const float* st1 = h->io_out_h + (h->stats_d - h->out_block_d) + kernels::STATS_STRIDE;
+      h->stats_h.nominal_state_used = st1[7] != 0.0f ? 1 : 0;
+      if (h->stats_h.nominal_state_used == 0)  // the nominal system restarted from the actual state (row 0 of its trajectory)
+        std::copy(x0, x0 + S, h->nominal_state_h.begin());
+    }
     if (!allFinite(h->control_h) || !allFinite(h->nominal_control_h))
       return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control sequence");
     return MPPI_OK;

@@ -493,6 +493,30 @@ __global__ void __launch_bounds__(256) ingestKernel(const float* __restrict__ ho
     dst[i] = host_mapped[i];
 }
 
+/**
+ * Tube-MPPI's choice between the two systems after an optimisation pass, on the device
+ * (controllers/Tube-MPPI/tube_mppi_controller.cu:264-277): when the actual system's baseline is below the nominal one's plus
+ * the threshold, the nominal system restarts from the actual one — its control sequence and its initial state are overwritten
+ * with the actual system's; stats[1][7] records which it was (0: the actual state was taken over, 1: the nominal state was kept,
+ * the reference's nominalStateUsed).  The reference (and rounds 2-4 here) made this choice on the host, between two device
+ * passes, which cost mppi_compute_control a second hand-over and a wait for trajectories nobody needed.
+ */
+__global__ void __launch_bounds__(256) tubeSelectKernel(float* __restrict__ stats_d, float* __restrict__ mean_d,
+                                                        float* __restrict__ x0_d, const int TC, const int S,
+                                                        const float nominal_threshold)
+{
+  const bool take_actual = stats_d[0] < stats_d[STATS_STRIDE] + nominal_threshold;  // block-uniform
+  if (take_actual)
+  {
+    for (int i = (int)threadIdx.x; i < TC; i += 256)
+      mean_d[TC + i] = mean_d[i];
+    for (int i = (int)threadIdx.x; i < S; i += 256)
+      x0_d[S + i] = x0_d[i];
+  }
+  if (threadIdx.x == 0)
+    stats_d[STATS_STRIDE + 7] = take_actual ? 0.0f : 1.0f;
+}
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Unfused kernel-level operators with the reference's launch-wrapper semantics, exported through the C ABI for the
  * kernel-level parity tests (reference tests: tests/mppi_core/normexp_kernel_tests.cu, weightedreduction_kernel_tests.cu)
