@@ -147,6 +147,16 @@ struct mppi_handle_s
   bool results_in_io = false;      // the last finalize pass wrote to io_out_h (low-latency path), not to out_block_d
   bool traj_pending = false;       // state_h / output of the last call are still being written by the finalize kernel
   bool low_latency = true;         // MPPI_AMD_NO_SPIN=1 in the environment: copy + hipStreamSynchronize hand-over instead
+  /* Round 5: the input block of the low-latency hand-over is DEVICE memory the host writes through the PCIe BAR
+   * (hipExtMallocWithFlags(hipDeviceMallocFinegrained) on a large-BAR device: the allocation accepts CPU stores,
+   * tools/ubench/bar_write.hip — {write 2 KB, launch, flag back} 8.3 us against 17.4 us with mapped host memory).  io_in_h and
+   * io_in_dev then are the same pointer; the host only ever WRITES it (write-combined, fenced before the launch).  With it
+   * the Vanilla / Colored computeControl needs no ingest launch: the first rollout launch reads its mean, every rollout launch
+   * and the finalize kernel their initial state and history, from the inbox (HBM, not PCIe).  MPPI_AMD_BAR_INBOX=0: mapped
+   * host memory + ingest kernel as before. */
+  bool bar_inbox = false;
+  const float* x0_src_d = nullptr;    // where rollout launches read the initial state from (nullptr: x0_d)
+  const float* mean_src_d = nullptr;  // where the NEXT rollout launch reads its nominal control from (nullptr: mean_d; one-shot)
   /* host-side stamps of the last low-latency Vanilla mppi_compute_control, microseconds since the call's first statement
    * (mppi_debug_host_stamps; tools/compute_control_host_timing.py): [0] inputs written, [1] ingest enqueued, [2] iterations
    * enqueued, [3] merge flushed, [4] finalize enqueued, [5] flag 0 seen, [6] results copied out */
@@ -428,7 +438,7 @@ static void freeAll(mppi_handle h)
   h->mbox_d = nullptr;
   h->p2p_ready = false;
   if (h->io_in_h)
-    (void)hipHostFree(h->io_in_h);
+    (void)(h->bar_inbox ? hipFree(h->io_in_h) : hipHostFree(h->io_in_h));
   if (h->io_out_h)
     (void)hipHostFree(h->io_out_h);
   if (h->io_flags_h)
@@ -745,10 +755,23 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     const char* no_spin = getenv("MPPI_AMD_NO_SPIN");
     h->low_latency = !(no_spin && no_spin[0] == '1');
     const unsigned map_flags = hipHostMallocMapped | hipHostMallocCoherent;
-    if (hipHostMalloc((void**)&h->io_in_h, h->in_floats * sizeof(float), map_flags) != hipSuccess ||
+    {
+      int large_bar = 0;
+      const char* env = getenv("MPPI_AMD_BAR_INBOX");
+      if (h->low_latency && !(env && env[0] == '0') &&
+          hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, cfg->device) == hipSuccess && large_bar &&
+          hipExtMallocWithFlags((void**)&h->io_in_h, h->in_floats * sizeof(float), hipDeviceMallocFinegrained) == hipSuccess)
+      {
+        h->bar_inbox = true;
+        h->io_in_dev = h->io_in_h;
+      }
+      else
+        (void)hipGetLastError();
+    }
+    if ((!h->bar_inbox && (hipHostMalloc((void**)&h->io_in_h, h->in_floats * sizeof(float), map_flags) != hipSuccess ||
+                           hipHostGetDevicePointer((void**)&h->io_in_dev, h->io_in_h, 0) != hipSuccess)) ||
         hipHostMalloc((void**)&h->io_out_h, h->out_floats * sizeof(float), map_flags) != hipSuccess ||
         hipHostMalloc((void**)&h->io_flags_h, 64, map_flags) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&h->io_in_dev, h->io_in_h, 0) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->io_out_dev, h->io_out_h, 0) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->io_flags_dev, h->io_flags_h, 0) != hipSuccess)
     {
@@ -1533,7 +1556,7 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   a.num_rollouts = h->K_local;
   a.lambda = h->cfg.lambda;
   a.alpha = h->cfg.alpha;
-  a.init_x_d = h->x0_d;
+  a.init_x_d = h->x0_src_d ? h->x0_src_d : h->x0_d;
   a.trajectory_costs_d = h->costs_d;
   a.partials_d = h->partials_d;
   a.save_samples = h->samples_d ? 1 : 0;
@@ -1556,7 +1579,8 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   s.rollout_offset = h->K_offset;
   s.num_timesteps = h->cfg.num_timesteps;
   s.num_distributions = h->D;
-  s.control_means_d = h->mean_d;
+  s.control_means_d = h->mean_src_d ? const_cast<float*>(h->mean_src_d) : h->mean_d;  // (the kernels only read it)
+  h->mean_src_d = nullptr;  // one launch only: later iterations read what the merge wrote to mean_d
   s.eps_d = nullptr;
   if (h->noise_source == MPPI_NOISE_INJECTED)
   {
@@ -2081,8 +2105,32 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     std::copy(h->control_h.begin(), h->control_h.end(), in + (h->mean_d - h->in_block_d));
     std::copy(h->history_h.begin(), h->history_h.end(), in + (h->history_d - h->in_block_d));
     stamp(0);
-    hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
-    HIP_TRY(h, hipGetLastError());
+    // BAR inbox: no ingest launch — the kernels of this call read the inbox (device memory the stores above went to) themselves
+    const bool direct = h->bar_inbox && h->cfg.num_iters >= 1 && h->reduction_mode == MPPI_REDUCTION_FUSED && !tsallisActive(h) &&
+                        !exchangeActive(h);
+    struct SourceGuard  // the overrides never outlive the call
+    {
+      mppi_handle h;
+      ~SourceGuard()
+      {
+        h->x0_src_d = h->mean_src_d = nullptr;
+      }
+    } source_guard{ h };
+    if (direct)
+    {
+#if defined(__x86_64__)
+      __builtin_ia32_sfence();  // the write-combined stores are out before the doorbell of the first launch
+#endif
+      h->x0_src_d = h->io_in_dev + (h->x0_d - h->in_block_d);
+      h->mean_src_d = h->io_in_dev + (h->mean_d - h->in_block_d);
+      a.x0_d = h->x0_src_d;
+      a.history_d = h->io_in_dev + (h->history_d - h->in_block_d);
+    }
+    else
+    {
+      hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+      HIP_TRY(h, hipGetLastError());
+    }
     stamp(1);
     for (int it = 0; it < h->cfg.num_iters; it++)
       MPPI_TRY(iteration(h, it, stride));
@@ -2100,6 +2148,13 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     const mppi_status st = h->model->launchFinalize(1, a, h->stream, err);
     if (st != MPPI_OK)
       return fail(h, st, err);
+    if (direct)
+    {  // behind the finalize kernel, off the caller's path: the device-resident x0 / history later mppi_optimize / operator calls read
+      hipLaunchKernelGGL(kernels::ingestRangesKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d,
+                         (int)(h->mean_d - h->in_block_d), (int)(h->history_d - h->in_block_d),
+                         (int)(h->in_floats - (size_t)(h->history_d - h->in_block_d)));
+      HIP_TRY(h, hipGetLastError());
+    }
     h->out_pin_fresh = false;
     h->results_in_io = true;
     h->traj_pending = true;  // set before the wait: a failing wait must not leave io_out unguarded for the next call

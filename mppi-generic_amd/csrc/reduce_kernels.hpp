@@ -492,6 +492,16 @@ __global__ void __launch_bounds__(256) ingestKernel(const float* __restrict__ ho
   for (int i = (int)threadIdx.x; i < n; i += 256)
     dst[i] = host_mapped[i];
 }
+/** two ranges of the same block in one launch: [0, n0) and [off1, off1 + n1) — the device-resident copies of x0 and the control
+ *  history behind a computeControl whose kernels read the inbox themselves (the nominal control between them holds u* by then) */
+__global__ void __launch_bounds__(256) ingestRangesKernel(const float* __restrict__ src, float* __restrict__ dst, int n0, int off1,
+                                                          int n1)
+{
+  for (int i = (int)threadIdx.x; i < n0; i += 256)
+    dst[i] = src[i];
+  for (int i = (int)threadIdx.x; i < n1; i += 256)
+    dst[off1 + i] = src[off1 + i];
+}
 
 /**
  * Tube-MPPI's choice between the two systems after an optimisation pass, on the device
