@@ -96,11 +96,11 @@ public:
       stabilizing_cost = this->params_.slip_coeff * (slip * slip);
       if (fabsf(slip) > this->params_.max_slip_ang)
       {
-        // If the slip angle is above the max slip angle kill the trajectory.
+        // beyond max_slip_ang the rollout pays the crash cost on top of the quadratic slip term
         stabilizing_cost += this->params_.crash_coeff;
       }
     }
-    // if we roll over kill the trajectory
+    // a roll angle beyond 90 degrees raises the crash flag (sticky for the rest of the rollout)
     if ((double)fabsf(s[3]) > 1.57079632679489661923)
     {
       crash_status[0] = 1;
@@ -165,8 +165,8 @@ public:
     return cost;
   }
 
-  const float FRONT_D = 0.5;  ///< Distance from GPS receiver to front of car.
-  const float BACK_D = -0.5;  ///< Distance from GPS receiver to back of car.
+  const float FRONT_D = 0.5;  ///< front query point of the track cost, metres ahead of the reference point (ar_standard_cost.cuh:75-76)
+  const float BACK_D = -0.5;  ///< rear query point, metres behind it
   bool l1_cost_ = false;      ///< L1 speed cost (if false it is L2)
 };
 
