@@ -133,7 +133,11 @@ def _colored_bicycle(K=512, T=40, **kw):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mk,T,stride", [(_colored_cartpole, 50, 1), (_colored_cartpole, 37, 0), (_colored_bicycle, 40, 2),
-                                          (_colored_bicycle, 200, 1)])
+                                          (_colored_bicycle, 200, 1),
+                                          # the radix-4 form's edges: its smallest horizon, one exactly full time block per class,
+                                          # five time blocks per class (two passes of MAX_TB4 = 4), offset sample 0 and late
+                                          (_colored_cartpole, 16, 0), (_colored_cartpole, 64, 1), (_colored_cartpole, 260, 3),
+                                          (_colored_bicycle, 128, 1)])
 def test_colored_noise_generator_bit_exact(gpu, mk, T, stride):
     """the MFMA prologue GEMM == the oracle's fp32 fma chains, bit for bit, for injected and Philox spectra"""
     cfg = mk(K=200, T=T)  # K not a multiple of 64: ragged last block
