@@ -21,7 +21,7 @@ Each loop runs
 
 Not pinned, because the reference does not pin it either: the plant's disturbance (std::mt19937 seeded from
 std::random_device, di_dynamics.cu:3-12, 60-66) — numpy's generator with a fixed seed here — and cuRAND's stream (the reference
-never fixes a seed in these tests; any seed must pass, three are run on the CPU).
+never fixes a seed in these tests; any seed must pass; the gpu tests run three).
 
 The DDP gain PRODUCER (include/mppi/ddp/ddp.h, host Eigen code) is outside the hot path: `ddp_gains_linear`
 restates its backward pass (ddp.h:93-127) for the double integrator, whose linear dynamics make the gains independent of the
@@ -296,13 +296,13 @@ def test_swingup_oracle():
     assert abs(x[0] + 20.0) < 0.1 and abs(x[2] - np.pi) < 0.05, x  # at the goal, pole up
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2])
 def test_di_vanilla_nominal_variance_oracle(seed):
     fail, x, _ = di_loop(_OracleSide(di_acceptance_cfg(1, 4.0, 3), seed, "vanilla"), "vanilla", 500, 1.0, seed)
     assert fail is None, (fail, x)
 
 
-@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("seed", [1])
 def test_di_tube_large_variance_oracle(seed):
     side = _OracleSide(di_acceptance_cfg(2, 4.0, 3), seed, "tube", thr=100.0)
     fail, x, used = di_loop(side, "tube", 500, 100.0, seed, gains=GAINS)
