@@ -236,7 +236,8 @@ def compute_control_latency(device, x0):
             "definition": "control_ready: mppi_compute_control from an idle stream until the control sequence is on the host "
                           "(the call returns then; the finalize kernel is still re-rolling the state trajectory); "
                           "control_and_state_trajectory: + mppi_get_state_seq; closed_loop_period: computeControl + "
-                          "getControlSeq + slide back to back"}
+                          "getControlSeq + slide back to back (split hand-over: the trajectory re-rollout of one call runs on a "
+                          "side stream beside the next call's rollouts, DESIGN.md §2)"}
 
 
 def kernel_stats_us(kernel_prefix):

@@ -54,7 +54,64 @@ struct FinalizeArgs
    *  the smoothing buffer and the smoothed sequence; nullptr: both in LDS.  (One lane per rollout and replicated-lane
    *  kernels; the LDS + barrier variant keeps its trajectories in LDS as well and stays limited.) */
   float* scratch_d;
+  /* Split hand-over (round 5, one-system launches): the two halves of the pass as two launches on two streams, so that the
+   * re-rollout of call N — a lone wave's chain of T steps, most of the kernel — runs BESIDE the rollouts of call N + 1 instead
+   * of in front of them.  phases bit 0: the control phase (smoothing, constraints, write-out, statistics, flag 2 z); bit 1: the
+   * trajectory phase (re-rollout, flag 2 z + 1).  3: both, one launch (every other caller).  1: before it raises its flag the
+   * block leaves in carry_d a copy of the call's input block carry_src_d[carry_floats] (initial state, control history) with
+   * the smoothed control sequence in the place of the nominal control (offset carry_mean_off) — everything the trajectory
+   * phase and later device-side readers of the inputs need, none of which the host or the next call's launches write — and
+   * publishes seq in *carry_ready_d (release, device scope).  2: the trajectory phase alone, launched on the other stream with NO
+   * stream dependency (an event between two streams cost 5-12 us here, and a marker in front of the next call's rollouts): its
+   * wave sleeps until *carry_ready_d == seq (bounded), then reads control_in_d / x0_d, which point into that carry block;
+   * smooth_mask is 0. */
+  int phases = 3;
+  float* carry_d = nullptr;
+  const float* carry_src_d = nullptr;
+  int carry_floats = 0;
+  int carry_mean_off = 0;
+  unsigned* carry_ready_d = nullptr;
 };
+
+/** control phase of a split pass (FinalizeArgs::phases == 1): the carry block, written and published before the hand-over flag
+ *  goes up (the host may overwrite the inbox carry_src_d the moment it sees the flag).  One wave per block in every variant. */
+__device__ inline void finalizeWriteCarry(const FinalizeArgs& a, const int z, const float* ctrl, const int TC, const int lane,
+                                          const int stride)
+{
+  if (a.phases != 1 || !a.carry_d)
+    return;
+  const int m0 = a.carry_mean_off + z * TC;
+  if (z == 0)
+    for (int e = lane; e < a.carry_floats; e += stride)
+      if (e < a.carry_mean_off || e >= a.carry_mean_off + (int)gridDim.x * TC)
+        a.carry_d[e] = a.carry_src_d[e];
+  for (int e = lane; e < TC; e += stride)
+    a.carry_d[m0 + e] = ctrl[e];
+  __syncthreads();
+  if (lane == 0 && a.carry_ready_d)
+    __hip_atomic_store(a.carry_ready_d, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/** trajectory phase of a split pass (phases == 2): wait for the control phase of the same call (it may not even have started:
+ *  the two launches are ordered by nothing else).  false: it did not come within ~2 s — the block leaves without its flag and
+ *  the host's wait reports the failure. */
+__device__ inline bool finalizeAwaitCarry(const FinalizeArgs& a)
+{
+  if (a.phases != 2 || !a.carry_ready_d)
+    return true;
+  const unsigned long long t0 = wall_clock64();  // 100 MHz
+  bool ok = true;
+  while (__hip_atomic_load(a.carry_ready_d, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.seq)
+  {
+    __builtin_amdgcn_s_sleep(64);
+    if (wall_clock64() - t0 > 200000000ull)
+    {
+      ok = false;
+      break;
+    }
+  }
+  return __syncthreads_and(ok) != 0;  // the same answer in every wave of the block
+}
 
 /** floats of FinalizeArgs::scratch_d per system */
 __host__ __device__ inline size_t finalizeScratchFloats(int num_timesteps, int control_dim)
@@ -178,6 +235,8 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
   float* y_traj = x_traj + math::nearest_multiple_4(T * S);    // [T][O], BY > 1 only
 
   const float* uin = a.control_in_d + (size_t)z * T * C;
+  if (!finalizeAwaitCarry(a))  // (block-uniform)
+    return;
   for (int i = ty; i < S; i += NL)
     zero_state[i] = 0.0f;
 
@@ -211,8 +270,12 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
       ctrl[e] = uin[e];
   }
   __syncthreads();  // ctrl is complete
+  finalizeWriteCarry(a, z, ctrl, T * C, ty, NL);
   // the constrained control sequence goes out first: the host can act on it while the trajectory below is re-rolled
-  finalizeEmitControl(dynamics, a, z, ctrl, buf, zero_state, ty, NL, (BY == 1) ? lx : 0, LX);
+  if (a.phases & 1)
+    finalizeEmitControl(dynamics, a, z, ctrl, buf, zero_state, ty, NL, (BY == 1) ? lx : 0, LX);
+  if (!(a.phases & 2))
+    return;
   if constexpr (BY == 1)
   {
     if (lx == 0)
@@ -358,6 +421,8 @@ __global__ void __launch_bounds__(64) finalizeRepKernel(DYN_T dynamics_obj, cons
     buf = a.scratch_d + (size_t)z * finalizeScratchFloats(T, C);  // long horizons: smoothing buffer and sequence in HBM
   float* ctrl = buf + math::nearest_multiple_4((T + 4) * C);                                // [T][C]
   const float* uin = a.control_in_d + (size_t)z * T * C;
+  if (!finalizeAwaitCarry(a))
+    return;
 
   if ((a.smooth_mask >> z) & 1)
   {
@@ -389,7 +454,9 @@ __global__ void __launch_bounds__(64) finalizeRepKernel(DYN_T dynamics_obj, cons
       ctrl[e] = uin[e];
   }
   __syncthreads();
+  finalizeWriteCarry(a, z, ctrl, T * C, lane, 64);
   // the constrained control sequence goes out first (see finalizeKernel)
+  if (a.phases & 1)
   {
     float zero_state[S];
 #pragma unroll
@@ -397,6 +464,8 @@ __global__ void __launch_bounds__(64) finalizeRepKernel(DYN_T dynamics_obj, cons
       zero_state[i] = 0.0f;
     finalizeEmitControl(dynamics, a, z, ctrl, buf, zero_state, lane, 64, lane, 64);
   }
+  if (!(a.phases & 2))
+    return;
 
   float x[S], xn[S], xdot[S], u[C], y[O];
 #pragma unroll

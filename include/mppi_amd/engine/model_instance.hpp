@@ -228,8 +228,9 @@ struct ModelBase
  *  plugin built against other headers: its kernels would read the argument blocks with the wrong layout) */
 /** bumped BY HAND whenever ModelBase's virtual methods are added, removed or reordered or a field of an argument struct is
  *  swapped at equal size — changes sizeof() cannot see (a stale plugin would dispatch to the wrong vtable slot).
- *  3: rows-in-HBM arguments; 4: release-flag arguments of the finalize kernels (both round 3); 5: supportsStreamedMerge (round 4). */
-#define MPPI_ENGINE_ABI_VERSION 5
+ *  3: rows-in-HBM arguments; 4: release-flag arguments of the finalize kernels (both round 3); 5: supportsStreamedMerge (round 4);
+ *  6: FinalizeArgs::phases / carry block of the split hand-over (round 5). */
+#define MPPI_ENGINE_ABI_VERSION 6
 
 constexpr int engineAbiFingerprint()
 {

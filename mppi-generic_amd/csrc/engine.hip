@@ -155,6 +155,21 @@ struct mppi_handle_s
    * and the finalize kernel their initial state and history, from the inbox (HBM, not PCIe).  MPPI_AMD_BAR_INBOX=0: mapped
    * host memory + ingest kernel as before. */
   bool bar_inbox = false;
+  /* Split hand-over (round 5; one-system controllers, low-latency path): the finalize pass as two launches — the control phase on
+   * the handle's stream, the re-rollout of the state trajectory on side_stream behind an event — so the re-rollout of call N
+   * (a lone wave, T dependent steps: 22 of a Cartpole call's 61 us period) runs beside the rollouts of call N + 1.  The
+   * trajectory phase reads nothing but a carry block the control phase wrote (finalize_kernel.hpp: FinalizeArgs::phases) and
+   * writes nothing but the trajectory part of io_out and its flag; two carry blocks alternate, and the control phase of call
+   * N + 2 is not enqueued before call N's trajectory flag is up (carry_seq).  Every OTHER entry point that touches the device
+   * first orders the handle's stream behind the side stream (CHECK_HANDLE -> joinSideStream).  MPPI_AMD_SPLIT_FINALIZE=0: one
+   * launch as before. */
+  bool split_finalize = false;
+  bool side_pending = false;        // a trajectory phase is (possibly) in flight that h->stream has not been ordered behind
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_side = nullptr;      // recorded behind every trajectory phase: what joinSideStream orders h->stream behind
+  float* carry_d = nullptr;         // [2][in_floats] + 2 words: the blocks' ready flags (FinalizeArgs::carry_ready_d)
+  float* fin_scratch2_d = nullptr;  // the trajectory phase's own smoothing-buffer block at long horizons (fin_scratch_d's twin)
+  unsigned carry_seq[2] = { 0, 0 };  // hand-over sequence number of the call whose trajectory phase reads carry block i (0: none)
   const float* x0_src_d = nullptr;    // where rollout launches read the initial state from (nullptr: x0_d)
   const float* mean_src_d = nullptr;  // where the NEXT rollout launch reads its nominal control from (nullptr: mean_d; one-shot)
   /* host-side stamps of the last low-latency Vanilla mppi_compute_control, microseconds since the call's first statement
@@ -281,10 +296,25 @@ static mppi_status fail(mppi_handle h, mppi_status s, const std::string& msg)
       return s__;                    \
   } while (0)
 
-#define CHECK_HANDLE(h)               \
+/** split hand-over: order the handle's stream behind the trajectory phase that may still run on the side stream — whatever an
+ *  entry point enqueues or synchronises on h->stream then sees the state a single in-order stream would have given it */
+static inline void joinSideStream(mppi_handle h)
+{
+  if (!h->side_pending)
+    return;
+  (void)hipStreamWaitEvent(h->stream, h->ev_side, 0);
+  h->side_pending = false;
+}
+/** entry points: lock the handle, join the side stream.  CHECK_HANDLE_HOST: the few that a control loop calls every cycle and
+ *  that either never touch the device or are written for the split (mppi_compute_control, the result getters, mppi_slide,
+ *  mppi_model_step): no join, so the next call's rollouts are not ordered behind the last call's re-rollout */
+#define CHECK_HANDLE_HOST(h)          \
   if (!(h))                           \
     return MPPI_ERR_INVALID_ARG;      \
   std::lock_guard<std::recursive_mutex> handle_lock__((h)->mu)
+#define CHECK_HANDLE(h)  \
+  CHECK_HANDLE_HOST(h);  \
+  joinSideStream(h)
 
 /** buffers of the reference-order reduction: samples in HBM (what cfg.save_samples allocates), weights, cell partials */
 static mppi_status ensureExactBuffers(mppi_handle h)
@@ -437,6 +467,16 @@ static void freeAll(mppi_handle h)
     (void)hipFree(h->mbox_d);
   h->mbox_d = nullptr;
   h->p2p_ready = false;
+  if (h->side_stream)
+  {  // a trajectory phase may still be writing io_out
+    (void)hipStreamSynchronize(h->side_stream);
+    (void)hipStreamDestroy(h->side_stream);
+  }
+  if (h->ev_side)
+    (void)hipEventDestroy(h->ev_side);
+  h->side_stream = nullptr;
+  h->ev_side = nullptr;
+  h->split_finalize = h->side_pending = false;
   if (h->io_in_h)
     (void)(h->bar_inbox ? hipFree(h->io_in_h) : hipHostFree(h->io_in_h));
   if (h->io_out_h)
@@ -455,7 +495,7 @@ static void freeAll(mppi_handle h)
   h->step_u_d = nullptr;  // slice of the step_x_d block
   float** bufs[] = { &h->in_block_d, &h->out_block_d, &h->costs_d,   &h->partials_d,  &h->partials_alt_d, &h->send_d,     &h->recv_d,
                      &h->eps_d,     &h->samples_d, &h->ctrl_in_d,  &h->step_x_d, &h->gather_tmp_d, &h->rows_d, &h->fin_scratch_d,
-                     &h->tsallis_weights_d, &h->tsallis_record_d, &h->rocrand_eps_d, &h->std_dev_time_d, &h->exact_weights_d, &h->exact_inter_d };
+                     &h->fin_scratch2_d, &h->carry_d, &h->tsallis_weights_d, &h->tsallis_record_d, &h->rocrand_eps_d, &h->std_dev_time_d, &h->exact_weights_d, &h->exact_inter_d };
   for (float** b : bufs)
   {
     if (*b)
@@ -817,6 +857,28 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     const size_t per_sys = kernels::finalizeScratchFloats(T, C);
     if (per_sys * sizeof(float) > 64 * 1024 || (force && force[0] == '1'))
       ALLOC_OR_FAIL(h->fin_scratch_d, (size_t)D * per_sys);
+    // split hand-over (mppi_handle_s::split_finalize): one-system controllers on the low-latency path
+    const char* split = getenv("MPPI_AMD_SPLIT_FINALIZE");
+    // (not on a caller's stream: there a stream synchronisation is the caller's way to wait for everything the library launched)
+    if (h->low_latency && h->own_stream && D == 1 && world == 1 && !cfg->force_exchange && !(split && split[0] == '0') &&
+        (cfg->controller == MPPI_CONTROLLER_VANILLA || cfg->controller == MPPI_CONTROLLER_COLORED))
+    {
+      ALLOC_OR_FAIL(h->carry_d, 2 * h->in_floats + 2);
+      if (hipMemsetAsync(h->carry_d, 0, sizeof(float) * (2 * h->in_floats + 2), h->stream) != hipSuccess)
+      {
+        freeAll(hp);
+        return fail(nullptr, MPPI_ERR_HIP, "mppi_create: clearing the carry blocks");
+      }
+      if (h->fin_scratch_d)
+        ALLOC_OR_FAIL(h->fin_scratch2_d, (size_t)D * per_sys);
+      if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess)
+      {
+        freeAll(hp);
+        return fail(nullptr, MPPI_ERR_HIP, "mppi_create: side stream of the split hand-over");
+      }
+      h->split_finalize = true;
+    }
   }
 #undef ALLOC_OR_FAIL
   {
@@ -884,7 +946,7 @@ void mppi_destroy(mppi_handle h)
 
 mppi_status mppi_get_dims(mppi_handle h, int* s, int* c, int* o, int* d)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   if (s)
     *s = h->S;
   if (c)
@@ -898,7 +960,7 @@ mppi_status mppi_get_dims(mppi_handle h, int* s, int* c, int* o, int* d)
 
 mppi_status mppi_get_local_rollouts(mppi_handle h, int* k_local, int* k_offset)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   if (k_local)
     *k_local = h->K_local;
   if (k_offset)
@@ -908,7 +970,7 @@ mppi_status mppi_get_local_rollouts(mppi_handle h, int* k_local, int* k_offset)
 
 mppi_status mppi_get_launch_counts(mppi_handle h, unsigned long long* rollout_launches, unsigned long long* merge_launches)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   if (rollout_launches)
     *rollout_launches = h->n_rollout_launches;
   if (merge_launches)
@@ -2012,8 +2074,35 @@ static mppi_status waitHostFlag(mppi_handle h, int idx, unsigned seq)
     if ((++spins & 0x3ff) == 0 && std::chrono::duration<double>(clock::now() - t0).count() > 2.0)
     {
       HIP_TRY(h, hipStreamSynchronize(h->stream));
+      if (h->side_stream)
+        HIP_TRY(h, hipStreamSynchronize(h->side_stream));
       if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
         return fail(h, MPPI_ERR_HIP, "the finalize kernel finished without raising its hand-over flag");
+      break;
+    }
+  }
+  return MPPI_OK;
+}
+
+/** the same for "the flag has reached seq" (sequence numbers only grow; wrap-around safe): the trajectory phases of a split
+ *  hand-over run in order on the side stream, so a later call's flag value covers the earlier ones */
+static mppi_status waitHostFlagReached(mppi_handle h, int idx, unsigned seq)
+{
+  using clock = std::chrono::steady_clock;
+  const clock::time_point t0 = clock::now();
+  volatile unsigned* flag = h->io_flags_h + idx;
+  unsigned spins = 0;
+  while ((int)(__atomic_load_n(flag, __ATOMIC_ACQUIRE) - seq) < 0)
+  {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+    if ((++spins & 0x3ff) == 0 && std::chrono::duration<double>(clock::now() - t0).count() > 2.0)
+    {
+      if (h->side_stream)
+        HIP_TRY(h, hipStreamSynchronize(h->side_stream));
+      if ((int)(__atomic_load_n(flag, __ATOMIC_ACQUIRE) - seq) < 0)
+        return fail(h, MPPI_ERR_HIP, "the trajectory phase of an earlier call finished without raising its flag");
       break;
     }
   }
@@ -2093,7 +2182,10 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
      * The call returns when the control sequence and the merge statistics are out (flag 0), while the finalize kernel
      * still re-rolls the state trajectory of u* — a T-step serial chain, ~1/3 of the call for Cartpole; the trajectory
      * getters wait for flag 1 (tools/ubench/handover.hip: 3 kernels + spin 15 us against 23 us with copies + synchronise). */
-    if (h->traj_pending)  // a caller that never asked for the previous trajectories: the kernel must be done with io_out
+    // a caller that never asked for the previous trajectories: the kernel must be done with io_out and — BAR inbox — with the
+    // inputs before the host overwrites them.  Split hand-over: the trajectory phase reads its carry block, writes nothing the
+    // control phase of this call writes, and the flag waits of the getters take sequence numbers: nothing to wait for
+    if (h->traj_pending && !h->split_finalize)
       MPPI_TRY(waitHostFlag(h, 1, h->io_seq));
     h->traj_pending = false;
     const std::chrono::steady_clock::time_point t_call = std::chrono::steady_clock::now();
@@ -2145,12 +2237,45 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     a.stats_floats = kernels::STATS_STRIDE;
     a.flags_d = h->io_flags_dev;
     a.seq = ++h->io_seq;
+    float* carry = nullptr;
+    if (h->split_finalize)
+    {
+      // this call's carry block was last read by the trajectory phase of the call two hand-overs ago: its flag is up, or we wait
+      const unsigned p = a.seq & 1u;
+      if (h->carry_seq[p] != 0)
+        MPPI_TRY(waitHostFlagReached(h, 1, h->carry_seq[p]));
+      carry = h->carry_d + (size_t)p * h->in_floats;
+      a.phases = 1;
+      a.carry_d = carry;
+      a.carry_src_d = direct ? h->io_in_dev : h->in_block_d;
+      a.carry_floats = (int)h->in_floats;
+      a.carry_mean_off = (int)(h->mean_d - h->in_block_d);
+      a.carry_ready_d = reinterpret_cast<unsigned*>(h->carry_d + 2 * h->in_floats) + p;
+    }
     const mppi_status st = h->model->launchFinalize(1, a, h->stream, err);
     if (st != MPPI_OK)
       return fail(h, st, err);
+    if (h->split_finalize)
+    {  // the trajectory phase, on the side stream: it waits for the control phase's carry block by itself (no event between the
+       // streams), and reads nothing else
+      kernels::FinalizeArgs b = a;
+      b.phases = 2;
+      b.carry_d = nullptr;
+      b.control_in_d = carry + (h->mean_d - h->in_block_d);
+      b.x0_d = carry + (h->x0_d - h->in_block_d);
+      b.smooth_mask = 0;
+      b.scratch_d = h->fin_scratch2_d;
+      const mppi_status st2 = h->model->launchFinalize(1, b, h->side_stream, err);
+      if (st2 != MPPI_OK)
+        return fail(h, st2, err);
+      HIP_TRY(h, hipEventRecord(h->ev_side, h->side_stream));
+      h->side_pending = true;
+      h->carry_seq[a.seq & 1u] = a.seq;
+    }
     if (direct)
-    {  // behind the finalize kernel, off the caller's path: the device-resident x0 / history later mppi_optimize / operator calls read
-      hipLaunchKernelGGL(kernels::ingestRangesKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d,
+    {  // behind the finalize kernel, off the caller's path: the device-resident x0 / history later mppi_optimize / operator calls
+       // read.  Split hand-over: from the carry block — the host may be rewriting the inbox for its next call by now
+      hipLaunchKernelGGL(kernels::ingestRangesKernel, dim3(1), dim3(256), 0, h->stream, carry ? carry : h->io_in_dev, h->in_block_d,
                          (int)(h->mean_d - h->in_block_d), (int)(h->history_d - h->in_block_d),
                          (int)(h->in_floats - (size_t)(h->history_d - h->in_block_d)));
       HIP_TRY(h, hipGetLastError());
@@ -2705,7 +2830,7 @@ static mppi_status computeControlRobust(mppi_handle h, const float* x0_real, int
 
 mppi_status mppi_compute_control(mppi_handle h, const float* x0, int stride)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   if (!x0 || stride < 0)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_compute_control: null state or negative stride");
   for (int i = 0; i < h->S; i++)  // base_plant.hpp:466-470 skips the iteration on a non-finite state; here the call says so
@@ -2723,7 +2848,7 @@ mppi_status mppi_compute_control(mppi_handle h, const float* x0, int stride)
 
 mppi_status mppi_get_control_seq(mppi_handle h, float* u)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   if (!u)
     return fail(h, MPPI_ERR_INVALID_ARG, "null");
   std::copy(h->control_h.begin(), h->control_h.end(), u);
@@ -2731,7 +2856,7 @@ mppi_status mppi_get_control_seq(mppi_handle h, float* u)
 }
 mppi_status mppi_get_state_seq(mppi_handle h, float* x)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   if (!x)
     return fail(h, MPPI_ERR_INVALID_ARG, "null");
   MPPI_TRY(ensureTrajectories(h));
@@ -2742,7 +2867,7 @@ mppi_status mppi_get_state_seq(mppi_handle h, float* x)
 }
 mppi_status mppi_get_output_seq(mppi_handle h, float* y)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   if (!y)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_get_output_seq: null");
   // system 0 of the last finalize pass is the trajectory mppi_get_state_seq reports (real system for Vanilla / Tube, the
@@ -2755,6 +2880,7 @@ mppi_status mppi_get_output_seq(mppi_handle h, float* y)
     return MPPI_OK;
   }
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  joinSideStream(h);
   HIP_TRY(h, hipMemcpyAsync(y, h->output_out_d, sizeof(float) * h->cfg.num_timesteps * h->O, hipMemcpyDeviceToHost,
                             h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -2763,7 +2889,7 @@ mppi_status mppi_get_output_seq(mppi_handle h, float* y)
 
 mppi_status mppi_get_nominal_control_seq(mppi_handle h, float* u)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   if (!u)
     return fail(h, MPPI_ERR_INVALID_ARG, "null");
   if (h->D != 2)
@@ -2773,7 +2899,7 @@ mppi_status mppi_get_nominal_control_seq(mppi_handle h, float* u)
 }
 mppi_status mppi_get_nominal_state_seq(mppi_handle h, float* x)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   if (!x)
     return fail(h, MPPI_ERR_INVALID_ARG, "null");
   if (h->D != 2)
@@ -2851,7 +2977,7 @@ static mppi_status modelStepInPlace(mppi_handle h, float* x, float* u, float dt,
 
 mppi_status mppi_slide(mppi_handle h, int steps)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   const int T = h->cfg.num_timesteps, C = h->C;
   if (steps < 0 || steps > T)
     return fail(h, MPPI_ERR_INVALID_ARG, "mppi_slide: steps out of range");
@@ -3228,7 +3354,7 @@ mppi_status mppi_choose_kernel(mppi_handle h, int num_evaluations, int* chosen_v
 /** diagnostics: the host-side stamps of the last low-latency Vanilla mppi_compute_control (see mppi_handle_s::host_stamps_us) */
 mppi_status mppi_debug_host_stamps(mppi_handle h, double* out8)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   if (!out8)
     return fail(h, MPPI_ERR_INVALID_ARG, "null");
   std::copy(h->host_stamps_us, h->host_stamps_us + 8, out8);
@@ -3600,7 +3726,7 @@ mppi_status mppi_enforce_constraints(mppi_handle h, const float* state, float* u
 
 mppi_status mppi_model_step(mppi_handle h, float* x, float* u, float dt, int enforce)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   if (!x || !u)
     return fail(h, MPPI_ERR_INVALID_ARG, "null");
   HIP_TRY(h, hipSetDevice(h->cfg.device));

@@ -1,0 +1,158 @@
+"""Split hand-over of mppi_compute_control (one-system controllers, low-latency path): the finalize pass as two launches — the
+control phase on the handle's stream, the re-rollout of the state trajectory on a side stream — so the re-rollout of call N runs
+beside the rollouts of call N + 1 (csrc/engine.hip: split_finalize; engine/finalize_kernel.hpp: FinalizeArgs::phases).  Every
+host-visible result must be the bits the single launch (MPPI_AMD_SPLIT_FINALIZE=0, read when the handle is created) gives:
+controls, state and output trajectories, statistics — with the trajectories read every call, never, or late; with the BAR
+inbox and without; with the smoothing buffer in LDS and in HBM; and with other entry points between the calls."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from common import autorally_cfg, cartpole_cfg, make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+class _Env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _loop(cfg, env, read_every, cycles=7, between=None):
+    """closed loop of `cycles` calls; trajectories fetched on calls where i % read_every == 0 (0: never, only after the loop)"""
+    with _Env(**env):
+        eng = make_engine(cfg)
+    x = cfg["x0"].copy()
+    rec = []
+    for i in range(cycles):
+        eng.computeControl(x, 1)
+        r = [eng.getControlSeq().copy()]
+        st = eng.getStats() if i % 3 == 2 else None  # (a device-touching entry point every third cycle)
+        if st is not None:
+            r.append(np.array([st.real_sys.baseline, st.real_sys.normalizer], np.float64))
+        if read_every and i % read_every == 0:
+            r += [eng.getTargetStateSeq().copy(), eng.getTargetOutputSeq().copy()]
+        if between is not None:
+            between(eng, i)
+        rec.append(r)
+        eng.slideControlSequence(1)
+        x = (x + np.float32(0.01) * np.arange(1, x.size + 1, dtype=np.float32)).astype(np.float32)
+    rec.append([eng.getTargetStateSeq().copy(), eng.getTargetOutputSeq().copy()])
+    eng.close()
+    return rec
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for p, q in zip(a, b):
+        assert len(p) == len(q)
+        for u, v in zip(p, q):
+            assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("read_every", [1, 2, 0])
+@pytest.mark.parametrize("bar", ["1", "0"])
+def test_split_equals_single_launch_cartpole(gpu, read_every, bar):
+    cfg = cartpole_cfg(K=2048, T=60, soft=True)
+    ref = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": "0", "MPPI_AMD_BAR_INBOX": bar}, read_every)
+    got = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": None, "MPPI_AMD_BAR_INBOX": bar}, read_every)
+    _same(ref, got)
+
+
+def test_split_equals_single_launch_scratch_in_hbm(gpu):
+    cfg = cartpole_cfg(K=1024, T=80, soft=True)
+    ref = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": "0", "MPPI_AMD_FINALIZE_SCRATCH": "1"}, 2)
+    got = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": None, "MPPI_AMD_FINALIZE_SCRATCH": "1"}, 2)
+    _same(ref, got)
+
+
+@pytest.mark.parametrize("num_iters", [1, 2])
+def test_split_equals_single_launch_autorally(gpu, num_iters):
+    """the NN model's re-rollout runs on its one-rollout-per-wave form (finalizeRepKernel), 150 steps: the longest trajectory
+    phase relative to its call"""
+    cfg = autorally_cfg(K=2048, T=150, num_iters=num_iters)
+    ref = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": "0"}, 2, cycles=5)
+    got = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": None}, 2, cycles=5)
+    _same(ref, got)
+
+
+def test_other_entry_points_between_calls(gpu):
+    """mppi_optimize / mppi_upload_state / the model step between two calls: they are ordered behind the trajectory phase (or do
+    not touch what it reads), and the device-resident inputs they see are the last call's"""
+    cfg = cartpole_cfg(K=1024, T=50, soft=True)
+
+    def between(eng, i):
+        if i == 1:
+            eng.optimize(2, True)
+        if i == 3:
+            x = cfg["x0"].copy()
+            u = np.zeros(eng.CONTROL_DIM, np.float32)
+            eng.modelStep(x, u)
+        if i == 4:
+            eng.uploadState(cfg["x0"])
+            eng.optimize(1, True)
+
+    ref = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": "0"}, 0, between=between)
+    got = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": None}, 0, between=between)
+    _same(ref, got)
+
+
+def test_many_unread_calls_then_read(gpu):
+    """40 calls back to back without a single trajectory read (the carry blocks alternate, the control phase of call N + 2 waits
+    for call N's trajectory flag on the host), then the last call's trajectory"""
+    cfg = cartpole_cfg(K=1024, T=100, soft=True)
+    out = []
+    for split in ("0", None):
+        with _Env(MPPI_AMD_SPLIT_FINALIZE=split):
+            eng = make_engine(cfg)
+        x = cfg["x0"].copy()
+        for i in range(40):
+            eng.computeControl(x, 1)
+            eng.slideControlSequence(1)
+        out.append((eng.getControlSeq().copy(), eng.getTargetStateSeq().copy()))
+        eng.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+
+
+def test_split_shortens_the_closed_loop(gpu):
+    """what the split is for: computeControl + getControlSeq + slide back to back.  The single launch's period is the call plus
+    the re-rollout; the split's is the call.  (Loose bound: a tenth of the re-rollout must show.)"""
+    cfg = cartpole_cfg(K=16384, T=100)
+    period = {}
+    for split in ("0", None):
+        with _Env(MPPI_AMD_SPLIT_FINALIZE=split):
+            eng = make_engine(cfg)
+        x = cfg["x0"].copy()
+        for _ in range(50):
+            eng.computeControl(x, 1)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(200):
+                eng.computeControl(x, 1)
+                eng.getControlSeq()
+                eng.slideControlSequence(1)
+            best = min(best, (time.perf_counter() - t0) / 200)
+        eng.getTargetStateSeq()
+        eng.close()
+        period[split] = best * 1e6
+    print("closed-loop period: single launch %.1f us, split %.1f us" % (period["0"], period[None]))
+    assert period[None] < period["0"] - 2.0
