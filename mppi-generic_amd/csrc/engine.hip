@@ -181,6 +181,7 @@ struct mppi_handle_s
   unsigned step_seq = 0;           // hand-over counter of the model-step flag (io_flags[8])
   size_t in_floats = 0, out_floats = 0;
   bool out_pin_fresh = false;      // out_pin_h holds the results (incl. stats) of the last finalize pass; reset by launches
+  bool stats_h_fresh = false;      // stats_h IS the statistics of the last merge (parsed at a low-latency hand-over); reset by launches
   float* step_x_d = nullptr;       // [S]
   float* step_u_d = nullptr;       // [C]
   int n_eps_iters = 0;
@@ -1678,6 +1679,7 @@ static mppi_status launchRollout(mppi_handle h, int iteration, int stride)
     return fail(h, st, err);
   h->generation++;
   h->out_pin_fresh = false;
+  h->stats_h_fresh = false;
   return MPPI_OK;
 }
 
@@ -1910,6 +1912,8 @@ static mppi_status iteration(mppi_handle h, int it, int stride)
 static void parseStats(mppi_handle h, const float* st);
 static mppi_status fetchStats(mppi_handle h)
 {
+  if (h->stats_h_fresh)  // parsed at the hand-over of the last mppi_compute_control, no launch since
+    return MPPI_OK;
   if (h->out_pin_fresh)
   {  // the last finalize pass brought the statistics along
     parseStats(h, h->out_pin_h + (h->stats_d - h->out_block_d));
@@ -2289,6 +2293,7 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     const float* out = h->io_out_h;
     std::copy(out, out + (size_t)T * h->C, h->control_h.begin());
     parseStats(h, out + (h->stats_d - h->out_block_d));
+    h->stats_h_fresh = true;
     stamp(6);
     if (!allFinite(h->control_h))
       return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control sequence");
@@ -2387,6 +2392,7 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
       std::copy(out, out + (size_t)T * h->C, h->control_h.begin());
       std::copy(out + (size_t)T * h->C, out + (size_t)2 * T * h->C, h->nominal_control_h.begin());
       parseStats(h, out + (h->stats_d - h->out_block_d));
+      h->stats_h_fresh = true;
       return MPPI_OK;
     };
     /* Round 5: ONE hand-over per call.  Between two optimisation passes the reference decides on the host whether the nominal
@@ -2809,6 +2815,7 @@ static mppi_status computeControlRobust(mppi_handle h, const float* x0_real, int
     std::copy(out, out + (size_t)T * h->C, h->nominal_control_h.begin());
     std::copy(out + (size_t)T * h->C, out + (size_t)2 * T * h->C, h->control_h.begin());
     parseStats(h, out + (h->stats_d - h->out_block_d));
+    h->stats_h_fresh = true;
     if (!allFinite(h->control_h) || !allFinite(h->nominal_control_h))
       return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control sequence");
     return MPPI_OK;
@@ -3093,10 +3100,14 @@ mppi_status mppi_get_costs(mppi_handle h, float* costs)
 }
 mppi_status mppi_get_stats(mppi_handle h, mppi_stats* out)
 {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_HOST(h);
   if (!out)
     return fail(h, MPPI_ERR_INVALID_ARG, "null");
-  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (!h->stats_h_fresh)
+  {  // a read from the device: behind everything, the side stream included
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    joinSideStream(h);
+  }
   const int used = h->stats_h.nominal_state_used;
   MPPI_TRY(fetchStats(h));
   h->stats_h.nominal_state_used = used;
