@@ -64,7 +64,7 @@ def _same(a, b):
     for p, q in zip(a, b):
         assert len(p) == len(q)
         for u, v in zip(p, q):
-            assert np.array_equal(u, v)
+            assert u.shape == v.shape and u.tobytes() == v.tobytes()  # bit for bit (outputs a model does not produce are NaN)
 
 
 @pytest.mark.parametrize("read_every", [1, 2, 0])
@@ -88,6 +88,27 @@ def test_split_equals_single_launch_autorally(gpu, num_iters):
     """the NN model's re-rollout runs on its one-rollout-per-wave form (finalizeRepKernel), 150 steps: the longest trajectory
     phase relative to its call"""
     cfg = autorally_cfg(K=2048, T=150, num_iters=num_iters)
+    ref = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": "0"}, 2, cycles=5)
+    got = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": None}, 2, cycles=5)
+    _same(ref, got)
+
+
+def test_split_equals_single_launch_racer_lstm_steering(gpu):
+    """the LSTM-steering RACER model: LSTM state inside the dynamics object, an elevation map, and an output trajectory with NaN
+    fields (outputs the model does not produce) — compared bit for bit.  Its re-rollout runs on the model's replicated-lane form
+    (finalizeRepKernel) with the default networks, on the two-lane contract form of finalizeKernel otherwise."""
+    from test_racer_dubins_lstm_steering import steering_cfg
+    cfg = steering_cfg(K=512, T=40)
+    ref = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": "0"}, 2, cycles=5)
+    got = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": None}, 2, cycles=5)
+    _same(ref, got)
+
+
+def test_split_equals_single_launch_colored_controller(gpu):
+    """ColoredMPPI: colored-noise sampler, channel-1-only clamp in the control phase, and the state leash — every call starts from
+    the previous call's state trajectory, i.e. waits for the trajectory phase on the host"""
+    cfg = cartpole_cfg(K=1024, T=64, soft=True)
+    cfg["colored"] = ([1.0], 0.97, 0.0)
     ref = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": "0"}, 2, cycles=5)
     got = _loop(cfg, {"MPPI_AMD_SPLIT_FINALIZE": None}, 2, cycles=5)
     _same(ref, got)
