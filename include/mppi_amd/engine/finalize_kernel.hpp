@@ -54,16 +54,16 @@ struct FinalizeArgs
    *  the smoothing buffer and the smoothed sequence; nullptr: both in LDS.  (One lane per rollout and replicated-lane
    *  kernels; the LDS + barrier variant keeps its trajectories in LDS as well and stays limited.) */
   float* scratch_d;
-  /* Split hand-over (round 5, one-system launches): the two halves of the pass as two launches on two streams, so that the
+  /* Split hand-over (round 5; Vanilla / Colored and Tube MPPI): the two halves of the pass as two launches on two streams, so that the
    * re-rollout of call N — a lone wave's chain of T steps, most of the kernel — runs BESIDE the rollouts of call N + 1 instead
    * of in front of them.  phases bit 0: the control phase (smoothing, constraints, write-out, statistics, flag 2 z); bit 1: the
    * trajectory phase (re-rollout, flag 2 z + 1).  3: both, one launch (every other caller).  1: before it raises its flag the
    * block leaves in carry_d a copy of the call's input block carry_src_d[carry_floats] (initial state, control history) with
    * the smoothed control sequence in the place of the nominal control (offset carry_mean_off) — everything the trajectory
    * phase and later device-side readers of the inputs need, none of which the host or the next call's launches write — and
-   * publishes seq in *carry_ready_d (release, device scope).  2: the trajectory phase alone, launched on the other stream with NO
+   * publishes seq in carry_ready_d[z] (release, device scope; one word per system).  2: the trajectory phase alone, launched on the other stream with NO
    * stream dependency (an event between two streams cost 5-12 us here, and a marker in front of the next call's rollouts): its
-   * wave sleeps until *carry_ready_d == seq (bounded), then reads control_in_d / x0_d, which point into that carry block;
+   * wave sleeps until carry_ready_d[0] and carry_ready_d[z] hold seq (bounded), then reads control_in_d / x0_d, which point into that carry block;
    * smooth_mask is 0. */
   int phases = 3;
   float* carry_d = nullptr;
@@ -88,20 +88,22 @@ __device__ inline void finalizeWriteCarry(const FinalizeArgs& a, const int z, co
   for (int e = lane; e < TC; e += stride)
     a.carry_d[m0 + e] = ctrl[e];
   __syncthreads();
-  if (lane == 0 && a.carry_ready_d)
-    __hip_atomic_store(a.carry_ready_d, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0 && a.carry_ready_d)  // one word per system: block z of the trajectory phase waits for words 0 and z
+    __hip_atomic_store(a.carry_ready_d + z, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /** trajectory phase of a split pass (phases == 2): wait for the control phase of the same call (it may not even have started:
  *  the two launches are ordered by nothing else).  false: it did not come within ~2 s — the block leaves without its flag and
  *  the host's wait reports the failure. */
-__device__ inline bool finalizeAwaitCarry(const FinalizeArgs& a)
+__device__ inline bool finalizeAwaitCarry(const FinalizeArgs& a, const int z)
 {
   if (a.phases != 2 || !a.carry_ready_d)
     return true;
   const unsigned long long t0 = wall_clock64();  // 100 MHz
   bool ok = true;
-  while (__hip_atomic_load(a.carry_ready_d, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.seq)
+  // block 0 of the control phase wrote the shared part (initial states, history), block z this system's control sequence
+  while (__hip_atomic_load(a.carry_ready_d, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.seq ||
+         __hip_atomic_load(a.carry_ready_d + z, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.seq)
   {
     __builtin_amdgcn_s_sleep(64);
     if (wall_clock64() - t0 > 200000000ull)
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(BY* finalizeBlockX(BY)) finalizeKernel(DYN_T d
   float* y_traj = x_traj + math::nearest_multiple_4(T * S);    // [T][O], BY > 1 only
 
   const float* uin = a.control_in_d + (size_t)z * T * C;
-  if (!finalizeAwaitCarry(a))  // (block-uniform)
+  if (!finalizeAwaitCarry(a, z))  // (block-uniform)
     return;
   for (int i = ty; i < S; i += NL)
     zero_state[i] = 0.0f;
@@ -421,7 +423,7 @@ __global__ void __launch_bounds__(64) finalizeRepKernel(DYN_T dynamics_obj, cons
     buf = a.scratch_d + (size_t)z * finalizeScratchFloats(T, C);  // long horizons: smoothing buffer and sequence in HBM
   float* ctrl = buf + math::nearest_multiple_4((T + 4) * C);                                // [T][C]
   const float* uin = a.control_in_d + (size_t)z * T * C;
-  if (!finalizeAwaitCarry(a))
+  if (!finalizeAwaitCarry(a, z))
     return;
 
   if ((a.smooth_mask >> z) & 1)

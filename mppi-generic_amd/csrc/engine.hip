@@ -155,7 +155,7 @@ struct mppi_handle_s
    * and the finalize kernel their initial state and history, from the inbox (HBM, not PCIe).  MPPI_AMD_BAR_INBOX=0: mapped
    * host memory + ingest kernel as before. */
   bool bar_inbox = false;
-  /* Split hand-over (round 5; one-system controllers, low-latency path): the finalize pass as two launches — the control phase on
+  /* Split hand-over (round 5; Vanilla / Colored and Tube MPPI, low-latency path): the finalize pass as two launches — the control phase on
    * the handle's stream, the re-rollout of the state trajectory on side_stream behind an event — so the re-rollout of call N
    * (a lone wave, T dependent steps: 22 of a Cartpole call's 61 us period) runs beside the rollouts of call N + 1.  The
    * trajectory phase reads nothing but a carry block the control phase wrote (finalize_kernel.hpp: FinalizeArgs::phases) and
@@ -167,7 +167,7 @@ struct mppi_handle_s
   bool side_pending = false;        // a trajectory phase is (possibly) in flight that h->stream has not been ordered behind
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_side = nullptr;      // recorded behind every trajectory phase: what joinSideStream orders h->stream behind
-  float* carry_d = nullptr;         // [2][in_floats] + 2 words: the blocks' ready flags (FinalizeArgs::carry_ready_d)
+  float* carry_d = nullptr;         // [2][in_floats] + 2 x 2 words: the blocks' ready flags (FinalizeArgs::carry_ready_d)
   float* fin_scratch2_d = nullptr;  // the trajectory phase's own smoothing-buffer block at long horizons (fin_scratch_d's twin)
   unsigned carry_seq[2] = { 0, 0 };  // hand-over sequence number of the call whose trajectory phase reads carry block i (0: none)
   const float* x0_src_d = nullptr;    // where rollout launches read the initial state from (nullptr: x0_d)
@@ -191,6 +191,7 @@ struct mppi_handle_s
   /* host state (the reference's control_, control_history_, state_, nominal_* members) */
   std::vector<float> control_h, history_h, state_h, nominal_control_h, nominal_state_h, slide_scale_h;
   bool nominal_state_init = false;
+  std::vector<float> tube_x_h;     // Tube MPPI: the nominal system's current state (the reference's nominal_state_; [S])
   float nominal_threshold = 20.0f;  // Tube-MPPI/tube_mppi_controller.cuh:20
   mppi_stats stats_h{};
   uint32_t generation = 0;
@@ -861,11 +862,12 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     // split hand-over (mppi_handle_s::split_finalize): one-system controllers on the low-latency path
     const char* split = getenv("MPPI_AMD_SPLIT_FINALIZE");
     // (not on a caller's stream: there a stream synchronisation is the caller's way to wait for everything the library launched)
-    if (h->low_latency && h->own_stream && D == 1 && world == 1 && !cfg->force_exchange && !(split && split[0] == '0') &&
-        (cfg->controller == MPPI_CONTROLLER_VANILLA || cfg->controller == MPPI_CONTROLLER_COLORED))
+    if (h->low_latency && h->own_stream && world == 1 && !cfg->force_exchange && !(split && split[0] == '0') &&
+        (((cfg->controller == MPPI_CONTROLLER_VANILLA || cfg->controller == MPPI_CONTROLLER_COLORED) && D == 1) ||
+         (cfg->controller == MPPI_CONTROLLER_TUBE && D == 2)))
     {
-      ALLOC_OR_FAIL(h->carry_d, 2 * h->in_floats + 2);
-      if (hipMemsetAsync(h->carry_d, 0, sizeof(float) * (2 * h->in_floats + 2), h->stream) != hipSuccess)
+      ALLOC_OR_FAIL(h->carry_d, 2 * h->in_floats + 4);  // two carry blocks + their ready words (one per system)
+      if (hipMemsetAsync(h->carry_d, 0, sizeof(float) * (2 * h->in_floats + 4), h->stream) != hipSuccess)
       {
         freeAll(hp);
         return fail(nullptr, MPPI_ERR_HIP, "mppi_create: clearing the carry blocks");
@@ -900,6 +902,7 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
   h->state_h.assign((size_t)T * S, 0.0f);
   h->nominal_control_h.assign((size_t)T * C, 0.0f);
   h->nominal_state_h.assign((size_t)T * S, 0.0f);
+  h->tube_x_h.assign((size_t)S, 0.0f);
   h->slide_scale_h.assign(C, 0.0f);  // controller.cuh:67 slide_control_scale_ = Zero()
   h->nominal_history_h.assign((size_t)2 * C, 0.0f);
   h->rm_nominal_state.assign(S, 0.0f);
@@ -2034,7 +2037,7 @@ static mppi_status uploadTube(mppi_handle h, const float* x0_actual)
   // both initial states and both nominal controls through the pinned input block: one copy
   float* in = h->in_pin_h;
   std::copy(x0_actual, x0_actual + h->S, in);
-  std::copy(h->nominal_state_h.begin(), h->nominal_state_h.begin() + h->S, in + h->S);
+  std::copy(h->tube_x_h.begin(), h->tube_x_h.end(), in + h->S);
   float* mean = in + (h->mean_d - h->in_block_d);
   std::copy(h->control_h.begin(), h->control_h.end(), mean);
   std::copy(h->nominal_control_h.begin(), h->nominal_control_h.end(), mean + h->TC);
@@ -2254,7 +2257,7 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
       a.carry_src_d = direct ? h->io_in_dev : h->in_block_d;
       a.carry_floats = (int)h->in_floats;
       a.carry_mean_off = (int)(h->mean_d - h->in_block_d);
-      a.carry_ready_d = reinterpret_cast<unsigned*>(h->carry_d + 2 * h->in_floats) + p;
+      a.carry_ready_d = reinterpret_cast<unsigned*>(h->carry_d + 2 * h->in_floats) + 2 * p;
     }
     const mppi_status st = h->model->launchFinalize(1, a, h->stream, err);
     if (st != MPPI_OK)
@@ -2337,6 +2340,7 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
   if (!h->nominal_state_init)
   {
     std::copy(x0, x0 + S, h->nominal_state_h.begin());
+    std::copy(x0, x0 + S, h->tube_x_h.begin());
     h->nominal_state_init = true;
   }
   if (h->low_latency)
@@ -2345,12 +2349,15 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
      * computeControlVanilla).  Every optimisation pass needs both trajectories on the host (the nominal system is replaced by
      * the actual one when that is the better of the two, :264-277), so the loop waits for all four flags; the final smoothing
      * pass returns with the control sequences and leaves its two trajectories to ensureTrajectories(). */
-    MPPI_TRY(ensureTrajectories(h));
+    // (split hand-over: nothing of this call touches what the last call's trajectory phase reads or writes — see
+    // computeControlVanilla — and the nominal system's state is tube_x_h, not row 0 of a trajectory still on its way)
+    if (!h->split_finalize)
+      MPPI_TRY(ensureTrajectories(h));
     const int T = h->cfg.num_timesteps;
     auto stage_inputs = [&]() -> mppi_status {
       float* in = h->io_in_h;
       std::copy(x0, x0 + S, in + (h->x0_d - h->in_block_d));
-      std::copy(h->nominal_state_h.begin(), h->nominal_state_h.begin() + S, in + (h->x0_d - h->in_block_d) + S);
+      std::copy(h->tube_x_h.begin(), h->tube_x_h.end(), in + (h->x0_d - h->in_block_d) + S);
       float* mean = in + (h->mean_d - h->in_block_d);
       std::copy(h->control_h.begin(), h->control_h.end(), mean);
       std::copy(h->nominal_control_h.begin(), h->nominal_control_h.end(), mean + h->TC);
@@ -2380,9 +2387,42 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
       a.flags_d = h->io_flags_dev;
       a.seq = ++h->io_seq;
       std::string err;
+      float* carry = nullptr;
+      if (h->split_finalize)
+      {  // as computeControlVanilla: control phase here, both systems' re-rollouts on the side stream from the carry block
+        const unsigned p = a.seq & 1u;
+        if (h->carry_seq[p] != 0)
+        {
+          MPPI_TRY(waitHostFlagReached(h, 1, h->carry_seq[p]));
+          MPPI_TRY(waitHostFlagReached(h, 3, h->carry_seq[p]));
+        }
+        carry = h->carry_d + (size_t)p * h->in_floats;
+        a.phases = 1;
+        a.carry_d = carry;
+        a.carry_src_d = h->in_block_d;  // (ingested; tubeSelectKernel has put the chosen nominal state and control there)
+        a.carry_floats = (int)h->in_floats;
+        a.carry_mean_off = (int)(h->mean_d - h->in_block_d);
+        a.carry_ready_d = reinterpret_cast<unsigned*>(h->carry_d + 2 * h->in_floats) + 2 * p;
+      }
       const mppi_status st = h->model->launchFinalize(2, a, h->stream, err);
       if (st != MPPI_OK)
         return fail(h, st, err);
+      if (h->split_finalize)
+      {
+        kernels::FinalizeArgs b = a;
+        b.phases = 2;
+        b.carry_d = nullptr;
+        b.control_in_d = carry + (h->mean_d - h->in_block_d);
+        b.x0_d = carry + (h->x0_d - h->in_block_d);
+        b.smooth_mask = 0;
+        b.scratch_d = h->fin_scratch2_d;
+        const mppi_status st2 = h->model->launchFinalize(2, b, h->side_stream, err);
+        if (st2 != MPPI_OK)
+          return fail(h, st2, err);
+        HIP_TRY(h, hipEventRecord(h->ev_side, h->side_stream));
+        h->side_pending = true;
+        h->carry_seq[a.seq & 1u] = a.seq;
+      }
       h->out_pin_fresh = false;
       h->results_in_io = true;
       h->traj_pending = true;  // set before the waits: a failing wait must not leave io_out unguarded for the next call
@@ -2417,7 +2457,7 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
       const float* st1 = h->io_out_h + (h->stats_d - h->out_block_d) + kernels::STATS_STRIDE;
       h->stats_h.nominal_state_used = st1[7] != 0.0f ? 1 : 0;
       if (h->stats_h.nominal_state_used == 0)  // the nominal system restarted from the actual state (row 0 of its trajectory)
-        std::copy(x0, x0 + S, h->nominal_state_h.begin());
+        std::copy(x0, x0 + S, h->tube_x_h.begin());
     }
     if (!allFinite(h->control_h) || !allFinite(h->nominal_control_h))
       return fail(h, MPPI_ERR_NAN, "mppi_compute_control: non-finite value in the control sequence");
@@ -2436,6 +2476,7 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
     {
       h->stats_h.nominal_state_used = 0;
       h->nominal_state_h = h->state_h;
+      std::copy(x0, x0 + S, h->tube_x_h.begin());
       h->nominal_control_h = h->control_h;
     }
     else
@@ -2447,8 +2488,7 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
   HIP_TRY(h, hipMemcpyAsync(h->ctrl_in_d, h->control_h.data(), sizeof(float) * h->TC, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->ctrl_in_d + h->TC, h->nominal_control_h.data(), sizeof(float) * h->TC,
                             hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->x0_d + S, h->nominal_state_h.data(), sizeof(float) * S, hipMemcpyHostToDevice,
-                            h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->x0_d + S, h->tube_x_h.data(), sizeof(float) * S, hipMemcpyHostToDevice, h->stream));
   MPPI_TRY(finalize(h, h->ctrl_in_d, /*smooth nominal*/ 2, 0, co, so));
   if (!allFinite(h->control_h) || !allFinite(h->nominal_control_h) || !allFinite(h->state_h) ||
       !allFinite(h->nominal_state_h))
@@ -2997,9 +3037,12 @@ mppi_status mppi_slide(mppi_handle h, int steps)
   {
     // tube_mppi_controller.cu:312-323: updateNominalState(nominal_control.col(0)) — one in-place model step, no clamp
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    MPPI_TRY(ensureTrajectories(h));  // the nominal trajectory of the last mppi_compute_control (low-latency hand-over)
+    // single launch: the step queues behind the last finalize kernel anyway, and a later trajectory read must not find io_out
+    // rewritten — take the trajectories now.  Split hand-over: the step runs beside the trajectory phase
+    if (!h->split_finalize)
+      MPPI_TRY(ensureTrajectories(h));
     std::vector<float> u0(h->nominal_control_h.begin(), h->nominal_control_h.begin() + C);
-    MPPI_TRY(modelStepInPlace(h, h->nominal_state_h.data(), u0.data(), h->cfg.dt, 0));
+    MPPI_TRY(modelStepInPlace(h, h->tube_x_h.data(), u0.data(), h->cfg.dt, 0));
     saveControlHistory(steps, h->nominal_control_h, h->history_h, C);
     slideSequence(h->nominal_control_h, T, C, steps, zero.data(), h->slide_scale_h.data());
     slideSequence(h->control_h, T, C, steps, zero.data(), h->slide_scale_h.data());

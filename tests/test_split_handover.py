@@ -114,6 +114,62 @@ def test_split_equals_single_launch_colored_controller(gpu):
     _same(ref, got)
 
 
+@pytest.mark.parametrize("num_iters", [1, 3])
+@pytest.mark.parametrize("read_every", [1, 2, 0])
+def test_split_equals_single_launch_tube(gpu, num_iters, read_every):
+    """Tube MPPI: two systems, one carry block with two ready words; the nominal system's state for the next call is advanced by
+    slide's model step beside the trajectory phase; the actual system is pushed away so that both outcomes of the choice occur"""
+    from common import di_cfg
+    cfg = di_cfg(K=1024, T=60, tube=True, num_iters=num_iters)
+    out = []
+    for split in ("0", None):
+        with _Env(MPPI_AMD_SPLIT_FINALIZE=split):
+            eng = make_engine(cfg)
+        x = cfg["x0"].copy()
+        rec = []
+        for i in range(8):
+            eng.computeControl(x, 1)
+            st = eng.getStats()
+            r = [eng.getControlSeq().copy(), eng.getNominalControlSeq().copy(),
+                 np.array([st.real_sys.baseline, st.nominal_sys.baseline, st.nominal_state_used], np.float32)]
+            if read_every and i % read_every == 0:
+                r += [eng.getTargetStateSeq().copy(), eng.getNominalStateSeq().copy(), eng.getTargetOutputSeq().copy()]
+            rec.append(r)
+            eng.slideControlSequence(1)
+            x = x + np.float32(0.05 * (i + 1)) * np.float32(1 if i % 3 else -2)
+        rec.append([eng.getTargetStateSeq().copy(), eng.getNominalStateSeq().copy()])
+        out.append(rec)
+        eng.close()
+    _same(out[0], out[1])
+    assert {int(r[2][2]) for r in out[0][:-1]} == {0, 1}
+
+
+def test_split_shortens_the_tube_closed_loop(gpu):
+    from common import di_cfg
+    cfg = di_cfg(K=8192, T=150, tube=True)
+    period = {}
+    for split in ("0", None):
+        with _Env(MPPI_AMD_SPLIT_FINALIZE=split):
+            eng = make_engine(cfg)
+        x = cfg["x0"].copy()
+        for _ in range(30):
+            eng.computeControl(x, 1)
+            eng.slideControlSequence(1)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(150):
+                eng.computeControl(x, 1)
+                eng.getControlSeq()
+                eng.slideControlSequence(1)
+            best = min(best, (time.perf_counter() - t0) / 150)
+        eng.getTargetStateSeq()
+        eng.close()
+        period[split] = best * 1e6
+    print("Tube closed-loop period: single launch %.1f us, split %.1f us" % (period["0"], period[None]))
+    assert period[None] < period["0"] - 2.0
+
+
 def test_other_entry_points_between_calls(gpu):
     """mppi_optimize / mppi_upload_state / the model step between two calls: they are ordered behind the trajectory phase (or do
     not touch what it reads), and the device-resident inputs they see are the last call's"""
