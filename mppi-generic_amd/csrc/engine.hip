@@ -156,7 +156,7 @@ struct mppi_handle_s
    * host memory + ingest kernel as before. */
   bool bar_inbox = false;
   /* Split hand-over (round 5; Vanilla / Colored and Tube MPPI, low-latency path): the finalize pass as two launches — the control phase on
-   * the handle's stream, the re-rollout of the state trajectory on side_stream behind an event — so the re-rollout of call N
+   * the handle's stream, the re-rollout of the state trajectory on side_stream, which waits for it on a device flag — so the re-rollout of call N
    * (a lone wave, T dependent steps: 22 of a Cartpole call's 61 us period) runs beside the rollouts of call N + 1.  The
    * trajectory phase reads nothing but a carry block the control phase wrote (finalize_kernel.hpp: FinalizeArgs::phases) and
    * writes nothing but the trajectory part of io_out and its flag; two carry blocks alternate, and the control phase of call
@@ -859,7 +859,7 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     const size_t per_sys = kernels::finalizeScratchFloats(T, C);
     if (per_sys * sizeof(float) > 64 * 1024 || (force && force[0] == '1'))
       ALLOC_OR_FAIL(h->fin_scratch_d, (size_t)D * per_sys);
-    // split hand-over (mppi_handle_s::split_finalize): one-system controllers on the low-latency path
+    // split hand-over (mppi_handle_s::split_finalize): Vanilla / Colored / Tube handles on the low-latency path
     const char* split = getenv("MPPI_AMD_SPLIT_FINALIZE");
     // (not on a caller's stream: there a stream synchronisation is the caller's way to wait for everything the library launched)
     if (h->low_latency && h->own_stream && world == 1 && !cfg->force_exchange && !(split && split[0] == '0') &&
