@@ -17,33 +17,79 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(REPO, "examples", "_build")
 
 
-def _build(name):
-    """hipcc cross-compiles the user's translation unit for gfx950 (the kernels of ITS plugin types) without a GPU"""
-    os.makedirs(OUT, exist_ok=True)
-    m.load_library()
+NAMES = ("templated_cartpole", "templated_double_integrator")
+
+
+def _cmd(name, exe):
+    lib_dir = os.path.dirname(m.library_path())
+    return ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Werror",
+            "-I" + os.path.join(REPO, "include"), os.path.join(REPO, "examples", name + ".hip"), "-L" + lib_dir, "-lmppi_amd",
+            "-Wl,-rpath," + lib_dir, "-o", exe]
+
+
+def _fresh(name):
     src, exe = os.path.join(REPO, "examples", name + ".hip"), os.path.join(OUT, name)
     deps = [src, m.library_path()]
     for d, _, files in os.walk(os.path.join(REPO, "include")):
         deps += [os.path.join(d, f) for f in files]
-    if os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(p) for p in deps):
+    return os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(p) for p in deps)
+
+
+# templated_double_integrator (Vanilla + Tube + Robust controllers in one unit) is a three-minute hipcc run: when this module is
+# collected and the library is already built, the compiles start in the background and run beside the tests collected before it
+_BACKGROUND = {}
+
+
+def _start_background_builds():
+    try:
+        from mppi_generic_amd import buildlib
+        if not os.path.exists("/opt/rocm/bin/hipcc") or buildlib.needs_build():
+            return
+        os.makedirs(OUT, exist_ok=True)
+        for name in NAMES:
+            if not _fresh(name):
+                tmp = os.path.join(OUT, name + ".building")
+                log = open(tmp + ".log", "w")
+                _BACKGROUND[name] = (subprocess.Popen(_cmd(name, tmp), stdout=log, stderr=subprocess.STDOUT), tmp, log)
+    except Exception:  # noqa: BLE001 — the tests build in the foreground then
+        _BACKGROUND.clear()
+
+
+_start_background_builds()
+
+
+def _build(name):
+    """hipcc cross-compiles the user's translation unit for gfx950 (the kernels of ITS plugin types) without a GPU"""
+    os.makedirs(OUT, exist_ok=True)
+    m.load_library()
+    exe = os.path.join(OUT, name)
+    if name in _BACKGROUND:
+        proc, tmp, log = _BACKGROUND.pop(name)
+        rc = proc.wait(timeout=1200)
+        log.close()
+        assert rc == 0, open(tmp + ".log").read()[-8000:]
+        os.replace(tmp, exe)
+        os.remove(tmp + ".log")
         return exe
-    lib_dir = os.path.dirname(m.library_path())
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Werror",
-                        "-I" + os.path.join(REPO, "include"), src, "-L" + lib_dir, "-lmppi_amd", "-Wl,-rpath," + lib_dir,
-                        "-o", exe], capture_output=True, text=True, timeout=1200)
+    if _fresh(name):
+        return exe
+    r = subprocess.run(_cmd(name, exe), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     return exe
 
 
 def test_reference_shaped_callers_compile():
     """the two examples use ONLY the reference's include paths (<mppi/...>) and class spellings"""
-    for name in ("templated_cartpole", "templated_double_integrator"):
+    names = NAMES
+    for name in names:
         txt = open(os.path.join(REPO, "examples", name + ".hip")).read()
         incs = re.findall(r'#include [<"]([^>"]+)[>"]', txt)
         assert all(i.startswith("mppi/") or "/" not in i for i in incs), incs
         assert "mppi_amd" not in re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-        exe = _build(name)
-        assert os.path.exists(exe)
+    import concurrent.futures
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(names)) as pool:  # two hipcc runs of ~100 s, side by side
+        for exe in pool.map(_build, names):
+            assert os.path.exists(exe)
     blob = open(os.path.join(OUT, "templated_cartpole"), "rb").read()
     assert b"rolloutPipelineKernel" in blob and b"gfx950" in blob  # the kernels were instantiated in the user's unit
 

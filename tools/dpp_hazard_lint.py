@@ -171,6 +171,14 @@ def lint_disassembly(text, name):
     return n_dpp, hazards
 
 
+def _lint_code_object(path):
+    text = subprocess.run([LLVM + "llvm-objdump", "-d", path], check=True, capture_output=True, text=True).stdout
+    f = os.path.basename(path)
+    n, h = lint_disassembly(text, f)
+    nx, hx = lint_cross_lane(text, f)
+    return n, h, nx, hx
+
+
 def main():
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "mppi-generic_amd", "lib", "libmppi_amd.so")
     work = tempfile.mkdtemp(prefix="dpp_lint_")
@@ -179,16 +187,14 @@ def main():
         shutil.copy(lib, local)
         subprocess.run([LLVM + "llvm-objdump", "--offloading", local], check=True, stdout=subprocess.DEVNULL, cwd=work)
         total, total_x, hazards = 0, 0, []
-        for f in sorted(os.listdir(work)):
-            if "gfx950" not in f:
-                continue
-            text = subprocess.run([LLVM + "llvm-objdump", "-d", os.path.join(work, f)], check=True, capture_output=True, text=True).stdout
-            n, h = lint_disassembly(text, f)
-            total += n
-            hazards += h
-            n, h = lint_cross_lane(text, f)
-            total_x += n
-            hazards += h
+        files = [os.path.join(work, f) for f in sorted(os.listdir(work)) if "gfx950" in f]
+        # one process per code object (disassembly + the scan, which is pure Python): the library holds ~25 of them
+        import concurrent.futures
+        with concurrent.futures.ProcessPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as pool:
+            for n, h, nx, hx in pool.map(_lint_code_object, files):
+                total += n
+                total_x += nx
+                hazards += h + hx
         print("%d DPP instructions checked, %d hazard(s)" % (total, len(hazards)))
         print("%d ds_bpermute / v_readlane / v_writelane instructions checked" % total_x)
         for h in hazards[:50]:

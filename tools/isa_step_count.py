@@ -60,6 +60,11 @@ def loops_of(tu, keys):
 
 def main():
     res = {}
+    # the units' device-only compiles (tools/isa_tu.py's cache) side by side: they are what this tool's time goes to
+    import concurrent.futures
+    units = sorted({os.path.join(isa_tu.REPO, "mppi-generic_amd", "csrc", "models", k[1]) for k in KERNELS})
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(units)) as pool:
+        list(pool.map(isa_tu.disassemble, units))
     for key, tu, subs, steps, marker in KERNELS:
         cands = loops_of(tu, subs)
         if not cands:
