@@ -1069,6 +1069,10 @@ def main():
                              "ms_per_step_max": head["ms_per_step_max"],
                              "rule": "each repetition = exactly --steps iterations between barrier + synchronize; "
                                      "ms_per_step is the median repetition"},
+            # scalars the driver's consistency check can read: seconds of the median K-step repetition (= steps * ms_per_step)
+            # and of everything that was timed
+            "timed_region_s": round(elapsed, 6),
+            "timed_total_s": round(float(sum(reps)), 6),
             "finite": head["finite"],
             "roofline": roofline,
         }

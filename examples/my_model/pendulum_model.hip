@@ -48,6 +48,9 @@ using namespace MPPI_internal;
 class PendulumDynamics : public Dynamics<PendulumDynamics, PendulumParams>
 {
 public:
+  /** no __syncthreads() in the per-step methods below (mppi::lane_sync() where the reference's step has its barriers): the model
+   *  may run on the role-separated kernels — without this line PIPELINE = true is refused (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   using PARENT_CLASS = Dynamics<PendulumDynamics, PendulumParams>;
   PendulumDynamics(hipStream_t stream = nullptr) : PARENT_CLASS(stream)
   {
@@ -75,6 +78,7 @@ struct PendulumCostParams : public CostParams<1>
 class PendulumCost : public Cost<PendulumCost, PendulumCostParams, PendulumParams>
 {
 public:
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   PendulumCost(hipStream_t stream = nullptr)
   {
     bindToStream(stream);

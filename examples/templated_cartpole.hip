@@ -8,7 +8,10 @@
  *
  * Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I<repo>/include examples/templated_cartpole.hip \
  *               -L<repo>/mppi-generic_amd/lib -lmppi_amd -Wl,-rpath,<repo>/mppi-generic_amd/lib -o templated_cartpole
- * Run:    ./templated_cartpole [steps]      prints the state every 50 steps and a checksum of the last control sequence
+ * Run:    ./templated_cartpole [steps] [lanes per rollout]    prints the state every 50 steps and a checksum of the last control
+ *         sequence.  lanes per rollout = dynamics_rollout_dim_.y: 1 (default; the role-pipelined kernels, one lane per rollout) or
+ *         4 — the reference example's own dim3(64, 4, 1) (examples/cartpole_example.cu:50-51): the LDS + barrier form of the
+ *         plugin contract on the fused kernel; same trajectory costs, bit for bit
  */
 #include <mppi/instantiations/cartpole_mppi/cartpole_mppi.cuh>
 
@@ -25,6 +28,7 @@ using CartpoleMPPI = VanillaMPPIController<CartpoleDynamics, CartpoleQuadraticCo
 int main(int argc, char** argv)
 {
   const int steps = argc > 1 ? atoi(argv[1]) : 500;
+  const int lanes = argc > 2 ? atoi(argv[2]) : 1;
 
   CartpoleDynamics model(1.0f, 1.0f, 1.0f);  // cart mass, pole mass, pole length
   model.control_rngs_->x = -5;
@@ -55,8 +59,8 @@ int main(int argc, char** argv)
 
   CartpoleMPPI controller(&model, &cost, &fb_controller, &sampler, dt, max_iter, lambda, alpha);
   auto controller_params = controller.getParams();
-  controller_params.dynamics_rollout_dim_ = dim3(64, 1, 1);
-  controller_params.cost_rollout_dim_ = dim3(64, 1, 1);
+  controller_params.dynamics_rollout_dim_ = dim3(64, lanes, 1);
+  controller_params.cost_rollout_dim_ = dim3(64, lanes, 1);
   controller.setParams(controller_params);
 
   CartpoleDynamics::state_array x = CartpoleDynamics::state_array::Zero(), x_next = x, xdot = x;

@@ -185,6 +185,17 @@ typedef void* (*mppi_model_factory)(void);
 /** abi_fingerprint = mppi::engine::engineAbiFingerprint() in the caller's build (sizes of ModelBase and of the kernel argument
  *  blocks): a mismatch (header / library skew) is refused */
 mppi_status mppi_register_model(const char* name, int sampler_kind, mppi_model_factory factory, int abi_fingerprint);
+/** what MPPI_REGISTER_MODEL and the templated controllers call: the same, plus what the instantiation says about itself.
+ *  MPPI_MODEL_ROLE_SEPARATED: it carries role-separated rollout kernels (waves of a block with different jobs: a block barrier
+ *  inside a plugin's per-step method would never complete there); MPPI_MODEL_BARRIER_FREE_DECLARED: every plugin class those
+ *  kernels would run declares `static constexpr bool MPPI_BARRIER_FREE_STEP = true` (mppi_amd/plugin/parallel_utils.hpp).
+ *  ROLE_SEPARATED without BARRIER_FREE_DECLARED is refused with MPPI_ERR_INVALID_ARG — the reference's own Dynamics::step has
+ *  two block barriers (dynamics/dynamics.cu:138,140), so a model that says nothing is taken to have them and belongs on the
+ *  fused kernel (PIPELINE = false).  (mppi_create checks the model object again, whichever way it was registered.) */
+#define MPPI_MODEL_ROLE_SEPARATED 1u
+#define MPPI_MODEL_BARRIER_FREE_DECLARED 2u
+mppi_status mppi_register_model_checked(const char* name, int sampler_kind, mppi_model_factory factory, int abi_fingerprint,
+                                        unsigned flags);
 /** dlopen()s a library whose static initialisers call mppi_register_model; the library stays loaded */
 mppi_status mppi_load_plugin(const char* path);
 

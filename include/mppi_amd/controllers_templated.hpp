@@ -57,23 +57,54 @@ namespace mppi_amd
 {
 namespace templated
 {
+/**
+ * The rollout block shapes a controller type is instantiated for — (rollouts per block, lanes per rollout, systems per launch),
+ * the reference's dynamics_rollout_dim_ with z chosen by the controller kind (Tube / Robust: 2).  Default: one lane per rollout
+ * (64 or 32 rollouts per block: what the analytic in-tree models run on) and the reference's own example shape (64, 4, .)
+ * (examples/cartpole_example.cu:50-51) on the LDS + barrier form of the plugin contract.  A caller that sets another
+ * dynamics_rollout_dim_ specialises this for its types (every shape is one more set of kernels in the caller's translation
+ * unit); a dynamics_rollout_dim_ that is not in the list makes the controller THROW MPPI_ERR_LAUNCH_SHAPE naming the list — it
+ * is never replaced by another shape silently.
+ */
+template <class DYN_T, class COST_T, class SAMPLING_T>
+struct RolloutShapes
+{
+  using type = mppi::engine::Shapes<mppi::engine::Shape<64, 1, 1>, mppi::engine::Shape<64, 1, 2>, mppi::engine::Shape<32, 1, 1>,
+                                    mppi::engine::Shape<32, 1, 2>, mppi::engine::Shape<64, 4, 1>, mppi::engine::Shape<64, 4, 2>>;
+};
+
+/**
+ * May the user's plugin classes run on the ROLE-SEPARATED rollout kernels?  Only when all three say so
+ * (`static constexpr bool MPPI_BARRIER_FREE_STEP = true;`, plugin/parallel_utils.hpp) — the in-tree models do.  A model written
+ * like the reference's, with the two block barriers of Dynamics::step (dynamics/dynamics.cu:138,140) or a __syncthreads() of
+ * its own in computeDynamics, says nothing, is taken to have barriers and runs on the FUSED kernel, where every thread of the
+ * block reaches every plugin call as in the reference.  (Round 5 instantiated every user model with PIPELINE = true: a
+ * reference-style model hung the GPU.)
+ */
+template <class DYN_T, class COST_T, class SAMPLING_T>
+constexpr bool rolePipelineAllowed()
+{
+  return mppi::barrier_free_step<DYN_T>::value && mppi::barrier_free_step<COST_T>::value &&
+         mppi::barrier_free_step<SAMPLING_T>::value;
+}
+
 /** registers ModelT<DYN_T, COST_T, SAMPLING_T> once per process and returns the name it is registered under */
 template <class DYN_T, class COST_T, class SAMPLING_T>
 inline const std::string& registeredModelName()
 {
   using namespace mppi::engine;
-  // block shapes instantiated for a user's model: one lane per rollout (64 or 32 rollouts per block), one or two systems
-  // per launch (Tube / Robust MPPI) — the shapes the analytic in-tree models run on
-  using MODEL = ModelT<DYN_T, COST_T, SAMPLING_T, Shapes<Shape<64, 1, 1>, Shape<64, 1, 2>, Shape<32, 1, 1>, Shape<32, 1, 2>>,
-                       /*FIN_BY=*/1, void, Shapes<>, /*PIPELINE=*/true, /*RMPPI=*/!SAMPLING_T::COLORED>;
+  using MODEL = ModelT<DYN_T, COST_T, SAMPLING_T, typename RolloutShapes<DYN_T, COST_T, SAMPLING_T>::type,
+                       /*FIN_BY=*/1, void, Shapes<>, /*PIPELINE=*/rolePipelineAllowed<DYN_T, COST_T, SAMPLING_T>(),
+                       /*RMPPI=*/!SAMPLING_T::COLORED>;
   static const std::string name = [] {
     // the sampler type is part of the instantiation (two controllers that differ only in their Gaussian sampler class must
     // not share a registration: the parameter layouts differ)
     std::string n = std::string("tpl:") + typeid(DYN_T).name() + ":" + typeid(COST_T).name() + ":" + typeid(SAMPLING_T).name();
-    const mppi_status s = mppi_register_model(n.c_str(), SAMPLING_T::COLORED ? MPPI_SAMPLER_COLORED : MPPI_SAMPLER_GAUSSIAN,
-                                              &modelFactory<MODEL, 64, 1>, engineAbiFingerprint());
+    const mppi_status s =
+        mppi_register_model_checked(n.c_str(), SAMPLING_T::COLORED ? MPPI_SAMPLER_COLORED : MPPI_SAMPLER_GAUSSIAN,
+                                    &modelFactory<MODEL, 64, 1>, engineAbiFingerprint(), modelFlags<MODEL>());
     if (s != MPPI_OK)
-      throw Error(s, "mppi_register_model failed for " + n + " (was libmppi_amd.so built from the same headers?)");
+      throw Error(s, "mppi_register_model failed for " + n + ": " + mppi_last_error(nullptr));
     return n;
   }();
   return name;
@@ -311,16 +342,15 @@ protected:
     cfg.seed = (unsigned long long)params_.seed_;
     cfg.noise_source = MPPI_NOISE_PHILOX_FUSED;
     cfg.stream = (void*)stream_;
-    // dynamics_rollout_dim_ = (rollouts per block, lanes per rollout, .): a shape the model is not instantiated for (the
-    // reference's (64, 4, 1) for an analytic model, say) falls back to the registered default instead of failing
+    // dynamics_rollout_dim_ = (rollouts per block, lanes per rollout, .) is honoured or refused, never replaced: (0, 0, .) asks
+    // for the engine's default, anything else has to be one of RolloutShapes<...>::type (the reference's (64, 4, 1) is)
     cfg.block_x = (int)params_.dynamics_rollout_dim_.x;
     cfg.block_y = (int)params_.dynamics_rollout_dim_.y;
-    mppi_status s = mppi_create(&cfg, &h_);
-    if (s == MPPI_ERR_LAUNCH_SHAPE && (cfg.block_x || cfg.block_y))
-    {
-      cfg.block_x = cfg.block_y = 0;
-      s = mppi_create(&cfg, &h_);
-    }
+    const mppi_status s = mppi_create(&cfg, &h_);
+    if (s == MPPI_ERR_LAUNCH_SHAPE)
+      throw Error(s, std::string("mppi_create: ") + mppi_last_error(nullptr) +
+                         " — dynamics_rollout_dim_ has to be (0, 0, .) or one of mppi_amd::templated::RolloutShapes<DYN_T, COST_T, "
+                         "SAMPLING_T>::type (specialise it to instantiate the kernels for another block shape)");
     if (s != MPPI_OK)
       throw Error(s, std::string("mppi_create: ") + mppi_last_error(nullptr));
     pushControllerParams();

@@ -173,6 +173,8 @@ public:
 class ARStandardCost : public ARStandardCostImpl<ARStandardCost>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   ARStandardCost(hipStream_t stream = 0) : ARStandardCostImpl<ARStandardCost>(stream)
   {
   }

@@ -26,6 +26,8 @@ struct CartpoleQuadraticCostParams : public CostParams<1>
 class CartpoleQuadraticCost : public Cost<CartpoleQuadraticCost, CartpoleQuadraticCostParams, CartpoleDynamicsParams>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   CartpoleQuadraticCost(hipStream_t stream = 0)
   {
     bindToStream(stream);

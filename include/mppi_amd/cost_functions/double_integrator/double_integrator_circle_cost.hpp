@@ -30,6 +30,8 @@ class DoubleIntegratorCircleCost
   : public Cost<DoubleIntegratorCircleCost, DoubleIntegratorCircleCostParams, DoubleIntegratorParams>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   DoubleIntegratorCircleCost(hipStream_t stream = nullptr)
   {
     bindToStream(stream);

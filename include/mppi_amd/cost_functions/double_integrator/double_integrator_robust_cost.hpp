@@ -21,6 +21,8 @@ class DoubleIntegratorRobustCost
   : public Cost<DoubleIntegratorRobustCost, DoubleIntegratorCircleCostParams, DoubleIntegratorParams>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   DoubleIntegratorRobustCost(hipStream_t stream = nullptr)
   {
     bindToStream(stream);

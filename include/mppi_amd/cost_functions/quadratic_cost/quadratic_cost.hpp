@@ -40,6 +40,8 @@ class QuadraticCost
   : public Cost<QuadraticCost<DYN_T, SKIP_ZERO_COEFF>, QuadraticCostParams<DYN_T>, typename DYN_T::DYN_PARAMS_T>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   static constexpr float MAX_COST_VALUE = 1e16;
   QuadraticCost(hipStream_t stream = nullptr)
   {

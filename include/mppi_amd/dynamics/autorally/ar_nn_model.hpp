@@ -124,6 +124,8 @@ template <int S_DIM, int C_DIM, int K_DIM>
 class NeuralNetModelMFMA : public Dynamics<NeuralNetModelMFMA<S_DIM, C_DIM, K_DIM>, NNDynamicsParams>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   using PARENT_CLASS = Dynamics<NeuralNetModelMFMA<S_DIM, C_DIM, K_DIM>, NNDynamicsParams>;
   static const int DYNAMICS_DIM = S_DIM - K_DIM;
   static constexpr int REPLICATED_LANES = 4;

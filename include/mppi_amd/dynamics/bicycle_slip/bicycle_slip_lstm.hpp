@@ -131,6 +131,8 @@ class BicycleSlipLSTMWave;
 class BicycleSlipLSTMMFMA : public MPPI_internal::Dynamics<BicycleSlipLSTMMFMA, BicycleSlipLSTMParams>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   using PARENT_CLASS = MPPI_internal::Dynamics<BicycleSlipLSTMMFMA, BicycleSlipLSTMParams>;
   static const int DYNAMICS_DIM = 4;
   static constexpr int REPLICATED_LANES = 4;

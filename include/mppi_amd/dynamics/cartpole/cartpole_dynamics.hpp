@@ -45,6 +45,8 @@ using namespace MPPI_internal;
 class CartpoleDynamics : public Dynamics<CartpoleDynamics, CartpoleDynamicsParams>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   using PARENT_CLASS = Dynamics<CartpoleDynamics, CartpoleDynamicsParams>;
   CartpoleDynamics(float cart_mass = 1.0f, float pole_mass = 1.0f, float pole_length = 1.0f, hipStream_t stream = 0)
     : PARENT_CLASS(stream)

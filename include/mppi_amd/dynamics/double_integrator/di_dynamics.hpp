@@ -41,6 +41,8 @@ using namespace MPPI_internal;
 class DoubleIntegratorDynamics : public Dynamics<DoubleIntegratorDynamics, DoubleIntegratorParams>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   using PARENT_CLASS = Dynamics<DoubleIntegratorDynamics, DoubleIntegratorParams>;
   DoubleIntegratorDynamics(float system_noise = 1, hipStream_t stream = nullptr) : PARENT_CLASS(stream)
   {

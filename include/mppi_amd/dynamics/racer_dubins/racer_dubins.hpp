@@ -92,6 +92,8 @@ using namespace MPPI_internal;
 class RacerDubins : public Dynamics<RacerDubins, RacerDubinsParams>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   using PARENT_CLASS = Dynamics<RacerDubins, RacerDubinsParams>;
   RacerDubins(hipStream_t stream = nullptr) : PARENT_CLASS(stream)
   {

@@ -781,6 +781,8 @@ public:
 class RacerDubinsElevation : public RacerDubinsElevationImpl<RacerDubinsElevation>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   using PARAMS_T = RacerDubinsElevationParams;
   RacerDubinsElevation(hipStream_t stream = nullptr) : RacerDubinsElevationImpl<RacerDubinsElevation>(stream)
   {
@@ -807,6 +809,8 @@ public:
 class RacerDubinsElevationQuad : public RacerDubinsElevationImpl<RacerDubinsElevationQuad>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationQuad>;
   using PARAMS_T = RacerDubinsElevationParams;
   static constexpr int REPLICATED_LANES = 4;

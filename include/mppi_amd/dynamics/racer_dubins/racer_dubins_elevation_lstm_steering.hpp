@@ -235,6 +235,8 @@ public:
 class RacerDubinsElevationLSTMSteeringQuad : public RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteeringQuad>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteeringQuad>;
   using PARAMS_T = RacerDubinsElevationParams;
   static constexpr int REPLICATED_LANES = 4;

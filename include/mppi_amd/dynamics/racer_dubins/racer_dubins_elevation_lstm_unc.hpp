@@ -361,6 +361,8 @@ class RacerDubinsElevationLSTMUncertaintyQuad
   : public RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationLSTMUncertaintyQuad, RacerDubinsElevationUncertaintyParams>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   using PARAMS_T = RacerDubinsElevationUncertaintyParams;
   using QUAD = RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationLSTMUncertaintyQuad, PARAMS_T>;
   using MEAN_NET = mppi::LSTMQuadRows<12, 20, 2>;

@@ -517,6 +517,8 @@ public:
 class RacerDubinsElevationSuspensionQuad : public RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationSuspensionQuad>
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   using PARAMS_T = RacerDubinsElevationSuspensionParams;
   RacerDubinsElevationSuspensionQuad(const RacerDubinsElevationSuspension& other)
     : RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationSuspensionQuad>(other.stream_)

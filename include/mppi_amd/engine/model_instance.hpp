@@ -183,6 +183,14 @@ struct ModelBase
   {
     return false;
   }
+  /** "" when every plugin class the model's ROLE-SEPARATED kernels would run declares MPPI_BARRIER_FREE_STEP
+   *  (plugin/parallel_utils.hpp: barrier_free_step) — or when the model has no such kernels; otherwise the names the
+   *  declaration is missing from.  mppi_create refuses a model with a non-empty answer: a block barrier inside a per-step
+   *  method would hang those kernels (only the wave whose role it is calls the method). */
+  virtual std::string undeclaredBarrierFreePlugins() const
+  {
+    return std::string();
+  }
   /** rolloutPipelineKernel's STREAM_MERGE form exists: one system, Gaussian sampler drawing in the loop */
   virtual bool supportsStreamedMerge() const
   {
@@ -229,8 +237,8 @@ struct ModelBase
 /** bumped BY HAND whenever ModelBase's virtual methods are added, removed or reordered or a field of an argument struct is
  *  swapped at equal size — changes sizeof() cannot see (a stale plugin would dispatch to the wrong vtable slot).
  *  3: rows-in-HBM arguments; 4: release-flag arguments of the finalize kernels (both round 3); 5: supportsStreamedMerge (round 4);
- *  6: FinalizeArgs::phases / carry block of the split hand-over (round 5). */
-#define MPPI_ENGINE_ABI_VERSION 6
+ *  6: FinalizeArgs::phases / carry block of the split hand-over (round 5); 7: undeclaredBarrierFreePlugins (round 6). */
+#define MPPI_ENGINE_ABI_VERSION 7
 
 constexpr int engineAbiFingerprint()
 {
@@ -701,6 +709,35 @@ struct ModelT : ModelBase
   bool supportsPipeline() const override
   {
     return PIPELINE;
+  }
+  /** does the instantiation ask for role-separated kernels (the one-lane pipeline, or the replicated-lane one), and do the
+   *  classes those kernels would run say that their per-step methods hold no block barrier? */
+  static constexpr bool ROLE_SEPARATED = PIPELINE || !std::is_void<DYN_FAST_T>::value;
+  static constexpr bool fastDeclared()
+  {
+    if constexpr (std::is_void<DYN_FAST_T>::value)
+      return true;
+    else
+      return mppi::barrier_free_step<DYN_FAST_T>::value;
+  }
+  static constexpr bool BARRIER_FREE_DECLARED = (!PIPELINE || mppi::barrier_free_step<DYN_T>::value) && fastDeclared() &&
+                                                (!ROLE_SEPARATED || (mppi::barrier_free_step<COST_T>::value &&
+                                                                     mppi::barrier_free_step<SAMPLING_T>::value));
+  std::string undeclaredBarrierFreePlugins() const override
+  {
+    std::string missing;
+    if constexpr (ROLE_SEPARATED)
+    {
+      if (PIPELINE && !mppi::barrier_free_step<DYN_T>::value)
+        missing += "Dynamics ";
+      if (!fastDeclared())
+        missing += "Dynamics(replicated-lane form) ";
+      if (!mppi::barrier_free_step<COST_T>::value)
+        missing += "Cost ";
+      if (!mppi::barrier_free_step<SAMPLING_T>::value)
+        missing += "SamplingDistribution ";
+    }
+    return missing;
   }
   bool supportsStreamedMerge() const override
   {

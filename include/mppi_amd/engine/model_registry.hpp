@@ -10,6 +10,11 @@
  *     using MyModel = mppi::engine::ModelT<MyDynamics, MyCost, MySampler, Shapes<Shape<64, 1, 1>>, 1, void, Shapes<>, true>;
  *     MPPI_REGISTER_MODEL("my_model", MPPI_SAMPLER_GAUSSIAN, MyModel, 64, 1)
  *
+ * (the trailing `true` = PIPELINE asks for the role-separated rollout kernels: MyDynamics and MyCost then have to DECLARE that
+ * their per-step device methods hold no block barrier — `static constexpr bool MPPI_BARRIER_FREE_STEP = true;`,
+ * plugin/parallel_utils.hpp — or the registration is refused: a barrier there would hang the GPU.  A model written like the
+ * reference's, __syncthreads() and all, registers with PIPELINE = false and runs on the fused kernel.)
+ *
  * compiled with   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -I<include> my_model.hip -o libmy_model.so
  * and either linked next to libmppi_amd.so or loaded at run time with mppi_load_plugin("libmy_model.so").
  * The kernels of the model live in the user's library; libmppi_amd.so only ever calls them through ModelBase.
@@ -33,11 +38,19 @@ void* modelFactory()
   return m;
 }
 
+/** mppi_register_model_checked's flags for an instantiation (mppi_amd.h: MPPI_MODEL_ROLE_SEPARATED, MPPI_MODEL_BARRIER_FREE_DECLARED) */
+template <class MODEL_T>
+constexpr unsigned modelFlags()
+{
+  return (MODEL_T::ROLE_SEPARATED ? MPPI_MODEL_ROLE_SEPARATED : 0u) |
+         (MODEL_T::BARRIER_FREE_DECLARED ? MPPI_MODEL_BARRIER_FREE_DECLARED : 0u);
+}
+
 struct ModelRegistrar
 {
-  ModelRegistrar(const char* name, int sampler_kind, mppi_model_factory factory)
+  ModelRegistrar(const char* name, int sampler_kind, mppi_model_factory factory, unsigned flags)
   {
-    (void)mppi_register_model(name, sampler_kind, factory, engineAbiFingerprint());
+    (void)mppi_register_model_checked(name, sampler_kind, factory, engineAbiFingerprint(), flags);
   }
 };
 }  // namespace engine
@@ -48,6 +61,7 @@ struct ModelRegistrar
 /** one line per instantiation, at namespace scope of a .hip file */
 #define MPPI_REGISTER_MODEL(name, sampler_kind, MODEL_T, default_bx, default_by)                                         \
   static ::mppi::engine::ModelRegistrar MPPI_REGISTRY_CAT(mppi_model_registrar_, __LINE__)(                             \
-      name, sampler_kind, &::mppi::engine::modelFactory<MODEL_T, default_bx, default_by>);
+      name, sampler_kind, &::mppi::engine::modelFactory<MODEL_T, default_bx, default_by>,                               \
+      ::mppi::engine::modelFlags<MODEL_T>());
 
 #endif

@@ -13,6 +13,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace mppi
 {
 namespace p1  // one index and one step out of the block shape
@@ -220,6 +222,33 @@ __device__ inline void lane_sync()
     __syncthreads();
   }
 }
+
+/**
+ * May the device methods of plugin class T run on the ROLE-SEPARATED rollout kernels (engine/rollout_pipeline_kernel.hpp,
+ * rmppi_pipeline_kernel.hpp)?  There the waves of a block have different jobs — sampler waves, a dynamics wave (or four), cost
+ * waves — and only the wave whose job it is calls a plugin's per-step methods: a block barrier (__syncthreads()) inside
+ * Dynamics::step / computeDynamics, Cost::computeRunningCost or a sampler's per-step methods would wait for waves that never
+ * arrive, i.e. hang the GPU.  The reference's own Dynamics::step has two such barriers (dynamics/dynamics.cu:138,140) and a
+ * good part of its models call __syncthreads() themselves, so the engine ASSUMES BARRIERS unless the class says otherwise:
+ *
+ *     static constexpr bool MPPI_BARRIER_FREE_STEP = true;   // in the plugin class
+ *
+ * declares that no device method the rollout kernels call per step contains a block barrier (mppi::lane_sync() does not
+ * count: it is a barrier only when blockDim.y > 1, and the role-separated kernels give every rollout one lane).  A class without the
+ * declaration is a class with barriers: it runs on the fused kernels (engine/rollout_kernel.hpp), where every thread of the
+ * block reaches every plugin call, as in the reference.  The declaration is deliberately NOT made in the CRTP bases
+ * (plugin/dynamics.hpp, plugin/cost.hpp) — a user's class would inherit it; the in-tree models make it themselves.
+ * Consumers: controllers_templated.hpp chooses PIPELINE from it; ModelT refuses PIPELINE = true / a replicated-lane form
+ * without it, at registration (mppi_register_model_checked) and again at mppi_create.
+ */
+template <class T, class = void>
+struct barrier_free_step : std::false_type
+{
+};
+template <class T>
+struct barrier_free_step<T, std::void_t<decltype(T::MPPI_BARRIER_FREE_STEP)>> : std::integral_constant<bool, T::MPPI_BARRIER_FREE_STEP>
+{
+};
 }  // namespace mppi
 
 #endif

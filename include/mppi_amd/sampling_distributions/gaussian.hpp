@@ -76,6 +76,8 @@ template <class DYN_PARAMS_T>
 class GaussianDistribution : public Managed
 {
 public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
   static const int CONTROL_DIM = E_INDEX(DYN_PARAMS_T::ControlIndex, NUM_CONTROLS);
   typedef GaussianParamsImpl<CONTROL_DIM, 2> SAMPLING_PARAMS_T;
   typedef GaussianDistribution<DYN_PARAMS_T> SAMPLING_T;

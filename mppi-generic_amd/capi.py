@@ -71,6 +71,7 @@ SIGNATURES = {
     "mppi_list_models": (C.c_char_p, []),
     "mppi_source_hash": (C.c_char_p, []),
     "mppi_register_model": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int]),
+    "mppi_register_model_checked": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_uint]),
     "mppi_load_plugin": (C.c_int, [C.c_char_p]),
     "mppi_create": (C.c_int, [C.POINTER(MppiConfig), C.POINTER(H)]),
     "mppi_destroy": (None, [H]),

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -155,6 +156,7 @@ struct mppi_handle_s
    * and the finalize kernel their initial state and history, from the inbox (HBM, not PCIe).  MPPI_AMD_BAR_INBOX=0: mapped
    * host memory + ingest kernel as before. */
   bool bar_inbox = false;
+  int combine_sharded_max_blocks = -1;  // co-residency bound of combineShardedKernel on this device (-1: not asked yet)
   /* Split hand-over (round 5; Vanilla / Colored and Tube MPPI, low-latency path): the finalize pass as two launches — the control phase on
    * the handle's stream, the re-rollout of the state trajectory on side_stream, which waits for it on a device flag — so the re-rollout of call N
    * (a lone wave, T dependent steps: 22 of a Cartpole call's 61 us period) runs beside the rollouts of call N + 1.  The
@@ -403,7 +405,8 @@ mppi_status mppi_register_model(const char* name, int sampler_kind, mppi_model_f
     ModelRegistry& rr = registry();
     std::lock_guard<std::mutex> lock(rr.mu);
     rr.refused++;
-    rr.last_refusal = std::string("model '") + name + "' was built against other mppi_amd/engine headers than this library";
+    rr.last_refusal = std::string("model '") + name + "' was built against other mppi_amd/engine headers than this library — "
+                      "rebuild the plugin";
   }
   if (model_base_size != engineAbiFingerprint())
     return fail(nullptr, MPPI_ERR_INVALID_ARG,
@@ -420,6 +423,27 @@ mppi_status mppi_register_model(const char* name, int sampler_kind, mppi_model_f
                                          "with a different factory");
   r.factories[{ name, sampler_kind }] = factory;
   return MPPI_OK;
+}
+
+mppi_status mppi_register_model_checked(const char* name, int sampler_kind, mppi_model_factory factory, int model_base_size,
+                                        unsigned flags)
+{
+  if ((flags & MPPI_MODEL_ROLE_SEPARATED) && !(flags & MPPI_MODEL_BARRIER_FREE_DECLARED))
+  {
+    const std::string what =
+        std::string("model '") + (name ? name : "?") +
+        "' asks for the role-separated rollout kernels (PIPELINE = true or a replicated-lane dynamics form) but its plugin "
+        "classes do not all declare MPPI_BARRIER_FREE_STEP (mppi_amd/plugin/parallel_utils.hpp): a block barrier inside a "
+        "per-step method would hang those kernels — declare it, or register with PIPELINE = false";
+    {
+      ModelRegistry& rr = registry();
+      std::lock_guard<std::mutex> lock(rr.mu);
+      rr.refused++;
+      rr.last_refusal = what;
+    }
+    return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_register_model: " + what);
+  }
+  return mppi_register_model(name, sampler_kind, factory, model_base_size);
 }
 
 mppi_status mppi_load_plugin(const char* path)
@@ -440,7 +464,7 @@ mppi_status mppi_load_plugin(const char* path)
   {
     std::lock_guard<std::mutex> lock(registry().mu);
     if (registry().refused != refused_before)
-      return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_load_plugin: " + registry().last_refusal + " — rebuild the plugin");
+      return fail(nullptr, MPPI_ERR_INVALID_ARG, "mppi_load_plugin: " + registry().last_refusal);
   }
   return MPPI_OK;  // its static initialisers have registered the models; the library stays loaded
 }
@@ -550,6 +574,14 @@ mppi_status mppi_create(const mppi_config* cfg, mppi_handle* out)
     return fail(nullptr, MPPI_ERR_UNSUPPORTED, "mppi_create: model '" + h->model_name + "' has no colored-noise instantiation");
   if (!h->model)
     return fail(nullptr, MPPI_ERR_UNKNOWN_MODEL, "mppi_create: model '" + h->model_name + "' is not registered; have:\n" + mppi_list_models());
+  {  // whichever way the model got into the table: role-separated kernels only for plugins that declare barrier-free steps
+    const std::string undeclared = h->model->undeclaredBarrierFreePlugins();
+    if (!undeclared.empty())
+      return fail(nullptr, MPPI_ERR_INVALID_ARG,
+                  "mppi_create: model '" + h->model_name + "' carries role-separated rollout kernels but these plugin classes do "
+                  "not declare MPPI_BARRIER_FREE_STEP (mppi_amd/plugin/parallel_utils.hpp): " + undeclared +
+                  "— a block barrier inside a per-step method would hang the GPU there; declare it or register with PIPELINE = false");
+  }
   mppi_handle hp = h.get();
   switch (cfg->controller)
   {
@@ -1812,8 +1844,23 @@ static mppi_status launchCombineSharded(mppi_handle h)
   RoctxRange range("mppi:merge_sharded");
   const unsigned seq = ++h->xseq;
   const kernels::PostTargets t = p2pTargets(h, seq);
-  if (h->D * kernels::combineGridY(h->TC) > kernels::COMBINE_SHARDED_MAX_BLOCKS)
-  {  // the fused form's waves wait for the launch's own last ticket: a grid that cannot be resident at once takes two launches
+  // The fused form's waves wait for the launch's own last ticket: a grid that cannot be resident at once takes two launches.
+  // The bound is THIS device's: its CU count x the occupancy the runtime reports for the kernel, halved — rollout kernels of
+  // other handles / streams may hold slots — and never above the constant the kernel was reviewed for (round-5 advice: the
+  // constant alone assumed 256 free CUs).
+  if (h->combine_sharded_max_blocks < 0)
+  {
+    int per_cu = 0, cus = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernels::combineShardedKernel, kernels::MERGE_THREADS, 0) == hipSuccess &&
+        hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    (void)hipGetLastError();
+    const long bound = (long)per_cu * cus / 2;
+    h->combine_sharded_max_blocks = (int)std::min<long>(kernels::COMBINE_SHARDED_MAX_BLOCKS, bound > 0 ? bound : 0);
+  }
+  if (h->D * kernels::combineGridY(h->TC) > h->combine_sharded_max_blocks)
+  {
     MPPI_TRY(launchCombine(h, h->partials_d, h->num_blocks, 0, h->send_d, h->K_local, false, nullptr, 0, &t));
     return iterationMergeP2P(h);
   }
@@ -2065,6 +2112,29 @@ static void parseStats(mppi_handle h, const float* st)
   }
 }
 
+/** Host writes to the inbox (io_in_h) are complete, in order, before anything that makes the device read it.  With the BAR inbox
+ *  the block is device memory behind the PCIe BAR, mapped write-combined: stores sit in the core's WC buffers until a fence (or
+ *  an uncached write that happens to flush them) — every path that hands the inbox to a kernel goes through here, not only the
+ *  `direct` Vanilla one (round-5 advice: the ingest launches relied on the launch path flushing the buffers).  Pinned host
+ *  memory needs no fence beyond the release the doorbell write already is; one is issued anyway on non-x86 builds. */
+static inline void publishInbox(mppi_handle h)
+{
+#if defined(__x86_64__)
+  if (h->bar_inbox)
+    __builtin_ia32_sfence();
+#else
+  (void)h;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+#endif
+}
+
+/** inbox -> in_block_d (one tiny kernel on the handle's stream), behind publishInbox() */
+static inline void launchIngest(mppi_handle h)
+{
+  publishInbox(h);
+  hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+}
+
 /** spins on a flag the finalize kernel raises in host memory; falls back to a stream synchronisation when the flag does not
  *  show within the limit (a failed launch, a wedged device): the caller then sees the HIP error instead of a hang */
 static mppi_status waitHostFlag(mppi_handle h, int idx, unsigned seq)
@@ -2217,9 +2287,7 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     } source_guard{ h };
     if (direct)
     {
-#if defined(__x86_64__)
-      __builtin_ia32_sfence();  // the write-combined stores are out before the doorbell of the first launch
-#endif
+      publishInbox(h);  // the write-combined stores are out before the doorbell of the first launch
       h->x0_src_d = h->io_in_dev + (h->x0_d - h->in_block_d);
       h->mean_src_d = h->io_in_dev + (h->mean_d - h->in_block_d);
       a.x0_d = h->x0_src_d;
@@ -2227,7 +2295,7 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     }
     else
     {
-      hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+      launchIngest(h);
       HIP_TRY(h, hipGetLastError());
     }
     stamp(1);
@@ -2259,6 +2327,19 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
       a.carry_mean_off = (int)(h->mean_d - h->in_block_d);
       a.carry_ready_d = reinterpret_cast<unsigned*>(h->carry_d + 2 * h->in_floats) + 2 * p;
     }
+    auto ingest_ranges = [&](const float* src) -> mppi_status {
+      hipLaunchKernelGGL(kernels::ingestRangesKernel, dim3(1), dim3(256), 0, h->stream, src, h->in_block_d,
+                         (int)(h->mean_d - h->in_block_d), (int)(h->history_d - h->in_block_d),
+                         (int)(h->in_floats - (size_t)(h->history_d - h->in_block_d)));
+      HIP_TRY(h, hipGetLastError());
+      return MPPI_OK;
+    };
+    // Single-launch hand-over with the BAR inbox (MPPI_AMD_SPLIT_FINALIZE=0): the device-resident copy of x0 / history is taken
+    // from the INBOX, so it has to be taken before the finalize kernel raises flag 1 — the next call waits for nothing else
+    // before it rewrites the inbox (round-5 advice: behind the finalize kernel the copy could read a half-rewritten inbox).  It
+    // touches neither what the finalize kernel reads (inbox, mean_d) nor what it writes.
+    if (direct && !h->split_finalize)
+      MPPI_TRY(ingest_ranges(h->io_in_dev));
     const mppi_status st = h->model->launchFinalize(1, a, h->stream, err);
     if (st != MPPI_OK)
       return fail(h, st, err);
@@ -2279,13 +2360,11 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
       h->side_pending = true;
       h->carry_seq[a.seq & 1u] = a.seq;
     }
-    if (direct)
-    {  // behind the finalize kernel, off the caller's path: the device-resident x0 / history later mppi_optimize / operator calls
-       // read.  Split hand-over: from the carry block — the host may be rewriting the inbox for its next call by now
-      hipLaunchKernelGGL(kernels::ingestRangesKernel, dim3(1), dim3(256), 0, h->stream, carry ? carry : h->io_in_dev, h->in_block_d,
-                         (int)(h->mean_d - h->in_block_d), (int)(h->history_d - h->in_block_d),
-                         (int)(h->in_floats - (size_t)(h->history_d - h->in_block_d)));
-      HIP_TRY(h, hipGetLastError());
+    if (direct && h->split_finalize)
+    {  // behind the control phase, off the caller's path: the device-resident x0 / history later mppi_optimize / operator calls
+       // read — from the CARRY block (the host may be rewriting the inbox for its next call by now; the carry block of this parity
+       // is not rewritten before the call after next, which first waits for this call's flag 1)
+      MPPI_TRY(ingest_ranges(carry));
     }
     h->out_pin_fresh = false;
     h->results_in_io = true;
@@ -2362,7 +2441,7 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
       std::copy(h->control_h.begin(), h->control_h.end(), mean);
       std::copy(h->nominal_control_h.begin(), h->nominal_control_h.end(), mean + h->TC);
       std::copy(h->history_h.begin(), h->history_h.end(), in + (h->history_d - h->in_block_d));
-      hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+      launchIngest(h);
       HIP_TRY(h, hipGetLastError());
       return MPPI_OK;
     };
@@ -2455,8 +2534,12 @@ static mppi_status computeControlTube(mppi_handle h, const float* x0, int stride
     if (h->cfg.num_iters > 0)
     {
       const float* st1 = h->io_out_h + (h->stats_d - h->out_block_d) + kernels::STATS_STRIDE;
-      h->stats_h.nominal_state_used = st1[7] != 0.0f ? 1 : 0;
-      if (h->stats_h.nominal_state_used == 0)  // the nominal system restarted from the actual state (row 0 of its trajectory)
+      // tubeSelectKernel: bit 0 = the LAST pass kept the nominal system (nominalStateUsed), bit 1 = the nominal system's initial
+      // state on the device is the actual one — after a take-over in ANY pass of this call (the reference's
+      // nominal_state_trajectory_ persists across the passes, tube_mppi_controller.cu:268-277), not only in the last
+      const int sel = (int)st1[7];
+      h->stats_h.nominal_state_used = sel & 1;
+      if (sel & 2)
         std::copy(x0, x0 + S, h->tube_x_h.begin());
     }
     if (!allFinite(h->control_h) || !allFinite(h->nominal_control_h))
@@ -2589,7 +2672,7 @@ static mppi_status rmNominalStateTrajectory(mppi_handle h)
     float* in = h->io_in_h;
     std::copy(h->rm_nominal_state.begin(), h->rm_nominal_state.begin() + h->S, in + (h->x0_d - h->in_block_d));
     std::copy(h->nominal_control_h.begin(), h->nominal_control_h.end(), in + (h->mean_d - h->in_block_d));
-    hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+    launchIngest(h);
     HIP_TRY(h, hipGetLastError());
     kernels::FinalizeArgs a{};
     a.scratch_d = h->fin_scratch_d;
@@ -2662,7 +2745,7 @@ static mppi_status rmNominalStateAndStride(mppi_handle h, const float* state, in
     std::copy(h->rm_cand_states.begin(), h->rm_cand_states.end(), h->cand_io_h);
     std::memcpy(h->cand_io_h + (size_t)nc * S, h->rm_cand_strides.data(), sizeof(int) * nc);
     std::copy(h->nominal_control_h.begin(), h->nominal_control_h.end(), h->io_in_h + (h->mean_d - h->in_block_d));
-    hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+    launchIngest(h);
     HIP_TRY(h, hipGetLastError());
     cand_costs_dev = h->cand_io_dev + (size_t)nc * (S + 1);
   }
@@ -2814,7 +2897,7 @@ static mppi_status computeControlRobust(mppi_handle h, const float* x0_real, int
     float* hist = in + (h->history_d - h->in_block_d);
     std::copy(h->nominal_history_h.begin(), h->nominal_history_h.end(), hist);
     std::copy(h->history_h.begin(), h->history_h.end(), hist + 2 * h->C);
-    hipLaunchKernelGGL(kernels::ingestKernel, dim3(1), dim3(256), 0, h->stream, h->io_in_dev, h->in_block_d, (int)h->in_floats);
+    launchIngest(h);
     HIP_TRY(h, hipGetLastError());
     for (int it = 0; it < h->cfg.num_iters; it++)
     {

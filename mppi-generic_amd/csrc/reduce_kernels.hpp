@@ -372,7 +372,9 @@ __global__ void __launch_bounds__(MERGE_THREADS) combineKernel(const CombineArgs
  * D x combineGridY(T*C) blocks of one wave without LDS — 101 at Cartpole's T*C = 100 — and the host refuses the fused form
  * above COMBINE_SHARDED_MAX_BLOCKS (engine.hip: launchCombineSharded falls back to the two-launch form there).
  */
-constexpr int COMBINE_SHARDED_MAX_BLOCKS = 2048;  ///< 256 CUs x 8 one-wave blocks: resident at once with a wide margin
+/** upper limit of the co-resident grid; the host lowers it to half of (CUs x blocks per CU the runtime reports) of the device at
+ *  hand (engine.hip: launchCombineSharded) */
+constexpr int COMBINE_SHARDED_MAX_BLOCKS = 2048;
 __global__ void __launch_bounds__(MERGE_THREADS) combineShardedKernel(const CombineArgs loc, const CombineArgs glob)
 {
   const int z = blockIdx.x;
@@ -507,8 +509,14 @@ __global__ void __launch_bounds__(256) ingestRangesKernel(const float* __restric
  * Tube-MPPI's choice between the two systems after an optimisation pass, on the device
  * (controllers/Tube-MPPI/tube_mppi_controller.cu:264-277): when the actual system's baseline is below the nominal one's plus
  * the threshold, the nominal system restarts from the actual one — its control sequence and its initial state are overwritten
- * with the actual system's; stats[1][7] records which it was (0: the actual state was taken over, 1: the nominal state was kept,
- * the reference's nominalStateUsed).  The reference (and rounds 2-4 here) made this choice on the host, between two device
+ * with the actual system's.  stats[1][7] carries two bits for the host: bit 0 = this pass's choice (0: the actual state was
+ * taken over, 1: the nominal state was kept, the reference's nominalStateUsed), bit 1 = the nominal system's initial state now
+ * EQUALS the actual one, bit for bit.  Bit 1 is what the host's copy of the nominal state follows (nominal_state_trajectory_
+ * persists across the passes of one call, :268-277): a take-over in pass 0 followed by a pass that keeps the nominal system
+ * leaves bit 0 = 1 with x0_d[S..2S) = x0, and the combine of every pass clears the slot, so the fact is re-derived from the
+ * states themselves instead of remembered (x0_d[0..S) does not change within a call; when the two states happen to be equal
+ * without any take-over, copying one over the other changes nothing).
+ * The reference (and rounds 2-4 here) made this choice on the host, between two device
  * passes, which cost mppi_compute_control a second hand-over and a wait for trajectories nobody needed.
  */
 __global__ void __launch_bounds__(256) tubeSelectKernel(float* __restrict__ stats_d, float* __restrict__ mean_d,
@@ -516,6 +524,7 @@ __global__ void __launch_bounds__(256) tubeSelectKernel(float* __restrict__ stat
                                                         const float nominal_threshold)
 {
   const bool take_actual = stats_d[0] < stats_d[STATS_STRIDE] + nominal_threshold;  // block-uniform
+  int same = 1;
   if (take_actual)
   {
     for (int i = (int)threadIdx.x; i < TC; i += 256)
@@ -523,8 +532,14 @@ __global__ void __launch_bounds__(256) tubeSelectKernel(float* __restrict__ stat
     for (int i = (int)threadIdx.x; i < S; i += 256)
       x0_d[S + i] = x0_d[i];
   }
+  else
+  {
+    for (int i = (int)threadIdx.x; i < S; i += 256)
+      same &= __float_as_uint(x0_d[S + i]) == __float_as_uint(x0_d[i]) ? 1 : 0;
+  }
+  same = __syncthreads_and(same);
   if (threadIdx.x == 0)
-    stats_d[STATS_STRIDE + 7] = take_actual ? 0.0f : 1.0f;
+    stats_d[STATS_STRIDE + 7] = (take_actual ? 0.0f : 1.0f) + (same ? 2.0f : 0.0f);
 }
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -73,3 +73,60 @@ def test_effect_on_one_iteration_autorally_and_lstm():
         print(cfg["model"], "u* L-inf between the orders", du, "costs rel", dc)
         assert du <= 1e-6, (cfg["model"], du)
         assert dc <= 1e-5, (cfg["model"], dc)
+
+
+def _kat_theta():
+    return np.ones(6 * 32 + 32 + 32 * 32 + 32 + 32 * 4 + 4, np.float32)
+
+
+def test_reference_bias_and_weight_edit_known_answers_pin_the_blob_layout():
+    """tests/nn_helpers/fnn_helper_test.cu:403-446, ALL THREE stages with the reference's literal inputs (input = 0):
+    all-ones -> 33; output biases theta[1408..1411] = 2, 3, 4, 5 -> 34, 35, 36, 37; first weight of each output row
+    theta[1280], [1312], [1344], [1376] = 2 -> 35, 36, 37, 38.  The second and third stages pin the LAYOUT of the blob
+    ([W row-major out x in][b] per layer: output weights start at 1280 with a row stride of 32, biases at 1408) on a vector
+    the reference holds — an oracle that transposed W3 or put the biases first would miss them (by >= 1.0, not by an ulp).
+    The bar is the reference's own EXPECT_FLOAT_EQ (4 ulp): the hidden values are det::tanh(25.4) = 1 - 2^-24, not the 1.0f of
+    CUDA's tanhf, so a sum that is not all ones may land an ulp below the integer; where the reference's order does hit the
+    integer exactly (the first two stages) that is asserted too."""
+    layers, x = [6, 32, 32, 4], np.zeros(6, np.float32)
+    for split, tol in ((False, 0), (True, 4)):
+        theta = _kat_theta()
+        out = po.fnn_forward(layers, theta, x, split_output_sum=split)
+        assert ulp_diff(out, np.full(4, 33.0, np.float32)).max() <= tol, (split, out)
+        theta[1408:1412] = [2.0, 3.0, 4.0, 5.0]
+        out = po.fnn_forward(layers, theta, x, split_output_sum=split)
+        assert ulp_diff(out, np.array([34, 35, 36, 37], np.float32)).max() <= tol, (split, out)
+        theta[[1280, 1312, 1344, 1376]] = 2.0
+        out = po.fnn_forward(layers, theta, x, split_output_sum=split)
+        assert ulp_diff(out, np.array([35, 36, 37, 38], np.float32)).max() <= 4, (split, out)
+    # the edits address what the docstring says they address: a weight edit one column further scales hidden unit 1 instead
+    # (tanh(33) rounds to 1.0f, so the answer is the same) while an edit one ROW off (index 1280 + 4) moves output 0 again, not 1
+    theta = _kat_theta()
+    theta[1284] = 3.0
+    out = po.fnn_forward(layers, theta, x, split_output_sum=False)
+    assert ulp_diff(out, np.array([35, 33, 33, 33], np.float32)).max() <= 4, out
+
+
+def test_ar_dynamics_all_ones_with_the_reference_inputs_and_the_edits():
+    """tests/dynamics/ar_dynamics_nn_test.cu:445-481: s = 0, u = (1, -1), all-ones network -> xdot = (0, 0, 0, 33, 33, 33, 33),
+    state and control untouched; then the same bias / weight edits as the helper's test through the MODEL (they must land in
+    xdot[3..6] in the same order: output i of the network is state derivative 3 + i, ar_nn_model.cu:160-166)."""
+    cfg = autorally_cfg(K=64, T=4)
+    for split, tol in ((False, 0), (True, 4)):
+        o = make_oracle(cfg)
+        o.set_split_output_sum(split)
+        theta = _kat_theta()
+        o.set_blob("dynamics_weights", theta)
+        s, u = np.zeros(7, np.float32), np.array([1.0, -1.0], np.float32)
+        xd = o.state_deriv(s, u)
+        assert np.array_equal(xd[:3], np.zeros(3, np.float32))
+        assert ulp_diff(xd[3:], np.full(4, 33.0, np.float32)).max() <= tol, (split, xd)
+        assert np.array_equal(s, np.zeros(7, np.float32)) and np.array_equal(u, np.array([1.0, -1.0], np.float32))
+        theta[1408:1412] = [2.0, 3.0, 4.0, 5.0]
+        o.set_blob("dynamics_weights", theta)
+        xd = o.state_deriv(s, u)
+        assert ulp_diff(xd[3:], np.array([34, 35, 36, 37], np.float32)).max() <= tol, (split, xd)
+        theta[[1280, 1312, 1344, 1376]] = 2.0
+        o.set_blob("dynamics_weights", theta)
+        xd = o.state_deriv(s, u)
+        assert ulp_diff(xd[3:], np.array([35, 36, 37, 38], np.float32)).max() <= 4, (split, xd)

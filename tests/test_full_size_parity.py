@@ -278,3 +278,117 @@ def test_suspension_two_systems_64x4x2_16384x100_vs_oracle(gpu):
     assert np.abs(eng.getNominalControlSeq() - orc.nominal_control()).max() <= U_TOL
     eng.close()
 
+
+
+# ------------------------------------------------------------------ Robust MPPI at the sizes bench.py times it ---------------
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _robust_pair(cfg, thr, reference_order, nc=9, ns=32, **kw):
+    eng = m.RobustMPPIController(cfg["model"], cfg["K"], cfg["T"], cfg["dt"], cfg["lambda_"], cfg["alpha"], cfg["num_iters"],
+                                 seed=42, **kw)
+    if cfg["dyn"] is not None:
+        eng.setDynamicsParams(cfg["dyn"])
+    eng.setCostParams(cfg["cost"])
+    for name, blob in cfg.get("blobs", {}).items():
+        eng.setModelBlob(name, blob)
+    if cfg["ranges"] is not None:
+        eng.setControlRanges(cfg["ranges"])
+    eng.setSamplingParams(cfg["std_dev"], cfg["control_cost_coeff"])
+    eng.setRMPPIParams(thr, nc, ns)
+    if reference_order:
+        eng.setReductionMode(m.MPPI_REDUCTION_REFERENCE_ORDER)
+    orc = make_oracle(cfg)
+    return eng, orc, po.RobustOracle(orc, thr, nc, ns)
+
+
+def _robust_two_cycles(cfg, thr, reference_order, x_real, **kw):
+    """Two control cycles of RobustMPPIController on injected noise, engine and oracle side by side (reference:
+    controllers/R-MPPI/robust_mppi_controller.cu:635-755 computeControl, :508-633 updateImportanceSamplingControl;
+    core/rmppi_kernels.cu:231-356 initEvalKernel, :666-866 rolloutRMPPIKernel).
+      cycle 0   the nominal state is not set yet: no candidates; setFeedbackGains; computeControl from identical inputs —
+                the TRAJECTORY COSTS OF BOTH SYSTEMS are the oracle's bits, baselines exact, both u* <= 1e-5
+      cycle 1   real state moved off the nominal one: 9 x 32 candidate rollouts of time-shifted samples (init-eval kernel),
+                best index, nominal state, then computeControl again.
+    reference_order: the last stage in the reference's own summation order — then cycle 0's u* is the oracle's bits and
+    EVERYTHING of cycle 1 is too (candidate free energies, nominal state, both control sequences, statistics).  Default
+    reduction: cycle 1 starts from a u* that differs at the 1e-7 level, so its quantities are held to fp32 accuracy and the
+    discrete choice (best candidate) to equality."""
+    eng, orc, rob = _robust_pair(cfg, thr, reference_order, **kw)
+    S, C, T, K = eng.STATE_DIM, eng.CONTROL_DIM, cfg["T"], cfg["K"]
+    g = np.random.default_rng(5).uniform(-0.3, 0.3, (T, S, C)).astype(np.float32)  # bench.py's gains
+    x = cfg["x0"].copy()
+    for cycle in range(2):
+        eps = host_noise(2, K, T, C, seed=900 + cycle)
+        eng.injectNoise(eps[1:] if cycle == 0 else eps)
+        eng.updateImportanceSamplingControl(x, 1)
+        rob.update_importance_sampling(x, 1, eps[0])
+        ns_g, best_g, stride_g, fe_g = eng.getRMPPIState()
+        ns_o, best_o, stride_o, fe_o = rob.state()
+        assert best_g == best_o and stride_g == stride_o, cycle
+        if cycle == 1:
+            assert np.isfinite(fe_g).all()
+            if reference_order:
+                assert np.array_equal(_bits(fe_g), _bits(fe_o)), (fe_g, fe_o)
+                assert np.array_equal(_bits(ns_g), _bits(ns_o))
+            else:
+                np.testing.assert_allclose(fe_g, fe_o, rtol=1e-5)
+                np.testing.assert_allclose(ns_g, ns_o, rtol=1e-5, atol=1e-6)
+        eng.setFeedbackGains(g)
+        rob.set_gains(g)
+        eng.computeControl(x, 1)
+        rob.compute_control(x, 1, eps[1:])
+        costs_g, costs_o = eng.getSampledCostSeq(), orc.costs()
+        assert costs_g.shape == costs_o.shape == (2, K)
+        assert np.isfinite(costs_g).all()
+        st, so = eng.getStats(), orc.stats()
+        if cycle == 0 or reference_order:
+            dc = int(ulp_diff(costs_g, costs_o).max())
+            assert dc == 0, "cycle %d: trajectory costs of the two systems differ by up to %d ulp" % (cycle, dc)
+            assert st.nominal_sys.baseline == so["baseline"][0] and st.real_sys.baseline == so["baseline"][1]
+            for got, z in ((st.nominal_sys.normalizer, 0), (st.real_sys.normalizer, 1)):
+                eta = float(so["normalizer"][z])
+                assert abs(got - eta) <= (0.0 if reference_order else ETA_RTOL * eta), (cycle, z, got, eta)
+        else:
+            np.testing.assert_allclose(costs_g, costs_o, rtol=1e-5)
+        assert np.abs(costs_o[0] - costs_o[1]).max() > 1e-3 or cycle == 0  # the two systems really differ once x moved
+        u_g, un_g = eng.getControlSeq(), eng.getNominalControlSeq()
+        du, dun = float(np.abs(u_g - orc.control()).max()), float(np.abs(un_g - orc.nominal_control()).max())
+        assert du <= U_TOL and dun <= U_TOL, (cycle, du, dun)
+        assert np.abs(eng.getTargetStateSeq() - orc.nominal_state_traj()).max() <= X_TOL
+        if reference_order:
+            assert np.array_equal(_bits(u_g), _bits(orc.control())), cycle
+            assert np.array_equal(_bits(un_g), _bits(orc.nominal_control())), cycle
+            assert np.array_equal(_bits(eng.getTargetStateSeq()), _bits(orc.nominal_state_traj())), cycle
+        x = x_real.copy()
+    eng.close()
+
+
+@pytest.mark.parametrize("reference_order", [False, True], ids=["default-reduction", "reference-order"])
+def test_robust_autorally_16384x150_vs_oracle(gpu, reference_order):
+    """The kernel bench.py's `robust_autorally_nn` leg times — rolloutRMPPIPipelineKernel<NeuralNetModelMFMA<7,2,3>, ARStandardCost,
+    DeviceDDP, Gaussian>, 960-thread blocks, chain-masked MFMA rows, 256 blocks = one per CU — AT THE SIZE IT IS TIMED
+    (K = 16384, T = 150, lambda = 1, threshold 500, the bench's gains), held to oracle_rmppi.hpp.  Round 5 checked this
+    instantiation up to K = 4096 only."""
+    cfg = autorally_cfg(K=16384, T=150, lambda_=1.0)
+    cfg["D"] = 2
+    cfg["control_cost_coeff"] = [0.2, 0.1]
+    x_real = cfg["x0"] + np.array([0.15, -0.1, 0.05, 0.02, 0.1, 0.02, 0.0], np.float32)
+    _robust_two_cycles(cfg, 500.0, reference_order, x_real)
+
+
+@pytest.mark.parametrize("variant", ["pipeline", "fused"])
+def test_robust_complete_racer_4096x100_vs_oracle(gpu, variant):
+    """Robust MPPI on the COMPLETE RACER model (RacerDubinsElevationLSTMUncertaintyQuad: steering LSTM + mean and uncertainty
+    networks, covariance propagation, elevation / normals maps): the instantiation with the most spilled registers of the whole
+    library (round 5's code object: 217-222 spilled VGPRs, 405-438 spilled SGPRs, 672-688 B of scratch per lane), at K = 4096,
+    T = 100 — 64 blocks of 64 rollouts x 2 systems, past the K ~ 1000 the round-5 tests stopped at.  Both kernel structures."""
+    from test_racer_dubins_lstm_unc import uncertainty_cfg
+    cfg = uncertainty_cfg(K=4096, T=100, D=2)
+    cfg["control_cost_coeff"] = [0.2, 0.1]
+    dx = np.zeros_like(cfg["x0"])
+    dx[:7] = [0.3, -0.2, 0.1, 0.05, 0.02, 0.01, 0.0]
+    kv = m.MPPI_KERNEL_PIPELINE if variant == "pipeline" else m.MPPI_KERNEL_FUSED
+    _robust_two_cycles(cfg, 2000.0, True, cfg["x0"] + dx, kernel_variant=kv)
+    _robust_two_cycles(cfg, 2000.0, False, cfg["x0"] + dx, kernel_variant=kv)

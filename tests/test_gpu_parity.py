@@ -244,6 +244,52 @@ def test_tube_double_integrator_parity(gpu):
         x = x + np.array([0.05, -0.03, 0.2, -0.1], np.float32) * (i + 1)
 
 
+def _tube_sticky_scenario(cfg, calls=8):
+    """the oracle's closed loop with independent per-system noise and a zero threshold; returns per call (x, eps) and whether the
+    call was of the kind the advisor found: the nominal system restarted from the actual state in an EARLIER pass of the call
+    and was kept by the last one (nominal_state_used = 1 although the nominal trajectory starts at x)"""
+    orc = make_oracle(cfg)
+    orc.set_independent_noise(True)
+    orc.set_controller_params(nominal_threshold=0.0)
+    x = cfg["x0"].copy()
+    out = []
+    for i in range(calls):
+        eps = np.stack([host_noise(cfg["num_iters"], cfg["K"], cfg["T"], 2, seed=100 + 2 * i + d) for d in range(2)], axis=1)
+        orc.tube_compute_control(x, 1, eps)
+        kept_after_takeover = orc.stats()["nominal_state_used"] == 1 and np.array_equal(orc.nominal_state_traj()[0], x)
+        out.append((x.copy(), eps, kept_after_takeover, orc.control().copy(), orc.nominal_control().copy(),
+                    orc.state_traj().copy(), orc.nominal_state_traj().copy(), orc.stats()["nominal_state_used"]))
+        orc.tube_slide(1)
+        x = x + np.array([0.05, -0.03, 0.2, -0.1], np.float32) * (1 + i % 3)
+    return out
+
+
+@pytest.mark.parametrize("low_latency", [True, False], ids=["flags", "copies"])
+def test_tube_take_over_is_sticky_within_a_call(gpu, low_latency, monkeypatch):
+    """num_iters = 2, independent noise per system, threshold 0, slide between the calls: when pass 0 restarts the nominal system
+    from the actual state and pass 1 keeps it, the nominal state the NEXT call and the slide start from is the actual one
+    (tube_mppi_controller.cu:268-277: nominal_state_trajectory_ persists across the passes of a call).  Round 5's flag
+    hand-over looked at the last pass's choice only and kept the pre-call nominal state on the host."""
+    if not low_latency:
+        monkeypatch.setenv("MPPI_AMD_NO_SPIN", "1")
+    cfg = di_cfg(K=256, T=30, tube=True, num_iters=2)
+    rec = _tube_sticky_scenario(cfg)
+    assert any(r[2] for r in rec[:-1])
+    eng = make_engine(cfg)
+    eng.setIndependentNoise(True)
+    eng.setNominalThreshold(0.0)
+    for x, eps, _, u, un, xs, xn, used in rec:
+        eng.injectNoise(eps)
+        eng.computeControl(x, 1)
+        assert eng.getStats().nominal_state_used == used
+        assert np.abs(eng.getControlSeq() - u).max() <= U_TOL
+        assert np.abs(eng.getNominalControlSeq() - un).max() <= U_TOL
+        assert np.abs(eng.getTargetStateSeq() - xs).max() <= 1e-4
+        assert np.abs(eng.getNominalStateSeq() - xn).max() <= 1e-4
+        eng.slideControlSequence(1)
+    eng.close()
+
+
 def test_tube_costs_identical_when_states_identical(gpu):
     """reference: tests/mppi_core/rollout_kernel_tests.cu:181-198 — same x0 for both systems => identical costs"""
     cfg = di_cfg(K=512, T=40, tube=True)

@@ -191,3 +191,13 @@ def test_controller_loop_consistency():
     u = np.clip(u, -5, 5)
     assert np.array_equal(o.control(), u)
     assert np.array_equal(o.state_traj(), o2.state_trajectory(cfg["x0"], po.smooth(mean[0], np.zeros((2, 1), np.float32))))
+
+
+def test_tube_sticky_scenario_occurs_in_the_oracle():
+    """the seeds of test_gpu_parity.py::test_tube_take_over_is_sticky_within_a_call do produce the case it is there for: a call
+    whose pass 0 restarts the nominal system from the actual state and whose pass 1 keeps it — and not only as the last call
+    (the stale host state the advisor found in round 5 shows in the call AFTER it)"""
+    from common import di_cfg
+    from test_gpu_parity import _tube_sticky_scenario
+    kinds = [r[2] for r in _tube_sticky_scenario(di_cfg(K=256, T=30, tube=True, num_iters=2))]
+    assert any(kinds[:-1]), kinds

@@ -33,7 +33,7 @@ PLUGIN_REF_STYLE = os.path.join(OUT_DIR, "libpendulum_model_reference_style.so")
 
 
 def build_plugin(src=SRC, out=PLUGIN):
-    newest = os.path.getmtime(src)
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(REPO, "examples", "my_model", "pendulum_reference_style.cuh")))
     for d, _, files in os.walk(os.path.join(REPO, "include")):
         for f in files:
             newest = max(newest, os.path.getmtime(os.path.join(d, f)))
@@ -69,6 +69,55 @@ def test_register_model_argument_checks(plugin):
     assert plugin.mppi_register_model(b"x", 0, fn, 12345) == 1  # header / library skew: the ABI fingerprint differs
     assert b"different mppi_amd/engine/model_instance.hpp" in plugin.mppi_last_error(None)
     assert plugin.mppi_load_plugin(b"/nonexistent/libnothing.so") == 1
+
+
+def test_barrier_bearing_model_forced_onto_the_pipeline_is_refused_at_registration(plugin):
+    """tests/probes/pendulum_forced_pipeline.hip: the reference-style pendulum — a step() with the reference's two
+    __syncthreads() (dynamics/dynamics.cu:138,140), no MPPI_BARRIER_FREE_STEP declaration — registered with PIPELINE = true.
+    Launched, its dynamics wave would wait at a barrier the sampler and cost waves never reach (a GPU hang, no status).  The
+    registration is refused instead: mppi_load_plugin fails with MPPI_ERR_INVALID_ARG and says why, the model never enters the
+    table, and mppi_create of its name is an unknown-model error.  Runs without a GPU (nothing is launched)."""
+    src = os.path.join(REPO, "tests", "probes", "pendulum_forced_pipeline.hip")
+    out = build_plugin(src, os.path.join(OUT_DIR, "libpendulum_forced_pipeline.so"))
+    rc = plugin.mppi_load_plugin(out.encode())
+    assert rc == 1, rc  # MPPI_ERR_INVALID_ARG
+    msg = plugin.mppi_last_error(None).decode()
+    assert "MPPI_BARRIER_FREE_STEP" in msg and "user_pendulum_forced_pipeline" in msg, msg
+    assert "user_pendulum_forced_pipeline" not in plugin.mppi_list_models().decode().split("\n")
+    # the C entry itself: ROLE_SEPARATED without BARRIER_FREE_DECLARED is refused, with it or without ROLE_SEPARATED it is not
+    fn = C.cast(plugin.mppi_device_count, C.c_void_p)
+    assert plugin.mppi_register_model_checked(b"probe_forced", 0, fn, 0, 1) == 1
+    assert b"MPPI_BARRIER_FREE_STEP" in plugin.mppi_last_error(None)
+    assert plugin.mppi_register_model_checked(b"probe_forced", 0, fn, 12345, 3) == 1  # passes the flag check, fails the fingerprint
+    assert b"different mppi_amd/engine/model_instance.hpp" in plugin.mppi_last_error(None)
+
+
+def test_in_tree_models_declare_barrier_free_steps_and_reference_style_ones_do_not():
+    """the trait the engine decides on (plugin/parallel_utils.hpp: barrier_free_step): compiled as static_asserts — host only"""
+    probe = os.path.join(OUT_DIR, "barrier_trait_probe.hip")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(probe, "w") as f:
+        f.write("""#include <mppi/dynamics/cartpole/cartpole_dynamics.cuh>
+#include <mppi/cost_functions/cartpole/cartpole_quadratic_cost.cuh>
+#include <mppi/dynamics/double_integrator/di_dynamics.cuh>
+#include <mppi/cost_functions/double_integrator/double_integrator_circle_cost.cuh>
+#include <mppi/controllers/MPPI/mppi_controller.cuh>
+#include "my_model/pendulum_reference_style.cuh"
+using G = mppi::sampling_distributions::GaussianDistribution<CartpoleDynamicsParams>;
+static_assert(mppi::barrier_free_step<CartpoleDynamics>::value && mppi::barrier_free_step<CartpoleQuadraticCost>::value, "");
+static_assert(mppi::barrier_free_step<DoubleIntegratorDynamics>::value && mppi::barrier_free_step<DoubleIntegratorCircleCost>::value, "");
+static_assert(mppi::barrier_free_step<G>::value, "");
+static_assert(!mppi::barrier_free_step<RefPendulumDynamics>::value && !mppi::barrier_free_step<RefPendulumCost>::value,
+              "a class that says nothing is taken to have barriers: the CRTP bases must not declare it for it");
+using RG = mppi::sampling_distributions::GaussianDistribution<RefPendulumParams>;
+static_assert(mppi_amd::templated::rolePipelineAllowed<CartpoleDynamics, CartpoleQuadraticCost, G>(), "");
+static_assert(!mppi_amd::templated::rolePipelineAllowed<RefPendulumDynamics, RefPendulumCost, RG>(), "");
+static_assert(!mppi_amd::templated::rolePipelineAllowed<CartpoleDynamics, RefPendulumCost, G>(), "one undeclared plugin is enough");
+int main() { return 0; }
+""")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(REPO, "include"),
+                        "-I" + os.path.join(REPO, "examples"), probe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
 
 
 def _numpy_rollout_costs(v, x0, dt, p, c):
@@ -149,8 +198,10 @@ def test_reference_style_model_source_is_what_integration_md_says(plugin_referen
     """INTEGRATION.md §1 as an executable statement: a model written with the reference's include paths, its own step() with
     __syncthreads(), threadIdx.y-strided loops and the platform's sinf / cosf builds ALONE against include/ — the only edit
     against a CUDA source is cudaStream_t -> hipStream_t"""
-    src = open(SRC_REF_STYLE).read()
+    # (the classes live in pendulum_reference_style.cuh since round 6: the templated example includes them too)
+    src = open(os.path.join(os.path.dirname(SRC_REF_STYLE), "pendulum_reference_style.cuh")).read()
     code = src[src.index("#include"):]  # below the header comment
+    assert "MPPI_BARRIER_FREE_STEP" not in code and "mppi_amd" not in code  # no engine-specific line in the model's classes
     assert "<mppi/dynamics/dynamics.cuh>" in code and "<mppi/cost_functions/cost.cuh>" in code
     assert "__syncthreads()" in code and "sinf(" in code and "cosf(" in code and "threadIdx.y" in code and "blockDim.y" in code
     assert "mppi::det::" not in code and "lane_sync" not in code and "cuda" not in code.replace("cudaStream_t stream = nullptr", "")

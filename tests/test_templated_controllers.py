@@ -17,19 +17,20 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(REPO, "examples", "_build")
 
 
-NAMES = ("templated_cartpole", "templated_double_integrator")
+NAMES = ("templated_cartpole", "templated_double_integrator", "templated_pendulum_reference_style")
 
 
 def _cmd(name, exe):
     lib_dir = os.path.dirname(m.library_path())
     return ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Werror",
-            "-I" + os.path.join(REPO, "include"), os.path.join(REPO, "examples", name + ".hip"), "-L" + lib_dir, "-lmppi_amd",
+            "-I" + os.path.join(REPO, "include"), "-I" + os.path.join(REPO, "examples"),
+            os.path.join(REPO, "examples", name + ".hip"), "-L" + lib_dir, "-lmppi_amd",
             "-Wl,-rpath," + lib_dir, "-o", exe]
 
 
 def _fresh(name):
     src, exe = os.path.join(REPO, "examples", name + ".hip"), os.path.join(OUT, name)
-    deps = [src, m.library_path()]
+    deps = [src, m.library_path(), os.path.join(REPO, "examples", "my_model", "pendulum_reference_style.cuh")]
     for d, _, files in os.walk(os.path.join(REPO, "include")):
         deps += [os.path.join(d, f) for f in files]
     return os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(p) for p in deps)
@@ -84,14 +85,21 @@ def test_reference_shaped_callers_compile():
     for name in names:
         txt = open(os.path.join(REPO, "examples", name + ".hip")).read()
         incs = re.findall(r'#include [<"]([^>"]+)[>"]', txt)
-        assert all(i.startswith("mppi/") or "/" not in i for i in incs), incs
-        assert "mppi_amd" not in re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        assert all(i.startswith("mppi/") or i.startswith("my_model/") or "/" not in i for i in incs), incs
+        code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        assert "mppi_amd" not in code.replace("mppi_amd::Error", "")  # (the one engine name: the exception type a refusal throws)
     import concurrent.futures
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(names)) as pool:  # two hipcc runs of ~100 s, side by side
         for exe in pool.map(_build, names):
             assert os.path.exists(exe)
     blob = open(os.path.join(OUT, "templated_cartpole"), "rb").read()
     assert b"rolloutPipelineKernel" in blob and b"gfx950" in blob  # the kernels were instantiated in the user's unit
+    # the reference-style model (block barriers inside step(), no MPPI_BARRIER_FREE_STEP): NO role-pipelined kernel is even
+    # instantiated for it — the templated classes put it on the fused kernel, in the reference's own (64, 4, .) shape too
+    blob = open(os.path.join(OUT, "templated_pendulum_reference_style"), "rb").read()
+    assert b"rolloutPipelineKernel" not in blob and b"rolloutRMPPIPipelineKernel" not in blob
+    assert b"rolloutKernelI19RefPendulumDynamics15RefPendulumCost" in blob
+    assert re.search(rb"rolloutKernelI19RefPendulumDynamics15RefPendulumCost[A-Za-z0-9_]*?Li64ELi4ELi1E", blob)
 
 
 def test_forwarding_tree_points_at_existing_headers():
@@ -129,6 +137,13 @@ def test_templated_cartpole_equals_the_name_keyed_controller(gpu):
     eng.close()
     assert abs(float(mt.group(1)) - float(x[2])) <= 2e-4, (mt.group(1), x[2])
     assert abs(float(mt.group(2)) - chk) <= 1e-3 * max(1.0, abs(chk)), (mt.group(2), chk)
+    # the reference example's own block shape, dim3(64, 4, 1) (examples/cartpole_example.cu:50-51), is HONOURED (round 5 fell
+    # back to the default shape silently): four lanes per rollout on the fused kernel, the same closed loop
+    r4 = subprocess.run([exe, str(steps), "4"], capture_output=True, text=True, timeout=300)
+    assert r4.returncode == 0, r4.stdout[-2000:] + r4.stderr[-2000:]
+    m4 = re.search(r"pole angle (-?[\d.]+) rad, checksum (-?[\d.]+)", r4.stdout)
+    assert m4 and abs(float(m4.group(1)) - float(mt.group(1))) <= 2e-4 and \
+        abs(float(m4.group(2)) - float(mt.group(2))) <= 1e-3 * max(1.0, abs(chk)), (m4.groups(), mt.groups())
 
 
 @pytest.mark.gpu
@@ -142,3 +157,33 @@ def test_templated_double_integrator_runs_all_four_controllers(gpu):
         radius = float(re.search(r"radius ([\d.]+)", l).group(1))
         assert 1.6 < radius < 2.4, l  # the car stays on (or next to) the circular track of radius 2
         assert np.isfinite(float(re.search(r"checksum (-?[\d.]+)", l).group(1)))
+
+
+@pytest.mark.gpu
+def test_reference_style_model_with_block_barriers_finishes_through_the_templated_controllers(gpu):
+    """A model whose step() is the reference's own — computeStateDeriv / __syncthreads() / updateState / __syncthreads() /
+    stateToOutput (dynamics/dynamics.cu:130-142) — through VanillaMPPIController<...> and TubeMPPIController<...>: round 5
+    instantiated every user model for the role-pipelined kernels, where that barrier never completes (a silent GPU hang).  Now
+    the classes pick the fused kernel for plugins that do not declare MPPI_BARRIER_FREE_STEP: the run FINISHES (bounded by the
+    timeout), with the reference example's block shape (64, 4, 1) (examples/cartpole_example.cu:50-51) and with (64, 1, 1), and
+    the two shapes steer the pendulum the same way; a shape the classes are not instantiated for is refused with
+    MPPI_ERR_LAUNCH_SHAPE — not silently replaced."""
+    exe = _build("templated_pendulum_reference_style")
+    out = {}
+    for lanes in (4, 1):
+        r = subprocess.run([exe, "80", str(lanes)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        got = {}
+        for l in r.stdout.splitlines():
+            mt = re.match(r"(Vanilla|Tube) MPPI lanes %d: 80 control steps, angle (-?[\d.]+) rad, velocity (-?[\d.]+) rad/s, "
+                          r"baseline (-?[\d.]+), checksum (-?[\d.]+)" % lanes, l)
+            if mt:
+                got[mt.group(1)] = [float(x) for x in mt.groups()[1:]]
+        assert set(got) == {"Vanilla", "Tube"}, r.stdout
+        out[lanes] = got
+    for kind in ("Vanilla", "Tube"):
+        a, b = np.array(out[4][kind]), np.array(out[1][kind])
+        assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-3 * max(1.0, np.abs(b).max()), (kind, a, b)
+        assert abs(a[0]) > 0.05  # the controller did swing the pendulum
+    r = subprocess.run([exe, "3", "8"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "refused with status 5" in r.stdout and "RolloutShapes" in r.stdout, r.stdout + r.stderr
