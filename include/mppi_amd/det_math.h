@@ -445,7 +445,7 @@ MPPI_HD static inline void tanh2(const float xa, const float xb, float* ra, floa
  * Q polynomials alternately) before the next step.  Same operations per element as tanh() — the results are bit-identical —
  * but no two consecutive instructions depend on each other.  On gfx950 a packed-fp32 result may not be read by the very
  * next instruction: the compiler fills that wait state with an `s_nop 0`, and a wave that is alone on its SIMD pays an
- * issue slot for it (engine.hip's issue probe: 3.4 ns per dependent v_fmac + s_nop pair against 1.7 ns per independent
+ * issue slot for it (engine_operators.hip's issue probe: 3.4 ns per dependent v_fmac + s_nop pair against 1.7 ns per independent
  * v_fmac).  Evaluated pair after pair, the Newton-Raphson tail of every tanh2() is such a chain: 82 s_nop per AutoRally
  * step.  (Round 2 tried this form and saw no gain — the cost waves' relay chain was as long as the dynamics waves then and
  * hid it; see rollout_pipeline_kernel.hpp.)

@@ -32,6 +32,7 @@
 
 #include "rmppi_kernels.hpp"
 #include "rollout_pipeline_kernel.hpp"
+#include "kernarg_view.hpp"
 
 namespace mppi
 {
@@ -327,6 +328,12 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
     const float* my_smp = smp_ring + (size_t)thread_idz * rings.sample_steps * C * 64;
     const bool last_state_only = fb_controller->lastStateOnly();
     auto dyn_step = [&](float* xc, float* xn, int t, const float* u_in) {
+#if MPPI_KERNARG_RELOAD
+      // the read-only members of the dynamics object, for THIS step: from the kernel's argument block inside the loop, not held
+      // in (spilled) SGPRs across it (kernarg_view.hpp) — five plugin objects' worth of kernel arguments compete for a wave's
+      // ~100 SGPRs here
+      refreshStepInvariants(dynamics, KernargLayout<DYN_T, COST_T, FB_T>::template offset<0>());
+#endif
 #pragma unroll
       for (int i = 0; i < C; i++)
       {

@@ -35,6 +35,7 @@
 #include <type_traits>
 #include "rollout_kernel.hpp"
 #include "merge_wave.hpp"
+#include "kernarg_view.hpp"
 
 namespace mppi
 {
@@ -511,6 +512,9 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
     /* ------------------------------------------------ dynamics wave ----------------------------------------------- */
     // the four samples of a trip are fetched up front (their LDS latency overlaps the first step's arithmetic)
     auto dyn_step = [&](float* xc, float* xn, int t, const float* u_in) {
+#if MPPI_KERNARG_RELOAD
+      refreshStepInvariants(dynamics, 0);  // see rolloutPipelineRepKernel / kernarg_view.hpp
+#endif
 #pragma unroll
       for (int i = 0; i < C; i++)
         u[i] = u_in[i];
@@ -943,6 +947,11 @@ __global__ void MPPI_PIPE_REP_BOUNDS(64 * (replicated_lanes<DYN_T>::value + PIPE
     /* ------------------------------------------------ dynamics waves ---------------------------------------------- */
     lds_counter_t my_prog = counters + 4 + wave;
     auto dyn_step = [&](float* xc, float* xn, int t, const float* u_in) {
+#if MPPI_KERNARG_RELOAD
+      // the read-only members of the dynamics object, for THIS step: from the kernel's argument block inside the loop
+      // (kernarg_view.hpp; plugin/dynamics.hpp: refreshStepInvariants), not held in — spilled — SGPRs across it
+      refreshStepInvariants(dynamics, 0);
+#endif
 #pragma unroll
       for (int i = 0; i < C; i++)
         u[i] = u_in[i];

@@ -5,7 +5,7 @@ hipcc cross-compiles without a GPU.  Flags that matter:
   -ffp-contract=off       the only fused multiply-adds are the explicit det::fma() calls, so device results match the
                           CPU oracle bit for bit (include/mppi_amd/det_math.h)
 
-One object per translation unit (csrc/engine.hip + csrc/models/*.hip), compiled in parallel and cached under
+One object per translation unit (csrc/engine_*.hip + csrc/models/*.hip), compiled in parallel and cached under
 csrc/build/ with the compiler's own dependency files (-MD), then linked.  The library carries the digest of the
 sources it was built from (mppi_source_hash()); build() rebuilds whenever the tree's digest differs from the
 library's, so "the shipped .so matches the sources" is checked, not assumed.
@@ -56,7 +56,7 @@ def unit_flags(tu):
 
 
 def translation_units():
-    tus = [os.path.join(CSRC, "engine.hip")]
+    tus = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith("engine_") and f.endswith(".hip"))
     mdir = os.path.join(CSRC, "models")
     tus += sorted(os.path.join(mdir, f) for f in os.listdir(mdir) if f.endswith(".hip"))
     return tus
@@ -176,7 +176,7 @@ def build_variant(tag, extra_flags, only=None, verbose=False):
 
 
 def build(force=False, verbose=False, jobs=None):
-    """Compile csrc/engine.hip + csrc/models/*.hip -> lib/libmppi_amd.so.  Returns the library path."""
+    """Compile csrc/engine_*.hip + csrc/models/*.hip -> lib/libmppi_amd.so.  Returns the library path."""
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)

@@ -56,7 +56,7 @@ struct ExactWeightsArgs
  * Pass 1 (all waves): rho.  Pass 2, tile by tile: all waves compute the tile's weights (-> HBM, and as double / float /
  * squared float -> LDS); then waves 0, 1, 2 each add the tile to their running sum IN INDEX ORDER.
  */
-__global__ void __launch_bounds__(COMBINE_THREADS) exactWeightsKernel(const ExactWeightsArgs a)
+static __global__ void __launch_bounds__(COMBINE_THREADS) exactWeightsKernel(const ExactWeightsArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char exact_smem_raw[];
   double* wd_s = reinterpret_cast<double*>(exact_smem_raw);              // [EXACT_TILE + EXACT_PAD]
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(COMBINE_THREADS)
 
 /** rolloutWeightReductionAndSaveControl (core/mppi_common.cu:1138-1160): thread 0's serial sum over the cells.
  *  grid = (ceil(T C / 64), D), block = 64: lane = column. */
-__global__ void __launch_bounds__(64)
+static __global__ void __launch_bounds__(64)
     exactReductionFinalKernel(const float* __restrict__ inter_d, int TC, int cells, float* __restrict__ mean_out_d)
 {
   const int z = blockIdx.y;

@@ -296,7 +296,7 @@ __device__ inline void combineWave(const CombineArgs& a, const int z, const int 
   COMBINE_T(6);
 }
 
-__global__ void __launch_bounds__(MERGE_THREADS) combineKernel(const CombineArgs a)
+static __global__ void __launch_bounds__(MERGE_THREADS) combineKernel(const CombineArgs a)
 {
   const int z = blockIdx.x;
   const int tid = threadIdx.x;
@@ -370,12 +370,12 @@ __global__ void __launch_bounds__(MERGE_THREADS) combineKernel(const CombineArgs
  * ticket raises: every wave therefore waits until all one-wave blocks of this launch have taken their tickets, i.e. the grid
  * must be CO-RESIDENT (a block that cannot start while the resident ones spin would run them into the 2 s limit).  The grid is
  * D x combineGridY(T*C) blocks of one wave without LDS — 101 at Cartpole's T*C = 100 — and the host refuses the fused form
- * above COMBINE_SHARDED_MAX_BLOCKS (engine.hip: launchCombineSharded falls back to the two-launch form there).
+ * above COMBINE_SHARDED_MAX_BLOCKS (engine_iteration.hip: launchCombineSharded falls back to the two-launch form there).
  */
 /** upper limit of the co-resident grid; the host lowers it to half of (CUs x blocks per CU the runtime reports) of the device at
- *  hand (engine.hip: launchCombineSharded) */
+ *  hand (engine_iteration.hip: launchCombineSharded) */
 constexpr int COMBINE_SHARDED_MAX_BLOCKS = 2048;
-__global__ void __launch_bounds__(MERGE_THREADS) combineShardedKernel(const CombineArgs loc, const CombineArgs glob)
+static __global__ void __launch_bounds__(MERGE_THREADS) combineShardedKernel(const CombineArgs loc, const CombineArgs glob)
 {
   const int z = blockIdx.x;
   const int tid = threadIdx.x;
@@ -433,7 +433,7 @@ struct AuxTargets
   int world;
   unsigned seq;
 };
-__global__ void __launch_bounds__(256) postAuxKernel(const float* __restrict__ src, const int offset, const int count, const AuxTargets t)
+static __global__ void __launch_bounds__(256) postAuxKernel(const float* __restrict__ src, const int offset, const int count, const AuxTargets t)
 {
   for (int p = 0; p < t.world; p++)
     for (int i = (int)threadIdx.x; i < count; i += 256)
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) postAuxKernel(const float* __restrict__ s
   }
 }
 /** dst[0..n) <- the assembled array; a peer that never posts: dst is filled with NaN (the host reports MPPI_ERR_COMM) */
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
     gatherAuxKernel(const float* __restrict__ aux, const unsigned* __restrict__ flags, const int world, const unsigned seq,
                     const unsigned long long wait_limit_ticks, const int n, float* __restrict__ dst)
 {
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(256)
 
 /** every store of the kernels in front of it on the stream is out: publish `seq` where the host spins (device-mapped host
  *  memory, system scope) — the hand-over of a small kernel whose signature has no flag argument (model step) */
-__global__ void __launch_bounds__(64) raiseFlagKernel(unsigned* flag, unsigned seq)
+static __global__ void __launch_bounds__(64) raiseFlagKernel(unsigned* flag, unsigned seq)
 {
   if (threadIdx.x == 0)
   {
@@ -489,14 +489,14 @@ __global__ void __launch_bounds__(64) raiseFlagKernel(unsigned* flag, unsigned s
  * handle's input block) are read straight from host memory mapped into the device and written to the device-resident
  * block the rollout kernels read — one launch boundary (~1.5 us) instead of a copy command (~3 us, tools/ubench/handover.hip).
  */
-__global__ void __launch_bounds__(256) ingestKernel(const float* __restrict__ host_mapped, float* __restrict__ dst, int n)
+static __global__ void __launch_bounds__(256) ingestKernel(const float* __restrict__ host_mapped, float* __restrict__ dst, int n)
 {
   for (int i = (int)threadIdx.x; i < n; i += 256)
     dst[i] = host_mapped[i];
 }
 /** two ranges of the same block in one launch: [0, n0) and [off1, off1 + n1) — the device-resident copies of x0 and the control
  *  history behind a computeControl whose kernels read the inbox themselves (the nominal control between them holds u* by then) */
-__global__ void __launch_bounds__(256) ingestRangesKernel(const float* __restrict__ src, float* __restrict__ dst, int n0, int off1,
+static __global__ void __launch_bounds__(256) ingestRangesKernel(const float* __restrict__ src, float* __restrict__ dst, int n0, int off1,
                                                           int n1)
 {
   for (int i = (int)threadIdx.x; i < n0; i += 256)
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256) ingestRangesKernel(const float* __restric
  * The reference (and rounds 2-4 here) made this choice on the host, between two device
  * passes, which cost mppi_compute_control a second hand-over and a wait for trajectories nobody needed.
  */
-__global__ void __launch_bounds__(256) tubeSelectKernel(float* __restrict__ stats_d, float* __restrict__ mean_d,
+static __global__ void __launch_bounds__(256) tubeSelectKernel(float* __restrict__ stats_d, float* __restrict__ mean_d,
                                                         float* __restrict__ x0_d, const int TC, const int S,
                                                         const float nominal_threshold)
 {
@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(256) tubeSelectKernel(float* __restrict__ stat
  * and for callers that hold their own cost / sample buffers.
  * ------------------------------------------------------------------------------------------------------------------ */
 /** in-place w_i = exp(-lambda_inv * (S_i - baseline)); reference: normExpKernel mppi_common.cu:686-701, :958-966 */
-__global__ void normExpKernel(int num_rollouts, float* trajectory_costs_d, float lambda_inv, float baseline)
+static __global__ void normExpKernel(int num_rollouts, float* trajectory_costs_d, float lambda_inv, float baseline)
 {
   const int stride = blockDim.x * gridDim.x;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_rollouts; i += stride)
@@ -563,7 +563,7 @@ __global__ void normExpKernel(int num_rollouts, float* trajectory_costs_d, float
  * two-pass device reduction the reference sketches in fullGPUcomputeWeights (mppi_common.cu:1031-1053) but never uses;
  * also applies the exp transform in place.
  */
-__global__ void __launch_bounds__(COMBINE_THREADS)
+static __global__ void __launch_bounds__(COMBINE_THREADS)
     computeWeightsKernel(int num_rollouts, float* trajectory_costs_d, float lambda_inv, float* baseline_and_normalizer)
 {
   __shared__ double red_d[COMBINE_THREADS / 64];
@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(COMBINE_THREADS)
  * rows of system 0, tail[0] = the rank's own minimum; nullptr: un-sharded) — and `record_tail_out_d` receives {rho, eta_local,
  * sum w^2 local, 0}: the tail of the record of the SECOND exchange, whose merge then needs no rescaling (all rho equal).
  */
-__global__ void __launch_bounds__(COMBINE_THREADS)
+static __global__ void __launch_bounds__(COMBINE_THREADS)
     tsallisWeightsKernel(int num_rollouts, const float* __restrict__ costs_d, float gamma, float r, float lambda,
                          float* __restrict__ weights_d, float* __restrict__ stats_out_d,
                          const float* __restrict__ peer_records_d = nullptr, int world = 0, int peer_stride = 0, int TC = 0,
@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(COMBINE_THREADS)
 
 /** u*[j] = sum_k w_k v[k][j] / eta over samples in HBM (v: [K][T*C]); block = 64 columns x 16 waves, wave w takes rollouts
  *  w, w + 16, ... in ascending order and the sixteen partials are added in a fixed order (reproducible run to run) */
-__global__ void __launch_bounds__(COMBINE_THREADS)
+static __global__ void __launch_bounds__(COMBINE_THREADS)
     tsallisMeanKernel(const float* __restrict__ weights_d, const float* __restrict__ v_d, const float* __restrict__ stats_d,
                       int TC, int num_rollouts, float* __restrict__ mean_out_d, int normalize = 1)
 {
@@ -720,7 +720,7 @@ __global__ void __launch_bounds__(COMBINE_THREADS)
  * rows fully coalesced (a row is contiguous), accumulates T*C columns in registers per thread, and merges chunks with
  * one float atomicAdd per (block, column) into a zeroed output.
  */
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
     weightedReductionKernel(const float* __restrict__ exp_costs_d, const float* __restrict__ v_d,
                             float* __restrict__ new_u_d, const float normalizer, const int TC, const int num_rollouts,
                             const int rollouts_per_block)

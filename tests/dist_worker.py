@@ -52,7 +52,7 @@ def main():
             assert abs(rho - costs[d].min()) == 0.0
             assert np.abs(u.reshape(T, C) - u_ref[d]).max() <= 2e-6, (rank, d, np.abs(u.reshape(T, C) - u_ref[d]).max())
             assert abs(eta - orc.stats()["normalizer"][d]) <= 1e-5 * eta
-    # ---- Tsallis weights on K-sharded ranks (engine.hip: iterationShardedTsallis): the weights are not shift-invariant, so the
+    # ---- Tsallis weights on K-sharded ranks (engine_iteration.hip: iterationShardedTsallis): the weights are not shift-invariant, so the
     # ranks exchange their MINIMA first and only then {sum w v | rho, sum w, sum w^2} under the common baseline — the merge of
     # the second exchange then rescales by exp(0) = 1.  Same two hops here over gloo, against the oracle's un-sharded iteration.
     cfg = cartpole_cfg(K=512, T=30, soft=True)
@@ -83,7 +83,7 @@ def main():
     assert rho_m == orc.stats()["baseline"][0]
     assert np.abs(u.reshape(T, 1) - u_ref).max() <= 2e-6, np.abs(u.reshape(T, 1) - u_ref).max()
     assert abs(eta - orc.stats()["normalizer"][0]) <= 1e-5 * eta
-    # ---- Robust MPPI's candidate evaluation sharded BY CANDIDATE (engine.hip: rmNominalStateAndStride): rank r owns the
+    # ---- Robust MPPI's candidate evaluation sharded BY CANDIDATE (engine_controllers.hip: rmNominalStateAndStride): rank r owns the
     # candidates [r * ceil(nc / world), ...) and writes their costs at their position of the nc x ns array on every rank; the
     # slices must tile the array exactly once, for any world size, including ranks that own nothing
     for nc, ns in ((9, 32), (3, 64), (5, 8)):

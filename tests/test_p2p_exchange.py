@@ -63,7 +63,7 @@ def test_p2p_local_matches_unsharded(gpu, world):
 def test_p2p_tsallis_weights_on_sharded_handles(gpu, world):
     """ColoredMPPI's Tsallis weights (core/mppi_common.cu:968-985) need the GLOBAL baseline before any weight: on K-sharded
     handles the ranks exchange their minima first, then {sum w v | rho, sum w, sum w^2} under the common baseline (two mailbox
-    exchanges per iteration, engine.hip: iterationShardedTsallis) — against the un-sharded engine on the same noise and
+    exchanges per iteration, engine_iteration.hip: iterationShardedTsallis) — against the un-sharded engine on the same noise and
     against the oracle's un-sharded iteration"""
     from common import host_spectrum
     from test_colored_noise import _colored_cartpole

@@ -102,7 +102,7 @@ def di_acceptance_cfg(D, lambda_, num_iters, robust_cost=False, sampler_cost=1.0
 
 
 class _Stream:
-    """the engine's noise stream on the host: one Philox generation per rollout launch (engine.hip: h->generation)"""
+    """the engine's noise stream on the host: one Philox generation per rollout launch (engine_iteration.hip: h->generation)"""
 
     def __init__(self, seed, K, T, C):
         self.seed, self.K, self.T, self.C, self.g = seed, K, T, C, 0

@@ -1,6 +1,6 @@
 """Split hand-over of mppi_compute_control (one-system controllers, low-latency path): the finalize pass as two launches — the
 control phase on the handle's stream, the re-rollout of the state trajectory on a side stream — so the re-rollout of call N runs
-beside the rollouts of call N + 1 (csrc/engine.hip: split_finalize; engine/finalize_kernel.hpp: FinalizeArgs::phases).  Every
+beside the rollouts of call N + 1 (csrc/engine_controllers.hip: split_finalize; engine/finalize_kernel.hpp: FinalizeArgs::phases).  Every
 host-visible result must be the bits the single launch (MPPI_AMD_SPLIT_FINALIZE=0, read when the handle is created) gives:
 controls, state and output trajectories, statistics — with the trajectories read every call, never, or late; with the BAR
 inbox and without; with the smoothing buffer in LDS and in HBM; and with other entry points between the calls."""

@@ -2,7 +2,7 @@
 """Phases of combineKernel (the merge launch of a Cartpole iteration, K=16384, T=100: 256 block records -> u*), from s_memtime
 stamps inside the kernel (A/B build with -DMPPI_COMBINE_TIMING, never a product build).
 
-  python mppi-generic_amd/buildlib.py --variant timing_merge engine.hip -DMPPI_COMBINE_TIMING                       (CPU)
+  python mppi-generic_amd/buildlib.py --variant timing_merge engine_iteration.hip -DMPPI_COMBINE_TIMING                       (CPU)
   MPPI_AMD_LIB=$PWD/mppi-generic_amd/lib/libmppi_amd_timing_merge.so python tools/combine_timing.py [out.json]      (GPU box)"""
 import ctypes as C
 import json

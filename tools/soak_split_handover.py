@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the split hand-over (engine.hip: split_finalize): long closed loops with the entry points a plant mixes in at random
+"""Soak of the split hand-over (engine_controllers.hip: split_finalize): long closed loops with the entry points a plant mixes in at random
 — trajectory reads, statistics, model steps, parameter updates, optimisation calls — run once with the split and once with the
 single launch; every host-visible result must be the same bits, and nothing may hang (run under `timeout`).
 Usage: timeout 600 python tools/soak_split_handover.py [cycles (20000)]"""
