@@ -90,36 +90,53 @@ def pmc_pipe_util(kernel_prefix, suffix=""):
 
 def cpu_baseline(cfg, budget_s=12.0, label=None, min_iters=1, one_core_k=None, noise_note=""):
     """oracle iterations/s on the host cores, bounded sample (never the thing shipped or measured as `value`); any of the
-    Vanilla / Tube configurations (cfg["D"] systems per iteration).  one_core_k: the single-thread figure is taken on a slice
-    of that many rollouts (rollouts are independent: the time is proportional) and scaled to the full K."""
+    Vanilla / Tube configurations (cfg["D"] systems per iteration).
+
+    SURVEY.md §8d's rule — at least 5 warm-up and 50 timed iterations, the MEDIAN — inside the bounded sample the contract
+    asks for (budget_s of CPU work): where 55 iterations of the full problem do not fit the budget, the sample is a SLICE of
+    K / 2^j rollouts (rollouts are independent and spread over the threads either way: the time of an iteration is
+    proportional to K) and the rate is scaled back by the slice; the line says so.  The single-thread figure (the reference's
+    CPU path is single-threaded) is taken the same way with a smaller count (>= 1 warm-up + >= 5 timed, median).
+    min_iters / one_core_k: accepted for the callers of earlier rounds, superseded by the rule above."""
     import numpy as np
     import pyoracle as po
     from common import make_oracle
     K, Tn, D = cfg["K"], cfg["T"], cfg["D"]
     threads = max(1, min(po.max_threads(), usable_cores()))
-    out = {}
-    for key, th, k_used in (("all", threads, K), ("one", 1, one_core_k or K)):
-        c = dict(cfg, K=k_used)
-        o = make_oracle(c)
-        eps = po.philox_normal(42, 0, k_used, Tn, o.C)
-        mean = np.zeros((D, Tn, o.C), np.float32)
-        x0 = np.tile(np.asarray(cfg["x0"], np.float32), (D, 1))
-        t1 = o.time_iterations(x0, mean, eps, 1, th)  # warm-up (and the estimate the sample size comes from)
-        n = max(min_iters if key == "all" else 1, int(budget_s / 2 / max(t1, 1e-4)))
-        n = min(n, 400)
-        tt = o.time_iterations(x0, mean, eps, n, th)
-        out[key] = (n / tt * (k_used / float(K)), n, th, k_used)
+
+    def sample(th, warm, timed, budget):
+        k_used = K
+        while True:
+            c = dict(cfg, K=k_used)
+            o = make_oracle(c)
+            eps = po.philox_normal(42, 0, k_used, Tn, o.C)
+            mean = np.zeros((D, Tn, o.C), np.float32)
+            x0 = np.tile(np.asarray(cfg["x0"], np.float32), (D, 1))
+            t1 = o.time_iterations(x0, mean, eps, 1, th)  # first warm-up iteration: also the estimate the slice comes from
+            if (warm + timed) * t1 <= budget or k_used <= max(256, 64 * th) or k_used % 2:
+                break
+            del o
+            k_used //= 2
+        for _ in range(warm - 1):
+            o.time_iterations(x0, mean, eps, 1, th)
+        ts = [o.time_iterations(x0, mean, eps, 1, th) for _ in range(timed)]
         del o
-    v, n, th, _ = out["all"]
+        med = float(np.median(ts))
+        return (1.0 / med) * (k_used / float(K)), k_used, med, float(min(ts)), float(max(ts))
+
+    v, k_all, med, lo, hi = sample(threads, 5, 50, budget_s * 0.75)
+    v1, k_one, med1, _, _ = sample(1, 1, 5, budget_s * 0.25)
     what = label or ("Cartpole K=%d T=%d" % (K, Tn))
-    one = out["one"]
+
+    def slice_text(k_used):
+        return "" if k_used == K else " on a slice of %d of the %d rollouts (rate scaled by 1/%d)" % (k_used, K, K // k_used)
     return {
-        "value": round(v, 3), "unit": "MPPI iters/s", "cores": th, "kind": "port",
-        "sample": "%d iterations of the same workload (%s, one optimisation-loop body each) with the "
-                  "rollouts spread over %d OpenMP threads%s" % (n, what, th, noise_note),
-        "value_1core": round(one[0], 4),
-        "sample_1core": "%d iteration(s), single thread (the reference's CPU path is single-threaded)%s" % (
-            one[1], "" if one[3] == K else ", on a slice of %d of the %d rollouts, scaled by %d" % (one[3], K, K // one[3])),
+        "value": round(v, 3), "unit": "MPPI iters/s", "cores": threads, "kind": "port",
+        "sample": "5 warm-up + 50 timed iterations, median (%.4f s; min %.4f, max %.4f)%s: %s, one optimisation-loop body each, "
+                  "the rollouts spread over %d OpenMP threads%s" % (med, lo, hi, slice_text(k_all), what, threads, noise_note),
+        "value_1core": round(v1, 4),
+        "sample_1core": "1 warm-up + 5 timed iterations, median (%.4f s), single thread (the reference's CPU path is "
+                        "single-threaded)%s" % (med1, slice_text(k_one)),
     }
 
 

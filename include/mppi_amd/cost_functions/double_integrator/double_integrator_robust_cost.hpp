@@ -23,6 +23,8 @@ class DoubleIntegratorRobustCost
 public:
   /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
   static constexpr bool MPPI_BARRIER_FREE_STEP = true;
+  /** a pure parameter block on the device: role loops may run it straight off the kernel's argument block (engine/kernarg_view.hpp) */
+  static constexpr bool MPPI_KERNARG_VIEWABLE = true;
   DoubleIntegratorRobustCost(hipStream_t stream = nullptr)
   {
     bindToStream(stream);

@@ -42,6 +42,8 @@ class QuadraticCost
 public:
   /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
   static constexpr bool MPPI_BARRIER_FREE_STEP = true;
+  /** a pure parameter block on the device: role loops may run it straight off the kernel's argument block (engine/kernarg_view.hpp) */
+  static constexpr bool MPPI_KERNARG_VIEWABLE = true;
   static constexpr float MAX_COST_VALUE = 1e16;
   QuadraticCost(hipStream_t stream = nullptr)
   {

@@ -27,6 +27,7 @@
 #define MPPI_AMD_RACER_DUBINS_ELEVATION_HPP_
 
 #include "mppi_amd/dynamics/racer_dubins/racer_dubins.hpp"
+#include "mppi_amd/engine/kernarg_view.hpp"
 #include "mppi_amd/utils/texture_helpers/two_d_texture_helper.hpp"
 
 #ifndef U_INDEX
@@ -105,6 +106,101 @@ public:
   /** the elevation map (texture 0), reference: tex_helper_ of racer_dubins_elevation.cuh:88-96 */
   mppi::texture::TwoDTextureHelper<1, 1> tex_helper_;
 
+  /**
+   * S(): where the per-step device methods READ this object's read-only members (params_, the maps' frames, blob pointers)
+   * from.  Three sources exist; the product uses the first — the other two are the round-6 experiment the round-5 review asked
+   * for ("get kernel arguments out of spilled SGPRs"), kept behind -DMPPI_STEP_SOURCE_QUAD=1|2 with their measurements.
+   *
+   * The question.  Written `this->params_.x`, every parameter is a loop-invariant scalar load: the compiler hoists all of them
+   * in front of the step loop and keeps them in SGPRs across it.  A step of these models reads a few hundred parameters, a wave
+   * has ~100 SGPRs: the code objects carry 300-460 SPILLED SGPRs (to VGPR lanes; one v_readlane_b32 + hazard s_nops per use —
+   * 680 + 456 of the 7740 instructions of a pair of steps of the complete model's dynamics wave).  Read through a pointer the
+   * optimiser cannot see through, or from LDS, the loads stay inside the method that asked for them: 7740 -> 6680
+   * instructions, v_readlane 680 -> 204 (argument block) / 177 (LDS).
+   *
+   * The answer (MI355X, K = 16384, T = 100, us per rollout launch; profiles/r06_step_source_ab.json):
+   *                          this (0)   argument block (1)   LDS copy (2)
+   *     elevation, 4 lanes     221.4         254.8               260.9
+   *     + steering LSTM        305.4         329.9               328.4
+   *     + suspension           393.9         412.3               416.7
+   *     complete model         811.0         860.9               865.0
+   *     Robust complete model 3398.9        2953.1              2979.4      (the one kernel that spills VGPRs to scratch)
+   * The 14 % fewer instructions run 6-18 % LONGER: the dynamics waves are not short of issue slots — a lone wave per SIMD
+   * issues a dependent instruction every ~7 cycles and an independent one every 4 (tools/ubench/exec_width.hip), the step is a
+   * long dependent chain, and the v_readlane / s_nop pairs sit in slots that were idle anyway — while every s_load / ds_read
+   * puts its memory latency INTO the chain (SMEM results return out of order: each use waits for lgkmcnt(0), LDS traffic
+   * included).  Spilled SGPRs are the cheapest place those parameters can live.  Only where VGPRs spill to scratch memory
+   * (the Robust kernel of the complete model, 960 threads per block = 128 VGPRs per lane) does taking the parameters out of
+   * the register file pay.
+   *
+   * Why a function and not a pointer member (both tried): members that hold PER-LANE STATE (a network's parameters in this
+   * lane's registers, loaded by initializeDynamics) must stay the object's own, so the kernels cannot run the methods on a view
+   * of the argument block (the matrix-core and four-lane models lose their weights); and a `step_src_` member set by the
+   * kernels makes the by-value argument a private copy that cannot be split into registers where a method indexes a member
+   * array with a run-time index — the whole object moved to scratch (12 -> 1072 B in the finalize and model-step kernels).
+   * Coupling of sources 1 and 2: the object is the running kernel's argument at byte STEP_SOURCE_KERNARG_OFFSET (0: the dynamics
+   * object is the first argument of every kernel of the engine) / the dynamics region starts the kernel's dynamic LDS
+   * (theta_s_shared = smem_raw everywhere).  On the host S() is the object.
+   */
+  static constexpr size_t STEP_SOURCE_KERNARG_OFFSET = 0;
+  /** which of the three a class gets: `static constexpr int MPPI_STEP_SOURCE = ...` in the (most derived) class —
+   *    0  the object itself (`this->params_`) — the default, and what the product builds;
+   *    1  the argument block behind the opaque pointer (engine/kernarg_view.hpp): s_load next to the use;
+   *    2  a copy of the object in LDS, at the start of the class's block-shared (Grd) region = the start of the kernel's dynamic
+   *       LDS: staged once per block by initializeDynamics (stageStepSource), read with ds_read (uniform address: a broadcast). */
+  template <class T, class = void>
+  struct step_source_of : std::integral_constant<int, 0>
+  {
+  };
+  template <class T>
+  struct step_source_of<T, std::void_t<decltype(T::MPPI_STEP_SOURCE)>> : std::integral_constant<int, T::MPPI_STEP_SOURCE>
+  {
+  };
+  static constexpr int stepSourceBytes()  // (a function: its body is only instantiated once CLASS_T is complete)
+  {
+    return (int)((sizeof(CLASS_T) + 15) / 16 * 16);
+  }
+  __host__ __device__ __forceinline__ const CLASS_T& S() const
+  {
+#if defined(__HIP_DEVICE_COMPILE__) && MPPI_KERNARG_RELOAD
+    if constexpr (step_source_of<CLASS_T>::value == 2)
+    {
+      extern __shared__ __attribute__((aligned(16))) char mppi_step_source_lds[];
+      return *reinterpret_cast<const CLASS_T*>(mppi_step_source_lds);
+    }
+    else if constexpr (step_source_of<CLASS_T>::value == 1)
+      return *mppi::kernels::kernargObject<CLASS_T>(mppi::kernels::kernargBase(), STEP_SOURCE_KERNARG_OFFSET);
+    else
+      return *static_cast<const CLASS_T*>(this);
+#else
+    return *static_cast<const CLASS_T*>(this);
+#endif
+  }
+  /** MPPI_STEP_SOURCE == 2: every thread of the block copies its share of the kernel's argument block into the class's Grd
+   *  region (theta_s), then a block barrier.  FIRST statement of every initializeDynamics of the hierarchy (all threads of a
+   *  block reach initializeDynamics: the plugin contract). */
+  __device__ __forceinline__ void stageStepSource(float* theta_s) const
+  {
+#if defined(__HIP_DEVICE_COMPILE__) && MPPI_KERNARG_RELOAD
+    if constexpr (step_source_of<CLASS_T>::value == 2)
+    {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(mppi::kernels::kernargObject<CLASS_T>(
+          (mppi::kernels::kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr(), STEP_SOURCE_KERNARG_OFFSET));
+      uint32_t* dst = reinterpret_cast<uint32_t*>(theta_s);
+      const int nthreads = (int)(blockDim.x * blockDim.y * blockDim.z);
+      const int tid = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
+      for (int i = tid; i < (int)(sizeof(CLASS_T) / 4); i += nthreads)
+        dst[i] = src[i];
+      __syncthreads();  // initializeDynamics itself reads through S() right away (setOutputs); block-uniform, as the contract allows
+    }
+#endif
+  }
+  /** the staged copy is this class's block-shared request (the four-lane forms ask for nothing else) */
+  __host__ __device__ int getGrdSharedSizeBytes() const
+  {
+    return (MPPI_KERNARG_RELOAD && step_source_of<CLASS_T>::value == 2) ? stepSourceBytes() : 0;
+  }
+
   RacerDubinsElevationImpl(hipStream_t stream = nullptr) : PARENT_CLASS(stream)
   {
   }
@@ -133,6 +229,7 @@ public:
   __device__ __forceinline__ void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
                                             float dt)
   {
+    stageStepSource(theta_s);  // MPPI_STEP_SOURCE == 2: the read-only members' copy in LDS (see S())
     PARENT_CLASS::initializeDynamics(state, control, output, theta_s, t_0, dt);
     int first, stride;
     mppi::p1::getParallel1DIndex<mppi::p1::Parallel1Dir::THREAD_Y>(first, stride);
@@ -200,7 +297,7 @@ public:
   /** racer_dubins.cu:281-293 (brake lag, faster on release) and :295-305 (steering lag) */
   __device__ inline void computeParametricDelayDeriv(const float* state, const float* control, float* state_der) const
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     const bool enable_brake = control[RDE_C(THROTTLE_BRAKE)] < 0.0f;
     const float brake_error = (enable_brake * -control[RDE_C(THROTTLE_BRAKE)] - state[RDE_S(BRAKE_STATE)]);
     state_der[RDE_S(BRAKE_STATE)] = fminf(fmaxf((brake_error > 0) * brake_error * p.brake_delay_constant +
@@ -210,7 +307,7 @@ public:
   }
   __device__ inline void computeParametricSteerDeriv(const float* state, const float* control, float* state_der) const
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     state_der[RDE_S(STEER_ANGLE)] =
         fmaxf(fminf((control[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - state[RDE_S(STEER_ANGLE)]) *
                         p.steering_constant,
@@ -234,7 +331,7 @@ public:
   __device__ inline StepTrig stateTrig(const float* state) const
   {
     StepTrig g;
-    const float delta = state[RDE_S(STEER_ANGLE)] / this->params_.steer_angle_scale;
+    const float delta = state[RDE_S(STEER_ANGLE)] / this->S().params_.steer_angle_scale;
     float s, c;
     mppi::det::sincos(angle_utils::normalizeAngle(state[RDE_S(YAW)]), &g.sin_yaw, &g.cos_yaw);
     mppi::det::sincos(angle_utils::normalizeAngle(delta), &s, &c);
@@ -252,7 +349,7 @@ public:
   __device__ inline void computeParametricAccelDeriv(const float* state, const float* control, float* state_der,
                                                      const StepTrig& g) const
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     const float vx = state[RDE_S(VEL_X)];
     const float linear_brake_slope = 0.2f;
     const bool enable_brake = control[RDE_C(THROTTLE_BRAKE)] < 0.0f;
@@ -281,7 +378,7 @@ public:
   /** racer_dubins_elevation.cu:800-834: Euler step of the six integrated states, as in RacerDubins */
   __device__ inline void updateState(const float* state, float* next_state, const float* state_der, const float dt) const
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
 #pragma unroll
     for (int i = 0; i < CLASS_T::NUM_EULER_STATES; i++)
     {
@@ -308,7 +405,7 @@ public:
   /** racer_dubins_elevation.cu:336-419 (device branch): A = df/dx + df/du K of the (v, yaw, x, y) error dynamics */
   __device__ inline void computeUncertaintyJacobian(const float* state, const StepTrig& g, float* A) const
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     const float vx = state[RDE_S(VEL_X)];
     const float sin_yaw = g.sin_yaw, cos_yaw = g.cos_yaw;
     const float tan_steer_angle = g.tan_delta;
@@ -340,7 +437,7 @@ public:
   /** racer_dubins_elevation.cu:421-506 (device branch): process noise from |a_x|, |v|, steering and the side force */
   __device__ inline void computeQ(const float* state, const float* state_der, const StepTrig& g, float* Q) const
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     const float abs_vx = fabsf(state[RDE_S(VEL_X)]);
     const float abs_acc_x = fabsf(state_der[RDE_S(VEL_X)]);
     const float delta = state[RDE_S(STEER_ANGLE)] / p.steer_angle_scale;
@@ -526,7 +623,7 @@ public:
                                                float& pitch, float& height) const
   {
     height = 0.0f;
-    if (!tex_helper_.checkTextureUse(0))
+    if (!this->S().tex_helper_.checkTextureUse(0))
     {
       roll = 0.0f;
       pitch = 0.0f;
@@ -539,7 +636,7 @@ public:
 #pragma unroll
     for (int w = 0; w < 4; w++)
       wheelWorldPoint(M, wheelOffsetX(w), wheelOffsetY(w), x, y, world[w]);
-    tex_helper_.template queryTextureAtWorldPoseBatch<4>(0, world, h);  // the sixteen loads of the four wheels in flight together
+    this->S().tex_helper_.template queryTextureAtWorldPoseBatch<4>(0, world, h);  // the sixteen loads of the four wheels in flight together
     float angle[4];
 #pragma unroll
     for (int w = 0; w < 4; w++)
@@ -656,12 +753,12 @@ public:
     roll = 0.0f;
     pitch = 0.0f;
     height = 0.0f;
-    if (tex_helper_.checkTextureUse(0))
+    if (this->S().tex_helper_.checkTextureUse(0))
     {
       float M[3][3], world[3], h_own, h[4], angle[4];
       bodyRotation(g, sin_psi, cos_psi, M);
       wheelWorldPoint(M, wheelOffsetX(rep), wheelOffsetY(rep), x, y, world);
-      tex_helper_.queryTextureAtWorldPose(0, world, &h_own);
+      this->S().tex_helper_.queryTextureAtWorldPose(0, world, &h_own);
       allReplicas(h_own, h);
       allReplicas(mppi::det::asin(settlingSine(rep, h)), angle);
       settle(angle, h, roll, pitch, height);
@@ -678,7 +775,7 @@ public:
   __device__ __forceinline__ void stepFourLanes(float* state, float* next_state, float* state_der, float* control, float* output,
                                        const float dt, STEER&& steer, POST&& post)
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     const int rep = (int)(threadIdx.x & 63) >> 4;
     float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM];
 #pragma unroll
@@ -811,6 +908,9 @@ class RacerDubinsElevationQuad : public RacerDubinsElevationImpl<RacerDubinsElev
 public:
   /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
   static constexpr bool MPPI_BARRIER_FREE_STEP = true;
+  /** S() of RacerDubinsElevationImpl: 0 = the object itself.  1 (argument block, s_load) and 2 (copy in LDS, ds_read) remove
+   *  most of the spilled-SGPR reads of the step loop and are SLOWER (profiles/r06_step_source_ab.json) — A/B: -DMPPI_STEP_SOURCE_QUAD=1|2 */
+  static constexpr int MPPI_STEP_SOURCE = MPPI_STEP_SOURCE_QUAD;
   using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationQuad>;
   using PARAMS_T = RacerDubinsElevationParams;
   static constexpr int REPLICATED_LANES = 4;

@@ -137,7 +137,7 @@ public:
   __device__ __forceinline__ void computeLSTMSteering(const float* state, const float* control, float* state_der,
                                              float* theta_s) const
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     const float steer = state[RDE_S(STEER_ANGLE)], rate = state[RDE_S(STEER_ANGLE_RATE)];
     const float parametric_accel = (control[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - steer) * p.steering_constant;
     float rate_dot = fmaxf(fminf((parametric_accel - rate) * p.steer_accel_constant - rate * p.steer_accel_drag_constant,
@@ -237,6 +237,9 @@ class RacerDubinsElevationLSTMSteeringQuad : public RacerDubinsElevationImpl<Rac
 public:
   /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
   static constexpr bool MPPI_BARRIER_FREE_STEP = true;
+  /** S() of RacerDubinsElevationImpl: 0 = the object itself.  1 (argument block, s_load) and 2 (copy in LDS, ds_read) remove
+   *  most of the spilled-SGPR reads of the step loop and are SLOWER (profiles/r06_step_source_ab.json) — A/B: -DMPPI_STEP_SOURCE_QUAD=1|2 */
+  static constexpr int MPPI_STEP_SOURCE = MPPI_STEP_SOURCE_QUAD;
   using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteeringQuad>;
   using PARAMS_T = RacerDubinsElevationParams;
   static constexpr int REPLICATED_LANES = 4;
@@ -263,6 +266,7 @@ public:
   __device__ __forceinline__ void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
                                             float dt)
   {
+    this->stageStepSource(theta_s);  // the read-only members' copy in LDS first: setOutputs below reads through S()
     net_.load((int)(threadIdx.x & 63) >> 4, lstm_d_, fnn_d_);
     output[RDE_O(BASELINK_POS_I_Z)] = 0.0f;
     output[RDE_O(FILLER_1)] = 0.0f;
@@ -272,7 +276,7 @@ public:
   /** racer_dubins_elevation_lstm_steering.cu:131-167, the network shared out over the four replicas */
   __device__ __forceinline__ void computeLSTMSteering(const float* state, const float* control, float* state_der)
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     const float steer = state[RDE_S(STEER_ANGLE)], rate = state[RDE_S(STEER_ANGLE_RATE)];
     const float parametric_accel = (control[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - steer) * p.steering_constant;
     float rate_dot = fmaxf(fminf((parametric_accel - rate) * p.steer_accel_constant - rate * p.steer_accel_drag_constant,
@@ -280,7 +284,7 @@ public:
                            -p.max_steer_rate);
     const float input[4] = { steer * 0.2f, rate * 0.2f, control[RDE_C(STEER_CMD)], rate_dot * 0.2f };
     float out[1] = { 0.0f };
-    net_.forward(fnn_d_, input, out);
+    net_.forward(this->S().fnn_d_, input, out);
     rate_dot += out[0] * 5.0f;
     state_der[RDE_S(STEER_ANGLE_RATE)] = rate_dot;
     state_der[RDE_S(STEER_ANGLE)] = rate;

@@ -236,7 +236,7 @@ public:
   __device__ __forceinline__ void computeNetworkQ(const float* state, const float* control, const float* state_der,
                                          const StepTrig& g, float* theta_s, float* Q) const
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     const float vx = state[RDE_S(VEL_X)];
     const float tb = control[RDE_C(THROTTLE_BRAKE)];
     const float input[13] = { vx,
@@ -275,7 +275,7 @@ public:
   __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
                               float* theta_s, const float t, const float dt)
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM], wheel_out[OUTPUT_DIM];
 #pragma unroll
     for (int i = 0; i < STATE_DIM; i++)
@@ -363,6 +363,9 @@ class RacerDubinsElevationLSTMUncertaintyQuad
 public:
   /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
   static constexpr bool MPPI_BARRIER_FREE_STEP = true;
+  /** S() of RacerDubinsElevationImpl: 0 = the object itself.  1 (argument block, s_load) and 2 (copy in LDS, ds_read) remove
+   *  most of the spilled-SGPR reads of the step loop and are SLOWER (profiles/r06_step_source_ab.json) — A/B: -DMPPI_STEP_SOURCE_QUAD=1|2 */
+  static constexpr int MPPI_STEP_SOURCE = MPPI_STEP_SOURCE_QUAD;
   using PARAMS_T = RacerDubinsElevationUncertaintyParams;
   using QUAD = RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationLSTMUncertaintyQuad, PARAMS_T>;
   using MEAN_NET = mppi::LSTMQuadRows<12, 20, 2>;
@@ -396,7 +399,7 @@ public:
   __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
                                        float* theta_s, const float t, const float dt)
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     const int rep = replica();
     float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM], wheel_out[OUTPUT_DIM];
 #pragma unroll
@@ -445,7 +448,7 @@ public:
                                 xd[RDE_S(YAW)],
                                 0.0f };
       float mean_output[2];
-      mean_.forward(mean_fnn_d_, input, mean_output);
+      mean_.forward(this->S().mean_fnn_d_, input, mean_output);
       xd[RDE_S(VEL_X)] += mean_output[0];
       xd[RDE_S(YAW)] += mean_output[1];
     }
@@ -468,7 +471,7 @@ public:
                                 xd[RDE_S(YAW)],
                                 0.0f };
       float o[5];
-      unc_.forward(unc_fnn_d_, input, o);
+      unc_.forward(this->S().unc_fnn_d_, input, o);
       networkOutputsToQ(p, x[RDE_S(VEL_X)], g, speedRegime(x[RDE_S(VEL_X)]), o, Q);
     });
     // ---- static settling at the next pose from the settled angles of the current state

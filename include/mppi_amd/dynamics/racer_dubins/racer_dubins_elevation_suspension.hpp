@@ -216,7 +216,7 @@ public:
   __device__ __forceinline__ void computeSimpleSuspensionStep(const float* state, float* state_der, const StepTrig& g,
                                                      float* output) const
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     state_der[RDE_S(ROLL)] = state[RDE_S(ROLL_RATE)];
     state_der[RDE_S(PITCH)] = state[RDE_S(PITCH_RATE)];
     state_der[RDE_S(CG_POS_Z)] = state[RDE_S(CG_VEL_I_Z)];
@@ -236,17 +236,17 @@ public:
       normal[i][2] = 1.0f;
       normal[i][3] = 0.0f;
     }
-    if (this->tex_helper_.checkTextureUse(0))
+    if (this->S().tex_helper_.checkTextureUse(0))
     {
-      this->tex_helper_.template queryTextureAtWorldPoseBatch<4>(0, world, height);
+      this->S().tex_helper_.template queryTextureAtWorldPoseBatch<4>(0, world, height);
 #pragma unroll
       for (int i = 0; i < 4; i++)
         if (!isfinite(height[i]))
           height[i] = state[RDE_S(CG_POS_Z)] - p.wheel_radius;
     }
-    if (normals_tex_helper_.checkTextureUse(0))
+    if (this->S().normals_tex_helper_.checkTextureUse(0))
     {
-      normals_tex_helper_.template queryTextureAtWorldPoseBatch<4>(0, world, &normal[0][0]);
+      this->S().normals_tex_helper_.template queryTextureAtWorldPoseBatch<4>(0, world, &normal[0][0]);
 #pragma unroll
       for (int i = 0; i < 4; i++)
         if (!isfinite(normal[i][0]) || !isfinite(normal[i][1]) || !isfinite(normal[i][2]))
@@ -269,7 +269,7 @@ public:
 
   __device__ inline void setSuspensionOutputs(const float* state_der, const float* next_state, float* output) const
   {
-    MATH::setSuspensionOutputs(this->params_, state_der, next_state, output);
+    MATH::setSuspensionOutputs(this->S().params_, state_der, next_state, output);
   }
 
   /** racer_dubins_elevation_suspension_lstm.cu:342-392 */
@@ -378,6 +378,7 @@ public:
   __device__ __forceinline__ void initializeDynamics(float* state, float* control, float* output, float* theta_s, float t_0,
                                                      float dt)
   {
+    this->stageStepSource(theta_s);  // the read-only members' copy in LDS first: setOutputs below reads through S()
     net_.load(replica(), lstm_d_, fnn_d_);
     output[RDE_O(BASELINK_POS_I_Z)] = 0.0f;
     output[RDE_O(FILLER_1)] = 0.0f;
@@ -390,7 +391,7 @@ public:
   __device__ __forceinline__ void quadTrig(const float* x, const int rep, StepTrig& g, float& sin_wheel_yaw,
                                            float& cos_wheel_yaw) const
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     {
       const float delta = x[RDE_S(STEER_ANGLE)] / p.steer_angle_scale;
       const float raw = pick4(rep, x[RDE_S(YAW)], delta, delta, x[RDE_S(PITCH)]);
@@ -422,7 +423,7 @@ public:
   /** racer_dubins_elevation_lstm_steering.cu:131-167, the network shared out over the replicas */
   __device__ __forceinline__ void quadSteering(const float* x, const float* u, float* xd)
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     const float steer = x[RDE_S(STEER_ANGLE)], rate = x[RDE_S(STEER_ANGLE_RATE)];
     const float parametric_accel = (u[RDE_C(STEER_CMD)] * p.steer_command_angle_scale - steer) * p.steering_constant;
     float rate_dot = fmaxf(fminf((parametric_accel - rate) * p.steer_accel_constant - rate * p.steer_accel_drag_constant,
@@ -430,7 +431,7 @@ public:
                            -p.max_steer_rate);
     const float input[4] = { steer * 0.2f, rate * 0.2f, u[RDE_C(STEER_CMD)], rate_dot * 0.2f };
     float out[1] = { 0.0f };
-    net_.forward(fnn_d_, input, out);
+    net_.forward(this->S().fnn_d_, input, out);
     rate_dot += out[0] * 5.0f;
     xd[RDE_S(STEER_ANGLE_RATE)] = rate_dot;
     xd[RDE_S(STEER_ANGLE)] = rate;
@@ -441,7 +442,7 @@ public:
   __device__ __forceinline__ void quadSuspension(const float* x, const StepTrig& g, const int rep, const float sin_wheel_yaw,
                                                  const float cos_wheel_yaw, float* xd, float* wheel_out) const
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     xd[RDE_S(ROLL)] = x[RDE_S(ROLL_RATE)];
     xd[RDE_S(PITCH)] = x[RDE_S(PITCH_RATE)];
     xd[RDE_S(CG_POS_Z)] = x[RDE_S(CG_VEL_I_Z)];
@@ -449,15 +450,15 @@ public:
     bodyRotation(g, g.sin_yaw, g.cos_yaw, M);
     wheelWorldPoint(M, MATH::wheelBodyX(rep), MATH::wheelBodyY(rep), x[RDE_S(POS_X)], x[RDE_S(POS_Y)], world);
     float height = 0.0f, normal[4] = { 0.0f, 0.0f, 1.0f, 0.0f };
-    if (this->tex_helper_.checkTextureUse(0))
+    if (this->S().tex_helper_.checkTextureUse(0))
     {
-      this->tex_helper_.queryTextureAtWorldPose(0, world, &height);
+      this->S().tex_helper_.queryTextureAtWorldPose(0, world, &height);
       if (!isfinite(height))
         height = x[RDE_S(CG_POS_Z)] - p.wheel_radius;
     }
-    if (normals_tex_helper_.checkTextureUse(0))
+    if (this->S().normals_tex_helper_.checkTextureUse(0))
     {
-      normals_tex_helper_.queryTextureAtWorldPose(0, world, normal);
+      this->S().normals_tex_helper_.queryTextureAtWorldPose(0, world, normal);
       if (!isfinite(normal[0]) || !isfinite(normal[1]) || !isfinite(normal[2]))
       {
         normal[0] = 0.0f;
@@ -478,7 +479,7 @@ public:
   __device__ __forceinline__ void step(float* state, float* next_state, float* state_der, float* control, float* output,
                                        float* theta_s, const float t, const float dt)
   {
-    const PARAMS_T& p = this->params_;
+    const PARAMS_T& p = this->S().params_;
     const int rep = replica();
     float x[STATE_DIM], xn[STATE_DIM], xd[XD], u[CONTROL_DIM], wheel_out[OUTPUT_DIM];
 #pragma unroll
@@ -519,6 +520,9 @@ class RacerDubinsElevationSuspensionQuad : public RacerDubinsElevationSuspension
 public:
   /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
   static constexpr bool MPPI_BARRIER_FREE_STEP = true;
+  /** S() of RacerDubinsElevationImpl: 0 = the object itself.  1 (argument block, s_load) and 2 (copy in LDS, ds_read) remove
+   *  most of the spilled-SGPR reads of the step loop and are SLOWER (profiles/r06_step_source_ab.json) — A/B: -DMPPI_STEP_SOURCE_QUAD=1|2 */
+  static constexpr int MPPI_STEP_SOURCE = MPPI_STEP_SOURCE_QUAD;
   using PARAMS_T = RacerDubinsElevationSuspensionParams;
   RacerDubinsElevationSuspensionQuad(const RacerDubinsElevationSuspension& other)
     : RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationSuspensionQuad>(other.stream_)

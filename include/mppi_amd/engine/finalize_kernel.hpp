@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 #include "mppi_amd/plugin/managed.hpp"
+#include "kernarg_view.hpp"
 #include "mppi_amd/plugin/math_utils.hpp"
 #include "mppi_amd/plugin/parallel_utils.hpp"
 #include "rollout_kernel.hpp"

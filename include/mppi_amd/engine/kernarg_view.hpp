@@ -9,15 +9,25 @@
  * with a v_readlane_b32 — a VALU issue slot plus hazard s_nops — at every use: 680 v_readlane + 456 s_nop in the 7740 instructions
  * of a pair of steps of the complete model's dynamics wave).
  *
- * kernargObject<T>(offset) hands out a pointer to argument `offset` that the optimiser cannot see through (the segment pointer
- * passes an empty volatile asm): taken INSIDE the loop, the loads that hang off it cannot be hoisted out of the loop, so each
- * step loads what it needs with s_load_dwordx{2,4,8,16} from the scalar cache (the whole block is resident after the first
- * step; SMEM instructions do not take VALU issue slots) into SGPRs that are free again at the end of the step.  The address space
- * survives the asm (address space 4 = constant): the loads stay scalar.
+ * kernargObject<T>(base, offset) hands out a pointer to the argument at `offset` that the optimiser cannot see through (the
+ * segment pointer passes an empty volatile asm, kernargBase()): taken INSIDE the loop, the loads that hang off it cannot be hoisted
+ * out of the loop, so each step loads what it needs, where it needs it, with s_load_dwordx{2,4,8,16} from the scalar cache (the
+ * whole block is resident after the first step; SMEM instructions do not take VALU issue slots) into SGPRs that are free again
+ * afterwards.  The address space survives the asm (address space 4 = constant): the loads stay scalar.
  *
- * The objects are never written by device code (they could not be: a by-value argument the kernel stored to would have been
- * copied to scratch by the front end — the kernels that use this have 0 B of scratch for it), so a const view is sufficient; the
- * plugin methods are non-const by the reference's signatures, hence the const_cast inside.
+ * Two things it cannot be used for, both found the hard way in round 6 (profiles/r06_b_*):
+ *   - as the OBJECT the per-step methods run on (`DYN_T* dynamics = kernargObject<DYN_T>(...)`) when the class keeps per-lane
+ *     state in members: the matrix-core network models and the four-lane RACER models load their weights into registers in
+ *     initializeDynamics — members of the kernel's local copy, which the argument block knows nothing of (AutoRally's costs came
+ *     out wrong by 3e8 ulp, a null pointer was dereferenced);
+ *   - as a per-step COPY of the read-only members (`params_ = src->params_`): the copy is loaded at the top of the step and is
+ *     live from there to every use — spilled within the step instead of across the loop (642 v_readlane per pair of steps
+ *     against 680 before; the view proper: 220).
+ *   - as a pointer MEMBER the kernels set (`step_src_`): writing any member of a by-value argument makes it a private copy, and a
+ *     copy with run-time-indexed member arrays cannot be split into registers — the whole object moved to scratch memory in the
+ *     blockDim.y > 1 kernels.
+ * What works: the class routes the READS of its read-only members through a function, S(), that returns the argument block
+ * behind the opaque pointer (dynamics/racer_dubins/racer_dubins_elevation.hpp); per-lane state stays in the object.
  *
  * Argument offsets: the AMDGPU HIP ABI lays the explicit arguments out in order, each at the next multiple of its alignment,
  * starting at offset 0 of the segment (hidden arguments follow the explicit ones) — KernargLayout<Ts...>::offset<I>().
@@ -31,6 +41,7 @@
 
 #include <cstddef>
 #include <type_traits>
+#include <utility>
 
 namespace mppi
 {
@@ -72,31 +83,37 @@ __device__ inline T* kernargObject(kernarg_ptr_t base, const size_t offset)
   return const_cast<T*>(reinterpret_cast<const T*>((const char*)(base + offset)));
 }
 
-/** does plugin class T ask for its read-only members to be re-read from the kernel's argument block at every step
- *  (plugin/dynamics.hpp: refreshStepInvariants)? */
+/** Is plugin class T a pure parameter block on the device — no device method ever stores to a member (no per-lane state, no
+ *  cached pointers)?  `static constexpr bool MPPI_KERNARG_VIEWABLE = true;` in the class.  A role loop may then run T's per-step
+ *  methods on kernargObject<T>(...) itself — the argument block behind the opaque pointer — instead of on the kernel's copy (whose
+ *  parameters would be held in SGPRs, or pinned to VGPRs, across the loop).  The in-tree cost classes are; the samplers
+ *  (thread mapping, noise stream) and the network dynamics (weights in registers) are not. */
 template <class T, class = void>
-struct refreshes_step_invariants : std::false_type
+struct kernarg_viewable : std::false_type
 {
 };
 template <class T>
-struct refreshes_step_invariants<T, std::void_t<decltype(T::MPPI_REFRESH_STEP_INVARIANTS)>>
-  : std::integral_constant<bool, T::MPPI_REFRESH_STEP_INVARIANTS>
+struct kernarg_viewable<T, std::void_t<decltype(T::MPPI_KERNARG_VIEWABLE)>> : std::integral_constant<bool, T::MPPI_KERNARG_VIEWABLE>
 {
 };
 
-/** top of a step of a role loop: `obj` (the kernel's by-value argument at byte `offset` of the argument block, possibly carrying
- *  per-lane state in some of its members) takes its read-only members from the argument block again */
-template <class T>
-__device__ inline void refreshStepInvariants(T* obj, const size_t offset)
-{
-  if constexpr (refreshes_step_invariants<T>::value)
-    obj->refreshStepInvariants(kernargObject<T>(kernargBase(), offset));
-}
-
-/** which role loops read their plugin objects from the kernarg segment per step (A/B: -DMPPI_KERNARG_RELOAD=0 restores the
- *  objects-in-SGPRs form everywhere) */
+/** do the plugin classes that have an S() read their read-only members from the kernarg segment (A/B: -DMPPI_KERNARG_RELOAD=0
+ *  restores the parameters-in-SGPRs form everywhere) */
 #if !defined(MPPI_KERNARG_RELOAD)
 #define MPPI_KERNARG_RELOAD 1
+#endif
+/** S() source of the four-lane RACER dynamics classes (dynamics/racer_dubins/racer_dubins_elevation.hpp): 0 the object itself
+ *  (product), 1 the argument block, 2 a copy in LDS — the A/B of round 6 */
+#if !defined(MPPI_STEP_SOURCE_QUAD)
+#define MPPI_STEP_SOURCE_QUAD 0
+#endif
+/** do the cost waves of the role-pipelined kernels run a kernarg_viewable cost class off the argument block (1), or on a copy
+ *  pinned to VGPRs as in rounds 3-5 (0)?  A/B switch.  Measured (profiles/r06_c_*, r06_d_*): AutoRally-NN 175.3 -> 179.9 us per
+ *  launch, the RACER models +1 %, Robust AutoRally 394 -> 402; only the kernel that spills VGPRs to scratch gains (Robust
+ *  complete RACER 2953 -> 2704 us): the s_loads' results return out of order, every use waits for lgkmcnt(0) — LDS traffic
+ *  included — and that costs more than the VGPRs the copy occupies.  Off. */
+#if !defined(MPPI_COST_KERNARG_VIEW)
+#define MPPI_COST_KERNARG_VIEW 0
 #endif
 }  // namespace kernels
 }  // namespace mppi

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "mppi_amd.h"
+#include "kernarg_view.hpp"
 #include "rollout_kernel.hpp"
 #include "finalize_kernel.hpp"
 #include "rollout_pipeline_kernel.hpp"

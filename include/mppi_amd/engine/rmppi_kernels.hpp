@@ -32,6 +32,7 @@
 #define MPPI_AMD_RMPPI_KERNELS_HPP_
 
 #include "rollout_kernel.hpp"
+#include "kernarg_view.hpp"
 
 namespace mppi
 {

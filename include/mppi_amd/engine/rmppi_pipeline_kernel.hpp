@@ -129,17 +129,28 @@ __host__ inline RMPPIPipeRings rmppiPipelineRings(const DYN_T& dyn, const COST_T
 template <int REP, int N>
 __device__ inline void stripedStore(float* base, const float (&vals)[N], const int rep_lane)
 {
+  // The selects below work on a COPY of the values, not on the caller's array.  Straight on `vals`, the optimiser folds
+  // `select(c, load vals[j + q], load vals[j])` into `load vals[select(...)]` — the caller's array indexed by a lane-dependent
+  // value, which cannot live in registers: the state / record arrays of the dynamics waves went to SCRATCH MEMORY (7 + 9
+  // floats per lane and step in the Robust AutoRally kernel: the 64 B of private segment and the 1.45x HBM traffic that round 5
+  // attributed to spilled kernel arguments).  With the copy: 0 B, 114.7 -> 83.5 MB per launch = 1.06x the algorithmic bytes
+  // (profiles/r06_robust_pmc_hbm_traffic.json), the Robust complete RACER kernel 3399 -> 3099 us.  (Pinning the copy to VGPRs
+  // with an empty asm as well was 2 % slower on the AutoRally kernel: 403 against 396 us.)
+  float r[N];
+#pragma unroll
+  for (int j = 0; j < N; j++)
+    r[j] = vals[j];
 #pragma unroll
   for (int j = 0; j < N; j += REP)
   {
-    float v = vals[j];
+    float v = r[j];
     int field = j;
 #pragma unroll
     for (int q = 1; q < REP; q++)
     {
       if (j + q < N)
       {
-        v = (rep_lane == q) ? vals[j + q] : v;
+        v = (rep_lane == q) ? r[j + q] : v;
         field = (rep_lane == q) ? j + q : field;
       }
     }
@@ -328,12 +339,6 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
     const float* my_smp = smp_ring + (size_t)thread_idz * rings.sample_steps * C * 64;
     const bool last_state_only = fb_controller->lastStateOnly();
     auto dyn_step = [&](float* xc, float* xn, int t, const float* u_in) {
-#if MPPI_KERNARG_RELOAD
-      // the read-only members of the dynamics object, for THIS step: from the kernel's argument block inside the loop, not held
-      // in (spilled) SGPRs across it (kernarg_view.hpp) — five plugin objects' worth of kernel arguments compete for a wave's
-      // ~100 SGPRs here
-      refreshStepInvariants(dynamics, KernargLayout<DYN_T, COST_T, FB_T>::template offset<0>());
-#endif
 #pragma unroll
       for (int i = 0; i < C; i++)
       {
@@ -435,8 +440,11 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
     // PAIRS of steps in turn, evaluate ahead of the relay with the status they last saw and redo the pair (wave-uniform) when
     // a rollout arrives with another one.  Two accumulators travel through the relay here (rmppi_kernels.cu:797-812):
     //   nominal: A += running cost, B += likelihood-ratio cost;  real: A += running + likelihood ratio, B += running + feedback
+    constexpr bool COST_VIEW = MPPI_KERNARG_RELOAD && MPPI_COST_KERNARG_VIEW && kernarg_viewable<COST_T>::value;  // see rolloutPipelineRepKernel
+    constexpr size_t COST_OFFSET = KernargLayout<DYN_T, COST_T>::template offset<1>();
     COST_T costs_v = *costs;
-    vgprResident(costs_v);
+    if constexpr (!COST_VIEW)
+      vgprResident(costs_v);
     COST_T* costs_w = &costs_v;
     const float* my_out = out_ring + (size_t)thread_idz * rings.out_steps * F * 64;
     float* rl_a = relay_a + BX * thread_idz;
@@ -490,6 +498,8 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
       }
       float da[2] = { 0.0f, 0.0f }, db[2] = { 0.0f, 0.0f };
       auto evaluate = [&](int status) {
+        if constexpr (COST_VIEW)
+          costs_w = kernargObject<COST_T>(kernargBase(), COST_OFFSET);
 #pragma unroll
         for (int q = 0; q < 2; q++)
         {

@@ -31,6 +31,7 @@
 #include <math.h>
 #include <type_traits>
 #include "mppi_amd/plugin/managed.hpp"
+#include "kernarg_view.hpp"
 #include "mppi_amd/plugin/math_utils.hpp"
 #include "mppi_amd/plugin/parallel_utils.hpp"
 

@@ -512,9 +512,6 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
     /* ------------------------------------------------ dynamics wave ----------------------------------------------- */
     // the four samples of a trip are fetched up front (their LDS latency overlaps the first step's arithmetic)
     auto dyn_step = [&](float* xc, float* xn, int t, const float* u_in) {
-#if MPPI_KERNARG_RELOAD
-      refreshStepInvariants(dynamics, 0);  // see rolloutPipelineRepKernel / kernarg_view.hpp
-#endif
 #pragma unroll
       for (int i = 0; i < C; i++)
         u[i] = u_in[i];
@@ -947,11 +944,6 @@ __global__ void MPPI_PIPE_REP_BOUNDS(64 * (replicated_lanes<DYN_T>::value + PIPE
     /* ------------------------------------------------ dynamics waves ---------------------------------------------- */
     lds_counter_t my_prog = counters + 4 + wave;
     auto dyn_step = [&](float* xc, float* xn, int t, const float* u_in) {
-#if MPPI_KERNARG_RELOAD
-      // the read-only members of the dynamics object, for THIS step: from the kernel's argument block inside the loop
-      // (kernarg_view.hpp; plugin/dynamics.hpp: refreshStepInvariants), not held in — spilled — SGPRs across it
-      refreshStepInvariants(dynamics, 0);
-#endif
 #pragma unroll
       for (int i = 0; i < C; i++)
         u[i] = u_in[i];
@@ -1087,8 +1079,14 @@ __global__ void MPPI_PIPE_REP_BOUNDS(64 * (replicated_lanes<DYN_T>::value + PIPE
     // same plugin calls with the same inputs as the in-order evaluation, so the costs are the same bits.
     // (Round 2 evaluated inside the relay: the in-kernel timers showed that chain — 2 x 3100 cycles per pair — busy for
     // the whole launch, as long as the dynamics waves themselves.)
+    // (Round 6: a cost class that is a pure parameter block — kernarg_viewable — is not copied at all: every evaluation runs on
+    // the kernel's argument block behind an opaque pointer, the parameters arrive by s_load where they are used and occupy
+    // neither SGPRs across the loop nor VGPRs.)
+    constexpr bool COST_VIEW = MPPI_KERNARG_RELOAD && MPPI_COST_KERNARG_VIEW && kernarg_viewable<COST_T>::value;
+    constexpr size_t COST_OFFSET = KernargLayout<DYN_T, COST_T>::template offset<1>();
     COST_T costs_v = *costs;
-    vgprResident(costs_v);
+    if constexpr (!COST_VIEW)
+      vgprResident(costs_v);
     COST_T* costs_w = &costs_v;
     int seen_dyn[DW], seen_cost = 0;
 #pragma unroll
@@ -1119,6 +1117,8 @@ __global__ void MPPI_PIPE_REP_BOUNDS(64 * (replicated_lanes<DYN_T>::value + PIPE
       PIPE_T(tm.stop(3);)  // slot 3: fetching outputs / controls of the pair
       float cq[2] = { 0.0f, 0.0f };
       auto evaluate = [&](int status) {
+        if constexpr (COST_VIEW)
+          costs_w = kernargObject<COST_T>(kernargBase(), COST_OFFSET);
 #pragma unroll
         for (int q = 0; q < 2; q++)
         {
