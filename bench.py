@@ -406,6 +406,42 @@ def robust_di_leg(device):
                       "x 2 systems"}
 
 
+def robust_racer_leg(device):
+    """Robust MPPI on the elevation-map RACER models, K=16384, T=100: the role-pipelined rollout kernel per launch (HIP events)
+    — the kernels whose dynamics waves are short of REGISTERS (profiles/r06_robust_racer_ab.json)"""
+    import numpy as np
+    import mppi_generic_amd as m
+    from test_racer_dubins_lstm_unc import uncertainty_cfg
+    from test_racer_dubins_suspension import suspension_cfg
+    out = {"workload": "RobustMPPI (nominal + real system) on RacerDubinsElevationSuspension and on the complete RACER model "
+                       "(RacerDubinsElevationLSTMUncertainty), QuadraticCost, K=16384, T=100, 9 x 32 candidate rollouts; "
+                       "rollout kernel per launch"}
+    for name, mk in (("suspension", suspension_cfg), ("complete_model", uncertainty_cfg)):
+        cfg = mk(K=16384, T=100, D=2)
+        eng = m.RobustMPPIController(cfg["model"], cfg["K"], cfg["T"], cfg["dt"], cfg["lambda_"], 0.0, 1, seed=42, device=device)
+        eng.setDynamicsParams(cfg["dyn"])
+        eng.setCostParams(cfg["cost"])
+        for bname, blob in cfg["blobs"].items():
+            eng.setModelBlob(bname, blob)
+        if cfg["ranges"] is not None:
+            eng.setControlRanges(cfg["ranges"])
+        eng.setSamplingParams(cfg["std_dev"], [0.2, 0.1])
+        eng.setRMPPIParams(2000.0, 9, 32)
+        g = np.random.default_rng(5).uniform(-0.3, 0.3, (cfg["T"], eng.STATE_DIM, eng.CONTROL_DIM)).astype(np.float32)
+        x = cfg["x0"].copy()
+        for _ in range(3):
+            eng.updateImportanceSamplingControl(x, 1)
+            eng.setFeedbackGains(g)
+            eng.computeControl(x, 1)
+        best = None
+        for _ in range(3):
+            _, roll = eng.timeIterations(10)
+            best = roll if best is None else min(best, roll)
+        out[name] = {"rollout_kernel_us": round(best / 10 * 1e3, 1), "finite": bool(np.isfinite(eng.getControlSeq()).all())}
+        eng.close()
+    return out
+
+
 def autorally_leg(device, with_cpu_baseline=True):
     """AutoRally NeuralNetModel (FNN 6-32-32-4, synthetic weights) + ARStandardCost, K=16384, T=150, one GPU:
     iterations/s and the MFMA roofline of the NN forward (F_alg = 2 * sum(MAC) * K * T)."""
@@ -1103,7 +1139,8 @@ def main():
         if not args.primary_only and world == 1 and args.workload == "cartpole":
             for key, leg_fn in (("autorally_nn", autorally_leg), ("lstm_colored", lstm_colored_leg), ("di_tube", di_tube_leg),
                                 ("racer_elevation", racer_elevation_leg), ("robust_autorally_nn", robust_autorally_leg),
-                                ("robust_double_integrator", robust_di_leg), ("reference_order_reduction", reference_order_leg)):
+                                ("robust_double_integrator", robust_di_leg), ("robust_racer", robust_racer_leg),
+                                ("reference_order_reduction", reference_order_leg)):
                 try:
                     if key in ("autorally_nn", "di_tube", "lstm_colored"):
                         out[key] = leg_fn(local_rank, with_cpu_baseline=not args.no_cpu_baseline)

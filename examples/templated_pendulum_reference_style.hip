@@ -49,6 +49,7 @@ static int run(const char* label, int steps, int lanes)
   controller.setParams(controller_params);
 
   RefPendulumDynamics::state_array x = RefPendulumDynamics::state_array::Zero();
+  x[0] = 0.3f;  // off the hanging equilibrium (where both directions cost the same and MPPI's mean torque is zero)
   double sum = 0.0;
   try
   {

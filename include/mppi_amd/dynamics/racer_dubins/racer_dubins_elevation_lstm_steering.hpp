@@ -240,6 +240,12 @@ public:
   /** S() of RacerDubinsElevationImpl: 0 = the object itself.  1 (argument block, s_load) and 2 (copy in LDS, ds_read) remove
    *  most of the spilled-SGPR reads of the step loop and are SLOWER (profiles/r06_step_source_ab.json) — A/B: -DMPPI_STEP_SOURCE_QUAD=1|2 */
   static constexpr int MPPI_STEP_SOURCE = MPPI_STEP_SOURCE_QUAD;
+  /** helper waves of the role-pipelined Robust kernel for this model (engine/rmppi_pipeline_kernel.hpp): one sampler and ONE cost
+   *  wave per system = 11 waves per block = 3 per SIMD = 168 VGPRs per lane instead of 15 waves / 128 (K = 16384, T = 100, us per
+   *  launch: elevation 356 -> 352, LSTM steering 601 -> 489, suspension 1013 -> 615; two cost waves per system = 13 waves change
+   *  nothing — profiles/r06_robust_racer_ab.json) */
+  static constexpr int MPPI_RMPPI_PIPE_SAMPLERS = 1;
+  static constexpr int MPPI_RMPPI_PIPE_COSTS = 1;
   using ELEVATION = RacerDubinsElevationImpl<RacerDubinsElevationLSTMSteeringQuad>;
   using PARAMS_T = RacerDubinsElevationParams;
   static constexpr int REPLICATED_LANES = 4;

@@ -357,19 +357,25 @@ public:
  * per 16-lane row and fetched with DPP row broadcasts), the static settling as in the elevation model's four-lane form.
  * Same arithmetic per value as the one-lane class above.
  */
-class RacerDubinsElevationLSTMUncertaintyQuad
-  : public RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationLSTMUncertaintyQuad, RacerDubinsElevationUncertaintyParams>
+template <class CLASS_T>
+class RacerDubinsElevationLSTMUncertaintyQuadImpl
+  : public RacerDubinsElevationSuspensionQuadImpl<CLASS_T, RacerDubinsElevationUncertaintyParams>
 {
 public:
-  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
-  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
-  /** S() of RacerDubinsElevationImpl: 0 = the object itself.  1 (argument block, s_load) and 2 (copy in LDS, ds_read) remove
-   *  most of the spilled-SGPR reads of the step loop and are SLOWER (profiles/r06_step_source_ab.json) — A/B: -DMPPI_STEP_SOURCE_QUAD=1|2 */
-  static constexpr int MPPI_STEP_SOURCE = MPPI_STEP_SOURCE_QUAD;
   using PARAMS_T = RacerDubinsElevationUncertaintyParams;
-  using QUAD = RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationLSTMUncertaintyQuad, PARAMS_T>;
+  using QUAD = RacerDubinsElevationSuspensionQuadImpl<CLASS_T, PARAMS_T>;
   using MEAN_NET = mppi::LSTMQuadRows<12, 20, 2>;
   using UNC_NET = mppi::LSTMQuadRows<13, 20, 5>;
+  using StepTrig = typename QUAD::StepTrig;
+  using MATH = typename QUAD::MATH;
+  static constexpr int STATE_DIM = QUAD::STATE_DIM, CONTROL_DIM = QUAD::CONTROL_DIM, OUTPUT_DIM = QUAD::OUTPUT_DIM, XD = QUAD::XD;
+  using QUAD::copyFrom;
+  using QUAD::fromReplica;
+  using QUAD::quadSteering;
+  using QUAD::quadSuspension;
+  using QUAD::quadTrig;
+  using QUAD::replica;
+  using QUAD::speedRegime;
 
   const float* mean_lstm_d_ = nullptr;
   const float* mean_fnn_d_ = nullptr;
@@ -378,7 +384,7 @@ public:
   MEAN_NET mean_ = {};
   UNC_NET unc_ = {};
 
-  RacerDubinsElevationLSTMUncertaintyQuad(const RacerDubinsElevationLSTMUncertainty& other) : QUAD(other.stream_)
+  RacerDubinsElevationLSTMUncertaintyQuadImpl(const RacerDubinsElevationLSTMUncertainty& other) : QUAD(other.stream_)
   {
     copyFrom(other);
     mean_lstm_d_ = other.mean_lstm_d_;
@@ -492,6 +498,51 @@ public:
     output[RDE_O(WHEEL_FORCE_FWD_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_FWD_MAX)];
     output[RDE_O(WHEEL_FORCE_SIDE_MAX)] = wheel_out[RDE_O(WHEEL_FORCE_SIDE_MAX)];
     MATH::setSuspensionOutputs(p, xd, xn, output);
+  }
+};
+
+class RacerDubinsElevationLSTMUncertaintyQuadRobust;
+/** the four-lane form the rollout / re-rollout / init-eval kernels run */
+class RacerDubinsElevationLSTMUncertaintyQuad
+  : public RacerDubinsElevationLSTMUncertaintyQuadImpl<RacerDubinsElevationLSTMUncertaintyQuad>
+{
+public:
+  /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
+  /** S() of RacerDubinsElevationImpl: 0 = the object itself.  1 (argument block, s_load) and 2 (copy in LDS, ds_read) remove
+   *  most of the spilled-SGPR reads of the step loop and are SLOWER here (profiles/r06_step_source_ab.json) — A/B:
+   *  -DMPPI_STEP_SOURCE_QUAD=1|2 */
+  static constexpr int MPPI_STEP_SOURCE = MPPI_STEP_SOURCE_QUAD;
+  /** the form the role-pipelined ROBUST rollout kernel runs instead (engine/model_instance.hpp: withRmppiPipelineDynamics) */
+  using RMPPI_PIPELINE_FORM = RacerDubinsElevationLSTMUncertaintyQuadRobust;
+  RacerDubinsElevationLSTMUncertaintyQuad(const RacerDubinsElevationLSTMUncertainty& other)
+    : RacerDubinsElevationLSTMUncertaintyQuadImpl<RacerDubinsElevationLSTMUncertaintyQuad>(other)
+  {
+  }
+};
+
+/**
+ * The same model for rolloutRMPPIPipelineKernel — the one kernel where registers, not the dependent chain, are what is short:
+ * two systems x four dynamics waves + helpers = 15 waves per block leave every wave 128 VGPRs, and this model's dynamics waves
+ * then spill 200+ of them to scratch memory (round 5: 3399 us per launch at K = 16384, T = 100 — 4.2 x the one-system kernel).
+ * Three choices that LOSE everywhere else win here (profiles/r06_robust_racer_ab.json):
+ *   - one sampler wave and ONE cost wave per system: 11 waves = 3 per SIMD = 168 VGPRs (spilled 210 -> 99; 3072 -> 2047 us);
+ *   - the read-only members through the kernel's argument block (S() source 1) and the cost class off the argument block instead
+ *     of a VGPR-pinned copy: the parameters leave the register file altogether (spilled 99 -> 63-68; 2047 -> 1598 us).
+ * Same arithmetic, same bits (tests/test_full_size_parity.py::test_robust_complete_racer_4096x100_vs_oracle, tests/test_rmppi.py).
+ */
+class RacerDubinsElevationLSTMUncertaintyQuadRobust
+  : public RacerDubinsElevationLSTMUncertaintyQuadImpl<RacerDubinsElevationLSTMUncertaintyQuadRobust>
+{
+public:
+  static constexpr bool MPPI_BARRIER_FREE_STEP = true;
+  static constexpr int MPPI_STEP_SOURCE = MPPI_KERNARG_RELOAD ? 1 : 0;
+  static constexpr bool MPPI_RMPPI_COST_VIEW = true;
+  static constexpr int MPPI_RMPPI_PIPE_SAMPLERS = 1;
+  static constexpr int MPPI_RMPPI_PIPE_COSTS = 1;
+  RacerDubinsElevationLSTMUncertaintyQuadRobust(const RacerDubinsElevationLSTMUncertainty& other)
+    : RacerDubinsElevationLSTMUncertaintyQuadImpl<RacerDubinsElevationLSTMUncertaintyQuadRobust>(other)
+  {
   }
 };
 

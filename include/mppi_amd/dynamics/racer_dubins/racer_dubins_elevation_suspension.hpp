@@ -523,6 +523,14 @@ public:
   /** S() of RacerDubinsElevationImpl: 0 = the object itself.  1 (argument block, s_load) and 2 (copy in LDS, ds_read) remove
    *  most of the spilled-SGPR reads of the step loop and are SLOWER (profiles/r06_step_source_ab.json) — A/B: -DMPPI_STEP_SOURCE_QUAD=1|2 */
   static constexpr int MPPI_STEP_SOURCE = MPPI_STEP_SOURCE_QUAD;
+  /** helper waves of the role-pipelined Robust kernel for this model (engine/rmppi_pipeline_kernel.hpp): one sampler and ONE cost
+   *  wave per system = 11 waves per block = 3 per SIMD = 168 VGPRs per lane instead of 15 waves / 128 (K = 16384, T = 100, us per
+   *  launch: elevation 356 -> 352, LSTM steering 601 -> 489, suspension 1013 -> 615; two cost waves per system = 13 waves change
+   *  nothing; with 168 VGPRs this model no longer spills any, and a RMPPI_PIPELINE_FORM reading its parameters from the argument
+   *  block — what the complete model's Robust kernel gains another 22 % from — makes no difference here: 618 us —
+   *  profiles/r06_robust_racer_ab.json) */
+  static constexpr int MPPI_RMPPI_PIPE_SAMPLERS = 1;
+  static constexpr int MPPI_RMPPI_PIPE_COSTS = 1;
   using PARAMS_T = RacerDubinsElevationSuspensionParams;
   RacerDubinsElevationSuspensionQuad(const RacerDubinsElevationSuspension& other)
     : RacerDubinsElevationSuspensionQuadImpl<RacerDubinsElevationSuspensionQuad>(other.stream_)

@@ -524,7 +524,19 @@ struct ModelT : ModelBase
     else
       return rmppiUseFast();
   }
-  /** f(pipe_dyn): the dynamics object the pipelined kernels take — the replicated-lane form, or the model itself */
+  /** f(pipe_dyn): the dynamics object the pipelined kernels take — the replicated-lane form (or the form IT names for this
+   *  kernel: `using RMPPI_PIPELINE_FORM = ...` — a class of the same arithmetic whose trade-offs are made for a block of 11-15
+   *  waves at 128-168 VGPRs each: dynamics/racer_dubins/racer_dubins_elevation_lstm_unc.hpp), or the model itself */
+  template <class T, class = void>
+  struct rmppi_pipeline_form
+  {
+    using type = T;
+  };
+  template <class T>
+  struct rmppi_pipeline_form<T, std::void_t<typename T::RMPPI_PIPELINE_FORM>>
+  {
+    using type = typename T::RMPPI_PIPELINE_FORM;
+  };
   template <class F>
   auto withRmppiPipelineDynamics(F&& f)
   {
@@ -532,7 +544,7 @@ struct ModelT : ModelBase
       return f(dyn);
     else
     {
-      DYN_FAST_T fast(dyn);
+      typename rmppi_pipeline_form<DYN_FAST_T>::type fast(dyn);
       return f(fast);
     }
   }

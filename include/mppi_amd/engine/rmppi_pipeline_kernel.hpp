@@ -59,14 +59,47 @@ namespace kernels
 #if !defined(MPPI_RMPPI_PIPE_NC1)
 #define MPPI_RMPPI_PIPE_NC1 3
 #endif
+/** A dynamics class may name its own helper-wave counts for this kernel (`static constexpr int MPPI_RMPPI_PIPE_SAMPLERS = ..,
+ *  MPPI_RMPPI_PIPE_COSTS = ..` — cost waves PER SYSTEM): the counts above were tuned on models whose step is short (AutoRally-NN:
+ *  the cost waves' chain sets the pace).  A model whose dynamics step is thousands of instructions wants the opposite trade —
+ *  FEWER waves per block, because the block's wave count sets the register file share of every wave (15 waves = 4 per SIMD =
+ *  128 VGPRs each; 11 waves = 3 per SIMD = 168) and its dynamics waves spill. */
+template <class T, class = void>
+struct rmppi_pipe_samplers_of : std::integral_constant<int, 0>
+{
+};
+template <class T>
+struct rmppi_pipe_samplers_of<T, std::void_t<decltype(T::MPPI_RMPPI_PIPE_SAMPLERS)>> : std::integral_constant<int, T::MPPI_RMPPI_PIPE_SAMPLERS>
+{
+};
+template <class T, class = void>
+struct rmppi_pipe_costs_of : std::integral_constant<int, 0>
+{
+};
+template <class T>
+struct rmppi_pipe_costs_of<T, std::void_t<decltype(T::MPPI_RMPPI_PIPE_COSTS)>> : std::integral_constant<int, T::MPPI_RMPPI_PIPE_COSTS>
+{
+};
+template <class T, class = void>
+struct rmppi_cost_view_of : std::false_type
+{
+};
+template <class T>
+struct rmppi_cost_view_of<T, std::void_t<decltype(T::MPPI_RMPPI_COST_VIEW)>> : std::integral_constant<bool, T::MPPI_RMPPI_COST_VIEW>
+{
+};
 template <class DYN_T>
 __host__ __device__ constexpr int rmppiPipeSamplers()
 {
+  if (rmppi_pipe_samplers_of<DYN_T>::value > 0)
+    return rmppi_pipe_samplers_of<DYN_T>::value;
   return replicated_lanes<DYN_T>::value > 1 ? MPPI_RMPPI_PIPE_NS : MPPI_RMPPI_PIPE_NS1;
 }
 template <class DYN_T>
 __host__ __device__ constexpr int rmppiPipeCosts()
 {
+  if (rmppi_pipe_costs_of<DYN_T>::value > 0)
+    return rmppi_pipe_costs_of<DYN_T>::value;
   return replicated_lanes<DYN_T>::value > 1 ? MPPI_RMPPI_PIPE_NC : MPPI_RMPPI_PIPE_NC1;
 }
 
@@ -134,7 +167,7 @@ __device__ inline void stripedStore(float* base, const float (&vals)[N], const i
   // value, which cannot live in registers: the state / record arrays of the dynamics waves went to SCRATCH MEMORY (7 + 9
   // floats per lane and step in the Robust AutoRally kernel: the 64 B of private segment and the 1.45x HBM traffic that round 5
   // attributed to spilled kernel arguments).  With the copy: 0 B, 114.7 -> 83.5 MB per launch = 1.06x the algorithmic bytes
-  // (profiles/r06_robust_pmc_hbm_traffic.json), the Robust complete RACER kernel 3399 -> 3099 us.  (Pinning the copy to VGPRs
+  // (profiles/r06_robust_hbm_traffic_pmc.json), the Robust complete RACER kernel 3399 -> 3099 us.  (Pinning the copy to VGPRs
   // with an empty asm as well was 2 % slower on the AutoRally kernel: 403 against 396 us.)
   float r[N];
 #pragma unroll
@@ -440,7 +473,10 @@ __global__ void __launch_bounds__(64 * rmppiPipelineWaves<DYN_T>())
     // PAIRS of steps in turn, evaluate ahead of the relay with the status they last saw and redo the pair (wave-uniform) when
     // a rollout arrives with another one.  Two accumulators travel through the relay here (rmppi_kernels.cu:797-812):
     //   nominal: A += running cost, B += likelihood-ratio cost;  real: A += running + likelihood ratio, B += running + feedback
-    constexpr bool COST_VIEW = MPPI_KERNARG_RELOAD && MPPI_COST_KERNARG_VIEW && kernarg_viewable<COST_T>::value;  // see rolloutPipelineRepKernel
+    // the cost class off the argument block instead of a VGPR-pinned copy (rolloutPipelineRepKernel; kernarg_view.hpp): a loss
+    // wherever registers are not what is short — so only where the dynamics form asks for it (MPPI_RMPPI_COST_VIEW)
+    constexpr bool COST_VIEW = MPPI_KERNARG_RELOAD && (MPPI_COST_KERNARG_VIEW || rmppi_cost_view_of<DYN_T>::value) &&
+                               kernarg_viewable<COST_T>::value;
     constexpr size_t COST_OFFSET = KernargLayout<DYN_T, COST_T>::template offset<1>();
     COST_T costs_v = *costs;
     if constexpr (!COST_VIEW)

@@ -70,6 +70,13 @@ MPPI_HD static inline void box_muller(uint32_t xa, uint32_t xb, float* z0, float
 {
   const float u1 = u01(xa);
   const float u2 = u01(xb);
+#if defined(MPPI_EXPERIMENT_CHEAP_NORMAL)
+  /* A/B ONLY (never in a product build): a draw of a third of the instructions — is the Cartpole dynamics wave waiting for its
+   * sampler waves?  (tools/ab_kernels.py cartpole on `buildlib.py --variant cheap cartpole.hip -DMPPI_EXPERIMENT_CHEAP_NORMAL`) */
+  *z0 = u1 - 0.5f;
+  *z1 = u2 - 0.5f;
+  return;
+#endif
   const float r = det::sqrt(-2.0f * det::log(u1));
   float s, c;
   det::sincos(MPPI_DET_TWO_PI * u2, &s, &c);

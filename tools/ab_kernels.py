@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rollout-kernel and iteration times (HIP events on the engine's stream, best of several passes) of the benchmarked
 workloads for the library MPPI_AMD_LIB selects — the A/B companion of `buildlib.py --variant`.
-Usage: [MPPI_AMD_LIB=.../libmppi_amd_<tag>.so] python tools/ab_kernels.py [cartpole autorally ditube lstm racer robust_ar robust_di robust_racer] [--json out]"""
+Usage: [MPPI_AMD_LIB=.../libmppi_amd_<tag>.so] python tools/ab_kernels.py [cartpole autorally ditube lstm racer robust_ar robust_di robust_racer robust_racer_all] [--json out]"""
 import json
 import os
 import sys
@@ -89,6 +89,14 @@ def main():
         cfg["control_cost_coeff"] = [0.3, 0.2]
         cfg["ranges"] = [[-3.0, 3.0], [-3.0, 3.0]]
         res["robust_di_8192x150"] = robust(cfg, 25.0, 50)
+    if "robust_racer_all" in which:
+        from test_racer_dubins_elevation import elevation_cfg
+        from test_racer_dubins_lstm_steering import steering_cfg
+        from test_racer_dubins_suspension import suspension_cfg
+        for name, mk in (("elevation", elevation_cfg), ("lstm_steering", steering_cfg), ("suspension", suspension_cfg)):
+            cfg = mk(K=16384, T=100, D=2)
+            cfg["control_cost_coeff"] = [0.2, 0.1]
+            res["robust_racer_%s_16384x100" % name] = robust(cfg, 2000.0, 10, passes=3)
     if "robust_racer" in which:
         from test_racer_dubins_lstm_unc import uncertainty_cfg
         cfg = uncertainty_cfg(K=16384, T=100, D=2)
