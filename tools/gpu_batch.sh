@@ -1,3 +1,7 @@
 set -x
-python tools/ab_kernels.py robust_racer_all robust_racer racer 2>&1 | tail -n 8
-timeout 900 python -m pytest tests/test_rmppi.py tests/test_full_size_parity.py tests/test_handover.py tests/test_racer_dubins_suspension.py tests/test_racer_dubins_lstm_unc.py -m gpu -x -q 2>&1 | tail -n 4
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > gpurun_out/r06_n_gputest.log
+tail -n 4 gpurun_out/r06_n_gputest.log
+bash tools/profile_bench.sh > gpurun_out/r06_n_profile.log 2>&1
+tail -n 5 gpurun_out/r06_n_profile.log
+ls gpurun_out/prof
