@@ -283,6 +283,24 @@ class MPPIController:
         self.num_rollouts_local, self.rollout_offset = kl.value, ko.value
         self.num_rollouts, self.num_timesteps = num_rollouts, num_timesteps
         self.dt, self.lambda_, self.alpha = dt, lambda_, alpha
+        self._init_fast_calls()
+
+    def _init_fast_calls(self):
+        """The three calls a control loop makes every cycle (computeControl, getControlSeq, slide) with raw-pointer signatures and
+        persistent staging arrays: a numpy.ctypeslib.ndpointer argument costs ~3.3 us of marshalling PER CALL on this class of
+        host (measured: 3.31 us against 0.21 us for an integer address) — 7-8 us of a 45 us closed-loop cycle were this wrapper,
+        not the engine.  Same library entry points, same values; everything else keeps the checked ndpointer signatures."""
+        def raw(name, *argtypes):
+            addr = C.cast(getattr(self._lib, name), C.c_void_p).value
+            return C.CFUNCTYPE(C.c_int, *argtypes)(addr)
+        self._fast_compute = raw("mppi_compute_control", C.c_void_p, C.c_void_p, C.c_int)
+        self._fast_get_control = raw("mppi_get_control_seq", C.c_void_p, C.c_void_p)
+        self._fast_slide = raw("mppi_slide", C.c_void_p, C.c_int)
+        self._hv = self._h.value
+        self._x_stage = np.zeros(2 * self.STATE_DIM, np.float32)  # [S], or [D][S] where a caller hands both systems' states
+        self._x_ptr = self._x_stage.ctypes.data
+        self._u_stage = np.empty((self.num_timesteps, self.CONTROL_DIM), np.float32)
+        self._u_ptr = self._u_stage.ctypes.data
 
     def launchCounts(self):
         """(rollout launches, reduction-stage launches) of this handle since creation (mppi_get_launch_counts)"""
@@ -299,6 +317,7 @@ class MPPIController:
         if getattr(self, "_h", None) and self._h.value:
             self._lib.mppi_destroy(self._h)
             self._h = C.c_void_p()
+            self._hv = None  # (a call on a closed controller reaches the library with a null handle: MPPI_ERR_INVALID_ARG)
 
     def __del__(self):
         try:
@@ -412,12 +431,22 @@ class MPPIController:
         return eps
 
     def computeControl(self, state, optimization_stride=1):
-        self._check(self._lib.mppi_compute_control(self._h, _f32(state).reshape(-1), optimization_stride))
+        if type(state) is not np.ndarray:
+            state = np.asarray(state, np.float32)
+        n = state.size
+        if n > self._x_stage.size:  # (not a state of this model: let the checked path say so)
+            self._check(self._lib.mppi_compute_control(self._h, _f32(state).reshape(-1), optimization_stride))
+            return
+        self._x_stage[:n] = state if state.ndim == 1 else state.reshape(-1)
+        st = self._fast_compute(self._hv, self._x_ptr, optimization_stride)
+        if st != 0:
+            self._check(st)
 
     def getControlSeq(self):
-        u = np.empty((self.num_timesteps, self.CONTROL_DIM), np.float32)
-        self._check(self._lib.mppi_get_control_seq(self._h, u))
-        return u
+        st = self._fast_get_control(self._hv, self._u_ptr)
+        if st != 0:
+            self._check(st)
+        return self._u_stage.copy()
 
     def getTargetStateSeq(self):
         x = np.empty((self.num_timesteps, self.STATE_DIM), np.float32)
@@ -430,7 +459,9 @@ class MPPIController:
         return y
 
     def slideControlSequence(self, steps):
-        self._check(self._lib.mppi_slide(self._h, steps))
+        st = self._fast_slide(self._hv, steps)
+        if st != 0:
+            self._check(st)
 
     def getSampledCostSeq(self):
         costs = np.empty((self.num_systems, self.num_rollouts_local), np.float32)
