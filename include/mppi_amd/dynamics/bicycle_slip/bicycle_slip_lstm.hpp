@@ -133,6 +133,14 @@ class BicycleSlipLSTMMFMA : public MPPI_internal::Dynamics<BicycleSlipLSTMMFMA, 
 public:
   /** no block barrier in the per-step device methods: may run on the role-separated kernels (plugin/parallel_utils.hpp) */
   static constexpr bool MPPI_BARRIER_FREE_STEP = true;
+  /**
+   * Helper waves of the role-pipelined Robust kernel for this model (engine/rmppi_pipeline_kernel.hpp): one sampler and
+   * one cost wave per block beside the eight dynamics waves, so that the block fits the register budget of the MFMA
+   * network without spills; measured 760 -> 628 us on the 16384 x 150 Robust launch (2 cost waves: 708 us),
+   * profiles/r06_robust_racer_ab.json
+   */
+  static constexpr int MPPI_RMPPI_PIPE_SAMPLERS = 1;
+  static constexpr int MPPI_RMPPI_PIPE_COSTS = 1;
   using PARENT_CLASS = MPPI_internal::Dynamics<BicycleSlipLSTMMFMA, BicycleSlipLSTMParams>;
   static const int DYNAMICS_DIM = 4;
   static constexpr int REPLICATED_LANES = 4;

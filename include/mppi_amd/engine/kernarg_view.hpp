@@ -15,24 +15,32 @@
  * whole block is resident after the first step; SMEM instructions do not take VALU issue slots) into SGPRs that are free again
  * afterwards.  The address space survives the asm (address space 4 = constant): the loads stay scalar.
  *
- * Two things it cannot be used for, both found the hard way in round 6 (profiles/r06_b_*):
+ * Three uses that do not work, all found the hard way in round 6 (profiles/r06_step_source_ab.json):
  *   - as the OBJECT the per-step methods run on (`DYN_T* dynamics = kernargObject<DYN_T>(...)`) when the class keeps per-lane
  *     state in members: the matrix-core network models and the four-lane RACER models load their weights into registers in
  *     initializeDynamics — members of the kernel's local copy, which the argument block knows nothing of (AutoRally's costs came
  *     out wrong by 3e8 ulp, a null pointer was dereferenced);
  *   - as a per-step COPY of the read-only members (`params_ = src->params_`): the copy is loaded at the top of the step and is
  *     live from there to every use — spilled within the step instead of across the loop (642 v_readlane per pair of steps
- *     against 680 before; the view proper: 220).
+ *     against 680 before; the view proper: 220);
  *   - as a pointer MEMBER the kernels set (`step_src_`): writing any member of a by-value argument makes it a private copy, and a
  *     copy with run-time-indexed member arrays cannot be split into registers — the whole object moved to scratch memory in the
  *     blockDim.y > 1 kernels.
  * What works: the class routes the READS of its read-only members through a function, S(), that returns the argument block
- * behind the opaque pointer (dynamics/racer_dubins/racer_dubins_elevation.hpp); per-lane state stays in the object.
+ * behind the opaque pointer (dynamics/racer_dubins/racer_dubins_elevation.hpp); per-lane state stays in the object.  A stateless
+ * class (the cost classes: kernarg_viewable<T>) may be viewed whole.
+ *
+ * What it buys, measured: nothing where registers are not short — the step loops are bound by the latency of
+ * their dependent VALU chain, the v_readlanes sit in its shadow, and an s_load + s_waitcnt in the chain is slower than a
+ * v_readlane beside it (the vanilla kernels got 6-18 % SLOWER with the view on; it is off for them).  It pays in the Robust
+ * kernels of the RACER models, which are VGPR-starved: fewer SGPR-spill lanes let the register allocator keep the vector state
+ * out of scratch (complete model 3399 -> 1565 us together with the helper-wave traits).  Hence the per-class switches:
+ * MPPI_STEP_SOURCE in the RACER classes, MPPI_RMPPI_COST_VIEW, and the A/B macros below.
  *
  * Argument offsets: the AMDGPU HIP ABI lays the explicit arguments out in order, each at the next multiple of its alignment,
  * starting at offset 0 of the segment (hidden arguments follow the explicit ones) — KernargLayout<Ts...>::offset<I>().
- * tests/test_kernarg_layout.py checks the formula against the `.offset` fields the compiler wrote into the code object's
- * metadata for every kernel that uses it.
+ * tests/test_kernarg_layout.py checks the formula against the `.offset` fields the compiler wrote into the metadata of a probe
+ * kernel's code object (tests/probes/kernarg_layout_probe.hip) with arguments of mixed size and alignment.
  */
 #ifndef MPPI_AMD_ENGINE_KERNARG_VIEW_HPP_
 #define MPPI_AMD_ENGINE_KERNARG_VIEW_HPP_

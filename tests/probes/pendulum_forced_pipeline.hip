@@ -15,3 +15,18 @@ using ForcedModel = ModelT<RefPendulumDynamics, RefPendulumCost, ForcedSampler, 
                            /*PIPELINE=*/true>;
 static_assert(ForcedModel::ROLE_SEPARATED && !ForcedModel::BARRIER_FREE_DECLARED, "the probe must be the refused case");
 MPPI_REGISTER_MODEL("user_pendulum_forced_pipeline", MPPI_SAMPLER_GAUSSIAN, ForcedModel, 64, 1)
+
+/* The same instantiation through the UNCHECKED entry point (what a plugin built before round 6's macro, or a hand-written
+ * registration, would call): it does enter the table — and mppi_create refuses it (ModelBase::undeclaredBarrierFreePlugins), so the
+ * second line of defence is tested too (tests/test_plugin_model.py, on a GPU: creation needs a device). */
+namespace
+{
+struct UncheckedRegistrar
+{
+  UncheckedRegistrar()
+  {
+    (void)mppi_register_model("user_pendulum_forced_pipeline_unchecked", MPPI_SAMPLER_GAUSSIAN, &modelFactory<ForcedModel, 64, 1>,
+                              engineAbiFingerprint());
+  }
+} unchecked_registrar;
+}  // namespace

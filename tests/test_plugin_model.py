@@ -92,6 +92,20 @@ def test_barrier_bearing_model_forced_onto_the_pipeline_is_refused_at_registrati
     assert b"different mppi_amd/engine/model_instance.hpp" in plugin.mppi_last_error(None)
 
 
+@pytest.mark.gpu
+def test_barrier_bearing_pipeline_model_registered_unchecked_is_refused_at_create(gpu, plugin):
+    """the second line of defence: the probe library also registers the forced instantiation through the UNCHECKED
+    mppi_register_model (which cannot know what the factory builds) — it enters the table, and mppi_create turns it down
+    (MPPI_ERR_INVALID_ARG, naming the classes without MPPI_BARRIER_FREE_STEP) before anything is launched"""
+    src = os.path.join(REPO, "tests", "probes", "pendulum_forced_pipeline.hip")
+    out = build_plugin(src, os.path.join(OUT_DIR, "libpendulum_forced_pipeline.so"))
+    plugin.mppi_load_plugin(out.encode())  # (reports the checked registration's refusal; the unchecked one went through)
+    assert "user_pendulum_forced_pipeline_unchecked" in plugin.mppi_list_models().decode().split("\n")
+    with pytest.raises(m.MPPIError) as e:
+        m.VanillaMPPIController("user_pendulum_forced_pipeline_unchecked", 256, 20, 0.02, 1.0)
+    assert e.value.status == 1 and "MPPI_BARRIER_FREE_STEP" in str(e.value) and "Dynamics" in str(e.value), str(e.value)
+
+
 def test_in_tree_models_declare_barrier_free_steps_and_reference_style_ones_do_not():
     """the trait the engine decides on (plugin/parallel_utils.hpp: barrier_free_step): compiled as static_asserts — host only"""
     probe = os.path.join(OUT_DIR, "barrier_trait_probe.hip")

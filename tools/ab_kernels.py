@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rollout-kernel and iteration times (HIP events on the engine's stream, best of several passes) of the benchmarked
 workloads for the library MPPI_AMD_LIB selects — the A/B companion of `buildlib.py --variant`.
-Usage: [MPPI_AMD_LIB=.../libmppi_amd_<tag>.so] python tools/ab_kernels.py [cartpole autorally ditube lstm racer robust_ar robust_di robust_racer robust_racer_all] [--json out]"""
+Usage: [MPPI_AMD_LIB=.../libmppi_amd_<tag>.so] python tools/ab_kernels.py [cartpole autorally ditube lstm racer robust_ar robust_lstm robust_di robust_racer robust_racer_all] [--json out]"""
 import json
 import os
 import sys
@@ -84,6 +84,11 @@ def main():
         cfg["D"] = 2
         cfg["control_cost_coeff"] = [0.2, 0.1]
         res["robust_autorally_16384x150"] = robust(cfg, 500.0, 20)
+    if "robust_lstm" in which:
+        cfg = bicycle_lstm_cfg(K=16384, T=150, lambda_=1.0)
+        cfg["D"] = 2
+        cfg["control_cost_coeff"] = [0.2, 0.1]
+        res["robust_bicycle_lstm_16384x150"] = robust(cfg, 500.0, 10, passes=3)
     if "robust_di" in which:
         cfg = di_cfg(K=8192, T=150, tube=True)
         cfg["control_cost_coeff"] = [0.3, 0.2]
