@@ -19,6 +19,7 @@
 #include "mppi_amd/plugin/math_utils.hpp"
 #include "mppi_amd/plugin/parallel_utils.hpp"
 #include "rollout_kernel.hpp"
+#include "merge_wave.hpp"
 
 namespace mppi
 {
@@ -75,7 +76,9 @@ struct FinalizeArgs
 };
 
 /** control phase of a split pass (FinalizeArgs::phases == 1): the carry block, written and published before the hand-over flag
- *  goes up (the host may overwrite the inbox carry_src_d the moment it sees the flag).  One wave per block in every variant. */
+ *  goes up (the host may overwrite the inbox carry_src_d the moment it sees the flag).  `stride` lanes of one block share the
+ *  copy (one wave in the finalize kernels, sixteen in mergeControlKernel); the barrier in front of the release store has every
+ *  wave's stores out. */
 __device__ inline void finalizeWriteCarry(const FinalizeArgs& a, const int z, const float* ctrl, const int TC, const int lane,
                                           const int stride)
 {
@@ -532,6 +535,240 @@ __global__ void __launch_bounds__(64) finalizeRepKernel(DYN_T dynamics_obj, cons
   raiseHostFlag(a.flags_d, 2 * z + 1, a.seq, lane == 0);
 }
 
+
+/**
+ * mergeControlKernel — the control phase of a split hand-over (FinalizeArgs::phases == 1) that MERGES the last rollout launch's
+ * block records itself: one launch where mppi_compute_control had two on its critical path (combineKernel, then the control
+ * phase of finalizeKernel, a dependent launch boundary of ~1.5 us between them and the merge kernel's own ramp in front).
+ *
+ * What made the merge a grid of 26 one-wave blocks on 26 CUs (csrc/reduce_kernels.hpp: MERGE_WAVES) was the record layout: lane =
+ * record with the records 416 B apart is 64 cache lines per load instruction, and one CU's address unit needed ~6 us for
+ * 256 records.  The rollout kernels of one-system launches now leave a TRANSPOSED copy of their records
+ * (RolloutArgs::records_t_d) for the next launch's sampler waves; read from that copy a load instruction is 1 KB of contiguous
+ * memory, and one block of 16 waves pulls the 106 KB of a 256-record launch through one CU in well under a microsecond.
+ *
+ * Arithmetic: merge_wave.hpp, the functions combineWave calls, with the same lane <-> record assignment — every wave forms rho,
+ * the scale factors, eta and sum w^2 for itself, wave w then takes the column quads w, w + 16, ...; u*[j] = U[j] / float(eta);
+ * wave 0 writes the statistics.  The same bits as combineKernel + finalizeKernel (tests/test_merge_control.py).  The merged mean
+ * also goes to mean_out_d (what later mppi_optimize / getter calls read), the statistics to stats_d.
+ * One system (grid = 1 block), T * C a multiple of 4, at most 256 records (the conditions of the streamed merge), control
+ * sequence in LDS (no FinalizeArgs::scratch_d).
+ */
+struct MergeControlArgs
+{
+  const float* records_t_d;  ///< the transposed copy of the records (rollout_kernel.hpp: RolloutArgs::records_t_d)
+  int num_records;
+  float lambda;
+  int num_rollouts_total;    ///< K (free-energy normalisation)
+  float* mean_out_d;         ///< [T*C]
+  float* stats_d;            ///< [STATS_STRIDE]; [6] is read, not written (sticky failure mark)
+};
+
+constexpr int MERGE_CONTROL_WAVES = 16;
+constexpr int MERGE_CONTROL_STATS = 8;  ///< == STATS_STRIDE (csrc/reduce_kernels.hpp; static_assert there)
+
+template <class DYN_T>
+__host__ inline size_t mergeControlSharedBytes(const DYN_T& dyn, int num_timesteps)
+{
+  constexpr int C = DYN_T::CONTROL_DIM;
+  return finalizeSharedBytes(dyn, num_timesteps, 1, false) +
+         sizeof(float) * (math::nearest_multiple_4(num_timesteps * C) + MERGE_CONTROL_STATS);
+}
+
+template <class DYN_T>
+__global__ void __launch_bounds__(64 * MERGE_CONTROL_WAVES) mergeControlKernel(DYN_T dynamics_obj, const FinalizeArgs a,
+                                                                                 const MergeControlArgs m)
+{
+  constexpr int NL = 64 * MERGE_CONTROL_WAVES;
+  __builtin_assume(__builtin_amdgcn_workgroup_size_x() == NL);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_y() == 1);
+  __builtin_assume(__builtin_amdgcn_workgroup_size_z() == 1);
+  __builtin_assume(__builtin_amdgcn_workitem_id_x() < NL);
+  DYN_T* dynamics = &dynamics_obj;
+  constexpr int S = DYN_T::STATE_DIM, C = DYN_T::CONTROL_DIM, O = DYN_T::OUTPUT_DIM;
+  static_assert(MERGE_COLS == 4 && MERGE_LANE_RECORDS == 4, "the transposed copy is laid out in column quads; 256 records");
+  const int T = a.num_timesteps;
+  const int TC = T * C;
+  const int z = 0;
+  const int tid = (int)__builtin_amdgcn_workitem_id_x();
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* theta_s = reinterpret_cast<float*>(smem_raw);
+  float* buf = theta_s + calcClassSharedMemSize(dynamics, 1) / (int)sizeof(float);  // [(T+4)][C]
+  float* ctrl = buf + math::nearest_multiple_4((T + 4) * C);                         // [T][C]
+  float* zero_state = buf + finalizeScratchFloats(T, C) + 3 * math::nearest_multiple_4(S);  // (finalizeKernel's layout)
+  float* mean_s = zero_state + math::nearest_multiple_4(S) + math::nearest_multiple_4(C) + math::nearest_multiple_4(O);
+  float* st_s = mean_s + math::nearest_multiple_4(TC);
+
+  /* ---- the merge: every load of the wave in flight before anything is waited for ---- */
+  typedef float merge_f4 __attribute__((ext_vector_type(4)));
+  typedef float merge_f2 __attribute__((ext_vector_type(2)));
+  const int NR = m.num_records;
+  const int quads = TC >> 2;
+  const float* tails_t = m.records_t_d + (size_t)TC * NR;
+  const float* eta2_t = m.records_t_d + (size_t)(TC + 2) * NR;
+  constexpr int PRE = 2;  // quads per wave whose loads are issued up front (T * C <= 128: all of them)
+  merge_f2 tailq[MERGE_LANE_RECORDS];
+  float eta2q[MERGE_LANE_RECORDS];
+  merge_f4 vq[PRE][MERGE_LANE_RECORDS];
+#pragma unroll
+  for (int i = 0; i < MERGE_LANE_RECORDS; i++)
+  {
+    const int b = lane + 64 * i;
+    const int bb = b < NR ? b : 0;
+    tailq[i] = *reinterpret_cast<const merge_f2*>(tails_t + 2 * bb);
+    eta2q[i] = eta2_t[bb];
+  }
+#pragma unroll
+  for (int p = 0; p < PRE; p++)
+  {
+    const int q = wave + MERGE_CONTROL_WAVES * p;
+#pragma unroll
+    for (int i = 0; i < MERGE_LANE_RECORDS; i++)
+    {
+      const int b = lane + 64 * i;
+      const bool ok = b < NR && q < quads;
+      vq[p][i] = *reinterpret_cast<const merge_f4*>(m.records_t_d + ((size_t)(ok ? q : 0) * NR + (ok ? b : 0)) * 4);
+    }
+  }
+  // ... and everything else the block reads from global memory, in the same round trip: the control history the smoothing starts
+  // from, the sticky failure mark of the statistics block, the call's inputs that go into the carry block (finalizeWriteCarry:
+  // every float of carry_src_d outside the control sequence — initial state and history, a handful)
+  const bool smooth = (a.smooth_mask >> z) & 1;
+  float hist0 = 0.0f, hist1 = 0.0f;
+  if (smooth && tid < C)
+  {
+    hist0 = a.history_d[z * a.history_stride + 0 * C + tid];
+    hist1 = a.history_d[z * a.history_stride + 1 * C + tid];
+  }
+  const float sticky_mark = tid == 0 ? m.stats_d[6] : 0.0f;
+  const bool carry = a.phases == 1 && a.carry_d;
+  const int carry_others = carry ? a.carry_floats - TC : 0;  // floats of the input block that are not the control sequence
+  auto carry_index = [&](const int k) { return k < a.carry_mean_off ? k : k + TC; };
+  float carry_v = 0.0f;
+  if (tid < carry_others)
+    carry_v = a.carry_src_d[carry_index(tid)];
+  asm volatile("" ::: "memory");  // (issued here, not sunk to their uses behind the merge)
+  for (int i = tid; i < S; i += NL)
+    zero_state[i] = 0.0f;
+  MergeTails mt;
+  {
+    float rho_b[MERGE_LANE_RECORDS], eta_b[MERGE_LANE_RECORDS], eta2_b[MERGE_LANE_RECORDS];
+#pragma unroll
+    for (int i = 0; i < MERGE_LANE_RECORDS; i++)
+    {
+      const bool ok = lane + 64 * i < NR;  // padding records: rho_b = inf, eta_b = eta2_b = 0 (combineWave's rule)
+      rho_b[i] = ok ? tailq[i].x : INFINITY;
+      eta_b[i] = ok ? tailq[i].y : 0.0f;
+      eta2_b[i] = ok ? eta2q[i] : 0.0f;
+    }
+    mergeTails(rho_b, eta_b, eta2_b, (float)(1.0 / (double)m.lambda), mt);
+  }
+  auto merge_quad = [&](const int q, const merge_f4 (&raw)[MERGE_LANE_RECORDS]) {
+    float v[MERGE_LANE_RECORDS][MERGE_COLS], tot[MERGE_COLS];
+#pragma unroll
+    for (int i = 0; i < MERGE_LANE_RECORDS; i++)
+    {
+      const bool ok = lane + 64 * i < NR;
+      v[i][0] = ok ? raw[i].x : 0.0f;
+      v[i][1] = ok ? raw[i].y : 0.0f;
+      v[i][2] = ok ? raw[i].z : 0.0f;
+      v[i][3] = ok ? raw[i].w : 0.0f;
+    }
+    mergeColumns(mt.s, v, tot);
+    if (lane < MERGE_COLS)
+    {  // lane c takes column c (the sums are wave-uniform), as in combineWave
+      float mine = tot[0];
+#pragma unroll
+      for (int c = 1; c < MERGE_COLS; c++)
+        mine = lane == c ? tot[c] : mine;
+      const float mu = mine / mt.eta_f;
+      mean_s[4 * q + lane] = mu;
+      m.mean_out_d[4 * q + lane] = mu;
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < PRE; p++)
+  {
+    const int q = wave + MERGE_CONTROL_WAVES * p;
+    if (q < quads)  // (wave-uniform)
+      merge_quad(q, vq[p]);
+  }
+  for (int q = wave + MERGE_CONTROL_WAVES * PRE; q < quads; q += MERGE_CONTROL_WAVES)
+  {  // longer sequences: further rounds, a memory round trip each
+    merge_f4 raw[MERGE_LANE_RECORDS];
+#pragma unroll
+    for (int i = 0; i < MERGE_LANE_RECORDS; i++)
+    {
+      const int b = lane + 64 * i;
+      raw[i] = *reinterpret_cast<const merge_f4*>(m.records_t_d + ((size_t)q * NR + (b < NR ? b : 0)) * 4);
+    }
+    merge_quad(q, raw);
+  }
+  if (tid == 0)
+  {
+    mergeStatistics(mt.rho, mt.eta_f, mt.eta2, m.lambda, m.num_rollouts_total, st_s);
+    st_s[6] = sticky_mark;
+#pragma unroll
+    for (int i = 0; i < MERGE_CONTROL_STATS; i++)
+      if (i != 6)
+        m.stats_d[i] = st_s[i];
+  }
+  __syncthreads();  // mean_s, st_s complete
+
+  /* ---- the control phase of finalizeKernel on the merged mean ---- */
+  const float* uin = mean_s;
+  if (smooth)
+  {
+    if (tid < C)
+    {
+      buf[0 * C + tid] = hist0;
+      buf[1 * C + tid] = hist1;
+      buf[(T + 2) * C + tid] = uin[(T - 1) * C + tid];
+      buf[(T + 3) * C + tid] = uin[(T - 1) * C + tid];
+    }
+    for (int e = tid; e < TC; e += NL)
+      buf[2 * C + e] = uin[e];
+    __syncthreads();
+    // filter_coefficients << -3, 12, 17, 12, -3; filter_coefficients /= 35.0  (controller.cuh:564-566)
+    const float c0 = (float)(-3.0 / 35.0), c1 = (float)(12.0 / 35.0), c2 = (float)(17.0 / 35.0);
+    for (int e = tid; e < TC; e += NL)
+    {
+      float acc = c0 * buf[e];
+      acc += c1 * buf[e + C];
+      acc += c2 * buf[e + 2 * C];
+      acc += c1 * buf[e + 3 * C];
+      acc += c0 * buf[e + 4 * C];
+      ctrl[e] = acc;
+    }
+  }
+  else
+  {
+    for (int e = tid; e < TC; e += NL)
+      ctrl[e] = uin[e];
+  }
+  __syncthreads();  // ctrl is complete
+  if (carry)
+  {  // finalizeWriteCarry with the input block's floats already in registers
+    if (tid < carry_others)
+      a.carry_d[carry_index(tid)] = carry_v;
+    for (int k = tid + NL; k < carry_others; k += NL)
+      a.carry_d[carry_index(k)] = a.carry_src_d[carry_index(k)];
+    for (int e = tid; e < TC; e += NL)
+      a.carry_d[a.carry_mean_off + e] = ctrl[e];
+    __syncthreads();
+    if (tid == 0 && a.carry_ready_d)
+      __hip_atomic_store(a.carry_ready_d + z, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (a.stats_out_d)
+    for (int e = tid; e < MERGE_CONTROL_STATS; e += NL)
+      a.stats_out_d[e] = st_s[e];
+  FinalizeArgs emit = a;
+  emit.stats_in_d = nullptr;  // (written above, from this block's own merge)
+  finalizeEmitControl(dynamics, emit, z, ctrl, buf, zero_state, tid, NL, tid, NL);
+}
 }  // namespace kernels
 }  // namespace mppi
 #endif

@@ -80,6 +80,28 @@ __device__ inline void mergeColumns(const float (&s)[MERGE_LANE_RECORDS], const 
   for (int c = 0; c < MERGE_COLS; c++)
     tot[c] = mppi::wave::waveAllSum(acc[c]);
 }
+
+/** statistics block of a finished merge, [STATS_STRIDE = 8] floats: baseline, normaliser, free energy and its variance terms
+ *  (reference: mppi_common.cu:1065-1081 computeFreeEnergy).  st[6] — the exchange-failure mark (a bounded wait that ran out) —
+ *  is STICKY: no kernel clears it, so that a later successful merge cannot erase it before the host has looked; it is not
+ *  written here.  One definition for the merge kernel and the merging control phase (finalize_kernel.hpp: mergeControlKernel). */
+__device__ inline void mergeStatistics(const float rho, const float eta_f, const double eta2, const float lambda,
+                                       const int num_rollouts_total, float* st)
+{
+  const float K = (float)num_rollouts_total;
+  const float norm = eta_f / K;
+  const float var = (float)eta2;
+  const float fe = -lambda * mppi::det::log(norm) + rho;
+  const float fe_var = lambda * (var / K - norm * norm);
+  const float weird = fe_var / (norm * mppi::det::sqrt(K));
+  st[0] = rho;
+  st[1] = eta_f;
+  st[2] = fe;
+  st[3] = fe_var;
+  st[4] = lambda * (weird + 0.5f * (weird * weird));
+  st[5] = var;
+  st[7] = 0.0f;
+}
 }  // namespace kernels
 }  // namespace mppi
 

@@ -228,6 +228,18 @@ struct ModelBase
   virtual mppi_status launchRollout(int bx, int by, int bz, bool pipeline, const kernels::RolloutArgs& args,
                                     const SamplerLaunchState& s, hipStream_t stream, std::string& err) = 0;
   virtual mppi_status launchFinalize(int D, const kernels::FinalizeArgs& a, hipStream_t stream, std::string& err) = 0;
+  /** the control phase of a split hand-over that merges the last launch's block records itself (kernels::mergeControlKernel):
+   *  one system on the plain one-wave finalize form, control sequence in LDS */
+  virtual bool supportsMergeControl(int num_timesteps) const
+  {
+    return false;
+  }
+  virtual mppi_status launchMergeControl(const kernels::FinalizeArgs& a, const kernels::MergeControlArgs& m, hipStream_t stream,
+                                         std::string& err)
+  {
+    err = "model has no merging control phase";
+    return MPPI_ERR_LAUNCH_SHAPE;
+  }
   /** x <- one model step (optionally after enforceConstraints on u), one block (1, by, 1) */
   virtual mppi_status launchModelStep(float* x_d, float* u_d, float dt, int enforce, hipStream_t stream,
                                       std::string& err) = 0;
@@ -238,14 +250,16 @@ struct ModelBase
 /** bumped BY HAND whenever ModelBase's virtual methods are added, removed or reordered or a field of an argument struct is
  *  swapped at equal size — changes sizeof() cannot see (a stale plugin would dispatch to the wrong vtable slot).
  *  3: rows-in-HBM arguments; 4: release-flag arguments of the finalize kernels (both round 3); 5: supportsStreamedMerge (round 4);
- *  6: FinalizeArgs::phases / carry block of the split hand-over (round 5); 7: undeclaredBarrierFreePlugins (round 6). */
-#define MPPI_ENGINE_ABI_VERSION 7
+ *  6: FinalizeArgs::phases / carry block of the split hand-over (round 5); 7: undeclaredBarrierFreePlugins; 8: the transposed
+ *  record copy (RolloutArgs) and supportsMergeControl / launchMergeControl (both round 6). */
+#define MPPI_ENGINE_ABI_VERSION 8
 
 constexpr int engineAbiFingerprint()
 {
   return MPPI_ENGINE_ABI_VERSION * 1000003 +
          (int)(sizeof(ModelBase) + 131 * sizeof(kernels::RolloutArgs) + 131 * 131 * sizeof(kernels::FinalizeArgs) +
-               7 * sizeof(kernels::RMPPIArgs) + 17 * sizeof(kernels::InitEvalArgs) + 31 * sizeof(SamplerLaunchState));
+               7 * sizeof(kernels::RMPPIArgs) + 17 * sizeof(kernels::InitEvalArgs) + 31 * sizeof(SamplerLaunchState) +
+               37 * sizeof(kernels::MergeControlArgs));
 }
 
 template <class DYN_T, int BY>
@@ -835,11 +849,11 @@ struct ModelT : ModelBase
       if constexpr (Z == 1 && !FOLD && SAMPLING_T::IN_LOOP_DRAW && !SAMPLING_T::COLORED)
       {
         // the previous iteration's block records merged by this launch's sampler waves (RolloutArgs::prev_records_d)
-        if (args.prev_records_d && in_loop && !smp.rows_global_d_)
+        if (args.prev_records_d && args.prev_records_t_d && in_loop && !smp.rows_global_d_)
           kfn = kernels::rolloutPipelineKernel<DYN_T, COST_T, SAMPLING_T, 1, SAMPLING_T::IN_LOOP_DRAW, false, false, true>;
         else if (args.prev_records_d)
         {
-          err = "prev_records_d: this launch cannot merge the previous records itself (noise source / rows in HBM)";
+          err = "prev_records_d: this launch cannot merge the previous records itself (noise source / rows in HBM / no transposed copy)";
           return MPPI_ERR_STATE;
         }
       }
@@ -1712,6 +1726,43 @@ struct ModelT : ModelBase
       return MPPI_ERR_HIP;
     }
     return MPPI_OK;
+  }
+
+  /** plain one-wave finalize form only (FIN_BY == 1, no replicated-lane / wave form): what the one-lane pipeline models have */
+  static constexpr bool MERGE_CONTROL = FIN_BY == 1 && std::is_void<DYN_FAST_T>::value;
+  bool supportsMergeControl(int num_timesteps) const override
+  {
+    if constexpr (MERGE_CONTROL)
+      return kernels::mergeControlSharedBytes(dyn, num_timesteps) <= MAX_LDS_BYTES;
+    return false;
+  }
+  mppi_status launchMergeControl(const kernels::FinalizeArgs& a, const kernels::MergeControlArgs& m, hipStream_t stream,
+                                 std::string& err) override
+  {
+    if constexpr (MERGE_CONTROL)
+    {
+      if (!blobsReady(err))
+        return MPPI_ERR_STATE;
+      if (a.scratch_d || a.phases != 1 || ((a.num_timesteps * DYN_T::CONTROL_DIM) & 3) != 0 || m.num_records > 256)
+      {
+        err = "mergeControlKernel: control phase of a split hand-over, sequence in LDS, T*C a multiple of 4, <= 256 records";
+        return MPPI_ERR_LAUNCH_SHAPE;
+      }
+      const size_t smem = kernels::mergeControlSharedBytes(dyn, a.num_timesteps);
+      auto kfn = kernels::mergeControlKernel<DYN_T>;
+      if (smem > 48 * 1024)
+        (void)ensureDynamicLds(reinterpret_cast<const void*>(kfn), smem);
+      hipLaunchKernelGGL(kfn, dim3(1), dim3(64 * kernels::MERGE_CONTROL_WAVES, 1, 1), smem, stream, dyn, a, m);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess)
+      {
+        err = std::string("mergeControlKernel launch: ") + hipGetErrorString(e);
+        return MPPI_ERR_HIP;
+      }
+      return MPPI_OK;
+    }
+    err = "model has no merging control phase";
+    return MPPI_ERR_LAUNCH_SHAPE;
   }
 
   mppi_status launchModelStep(float* x_d, float* u_d, float dt, int enforce, hipStream_t stream,

@@ -91,7 +91,22 @@ struct RolloutArgs
    * trip, instead of a merge launch in between; nullptr: the mean is in sampler.control_means_d_ */
   const float* prev_records_d;  ///< [prev_num_records][partialStride]
   int prev_num_records;
+  /* The streamed merge reads the records lane = record: in [record][partialStride] every lane of a load instruction touches a
+   * cache line of its own (64 line requests for 1 KB of data; 2 waves x 8 instructions per block at kernel entry, in front of the
+   * first sample of the launch).  The epilogue therefore writes a second, TRANSPOSED copy of a one-system launch's records —
+   * [T*C/4][num_blocks][4] column quads, then [num_blocks][2] tails {rho_b, eta_b}, then [num_blocks] sums of w^2 — which the
+   * sampler waves read with 8 / 4 lines per instruction (tools/ubench/record_layout.hip: kernel entry -> data back 1.05 ->
+   * 0.58 us), and which lets ONE block merge all records (finalize_kernel.hpp: mergeControlKernel — a hand-over's merge inside
+   * its control phase).  Same values, same order of the sums.  nullptr: no copy written / (reader) not a streamed-merge launch. */
+  float* records_t_d;
+  const float* prev_records_t_d;
 };
+
+/** floats of the transposed copy of `num_blocks` one-system records (RolloutArgs::records_t_d) */
+__host__ __device__ inline size_t transposedRecordFloats(int num_timesteps, int control_dim, int num_blocks)
+{
+  return (size_t)num_blocks * (num_timesteps * control_dim + 4);
+}
 
 template <class DYN_T, class COST_T, class SAMPLING_T>
 __host__ inline size_t rolloutSharedBytes(const DYN_T& dyn, const COST_T& cost, const SAMPLING_T& smp, int bx, int by,
@@ -207,7 +222,11 @@ __device__ inline void blockSoftminEpilogueCost(SAMPLING_T* sampling, const Roll
       }
       acc += __shfl_xor(acc, 32, 64);
       if (ok && half == 0)
+      {
         args.partials_d[((size_t)z * num_blocks + block_idx) * PS + j] = acc;
+        if (BZ == 1 && args.records_t_d)
+          args.records_t_d[((size_t)(j >> 2) * num_blocks + block_idx) * 4 + (j & 3)] = acc;
+      }
     }
   }
   else
@@ -222,6 +241,8 @@ __device__ inline void blockSoftminEpilogueCost(SAMPLING_T* sampling, const Roll
       for (int i = 0; i < nrows; i++)
         acc += wz[i] * rows[i * row_stride];
       args.partials_d[((size_t)z * num_blocks + block_idx) * PS + j] = acc;
+      if (BZ == 1 && args.records_t_d)
+        args.records_t_d[((size_t)(j >> 2) * num_blocks + block_idx) * 4 + (j & 3)] = acc;
     }
   }
   if (WAVE_REDUCE)
@@ -244,6 +265,13 @@ __device__ inline void blockSoftminEpilogueCost(SAMPLING_T* sampling, const Roll
           rec[1] = (float)eta;
           rec[2] = (float)eta2;
           rec[3] = 0.0f;
+          if (BZ == 1 && args.records_t_d)
+          {
+            float* tail_t = args.records_t_d + (size_t)TC * num_blocks + 2 * block_idx;
+            tail_t[0] = rho_b;
+            tail_t[1] = (float)eta;
+            args.records_t_d[(size_t)(TC + 2) * num_blocks + block_idx] = (float)eta2;
+          }
         }
       }
     }
@@ -265,6 +293,13 @@ __device__ inline void blockSoftminEpilogueCost(SAMPLING_T* sampling, const Roll
     rec[1] = (float)eta;
     rec[2] = (float)eta2;
     rec[3] = 0.0f;
+    if (BZ == 1 && args.records_t_d)
+    {
+      float* tail_t = args.records_t_d + (size_t)TC * num_blocks + 2 * block_idx;
+      tail_t[0] = rho_b;
+      tail_t[1] = (float)eta;
+      args.records_t_d[(size_t)(TC + 2) * num_blocks + block_idx] = (float)eta2;
+    }
   }
   if (args.save_samples)
   {

@@ -299,7 +299,9 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
   auto load_trip_columns = [&](const int t) {
     if constexpr (STREAM_MERGE)
     {
-      const int PS = partialStride(num_timesteps, C);
+      // the transposed copy of the records (RolloutArgs::records_t_d): quad q of record b at [q][b][4] — a load instruction's 64
+      // lanes read 1 KB of contiguous memory
+      static_assert(MERGE_COLS == 4, "the transposed copy is laid out in column quads");
 #pragma unroll
       for (int g = 0; g < TRIP_GROUPS; g++)
       {
@@ -309,7 +311,8 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
         {
           const int b = lane + 64 * i;
           const bool ok = b < args.prev_num_records && col0 < TC_all;  // (else: any valid address; the value is not used)
-          vq[g][i] = *reinterpret_cast<const merge_f4*>(args.prev_records_d + (size_t)(ok ? b : 0) * PS + (ok ? col0 : 0));
+          vq[g][i] = *reinterpret_cast<const merge_f4*>(args.prev_records_t_d +
+                                                        ((size_t)(ok ? col0 >> 2 : 0) * args.prev_num_records + (ok ? b : 0)) * 4);
         }
       }
     }
@@ -401,14 +404,14 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
   {
     if (role == 0)
     {
-      // the record tails (one 16-byte load per record and lane) and the first trip's quads: one memory round trip, under which
+      // the record tails (one 8-byte load per record and lane) and the first trip's quads: one memory round trip, under which
       // the first draw runs (the loads' results are first touched by mergeTails inside the first trip)
-      const int PS = partialStride(num_timesteps, C);
+      const float* tails_t = args.prev_records_t_d + (size_t)TC_all * args.prev_num_records;  // [record][2] behind the quads
 #pragma unroll
       for (int i = 0; i < MERGE_LANE_RECORDS; i++)
       {
         const int b = lane + 64 * i;
-        tailq[i] = *reinterpret_cast<const merge_f2*>(args.prev_records_d + (size_t)(b < args.prev_num_records ? b : 0) * PS + TC_all);
+        tailq[i] = *reinterpret_cast<const merge_f2*>(tails_t + 2 * (b < args.prev_num_records ? b : 0));
       }
       load_trip_columns(SMP_STEPS * smp_id);
       asm volatile("" ::: "memory");  // the loads are issued here, not sunk to their first use behind the draw

@@ -266,7 +266,18 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     for (int it = 0; it < h->cfg.num_iters; it++)
       MPPI_TRY(iteration(h, it, stride));
     stamp(2);
-    MPPI_TRY(flushMerge(h));  // the last iteration's records (streamed merge): everything below reads mean_d / stats_d
+    // The last iteration's records (streamed merge) are still un-merged.  Split hand-over on a model with the plain one-wave
+    // finalize form: the control phase merges them itself (kernels::mergeControlKernel) — one launch on the call's critical
+    // path where combineKernel + control phase were two.  Otherwise: merge now; everything below reads mean_d / stats_d.
+    const float* fuse_records = nullptr;
+    if (h->pending_records_d && h->split_finalize && h->merge_control_enabled && !a.scratch_d && streamMergeApplies(h) &&
+        h->model->supportsMergeControl(T))
+    {
+      fuse_records = h->pending_records_d;
+      h->pending_records_d = nullptr;
+    }
+    else
+      MPPI_TRY(flushMerge(h));
     stamp(3);
     a.control_out_d = h->io_out_dev + (h->ctrl_out_d - h->out_block_d);
     a.state_out_d = h->io_out_dev + (h->state_out_d - h->out_block_d);
@@ -304,7 +315,21 @@ static mppi_status computeControlVanilla(mppi_handle h, const float* x0_true, in
     // touches neither what the finalize kernel reads (inbox, mean_d) nor what it writes.
     if (direct && !h->split_finalize)
       MPPI_TRY(ingest_ranges(h->io_in_dev));
-    const mppi_status st = h->model->launchFinalize(1, a, h->stream, err);
+    mppi_status st;
+    if (fuse_records)
+    {
+      kernels::MergeControlArgs m{};
+      m.records_t_d = recordsTransposed(h, const_cast<float*>(fuse_records));
+      m.num_records = h->num_blocks;
+      m.lambda = h->cfg.lambda;
+      m.num_rollouts_total = h->cfg.num_rollouts;
+      m.mean_out_d = h->mean_d;
+      m.stats_d = h->stats_d;
+      h->n_merge_launches++;  // (the merge of this call: inside the control phase's launch)
+      st = h->model->launchMergeControl(a, m, h->stream, err);
+    }
+    else
+      st = h->model->launchFinalize(1, a, h->stream, err);
     if (st != MPPI_OK)
       return fail(h, st, err);
     if (h->split_finalize)

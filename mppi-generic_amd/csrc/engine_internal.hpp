@@ -39,6 +39,7 @@
 #include "mppi_amd/engine/model_instance.hpp"
 #include "reduce_kernels.hpp"
 #include "exact_reduce_kernels.hpp"
+static_assert(mppi::kernels::STATS_STRIDE == mppi::kernels::MERGE_CONTROL_STATS, "mergeControlKernel writes the statistics block");
 #include "mppi_amd/utils/texture_helpers/two_d_texture_helper.hpp"
 #include "mppi_amd/utils/nn_helpers/lstm_lstm_helper.hpp"
 
@@ -101,7 +102,7 @@ struct mppi_handle_s
   float* x0_d = nullptr;           // [D][S]
   float* mean_d = nullptr;         // [D][T][C]
   float* costs_d = nullptr;        // [D][K_local]
-  float* partials_d = nullptr;     // [D][num_blocks][PS]: the records the NEXT rollout launch writes
+  float* partials_d = nullptr;     // [D][num_blocks][PS]: the records the NEXT rollout launch writes (+ their transposed copy)
   /* Streamed merge (rolloutPipelineKernel, STREAM_MERGE): the records of the last rollout launch stay un-merged in
    * pending_records_d until the next rollout launch merges them in its sampler waves — or flushMerge() runs combineKernel on
    * them, which everything that reads mean_d / stats_d does first.  Two record buffers alternate. */
@@ -109,6 +110,7 @@ struct mppi_handle_s
   const float* pending_records_d = nullptr;
   unsigned long long n_rollout_launches = 0, n_merge_launches = 0;  // mppi_get_launch_counts
   bool stream_merge_enabled = true;  // MPPI_AMD_NO_STREAM_MERGE=1 switches it off (A/B)
+  bool merge_control_enabled = true;  // MPPI_AMD_NO_MERGE_CONTROL=1: combineKernel + control phase as two launches (A/B, tests)
   float* send_d = nullptr;         // [D][PS]
   float* recv_d = nullptr;         // [world][D][PS]
   float* gather_tmp_d = nullptr;   // [D][world][PS] (records regrouped per system)
@@ -430,6 +432,7 @@ MPPI_ENGINE_INTERNAL mppi_status launchCombine(mppi_handle h, const float* recor
                                  int k_total, bool world_major = false, const unsigned* wait_flags = nullptr,
                                  unsigned wait_seq = 0, const kernels::PostTargets* post = nullptr);
 MPPI_ENGINE_INTERNAL bool streamMergeApplies(const mppi_handle_s* h);
+MPPI_ENGINE_INTERNAL float* recordsTransposed(const mppi_handle_s* h, float* records);
 MPPI_ENGINE_INTERNAL mppi_status flushMerge(mppi_handle h);
 MPPI_ENGINE_INTERNAL mppi_status launchRollout(mppi_handle h, int iteration, int stride);
 MPPI_ENGINE_INTERNAL mppi_status iterationLocal(mppi_handle h, int iteration, int stride);

@@ -54,6 +54,11 @@ bool streamMergeApplies(const mppi_handle_s* h)
          !tsallisActive(h) && h->cfg.controller != MPPI_CONTROLLER_ROBUST && (h->TC & 3) == 0 && h->num_blocks <= 256 &&
          h->model->supportsStreamedMerge();
 }
+/** the transposed copy that belongs to a record buffer (partials_d / partials_alt_d): behind its [D][num_blocks][PS] records */
+float* recordsTransposed(const mppi_handle_s* h, float* records)
+{
+  return records + (size_t)h->D * h->num_blocks * h->PS;
+}
 /** the records of the last rollout launch are still un-merged: merge them now (combineKernel -> mean_d, stats_d) */
 mppi_status flushMerge(mppi_handle h)
 {
@@ -80,6 +85,9 @@ mppi_status launchRollout(mppi_handle h, int iteration, int stride)
   a.save_samples = h->samples_d ? 1 : 0;
   a.prev_records_d = nullptr;
   a.prev_num_records = 0;
+  a.prev_records_t_d = nullptr;
+  // the launches whose records the next launch may merge itself also write the transposed copy its sampler waves read
+  a.records_t_d = streamMergeApplies(h) ? recordsTransposed(h, h->partials_d) : nullptr;
   if (h->pending_records_d)
   {
     if (!streamMergeApplies(h))
@@ -87,6 +95,7 @@ mppi_status launchRollout(mppi_handle h, int iteration, int stride)
     else
     {
       a.prev_records_d = h->pending_records_d;
+      a.prev_records_t_d = recordsTransposed(h, const_cast<float*>(h->pending_records_d));
       a.prev_num_records = h->num_blocks;
       h->pending_records_d = nullptr;
     }

@@ -262,24 +262,8 @@ __device__ inline void combineWave(const CombineArgs& a, const int z, const int 
   {
     if (a.finalize)
     {
-      // reference: mppi_common.cu:1065-1081 computeFreeEnergy
-      const float K = (float)a.num_rollouts_total;
-      const float norm = eta_f / K;
-      const float var = (float)eta2;
-      const float lambda = a.lambda;
-      const float fe = -lambda * mppi::det::log(norm) + rho;
-      const float fe_var = lambda * (var / K - norm * norm);
-      const float weird = fe_var / (norm * mppi::det::sqrt(K));
-      float* st = a.stats_out_d + (size_t)z * STATS_STRIDE;
-      st[0] = rho;
-      st[1] = eta_f;
-      st[2] = fe;
-      st[3] = fe_var;
-      st[4] = lambda * (weird + 0.5f * (weird * weird));
-      st[5] = var;
-      // st[6] is the exchange-failure mark (a bounded wait that ran out): STICKY — no kernel clears it, so that a later
-      // successful merge cannot erase it before the host has looked; the host resets it where a session starts
-      st[7] = 0.0f;
+      // free energy and its variance terms; st[6], the sticky exchange-failure mark, is left alone (merge_wave.hpp)
+      mergeStatistics(rho, eta_f, eta2, a.lambda, a.num_rollouts_total, a.stats_out_d + (size_t)z * STATS_STRIDE);
     }
     else
     {

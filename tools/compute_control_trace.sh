@@ -7,34 +7,35 @@ rm -rf gpurun_out/cc_trace
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/cc_trace -- python tools/compute_control_latency.py idle > gpurun_out/cc_trace.log 2>&1
 f=$(find gpurun_out/cc_trace -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
-import csv, json, sys, collections
+import csv, json, re, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-seq = [(r['Kernel_Name'], int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows]
-calls = []
-i = 0
-while i + 3 < len(seq):
-    a, b, c, d = seq[i:i + 4]
-    if 'ingestKernel' in a[0] and 'rolloutPipelineKernel' in b[0] and 'combineKernel' in c[0] and 'finalizeKernel' in d[0]:
-        calls.append((a, b, c, d))
-        i += 4
-    else:
-        i += 1
+def short(n):
+    return re.sub(r'^void\s+', '', n).split('<')[0].split('(')[0].replace('mppi::kernels::', '')
+seq = [(short(r['Kernel_Name']), int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows]
+# a call = a rollout launch and every kernel up to the next rollout launch (whatever form the hand-over has: with or without
+# ingest launch, merge as a launch of its own or inside the control phase, trajectory phase on the side stream)
+calls, cur = [], None
+for k in seq:
+    if k[0].startswith('rolloutPipelineKernel'):
+        if cur:
+            calls.append(cur)
+        cur = [k]
+    elif cur:
+        cur.append(k)
 calls = calls[len(calls) // 2:]  # the idle-stream loop is the last one the tool runs
-out = collections.OrderedDict()
+shape = collections.Counter(tuple(k[0] for k in c) for c in calls).most_common(1)[0][0]
+calls = [c for c in calls if tuple(k[0] for k in c) == shape]
 def med(v):
     v = sorted(v)
     return round(v[len(v) // 2] / 1e3, 2)
+out = collections.OrderedDict()
 out['calls'] = len(calls)
-out['ingest_us'] = med([a[2] - a[1] for a, b, c, d in calls])
-out['gap_ingest_rollout_us'] = med([b[1] - a[2] for a, b, c, d in calls])
-out['rollout_us'] = med([b[2] - b[1] for a, b, c, d in calls])
-out['gap_rollout_merge_us'] = med([c[1] - b[2] for a, b, c, d in calls])
-out['merge_us'] = med([c[2] - c[1] for a, b, c, d in calls])
-out['gap_merge_finalize_us'] = med([d[1] - c[2] for a, b, c, d in calls])
-out['finalize_whole_us'] = med([d[2] - d[1] for a, b, c, d in calls])
-out['ingest_start_to_finalize_start_us'] = med([d[1] - a[1] for a, b, c, d in calls])
-out['ingest_start_to_finalize_end_us'] = med([d[2] - a[1] for a, b, c, d in calls])
+out['kernels_of_a_call'] = list(shape)
+for i, name in enumerate(shape):
+    out['%d_%s' % (i, name)] = {'start_after_rollout_start_us': med([c[i][1] - c[0][1] for c in calls]),
+                                'duration_us': med([c[i][2] - c[i][1] for c in calls]),
+                                'gap_after_previous_end_us': med([c[i][1] - c[i - 1][2] for c in calls]) if i else None}
 print(json.dumps(out, indent=1))
 json.dump(out, open('gpurun_out/compute_control_trace.json', 'w'), indent=1)
 PY
