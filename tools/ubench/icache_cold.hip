@@ -1,9 +1,13 @@
-// Is the front of a launch bound by INSTRUCTION FETCH?  The Cartpole rollout kernel spends 0.8 us between kernel entry and the issue
-// of its first loads (~150 instructions) and ~3 us before the first sample exists, on code that runs once per launch (prologue +
-// the sampler waves' first trip: ~1500 instructions of straight-line code, each executed once).  If the instruction cache starts
-// cold at every launch, that code runs at the speed of its misses.  Here: a straight-line body of N distinct VALU instructions
-// (8 bytes each, four independent chains), executed TWICE per launch by wave 0 of every block; s_memtime around each pass.
-// Pass 1 = cold (if the cache is cold at launch), pass 2 = warm.  1000 back-to-back launches of the same kernel, like the bench.
+// Is the front of a launch bound by INSTRUCTION FETCH?  The Cartpole rollout kernel spends ~3 us before the first sample of a launch
+// exists, on code that runs once per launch (prologue + the sampler waves' first trip: ~1500 instructions of straight-line code).
+// If the instruction cache started cold at every launch, that code would run at the speed of its misses.  Here: a straight-line
+// body of N fused multiply-adds with distinct literal constants (the compiler emits a v_mov + a v_fmamk per FMA: 2 N instructions,
+// 8 bytes each, four independent chains), executed three times per launch by wave 0 of every block; s_memtime around each pass.
+// Pass 1 = cold (if the cache is cold at launch), passes 2 / 3 = warm.  1000 back-to-back launches of the same kernel, like the bench.
+// RESULT (MI355X): pass 1 = pass 2 = pass 3 at every size (16 KB of code: 15468 / 15480 / 15477 ticks) — no cold start between
+// back-to-back launches of one kernel; 8.0 cycles per FMA = 4.0 per instruction, the issue rate of a lone wave64 — and
+// tools/ubench/ifetch_rate.hip: 4-byte and 8-byte encodings issue at the same 4.04 cycles, alone or with three other waves
+// fetching beside them.  The front of the launch is not a fetch problem.
 //   hipcc --offload-arch=gfx950 -O3 -o icache_cold tools/ubench/icache_cold.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>

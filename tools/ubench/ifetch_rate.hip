@@ -1,9 +1,11 @@
-// Instruction FETCH rate of one wave on gfx950, by encoding size.  tools/ubench/icache_cold.hip found no cold-start cost (the
-// first pass over 16 KB of straight-line code costs what the third does) but a steady 8.0 cycles per 8-byte VALU instruction where
-// the issue rate of a wave64 is 4: one byte per cycle?  Here the same measurement with the encoding under control (.rept blocks of
-// inline asm, four independent accumulators): E32 = v_fmac_f32_e32 (4 bytes), E64 = v_fma_f32 (VOP3, 8 bytes), MIX = alternating;
-// with 1, 2 or 4 waves of the block (one per SIMD) running the body at the same time — the rollout kernels' role waves share
-// the CU's instruction cache port.   hipcc --offload-arch=gfx950 -O3 -o ifetch_rate tools/ubench/ifetch_rate.hip
+// Instruction FETCH rate of one wave on gfx950, by encoding size (the companion of tools/ubench/icache_cold.hip): does a lone wave
+// per SIMD — the rollout kernels' dynamics waves — pay for 8-byte encodings (VOP3, VOP3P: v_fma_f32, v_pk_fma_f32) what it does
+// not pay for 4-byte ones?  .rept blocks of inline asm, four independent accumulators: E32 = v_fmac_f32_e32 (4 bytes), E64 =
+// v_fma_f32 (VOP3, 8 bytes), MIX = alternating; with 1, 2 or 4 waves of the block (one per SIMD) running the body at the same time
+// — the role waves of a block share the CU's instruction cache port.
+// RESULT (MI355X, 2048 instructions = 8 / 16 KB, third pass): E32 4.04, MIX 4.04, E64 4.04-4.65 cycles per instruction with one
+// wave, 4.04-4.05 with two or four: the encoding size does not matter, neither do the neighbours.
+//   hipcc --offload-arch=gfx950 -O3 -o ifetch_rate tools/ubench/ifetch_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
