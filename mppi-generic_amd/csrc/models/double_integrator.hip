@@ -23,3 +23,18 @@ using DIModel = ModelT<DoubleIntegratorDynamics, DoubleIntegratorCircleCost, DIS
                        Shapes<Shape<64, 1, 1>, Shape<64, 1, 2>, Shape<32, 2, 2>, Shape<64, 2, 1>, Shape<16, 1, 1>, Shape<16, 1, 2>>,
                        /*FIN_BY=*/1, void, Shapes<>, /*PIPELINE=*/true, /*RMPPI=*/true>;
 MPPI_REGISTER_MODEL("double_integrator", MPPI_SAMPLER_GAUSSIAN, DIModel, 64, 1)
+
+#if defined(MPPI_PIPE_TIMING)
+/* A/B instrumentation read-back (tools/pipe_timing_cartpole.py di_tube): ticks[blocks][waves][slots] of the last pipelined launch */
+extern "C" int mppi_debug_read_pipe_timing_double_integrator(unsigned long long* out, int capacity)
+{
+  constexpr int N = kernels::PIPE_TIMING_BLOCKS * kernels::PIPE_TIMING_WAVES * kernels::PIPE_TIMING_SLOTS;
+  if (!out || capacity < N)
+    return -N;
+  if (hipDeviceSynchronize() != hipSuccess)
+    return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(kernels::g_pipe_timing), sizeof(unsigned long long) * N) != hipSuccess)
+    return -2;
+  return N;
+}
+#endif

@@ -19,14 +19,17 @@ for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
     sys.path.insert(0, p)
 import numpy as np  # noqa: E402
 import mppi_generic_amd as m  # noqa: E402
-from common import cartpole_cfg, make_engine  # noqa: E402
+from common import cartpole_cfg, di_cfg, make_engine  # noqa: E402
 
 BLOCKS, WAVES, SLOTS = 256, 24, 8
 
 
 def main():
     lib = C.CDLL(m.library_path())
-    cfg = cartpole_cfg(K=16384, T=100)
+    args = [a for a in sys.argv[1:] if a != "di_tube"]
+    di = "di_tube" in sys.argv[1:]  # the two-system form (32 rollouts x 2 systems per wave) on the double integrator, K=8192, T=150
+    sys.argv[1:] = args
+    cfg = di_cfg(K=8192, T=150, tube=True) if di else cartpole_cfg(K=16384, T=100)
     eng = make_engine(cfg)
     eng.uploadState(cfg["x0"])
     eng.optimize(50)
@@ -34,7 +37,7 @@ def main():
     tot, roll = eng.timeIterations(n_it)
     eng.optimize(2)  # the stamps of the LAST launch: the second one merges the first one's records in its sampler waves
     buf = (C.c_ulonglong * (BLOCKS * WAVES * SLOTS))()
-    n = lib.mppi_debug_read_pipe_timing_cartpole(buf, len(buf))
+    n = (lib.mppi_debug_read_pipe_timing_double_integrator if di else lib.mppi_debug_read_pipe_timing_cartpole)(buf, len(buf))
     assert n == len(buf), n
     t = np.frombuffer(buf, np.uint64).reshape(BLOCKS, WAVES, SLOTS).astype(np.float64)
     kernel_us = roll / n_it * 1e3
@@ -51,12 +54,13 @@ def main():
         return round(float(x) / ticks_per_us, 3)
 
     out = {
-        "workload": "Cartpole K=16384 T=100, rolloutPipelineKernel: per block 1 dynamics + 2 sampler + 1 cost wave; 256 blocks",
+        "workload": ("Double integrator, Tube (2 systems folded into the lanes) K=8192 T=150" if di else "Cartpole K=16384 T=100") +
+                    ", rolloutPipelineKernel: per block 1 dynamics + 2 sampler + 1 cost wave; 256 blocks",
         "rollout_kernel_us_hip_events_instrumented_build": round(kernel_us, 2),
         "iteration_us_instrumented_build": round(tot / n_it * 1e3, 2),
         "s_memtime_ticks_per_us": round(ticks_per_us, 1),
         "unit": "microseconds per launch and wave, mean over the 256 blocks (converted from s_memtime ticks)",
-        "dynamics_wave": {"entry_to_loop": us(dyn[:, 3].mean()), "work_100_steps": us(dyn[:, 0].mean()),
+        "dynamics_wave": {"entry_to_loop": us(dyn[:, 3].mean()), "work_all_steps": us(dyn[:, 0].mean()),
                           "wait_sampler": us(dyn[:, 1].mean()), "wait_cost_ring": us(dyn[:, 2].mean()),
                           "loop_done_to_block_done": us(dyn[:, 4].mean()), "epilogue": us(dyn[:, 5].mean()),
                           "work_slowest_block": us(dyn[:, 0].max()), "work_fastest_block": us(dyn[:, 0].min())},
@@ -86,8 +90,8 @@ def main():
         "record loads issued": us(st[0]), "draw done": us(st[1]), "tails merged (rho, scales, eta)": us(st[2]),
         "first four columns of the mean merged": us(st[3]), "samples shaped and stored": us(st[4])}
     d = out["dynamics_wave"]
-    out["dynamics_work_share_of_block_life"] = round(d["work_100_steps"] / out["across_blocks_real_time_us"]["block_life_mean"], 3)
-    out["dynamics_work_share_of_launch"] = round(d["work_100_steps"] / kernel_us, 3)
+    out["dynamics_work_share_of_block_life"] = round(d["work_all_steps"] / out["across_blocks_real_time_us"]["block_life_mean"], 3)
+    out["dynamics_work_share_of_launch"] = round(d["work_all_steps"] / kernel_us, 3)
     print(json.dumps(out, indent=1))
     if len(sys.argv) > 1:
         open(sys.argv[1], "w").write(json.dumps(out, indent=1) + "\n")
