@@ -1,6 +1,8 @@
-# kernel trace of mppi_compute_control (Cartpole K=16384, T=100) calls from an idle stream: where the call's ~42 us go on the
-# device — ingest, rollout, merge, finalize (start of the kernel to the end), the gaps between them, and what is left for the
-# host side (launch-to-start latency of the first kernel + the flag's way back).  Writes gpurun_out/compute_control_trace.json
+# kernel trace of mppi_compute_control (Cartpole K=16384, T=100) calls from an idle stream: where the call's ~36-38 us go on the
+# device — every kernel of a call (rollout, then whatever the hand-over launches: merge + control phase or the merging control
+# phase, trajectory phase, input copy), start relative to the rollout's, duration, gap to the previous kernel's end; what is left
+# is the host side (launch-to-start latency of the first kernel + the flag's way back).  MPPI_AMD_NO_MERGE_CONTROL=1 for the
+# two-launch form.  Writes gpurun_out/compute_control_trace.json
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/cc_trace
