@@ -548,8 +548,8 @@ __global__ void __launch_bounds__(64) finalizeRepKernel(DYN_T dynamics_obj, cons
  * memory, and one block of 16 waves pulls the 106 KB of a 256-record launch through one CU in well under a microsecond.
  *
  * Arithmetic: merge_wave.hpp, the functions combineWave calls, with the same lane <-> record assignment — every wave forms rho,
- * the scale factors, eta and sum w^2 for itself, wave w then takes the column quads w, w + 16, ...; u*[j] = U[j] / float(eta);
- * wave 0 writes the statistics.  The same bits as combineKernel + finalizeKernel (tests/test_merge_control.py).  The merged mean
+ * the scale factors and eta for itself, wave w then takes the column quads w, w + 16, ...; u*[j] = U[j] / float(eta); the last
+ * wave also sums w^2 and writes the statistics.  The same bits as combineKernel + finalizeKernel (tests/test_merge_control.py).  The merged mean
  * also goes to mean_out_d (what later mppi_optimize / getter calls read), the statistics to stats_d.
  * One system (grid = 1 block), T * C a multiple of 4, at most 256 records (the conditions of the streamed merge), control
  * sequence in LDS (no FinalizeArgs::scratch_d).
@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(64 * MERGE_CONTROL_WAVES) mergeControlKernel(D
     hist0 = a.history_d[z * a.history_stride + 0 * C + tid];
     hist1 = a.history_d[z * a.history_stride + 1 * C + tid];
   }
-  const float sticky_mark = tid == 0 ? m.stats_d[6] : 0.0f;
+  const float sticky_mark = tid == NL - 64 ? m.stats_d[6] : 0.0f;
   const bool carry = a.phases == 1 && a.carry_d;
   const int carry_others = carry ? a.carry_floats - TC : 0;  // floats of the input block that are not the control sequence
   auto carry_index = [&](const int k) { return k < a.carry_mean_off ? k : k + TC; };
@@ -668,7 +668,11 @@ __global__ void __launch_bounds__(64 * MERGE_CONTROL_WAVES) mergeControlKernel(D
       eta_b[i] = ok ? tailq[i].y : 0.0f;
       eta2_b[i] = ok ? eta2q[i] : 0.0f;
     }
-    mergeTails(rho_b, eta_b, eta2_b, (float)(1.0 / (double)m.lambda), mt);
+    // the statistics are the business of the LAST wave (the one with the fewest column quads): only it sums w^2
+    if (wave == MERGE_CONTROL_WAVES - 1)
+      mergeTails<true>(rho_b, eta_b, eta2_b, (float)(1.0 / (double)m.lambda), mt);
+    else
+      mergeTails<false>(rho_b, eta_b, eta2_b, (float)(1.0 / (double)m.lambda), mt);
   }
   auto merge_quad = [&](const int q, const merge_f4 (&raw)[MERGE_LANE_RECORDS]) {
     float v[MERGE_LANE_RECORDS][MERGE_COLS], tot[MERGE_COLS];
@@ -711,7 +715,7 @@ __global__ void __launch_bounds__(64 * MERGE_CONTROL_WAVES) mergeControlKernel(D
     }
     merge_quad(q, raw);
   }
-  if (tid == 0)
+  if (tid == NL - 64)  // lane 0 of the last wave
   {
     mergeStatistics(mt.rho, mt.eta_f, mt.eta2, m.lambda, m.num_rollouts_total, st_s);
     st_s[6] = sticky_mark;

@@ -40,7 +40,10 @@ struct MergeTails
   float eta_f;
 };
 
-/** rho_b / eta_b / eta2_b: the lane's records' tails (padding records: rho_b = inf, eta_b = eta2_b = 0) */
+/** rho_b / eta_b / eta2_b: the lane's records' tails (padding records: rho_b = inf, eta_b = eta2_b = 0).
+ *  WITH_ETA2 = false: a wave that does not write the statistics skips the sum of w^2 and its all-reduce in double (out.eta2 = 0);
+ *  rho, the scale factors and eta are the same instructions on the same data either way. */
+template <bool WITH_ETA2 = true>
 __device__ inline void mergeTails(const float (&rho_b)[MERGE_LANE_RECORDS], const float (&eta_b)[MERGE_LANE_RECORDS],
                                   const float (&eta2_b)[MERGE_LANE_RECORDS], const float lambda_inv, MergeTails& out)
 {
@@ -56,10 +59,11 @@ __device__ inline void mergeTails(const float (&rho_b)[MERGE_LANE_RECORDS], cons
     const float s = mergeScale(rho_b[i], out.rho, lambda_inv);  // 0 for the padding records
     out.s[i] = s;
     eta += (double)s * (double)eta_b[i];
-    eta2 += (double)s * (double)s * (double)eta2_b[i];
+    if (WITH_ETA2)
+      eta2 += (double)s * (double)s * (double)eta2_b[i];
   }
   out.eta = mppi::wave::waveAllSum(eta);
-  out.eta2 = mppi::wave::waveAllSum(eta2);
+  out.eta2 = WITH_ETA2 ? mppi::wave::waveAllSum(eta2) : 0.0;
   out.eta_f = (float)out.eta;
 }
 

@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(pipelineBlockX(BZ, FOLD_Z) * (FOLD_Z ? 1 : BZ)
           eta_b[i] = ok ? tailq[i].y : 0.0f;
           eta2_b[i] = 0.0f;  // (MergeTails::eta2 is not used here)
         }
-        mergeTails(rho_b, eta_b, eta2_b, (float)(1.0 / (double)args.lambda), mt);
+        mergeTails<false>(rho_b, eta_b, eta2_b, (float)(1.0 / (double)args.lambda), mt);
       }
       PIPE_T(if (decltype(first_trip)::value && smp_id == 0) tm.trip(block_idx, 4, 2, lane, __builtin_amdgcn_s_memtime() - tm.t0);)
       // this trip's part of u* of the previous iteration: the merge kernel's arithmetic on the quads loaded a trip ago

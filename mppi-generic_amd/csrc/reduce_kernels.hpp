@@ -200,7 +200,11 @@ __device__ inline void combineWave(const CombineArgs& a, const int z, const int 
     }
     COMBINE_T(1);
     MergeTails mt;
-    mergeTails(rho_b, eta_b, eta2_b, lambda_inv, mt);  // (the first use of a loaded value waits for the round trip)
+    // (the first use of a loaded value waits for the round trip; only the statistics wave needs the sum of w^2)
+    if (stats_wave)
+      mergeTails<true>(rho_b, eta_b, eta2_b, lambda_inv, mt);
+    else
+      mergeTails<false>(rho_b, eta_b, eta2_b, lambda_inv, mt);
     COMBINE_T(3);
     rho = mt.rho;
     eta = mt.eta;
